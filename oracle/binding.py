@@ -1,0 +1,176 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package (acvm_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_DIR, "liboracle.so")
+
+ST_SOLVED, ST_IN_PROGRESS, ST_FAILURE, ST_REQUIRES_FOREIGN_CALL = 0, 1, 2, 3
+(E_NONE, E_MISSING_ASSIGNMENT, E_TOO_MANY_UNKNOWNS, E_UNSUPPORTED_BLACKBOX, E_UNSATISFIED, E_INDEX_OOB,
+ E_BLACKBOX_FAILED, E_BRILLIG_FAILED, E_PANIC) = range(9)
+BACKEND_BARRETENBERG, BACKEND_STUBBED, BACKEND_DUMMY = 0, 1, 2
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("err", C.c_uint32), ("opcode_index", C.c_uint32), ("aux0", C.c_uint32),
+                ("aux1", C.c_uint32), ("n_call_stack", C.c_uint32), ("call_stack", C.c_uint32 * 16),
+                ("message", C.c_char * 200)]
+
+    def as_tuple(self):
+        return (self.status, self.err, self.opcode_index, self.aux0, self.aux1)
+
+
+def build(force=False):
+    srcs = [os.path.join(_DIR, f) for f in os.listdir(_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", _DIR, "-s", "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.oracle_circuit_from_bytes.restype = C.c_void_p
+        L.oracle_circuit_from_bytes.argtypes = [C.c_char_p, C.c_size_t]
+        L.oracle_circuit_free.argtypes = [C.c_void_p]
+        for f in ("oracle_circuit_num_witnesses", "oracle_circuit_num_opcodes", "oracle_circuit_current_witness_index"):
+            getattr(L, f).restype = C.c_uint32
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.oracle_result_size.restype = C.c_size_t
+        L.oracle_acvm_create.restype = C.c_void_p
+        L.oracle_acvm_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.oracle_acvm_destroy.argtypes = [C.c_void_p]
+        for f in ("oracle_acvm_run", "oracle_acvm_step", "oracle_acvm_instruction_pointer", "oracle_acvm_num_witnesses",
+                  "oracle_acvm_pending_num_inputs"):
+            getattr(L, f).restype = C.c_uint32
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.oracle_acvm_result.argtypes = [C.c_void_p, C.POINTER(Result)]
+        L.oracle_acvm_witness_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_acvm_pending_function.restype = C.c_char_p
+        L.oracle_acvm_pending_function.argtypes = [C.c_void_p]
+        L.oracle_acvm_pending_input_len.restype = C.c_uint32
+        L.oracle_acvm_pending_input_len.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_acvm_pending_input.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.oracle_acvm_resolve.restype = C.c_int
+        L.oracle_acvm_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_solve_batch.restype = C.c_int
+        L.oracle_solve_batch.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.oracle_fr_op.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p]
+        L.oracle_fr_num_bits.restype = C.c_uint32
+        L.oracle_fr_num_bits.argtypes = [C.c_char_p]
+        L.oracle_fr_from_bytes_reduce.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.oracle_fr_fetch_nearest_bytes.restype = C.c_int
+        L.oracle_fr_fetch_nearest_bytes.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p]
+        for f in ("oracle_sha256", "oracle_keccak256", "oracle_blake2s"):
+            getattr(L, f).argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        assert L.oracle_result_size() == C.sizeof(Result)
+        _lib = L
+    return _lib
+
+
+def be32(x: int) -> bytes:
+    return int(x).to_bytes(32, "big")
+
+
+class Circuit:
+    def __init__(self, data: bytes):
+        self._h = lib().oracle_circuit_from_bytes(data, len(data))
+        if not self._h:
+            raise ValueError("oracle: malformed circuit bytes")
+        self.num_witnesses = lib().oracle_circuit_num_witnesses(self._h)
+        self.num_opcodes = lib().oracle_circuit_num_opcodes(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_circuit_free(self._h)
+            self._h = None
+
+
+class ACVM:
+    """Single-instance handle with the reference's call shape (pwg/mod.rs:145-304)."""
+
+    def __init__(self, circuit: Circuit, initial_witness: dict, backend=BACKEND_BARRETENBERG):
+        self.circuit = circuit
+        ids = sorted(initial_witness)
+        arr = (C.c_uint32 * len(ids))(*ids)
+        vals = b"".join(be32(initial_witness[i]) for i in ids)
+        self._h = lib().oracle_acvm_create(circuit._h, backend, len(ids), arr, vals)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_acvm_destroy(self._h)
+            self._h = None
+
+    def solve(self):
+        return lib().oracle_acvm_run(self._h)
+
+    def solve_opcode(self):
+        return lib().oracle_acvm_step(self._h)
+
+    def result(self) -> Result:
+        r = Result()
+        lib().oracle_acvm_result(self._h, C.byref(r))
+        return r
+
+    def instruction_pointer(self):
+        return lib().oracle_acvm_instruction_pointer(self._h)
+
+    def witness_map(self) -> dict:
+        n = lib().oracle_acvm_num_witnesses(self._h)
+        a = C.create_string_buffer(n)
+        v = C.create_string_buffer(32 * n)
+        lib().oracle_acvm_witness_map(self._h, a, v)
+        return {w: int.from_bytes(v.raw[32 * w:32 * w + 32], "big") for w in range(n) if a.raw[w]}
+
+    def get_pending_foreign_call(self):
+        f = lib().oracle_acvm_pending_function(self._h)
+        if f is None:
+            return None
+        inputs = []
+        for i in range(lib().oracle_acvm_pending_num_inputs(self._h)):
+            n = lib().oracle_acvm_pending_input_len(self._h, i)
+            buf = C.create_string_buffer(32 * max(n, 1))
+            lib().oracle_acvm_pending_input(self._h, i, buf)
+            inputs.append([int.from_bytes(buf.raw[32 * k:32 * k + 32], "big") for k in range(n)])
+        return f.decode(), inputs
+
+    def resolve_pending_foreign_call(self, values):
+        """values: list of int (Single) or list[int] (Array)."""
+        is_arr = bytes(0 if isinstance(v, int) else 1 for v in values)
+        lens = (C.c_uint32 * max(len(values), 1))(*[1 if isinstance(v, int) else len(v) for v in values])
+        flat = b"".join(be32(v) if isinstance(v, int) else b"".join(be32(x) for x in v) for v in values)
+        rc = lib().oracle_acvm_resolve(self._h, len(values), is_arr, lens, flat)
+        if rc != 0:
+            raise RuntimeError("ACVM is not expecting a foreign call response as no call was made")
+
+
+def solve_batch(circuit: Circuit, ids, values_be: bytes, B: int, want_witness=True, backend=BACKEND_BARRETENBERG,
+                n_threads=1):
+    """values_be: B * len(ids) * 32 bytes, instance-major. Returns (results[B], assigned bytes, values bytes)."""
+    import numpy as np
+    n_in = len(ids)
+    nw = circuit.num_witnesses
+    for i in ids:
+        nw = max(nw, i + 1)
+    arr = (C.c_uint32 * max(n_in, 1))(*ids)
+    res = (Result * B)()
+    assigned = np.zeros((B, nw), dtype=np.uint8) if want_witness else None
+    vals = np.zeros((B, nw, 32), dtype=np.uint8) if want_witness else None
+    buf = np.frombuffer(values_be, dtype=np.uint8)
+    assert buf.size == B * n_in * 32
+    lib().oracle_solve_batch(circuit._h, backend, B, n_in, arr, buf.ctypes.data, C.cast(res, C.c_void_p),
+                             assigned.ctypes.data if want_witness else None,
+                             vals.ctypes.data if want_witness else None, nw, n_threads)
+    return res, assigned, vals

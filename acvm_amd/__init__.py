@@ -1,0 +1,198 @@
+"""acvm_amd -- MI355X-native batched ACIR witness solver (drop-in for acvm::pwg::ACVM::solve()).
+
+The compute path is libacvm_amd.so (hand-written gfx950 HIP kernels behind the C ABI of
+include/acvm_amd.h). This module is only the ctypes view of that ABI for tests and the bench, shaped
+like the reference API (acvm/src/pwg/mod.rs:145-304): Circuit.read -> Batch(...).solve() ->
+results()/witness_map(). There is no CPU fallback: importing the solver without the built library, or
+creating a batch without a gfx950 device, raises.
+"""
+import ctypes as C
+import os
+
+from . import acir  # noqa: F401  (data model + wire format)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libacvm_amd.so")
+
+STATUS_SOLVED, STATUS_IN_PROGRESS, STATUS_FAILURE, STATUS_REQUIRES_FOREIGN_CALL = 0, 1, 2, 3
+(ERR_NONE, ERR_MISSING_ASSIGNMENT, ERR_TOO_MANY_UNKNOWNS, ERR_UNSUPPORTED_BLACKBOX, ERR_UNSATISFIED, ERR_INDEX_OOB,
+ ERR_BLACKBOX_FAILED, ERR_BRILLIG_FAILED, ERR_PANIC) = range(9)
+
+# every symbol include/acvm_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "acvm_last_error", "acvm_abi_version", "acvm_device_count", "acvm_set_device", "acvm_device_synchronize",
+    "acvm_device_arch", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
+    "acvm_circuit_num_witnesses", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
+    "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_reset", "acvm_batch_set_force_slow_path",
+    "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
+    "acvm_batch_set_profiling",
+]
+
+
+class AcvmError(RuntimeError):
+    pass
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("err", C.c_uint32), ("opcode_index", C.c_uint32), ("aux0", C.c_uint32),
+                ("aux1", C.c_uint32), ("n_call_stack", C.c_uint32), ("call_stack", C.c_uint32 * 16),
+                ("message", C.c_char * 200)]
+
+    def as_tuple(self):
+        return (self.status, self.err, self.opcode_index, self.aux0, self.aux1)
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_opcodes", C.c_uint32), ("n_witnesses", C.c_uint32), ("n_levels", C.c_uint32),
+                ("n_fast_gates", C.c_uint32), ("n_dyn_gates", C.c_uint32), ("max_level_width", C.c_uint32),
+                ("n_kernel_launches", C.c_uint32), ("n_slow_instances", C.c_uint32),
+                ("algorithmic_bytes_per_instance", C.c_uint64), ("arith_algorithmic_bytes_per_instance", C.c_uint64),
+                ("plan_ms", C.c_double), ("solve_device_ms", C.c_double), ("arith_kernel_ms", C.c_double),
+                ("slow_path_ms", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Load libacvm_amd.so. Raises if it has not been built (python -m acvm_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AcvmError(f"{LIB_PATH} is missing: build it with `python -m acvm_amd.build` (no CPU fallback exists)")
+    L = C.CDLL(LIB_PATH)
+    L.acvm_last_error.restype = C.c_char_p
+    L.acvm_device_arch.argtypes = [C.c_char_p, C.c_size_t]
+    L.acvm_circuit_from_bytes.restype = C.c_void_p
+    L.acvm_circuit_from_bytes.argtypes = [C.c_char_p, C.c_size_t]
+    L.acvm_circuit_free.argtypes = [C.c_void_p]
+    L.acvm_circuit_num_opcodes.restype = C.c_uint32
+    L.acvm_circuit_num_opcodes.argtypes = [C.c_void_p]
+    L.acvm_circuit_num_witnesses.restype = C.c_uint32
+    L.acvm_circuit_num_witnesses.argtypes = [C.c_void_p]
+    L.acvm_batch_new.restype = C.c_void_p
+    L.acvm_batch_new.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.acvm_batch_free.argtypes = [C.c_void_p]
+    L.acvm_batch_set_initial_witness.argtypes = [C.c_void_p, C.c_void_p]
+    L.acvm_batch_set_initial_witness_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.acvm_batch_solve.argtypes = [C.c_void_p]
+    L.acvm_batch_reset.argtypes = [C.c_void_p]
+    L.acvm_batch_set_force_slow_path.argtypes = [C.c_void_p, C.c_int]
+    L.acvm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.acvm_batch_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.acvm_batch_witness.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.acvm_batch_witness_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.acvm_batch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise AcvmError(f"acvm_amd error {rc}: {lib().acvm_last_error().decode()}")
+    return rc
+
+
+def device_count():
+    return lib().acvm_device_count()
+
+
+def set_device(i):
+    _check(lib().acvm_set_device(i))
+
+
+def synchronize():
+    _check(lib().acvm_device_synchronize())
+
+
+def device_arch():
+    buf = C.create_string_buffer(64)
+    _check(lib().acvm_device_arch(buf, 64))
+    return buf.value.decode()
+
+
+class Circuit:
+    """acir::circuit::Circuit::read (circuit/mod.rs:154-161)."""
+
+    def __init__(self, data: bytes):
+        self._h = lib().acvm_circuit_from_bytes(data, len(data))
+        if not self._h:
+            raise AcvmError(lib().acvm_last_error().decode())
+        self.num_opcodes = lib().acvm_circuit_num_opcodes(self._h)
+        self.num_witnesses = lib().acvm_circuit_num_witnesses(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.acvm_circuit_free(self._h)
+            self._h = None
+
+
+class Batch:
+    """ACVM::new / solve / witness_map for n_instances instances of one circuit."""
+
+    def __init__(self, circuit: Circuit, n_instances: int, initial_ids):
+        self.circuit = circuit
+        self.B = n_instances
+        self.ids = list(initial_ids)
+        arr = (C.c_uint32 * max(len(self.ids), 1))(*self.ids)
+        self._h = lib().acvm_batch_new(circuit._h, None, n_instances, arr, len(self.ids))
+        if not self._h:
+            raise AcvmError(lib().acvm_last_error().decode())
+        self.nw = self.stats()["n_witnesses"]
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.acvm_batch_free(self._h)
+            self._h = None
+
+    def free(self):
+        self.__del__()
+
+    def set_initial_witness(self, values_be: bytes):
+        """values_be: B * len(ids) * 32 bytes, instance-major canonical big-endian."""
+        import numpy as np
+        buf = np.frombuffer(values_be, dtype=np.uint8)
+        if buf.size != self.B * len(self.ids) * 32:
+            raise ValueError("initial witness buffer has the wrong size")
+        _check(lib().acvm_batch_set_initial_witness(self._h, buf.ctypes.data))
+
+    def solve(self) -> int:
+        return _check(lib().acvm_batch_solve(self._h))
+
+    def reset(self):
+        _check(lib().acvm_batch_reset(self._h))
+
+    def set_force_slow_path(self, on: bool):
+        _check(lib().acvm_batch_set_force_slow_path(self._h, int(on)))
+
+    def set_profiling(self, on: bool):
+        _check(lib().acvm_batch_set_profiling(self._h, int(on)))
+
+    def results(self):
+        out = (Result * max(self.B, 1))()
+        _check(lib().acvm_batch_results(self._h, C.cast(out, C.c_void_p)))
+        return out
+
+    def witness(self, w: int):
+        import numpy as np
+        vals = np.zeros((self.B, 32), dtype=np.uint8)
+        asg = np.zeros((self.B,), dtype=np.uint8)
+        _check(lib().acvm_batch_witness(self._h, w, vals.ctypes.data, asg.ctypes.data))
+        return vals, asg
+
+    def witness_map(self, first=0, n=None):
+        import numpy as np
+        n = self.B - first if n is None else n
+        asg = np.zeros((n, self.nw), dtype=np.uint8)
+        vals = np.zeros((n, self.nw, 32), dtype=np.uint8)
+        _check(lib().acvm_batch_witness_map(self._h, first, n, asg.ctypes.data, vals.ctypes.data))
+        return asg, vals
+
+    def stats(self) -> dict:
+        s = Stats()
+        _check(lib().acvm_batch_stats(self._h, C.byref(s)))
+        return s.as_dict()

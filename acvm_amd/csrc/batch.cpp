@@ -1,0 +1,435 @@
+// batch.cpp -- the C ABI (include/acvm_amd.h) and the batch driver: one handle = one circuit plan, one
+// device-resident witness table W[slot][half][instance], one HIP stream. Mirrors the call shape of
+// acvm::pwg::ACVM (acvm/src/pwg/mod.rs:145-304) for B instances at once.
+#include "../../include/acvm_amd.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace acvm;
+
+static thread_local std::string g_last_error;
+static int set_err(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return set_err(ACVM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+struct acvm_circuit {
+    std::unique_ptr<Circuit> c;
+};
+
+struct acvm_batch {
+    Plan plan;
+    uint32_t B = 0;
+    uint64_t Bp = 0;  // instance stride, multiple of 64
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint4 *d_W = nullptr;
+    uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
+    uint32_t *d_slow_stream = nullptr, *d_slow_offset = nullptr, *d_init_ids = nullptr, *d_init_words = nullptr;
+    uint32_t *d_event = nullptr;
+    std::vector<uint32_t> h_event;
+    // exact in-order path
+    std::vector<uint32_t> slow_ids;
+    std::vector<int32_t> slow_index;  // per instance: index into slow_ids or -1
+    std::vector<SlowResult> slow_res;
+    uint32_t *d_slow_ids = nullptr, *d_assigned = nullptr;
+    SlowResult *d_slow_res = nullptr;
+    uint32_t slow_cap = 0, n_words = 0;
+    bool inputs_set = false, solved = false, force_slow = false, profiling = false;
+    hipEvent_t ev_start = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    double solve_device_ms = 0, arith_kernel_ms = 0, slow_path_ms = 0;
+    uint32_t n_launches = 0;
+
+    ~acvm_batch() {
+        hipSetDevice(device);
+        for (void *p : {(void *)d_W, (void *)d_gate_stream, (void *)d_gate_offset, (void *)d_consts, (void *)d_slow_stream,
+                        (void *)d_slow_offset, (void *)d_init_ids, (void *)d_init_words, (void *)d_event, (void *)d_slow_ids,
+                        (void *)d_assigned, (void *)d_slow_res})
+            if (p) hipFree(p);
+        for (auto e : ev_pool) hipEventDestroy(e);
+        if (ev_start) hipEventDestroy(ev_start);
+        if (ev_end) hipEventDestroy(ev_end);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+template <class T>
+static int upload(T **dst, const std::vector<T> &src) {
+    size_t bytes = (src.size() ? src.size() : 1) * sizeof(T);
+    HIPCHK(hipMalloc((void **)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+const char *acvm_last_error(void) { return g_last_error.c_str(); }
+int acvm_abi_version(void) { return ACVM_AMD_ABI_VERSION; }
+
+int acvm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int acvm_set_device(int device) {
+    HIPCHK(hipSetDevice(device));
+    return 0;
+}
+int acvm_device_synchronize(void) {
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+int acvm_device_arch(char *out, size_t out_len) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    snprintf(out, out_len, "%s", prop.gcnArchName);
+    return 0;
+}
+
+acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) {
+    if (!bytes) { set_err(ACVM_E_INVALID, "null circuit bytes"); return nullptr; }
+    if (!frh::self_check()) { set_err(ACVM_E_INVALID, "field constants self-check failed"); return nullptr; }
+    std::string err;
+    auto c = circuit_from_bytes(bytes, len, err);
+    if (!c) { set_err(ACVM_E_MALFORMED, err); return nullptr; }
+    auto *h = new acvm_circuit;
+    h->c = std::move(c);
+    return h;
+}
+void acvm_circuit_free(acvm_circuit_t *c) { delete c; }
+uint32_t acvm_circuit_num_opcodes(const acvm_circuit_t *c) { return c ? (uint32_t)c->c->opcodes.size() : 0; }
+uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c) { return c ? c->c->max_witness + 1 : 0; }
+
+static int batch_init(acvm_batch *b) {
+    HIPCHK(hipGetDevice(&b->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, b->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(ACVM_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&b->ev_start));
+    HIPCHK(hipEventCreate(&b->ev_end));
+    const Plan &p = b->plan;
+    size_t w_bytes = (size_t)p.n_witnesses * 2 * b->Bp * sizeof(uint4);
+    HIPCHK(hipMalloc((void **)&b->d_W, w_bytes ? w_bytes : 16));
+    if (int rc = upload(&b->d_gate_stream, p.gate_stream)) return rc;
+    if (int rc = upload(&b->d_gate_offset, p.gate_offset)) return rc;
+    std::vector<uint32_t> consts(p.constants.size() * 8);
+    for (size_t i = 0; i < p.constants.size(); i++) memcpy(&consts[8 * i], p.constants[i].l, 32);
+    if (int rc = upload(&b->d_consts, consts)) return rc;
+    if (int rc = upload(&b->d_slow_stream, p.slow_stream)) return rc;
+    if (int rc = upload(&b->d_slow_offset, p.slow_offset)) return rc;
+    if (int rc = upload(&b->d_init_ids, p.initial_ids)) return rc;
+    b->n_words = (p.n_witnesses + 31) / 32;
+    std::vector<uint32_t> init_words(b->n_words ? b->n_words : 1, 0);
+    for (uint32_t w : p.initial_ids) init_words[w >> 5] |= 1u << (w & 31);
+    if (int rc = upload(&b->d_init_words, init_words)) return rc;
+    HIPCHK(hipMalloc((void **)&b->d_event, (size_t)(b->B ? b->B : 1) * 4));
+    b->h_event.assign(b->B, 0xFFFFFFFFu);
+    b->slow_index.assign(b->B, -1);
+    return 0;
+}
+
+acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances,
+                             const uint32_t *initial_ids, uint32_t n_initial) {
+    (void)solver;
+    if (!c || (n_initial && !initial_ids)) { set_err(ACVM_E_INVALID, "null argument"); return nullptr; }
+    {
+        std::vector<uint32_t> ids(initial_ids, initial_ids + n_initial);
+        std::sort(ids.begin(), ids.end());
+        if (std::adjacent_find(ids.begin(), ids.end()) != ids.end()) { set_err(ACVM_E_INVALID, "duplicate initial witness id"); return nullptr; }
+    }
+    auto *b = new acvm_batch;
+    b->plan = build_plan(*c->c, initial_ids, n_initial);
+    if (!b->plan.unsupported.empty()) {
+        set_err(ACVM_E_UNSUPPORTED, b->plan.unsupported);
+        delete b;
+        return nullptr;
+    }
+    b->B = n_instances;
+    b->Bp = ((uint64_t)n_instances + 63) / 64 * 64;
+    if (batch_init(b) != 0) { delete b; return nullptr; }
+    return b;
+}
+void acvm_batch_free(acvm_batch_t *b) { delete b; }
+
+int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32) {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    HIPCHK(hipSetDevice(b->device));
+    launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->d_init_ids, (uint32_t)b->plan.initial_ids.size());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->inputs_set = true;
+    b->solved = false;
+    return 0;
+}
+
+int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32) {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    size_t bytes = (size_t)b->B * b->plan.initial_ids.size() * 32;
+    if (bytes && !values_be32) return set_err(ACVM_E_INVALID, "null values");
+    HIPCHK(hipSetDevice(b->device));
+    uint8_t *d_in = nullptr;
+    HIPCHK(hipMalloc((void **)&d_in, bytes ? bytes : 1));
+    hipError_t e = bytes ? hipMemcpy(d_in, values_be32, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    int rc = e == hipSuccess ? acvm_batch_set_initial_witness_device(b, d_in) : set_err(ACVM_E_DEVICE, hipGetErrorString(e));
+    hipFree(d_in);
+    return rc;
+}
+
+int acvm_batch_set_force_slow_path(acvm_batch_t *b, int on) {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    b->force_slow = on != 0;
+    return 0;
+}
+int acvm_batch_set_profiling(acvm_batch_t *b, int on) {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    b->profiling = on != 0;
+    return 0;
+}
+int acvm_batch_reset(acvm_batch_t *b) {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    b->solved = false;
+    return 0;
+}
+
+static int ensure_slow_capacity(acvm_batch *b, uint32_t n) {
+    if (n <= b->slow_cap) return 0;
+    for (void *p : {(void *)b->d_slow_ids, (void *)b->d_assigned, (void *)b->d_slow_res})
+        if (p) hipFree(p);
+    b->d_slow_ids = nullptr; b->d_assigned = nullptr; b->d_slow_res = nullptr;
+    HIPCHK(hipMalloc((void **)&b->d_slow_ids, (size_t)n * 4));
+    HIPCHK(hipMalloc((void **)&b->d_assigned, (size_t)n * (b->n_words ? b->n_words : 1) * 4));
+    HIPCHK(hipMalloc((void **)&b->d_slow_res, (size_t)n * sizeof(SlowResult)));
+    b->slow_cap = n;
+    return 0;
+}
+
+int acvm_batch_solve(acvm_batch_t *b) {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
+    HIPCHK(hipSetDevice(b->device));
+    const Plan &p = b->plan;
+    hipStream_t s = b->stream;
+    b->n_launches = 0;
+    b->arith_kernel_ms = 0;
+    b->slow_path_ms = 0;
+    size_t ev_used = 0;
+    auto next_event = [&]() -> hipEvent_t {
+        if (ev_used == b->ev_pool.size()) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            b->ev_pool.push_back(e);
+        }
+        return b->ev_pool[ev_used++];
+    };
+    HIPCHK(hipEventRecord(b->ev_start, s));
+    if (b->force_slow) {
+        launch_fill_u32(s, b->d_event, 0u, b->B);
+    } else {
+        launch_fill_u32(s, b->d_event, 0xFFFFFFFFu, b->B);
+        for (size_t L = 0; L + 1 < p.level_start.size(); L++) {
+            uint32_t n = p.level_start[L + 1] - p.level_start[L];
+            if (!n) continue;
+            if (b->profiling) hipEventRecord(next_event(), s);
+            launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event);
+            if (b->profiling) hipEventRecord(next_event(), s);
+            b->n_launches += (n + 65534) / 65535;
+        }
+        if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
+    }
+    HIPCHK(hipGetLastError());
+    if (b->B) HIPCHK(hipMemcpyAsync(b->h_event.data(), b->d_event, (size_t)b->B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // instances that left the generic path (or hit a failing constraint): exact in-order re-solve
+    b->slow_ids.clear();
+    std::fill(b->slow_index.begin(), b->slow_index.end(), -1);
+    for (uint32_t j = 0; j < b->B; j++)
+        if (b->h_event[j] != 0xFFFFFFFFu) {
+            b->slow_index[j] = (int32_t)b->slow_ids.size();
+            b->slow_ids.push_back(j);
+        }
+    uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    hipEvent_t slow0 = nullptr, slow1 = nullptr;
+    if (n_slow) {
+        if (int rc = ensure_slow_capacity(b, n_slow)) return rc;
+        HIPCHK(hipMemcpyAsync(b->d_slow_ids, b->slow_ids.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        slow0 = next_event();
+        slow1 = next_event();
+        hipEventRecord(slow0, s);
+        launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, b->d_init_words);
+        launch_arith_inorder(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->d_slow_stream, b->d_slow_offset, p.n_opcodes, b->d_consts,
+                             b->d_assigned, b->d_slow_res);
+        hipEventRecord(slow1, s);
+        HIPCHK(hipGetLastError());
+        b->slow_res.resize(n_slow);
+        HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipEventRecord(b->ev_end, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev_start, b->ev_end));
+    b->solve_device_ms = ms;
+    if (b->profiling && !b->force_slow) {
+        size_t n_pairs = (n_slow ? ev_used - 2 : ev_used) / 2;
+        for (size_t i = 0; i < n_pairs; i++) {
+            float t = 0;
+            hipEventElapsedTime(&t, b->ev_pool[2 * i], b->ev_pool[2 * i + 1]);
+            b->arith_kernel_ms += t;
+        }
+    }
+    if (n_slow) {
+        float t = 0;
+        hipEventElapsedTime(&t, slow0, slow1);
+        b->slow_path_ms = t;
+    }
+    b->solved = true;
+    int not_solved = 0;
+    for (uint32_t t = 0; t < n_slow; t++)
+        if (b->slow_res[t].status != ACVM_STATUS_SOLVED) not_solved++;
+    return not_solved;
+}
+
+int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out) {
+    if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    for (uint32_t j = 0; j < b->B; j++) {
+        acvm_result_t &r = out[j];
+        memset(&r, 0, sizeof r);
+        if (b->plan.n_opcodes == 0 || b->slow_index[j] < 0) { r.status = ACVM_STATUS_SOLVED; continue; }
+        const SlowResult &sr = b->slow_res[b->slow_index[j]];
+        r.status = sr.status; r.err = sr.err; r.opcode_index = sr.opcode_index; r.aux0 = sr.aux0; r.aux1 = sr.aux1;
+        if (sr.err == ACVM_ERR_PANIC)
+            snprintf(r.message, sizeof r.message, "Mul term in the arithmetic opcode must contain either zero or one term");
+    }
+    return 0;
+}
+
+// assigned flags of instance j over all witnesses (host side bookkeeping + slow-path bitmap)
+static int fetch_assigned(acvm_batch *b, uint32_t first, uint32_t n, uint8_t *assigned) {
+    const Plan &p = b->plan;
+    uint32_t nw = p.n_witnesses;
+    std::vector<uint32_t> bitmap;
+    uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    bool any_slow = false;
+    for (uint32_t i = 0; i < n; i++) any_slow |= b->slow_index[first + i] >= 0;
+    if (any_slow) {
+        bitmap.resize((size_t)n_slow * b->n_words);
+        HIPCHK(hipMemcpy(bitmap.data(), b->d_assigned, bitmap.size() * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        uint8_t *a = assigned + (size_t)i * nw;
+        int32_t si = b->slow_index[first + i];
+        if (si < 0) {
+            for (uint32_t w = 0; w < nw; w++) a[w] = p.producer[w] != 0xFFFFFFFFu;
+        } else {
+            for (uint32_t w = 0; w < nw; w++) a[w] = (bitmap[(size_t)(w >> 5) * n_slow + si] >> (w & 31)) & 1u;
+        }
+    }
+    return 0;
+}
+
+int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *assigned, uint8_t *values_be32) {
+    if (!b || !assigned || !values_be32) return set_err(ACVM_E_INVALID, "null argument");
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
+    HIPCHK(hipSetDevice(b->device));
+    uint32_t nw = b->plan.n_witnesses;
+    if (!n || !nw) return 0;
+    if (int rc = fetch_assigned(b, first, n, assigned)) return rc;
+    std::vector<uint32_t> sel(nw);
+    for (uint32_t w = 0; w < nw; w++) sel[w] = w;
+    uint32_t *d_sel = nullptr;
+    HIPCHK(hipMalloc((void **)&d_sel, (size_t)nw * 4));
+    HIPCHK(hipMemcpy(d_sel, sel.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
+    // stage through a bounded device buffer
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)nw * 32));
+    if (chunk > n) chunk = n;
+    uint8_t *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)chunk * nw * 32);
+    if (e != hipSuccess) { hipFree(d_sel); return set_err(ACVM_E_DEVICE, hipGetErrorString(e)); }
+    int rc = 0;
+    for (uint32_t done = 0; done < n && !rc; done += chunk) {
+        uint32_t m = std::min(chunk, n - done);
+        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, nw, d_out);
+        e = hipMemcpyAsync(values_be32 + (size_t)done * nw * 32, d_out, (size_t)m * nw * 32, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) rc = set_err(ACVM_E_DEVICE, hipGetErrorString(e));
+    }
+    hipFree(d_out);
+    hipFree(d_sel);
+    if (rc) return rc;
+    for (size_t i = 0; i < (size_t)n * nw; i++)
+        if (!assigned[i]) memset(values_be32 + i * 32, 0, 32);
+    return 0;
+}
+
+int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uint8_t *assigned) {
+    if (!b || !out_be32 || !assigned) return set_err(ACVM_E_INVALID, "null argument");
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if (witness >= b->plan.n_witnesses) { memset(assigned, 0, b->B); memset(out_be32, 0, (size_t)b->B * 32); return 0; }
+    HIPCHK(hipSetDevice(b->device));
+    if (!b->B) return 0;
+    uint32_t *d_sel = nullptr;
+    uint8_t *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_sel, 4));
+    HIPCHK(hipMemcpy(d_sel, &witness, 4, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)b->B * 32);
+    if (e != hipSuccess) { hipFree(d_sel); return set_err(ACVM_E_DEVICE, hipGetErrorString(e)); }
+    launch_export(b->stream, b->d_W, b->Bp, 0, b->B, d_sel, 1, d_out);
+    e = hipMemcpyAsync(out_be32, d_out, (size_t)b->B * 32, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    hipFree(d_out);
+    hipFree(d_sel);
+    if (e != hipSuccess) return set_err(ACVM_E_DEVICE, hipGetErrorString(e));
+    std::vector<uint32_t> bitmap;
+    uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    if (n_slow) {
+        bitmap.resize(n_slow);
+        HIPCHK(hipMemcpy(bitmap.data(), b->d_assigned + (size_t)(witness >> 5) * n_slow, (size_t)n_slow * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t j = 0; j < b->B; j++) {
+        int32_t si = b->slow_index[j];
+        assigned[j] = si < 0 ? b->plan.producer[witness] != 0xFFFFFFFFu : (bitmap[si] >> (witness & 31)) & 1u;
+        if (!assigned[j]) memset(out_be32 + (size_t)j * 32, 0, 32);
+    }
+    return 0;
+}
+
+int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
+    if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
+    const Plan &p = b->plan;
+    memset(out, 0, sizeof *out);
+    out->n_opcodes = p.n_opcodes;
+    out->n_witnesses = p.n_witnesses;
+    out->n_levels = p.level_start.empty() ? 0 : (uint32_t)p.level_start.size() - 1;
+    out->n_fast_gates = p.n_fast_gates;
+    out->n_dyn_gates = p.n_dyn_gates;
+    out->max_level_width = p.max_level_width;
+    out->n_kernel_launches = b->n_launches;
+    out->n_slow_instances = (uint32_t)b->slow_ids.size();
+    out->algorithmic_bytes_per_instance = p.algorithmic_bytes;
+    out->arith_algorithmic_bytes_per_instance = p.arith_algorithmic_bytes;
+    out->plan_ms = p.plan_ms;
+    out->solve_device_ms = b->solve_device_ms;
+    out->arith_kernel_ms = b->arith_kernel_ms;
+    out->slow_path_ms = b->slow_path_ms;
+    return 0;
+}
+
+}  // extern "C"

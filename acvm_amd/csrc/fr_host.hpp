@@ -1,0 +1,153 @@
+// fr_host.hpp -- host-side BN254-Fr arithmetic used by the static planner (constant folding of circuit
+// coefficients: Montgomery conversion, negation, inverses of constant divisors). Product code: it shares
+// nothing with oracle/. Semantics follow acir_field::FieldElement (acir_field/src/generic_ark.rs:242-283,
+// 360-406): canonical residues mod p, inverse(0) == 0.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+namespace acvm {
+
+typedef unsigned __int128 u128;
+
+struct FrH {
+    uint64_t l[4];  // Montgomery form, R = 2^256
+    bool operator==(const FrH &o) const { return memcmp(l, o.l, 32) == 0; }
+    bool operator!=(const FrH &o) const { return !(*this == o); }
+    bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+};
+
+namespace frh {
+static constexpr uint64_t P[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL,
+                                  0x30644e72e131a029ULL};
+static constexpr uint64_t N0INV = 0xc2e1f593efffffffULL;  // -p^-1 mod 2^64
+// R mod p, R^2 mod p (checked at start-up by frh::self_check)
+static constexpr uint64_t R1[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL,
+                                   0x0e0a77c19a07df2fULL};
+static constexpr uint64_t R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL,
+                                   0x0216d0b17f4e44a5ULL};
+
+inline bool geq_p(const uint64_t a[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i] > P[i]) return true;
+        if (a[i] < P[i]) return false;
+    }
+    return true;
+}
+inline uint64_t add4(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a[i] + b[i];
+        r[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    return (uint64_t)c;
+}
+inline uint64_t sub4(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - b[i] - borrow;
+        r[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+    return borrow;
+}
+inline FrH mul(const FrH &a, const FrH &b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a.l[j] * b.l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * N0INV;
+        c = (u128)m * P[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * P[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    if (t[4] || geq_p(t)) sub4(t, t, P);
+    FrH r;
+    memcpy(r.l, t, 32);
+    return r;
+}
+inline FrH zero() { return FrH{{0, 0, 0, 0}}; }
+inline FrH one() { return FrH{{R1[0], R1[1], R1[2], R1[3]}}; }
+inline FrH add(const FrH &a, const FrH &b) {
+    FrH r;
+    uint64_t c = add4(r.l, a.l, b.l);
+    if (c || geq_p(r.l)) sub4(r.l, r.l, P);
+    return r;
+}
+inline FrH sub(const FrH &a, const FrH &b) {
+    FrH r;
+    if (sub4(r.l, a.l, b.l)) add4(r.l, r.l, P);
+    return r;
+}
+inline FrH neg(const FrH &a) {
+    if (a.is_zero()) return a;
+    FrH r;
+    sub4(r.l, P, a.l);
+    return r;
+}
+inline FrH from_canonical(const uint64_t v[4]) {
+    FrH t, r2;
+    memcpy(t.l, v, 32);
+    memcpy(r2.l, R2, 32);
+    return mul(t, r2);
+}
+inline void to_canonical(const FrH &a, uint64_t out[4]) {
+    FrH o{{1, 0, 0, 0}};
+    FrH t = mul(a, o);
+    memcpy(out, t.l, 32);
+}
+inline FrH from_u64(uint64_t v) {
+    uint64_t t[4] = {v, 0, 0, 0};
+    return from_canonical(t);
+}
+// from_be_bytes_reduce for <= 32 bytes (generic_ark.rs:281-283)
+inline FrH from_be_bytes32_reduce(const uint8_t *b, size_t len) {
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < len; i++) {
+        size_t pos = len - 1 - i;
+        v[pos / 8] |= (uint64_t)b[i] << (8 * (pos % 8));
+    }
+    while (geq_p(v)) sub4(v, v, P);
+    return from_canonical(v);
+}
+inline FrH pow_pm2(const FrH &a) {  // a^(p-2): Fermat inverse (planner only; a handful of calls per circuit)
+    uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
+    FrH r = one();
+    for (int i = 253; i >= 0; i--) {
+        r = mul(r, r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = mul(r, a);
+    }
+    return r;
+}
+inline FrH inverse(const FrH &a) { return a.is_zero() ? a : pow_pm2(a); }  // inverse(0) == 0
+inline bool self_check() {
+    // R1 = 2^256 mod p, R2 = R1^2 mod p: verify by doubling
+    uint64_t x[4] = {1, 0, 0, 0};
+    auto dbl = [&]() {
+        uint64_t c = add4(x, x, x);
+        if (c || geq_p(x)) sub4(x, x, P);
+    };
+    for (int i = 0; i < 256; i++) dbl();
+    if (memcmp(x, R1, 32)) return false;
+    for (int i = 0; i < 256; i++) dbl();
+    if (memcmp(x, R2, 32)) return false;
+    return (uint64_t)(P[0] * (0 - N0INV)) == 1;
+}
+}  // namespace frh
+}  // namespace acvm

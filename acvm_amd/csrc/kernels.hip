@@ -1,0 +1,240 @@
+// kernels.hip -- hand-written gfx950 kernels of the batched ACIR witness solver.
+//
+//  import_witness_kernel   ACVM::new's initial WitnessMap (pwg/mod.rs:146-156): canonical big-endian
+//                          -> Montgomery SoA (from_be_bytes_reduce, generic_ark.rs:281-283)
+//  arith_level_kernel      ArithmeticSolver::solve (pwg/arithmetic.rs:27-127) for one dependency level,
+//                          one lane per witness instance, generic-instance plan from plan.cpp
+//  arith_inorder_kernel    the same solver, exact in-order semantics with per-instance assigned bits
+//                          (evaluate :212-239, solve_mul_term :133-144, solve_fan_in_term :176-209,
+//                          insert_value pwg/mod.rs:338-357) for instances that left the generic path
+//  export_witness_kernel   FieldElement::to_be_bytes (generic_ark.rs:269-277) for witness_map()/finalize()
+//
+// Wave64 throughout; no LDS is needed by the streaming kernels (every operand is read once per lane);
+// gate records and circuit constants are wave-uniform and travel through the scalar cache.
+#include "fr_device.hpp"
+#include "kernels.hpp"
+
+namespace acvm {
+
+static constexpr uint32_t K_COEF_ONE = 0xFFFFFFFFu;
+static constexpr uint32_t K_COEF_MINUS_ONE = 0xFFFFFFFEu;
+static constexpr uint32_t K_COEF_ZERO = 0xFFFFFFFDu;
+
+__device__ __forceinline__ Fr apply_coef(const Fr &x, uint32_t coef, const uint32_t *__restrict__ consts) {
+    if (coef == K_COEF_ONE) return x;
+    if (coef == K_COEF_MINUS_ONE) return fr_neg(x);
+    return fr_mul(x, fr_const(consts, coef));
+}
+
+// R^2 mod p: to_montgomery(x) = mont_mul(x, R2)
+__device__ __forceinline__ Fr fr_r2() {
+    Fr r = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ import
+// in: [B][n_in][32] big-endian. One lane per (instance, input).
+__global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
+                                                             const uint8_t *__restrict__ in, const uint32_t *__restrict__ ids,
+                                                             uint32_t n_in) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = blockIdx.y;
+    if (j >= B) return;
+    const uint8_t *p = in + ((uint64_t)j * n_in + k) * 32;
+    Fr x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *q = p + 28 - 4 * i;  // limb i = bytes [28-4i, 32-4i) big-endian
+        x.v[i] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3];
+    }
+    // reduce: 2^256 / p < 6, so at most 5 subtractions
+    for (int it = 0; it < 5; it++) {
+        Fr d;
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)x.v[i] - fr_p(i) - br;
+            d.v[i] = (uint32_t)t;
+            br = (t >> 32) & 1;
+        }
+        if (!br) x = d;
+    }
+    fr_store(W, ids[k], Bp, j, fr_mul(x, fr_r2()));
+}
+
+// ------------------------------------------------------------------------------------------ export
+// out: [n][n_sel][32] big-endian for instances [first, first+n) and witness list sel.
+__global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first,
+                                                             uint32_t n, const uint32_t *__restrict__ sel, uint32_t n_sel,
+                                                             uint8_t *__restrict__ out) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = blockIdx.y;
+    if (t >= n) return;
+    Fr one = fr_zero();
+    one.v[0] = 1;
+    Fr x = fr_mul(fr_load(W, sel[k], Bp, first + t), one);  // out of Montgomery form
+    uint8_t *p = out + ((uint64_t)t * n_sel + k) * 32;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint8_t *q = p + 28 - 4 * i;
+        q[0] = (uint8_t)(x.v[i] >> 24);
+        q[1] = (uint8_t)(x.v[i] >> 16);
+        q[2] = (uint8_t)(x.v[i] >> 8);
+        q[3] = (uint8_t)x.v[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ level kernel
+// grid = (ceil(B/256), gates in level). Lane = instance. The gate record is wave-uniform.
+__global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
+                                                          const uint32_t *__restrict__ gate_stream,
+                                                          const uint32_t *__restrict__ gate_offset,
+                                                          const uint32_t *__restrict__ consts, uint32_t *__restrict__ event) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    const uint32_t *__restrict__ g = gate_stream + gate_offset[blockIdx.y];
+    const uint32_t w0 = g[0];
+    const uint32_t kind = w0 & 0xff, n_prod = (w0 >> 8) & 0xff, n_lin = (w0 >> 16) & 0xff;
+    const uint32_t opcode = g[1], out = g[2], qc = g[3], den_slot = g[4];
+    Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
+    const uint32_t *__restrict__ t = g + 5;
+    for (uint32_t i = 0; i < n_prod; i++, t += 3) {
+        Fr a = fr_load(W, t[1], Bp, j);
+        Fr b = fr_load(W, t[2], Bp, j);
+        acc = fr_add(acc, apply_coef(fr_mul(a, b), t[0], consts));
+    }
+    for (uint32_t i = 0; i < n_lin; i++, t += 2) {
+        Fr a = fr_load(W, t[1], Bp, j);
+        acc = fr_add(acc, apply_coef(a, t[0], consts));
+    }
+    if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
+        if (!fr_is_zero(acc)) atomicMin(&event[j], opcode);
+    } else if (kind == 1) {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
+        fr_store(W, out, Bp, j, acc);
+    } else {  // unknown multiplied by a known witness (arithmetic.rs:68-91): out = acc' / partner
+        Fr den = fr_load(W, den_slot, Bp, j);
+        if (fr_is_zero(den)) atomicMin(&event[j], opcode);  // zero-coefficient drop (:217-221): leaves the generic path
+        fr_store(W, out, Bp, j, fr_mul(acc, fr_inv(den)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ exact in-order kernel
+// One lane per flagged instance (gathered through slow_ids). Bit w of the instance's assigned set lives in
+// assigned[(w >> 5) * n_slow + t].
+__device__ __forceinline__ bool is_known(const uint32_t *assigned, uint32_t n_slow, uint32_t t, uint32_t w) {
+    return (assigned[(uint64_t)(w >> 5) * n_slow + t] >> (w & 31)) & 1u;
+}
+
+__global__ void __launch_bounds__(64) arith_inorder_kernel(uint4 *__restrict__ W, uint64_t Bp, const uint32_t *__restrict__ slow_ids,
+                                                           uint32_t n_slow, const uint32_t *__restrict__ stream,
+                                                           const uint32_t *__restrict__ offset, uint32_t n_opcodes,
+                                                           const uint32_t *__restrict__ consts, uint32_t *assigned,
+                                                           SlowResult *__restrict__ results) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slow) return;
+    const uint64_t j = slow_ids[t];
+    SlowResult res = {0u, 0u, 0u, 0u, 0u};  // Solved
+    if (n_opcodes == 0) { results[t] = res; return; }
+    for (uint32_t oi = 0; oi < n_opcodes; oi++) {
+        const uint32_t *__restrict__ g = stream + offset[oi];
+        if (g[0] != 0u) { res = {2u, 8u, oi, 0u, 0u}; break; }  // not an Arithmetic opcode: never scheduled here
+        const uint32_t n_mul = g[1], n_lin = g[2], qc = g[3];
+        Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
+        uint32_t residual_mul = 0, unknowns = 0, unk_w = 0, unk_ninv = 0;
+        bool unk_dynamic = false;
+        Fr unk_c = fr_zero();
+        const uint32_t *__restrict__ p = g + 4;
+        // evaluate (arithmetic.rs:212-239), mul terms first
+        for (uint32_t i = 0; i < n_mul; i++, p += 3) {
+            const uint32_t coef = p[0], l = p[1], r = p[2];
+            const bool kl = is_known(assigned, n_slow, t, l), kr = is_known(assigned, n_slow, t, r);
+            if (kl && kr) {
+                if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(fr_mul(fr_load(W, l, Bp, j), fr_load(W, r, Bp, j)), coef, consts));
+            } else if (!kl && !kr) {
+                if (coef != K_COEF_ZERO) residual_mul++;
+            } else if (coef != K_COEF_ZERO) {
+                Fr v = apply_coef(fr_load(W, kl ? l : r, Bp, j), coef, consts);
+                if (!fr_is_zero(v)) { unknowns++; unk_c = v; unk_w = kl ? r : l; unk_dynamic = true; }
+            }
+        }
+        for (uint32_t i = 0; i < n_lin; i++, p += 3) {
+            const uint32_t coef = p[0], w = p[2];
+            if (is_known(assigned, n_slow, t, w)) {
+                if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(fr_load(W, w, Bp, j), coef, consts));
+            } else if (coef != K_COEF_ZERO) {
+                unknowns++;
+                unk_ninv = p[1];
+                unk_dynamic = false;
+                unk_w = w;
+            }
+        }
+        if (residual_mul >= 2) { res = {2u, 8u, oi, 0u, 0u}; break; }                 // panic (arithmetic.rs:142)
+        if (residual_mul == 1 || unknowns > 1) { res = {2u, 2u, oi, 0u, 0u}; break; }  // TooManyUnknowns (:38-42)
+        if (unknowns == 0) {
+            if (!fr_is_zero(acc)) { res = {2u, 4u, oi, 0u, 0u}; break; }               // Unsatisfied (:92-102)
+        } else {
+            // assignment = -(total_sum / coeff) (:86,120); the witness is unassigned here, so insert_value cannot
+            // conflict. Constant coefficients carry their -1/c from the planner; a coefficient that is a product
+            // with a known witness (:217-221) is inverted per instance.
+            Fr val = unk_dynamic ? fr_neg(fr_mul(acc, fr_inv(unk_c))) : apply_coef(acc, unk_ninv, consts);
+            fr_store(W, unk_w, Bp, j, val);
+            assigned[(uint64_t)(unk_w >> 5) * n_slow + t] |= 1u << (unk_w & 31);
+        }
+    }
+    results[t] = res;
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+__global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void min_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && p[i] > v) p[i] = v;
+}
+// assigned-set initialisation for the exact kernel: bit set for every initial witness
+__global__ void init_assigned_kernel(uint32_t *assigned, uint32_t n_slow, uint32_t n_words, const uint32_t *__restrict__ init_words) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint64_t)n_slow * n_words) assigned[i] = init_words[i / n_slow];
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in) {
+    if (!B || !n_in) return;
+    hipLaunchKernelGGL(import_witness_kernel, dim3((B + 255) / 256, n_in), dim3(256), 0, s, W, Bp, B, in, ids, n_in);
+}
+void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out) {
+    if (!n || !n_sel) return;
+    hipLaunchKernelGGL(export_witness_kernel, dim3((n + 255) / 256, n_sel), dim3(256), 0, s, W, Bp, first, n, sel, n_sel, out);
+}
+void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
+                        uint32_t n_gates, const uint32_t *consts, uint32_t *event) {
+    // gridDim.y is limited to 65535
+    for (uint32_t done = 0; done < n_gates;) {
+        uint32_t n = n_gates - done > 65535u ? 65535u : n_gates - done;
+        hipLaunchKernelGGL(arith_level_kernel, dim3((B + 255) / 256, n), dim3(256), 0, s, W, Bp, B, gate_stream, gate_offset + done, consts, event);
+        done += n;
+    }
+}
+void launch_arith_inorder(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const uint32_t *stream,
+                          const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned, SlowResult *results) {
+    if (!n_slow) return;
+    hipLaunchKernelGGL(arith_inorder_kernel, dim3((n_slow + 63) / 64), dim3(64), 0, s, W, Bp, slow_ids, n_slow, stream, offset, n_opcodes,
+                       consts, assigned, results);
+}
+void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+}
+void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(min_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+}
+void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, const uint32_t *init_words) {
+    uint64_t n = (uint64_t)n_slow * n_words;
+    if (!n) return;
+    hipLaunchKernelGGL(init_assigned_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, assigned, n_slow, n_words, init_words);
+}
+
+}  // namespace acvm

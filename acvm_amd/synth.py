@@ -1,0 +1,128 @@
+"""Deterministic synthetic ACIR circuits and witness batches for tests and the bench.
+
+PRNG = splitmix64, seed 0xAC1D0000 + config number. Witness 0 is unused (Noir convention); inputs are
+witnesses 1..n_in (all assigned); gate i (0-based) solves witness n_in+1+i. Operands are drawn uniformly
+from already-defined witnesses. Gate mix (width-3 PLONK-shaped, acvm/src/compiler/transformers/csat.rs):
+  45 %  qM*a*b + qo*out + qc
+  30 %  q1*a + q2*b + qo*out + qc
+  20 %  qM*a*b + q1*c + qo*out + qc
+   5 %  qM*a*out + q1*c + qc        (unknown inside the mul term: per-instance inversion; zero multiplicand
+                                     leaves the generic path, arithmetic.rs:217-221)
+Coefficients: 50 % from {1, -1}, 50 % uniform Fr, never 0. Terms are sorted like Expression::sort
+(acir/src/native_types/expression/mod.rs:176-179).
+"""
+import numpy as np
+
+from .acir import Circuit, Expression, P
+
+MASK = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & MASK
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK
+        return z ^ (z >> 31)
+
+    def below(self, n):
+        return self.next() % n
+
+    def fr(self):
+        v = 0
+        for i in range(4):
+            v |= self.next() << (64 * i)
+        return v % P
+
+    def coef(self):
+        if self.next() & 1:
+            return 1 if self.next() & 1 else P - 1
+        while True:
+            c = self.fr()
+            if c:
+                return c
+
+
+def arithmetic_circuit(n_gates, n_in=16, seed=0xAC1D0002, chain=False, mix=(45, 30, 20, 5)):
+    """Returns (Circuit, input witness ids)."""
+    rng = SplitMix64(seed)
+    ops = []
+    defined = n_in  # witnesses 1..defined are known
+    for i in range(n_gates):
+        out = n_in + 1 + i
+        pick = lambda: 1 + rng.below(defined)  # noqa: E731
+        a, b, c = pick(), pick(), pick()
+        if chain and i > 0:
+            a = out - 1
+        r = rng.below(100)
+        qc = rng.coef() if rng.next() & 1 else 0
+        if r < mix[0]:
+            e = Expression([(rng.coef(), a, b)], [(rng.coef(), out)], qc)
+        elif r < mix[0] + mix[1]:
+            if a == b:
+                b = 1 + (b % defined)
+            e = Expression([], [(rng.coef(), a), (rng.coef(), b), (rng.coef(), out)], qc)
+        elif r < mix[0] + mix[1] + mix[2]:
+            e = Expression([(rng.coef(), a, b)], [(rng.coef(), c), (rng.coef(), out)], qc)
+        else:
+            e = Expression([(rng.coef(), a, out)], [(rng.coef(), c)], qc)
+        e.mul_terms.sort(key=lambda t: (t[1], t[2]))
+        e.linear_combinations.sort(key=lambda t: t[1])
+        ops.append(e)
+        defined += 1
+    circ = Circuit(current_witness_index=n_in + n_gates, opcodes=ops, private_parameters=list(range(1, n_in + 1)),
+                   return_values=[n_in + n_gates])
+    return circ, list(range(1, n_in + 1))
+
+
+def _splitmix_vec(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def witness_batch(B, n_in=16, seed=0xAC1D0002, edge_cases=True, first_instance=0):
+    """[B][n_in][32] big-endian input values as bytes. Values are raw 256-bit strings; both the reference
+    (from_be_bytes_reduce) and the device import reduce them mod p. Instances 0..7 of the global batch are edge
+    cases when edge_cases is set."""
+    with np.errstate(over="ignore"):
+        j = (np.arange(B, dtype=np.uint64) + np.uint64(first_instance))[:, None]
+        k = np.arange(n_in, dtype=np.uint64)[None, :]
+        base = np.uint64(seed) ^ ((j << np.uint64(16)) | k)
+        limbs = np.empty((B, n_in, 4), dtype=np.uint64)
+        s = base * np.uint64(4)
+        for i in range(4):
+            limbs[:, :, i] = _splitmix_vec(s + np.uint64(i))
+    out = limbs.byteswap().view(np.uint8).reshape(B, n_in, 32).copy()  # each u64 big-endian, limb 0 most significant
+    if edge_cases:
+        pm1 = np.frombuffer((P - 1).to_bytes(32, "big"), dtype=np.uint8)
+        one = np.frombuffer((1).to_bytes(32, "big"), dtype=np.uint8)
+        two128 = np.frombuffer((1 << 128).to_bytes(32, "big"), dtype=np.uint8)
+        for g in range(8):
+            idx = g - first_instance
+            if not (0 <= idx < B):
+                continue
+            if g == 0:
+                out[idx] = 0
+            elif g == 1:
+                out[idx] = one
+            elif g == 2:
+                out[idx] = pm1
+            elif g == 3:
+                out[idx, 0::2] = 0
+                out[idx, 1::2] = pm1
+            elif g == 4:
+                out[idx] = 0xFF  # 2^256 - 1: reduced on import
+            elif g == 5:
+                out[idx] = two128
+            elif g == 6:
+                out[idx, 0] = 0  # a single zero input
+            elif g == 7:
+                out[idx, :] = out[idx, 0]  # all inputs equal
+    return out.tobytes()

@@ -1,0 +1,149 @@
+/*
+ * acvm_amd.h -- C ABI of the MI355X-native batched ACIR witness solver (libacvm_amd.so).
+ *
+ * This header is the drop-in boundary for ONE hot path of noir-lang/acvm v0.27.0:
+ * `acvm::pwg::ACVM::solve()` and what it calls, for B independent witness instances of one circuit.
+ * Plain pointers and sizes only; no torch / HIP types. Every entry point cites the reference
+ * interface it replaces (paths relative to the acvm repository root).
+ *
+ *   reference                                               this ABI
+ *   ------------------------------------------------------  -------------------------------------------
+ *   acir::circuit::Circuit::read   circuit/mod.rs:154-161    acvm_circuit_from_bytes
+ *   ACVM::new(backend, opcodes, initial_witness)
+ *                         acvm/src/pwg/mod.rs:146-156        acvm_batch_new + acvm_batch_set_initial_witness
+ *   ACVM::solve           acvm/src/pwg/mod.rs:236-241        acvm_batch_solve
+ *   ACVMStatus / OpcodeResolutionError  mod.rs:33-51,100-114 acvm_result_t via acvm_batch_results
+ *   ACVM::witness_map / finalize        mod.rs:161,176-181   acvm_batch_witness_map / acvm_batch_witness
+ *   ACVM::instruction_pointer           mod.rs:171           acvm_result_t.opcode_index
+ *   ACVM::get_pending_foreign_call      mod.rs:203-209       acvm_batch_pending_foreign_call*
+ *   ACVM::resolve_pending_foreign_call  mod.rs:214-228       acvm_batch_resolve_foreign_call
+ *   trait BlackBoxFunctionSolver  blackbox_solver/src/lib.rs:27-45   acvm_bb_solver_t (vtable)
+ *
+ * Threading (reference: `&mut self`, backend not Sync): one batch handle = one host thread + one HIP
+ * device + one stream. Handles are independent; there is no global mutable state.
+ * Errors: functions return 0 on success or a negative ACVM_E_* code; acvm_last_error() gives text.
+ * The library requires a gfx950 device for every compute entry point and fails loudly without one;
+ * there is no CPU fallback.
+ */
+#ifndef ACVM_AMD_H
+#define ACVM_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACVM_AMD_ABI_VERSION 1
+
+/* library-level error codes */
+enum {
+    ACVM_OK = 0,
+    ACVM_E_INVALID = -1,     /* bad argument / handle */
+    ACVM_E_MALFORMED = -2,   /* circuit bytes do not decode (the reference would panic in bincode::deserialize) */
+    ACVM_E_UNSUPPORTED = -3, /* opcode outside the accelerated set -- refused at batch creation */
+    ACVM_E_DEVICE = -4,      /* no gfx950 device / HIP runtime error */
+    ACVM_E_STATE = -5        /* call not valid in the current state (reference: panic) */
+};
+
+/* ACVMStatus (acvm/src/pwg/mod.rs:33-51) */
+enum { ACVM_STATUS_SOLVED = 0, ACVM_STATUS_IN_PROGRESS = 1, ACVM_STATUS_FAILURE = 2, ACVM_STATUS_REQUIRES_FOREIGN_CALL = 3 };
+
+/* OpcodeResolutionError (mod.rs:100-114) with OpcodeNotSolvable (mod.rs:72-78) flattened */
+enum {
+    ACVM_ERR_NONE = 0,
+    ACVM_ERR_MISSING_ASSIGNMENT = 1,   /* aux0 = witness index */
+    ACVM_ERR_TOO_MANY_UNKNOWNS = 2,    /* OpcodeNotSolvable::ExpressionHasTooManyUnknowns */
+    ACVM_ERR_UNSUPPORTED_BLACKBOX = 3, /* aux0 = BlackBoxFunc tag */
+    ACVM_ERR_UNSATISFIED = 4,          /* UnsatisfiedConstrain{Resolved(Acir(opcode_index))} */
+    ACVM_ERR_INDEX_OOB = 5,            /* IndexOutOfBounds{index = aux0, array_size = aux1} */
+    ACVM_ERR_BLACKBOX_FAILED = 6,      /* BlackBoxFunctionFailed(func = aux0, message) */
+    ACVM_ERR_BRILLIG_FAILED = 7,       /* BrilligFunctionFailed{message, call_stack} */
+    ACVM_ERR_PANIC = 8                 /* the reference would panic at this opcode (message) */
+};
+
+/* Per-instance outcome. Same layout and numbering as the CPU oracle's result record. */
+typedef struct {
+    uint32_t status;       /* ACVM_STATUS_* */
+    uint32_t err;          /* ACVM_ERR_* when status == FAILURE */
+    uint32_t opcode_index; /* instruction pointer of the failing opcode (ACVM::instruction_pointer) */
+    uint32_t aux0, aux1;
+    uint32_t n_call_stack;
+    uint32_t call_stack[16]; /* Brillig indices for BrilligFunctionFailed */
+    char message[200];
+} acvm_result_t;
+
+/*
+ * BlackBoxFunctionSolver (blackbox_solver/src/lib.rs:27-45) as a vtable. Field elements cross as 32-byte
+ * canonical big-endian. Return 0 = Ok, 1 = BlackBoxResolutionError::Failed(err text), 2 = Unsupported.
+ * A NULL solver selects the built-in HIP implementation of barretenberg's three functions.
+ */
+typedef struct {
+    void *ctx;
+    int (*schnorr_verify)(void *ctx, const uint8_t pkx[32], const uint8_t pky[32], const uint8_t *sig, size_t sig_len,
+                          const uint8_t *msg, size_t msg_len, uint8_t *ok, char *err, size_t err_len);
+    int (*pedersen)(void *ctx, const uint8_t *inputs_be32, size_t n_inputs, uint32_t domain_separator, uint8_t x[32],
+                    uint8_t y[32], char *err, size_t err_len);
+    int (*fixed_base_scalar_mul)(void *ctx, const uint8_t low[32], const uint8_t high[32], uint8_t x[32], uint8_t y[32],
+                                 char *err, size_t err_len);
+} acvm_bb_solver_t;
+
+typedef struct acvm_circuit acvm_circuit_t;
+typedef struct acvm_batch acvm_batch_t;
+
+/* Statistics of the static plan and of the last solve (measurement). */
+typedef struct {
+    uint32_t n_opcodes, n_witnesses, n_levels, n_fast_gates, n_dyn_gates;
+    uint32_t max_level_width, n_kernel_launches, n_slow_instances;
+    uint64_t algorithmic_bytes_per_instance; /* sum over gates of 32 B x (distinct known operands + written witness) */
+    uint64_t arith_algorithmic_bytes_per_instance; /* the part moved by the arithmetic level kernels */
+    double plan_ms;         /* one-time levelisation, host */
+    double solve_device_ms; /* HIP events around the whole last solve, on the batch's stream */
+    double arith_kernel_ms; /* sum of HIP-event durations of the arithmetic level kernels of the last solve */
+    double slow_path_ms;
+} acvm_stats_t;
+
+const char *acvm_last_error(void);
+int acvm_abi_version(void);
+int acvm_device_count(void);
+int acvm_set_device(int device);
+int acvm_device_synchronize(void);
+/* name of the current device's gcnArch ("gfx950...") into out */
+int acvm_device_arch(char *out, size_t out_len);
+
+/* Circuit::read: gzip(bincode) or raw bincode bytes. */
+acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);
+void acvm_circuit_free(acvm_circuit_t *c);
+uint32_t acvm_circuit_num_opcodes(const acvm_circuit_t *c);
+uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c); /* 1 + highest witness index referenced */
+
+/*
+ * ACVM::new for n_instances instances that all assign the same initial witness ids.
+ * The circuit is levelised once against that set. `solver` may be NULL (built-in HIP backend).
+ */
+acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances,
+                             const uint32_t *initial_ids, uint32_t n_initial);
+void acvm_batch_free(acvm_batch_t *b);
+/* values_be32: [n_instances][n_initial][32] canonical big-endian (reduced mod p like from_be_bytes_reduce). */
+int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32);
+/* same, from a device-resident buffer of the same layout (no PCIe in the call) */
+int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32);
+/* ACVM::solve for every instance. Returns the number of instances not Solved, or a negative error. */
+int acvm_batch_solve(acvm_batch_t *b);
+/* back to the state right after set_initial_witness (same inputs, nothing solved) */
+int acvm_batch_reset(acvm_batch_t *b);
+/* force every instance through the exact in-order kernel instead of the level-parallel one (validation) */
+int acvm_batch_set_force_slow_path(acvm_batch_t *b, int on);
+int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out /*[n_instances]*/);
+/* one witness across the batch: out_be32 [n_instances][32], assigned [n_instances] (0/1) */
+int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uint8_t *assigned);
+/* full witness maps of instances [first, first+n): assigned [n][nw], values_be32 [n][nw][32] (zeros if unassigned) */
+int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *assigned, uint8_t *values_be32);
+int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out);
+/* enable per-kernel HIP-event timing of the level kernels (small overhead) */
+int acvm_batch_set_profiling(acvm_batch_t *b, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,106 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of include/acvm_amd.h) against the CPU oracle on
+identical seeded inputs. Bit-exact bar: status, error kind, failing opcode index, assigned set and every
+32-byte witness value of every instance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(oracle, circ, ids, values, B, force_slow=False):
+    import acvm_amd
+    data = circ.to_bytes()
+    oc = oracle.Circuit(data)
+    ores, oasg, ovals = oracle.solve_batch(oc, ids, values, B)
+    gc = acvm_amd.Circuit(data)
+    batch = acvm_amd.Batch(gc, B, ids)
+    batch.set_force_slow_path(force_slow)
+    batch.set_initial_witness(values)
+    batch.solve()
+    gres = batch.results()
+    gasg, gvals = batch.witness_map()
+    stats = batch.stats()
+    batch.free()
+    return (ores, oasg, ovals), (gres, gasg, gvals), stats
+
+
+def _assert_parity(o, g, B):
+    ores, oasg, ovals = o
+    gres, gasg, gvals = g
+    for j in range(B):
+        assert gres[j].as_tuple() == ores[j].as_tuple(), f"instance {j}: gpu {gres[j].as_tuple()} oracle {ores[j].as_tuple()}"
+    nw = min(oasg.shape[1], gasg.shape[1])
+    assert np.array_equal(oasg[:, :nw], gasg[:, :nw]), "assigned sets differ"
+    assert np.array_equal(ovals[:, :nw], gvals[:, :nw]), "witness values differ"
+
+
+@pytest.mark.parametrize("n_gates,B", [(64, 70), (1000, 256), (3000, 96)])
+def test_arithmetic_circuit_parity(oracle, n_gates, B):
+    from acvm_amd import synth
+    circ, ids = synth.arithmetic_circuit(n_gates, seed=0xAC1D0002 + n_gates)
+    values = synth.witness_batch(B, seed=0xAC1D0002 + n_gates)
+    o, g, stats = _run_both(oracle, circ, ids, values, B)
+    _assert_parity(o, g, B)
+    solved = sum(1 for j in range(B) if g[0][j].status == 0)
+    assert solved >= B - 8  # only the edge-case instances may fail / leave the generic path
+    assert stats["n_slow_instances"] <= 8
+
+
+def test_chain_circuit_parity(oracle):
+    from acvm_amd import synth
+    circ, ids = synth.arithmetic_circuit(300, seed=0xAC1D0077, chain=True)
+    values = synth.witness_batch(64, seed=0xAC1D0077)
+    o, g, stats = _run_both(oracle, circ, ids, values, 64)
+    _assert_parity(o, g, 64)
+    assert stats["n_levels"] >= 300
+
+
+def test_exact_inorder_kernel_parity(oracle):
+    """Every instance through the exact in-order kernel (the path taken by failing / non-generic instances)."""
+    from acvm_amd import synth
+    circ, ids = synth.arithmetic_circuit(400, seed=0xAC1D0123)
+    values = synth.witness_batch(80, seed=0xAC1D0123)
+    o, g, stats = _run_both(oracle, circ, ids, values, 80, force_slow=True)
+    _assert_parity(o, g, 80)
+    assert stats["n_slow_instances"] == 80
+
+
+def test_reference_addition_fixture(oracle, golden):
+    import acvm_amd
+    fx = golden["acvm_js"]["addition"]
+    gc = acvm_amd.Circuit(bytes(fx["bytecode"]))
+    iw = {int(k): int(v, 16) for k, v in fx["initialWitnessMap"].items()}
+    ids = sorted(iw)
+    batch = acvm_amd.Batch(gc, 1, ids)
+    batch.set_initial_witness(b"".join(iw[i].to_bytes(32, "big") for i in ids))
+    assert batch.solve() == 0
+    vals, asg = batch.witness(fx["resultWitness"])
+    assert asg[0] == 1 and int.from_bytes(vals[0].tobytes(), "big") == int(fx["expectedResult"], 16)
+
+
+def test_unsatisfied_constraint_reports_opcode(oracle):
+    """acvm/tests/solver.rs:490-525: x == y with 1 != 2 fails with UnsatisfiedConstrain at opcode 0."""
+    import acvm_amd
+    from acvm_amd.acir import Circuit, Expression, P
+    circ = Circuit(2, [Expression([], [(1, 1), (P - 1, 2)], 0)])
+    o, g, _ = _run_both(oracle, circ, [1, 2], (1).to_bytes(32, "big") + (2).to_bytes(32, "big"), 1)
+    _assert_parity(o, g, 1)
+    assert g[0][0].as_tuple() == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_UNSATISFIED, 0, 0, 0)
+
+
+def test_empty_and_ragged(oracle):
+    import acvm_amd
+    from acvm_amd import synth
+    from acvm_amd.acir import Circuit
+    # empty opcode list: Solved at construction (pwg/mod.rs:147)
+    gc = acvm_amd.Circuit(Circuit(1, []).to_bytes())
+    b = acvm_amd.Batch(gc, 3, [1])
+    b.set_initial_witness(b"\x00" * 96)
+    assert b.solve() == 0
+    assert all(r.status == 0 for r in b.results())
+    # batch sizes that are not multiples of the wavefront / block
+    circ, ids = synth.arithmetic_circuit(50, seed=5)
+    for B in (1, 63, 65, 257):
+        values = synth.witness_batch(B, seed=5, edge_cases=False)
+        o, g, _ = _run_both(oracle, circ, ids, values, B)
+        _assert_parity(o, g, B)

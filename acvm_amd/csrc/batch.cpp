@@ -37,11 +37,12 @@ struct acvm_batch {
     hipStream_t stream = nullptr;
     uint4 *d_W = nullptr;
     uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
-    uint32_t *d_slow_stream = nullptr, *d_slow_offset = nullptr, *d_init_ids = nullptr, *d_init_words = nullptr;
+    uint32_t *d_slow_stream = nullptr, *d_slow_offset = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
+    uint32_t *d_dyn_offset = nullptr, *d_slow_start = nullptr;
     uint32_t *d_event = nullptr;
     std::vector<uint32_t> h_event;
     // exact in-order path
-    std::vector<uint32_t> slow_ids;
+    std::vector<uint32_t> slow_ids, slow_start;
     std::vector<int32_t> slow_index;  // per instance: index into slow_ids or -1
     std::vector<SlowResult> slow_res;
     uint32_t *d_slow_ids = nullptr, *d_assigned = nullptr;
@@ -56,7 +57,8 @@ struct acvm_batch {
     ~acvm_batch() {
         hipSetDevice(device);
         for (void *p : {(void *)d_W, (void *)d_gate_stream, (void *)d_gate_offset, (void *)d_consts, (void *)d_slow_stream,
-                        (void *)d_slow_offset, (void *)d_init_ids, (void *)d_init_words, (void *)d_event, (void *)d_slow_ids,
+                        (void *)d_slow_offset, (void *)d_init_ids, (void *)d_producer, (void *)d_dyn_offset, (void *)d_slow_start,
+                        (void *)d_event, (void *)d_slow_ids,
                         (void *)d_assigned, (void *)d_slow_res})
             if (p) hipFree(p);
         for (auto e : ev_pool) hipEventDestroy(e);
@@ -136,9 +138,8 @@ static int batch_init(acvm_batch *b) {
     if (int rc = upload(&b->d_slow_offset, p.slow_offset)) return rc;
     if (int rc = upload(&b->d_init_ids, p.initial_ids)) return rc;
     b->n_words = (p.n_witnesses + 31) / 32;
-    std::vector<uint32_t> init_words(b->n_words ? b->n_words : 1, 0);
-    for (uint32_t w : p.initial_ids) init_words[w >> 5] |= 1u << (w & 31);
-    if (int rc = upload(&b->d_init_words, init_words)) return rc;
+    if (int rc = upload(&b->d_producer, p.producer)) return rc;
+    if (int rc = upload(&b->d_dyn_offset, p.dyn_offset)) return rc;
     HIPCHK(hipMalloc((void **)&b->d_event, (size_t)(b->B ? b->B : 1) * 4));
     b->h_event.assign(b->B, 0xFFFFFFFFu);
     b->slow_index.assign(b->B, -1);
@@ -210,10 +211,11 @@ int acvm_batch_reset(acvm_batch_t *b) {
 
 static int ensure_slow_capacity(acvm_batch *b, uint32_t n) {
     if (n <= b->slow_cap) return 0;
-    for (void *p : {(void *)b->d_slow_ids, (void *)b->d_assigned, (void *)b->d_slow_res})
+    for (void *p : {(void *)b->d_slow_ids, (void *)b->d_assigned, (void *)b->d_slow_res, (void *)b->d_slow_start})
         if (p) hipFree(p);
-    b->d_slow_ids = nullptr; b->d_assigned = nullptr; b->d_slow_res = nullptr;
+    b->d_slow_ids = nullptr; b->d_assigned = nullptr; b->d_slow_res = nullptr; b->d_slow_start = nullptr;
     HIPCHK(hipMalloc((void **)&b->d_slow_ids, (size_t)n * 4));
+    HIPCHK(hipMalloc((void **)&b->d_slow_start, (size_t)n * 4));
     HIPCHK(hipMalloc((void **)&b->d_assigned, (size_t)n * (b->n_words ? b->n_words : 1) * 4));
     HIPCHK(hipMalloc((void **)&b->d_slow_res, (size_t)n * sizeof(SlowResult)));
     b->slow_cap = n;
@@ -245,11 +247,20 @@ int acvm_batch_solve(acvm_batch_t *b) {
         launch_fill_u32(s, b->d_event, 0xFFFFFFFFu, b->B);
         for (size_t L = 0; L + 1 < p.level_start.size(); L++) {
             uint32_t n = p.level_start[L + 1] - p.level_start[L];
-            if (!n) continue;
-            if (b->profiling) hipEventRecord(next_event(), s);
-            launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event);
-            if (b->profiling) hipEventRecord(next_event(), s);
-            b->n_launches += (n + 65534) / 65535;
+            uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
+            if (n) {
+                if (b->profiling) hipEventRecord(next_event(), s);
+                launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event);
+                if (b->profiling) hipEventRecord(next_event(), s);
+                b->n_launches += (n + 65534) / 65535;
+            }
+            if (nd) {
+                if (b->profiling) hipEventRecord(next_event(), s);
+                launch_arith_dyn_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_consts,
+                                       b->d_event);
+                if (b->profiling) hipEventRecord(next_event(), s);
+                b->n_launches++;
+            }
         }
         if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
     }
@@ -269,12 +280,15 @@ int acvm_batch_solve(acvm_batch_t *b) {
     if (n_slow) {
         if (int rc = ensure_slow_capacity(b, n_slow)) return rc;
         HIPCHK(hipMemcpyAsync(b->d_slow_ids, b->slow_ids.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        b->slow_start.resize(n_slow);
+        for (uint32_t t = 0; t < n_slow; t++) b->slow_start[t] = b->h_event[b->slow_ids[t]];
+        HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         slow0 = next_event();
         slow1 = next_event();
         hipEventRecord(slow0, s);
-        launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, b->d_init_words);
+        launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
         launch_arith_inorder(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->d_slow_stream, b->d_slow_offset, p.n_opcodes, b->d_consts,
-                             b->d_assigned, b->d_slow_res);
+                             b->d_assigned, b->d_slow_start, b->d_slow_res);
         hipEventRecord(slow1, s);
         HIPCHK(hipGetLastError());
         b->slow_res.resize(n_slow);

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
     const uint32_t *__restrict__ g = gate_stream + gate_offset[blockIdx.y];
     const uint32_t w0 = g[0];
     const uint32_t kind = w0 & 0xff, n_prod = (w0 >> 8) & 0xff, n_lin = (w0 >> 16) & 0xff;
-    const uint32_t opcode = g[1], out = g[2], qc = g[3], den_slot = g[4];
+    const uint32_t opcode = g[1], out = g[2], qc = g[3];
     Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
     const uint32_t *__restrict__ t = g + 5;
     for (uint32_t i = 0; i < n_prod; i++, t += 3) {
@@ -109,12 +109,58 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
     }
     if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
         if (!fr_is_zero(acc)) atomicMin(&event[j], opcode);
-    } else if (kind == 1) {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
+    } else {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
         fr_store(W, out, Bp, j, acc);
-    } else {  // unknown multiplied by a known witness (arithmetic.rs:68-91): out = acc' / partner
-        Fr den = fr_load(W, den_slot, Bp, j);
-        if (fr_is_zero(den)) atomicMin(&event[j], opcode);  // zero-coefficient drop (:217-221): leaves the generic path
-        fr_store(W, out, Bp, j, fr_mul(acc, fr_inv(den)));
+    }
+}
+
+// gates whose unknown is multiplied by a known witness (arithmetic.rs:68-91): out = acc' / partner needs a
+// per-instance inversion. One wave = 64 instances x up to DYN_CHUNK independent gates of one level; the
+// inversions of a lane are batched with Montgomery's trick (prefix products staged in LDS), so a lane pays one
+// field inversion per chunk plus 4 multiplications per gate.
+static constexpr int DYN_CHUNK = 16;
+__global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
+                                                             const uint32_t *__restrict__ gate_stream,
+                                                             const uint32_t *__restrict__ dyn_offset, uint32_t n_dyn,
+                                                             const uint32_t *__restrict__ consts, uint32_t *__restrict__ event) {
+    __shared__ uint4 prefix_lds[DYN_CHUNK * 2 * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
+    if (j >= B) return;
+    const uint32_t first = blockIdx.y * DYN_CHUNK;
+    const uint32_t n = n_dyn - first < (uint32_t)DYN_CHUNK ? n_dyn - first : (uint32_t)DYN_CHUNK;
+    Fr prefix = fr_one();
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *__restrict__ g = gate_stream + dyn_offset[first + i];
+        Fr den = fr_load(W, g[4], Bp, j);
+        if (fr_is_zero(den)) {  // zero-coefficient drop (arithmetic.rs:217-221): this instance leaves the generic path
+            atomicMin(&event[j], g[1]);
+            den = fr_one();
+        }
+        prefix = fr_mul(prefix, den);
+        prefix_lds[(i * 2) * 64 + lane] = make_uint4(prefix.v[0], prefix.v[1], prefix.v[2], prefix.v[3]);
+        prefix_lds[(i * 2 + 1) * 64 + lane] = make_uint4(prefix.v[4], prefix.v[5], prefix.v[6], prefix.v[7]);
+    }
+    Fr inv = fr_inv(prefix);  // 1 / (den_0 ... den_{n-1})
+    for (uint32_t i = n; i-- > 0;) {
+        const uint32_t *__restrict__ g = gate_stream + dyn_offset[first + i];
+        const uint32_t w0 = g[0];
+        const uint32_t n_prod = (w0 >> 8) & 0xff, n_lin = (w0 >> 16) & 0xff, out = g[2], qc = g[3];
+        Fr den = fr_load(W, g[4], Bp, j);
+        if (fr_is_zero(den)) den = fr_one();
+        Fr inv_i = inv;
+        if (i > 0) {
+            const uint4 lo = prefix_lds[((i - 1) * 2) * 64 + lane], hi = prefix_lds[((i - 1) * 2 + 1) * 64 + lane];
+            Fr pm = {{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+            inv_i = fr_mul(inv, pm);
+        }
+        inv = fr_mul(inv, den);
+        Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
+        const uint32_t *__restrict__ t = g + 5;
+        for (uint32_t k = 0; k < n_prod; k++, t += 3)
+            acc = fr_add(acc, apply_coef(fr_mul(fr_load(W, t[1], Bp, j), fr_load(W, t[2], Bp, j)), t[0], consts));
+        for (uint32_t k = 0; k < n_lin; k++, t += 2) acc = fr_add(acc, apply_coef(fr_load(W, t[1], Bp, j), t[0], consts));
+        fr_store(W, out, Bp, j, fr_mul(acc, inv_i));
     }
 }
 
@@ -129,13 +175,14 @@ __global__ void __launch_bounds__(64) arith_inorder_kernel(uint4 *__restrict__ W
                                                            uint32_t n_slow, const uint32_t *__restrict__ stream,
                                                            const uint32_t *__restrict__ offset, uint32_t n_opcodes,
                                                            const uint32_t *__restrict__ consts, uint32_t *assigned,
+                                                           const uint32_t *__restrict__ start_opcode,
                                                            SlowResult *__restrict__ results) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slow) return;
     const uint64_t j = slow_ids[t];
     SlowResult res = {0u, 0u, 0u, 0u, 0u};  // Solved
     if (n_opcodes == 0) { results[t] = res; return; }
-    for (uint32_t oi = 0; oi < n_opcodes; oi++) {
+    for (uint32_t oi = start_opcode[t]; oi < n_opcodes; oi++) {
         const uint32_t *__restrict__ g = stream + offset[oi];
         if (g[0] != 0u) { res = {2u, 8u, oi, 0u, 0u}; break; }  // not an Arithmetic opcode: never scheduled here
         const uint32_t n_mul = g[1], n_lin = g[2], qc = g[3];
@@ -193,10 +240,24 @@ __global__ void min_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && p[i] > v) p[i] = v;
 }
-// assigned-set initialisation for the exact kernel: bit set for every initial witness
-__global__ void init_assigned_kernel(uint32_t *assigned, uint32_t n_slow, uint32_t n_words, const uint32_t *__restrict__ init_words) {
+// assigned-set initialisation for the exact kernel. Opcodes before an instance's first event behaved exactly
+// like the generic plan on exact data, so their outputs (producer[w] < start) are kept; the in-order kernel
+// resumes at the event. producer: 0xFFFFFFFE = initial witness, 0xFFFFFFFF = never assigned.
+__global__ void init_assigned_kernel(uint32_t *assigned, uint32_t n_slow, uint32_t n_words, uint32_t n_witnesses,
+                                     const uint32_t *__restrict__ producer, const uint32_t *__restrict__ start_opcode) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (uint64_t)n_slow * n_words) assigned[i] = init_words[i / n_slow];
+    if (i >= (uint64_t)n_slow * n_words) return;
+    const uint32_t word = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
+    const uint32_t start = start_opcode[t];
+    uint32_t bits = 0;
+    for (uint32_t k = 0; k < 32; k++) {
+        const uint32_t w = word * 32 + k;
+        if (w < n_witnesses) {
+            const uint32_t pr = producer[w];
+            if (pr == 0xFFFFFFFEu || pr < start) bits |= 1u << k;
+        }
+    }
+    assigned[i] = bits;
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -217,11 +278,18 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
         done += n;
     }
 }
+void launch_arith_dyn_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *dyn_offset,
+                            uint32_t n_dyn, const uint32_t *consts, uint32_t *event) {
+    if (!n_dyn || !B) return;
+    hipLaunchKernelGGL(arith_dyn_level_kernel, dim3((B + 63) / 64, (n_dyn + DYN_CHUNK - 1) / DYN_CHUNK), dim3(64), 0, s, W, Bp, B,
+                       gate_stream, dyn_offset, n_dyn, consts, event);
+}
 void launch_arith_inorder(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const uint32_t *stream,
-                          const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned, SlowResult *results) {
+                          const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned,
+                          const uint32_t *start_opcode, SlowResult *results) {
     if (!n_slow) return;
     hipLaunchKernelGGL(arith_inorder_kernel, dim3((n_slow + 63) / 64), dim3(64), 0, s, W, Bp, slow_ids, n_slow, stream, offset, n_opcodes,
-                       consts, assigned, results);
+                       consts, assigned, start_opcode, results);
 }
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n) {
     if (!n) return;
@@ -231,10 +299,12 @@ void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n) {
     if (!n) return;
     hipLaunchKernelGGL(min_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
 }
-void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, const uint32_t *init_words) {
+void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, uint32_t n_witnesses,
+                          const uint32_t *producer, const uint32_t *start_opcode) {
     uint64_t n = (uint64_t)n_slow * n_words;
     if (!n) return;
-    hipLaunchKernelGGL(init_assigned_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, assigned, n_slow, n_words, init_words);
+    hipLaunchKernelGGL(init_assigned_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, assigned, n_slow, n_words, n_witnesses,
+                       producer, start_opcode);
 }
 
 }  // namespace acvm

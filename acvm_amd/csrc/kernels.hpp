@@ -14,10 +14,14 @@ void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, u
                    uint8_t *out);
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event);
+void launch_arith_dyn_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *dyn_offset,
+                            uint32_t n_dyn, const uint32_t *consts, uint32_t *event);
 void launch_arith_inorder(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const uint32_t *stream,
-                          const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned, SlowResult *results);
+                          const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned,
+                          const uint32_t *start_opcode, SlowResult *results);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
-void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, const uint32_t *init_words);
+void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, uint32_t n_witnesses,
+                          const uint32_t *producer, const uint32_t *start_opcode);
 
 }  // namespace acvm

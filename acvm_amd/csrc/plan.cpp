@@ -185,17 +185,21 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     uint32_t max_level = 0;
     for (auto &g : gates) max_level = std::max(max_level, g.level);
     p.level_start.assign(max_level + 1, 0);
+    p.dyn_level_start.assign(max_level + 1, 0);
     size_t gi = 0;
     for (uint32_t L = 1; L <= max_level; L++) {
         p.level_start[L - 1] = (uint32_t)p.gate_offset.size();
+        p.dyn_level_start[L - 1] = (uint32_t)p.dyn_offset.size();
         for (; gi < gates.size() && gates[gi].level == L; gi++) {
-            p.gate_offset.push_back((uint32_t)p.gate_stream.size());
+            bool dyn = (gates[gi].words[0] & 0xff) == GATE_SOLVE_DYN;
+            (dyn ? p.dyn_offset : p.gate_offset).push_back((uint32_t)p.gate_stream.size());
             p.gate_stream.insert(p.gate_stream.end(), gates[gi].words.begin(), gates[gi].words.end());
         }
     }
     p.level_start[max_level] = (uint32_t)p.gate_offset.size();
+    p.dyn_level_start[max_level] = (uint32_t)p.dyn_offset.size();
     for (size_t l = 0; l + 1 < p.level_start.size(); l++)
-        p.max_level_width = std::max(p.max_level_width, p.level_start[l + 1] - p.level_start[l]);
+        p.max_level_width = std::max(p.max_level_width, p.level_start[l + 1] - p.level_start[l] + p.dyn_level_start[l + 1] - p.dyn_level_start[l]);
     p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return p;
 }

@@ -33,8 +33,10 @@ struct Plan {
     std::vector<uint32_t> initial_ids;
     // device program
     std::vector<uint32_t> gate_stream;          // all gate records
-    std::vector<uint32_t> gate_offset;          // per scheduled gate: offset into gate_stream (level-major order)
+    std::vector<uint32_t> gate_offset;          // per scheduled ASSERT/SOLVE gate: offset into gate_stream (level-major)
     std::vector<uint32_t> level_start;          // size n_levels + 1, indexes gate_offset
+    std::vector<uint32_t> dyn_offset;           // per scheduled SOLVE_DYN gate (needs a per-instance inversion), level-major
+    std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
     // bookkeeping for export / failure masking
     std::vector<uint32_t> producer;             // per witness: opcode index that assigns it, 0xFFFFFFFF if none,

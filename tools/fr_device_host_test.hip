@@ -1,0 +1,65 @@
+// Host-side execution of the device field library (fr_device.hpp is __host__ __device__) against the
+// planner's independent 4x64 implementation (fr_host.hpp). Run by tests/test_fr_device_on_host.py.
+#include "../acvm_amd/csrc/fr_device.hpp"
+#include "../acvm_amd/csrc/fr_host.hpp"
+#include <cstdio>
+#include <cstdlib>
+using namespace acvm;
+
+static uint64_t sm(uint64_t &s) {
+    s += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static Fr to_dev(const FrH &a) {
+    Fr r;
+    for (int i = 0; i < 4; i++) { r.v[2 * i] = (uint32_t)a.l[i]; r.v[2 * i + 1] = (uint32_t)(a.l[i] >> 32); }
+    return r;
+}
+static bool same(const Fr &d, const FrH &h) {
+    for (int i = 0; i < 4; i++)
+        if (d.v[2 * i] != (uint32_t)h.l[i] || d.v[2 * i + 1] != (uint32_t)(h.l[i] >> 32)) return false;
+    return true;
+}
+int main() {
+    if (!frh::self_check()) { printf("FAIL self_check\n"); return 1; }
+    uint64_t s = 12345;
+    int fails = 0;
+    FrH edge[6];
+    edge[0] = frh::zero(); edge[1] = frh::one(); edge[2] = frh::neg(frh::one());
+    uint64_t t128[4] = {0, 0, 1, 0}; edge[3] = frh::from_canonical(t128);
+    uint64_t t253[4] = {0, 0, 0, 1ULL << 61}; edge[4] = frh::from_canonical(t253);
+    edge[5] = frh::from_u64(5);
+    for (int it = 0; it < 3000; it++) {
+        FrH a, b;
+        if (it < 36) { a = edge[it / 6]; b = edge[it % 6]; }
+        else {
+            uint64_t x[4] = {sm(s), sm(s), sm(s), sm(s) >> 3}, y[4] = {sm(s), sm(s), sm(s), sm(s) >> 3};
+            while (frh::geq_p(x)) frh::sub4(x, x, frh::P);
+            while (frh::geq_p(y)) frh::sub4(y, y, frh::P);
+            a = frh::from_canonical(x); b = frh::from_canonical(y);
+        }
+        Fr da = to_dev(a), db = to_dev(b);
+        if (!same(fr_mul(da, db), frh::mul(a, b))) { fails++; printf("mul mismatch %d\n", it); }
+        if (!same(fr_add(da, db), frh::add(a, b))) { fails++; printf("add mismatch %d\n", it); }
+        if (!same(fr_sub(da, db), frh::sub(a, b))) { fails++; printf("sub mismatch %d\n", it); }
+        if (!same(fr_neg(da), frh::neg(a))) { fails++; printf("neg mismatch %d\n", it); }
+        if (it < 400) {
+            Fr inv = fr_inv(da);
+            if (!same(inv, frh::inverse(a))) { fails++; printf("inv mismatch %d\n", it); }
+        }
+        if (fr_is_zero(da) != a.is_zero()) { fails++; printf("is_zero mismatch %d\n", it); }
+    }
+    // 5^-1 = 0x135b5294...6667 (acvm_js/test/shared/foreign_call.ts)
+    {
+        Fr one_c = fr_zero(); one_c.v[0] = 1;
+        Fr inv5 = fr_mul(fr_inv(to_dev(frh::from_u64(5))), one_c);
+        const uint32_t expect[8] = {0xc6666667u, 0xe7f3fbd4u, 0xca4a2d06u, 0xa9ae5ce9u, 0x33cd568bu, 0x49b9b57cu, 0x5a13d9aau, 0x135b5294u};
+        for (int i = 0; i < 8; i++) if (inv5.v[i] != expect[i]) { fails++; printf("inv5 limb %d mismatch\n", i); }
+    }
+    if (!same(fr_one(), frh::one())) { fails++; printf("one mismatch\n"); }
+    printf(fails ? "FAIL %d\n" : "OK\n", fails);
+    return fails ? 1 : 0;
+}

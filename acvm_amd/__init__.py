@@ -21,7 +21,7 @@ STATUS_SOLVED, STATUS_IN_PROGRESS, STATUS_FAILURE, STATUS_REQUIRES_FOREIGN_CALL 
 # every symbol include/acvm_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "acvm_last_error", "acvm_abi_version", "acvm_device_count", "acvm_set_device", "acvm_device_synchronize",
-    "acvm_device_arch", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
+    "acvm_device_arch", "acvm_selftest", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
     "acvm_circuit_num_witnesses", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
     "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_reset", "acvm_batch_set_force_slow_path",
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
@@ -48,7 +48,8 @@ class Stats(C.Structure):
                 ("n_kernel_launches", C.c_uint32), ("n_slow_instances", C.c_uint32),
                 ("algorithmic_bytes_per_instance", C.c_uint64), ("arith_algorithmic_bytes_per_instance", C.c_uint64),
                 ("plan_ms", C.c_double), ("solve_device_ms", C.c_double), ("arith_kernel_ms", C.c_double),
-                ("slow_path_ms", C.c_double)]
+                ("slow_path_ms", C.c_double), ("dyn_kernel_ms", C.c_double),
+                ("dyn_algorithmic_bytes_per_instance", C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -67,6 +68,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.acvm_last_error.restype = C.c_char_p
     L.acvm_device_arch.argtypes = [C.c_char_p, C.c_size_t]
+    L.acvm_selftest.argtypes = [C.c_uint32, C.c_uint64]
     L.acvm_circuit_from_bytes.restype = C.c_void_p
     L.acvm_circuit_from_bytes.argtypes = [C.c_char_p, C.c_size_t]
     L.acvm_circuit_free.argtypes = [C.c_void_p]
@@ -107,6 +109,10 @@ def set_device(i):
 
 def synchronize():
     _check(lib().acvm_device_synchronize())
+
+
+def selftest(n=1 << 16, seed=1):
+    return _check(lib().acvm_selftest(n, seed))
 
 
 def device_arch():

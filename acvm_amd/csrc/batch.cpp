@@ -51,7 +51,10 @@ struct acvm_batch {
     bool inputs_set = false, solved = false, force_slow = false, profiling = false;
     hipEvent_t ev_start = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
-    double solve_device_ms = 0, arith_kernel_ms = 0, slow_path_ms = 0;
+    double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
+    hipStream_t stream_dyn = nullptr;
+    std::vector<hipEvent_t> ev_sync;
+    uint4 *d_dyn_scratch = nullptr;
     uint32_t n_launches = 0;
 
     ~acvm_batch() {
@@ -62,6 +65,9 @@ struct acvm_batch {
                         (void *)d_assigned, (void *)d_slow_res})
             if (p) hipFree(p);
         for (auto e : ev_pool) hipEventDestroy(e);
+        for (auto e : ev_sync) hipEventDestroy(e);
+        if (d_dyn_scratch) hipFree(d_dyn_scratch);
+        if (stream_dyn) hipStreamDestroy(stream_dyn);
         if (ev_start) hipEventDestroy(ev_start);
         if (ev_end) hipEventDestroy(ev_end);
         if (stream) hipStreamDestroy(stream);
@@ -103,6 +109,18 @@ int acvm_device_arch(char *out, size_t out_len) {
     return 0;
 }
 
+int acvm_selftest(uint32_t n, uint64_t seed) {
+    uint32_t *d = nullptr, h = 0;
+    HIPCHK(hipMalloc((void **)&d, 4));
+    HIPCHK(hipMemset(d, 0, 4));
+    launch_fr_selftest(nullptr, seed, n, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return (int)h;
+}
+
 acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) {
     if (!bytes) { set_err(ACVM_E_INVALID, "null circuit bytes"); return nullptr; }
     if (!frh::self_check()) { set_err(ACVM_E_INVALID, "field constants self-check failed"); return nullptr; }
@@ -124,6 +142,7 @@ static int batch_init(acvm_batch *b) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_err(ACVM_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&b->stream_dyn, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&b->ev_start));
     HIPCHK(hipEventCreate(&b->ev_end));
     const Plan &p = b->plan;
@@ -140,6 +159,12 @@ static int batch_init(acvm_batch *b) {
     b->n_words = (p.n_witnesses + 31) / 32;
     if (int rc = upload(&b->d_producer, p.producer)) return rc;
     if (int rc = upload(&b->d_dyn_offset, p.dyn_offset)) return rc;
+    {   // prefix-product scratch of the batched inversions: [max dyn gates per level][2 halves][Bp] x 16 B
+        uint32_t max_dyn = 0;
+        for (size_t l = 0; l + 1 < p.dyn_level_start.size(); l++) max_dyn = std::max(max_dyn, p.dyn_level_start[l + 1] - p.dyn_level_start[l]);
+        size_t bytes = (size_t)max_dyn * 2 * b->Bp * sizeof(uint4);
+        HIPCHK(hipMalloc((void **)&b->d_dyn_scratch, bytes ? bytes : 16));
+    }
     HIPCHK(hipMalloc((void **)&b->d_event, (size_t)(b->B ? b->B : 1) * 4));
     b->h_event.assign(b->B, 0xFFFFFFFFu);
     b->slow_index.assign(b->B, -1);
@@ -228,8 +253,10 @@ int acvm_batch_solve(acvm_batch_t *b) {
     HIPCHK(hipSetDevice(b->device));
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
+    hipStream_t s2 = b->stream_dyn;
     b->n_launches = 0;
     b->arith_kernel_ms = 0;
+    b->dyn_kernel_ms = 0;
     b->slow_path_ms = 0;
     size_t ev_used = 0;
     auto next_event = [&]() -> hipEvent_t {
@@ -240,28 +267,53 @@ int acvm_batch_solve(acvm_batch_t *b) {
         }
         return b->ev_pool[ev_used++];
     };
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> reg_pairs, dyn_pairs;
     HIPCHK(hipEventRecord(b->ev_start, s));
     if (b->force_slow) {
         launch_fill_u32(s, b->d_event, 0u, b->B);
     } else {
         launch_fill_u32(s, b->d_event, 0xFFFFFFFFu, b->B);
-        for (size_t L = 0; L + 1 < p.level_start.size(); L++) {
+        // Per level the constant-coefficient gates (stream s, HBM-bound) and the gates that need a per-instance
+        // inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of either
+        // stream waits for level L of both.
+        const size_t n_levels = p.level_start.empty() ? 0 : p.level_start.size() - 1;
+        while (b->ev_sync.size() < 2 * n_levels + 1) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            b->ev_sync.push_back(e);
+        }
+        bool any_dyn = !p.dyn_offset.empty();
+        if (any_dyn) {
+            HIPCHK(hipEventRecord(b->ev_sync[2 * n_levels], s));
+            HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
+        }
+        hipEvent_t last_reg = nullptr, last_dyn = nullptr;
+        for (size_t L = 0; L < n_levels; L++) {
             uint32_t n = p.level_start[L + 1] - p.level_start[L];
             uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
+            hipEvent_t prev_reg = last_reg, prev_dyn = last_dyn;
             if (n) {
-                if (b->profiling) hipEventRecord(next_event(), s);
+                if (prev_dyn) HIPCHK(hipStreamWaitEvent(s, prev_dyn, 0));
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }
                 launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event);
-                if (b->profiling) hipEventRecord(next_event(), s);
+                if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); reg_pairs.push_back({e0, e1}); }
                 b->n_launches += (n + 65534) / 65535;
+                if (any_dyn) { HIPCHK(hipEventRecord(b->ev_sync[2 * L], s)); last_reg = b->ev_sync[2 * L]; }
             }
             if (nd) {
-                if (b->profiling) hipEventRecord(next_event(), s);
-                launch_arith_dyn_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_consts,
-                                       b->d_event);
-                if (b->profiling) hipEventRecord(next_event(), s);
+                if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s2); }
+                launch_arith_dyn_level(s2, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_consts,
+                                       b->d_event, b->d_dyn_scratch);
+                if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s2); dyn_pairs.push_back({e0, e1}); }
                 b->n_launches++;
+                HIPCHK(hipEventRecord(b->ev_sync[2 * L + 1], s2));
+                last_dyn = b->ev_sync[2 * L + 1];
             }
         }
+        if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
         if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
     }
     HIPCHK(hipGetLastError());
@@ -299,13 +351,15 @@ int acvm_batch_solve(acvm_batch_t *b) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, b->ev_start, b->ev_end));
     b->solve_device_ms = ms;
-    if (b->profiling && !b->force_slow) {
-        size_t n_pairs = (n_slow ? ev_used - 2 : ev_used) / 2;
-        for (size_t i = 0; i < n_pairs; i++) {
-            float t = 0;
-            hipEventElapsedTime(&t, b->ev_pool[2 * i], b->ev_pool[2 * i + 1]);
-            b->arith_kernel_ms += t;
-        }
+    for (auto &pr : reg_pairs) {
+        float t = 0;
+        hipEventElapsedTime(&t, pr.first, pr.second);
+        b->arith_kernel_ms += t;
+    }
+    for (auto &pr : dyn_pairs) {
+        float t = 0;
+        hipEventElapsedTime(&t, pr.first, pr.second);
+        b->dyn_kernel_ms += t;
     }
     if (n_slow) {
         float t = 0;
@@ -442,6 +496,8 @@ int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     out->plan_ms = p.plan_ms;
     out->solve_device_ms = b->solve_device_ms;
     out->arith_kernel_ms = b->arith_kernel_ms;
+    out->dyn_kernel_ms = b->dyn_kernel_ms;
+    out->dyn_algorithmic_bytes_per_instance = p.dyn_algorithmic_bytes;
     out->slow_path_ms = b->slow_path_ms;
     return 0;
 }

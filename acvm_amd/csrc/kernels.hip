@@ -116,16 +116,17 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
 
 // gates whose unknown is multiplied by a known witness (arithmetic.rs:68-91): out = acc' / partner needs a
 // per-instance inversion. One wave = 64 instances x up to DYN_CHUNK independent gates of one level; the
-// inversions of a lane are batched with Montgomery's trick (prefix products staged in LDS), so a lane pays one
-// field inversion per chunk plus 4 multiplications per gate.
-static constexpr int DYN_CHUNK = 16;
+// inversions of a lane are batched with Montgomery's trick, so a lane pays one field inversion per chunk plus
+// 4 multiplications per gate. The prefix products are parked in a device scratch table laid out like W
+// ([gate in level][half][instance], 16 B per lane, coalesced); it stays L2/Infinity-Cache resident (<= 80 MB)
+// and, unlike an LDS stage, does not cap the number of resident waves of this latency-bound kernel.
+static constexpr int DYN_CHUNK = 8;
 __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
                                                              const uint32_t *__restrict__ gate_stream,
                                                              const uint32_t *__restrict__ dyn_offset, uint32_t n_dyn,
-                                                             const uint32_t *__restrict__ consts, uint32_t *__restrict__ event) {
-    __shared__ uint4 prefix_lds[DYN_CHUNK * 2 * 64];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
+                                                             const uint32_t *__restrict__ consts, uint32_t *__restrict__ event,
+                                                             uint4 *__restrict__ scratch) {
+    const uint64_t j = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= B) return;
     const uint32_t first = blockIdx.y * DYN_CHUNK;
     const uint32_t n = n_dyn - first < (uint32_t)DYN_CHUNK ? n_dyn - first : (uint32_t)DYN_CHUNK;
@@ -138,8 +139,7 @@ __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__
             den = fr_one();
         }
         prefix = fr_mul(prefix, den);
-        prefix_lds[(i * 2) * 64 + lane] = make_uint4(prefix.v[0], prefix.v[1], prefix.v[2], prefix.v[3]);
-        prefix_lds[(i * 2 + 1) * 64 + lane] = make_uint4(prefix.v[4], prefix.v[5], prefix.v[6], prefix.v[7]);
+        fr_store(scratch, first + i, Bp, j, prefix);
     }
     Fr inv = fr_inv(prefix);  // 1 / (den_0 ... den_{n-1})
     for (uint32_t i = n; i-- > 0;) {
@@ -150,9 +150,7 @@ __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__
         if (fr_is_zero(den)) den = fr_one();
         Fr inv_i = inv;
         if (i > 0) {
-            const uint4 lo = prefix_lds[((i - 1) * 2) * 64 + lane], hi = prefix_lds[((i - 1) * 2 + 1) * 64 + lane];
-            Fr pm = {{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
-            inv_i = fr_mul(inv, pm);
+            inv_i = fr_mul(inv, fr_load(scratch, first + i - 1, Bp, j));
         }
         inv = fr_mul(inv, den);
         Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
@@ -231,6 +229,41 @@ __global__ void __launch_bounds__(64) arith_inorder_kernel(uint4 *__restrict__ W
     results[t] = res;
 }
 
+// ------------------------------------------------------------------------------------------ self test
+// Cross-checks the hand-scheduled field routines against the portable ones on pseudo-random operands:
+// asm fr_mul == portable CIOS, a * inv(a) == 1, (a + b) - b == a, a + (-a) == 0. Counts mismatching lanes.
+__device__ __forceinline__ uint64_t st_mix(uint64_t &s) {
+    s += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) fr_selftest_kernel(uint64_t seed, uint32_t n, uint32_t *mismatches) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + 0x1234567ULL * i;
+    Fr a, b;
+    for (int k = 0; k < 4; k++) {
+        uint64_t x = st_mix(s), y = st_mix(s);
+        a.v[2 * k] = (uint32_t)x; a.v[2 * k + 1] = (uint32_t)(x >> 32);
+        b.v[2 * k] = (uint32_t)y; b.v[2 * k + 1] = (uint32_t)(y >> 32);
+    }
+    a.v[7] &= 0x1fffffffu;  // < 2^253 < p
+    b.v[7] &= 0x1fffffffu;
+    if (i == 0) a = fr_zero();
+    if (i == 1) { a = fr_modulus(); a.v[0] -= 1; }  // p - 1
+    if (i == 2) b = fr_one();
+    uint32_t bad = 0;
+    if (!fr_eq(fr_mul(a, b), fr_mul_portable(a, b))) bad |= 1;
+    if (!fr_eq(fr_mul(a, a), fr_mul_portable(a, a))) bad |= 2;
+    Fr ia = fr_inv(a);
+    if (fr_is_zero(a) ? !fr_is_zero(ia) : !fr_eq(fr_mul(a, ia), fr_one())) bad |= 4;
+    if (!fr_eq(fr_sub(fr_add(a, b), b), a)) bad |= 8;
+    if (!fr_is_zero(fr_add(a, fr_neg(a)))) bad |= 16;
+    if (bad) atomicAdd(mismatches, 1u);
+}
+
 // ------------------------------------------------------------------------------------------ helpers
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,10 +312,10 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
     }
 }
 void launch_arith_dyn_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *dyn_offset,
-                            uint32_t n_dyn, const uint32_t *consts, uint32_t *event) {
+                            uint32_t n_dyn, const uint32_t *consts, uint32_t *event, uint4 *scratch) {
     if (!n_dyn || !B) return;
     hipLaunchKernelGGL(arith_dyn_level_kernel, dim3((B + 63) / 64, (n_dyn + DYN_CHUNK - 1) / DYN_CHUNK), dim3(64), 0, s, W, Bp, B,
-                       gate_stream, dyn_offset, n_dyn, consts, event);
+                       gate_stream, dyn_offset, n_dyn, consts, event, scratch);
 }
 void launch_arith_inorder(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const uint32_t *stream,
                           const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned,
@@ -290,6 +323,10 @@ void launch_arith_inorder(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *
     if (!n_slow) return;
     hipLaunchKernelGGL(arith_inorder_kernel, dim3((n_slow + 63) / 64), dim3(64), 0, s, W, Bp, slow_ids, n_slow, stream, offset, n_opcodes,
                        consts, assigned, start_opcode, results);
+}
+void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches) {
+    if (!n) return;
+    hipLaunchKernelGGL(fr_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, n, mismatches);
 }
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n) {
     if (!n) return;

@@ -169,7 +169,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
         uint64_t bytes = 32ull * (reads.size() + (kind == GATE_ASSERT ? 0 : 1));
         p.algorithmic_bytes += bytes;
-        p.arith_algorithmic_bytes += bytes;
+        (kind == GATE_SOLVE_DYN ? p.dyn_algorithmic_bytes : p.arith_algorithmic_bytes) += bytes;
         if (kind != GATE_ASSERT) {
             known[unk_w] = 1;
             level[unk_w] = g.level;

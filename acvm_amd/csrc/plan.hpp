@@ -46,7 +46,7 @@ struct Plan {
     uint32_t truncated_at = 0xFFFFFFFFu;
     // statistics
     uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0;
-    uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0;
+    uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
     double plan_ms = 0;
     // in-order program for the exact kernel: per opcode offset into `slow_stream`
     std::vector<uint32_t> slow_stream;

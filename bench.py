@@ -80,12 +80,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     arith_ms = 0.0
+    dyn_ms = 0.0
     dev_ms = 0.0
     for _ in range(args.steps):
         batch.reset()
         batch.solve()
         st = batch.stats()
         arith_ms += st["arith_kernel_ms"]
+        dyn_ms += st["dyn_kernel_ms"]
         dev_ms += st["solve_device_ms"]
     acvm_amd.synchronize()
     elapsed = time.perf_counter() - t0
@@ -148,7 +150,9 @@ def main():
                        "device_ms_per_step": dev_ms / args.steps, "parallelism": f"instances sharded x{world}, no collectives"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "arith_level_kernel",
-                         "launches_per_step": st["n_kernel_launches"], "kernel_ms_per_step": arith_ms / args.steps},
+                         "launches_per_step": st["n_kernel_launches"], "kernel_ms_per_step": arith_ms / args.steps,
+                         "other_kernels": {"arith_dyn_level_kernel_ms_per_step": dyn_ms / args.steps,
+                                           "note": "batched-inversion gates, overlapped on a second stream"}},
             "cpu_baseline": cpu,
             "parity": parity,
         }

@@ -96,11 +96,13 @@ typedef struct {
     uint32_t n_opcodes, n_witnesses, n_levels, n_fast_gates, n_dyn_gates;
     uint32_t max_level_width, n_kernel_launches, n_slow_instances;
     uint64_t algorithmic_bytes_per_instance; /* sum over gates of 32 B x (distinct known operands + written witness) */
-    uint64_t arith_algorithmic_bytes_per_instance; /* the part moved by the arithmetic level kernels */
+    uint64_t arith_algorithmic_bytes_per_instance; /* the part moved by arith_level_kernel */
     double plan_ms;         /* one-time levelisation, host */
     double solve_device_ms; /* HIP events around the whole last solve, on the batch's stream */
     double arith_kernel_ms; /* sum of HIP-event durations of the arithmetic level kernels of the last solve */
     double slow_path_ms;
+    double dyn_kernel_ms;   /* same for the batched-inversion level kernels (they overlap the former on a 2nd stream) */
+    uint64_t dyn_algorithmic_bytes_per_instance;
 } acvm_stats_t;
 
 const char *acvm_last_error(void);
@@ -110,6 +112,10 @@ int acvm_set_device(int device);
 int acvm_device_synchronize(void);
 /* name of the current device's gcnArch ("gfx950...") into out */
 int acvm_device_arch(char *out, size_t out_len);
+
+/* Device self test of the field library: n pseudo-random operand pairs; returns the number of lanes whose
+ * hand-scheduled routines disagree with the portable ones (0 = pass), or a negative error. */
+int acvm_selftest(uint32_t n, uint64_t seed);
 
 /* Circuit::read: gzip(bincode) or raw bincode bytes. */
 acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);

@@ -104,3 +104,9 @@ def test_empty_and_ragged(oracle):
         values = synth.witness_batch(B, seed=5, edge_cases=False)
         o, g, _ = _run_both(oracle, circ, ids, values, B)
         _assert_parity(o, g, B)
+
+
+def test_device_field_selftest():
+    """hand-scheduled gfx950 field routines against the portable ones on 2^18 random operand pairs"""
+    import acvm_amd
+    assert acvm_amd.selftest(1 << 18, 7) == 0

@@ -75,6 +75,14 @@ def lib():
         L.oracle_fr_fetch_nearest_bytes.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p]
         for f in ("oracle_sha256", "oracle_keccak256", "oracle_blake2s"):
             getattr(L, f).argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.oracle_grumpkin_generator.argtypes = [C.c_uint32, C.c_char_p]
+        L.oracle_grumpkin_mul_g.argtypes = [C.c_char_p, C.c_char_p]
+        L.oracle_pedersen_compress.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p]
+        L.oracle_pedersen_hash_single.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        L.oracle_pedersen.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p]
+        L.oracle_fixed_base.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.oracle_schnorr_verify.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.oracle_schnorr_sign.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p]
         assert L.oracle_result_size() == C.sizeof(Result)
         _lib = L
     return _lib

@@ -1,0 +1,161 @@
+// ops_common.hpp -- device-side scaffolding shared by every non-arithmetic opcode kernel and by the exact
+// in-order kernel: record kinds, the two execution policies, expression evaluation (pwg/mod.rs:321-372 get_value,
+// arithmetic.rs:212-239 evaluate) and canonical-integer helpers.
+//
+// Every opcode's device routine is written once, templated on a Policy:
+//   FastPolicy  -- the generic instance of plan.cpp: every witness the planner saw as assigned is assigned; an output
+//                  the planner saw as already assigned is compared, never overwritten (insert_value conflict,
+//                  pwg/mod.rs:338-357); any error only flags the instance (event word) for the exact kernel.
+//   ExactPolicy -- per-instance assigned bitmap, exact error kind / aux values.
+#pragma once
+#include "fr_device.hpp"
+
+namespace acvm {
+
+static constexpr uint32_t K_COEF_ONE = 0xFFFFFFFFu;
+static constexpr uint32_t K_COEF_MINUS_ONE = 0xFFFFFFFEu;
+static constexpr uint32_t K_COEF_ZERO = 0xFFFFFFFDu;
+static constexpr uint32_t K_NONE = 0xFFFFFFFFu;
+
+// record kinds of the in-order program (w0 of each record; w1 = unused for ARITH, see plan.cpp)
+enum RecKind : uint32_t {
+    K_ARITH = 0, K_RANGE = 1, K_LOGIC = 2, K_HASH = 3, K_PEDERSEN = 4, K_FIXED_BASE = 5, K_SCHNORR = 6, K_ZERO_OUT = 7,
+    K_QUOTIENT = 8, K_TO_LE_RADIX = 9, K_MEM_INIT = 10, K_MEM_OP = 11, K_BRILLIG = 12
+};
+
+// error codes = ACVM_ERR_* of include/acvm_amd.h
+enum DevErr : uint32_t {
+    DE_NONE = 0, DE_MISSING_ASSIGNMENT = 1, DE_TOO_MANY_UNKNOWNS = 2, DE_UNSUPPORTED_BLACKBOX = 3, DE_UNSATISFIED = 4,
+    DE_INDEX_OOB = 5, DE_BLACKBOX_FAILED = 6, DE_BRILLIG_FAILED = 7, DE_PANIC = 8
+};
+// sub-codes carried in aux1 for errors whose message text is rebuilt on the host
+enum DevMsg : uint32_t {
+    DM_NONE = 0, DM_TWO_MUL_TERMS = 1, DM_LOGIC_BITS = 2, DM_FETCH_BYTES = 3, DM_HASH_OUTPUTS = 4, DM_KECCAK_VAR_LEN = 5,
+    DM_MEM_INDEX_U64 = 6, DM_MEM_READ_EXPR = 7, DM_RADIX = 8, DM_LIMB_LOW = 9, DM_LIMB_HIGH = 10, DM_SCALAR = 11,
+    DM_SCHNORR_SIG_LEN = 12, DM_SCHNORR_MSG_LEN = 13
+};
+
+struct OpResult {
+    uint32_t err, aux0, aux1;
+};
+__device__ __forceinline__ OpResult op_ok() { return OpResult{DE_NONE, 0u, 0u}; }
+__device__ __forceinline__ OpResult op_fail(uint32_t e, uint32_t a0 = 0, uint32_t a1 = 0) { return OpResult{e, a0, a1}; }
+
+__device__ __forceinline__ Fr apply_coef(const Fr &x, uint32_t coef, const uint32_t *__restrict__ consts) {
+    if (coef == K_COEF_ONE) return x;
+    if (coef == K_COEF_MINUS_ONE) return fr_neg(x);
+    return fr_mul(x, fr_const(consts, coef));
+}
+__device__ __forceinline__ Fr coef_value(uint32_t coef, const uint32_t *__restrict__ consts) {
+    if (coef == K_COEF_ONE) return fr_one();
+    if (coef == K_COEF_MINUS_ONE) return fr_neg(fr_one());
+    if (coef == K_COEF_ZERO) return fr_zero();
+    return fr_const(consts, coef);
+}
+// R^2 mod p: to_montgomery(x) = mont_mul(x, R2)
+__device__ __forceinline__ Fr fr_r2() {
+    Fr r = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
+    return r;
+}
+// Montgomery <-> canonical little-endian 8x32 integers
+__device__ __forceinline__ Fr fr_to_canonical(const Fr &a) {
+    Fr one = fr_zero();
+    one.v[0] = 1;
+    return fr_mul(a, one);
+}
+__device__ __forceinline__ Fr fr_from_canonical(const Fr &c) { return fr_mul(c, fr_r2()); }  // c < p
+__device__ __forceinline__ Fr fr_from_u32(uint32_t x) {
+    Fr c = fr_zero();
+    c.v[0] = x;
+    return fr_from_canonical(c);
+}
+// num_bits of a canonical integer (generic_ark.rs:214-221)
+__device__ __forceinline__ uint32_t canon_num_bits(const Fr &c) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (c.v[i]) n = 32u * i + (32u - __clz(c.v[i]));
+    return n;
+}
+// reduce an arbitrary 256-bit integer below p (2^256 / p < 6)
+__device__ __forceinline__ Fr canon_reduce(Fr x) {
+    for (int it = 0; it < 5; it++) {
+        Fr d;
+        if (!fr_sub256(d, x, fr_modulus())) x = d;
+    }
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------ policies
+struct FastPolicy {
+    uint4 *W;
+    uint64_t Bp, j;
+    static constexpr bool exact = false;
+    __device__ __forceinline__ bool known(uint32_t) const { return true; }
+    __device__ __forceinline__ Fr load(uint32_t w) const { return fr_load(W, w, Bp, j); }
+    // insert_value (pwg/mod.rs:338-357). `was_assigned` is the planner's static knowledge. Returns false on conflict.
+    __device__ __forceinline__ bool insert(uint32_t w, const Fr &v, uint32_t was_assigned) const {
+        if (was_assigned) return fr_eq(fr_load(W, w, Bp, j), v);  // never overwrite: the exact kernel needs the old value
+        fr_store(W, w, Bp, j, v);
+        return true;
+    }
+};
+struct ExactPolicy {
+    uint4 *W;
+    uint64_t Bp, j;
+    uint32_t *assigned;
+    uint32_t n_slow, t;
+    static constexpr bool exact = true;
+    __device__ __forceinline__ bool known(uint32_t w) const { return (assigned[(uint64_t)(w >> 5) * n_slow + t] >> (w & 31)) & 1u; }
+    __device__ __forceinline__ Fr load(uint32_t w) const { return fr_load(W, w, Bp, j); }
+    __device__ __forceinline__ bool insert(uint32_t w, const Fr &v, uint32_t) const {
+        const bool had = known(w);
+        Fr old = fr_zero();
+        if (had) old = fr_load(W, w, Bp, j);
+        fr_store(W, w, Bp, j, v);  // the map holds the new value even on conflict
+        assigned[(uint64_t)(w >> 5) * n_slow + t] |= 1u << (w & 31);
+        return !had || fr_eq(old, v);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ expressions
+// Expression record: [n_mul, n_lin, qc, (coef, l, r) x n_mul, (coef, -1/coef, w) x n_lin]. Returns the record length.
+__device__ __forceinline__ uint32_t expr_len(const uint32_t *e) { return 3u + 3u * e[0] + 3u * e[1]; }
+
+// get_value (pwg/mod.rs:321-332): the expression must evaluate to a constant, else MissingAssignment(w) with w chosen
+// like any_witness_from_expression (:362-372) on the partially evaluated expression.
+template <class P>
+__device__ __forceinline__ OpResult expr_value(const P &p, const uint32_t *__restrict__ e, const uint32_t *__restrict__ consts, Fr &out) {
+    const uint32_t n_mul = e[0], n_lin = e[1], qc = e[2];
+    Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
+    uint32_t first_lin = K_NONE, first_mul = K_NONE;
+    const uint32_t *t = e + 3;
+    for (uint32_t i = 0; i < n_mul; i++, t += 3) {
+        const uint32_t coef = t[0], l = t[1], r = t[2];
+        const bool kl = p.known(l), kr = p.known(r);
+        if (kl && kr) {
+            if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(fr_mul(p.load(l), p.load(r)), coef, consts));
+        } else if (P::exact) {
+            if (!kl && !kr) {
+                if (coef != K_COEF_ZERO && first_mul == K_NONE) first_mul = l;
+            } else if (coef != K_COEF_ZERO) {
+                Fr v = apply_coef(p.load(kl ? l : r), coef, consts);
+                if (!fr_is_zero(v) && first_lin == K_NONE) first_lin = kl ? r : l;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n_lin; i++, t += 3) {
+        const uint32_t coef = t[0], w = t[2];
+        if (p.known(w)) {
+            if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(p.load(w), coef, consts));
+        } else if (coef != K_COEF_ZERO && first_lin == K_NONE) first_lin = w;
+    }
+    out = acc;
+    if (P::exact) {
+        if (first_lin != K_NONE) return op_fail(DE_MISSING_ASSIGNMENT, first_lin);
+        if (first_mul != K_NONE) return op_fail(DE_MISSING_ASSIGNMENT, first_mul);
+    }
+    return op_ok();
+}
+
+}  // namespace acvm

@@ -1,0 +1,294 @@
+// ops_light.hpp -- device routines of the cheap non-arithmetic opcodes, written once for both policies:
+//   RANGE                  acvm/src/pwg/blackbox/range.rs:7-18
+//   AND / XOR              acvm/src/pwg/blackbox/logic.rs:11-56, acir_field/src/generic_ark.rs:328-355,446-473
+//   RecursiveAggregation   acvm/src/pwg/blackbox/mod.rs:154-161 (outputs := 0)
+//   Directive::Quotient    acvm/src/pwg/directives/mod.rs:28-59
+//   Directive::ToLeRadix   acvm/src/pwg/directives/mod.rs:60-87
+//   MemoryInit / MemoryOp  acvm/src/pwg/memory_op.rs:16-124
+// Record layouts are produced by plan.cpp (emit_* functions) and documented there.
+#pragma once
+#include "ops_common.hpp"
+
+namespace acvm {
+
+// black-box pre-check (blackbox/mod.rs:55-62): first unassigned input in get_inputs_vec order
+template <class P>
+__device__ __forceinline__ OpResult bb_inputs_assigned(const P &p, const uint32_t *ws, uint32_t n, uint32_t stride) {
+    if (P::exact)
+        for (uint32_t i = 0; i < n; i++)
+            if (!p.known(ws[i * stride])) return op_fail(DE_MISSING_ASSIGNMENT, ws[i * stride]);
+    return op_ok();
+}
+
+// [K_RANGE, opcode, w, num_bits]
+template <class P>
+__device__ __forceinline__ OpResult op_range(const P &p, const uint32_t *__restrict__ r) {
+    OpResult pre = bb_inputs_assigned(p, r + 2, 1, 1);
+    if (pre.err) return pre;
+    if (canon_num_bits(fr_to_canonical(p.load(r[2]))) > r[3]) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+// mask_vector_le (generic_ark.rs:446-473) on a canonical integer: keep the low num_bits bits
+__device__ __forceinline__ Fr canon_mask(const Fr &c, uint32_t num_bits) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t lo = 32u * i;
+        r.v[i] = num_bits <= lo ? 0u : (num_bits >= lo + 32u ? c.v[i] : (c.v[i] & ((1u << (num_bits - lo)) - 1u)));
+    }
+    return r;
+}
+
+// [K_LOGIC, opcode, is_xor, lhs, rhs, bits_l, bits_r, out, out_flag]
+template <class P>
+__device__ __forceinline__ OpResult op_logic(const P &p, const uint32_t *__restrict__ r) {
+    if (P::exact) {
+        if (!p.known(r[3])) return op_fail(DE_MISSING_ASSIGNMENT, r[3]);
+        if (!p.known(r[4])) return op_fail(DE_MISSING_ASSIGNMENT, r[4]);
+    }
+    if (r[5] != r[6]) return op_fail(DE_PANIC, 0, DM_LOGIC_BITS);  // logic.rs:17-20 assert_eq!
+    const Fr a = canon_mask(fr_to_canonical(p.load(r[3])), r[5]);
+    const Fr b = canon_mask(fr_to_canonical(p.load(r[4])), r[5]);
+    Fr c;
+#pragma unroll
+    for (int i = 0; i < 8; i++) c.v[i] = r[2] ? (a.v[i] ^ b.v[i]) : (a.v[i] & b.v[i]);
+    // from_be_bytes_reduce: only matters when num_bits >= 254
+    if (!p.insert(r[7], fr_from_canonical(canon_reduce(c)), r[8])) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+// [K_ZERO_OUT, opcode, n_in, n_out, in ws..., (out, flag)...]
+template <class P>
+__device__ __forceinline__ OpResult op_zero_out(const P &p, const uint32_t *__restrict__ r) {
+    OpResult pre = bb_inputs_assigned(p, r + 4, r[2], 1);
+    if (pre.err) return pre;
+    const uint32_t *o = r + 4 + r[2];
+    for (uint32_t i = 0; i < r[3]; i++)
+        if (!p.insert(o[2 * i], fr_zero(), o[2 * i + 1])) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+// 256-bit unsigned division of canonical integers (num-bigint semantics); b != 0
+__device__ __noinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr &rem) {
+    q = fr_zero();
+    rem = fr_zero();
+    for (int i = 255; i >= 0; i--) {
+#pragma unroll
+        for (int k = 7; k > 0; k--) rem.v[k] = rem.v[k] << 1 | rem.v[k - 1] >> 31;
+        rem.v[0] = rem.v[0] << 1 | ((a.v[i >> 5] >> (i & 31)) & 1u);
+        Fr d;
+        const uint32_t borrow = fr_sub256(d, rem, b);
+        if (!borrow) {
+            rem = d;
+            uint32_t bit = 1u << (i & 31);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k == (i >> 5)) q.v[k] |= bit;
+        }
+    }
+}
+
+// [K_QUOTIENT, opcode, q, fq, r, fr, has_pred, E(a), E(b), E(pred)?]
+template <class P>
+__device__ __forceinline__ OpResult op_quotient(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts) {
+    const uint32_t *ea = r + 7, *eb = ea + expr_len(ea), *ep = eb + expr_len(eb);
+    Fr va, vb, pred = fr_one();
+    OpResult e = expr_value(p, ea, consts, va);
+    if (e.err) return e;
+    e = expr_value(p, eb, consts, vb);
+    if (e.err) return e;
+    if (r[6]) {
+        e = expr_value(p, ep, consts, pred);
+        if (e.err) return e;
+    }
+    Fr q = fr_zero(), rem = fr_zero();
+    if (!fr_is_zero(pred) && !fr_is_zero(vb)) canon_divrem(fr_to_canonical(va), fr_to_canonical(vb), q, rem);
+    if (!p.insert(r[2], fr_from_canonical(q), r[3])) return op_fail(DE_UNSATISFIED);  // q, r <= a < p
+    if (!p.insert(r[4], fr_from_canonical(rem), r[5])) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+// [K_TO_LE_RADIX, opcode, radix, n_out, (out, flag) x n_out, E(a)]
+template <class P>
+__device__ __forceinline__ OpResult op_to_le_radix(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts) {
+    const uint32_t radix = r[2], n_out = r[3];
+    const uint32_t *outs = r + 4, *ea = outs + 2 * n_out;
+    Fr va;
+    OpResult e = expr_value(p, ea, consts, va);
+    if (e.err) return e;
+    if (radix < 2 || radix > 256) return op_fail(DE_PANIC, 0, DM_RADIX);  // num-bigint to_radix_le assert
+    Fr v = fr_to_canonical(va);
+    // BigUint::to_radix_le: little-endian digits, 0 -> [0]. Digits are produced one by one; more digits than
+    // outputs -> UnsatisfiedConstrain before anything is inserted (directives/mod.rs:67-71), so count first.
+    uint32_t nd;
+    const bool pow2 = (radix & (radix - 1)) == 0;
+    const uint32_t log2r = 31u - __clz(radix);
+    if (pow2) {
+        const uint32_t nb = canon_num_bits(v);
+        nd = nb == 0 ? 1u : (nb + log2r - 1) / log2r;
+    } else {
+        Fr t = v;
+        nd = 0;
+        do {
+            uint64_t rem = 0;
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                const uint64_t cur = rem << 32 | t.v[k];
+                t.v[k] = (uint32_t)(cur / radix);
+                rem = cur % radix;
+            }
+            nd++;
+        } while (!fr_is_zero(t));
+    }
+    if (n_out < nd) return op_fail(DE_UNSATISFIED);
+    Fr t = v;
+    for (uint32_t i = 0; i < n_out; i++) {
+        uint32_t digit = 0;
+        if (i < nd) {
+            if (pow2) {
+                const uint32_t pos = i * log2r;  // a digit never straddles more than two limbs (log2r <= 8)
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if ((uint32_t)k == (pos >> 5)) lo = v.v[k];
+                    if ((uint32_t)k == (pos >> 5) + 1) hi = v.v[k];
+                }
+                const uint64_t two = (uint64_t)hi << 32 | lo;
+                digit = (uint32_t)(two >> (pos & 31)) & (radix - 1);
+            } else {
+                uint64_t rem = 0;
+#pragma unroll
+                for (int k = 7; k >= 0; k--) {
+                    const uint64_t cur = rem << 32 | t.v[k];
+                    t.v[k] = (uint32_t)(cur / radix);
+                    rem = cur % radix;
+                }
+                digit = (uint32_t)rem;
+            }
+        }
+        if (!p.insert(outs[2 * i], fr_from_u32(digit), outs[2 * i + 1])) return op_fail(DE_UNSATISFIED);
+    }
+    return op_ok();
+}
+
+// ------------------------------------------------------------------------------------------------ memory
+// Per-instance memory blocks live in a table laid out like W: Mem[cell][half][instance].
+// [K_MEM_INIT, opcode, cell_base, len, ws...]   (memory_op.rs:47-60)
+template <class P>
+__device__ __forceinline__ OpResult op_mem_init(const P &p, const uint32_t *__restrict__ r, uint4 *Mem) {
+    const uint32_t base = r[2], len = r[3];
+    for (uint32_t i = 0; i < len; i++) {
+        const uint32_t w = r[4 + i];
+        if (P::exact && !p.known(w)) return op_fail(DE_MISSING_ASSIGNMENT, w);
+        fr_store(Mem, base + i, p.Bp, p.j, p.load(w));
+    }
+    return op_ok();
+}
+
+// partial evaluation summary of an expression (arithmetic.rs:212-239) for MemoryOp's value operand
+struct ExprPartial {
+    Fr constant, lin_coef;
+    uint32_t n_lin, n_mul, lin_w, first_w;
+};
+template <class P>
+__device__ __forceinline__ ExprPartial expr_partial(const P &p, const uint32_t *__restrict__ e, const uint32_t *__restrict__ consts) {
+    ExprPartial out;
+    const uint32_t n_mul = e[0], n_lin = e[1], qc = e[2];
+    out.constant = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
+    out.lin_coef = fr_zero();
+    out.n_lin = out.n_mul = 0;
+    out.lin_w = K_NONE;
+    uint32_t first_lin = K_NONE, first_mul = K_NONE;
+    const uint32_t *t = e + 3;
+    for (uint32_t i = 0; i < n_mul; i++, t += 3) {
+        const uint32_t coef = t[0], l = t[1], r = t[2];
+        const bool kl = p.known(l), kr = p.known(r);
+        if (kl && kr) {
+            if (coef != K_COEF_ZERO) out.constant = fr_add(out.constant, apply_coef(fr_mul(p.load(l), p.load(r)), coef, consts));
+        } else if (!kl && !kr) {
+            if (coef != K_COEF_ZERO) { out.n_mul++; if (first_mul == K_NONE) first_mul = l; }
+        } else if (coef != K_COEF_ZERO) {
+            Fr v = apply_coef(p.load(kl ? l : r), coef, consts);
+            if (!fr_is_zero(v)) {
+                out.n_lin++; out.lin_coef = v; out.lin_w = kl ? r : l;
+                if (first_lin == K_NONE) first_lin = out.lin_w;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n_lin; i++, t += 3) {
+        const uint32_t coef = t[0], w = t[2];
+        if (p.known(w)) {
+            if (coef != K_COEF_ZERO) out.constant = fr_add(out.constant, apply_coef(p.load(w), coef, consts));
+        } else if (coef != K_COEF_ZERO) {
+            out.n_lin++; out.lin_coef = coef_value(coef, consts); out.lin_w = w;
+            if (first_lin == K_NONE) first_lin = w;
+        }
+    }
+    out.first_w = first_lin != K_NONE ? first_lin : first_mul;
+    return out;
+}
+
+__device__ __forceinline__ bool canon_fits_u64(const Fr &c) { return (c.v[2] | c.v[3] | c.v[4] | c.v[5] | c.v[6] | c.v[7]) == 0; }
+
+// [K_MEM_OP, opcode, cell_base, block_len, readable_len, has_pred, mode, target_w, target_flag,
+//  E(operation), E(index), E(value), E(pred)?]   mode: 0 write, 1 read (planner: operation is a constant), 2 dynamic
+template <class P>
+__device__ __forceinline__ OpResult op_mem_op(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts, uint4 *Mem) {
+    const uint32_t base = r[2], block_len = r[3], readable_len = r[4], has_pred = r[5];
+    const uint32_t *e_op = r + 9, *e_idx = e_op + expr_len(e_op), *e_val = e_idx + expr_len(e_idx), *e_pred = e_val + expr_len(e_val);
+    Fr operation, index, pred = fr_one();
+    OpResult e = expr_value(p, e_op, consts, operation);
+    if (e.err) return e;
+    e = expr_value(p, e_idx, consts, index);
+    if (e.err) return e;
+    const Fr ci = fr_to_canonical(index);
+    if (!canon_fits_u64(ci)) return op_fail(DE_PANIC, 0, DM_MEM_INDEX_U64);  // try_to_u64().unwrap() (memory_op.rs:72)
+    const uint32_t mi = ci.v[0];                                              // `as MemoryIndex` wraps to u32
+    const bool is_read = fr_is_zero(operation);
+    if (P::exact) {
+        const ExprPartial v = expr_partial(p, e_val, consts);
+        if (has_pred) {
+            e = expr_value(p, e_pred, consts, pred);
+            if (e.err) return e;
+        }
+        if (is_read) {
+            // Expression::to_witness (expression/mod.rs:158-172)
+            if (!(v.n_mul == 0 && v.n_lin == 1 && fr_eq(v.lin_coef, fr_one()) && fr_is_zero(v.constant)))
+                return op_fail(DE_PANIC, 0, DM_MEM_READ_EXPR);
+            Fr val = fr_zero();
+            if (!fr_is_zero(pred)) {
+                if (mi >= readable_len) return op_fail(DE_INDEX_OOB, mi, block_len);  // key absent (memory_op.rs:37-44)
+                val = fr_load(Mem, base + mi, p.Bp, p.j);
+            }
+            if (!p.insert(v.lin_w, val, 0)) return op_fail(DE_UNSATISFIED);
+        } else if (!fr_is_zero(pred)) {
+            if (v.n_mul || v.n_lin) return op_fail(DE_MISSING_ASSIGNMENT, v.first_w);  // get_value(&value_write)
+            if (mi >= block_len) return op_fail(DE_INDEX_OOB, mi, block_len);
+            fr_store(Mem, base + mi, p.Bp, p.j, v.constant);
+        }
+        return op_ok();
+    }
+    // generic instance: the planner fixed read / write and the read target
+    if (has_pred) {
+        e = expr_value(p, e_pred, consts, pred);
+        if (e.err) return e;
+    }
+    if (r[6] == 1) {
+        Fr val = fr_zero();
+        if (!fr_is_zero(pred)) {
+            if (mi >= readable_len) return op_fail(DE_INDEX_OOB, mi, block_len);
+            val = fr_load(Mem, base + mi, p.Bp, p.j);
+        }
+        if (!p.insert(r[7], val, r[8])) return op_fail(DE_UNSATISFIED);
+    } else if (!fr_is_zero(pred)) {
+        Fr val;
+        e = expr_value(p, e_val, consts, val);
+        if (e.err) return e;
+        if (mi >= block_len) return op_fail(DE_INDEX_OOB, mi, block_len);
+        fr_store(Mem, base + mi, p.Bp, p.j, val);
+    }
+    return op_ok();
+}
+
+}  // namespace acvm

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <string>
 #include "../acvm_amd/csrc/fr_device.hpp"
 using namespace acvm;
 
@@ -70,10 +71,20 @@ static float time_ms(F f, int reps = 5) {
     return best;
 }
 
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     printf("device %s CUs %d clock %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
+    if (argc > 1 && std::string(argv[1]) == "copy") {  // PMC calibration: a known byte count, 16 B/lane coalesced
+        size_t bytes = 4ull << 30;
+        uint4 *a, *b;
+        CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes));
+        CHECK(hipMemset(a, 1, bytes));
+        for (int r = 0; r < 3; r++) copy_kernel<<<256 * 8, 256>>>(a, b, bytes / 16);
+        CHECK(hipDeviceSynchronize());
+        printf("copy_kernel: 3 launches, %zu bytes read + %zu bytes written each\n", bytes, bytes);
+        return 0;
+    }
     uint32_t *out;
     const int blocks = 256 * 8 * 4, iters = 2000;
     CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));

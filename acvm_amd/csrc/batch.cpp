@@ -29,16 +29,25 @@ struct acvm_circuit {
     std::unique_ptr<Circuit> c;
 };
 
+struct LaunchChunk { uint32_t first, count; };  // records [first, first+count) of a class's level-major list
+struct ExactSegment { uint32_t cls, begin, end; };  // opcodes [begin, end): one light span or one heavy opcode
+
 struct acvm_batch {
     Plan plan;
     uint32_t B = 0;
     uint64_t Bp = 0;  // instance stride, multiple of 64
     int device = 0;
     hipStream_t stream = nullptr;
-    uint4 *d_W = nullptr;
+    uint4 *d_W = nullptr, *d_Mem = nullptr;
     uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
-    uint32_t *d_slow_stream = nullptr, *d_slow_offset = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
+    uint32_t *d_prog = nullptr, *d_prog_offset = nullptr, *d_bytecode = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
     uint32_t *d_dyn_offset = nullptr, *d_slow_start = nullptr;
+    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::vector<LaunchChunk>> cls_chunks[N_CLS];  // per level
+    std::vector<ExactSegment> segments;
+    DeviceProgram dp{};
     uint32_t *d_event = nullptr;
     std::vector<uint32_t> h_event;
     // exact in-order path
@@ -52,6 +61,7 @@ struct acvm_batch {
     hipEvent_t ev_start = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
+    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr;
     std::vector<hipEvent_t> ev_sync;
     uint4 *d_dyn_scratch = nullptr;
@@ -59,11 +69,13 @@ struct acvm_batch {
 
     ~acvm_batch() {
         hipSetDevice(device);
-        for (void *p : {(void *)d_W, (void *)d_gate_stream, (void *)d_gate_offset, (void *)d_consts, (void *)d_slow_stream,
-                        (void *)d_slow_offset, (void *)d_init_ids, (void *)d_producer, (void *)d_dyn_offset, (void *)d_slow_start,
-                        (void *)d_event, (void *)d_slow_ids,
-                        (void *)d_assigned, (void *)d_slow_res})
+        for (void *p : {(void *)d_W, (void *)d_Mem, (void *)d_gate_stream, (void *)d_gate_offset, (void *)d_consts, (void *)d_prog,
+                        (void *)d_prog_offset, (void *)d_bytecode, (void *)d_init_ids, (void *)d_producer, (void *)d_dyn_offset,
+                        (void *)d_slow_start, (void *)d_event, (void *)d_slow_ids, (void *)d_assigned, (void *)d_slow_res})
             if (p) hipFree(p);
+        for (int k = 0; k < (int)N_CLS; k++)
+            for (void *p : {(void *)d_cls_offset[k], (void *)d_cls_scratch_off[k], (void *)d_cls_scratch[k]})
+                if (p) hipFree(p);
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
         if (d_dyn_scratch) hipFree(d_dyn_scratch);
@@ -153,9 +165,63 @@ static int batch_init(acvm_batch *b) {
     std::vector<uint32_t> consts(p.constants.size() * 8);
     for (size_t i = 0; i < p.constants.size(); i++) memcpy(&consts[8 * i], p.constants[i].l, 32);
     if (int rc = upload(&b->d_consts, consts)) return rc;
-    if (int rc = upload(&b->d_slow_stream, p.slow_stream)) return rc;
-    if (int rc = upload(&b->d_slow_offset, p.slow_offset)) return rc;
+    if (int rc = upload(&b->d_prog, p.prog)) return rc;
+    if (int rc = upload(&b->d_prog_offset, p.prog_offset)) return rc;
+    if (int rc = upload(&b->d_bytecode, p.bytecode)) return rc;
     if (int rc = upload(&b->d_init_ids, p.initial_ids)) return rc;
+    {   // per-instance memory blocks (MemoryInit / MemoryOp), laid out like W
+        size_t bytes = (size_t)p.mem_cells * 2 * b->Bp * sizeof(uint4);
+        HIPCHK(hipMalloc((void **)&b->d_Mem, bytes ? bytes : 16));
+    }
+    // non-arithmetic record classes: per level, launch chunks whose per-instance scratch fits the class's scratch buffer
+    const uint64_t scratch_cap_words = std::max<uint64_t>(1, (1ull << 30) / (b->Bp * 4));  // 1 GiB per class
+    for (int k = 0; k < (int)N_CLS; k++) {
+        const size_t n_levels = p.n_levels;
+        b->cls_chunks[k].assign(n_levels, {});
+        std::vector<uint32_t> scratch_off(p.cls_offset[k].size(), 0);
+        uint64_t need = 0;
+        for (size_t L = 0; L < n_levels; L++) {
+            uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
+            uint32_t first = lo;
+            uint64_t used = 0;
+            for (uint32_t r = lo; r < hi; r++) {
+                uint64_t w = p.cls_scratch[k][r];
+                if (r > first && used + w > scratch_cap_words) {
+                    b->cls_chunks[k][L].push_back({first, r - first});
+                    first = r;
+                    used = 0;
+                }
+                scratch_off[r] = (uint32_t)used;
+                used += w;
+                need = std::max(need, used);
+            }
+            if (hi > first) b->cls_chunks[k][L].push_back({first, hi - first});
+        }
+        // the exact kernels use slot 0 of the same buffer: it must hold the largest single record
+        for (uint32_t oi = 0; oi < p.n_opcodes; oi++)
+            if (p.prog_class[oi] == (uint32_t)k) need = std::max<uint64_t>(need, p.prog_scratch[oi]);
+        if (int rc = upload(&b->d_cls_offset[k], p.cls_offset[k])) return rc;
+        if (int rc = upload(&b->d_cls_scratch_off[k], scratch_off)) return rc;
+        if (need) HIPCHK(hipMalloc((void **)&b->d_cls_scratch[k], (size_t)need * b->Bp * 4));
+    }
+    // exact path: consecutive light opcodes form one span, every heavy opcode is its own launch
+    for (uint32_t oi = 0; oi < p.n_opcodes;) {
+        uint32_t cls = p.prog_class[oi], end = oi + 1;
+        if (cls == CLS_LIGHT)
+            while (end < p.n_opcodes && p.prog_class[end] == CLS_LIGHT) end++;
+        b->segments.push_back({cls, oi, end});
+        oi = end;
+    }
+    b->dp.prog = b->d_prog;
+    b->dp.prog_offset = b->d_prog_offset;
+    b->dp.consts = b->d_consts;
+    b->dp.bytecode = b->d_bytecode;
+    b->dp.Mem = b->d_Mem;
+    b->dp.grumpkin = nullptr;
+    if (p.needs_grumpkin) {
+        b->dp.grumpkin = grumpkin_tables_device();
+        if (!b->dp.grumpkin) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+    }
     b->n_words = (p.n_witnesses + 31) / 32;
     if (int rc = upload(&b->d_producer, p.producer)) return rc;
     if (int rc = upload(&b->d_dyn_offset, p.dyn_offset)) return rc;
@@ -247,6 +313,10 @@ static int ensure_slow_capacity(acvm_batch *b, uint32_t n) {
     return 0;
 }
 
+static ExactLanes exact_lanes(acvm_batch *b, uint32_t n_slow) {
+    return ExactLanes{b->d_slow_ids, n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res};
+}
+
 int acvm_batch_solve(acvm_batch_t *b) {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
@@ -258,6 +328,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
     b->arith_kernel_ms = 0;
     b->dyn_kernel_ms = 0;
     b->slow_path_ms = 0;
+    for (int k = 0; k < (int)N_CLS; k++) b->cls_kernel_ms[k] = 0;
     size_t ev_used = 0;
     auto next_event = [&]() -> hipEvent_t {
         if (ev_used == b->ev_pool.size()) {
@@ -267,16 +338,16 @@ int acvm_batch_solve(acvm_batch_t *b) {
         }
         return b->ev_pool[ev_used++];
     };
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> reg_pairs, dyn_pairs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> reg_pairs, dyn_pairs, cls_pairs[N_CLS];
     HIPCHK(hipEventRecord(b->ev_start, s));
     if (b->force_slow) {
         launch_fill_u32(s, b->d_event, 0u, b->B);
     } else {
         launch_fill_u32(s, b->d_event, 0xFFFFFFFFu, b->B);
-        // Per level the constant-coefficient gates (stream s, HBM-bound) and the gates that need a per-instance
-        // inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of either
-        // stream waits for level L of both.
-        const size_t n_levels = p.level_start.empty() ? 0 : p.level_start.size() - 1;
+        // Per level the constant-coefficient gates and the other record classes (stream s) and the gates that need a
+        // per-instance inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of
+        // either stream waits for level L of both.
+        const size_t n_levels = p.n_levels;
         while (b->ev_sync.size() < 2 * n_levels + 1) {
             hipEvent_t e;
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -292,15 +363,31 @@ int acvm_batch_solve(acvm_batch_t *b) {
             uint32_t n = p.level_start[L + 1] - p.level_start[L];
             uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
             hipEvent_t prev_reg = last_reg, prev_dyn = last_dyn;
+            bool s_work = n != 0;
+            for (int k = 0; k < (int)N_CLS; k++) s_work |= !b->cls_chunks[k][L].empty();
+            if (s_work && prev_dyn) HIPCHK(hipStreamWaitEvent(s, prev_dyn, 0));
             if (n) {
-                if (prev_dyn) HIPCHK(hipStreamWaitEvent(s, prev_dyn, 0));
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }
                 launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event);
                 if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); reg_pairs.push_back({e0, e1}); }
                 b->n_launches += (n + 65534) / 65535;
-                if (any_dyn) { HIPCHK(hipEventRecord(b->ev_sync[2 * L], s)); last_reg = b->ev_sync[2 * L]; }
             }
+            for (int k = 0; k < (int)N_CLS; k++)
+                for (const LaunchChunk &ch : b->cls_chunks[k][L]) {
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }
+                    const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + ch.first;
+                    switch (k) {
+                    case CLS_LIGHT: launch_light_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                    case CLS_HASH: launch_hash_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                    case CLS_GRUMPKIN: launch_grumpkin_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                    case CLS_BRILLIG: launch_brillig_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                    }
+                    if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); cls_pairs[k].push_back({e0, e1}); }
+                    b->n_launches++;
+                }
+            if (s_work && any_dyn) { HIPCHK(hipEventRecord(b->ev_sync[2 * L], s)); last_reg = b->ev_sync[2 * L]; }
             if (nd) {
                 if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
                 hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -319,7 +406,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
     HIPCHK(hipGetLastError());
     if (b->B) HIPCHK(hipMemcpyAsync(b->h_event.data(), b->d_event, (size_t)b->B * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    // instances that left the generic path (or hit a failing constraint): exact in-order re-solve
+    // instances that left the generic path (or hit a failing opcode): exact in-order re-solve from their event on
     b->slow_ids.clear();
     std::fill(b->slow_index.begin(), b->slow_index.end(), -1);
     for (uint32_t j = 0; j < b->B; j++)
@@ -333,14 +420,31 @@ int acvm_batch_solve(acvm_batch_t *b) {
         if (int rc = ensure_slow_capacity(b, n_slow)) return rc;
         HIPCHK(hipMemcpyAsync(b->d_slow_ids, b->slow_ids.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         b->slow_start.resize(n_slow);
-        for (uint32_t t = 0; t < n_slow; t++) b->slow_start[t] = b->h_event[b->slow_ids[t]];
+        uint32_t min_start = 0xFFFFFFFFu;
+        for (uint32_t t = 0; t < n_slow; t++) {
+            b->slow_start[t] = b->h_event[b->slow_ids[t]];
+            min_start = std::min(min_start, b->slow_start[t]);
+        }
         HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         slow0 = next_event();
         slow1 = next_event();
         hipEventRecord(slow0, s);
         launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
-        launch_arith_inorder(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->d_slow_stream, b->d_slow_offset, p.n_opcodes, b->d_consts,
-                             b->d_assigned, b->d_slow_start, b->d_slow_res);
+        const ExactLanes L = exact_lanes(b, n_slow);
+        launch_exact_init(s, L);
+        // memory side effects of the opcodes before the earliest event are replayed by the span kernel, so start at the
+        // first segment that holds a memory opcode or the earliest event, whichever comes first
+        bool has_mem = p.mem_cells != 0;
+        for (const ExactSegment &seg : b->segments) {
+            if (seg.end <= min_start && !(has_mem && seg.cls == CLS_LIGHT)) continue;
+            switch (seg.cls) {
+            case CLS_LIGHT: launch_exact_span(s, b->d_W, b->Bp, b->dp, L, seg.begin, seg.end); break;
+            case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
+            case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
+            case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
+            }
+        }
+        launch_exact_finish(s, L);
         hipEventRecord(slow1, s);
         HIPCHK(hipGetLastError());
         b->slow_res.resize(n_slow);
@@ -351,16 +455,18 @@ int acvm_batch_solve(acvm_batch_t *b) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, b->ev_start, b->ev_end));
     b->solve_device_ms = ms;
-    for (auto &pr : reg_pairs) {
-        float t = 0;
-        hipEventElapsedTime(&t, pr.first, pr.second);
-        b->arith_kernel_ms += t;
-    }
-    for (auto &pr : dyn_pairs) {
-        float t = 0;
-        hipEventElapsedTime(&t, pr.first, pr.second);
-        b->dyn_kernel_ms += t;
-    }
+    auto sum_pairs = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+        double total = 0;
+        for (auto &pr : v) {
+            float t = 0;
+            hipEventElapsedTime(&t, pr.first, pr.second);
+            total += t;
+        }
+        return total;
+    };
+    b->arith_kernel_ms = sum_pairs(reg_pairs);
+    b->dyn_kernel_ms = sum_pairs(dyn_pairs);
+    for (int k = 0; k < (int)N_CLS; k++) b->cls_kernel_ms[k] = sum_pairs(cls_pairs[k]);
     if (n_slow) {
         float t = 0;
         hipEventElapsedTime(&t, slow0, slow1);
@@ -373,17 +479,94 @@ int acvm_batch_solve(acvm_batch_t *b) {
     return not_solved;
 }
 
+// one witness of one instance as 32 canonical big-endian bytes (message texts only; rare)
+static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
+    uint32_t *d_sel = nullptr;
+    uint8_t *d_out = nullptr;
+    bool ok = hipMalloc((void **)&d_sel, 4) == hipSuccess && hipMalloc((void **)&d_out, 32) == hipSuccess &&
+              hipMemcpy(d_sel, &w, 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out);
+        ok = hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, b->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
+    }
+    if (d_sel) hipFree(d_sel);
+    if (d_out) hipFree(d_out);
+    return ok;
+}
+
+// message text of a failure, rebuilt from the device's DevMsg code (ops_common.hpp) + payload
+static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm_result_t &r) {
+    const Plan &p = b->plan;
+    const uint32_t *rec = sr.opcode_index < p.n_opcodes ? &p.prog[p.prog_offset[sr.opcode_index]] : nullptr;
+    auto hex_of = [&](uint32_t w, char out[65]) {
+        uint8_t be[32] = {0};
+        fetch_one(b, j, w, be);
+        for (int i = 0; i < 32; i++) snprintf(out + 2 * i, 3, "%02x", be[i]);
+    };
+    char hx[65];
+    switch (sr.msg) {
+    case 1: snprintf(r.message, sizeof r.message, "Mul term in the arithmetic opcode must contain either zero or one term"); break;
+    case 2: snprintf(r.message, sizeof r.message, "number of bits specified for each input must be the same"); break;
+    case 3: snprintf(r.message, sizeof r.message, "fetch_nearest_bytes: range end index out of range"); break;
+    case 4: snprintf(r.message, sizeof r.message, "Expected 32 outputs but encountered %u", sr.x0); break;
+    case 5: {
+        unsigned long long len = 0;
+        if (rec && rec[0] == PK_HASH)
+            for (uint32_t i = 0; i < rec[3]; i++) len += (rec[6 + 2 * i + 1] + 7) / 8;
+        snprintf(r.message, sizeof r.message,
+                 "the number of bytes to take from the message is more than the number of bytes in the message. %llu > %llu",
+                 (unsigned long long)sr.x1 << 32 | sr.x0, len);
+        break;
+    }
+    case 6: snprintf(r.message, sizeof r.message, "called `Option::unwrap()` on a `None` value (memory index)"); break;
+    case 7: snprintf(r.message, sizeof r.message, "Memory must be read into a specified witness index, encountered an Expression"); break;
+    case 8: snprintf(r.message, sizeof r.message, "The radix must be within 2...256"); break;
+    case 9: case 10:
+        if (rec && rec[0] == PK_FIXED_BASE) {
+            hex_of(rec[sr.msg == 9 ? 2 : 3], hx);
+            snprintf(r.message, sizeof r.message, "Limb %s is not less than 2^128", hx);
+        }
+        break;
+    case 11:
+        if (rec && rec[0] == PK_FIXED_BASE) {  // hex::encode(BigUint::to_bytes_be()) of high * 2^128 + low: minimal big-endian bytes
+            uint8_t lo[32] = {0}, hi[32] = {0}, k[32];
+            fetch_one(b, j, rec[2], lo);
+            fetch_one(b, j, rec[3], hi);
+            memcpy(k, hi + 16, 16);
+            memcpy(k + 16, lo + 16, 16);
+            int st = 0;
+            while (st < 31 && k[st] == 0) st++;
+            char hexs[65];
+            for (int i = st; i < 32; i++) snprintf(hexs + 2 * (i - st), 3, "%02x", k[i]);
+            snprintf(r.message, sizeof r.message, "Value %s is not a valid grumpkin scalar", hexs);
+        }
+        break;
+    case 12: snprintf(r.message, sizeof r.message, "range end index 64 out of range for slice of length %u", sr.x0); break;
+    case 13: snprintf(r.message, sizeof r.message, "Message overran wasm scratch space"); break;
+    case 14: snprintf(r.message, sizeof r.message, "explicit trap hit in brillig"); break;
+    case 15: snprintf(r.message, sizeof r.message, "return opcode hit, but callstack already empty"); break;
+    case 16: snprintf(r.message, sizeof r.message, "brillig vm panic (code %u)", sr.x0); break;
+    case 17: snprintf(r.message, sizeof r.message, "brillig memory write at %u beyond the device capacity (set ACVM_BRILLIG_MEM_CELLS)", sr.x0); break;
+    case 18: snprintf(r.message, sizeof r.message, "brillig step limit reached on the device"); break;
+    case 19: snprintf(r.message, sizeof r.message, "failed to solve blackbox function inside brillig (code %u)", sr.x0); break;
+    case 20: snprintf(r.message, sizeof r.message, "failed to solve blackbox function: pedersen, reason: Invalid signature length"); break;
+    default: break;
+    }
+}
+
 int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out) {
     if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    HIPCHK(hipSetDevice(b->device));
     for (uint32_t j = 0; j < b->B; j++) {
         acvm_result_t &r = out[j];
         memset(&r, 0, sizeof r);
         if (b->plan.n_opcodes == 0 || b->slow_index[j] < 0) { r.status = ACVM_STATUS_SOLVED; continue; }
         const SlowResult &sr = b->slow_res[b->slow_index[j]];
         r.status = sr.status; r.err = sr.err; r.opcode_index = sr.opcode_index; r.aux0 = sr.aux0; r.aux1 = sr.aux1;
-        if (sr.err == ACVM_ERR_PANIC)
-            snprintf(r.message, sizeof r.message, "Mul term in the arithmetic opcode must contain either zero or one term");
+        r.n_call_stack = sr.n_call_stack > 16 ? 16 : sr.n_call_stack;
+        for (uint32_t k = 0; k < r.n_call_stack; k++) r.call_stack[k] = sr.call_stack[k];
+        if (sr.status == ACVM_STATUS_FAILURE && sr.msg) format_message(b, j, sr, r);
     }
     return 0;
 }

@@ -4,33 +4,16 @@
 //                          -> Montgomery SoA (from_be_bytes_reduce, generic_ark.rs:281-283)
 //  arith_level_kernel      ArithmeticSolver::solve (pwg/arithmetic.rs:27-127) for one dependency level,
 //                          one lane per witness instance, generic-instance plan from plan.cpp
-//  arith_inorder_kernel    the same solver, exact in-order semantics with per-instance assigned bits
-//                          (evaluate :212-239, solve_mul_term :133-144, solve_fan_in_term :176-209,
-//                          insert_value pwg/mod.rs:338-357) for instances that left the generic path
+//  (the exact in-order kernels and every non-arithmetic opcode live in kernels_ops.hip / kernels_hash.hip /
+//   kernels_grumpkin.hip / kernels_brillig.hip)
 //  export_witness_kernel   FieldElement::to_be_bytes (generic_ark.rs:269-277) for witness_map()/finalize()
 //
 // Wave64 throughout; no LDS is needed by the streaming kernels (every operand is read once per lane);
 // gate records and circuit constants are wave-uniform and travel through the scalar cache.
-#include "fr_device.hpp"
+#include "ops_common.hpp"
 #include "kernels.hpp"
 
 namespace acvm {
-
-static constexpr uint32_t K_COEF_ONE = 0xFFFFFFFFu;
-static constexpr uint32_t K_COEF_MINUS_ONE = 0xFFFFFFFEu;
-static constexpr uint32_t K_COEF_ZERO = 0xFFFFFFFDu;
-
-__device__ __forceinline__ Fr apply_coef(const Fr &x, uint32_t coef, const uint32_t *__restrict__ consts) {
-    if (coef == K_COEF_ONE) return x;
-    if (coef == K_COEF_MINUS_ONE) return fr_neg(x);
-    return fr_mul(x, fr_const(consts, coef));
-}
-
-// R^2 mod p: to_montgomery(x) = mont_mul(x, R2)
-__device__ __forceinline__ Fr fr_r2() {
-    Fr r = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
-    return r;
-}
 
 // ------------------------------------------------------------------------------------------ import
 // in: [B][n_in][32] big-endian. One lane per (instance, input).
@@ -162,73 +145,6 @@ __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------ exact in-order kernel
-// One lane per flagged instance (gathered through slow_ids). Bit w of the instance's assigned set lives in
-// assigned[(w >> 5) * n_slow + t].
-__device__ __forceinline__ bool is_known(const uint32_t *assigned, uint32_t n_slow, uint32_t t, uint32_t w) {
-    return (assigned[(uint64_t)(w >> 5) * n_slow + t] >> (w & 31)) & 1u;
-}
-
-__global__ void __launch_bounds__(64) arith_inorder_kernel(uint4 *__restrict__ W, uint64_t Bp, const uint32_t *__restrict__ slow_ids,
-                                                           uint32_t n_slow, const uint32_t *__restrict__ stream,
-                                                           const uint32_t *__restrict__ offset, uint32_t n_opcodes,
-                                                           const uint32_t *__restrict__ consts, uint32_t *assigned,
-                                                           const uint32_t *__restrict__ start_opcode,
-                                                           SlowResult *__restrict__ results) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_slow) return;
-    const uint64_t j = slow_ids[t];
-    SlowResult res = {0u, 0u, 0u, 0u, 0u};  // Solved
-    if (n_opcodes == 0) { results[t] = res; return; }
-    for (uint32_t oi = start_opcode[t]; oi < n_opcodes; oi++) {
-        const uint32_t *__restrict__ g = stream + offset[oi];
-        if (g[0] != 0u) { res = {2u, 8u, oi, 0u, 0u}; break; }  // not an Arithmetic opcode: never scheduled here
-        const uint32_t n_mul = g[1], n_lin = g[2], qc = g[3];
-        Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
-        uint32_t residual_mul = 0, unknowns = 0, unk_w = 0, unk_ninv = 0;
-        bool unk_dynamic = false;
-        Fr unk_c = fr_zero();
-        const uint32_t *__restrict__ p = g + 4;
-        // evaluate (arithmetic.rs:212-239), mul terms first
-        for (uint32_t i = 0; i < n_mul; i++, p += 3) {
-            const uint32_t coef = p[0], l = p[1], r = p[2];
-            const bool kl = is_known(assigned, n_slow, t, l), kr = is_known(assigned, n_slow, t, r);
-            if (kl && kr) {
-                if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(fr_mul(fr_load(W, l, Bp, j), fr_load(W, r, Bp, j)), coef, consts));
-            } else if (!kl && !kr) {
-                if (coef != K_COEF_ZERO) residual_mul++;
-            } else if (coef != K_COEF_ZERO) {
-                Fr v = apply_coef(fr_load(W, kl ? l : r, Bp, j), coef, consts);
-                if (!fr_is_zero(v)) { unknowns++; unk_c = v; unk_w = kl ? r : l; unk_dynamic = true; }
-            }
-        }
-        for (uint32_t i = 0; i < n_lin; i++, p += 3) {
-            const uint32_t coef = p[0], w = p[2];
-            if (is_known(assigned, n_slow, t, w)) {
-                if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(fr_load(W, w, Bp, j), coef, consts));
-            } else if (coef != K_COEF_ZERO) {
-                unknowns++;
-                unk_ninv = p[1];
-                unk_dynamic = false;
-                unk_w = w;
-            }
-        }
-        if (residual_mul >= 2) { res = {2u, 8u, oi, 0u, 0u}; break; }                 // panic (arithmetic.rs:142)
-        if (residual_mul == 1 || unknowns > 1) { res = {2u, 2u, oi, 0u, 0u}; break; }  // TooManyUnknowns (:38-42)
-        if (unknowns == 0) {
-            if (!fr_is_zero(acc)) { res = {2u, 4u, oi, 0u, 0u}; break; }               // Unsatisfied (:92-102)
-        } else {
-            // assignment = -(total_sum / coeff) (:86,120); the witness is unassigned here, so insert_value cannot
-            // conflict. Constant coefficients carry their -1/c from the planner; a coefficient that is a product
-            // with a known witness (:217-221) is inverted per instance.
-            Fr val = unk_dynamic ? fr_neg(fr_mul(acc, fr_inv(unk_c))) : apply_coef(acc, unk_ninv, consts);
-            fr_store(W, unk_w, Bp, j, val);
-            assigned[(uint64_t)(unk_w >> 5) * n_slow + t] |= 1u << (unk_w & 31);
-        }
-    }
-    results[t] = res;
-}
-
 // ------------------------------------------------------------------------------------------ self test
 // Cross-checks the hand-scheduled field routines against the portable ones on pseudo-random operands:
 // asm fr_mul == portable CIOS, a * inv(a) == 1, (a + b) - b == a, a + (-a) == 0. Counts mismatching lanes.
@@ -316,13 +232,6 @@ void launch_arith_dyn_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, co
     if (!n_dyn || !B) return;
     hipLaunchKernelGGL(arith_dyn_level_kernel, dim3((B + 63) / 64, (n_dyn + DYN_CHUNK - 1) / DYN_CHUNK), dim3(64), 0, s, W, Bp, B,
                        gate_stream, dyn_offset, n_dyn, consts, event, scratch);
-}
-void launch_arith_inorder(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const uint32_t *stream,
-                          const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned,
-                          const uint32_t *start_opcode, SlowResult *results) {
-    if (!n_slow) return;
-    hipLaunchKernelGGL(arith_inorder_kernel, dim3((n_slow + 63) / 64), dim3(64), 0, s, W, Bp, slow_ids, n_slow, stream, offset, n_opcodes,
-                       consts, assigned, start_opcode, results);
 }
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches) {
     if (!n) return;

@@ -1,13 +1,39 @@
-// kernels.hpp -- host-visible launchers of the gfx950 kernels (kernels.hip).
+// kernels.hpp -- host-visible launchers of the gfx950 kernels (kernels*.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace acvm {
 
+// per-instance outcome of the exact in-order kernels. status 1 (InProgress) while the instance is still running.
 struct SlowResult {
     uint32_t status, err, opcode_index, aux0, aux1;
+    uint32_t msg, x0, x1;  // DevMsg code + payload for the host-side message text
+    uint32_t n_call_stack;
+    uint32_t call_stack[16];
 };
+
+// lanes of the exact path: flagged instances gathered through slow_ids
+struct ExactLanes {
+    const uint32_t *slow_ids;
+    uint32_t n_slow;
+    uint32_t *assigned;              // bit w of lane t at assigned[(w >> 5) * n_slow + t]
+    const uint32_t *start_opcode;    // first opcode the lane executes (its event)
+    SlowResult *results;
+};
+
+// everything a record needs besides the witness table
+struct DeviceProgram {
+    const uint32_t *prog;         // in-order program (one record per opcode)
+    const uint32_t *prog_offset;  // per opcode
+    const uint32_t *consts;       // circuit constants, 8 x u32 Montgomery each
+    const uint32_t *bytecode;     // Brillig programs
+    uint4 *Mem;                   // per-instance memory blocks, laid out like W
+    const void *grumpkin;         // GrumpkinTables (device), nullptr if the circuit has no Grumpkin opcode
+};
+
+// Grumpkin lookup tables of the current device (built once per process and device), nullptr on failure
+const void *grumpkin_tables_device();
 
 void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in);
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
@@ -16,13 +42,32 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event);
 void launch_arith_dyn_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *dyn_offset,
                             uint32_t n_dyn, const uint32_t *consts, uint32_t *event, uint4 *scratch);
-void launch_arith_inorder(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const uint32_t *stream,
-                          const uint32_t *offset, uint32_t n_opcodes, const uint32_t *consts, uint32_t *assigned,
-                          const uint32_t *start_opcode, SlowResult *results);
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, uint32_t n_witnesses,
                           const uint32_t *producer, const uint32_t *start_opcode);
+
+// ---- level kernels of the non-arithmetic record classes (FastPolicy): grid.y = records of the level.
+// offsets: device array of record offsets into prog; scratch_off: per record, u32-word offset (per instance) into scratch
+void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
+                        uint32_t *event);
+void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
+                       const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
+void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
+                           const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
+void launch_brillig_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
+                          const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
+
+// ---- exact in-order kernels (ExactPolicy): one lane per flagged instance
+void launch_exact_init(hipStream_t s, const ExactLanes &L);
+// opcodes [op_begin, op_end) of class CLS_LIGHT in program order
+void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end);
+// one opcode of a heavy class
+void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
+void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
+void launch_exact_brillig(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
+// InProgress -> Solved after the last opcode
+void launch_exact_finish(hipStream_t s, const ExactLanes &L);
 
 }  // namespace acvm

@@ -32,14 +32,19 @@ enum DevErr : uint32_t {
 enum DevMsg : uint32_t {
     DM_NONE = 0, DM_TWO_MUL_TERMS = 1, DM_LOGIC_BITS = 2, DM_FETCH_BYTES = 3, DM_HASH_OUTPUTS = 4, DM_KECCAK_VAR_LEN = 5,
     DM_MEM_INDEX_U64 = 6, DM_MEM_READ_EXPR = 7, DM_RADIX = 8, DM_LIMB_LOW = 9, DM_LIMB_HIGH = 10, DM_SCALAR = 11,
-    DM_SCHNORR_SIG_LEN = 12, DM_SCHNORR_MSG_LEN = 13
+    DM_SCHNORR_SIG_LEN = 12, DM_SCHNORR_MSG_LEN = 13, DM_BRILLIG_TRAP = 14, DM_BRILLIG_RETURN = 15, DM_BRILLIG_PANIC = 16,
+    DM_BRILLIG_MEM_CAP = 17, DM_BRILLIG_STEP_LIMIT = 18, DM_BRILLIG_BB_FAILED = 19, DM_PEDERSEN_DOMAIN = 20
 };
 
+// err / aux0 / aux1 are the ABI's acvm_result_t fields; msg (DevMsg) and x0, x1 let the host rebuild the message text
 struct OpResult {
-    uint32_t err, aux0, aux1;
+    uint32_t err, aux0, aux1, msg, x0, x1;
 };
-__device__ __forceinline__ OpResult op_ok() { return OpResult{DE_NONE, 0u, 0u}; }
-__device__ __forceinline__ OpResult op_fail(uint32_t e, uint32_t a0 = 0, uint32_t a1 = 0) { return OpResult{e, a0, a1}; }
+__device__ __forceinline__ OpResult op_ok() { return OpResult{DE_NONE, 0u, 0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ OpResult op_fail(uint32_t e, uint32_t a0 = 0, uint32_t a1 = 0) { return OpResult{e, a0, a1, 0u, 0u, 0u}; }
+__device__ __forceinline__ OpResult op_fail_msg(uint32_t e, uint32_t a0, uint32_t msg, uint32_t x0 = 0, uint32_t x1 = 0) {
+    return OpResult{e, a0, 0u, msg, x0, x1};
+}
 
 __device__ __forceinline__ Fr apply_coef(const Fr &x, uint32_t coef, const uint32_t *__restrict__ consts) {
     if (coef == K_COEF_ONE) return x;

@@ -1,0 +1,68 @@
+// ops_kernel.hpp -- the two kernel skeletons every non-arithmetic record class is instantiated in:
+//   record_level_kernel<Op>  FastPolicy: grid = (instances / block, records of one dependency level); errors only flag
+//                            the instance (event word = min failing opcode index) for the exact path
+//   record_exact_kernel<Op>  ExactPolicy: one opcode, one lane per flagged instance that is still InProgress and whose
+//                            event is not after this opcode; errors become the instance's final result
+// Op::run(policy, record, program, per-record scratch) is the templated device routine of the class.
+#pragma once
+#include "kernels.hpp"
+#include "ops_common.hpp"
+
+namespace acvm {
+
+__device__ __forceinline__ void exact_fail(const ExactLanes &L, uint32_t t, uint32_t opcode, const OpResult &r) {
+    SlowResult &o = L.results[t];
+    o.status = 2u;  // ACVM_STATUS_FAILURE
+    o.err = r.err;
+    o.opcode_index = opcode;
+    o.aux0 = r.aux0;
+    o.aux1 = r.aux1;
+    o.msg = r.msg;
+    o.x0 = r.x0;
+    o.x1 = r.x1;
+}
+
+template <class Op, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
+                                                             const uint32_t *__restrict__ scratch_off, uint32_t *__restrict__ event,
+                                                             uint32_t *scratch) {
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= B) return;
+    const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
+    uint32_t *sc = scratch ? scratch + (uint64_t)scratch_off[blockIdx.y] * Bp : nullptr;
+    FastPolicy p{W, Bp, j};
+    const OpResult r = Op::run(p, rec, dp, sc, (SlowResult *)nullptr);
+    if (r.err) atomicMin(&event[j], rec[1]);
+}
+
+template <class Op, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) record_exact_kernel(uint4 *W, uint64_t Bp, DeviceProgram dp, ExactLanes L, uint32_t opcode,
+                                                             uint32_t *scratch) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= L.n_slow) return;
+    if (L.results[t].status != 1u || L.start_opcode[t] > opcode) return;
+    const uint32_t *__restrict__ rec = dp.prog + dp.prog_offset[opcode];
+    ExactPolicy p{W, Bp, L.slow_ids[t], L.assigned, L.n_slow, t};
+    const OpResult r = Op::run(p, rec, dp, scratch, &L.results[t]);
+    if (r.err) exact_fail(L, t, opcode, r);
+}
+
+template <class Op, int BLOCK>
+static void launch_record_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
+                                const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch) {
+    if (!n || !B) return;
+    for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
+        const uint32_t m = n - done > 65535u ? 65535u : n - done;
+        hipLaunchKernelGGL((record_level_kernel<Op, BLOCK>), dim3((B + BLOCK - 1) / BLOCK, m), dim3(BLOCK), 0, s, W, Bp, B, dp, offsets + done,
+                           scratch_off ? scratch_off + done : nullptr, event, scratch);
+        done += m;
+    }
+}
+template <class Op, int BLOCK>
+static void launch_record_exact(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode,
+                                uint32_t *scratch) {
+    if (!L.n_slow) return;
+    hipLaunchKernelGGL((record_exact_kernel<Op, BLOCK>), dim3((L.n_slow + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, W, Bp, dp, L, opcode, scratch);
+}
+
+}  // namespace acvm

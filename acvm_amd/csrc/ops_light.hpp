@@ -47,7 +47,7 @@ __device__ __forceinline__ OpResult op_logic(const P &p, const uint32_t *__restr
         if (!p.known(r[3])) return op_fail(DE_MISSING_ASSIGNMENT, r[3]);
         if (!p.known(r[4])) return op_fail(DE_MISSING_ASSIGNMENT, r[4]);
     }
-    if (r[5] != r[6]) return op_fail(DE_PANIC, 0, DM_LOGIC_BITS);  // logic.rs:17-20 assert_eq!
+    if (r[5] != r[6]) return op_fail_msg(DE_PANIC, 0, DM_LOGIC_BITS);  // logic.rs:17-20 assert_eq!
     const Fr a = canon_mask(fr_to_canonical(p.load(r[3])), r[5]);
     const Fr b = canon_mask(fr_to_canonical(p.load(r[4])), r[5]);
     Fr c;
@@ -70,7 +70,7 @@ __device__ __forceinline__ OpResult op_zero_out(const P &p, const uint32_t *__re
 }
 
 // 256-bit unsigned division of canonical integers (num-bigint semantics); b != 0
-__device__ __noinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr &rem) {
+static __device__ __noinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr &rem) {
     q = fr_zero();
     rem = fr_zero();
     for (int i = 255; i >= 0; i--) {
@@ -117,7 +117,7 @@ __device__ __forceinline__ OpResult op_to_le_radix(const P &p, const uint32_t *_
     Fr va;
     OpResult e = expr_value(p, ea, consts, va);
     if (e.err) return e;
-    if (radix < 2 || radix > 256) return op_fail(DE_PANIC, 0, DM_RADIX);  // num-bigint to_radix_le assert
+    if (radix < 2 || radix > 256) return op_fail_msg(DE_PANIC, 0, DM_RADIX);  // num-bigint to_radix_le assert
     Fr v = fr_to_canonical(va);
     // BigUint::to_radix_le: little-endian digits, 0 -> [0]. Digits are produced one by one; more digits than
     // outputs -> UnsatisfiedConstrain before anything is inserted (directives/mod.rs:67-71), so count first.
@@ -233,8 +233,11 @@ __device__ __forceinline__ bool canon_fits_u64(const Fr &c) { return (c.v[2] | c
 
 // [K_MEM_OP, opcode, cell_base, block_len, readable_len, has_pred, mode, target_w, target_flag,
 //  E(operation), E(index), E(value), E(pred)?]   mode: 0 write, 1 read (planner: operation is a constant), 2 dynamic
+// `replay` (exact path only, FastPolicy semantics): re-apply the memory side effect of an opcode that ran before the
+// instance's event; the read target already holds the right value and no error is possible there.
 template <class P>
-__device__ __forceinline__ OpResult op_mem_op(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts, uint4 *Mem) {
+__device__ __forceinline__ OpResult op_mem_op(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts, uint4 *Mem,
+                                              bool replay = false) {
     const uint32_t base = r[2], block_len = r[3], readable_len = r[4], has_pred = r[5];
     const uint32_t *e_op = r + 9, *e_idx = e_op + expr_len(e_op), *e_val = e_idx + expr_len(e_idx), *e_pred = e_val + expr_len(e_val);
     Fr operation, index, pred = fr_one();
@@ -243,7 +246,7 @@ __device__ __forceinline__ OpResult op_mem_op(const P &p, const uint32_t *__rest
     e = expr_value(p, e_idx, consts, index);
     if (e.err) return e;
     const Fr ci = fr_to_canonical(index);
-    if (!canon_fits_u64(ci)) return op_fail(DE_PANIC, 0, DM_MEM_INDEX_U64);  // try_to_u64().unwrap() (memory_op.rs:72)
+    if (!canon_fits_u64(ci)) return op_fail_msg(DE_PANIC, 0, DM_MEM_INDEX_U64);  // try_to_u64().unwrap() (memory_op.rs:72)
     const uint32_t mi = ci.v[0];                                              // `as MemoryIndex` wraps to u32
     const bool is_read = fr_is_zero(operation);
     if (P::exact) {
@@ -255,7 +258,7 @@ __device__ __forceinline__ OpResult op_mem_op(const P &p, const uint32_t *__rest
         if (is_read) {
             // Expression::to_witness (expression/mod.rs:158-172)
             if (!(v.n_mul == 0 && v.n_lin == 1 && fr_eq(v.lin_coef, fr_one()) && fr_is_zero(v.constant)))
-                return op_fail(DE_PANIC, 0, DM_MEM_READ_EXPR);
+                return op_fail_msg(DE_PANIC, 0, DM_MEM_READ_EXPR);
             Fr val = fr_zero();
             if (!fr_is_zero(pred)) {
                 if (mi >= readable_len) return op_fail(DE_INDEX_OOB, mi, block_len);  // key absent (memory_op.rs:37-44)
@@ -275,6 +278,7 @@ __device__ __forceinline__ OpResult op_mem_op(const P &p, const uint32_t *__rest
         if (e.err) return e;
     }
     if (r[6] == 1) {
+        if (replay) return op_ok();
         Fr val = fr_zero();
         if (!fr_is_zero(pred)) {
             if (mi >= readable_len) return op_fail(DE_INDEX_OOB, mi, block_len);
@@ -289,6 +293,71 @@ __device__ __forceinline__ OpResult op_mem_op(const P &p, const uint32_t *__rest
         fr_store(Mem, base + mi, p.Bp, p.j, val);
     }
     return op_ok();
+}
+
+// ------------------------------------------------------------------------------------------------ arithmetic (exact)
+// ArithmeticSolver::solve (arithmetic.rs:27-127) with evaluate (:212-239), solve_mul_term (:133-144),
+// solve_fan_in_term (:176-209) and insert_value (pwg/mod.rs:338-357) restated on the per-instance assigned set.
+// [K_ARITH, opcode, E(expr)]. The level kernels use the planner's folded gate stream instead.
+template <class P>
+__device__ __forceinline__ OpResult op_arith(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts) {
+    const uint32_t *__restrict__ e = r + 2;
+    const uint32_t n_mul = e[0], n_lin = e[1], qc = e[2];
+    Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
+    uint32_t residual_mul = 0, unknowns = 0, unk_w = 0, unk_ninv = 0;
+    bool unk_dynamic = false;
+    Fr unk_c = fr_zero();
+    const uint32_t *__restrict__ t = e + 3;
+    for (uint32_t i = 0; i < n_mul; i++, t += 3) {
+        const uint32_t coef = t[0], l = t[1], rr = t[2];
+        const bool kl = p.known(l), kr = p.known(rr);
+        if (kl && kr) {
+            if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(fr_mul(p.load(l), p.load(rr)), coef, consts));
+        } else if (!kl && !kr) {
+            if (coef != K_COEF_ZERO) residual_mul++;
+        } else if (coef != K_COEF_ZERO) {
+            Fr v = apply_coef(p.load(kl ? l : rr), coef, consts);
+            if (!fr_is_zero(v)) { unknowns++; unk_c = v; unk_w = kl ? rr : l; unk_dynamic = true; }
+        }
+    }
+    for (uint32_t i = 0; i < n_lin; i++, t += 3) {
+        const uint32_t coef = t[0], w = t[2];
+        if (p.known(w)) {
+            if (coef != K_COEF_ZERO) acc = fr_add(acc, apply_coef(p.load(w), coef, consts));
+        } else if (coef != K_COEF_ZERO) {
+            unknowns++;
+            unk_ninv = t[1];
+            unk_dynamic = false;
+            unk_w = w;
+        }
+    }
+    if (residual_mul >= 2) return op_fail_msg(DE_PANIC, 0, DM_TWO_MUL_TERMS);       // panic (arithmetic.rs:142)
+    if (residual_mul == 1 || unknowns > 1) return op_fail(DE_TOO_MANY_UNKNOWNS);  // (:38-42)
+    if (unknowns == 0) {
+        if (!fr_is_zero(acc)) return op_fail(DE_UNSATISFIED);  // (:92-102)
+        return op_ok();
+    }
+    // assignment = -(total_sum / coeff) (:86,120). Constant coefficients carry their -1/c from the planner; a coefficient
+    // that is a product with a known witness (:217-221) is inverted per instance.
+    const Fr val = unk_dynamic ? fr_neg(fr_mul(acc, fr_inv(unk_c))) : apply_coef(acc, unk_ninv, consts);
+    if (!p.insert(unk_w, val, 0)) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+// every record kind of class CLS_LIGHT
+template <class P>
+__device__ __forceinline__ OpResult dispatch_light(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts, uint4 *Mem) {
+    switch (r[0]) {
+    case K_ARITH: return op_arith(p, r, consts);
+    case K_RANGE: return op_range(p, r);
+    case K_LOGIC: return op_logic(p, r);
+    case K_ZERO_OUT: return op_zero_out(p, r);
+    case K_QUOTIENT: return op_quotient(p, r, consts);
+    case K_TO_LE_RADIX: return op_to_le_radix(p, r, consts);
+    case K_MEM_INIT: return op_mem_init(p, r, Mem);
+    case K_MEM_OP: return op_mem_op(p, r, consts, Mem);
+    default: return op_fail_msg(DE_PANIC, 0, DM_NONE);
+    }
 }
 
 }  // namespace acvm

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <cstdlib>
 #include <map>
 
 namespace acvm {
@@ -11,6 +12,7 @@ namespace {
 struct ConstPool {
     std::vector<FrH> &pool;
     std::map<std::array<uint64_t, 4>, uint32_t> index;
+    std::map<std::array<uint64_t, 4>, FrH> neg_inv_cache;
     FrH one = frh::one(), minus_one = frh::neg(frh::one());
     explicit ConstPool(std::vector<FrH> &p) : pool(p) {}
     uint32_t coef(const FrH &c) {  // multiplicative coefficient
@@ -18,6 +20,7 @@ struct ConstPool {
         if (c == minus_one) return COEF_MINUS_ONE;
         return intern(c);
     }
+    uint32_t coef_or_zero(const FrH &c) { return c.is_zero() ? COEF_ZERO : coef(c); }
     uint32_t constant(const FrH &c) {  // additive constant
         if (c.is_zero()) return COEF_ZERO;
         return intern(c);
@@ -31,13 +34,69 @@ struct ConstPool {
         index.emplace(k, id);
         return id;
     }
+    // -1/c, memoised (real circuits repeat a handful of coefficients)
+    FrH neg_inv(const FrH &c) {
+        if (c == one) return minus_one;
+        if (c == minus_one) return one;
+        std::array<uint64_t, 4> k = {c.l[0], c.l[1], c.l[2], c.l[3]};
+        auto it = neg_inv_cache.find(k);
+        if (it != neg_inv_cache.end()) return it->second;
+        FrH r = frh::neg(frh::inverse(c));
+        neg_inv_cache.emplace(k, r);
+        return r;
+    }
 };
 
 struct PendingGate {
     uint32_t level;
-    uint32_t opcode;
     std::vector<uint32_t> words;
 };
+struct PendingRecord {
+    uint32_t level, cls, opcode;
+};
+
+// Expression record: [n_mul, n_lin, qc, (coef, l, r) x n_mul, (coef, -1/coef, w) x n_lin]
+void emit_expr(std::vector<uint32_t> &s, ConstPool &pool, const Expr &e) {
+    s.push_back((uint32_t)e.mul.size());
+    s.push_back((uint32_t)e.lin.size());
+    s.push_back(pool.constant(e.qc));
+    for (auto &t : e.mul) {
+        s.push_back(pool.coef_or_zero(t.c));
+        s.push_back(t.l);
+        s.push_back(t.r);
+    }
+    for (auto &t : e.lin) {
+        s.push_back(pool.coef_or_zero(t.c));
+        s.push_back(t.c.is_zero() ? COEF_ZERO : pool.coef(pool.neg_inv(t.c)));
+        s.push_back(t.w);
+    }
+}
+
+// generic-instance view of an expression: every witness it mentions must be known (get_value, pwg/mod.rs:321-332)
+struct Reads {
+    const std::vector<uint8_t> &known;
+    const std::vector<uint32_t> &level;
+    std::vector<uint32_t> ws;
+    uint32_t lvl = 0;
+    bool ok = true;
+    Reads(const std::vector<uint8_t> &k, const std::vector<uint32_t> &l) : known(k), level(l) {}
+    void witness(uint32_t w) {
+        if (w >= known.size() || !known[w]) { ok = false; return; }
+        lvl = std::max(lvl, level[w]);
+        ws.push_back(w);
+    }
+    void expr(const Expr &e) {
+        for (auto &t : e.mul) { witness(t.l); witness(t.r); }
+        for (auto &t : e.lin) witness(t.w);
+    }
+    size_t distinct() {
+        std::sort(ws.begin(), ws.end());
+        ws.erase(std::unique(ws.begin(), ws.end()), ws.end());
+        return ws.size();
+    }
+};
+
+uint32_t clamp_reg(uint64_t r) { return r > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)r; }
 
 }  // namespace
 
@@ -58,41 +117,349 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     }
     ConstPool pool(p.constants);
     std::vector<PendingGate> gates;
+    std::vector<PendingRecord> records;
     gates.reserve(c.opcodes.size());
 
-    // ---- in-order (exact kernel) program: original expressions, no folding
-    p.slow_offset.reserve(c.opcodes.size());
-    for (uint32_t oi = 0; oi < c.opcodes.size(); oi++) {
-        const Opcode &o = c.opcodes[oi];
-        p.slow_offset.push_back((uint32_t)p.slow_stream.size());
-        if (o.kind != OP_ARITHMETIC) {
-            if (p.unsupported.empty())
-                p.unsupported = "opcode " + std::to_string(oi) + ": kind " + std::to_string(o.kind) + " has no kernel yet";
-            p.slow_stream.push_back(0xFFFFFFFFu);
-            continue;
-        }
-        auto &s = p.slow_stream;
-        s.push_back(OP_ARITHMETIC);
-        s.push_back((uint32_t)o.expr.mul.size());
-        s.push_back((uint32_t)o.expr.lin.size());
-        s.push_back(pool.constant(o.expr.qc));
-        for (auto &t : o.expr.mul) {
-            s.push_back(t.c.is_zero() ? COEF_ZERO : pool.coef(t.c));
-            s.push_back(t.l);
-            s.push_back(t.r);
-        }
-        for (auto &t : o.expr.lin) {
-            // coefficient, -1/coefficient (so that a solved witness costs one multiplication), witness
-            s.push_back(t.c.is_zero() ? COEF_ZERO : pool.coef(t.c));
-            s.push_back(t.c.is_zero() ? COEF_ZERO : pool.coef(frh::neg(frh::inverse(t.c))));
-            s.push_back(t.w);
-        }
+    // memory blocks: cell ranges of the per-instance memory table + the program-order chain level
+    struct Block { uint32_t base = 0, cap = 0, len = 0, readable = 0, level = 0; bool seen = false; };
+    std::map<uint32_t, Block> blocks;
+    for (auto &o : c.opcodes)
+        if (o.kind == OP_MEMORY_INIT) {
+            Block &b = blocks[o.block_id];
+            b.cap = std::max(b.cap, (uint32_t)o.init.size());
+        } else if (o.kind == OP_MEMORY_OP) blocks[o.block_id];
+    for (auto &kv : blocks) {
+        kv.second.base = p.mem_cells;
+        p.mem_cells += kv.second.cap;
     }
 
-    // ---- level-parallel program for the generic instance
+    // =========================================================================== in-order program (all opcodes)
+    auto unsupported = [&](uint32_t oi, const std::string &what) {
+        if (p.unsupported.empty()) p.unsupported = "opcode " + std::to_string(oi) + ": " + what + " has no kernel";
+    };
+    p.prog_offset.reserve(c.opcodes.size());
+    p.prog_class.assign(c.opcodes.size(), CLS_LIGHT);
+    p.prog_scratch.assign(c.opcodes.size(), 0);
+    // the `flag` words (was the output already assigned for the generic instance?) are patched in the second pass
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> out_slots(c.opcodes.size());  // (position of flag word, witness)
+    {
+        std::map<uint32_t, Block> st = blocks;  // running len / readable per block in program order
+        for (auto &kv : st) { kv.second.len = 0; kv.second.readable = 0; }
+        for (uint32_t oi = 0; oi < c.opcodes.size(); oi++) {
+            const Opcode &o = c.opcodes[oi];
+            auto &s = p.prog;
+            p.prog_offset.push_back((uint32_t)s.size());
+            auto out = [&](uint32_t w) {
+                s.push_back(w);
+                out_slots[oi].push_back({(uint32_t)s.size(), w});
+                s.push_back(0);
+            };
+            switch (o.kind) {
+            case OP_ARITHMETIC:
+                s.push_back(PK_ARITH); s.push_back(oi);
+                emit_expr(s, pool, o.expr);
+                break;
+            case OP_BLACKBOX: {
+                const BlackBoxCall &b = *o.bb;
+                switch (b.func) {
+                case BB_RANGE:
+                    s.insert(s.end(), {PK_RANGE, oi, b.in[0][0].witness, b.in[0][0].num_bits});
+                    break;
+                case BB_AND: case BB_XOR:
+                    s.insert(s.end(), {PK_LOGIC, oi, b.func == BB_XOR ? 1u : 0u, b.in[0][0].witness, b.in[1][0].witness,
+                                       b.in[0][0].num_bits, b.in[1][0].num_bits});
+                    out(b.out[0]);
+                    break;
+                case BB_SHA256: case BB_BLAKE2S: case BB_KECCAK256: case BB_KECCAK256_VAR: case BB_HASH_TO_FIELD_128: {
+                    // [PK_HASH, oi, func, n_in, n_out, var_w (or NONE), (w, num_bits) x n_in, (out, flag) x n_out]
+                    p.prog_class[oi] = CLS_HASH;
+                    uint64_t bytes = 0;
+                    for (auto &in : b.in[0]) bytes += std::min<uint32_t>((in.num_bits + 7) / 8, 32);
+                    if (bytes > (1u << 24)) { unsupported(oi, "hash input above 16 MiB"); }
+                    p.prog_scratch[oi] = (uint32_t)((bytes + 3) / 4 + 1);
+                    s.insert(s.end(), {PK_HASH, oi, b.func, (uint32_t)b.in[0].size(), (uint32_t)b.out.size(),
+                                       b.func == BB_KECCAK256_VAR ? b.in[1][0].witness : 0xFFFFFFFFu});
+                    for (auto &in : b.in[0]) { s.push_back(in.witness); s.push_back(in.num_bits); }
+                    for (uint32_t w : b.out) out(w);
+                    break;
+                }
+                case BB_PEDERSEN:
+                    // [PK_PEDERSEN, oi, domain_separator, n_in, out_x, fx, out_y, fy, ws...]
+                    p.prog_class[oi] = CLS_GRUMPKIN;
+                    p.needs_grumpkin = true;
+                    s.insert(s.end(), {PK_PEDERSEN, oi, b.domain_separator, (uint32_t)b.in[0].size()});
+                    out(b.out[0]); out(b.out[1]);
+                    for (auto &in : b.in[0]) s.push_back(in.witness);
+                    break;
+                case BB_FIXED_BASE_SCALAR_MUL:
+                    p.prog_class[oi] = CLS_GRUMPKIN;
+                    p.needs_grumpkin = true;
+                    s.insert(s.end(), {PK_FIXED_BASE, oi, b.in[0][0].witness, b.in[1][0].witness});
+                    out(b.out[0]); out(b.out[1]);
+                    break;
+                case BB_SCHNORR_VERIFY: {
+                    // [PK_SCHNORR, oi, pkx, pky, n_sig, n_msg, out, flag, sig ws..., msg ws...]
+                    p.prog_class[oi] = CLS_GRUMPKIN;
+                    p.needs_grumpkin = true;
+                    p.prog_scratch[oi] = (uint32_t)((32 + b.in[3].size() + 3) / 4 + 1);
+                    s.insert(s.end(), {PK_SCHNORR, oi, b.in[0][0].witness, b.in[1][0].witness, (uint32_t)b.in[2].size(),
+                                       (uint32_t)b.in[3].size()});
+                    out(b.out[0]);
+                    for (auto &in : b.in[2]) s.push_back(in.witness);
+                    for (auto &in : b.in[3]) s.push_back(in.witness);
+                    break;
+                }
+                case BB_RECURSIVE_AGGREGATION: {
+                    // [PK_ZERO_OUT, oi, n_in, n_out, in ws..., (out, flag)...]; inputs in get_inputs_vec order
+                    // (black_box_function_call.rs:262-290: vk, proof, public_inputs, key_hash, input_aggregation_object?)
+                    std::vector<uint32_t> ins;
+                    for (int g = 0; g < 4; g++)
+                        for (auto &in : b.in[g]) ins.push_back(in.witness);
+                    if (b.has_in_agg)
+                        for (auto &in : b.in_agg) ins.push_back(in.witness);
+                    s.insert(s.end(), {PK_ZERO_OUT, oi, (uint32_t)ins.size(), (uint32_t)b.out.size()});
+                    s.insert(s.end(), ins.begin(), ins.end());
+                    for (uint32_t w : b.out) out(w);
+                    break;
+                }
+                default:
+                    unsupported(oi, "black box function tag " + std::to_string(b.func) + " (ECDSA)");
+                    s.insert(s.end(), {0xFFFFFFFFu, oi});
+                }
+                break;
+            }
+            case OP_DIRECTIVE: {
+                const Directive &d = *o.dir;
+                if (d.kind == DIR_QUOTIENT) {
+                    // [PK_QUOTIENT, oi, q, fq, r, fr, has_pred, E(a), E(b), E(pred)?]
+                    s.insert(s.end(), {PK_QUOTIENT, oi});
+                    out(d.q); out(d.r);
+                    s.push_back(d.has_predicate ? 1u : 0u);
+                    emit_expr(s, pool, d.a);
+                    emit_expr(s, pool, d.b);
+                    if (d.has_predicate) emit_expr(s, pool, d.predicate);
+                } else if (d.kind == DIR_TO_LE_RADIX) {
+                    // [PK_TO_LE_RADIX, oi, radix, n_out, (out, flag) x n_out, E(a)]
+                    s.insert(s.end(), {PK_TO_LE_RADIX, oi, d.radix, (uint32_t)d.bw.size()});
+                    for (uint32_t w : d.bw) out(w);
+                    emit_expr(s, pool, d.a);
+                } else {
+                    unsupported(oi, "Directive::PermutationSort");
+                    s.insert(s.end(), {0xFFFFFFFFu, oi});
+                }
+                break;
+            }
+            case OP_MEMORY_INIT: {
+                // [PK_MEM_INIT, oi, cell_base, len, ws...]
+                Block &b = st[o.block_id];
+                b.len = (uint32_t)o.init.size();
+                b.readable = std::max(b.readable, b.len);
+                s.insert(s.end(), {PK_MEM_INIT, oi, b.base, b.len});
+                s.insert(s.end(), o.init.begin(), o.init.end());
+                break;
+            }
+            case OP_MEMORY_OP: {
+                // [PK_MEM_OP, oi, cell_base, block_len, readable_len, has_pred, mode, target_w, target_flag,
+                //  E(operation), E(index), E(value), E(pred)?]; mode / target are patched in the second pass
+                Block &b = st[o.block_id];
+                s.insert(s.end(), {PK_MEM_OP, oi, b.base, b.len, b.readable, o.has_predicate ? 1u : 0u, 2u, 0xFFFFFFFFu, 0u});
+                emit_expr(s, pool, o.mem_operation);
+                emit_expr(s, pool, o.mem_index);
+                emit_expr(s, pool, o.mem_value);
+                if (o.has_predicate) emit_expr(s, pool, o.predicate);
+                break;
+            }
+            case OP_BRILLIG: {
+                // [PK_BRILLIG, oi, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap,
+                //  inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)..., E(pred)?]
+                const BrilligCall &b = *o.brillig;
+                p.prog_class[oi] = CLS_BRILLIG;
+                uint32_t bc_off = (uint32_t)p.bytecode.size();
+                uint64_t max_reg = std::max(b.inputs.size(), b.outputs.size());
+                uint64_t mem_hint = 0, arr_cells = 0;
+                auto reg = [&](uint64_t r) { if (r < 65536) max_reg = std::max<uint64_t>(max_reg, r + 1); return clamp_reg(r); };
+                for (auto &in : b.inputs) if (in.is_array) arr_cells += in.arr.size();
+                bool has_foreign = false, has_grumpkin = false;
+                uint32_t max_hash_hint = 0;
+                for (auto &op : b.bytecode) {
+                    // 8 words per instruction: [op, a, b, c, sub_op | bit_size << 8, location, const index, extra offset]
+                    uint32_t w[8] = {op.op, 0, 0, 0, 0, 0, 0, 0};
+                    switch (op.op) {
+                    case BR_BINARY_FIELD_OP: case BR_BINARY_INT_OP:
+                        w[1] = reg(op.a); w[2] = reg(op.b); w[3] = reg(op.c);
+                        w[4] = op.sub_op | (op.op == BR_BINARY_INT_OP ? std::min<uint32_t>(op.bit_size, 0xFFFFFFu) << 8 : 0u);
+                        break;
+                    case BR_JUMP_IF_NOT: case BR_JUMP_IF:
+                        w[1] = reg(op.a); w[5] = (uint32_t)std::min<uint64_t>(op.location, 0xFFFFFFFFull);
+                        break;
+                    case BR_JUMP: case BR_CALL: w[5] = (uint32_t)std::min<uint64_t>(op.location, 0xFFFFFFFFull); break;
+                    case BR_CONST: {
+                        w[1] = reg(op.a);
+                        w[6] = pool.intern(op.value);
+                        uint64_t cv[4];
+                        frh::to_canonical(op.value, cv);
+                        if (!(cv[1] | cv[2] | cv[3]) && cv[0] < 65536) mem_hint = std::max(mem_hint, cv[0]);
+                        break;
+                    }
+                    case BR_MOV: case BR_LOAD: case BR_STORE: w[1] = reg(op.a); w[2] = reg(op.b); break;
+                    case BR_BLACK_BOX: {
+                        // operands go to an extra block behind the instruction array (patched below)
+                        w[4] = op.bbop;
+                        if (op.bbop == 4 || op.bbop == 5) unsupported(oi, "Brillig ECDSA black box");
+                        if (op.bbop >= 6) has_grumpkin = true;
+                        max_hash_hint = 1;
+                        break;
+                    }
+                    case BR_FOREIGN_CALL: has_foreign = true; break;
+                    default: break;
+                    }
+                    p.bytecode.insert(p.bytecode.end(), w, w + 8);
+                }
+                // extra blocks (black box operands) after the fixed-size instruction array
+                for (size_t k = 0; k < b.bytecode.size(); k++) {
+                    const BrilligOp &op = b.bytecode[k];
+                    if (op.op != BR_BLACK_BOX) continue;
+                    // operand layout mirrors brillig/src/black_box.rs:7-53: HeapVector = (pointer reg, size reg),
+                    // HeapArray = (pointer reg, literal size), RegisterIndex = reg. n_reg_words = leading register words.
+                    static const int nwords[9] = {4, 4, 4, 3, 9, 9, 7, 5, 4};
+                    static const int n_reg_words[9] = {3, 3, 3, 3, 0, 0, 7, 4, 3};
+                    p.bytecode[bc_off + 8 * k + 7] = (uint32_t)p.bytecode.size();
+                    for (int i = 0; i < nwords[op.bbop]; i++)
+                        p.bytecode.push_back(i < n_reg_words[op.bbop] ? reg(op.bb[i]) : (uint32_t)std::min<uint64_t>(op.bb[i], 0xFFFFFFFFull));
+                }
+                if (has_foreign) unsupported(oi, "Brillig ForeignCall");
+                if (has_grumpkin) p.needs_grumpkin = true;
+                uint64_t mem_cap = arr_cells + mem_hint + 64 + (max_hash_hint ? 64 : 0);
+                if (const char *e = getenv("ACVM_BRILLIG_MEM_CELLS")) mem_cap = std::max<uint64_t>(mem_cap, strtoull(e, nullptr, 10));
+                mem_cap = std::min<uint64_t>(mem_cap, 1u << 20);
+                uint32_t n_regs = (uint32_t)std::max<uint64_t>(max_reg, 1);
+                // scratch: registers + memory cells (8 words each) + call stack (64 words) + byte staging for hashes
+                p.prog_scratch[oi] = (uint32_t)((n_regs + mem_cap) * 8 + 64 + (max_hash_hint ? mem_cap / 4 + 16 : 0));
+                s.insert(s.end(), {PK_BRILLIG, oi, b.has_predicate ? 1u : 0u, (uint32_t)b.inputs.size(), (uint32_t)b.outputs.size(), bc_off,
+                                   (uint32_t)b.bytecode.size(), n_regs, (uint32_t)mem_cap});
+                for (auto &in : b.inputs) {
+                    s.push_back(in.is_array ? 1u : 0u);
+                    s.push_back(in.is_array ? (uint32_t)in.arr.size() : 1u);
+                    if (in.is_array) for (auto &e : in.arr) emit_expr(s, pool, e);
+                    else emit_expr(s, pool, in.single);
+                }
+                for (auto &ot : b.outputs) {
+                    s.push_back(ot.is_array ? 1u : 0u);
+                    s.push_back(ot.is_array ? (uint32_t)ot.arr.size() : 1u);
+                    if (ot.is_array) for (uint32_t w : ot.arr) out(w);
+                    else out(ot.w);
+                }
+                if (b.has_predicate) emit_expr(s, pool, b.predicate);
+                break;
+            }
+            default:
+                unsupported(oi, "opcode kind " + std::to_string(o.kind));
+                s.insert(s.end(), {0xFFFFFFFFu, oi});
+            }
+        }
+    }
+    if (!p.unsupported.empty()) {
+        p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return p;
+    }
+
+    // =========================================================================== generic-instance replay + levels
+    auto assign_out = [&](uint32_t oi, uint32_t lvl) {
+        // insert_value (pwg/mod.rs:338-357) for the outputs of opcode oi, in record order
+        for (auto &slot : out_slots[oi]) {
+            uint32_t w = slot.second;
+            if (known[w]) p.prog[slot.first] = 1;  // compare, never overwrite
+            else {
+                known[w] = 1;
+                level[w] = lvl;
+                p.producer[w] = oi;
+            }
+        }
+    };
+    auto out_levels = [&](uint32_t oi, uint32_t lvl) {  // an already-assigned output is read (compared)
+        for (auto &slot : out_slots[oi])
+            if (known[slot.second]) lvl = std::max(lvl, level[slot.second]);
+        return lvl;
+    };
     for (uint32_t oi = 0; oi < c.opcodes.size() && p.truncated_at == 0xFFFFFFFFu; oi++) {
         const Opcode &o = c.opcodes[oi];
-        if (o.kind != OP_ARITHMETIC) { p.truncated_at = oi; break; }
+        if (o.kind != OP_ARITHMETIC) {
+            Reads rd(known, level);
+            uint32_t extra_level = 0;
+            uint64_t bytes_written = out_slots[oi].size();
+            switch (o.kind) {
+            case OP_BLACKBOX: {
+                const BlackBoxCall &b = *o.bb;
+                for (int g = 0; g < 4; g++)
+                    for (auto &in : b.in[g]) rd.witness(in.witness);
+                if (b.has_in_agg)
+                    for (auto &in : b.in_agg) rd.witness(in.witness);
+                break;
+            }
+            case OP_DIRECTIVE: {
+                const Directive &d = *o.dir;
+                rd.expr(d.a);
+                if (d.kind == DIR_QUOTIENT) { rd.expr(d.b); if (d.has_predicate) rd.expr(d.predicate); }
+                break;
+            }
+            case OP_MEMORY_INIT: {
+                Block &b = blocks[o.block_id];
+                for (uint32_t w : o.init) rd.witness(w);
+                extra_level = b.level;
+                bytes_written = o.init.size();
+                break;
+            }
+            case OP_MEMORY_OP: {
+                Block &b = blocks[o.block_id];
+                rd.expr(o.mem_operation);
+                rd.expr(o.mem_index);
+                if (o.has_predicate) rd.expr(o.predicate);
+                extra_level = b.level;
+                // read or write is decided by the VALUE of `operation` (memory_op.rs:91); static only if it is a constant
+                uint32_t off = p.prog_offset[oi];
+                const Expr &op = o.mem_operation;
+                bool is_const = op.mul.empty() && op.lin.empty();
+                if (!is_const) { rd.ok = false; break; }
+                if (op.qc.is_zero()) {
+                    // read: Expression::to_witness (expression/mod.rs:158-172) on the evaluated value expression
+                    const Expr &v = o.mem_value;
+                    bool shape = v.mul.empty() && v.lin.size() == 1 && v.lin[0].c == frh::one() && v.qc.is_zero() &&
+                                 v.lin[0].w < known.size() && !known[v.lin[0].w];
+                    if (!shape) { rd.ok = false; break; }
+                    p.prog[off + 6] = 1;
+                    p.prog[off + 7] = v.lin[0].w;
+                    out_slots[oi].push_back({off + 8, v.lin[0].w});
+                    bytes_written = 1;
+                } else {
+                    rd.expr(o.mem_value);
+                    p.prog[off + 6] = 0;
+                    bytes_written = 1;
+                }
+                break;
+            }
+            case OP_BRILLIG: {
+                const BrilligCall &b = *o.brillig;
+                if (b.has_predicate) rd.expr(b.predicate);
+                for (auto &in : b.inputs) {
+                    if (in.is_array) for (auto &e : in.arr) rd.expr(e);
+                    else rd.expr(in.single);
+                }
+                break;
+            }
+            default: rd.ok = false;
+            }
+            if (!rd.ok) { p.truncated_at = oi; break; }
+            uint32_t lvl = std::max(rd.lvl, extra_level);
+            lvl = out_levels(oi, lvl) + 1;
+            assign_out(oi, lvl);
+            if (o.kind == OP_MEMORY_INIT || o.kind == OP_MEMORY_OP) blocks[o.block_id].level = lvl;
+            uint64_t bytes = 32ull * (rd.distinct() + bytes_written);
+            p.algorithmic_bytes += bytes;
+            p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
+            p.n_other_records++;
+            records.push_back({lvl, p.prog_class[oi], oi});
+            continue;
+        }
         const Expr &e = o.expr;
         // classify terms like ArithmeticSolver::evaluate (arithmetic.rs:212-239) for the generic instance
         struct Prod { FrH c; uint32_t a, b; };
@@ -129,7 +496,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             break;
         }
         PendingGate g;
-        g.opcode = oi;
         uint32_t lvl = 0;
         std::vector<uint32_t> reads;
         auto rd = [&](uint32_t w) { lvl = std::max(lvl, level[w]); reads.push_back(w); };
@@ -140,7 +506,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         bool scaled = false;
         if (n_unknown == 1) {
             // out = -(sum)/coeff (arithmetic.rs:120) or -(sum)/(c*partner) (:86): fold -1/coeff into every coefficient
-            scale = frh::neg(frh::inverse(unk_coef));
+            scale = pool.neg_inv(unk_coef);
             scaled = true;
             if (unk_is_folded) { kind = GATE_SOLVE_DYN; rd(unk_partner); }
             else kind = GATE_SOLVE;
@@ -180,26 +546,39 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         gates.push_back(std::move(g));
     }
 
-    // ---- order by (level, program order) and lay out
+    // =========================================================================== order by (level, program order), lay out
     std::stable_sort(gates.begin(), gates.end(), [](const PendingGate &a, const PendingGate &b) { return a.level < b.level; });
+    std::stable_sort(records.begin(), records.end(), [](const PendingRecord &a, const PendingRecord &b) { return a.level < b.level; });
     uint32_t max_level = 0;
     for (auto &g : gates) max_level = std::max(max_level, g.level);
+    for (auto &r : records) max_level = std::max(max_level, r.level);
+    p.n_levels = max_level;
     p.level_start.assign(max_level + 1, 0);
     p.dyn_level_start.assign(max_level + 1, 0);
-    size_t gi = 0;
+    for (int k = 0; k < N_CLS; k++) p.cls_level_start[k].assign(max_level + 1, 0);
+    size_t gi = 0, ri = 0;
+    std::vector<uint32_t> width(max_level + 1, 0);
     for (uint32_t L = 1; L <= max_level; L++) {
         p.level_start[L - 1] = (uint32_t)p.gate_offset.size();
         p.dyn_level_start[L - 1] = (uint32_t)p.dyn_offset.size();
+        for (int k = 0; k < N_CLS; k++) p.cls_level_start[k][L - 1] = (uint32_t)p.cls_offset[k].size();
         for (; gi < gates.size() && gates[gi].level == L; gi++) {
             bool dyn = (gates[gi].words[0] & 0xff) == GATE_SOLVE_DYN;
             (dyn ? p.dyn_offset : p.gate_offset).push_back((uint32_t)p.gate_stream.size());
             p.gate_stream.insert(p.gate_stream.end(), gates[gi].words.begin(), gates[gi].words.end());
+            width[L]++;
+        }
+        for (; ri < records.size() && records[ri].level == L; ri++) {
+            const PendingRecord &r = records[ri];
+            p.cls_offset[r.cls].push_back(p.prog_offset[r.opcode]);
+            p.cls_scratch[r.cls].push_back(p.prog_scratch[r.opcode]);
+            width[L]++;
         }
     }
     p.level_start[max_level] = (uint32_t)p.gate_offset.size();
     p.dyn_level_start[max_level] = (uint32_t)p.dyn_offset.size();
-    for (size_t l = 0; l + 1 < p.level_start.size(); l++)
-        p.max_level_width = std::max(p.max_level_width, p.level_start[l + 1] - p.level_start[l] + p.dyn_level_start[l + 1] - p.dyn_level_start[l]);
+    for (int k = 0; k < N_CLS; k++) p.cls_level_start[k][max_level] = (uint32_t)p.cls_offset[k].size();
+    for (uint32_t L = 1; L <= max_level; L++) p.max_level_width = std::max(p.max_level_width, width[L]);
     p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return p;
 }

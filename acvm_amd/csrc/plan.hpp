@@ -1,57 +1,82 @@
 // plan.hpp -- static plan of one circuit against one set of initially-assigned witnesses.
 //
 // The reference interprets opcodes in program order per instance (acvm/src/pwg/mod.rs:236-303). Which
-// witness an Arithmetic opcode solves depends only on WHICH witnesses are assigned, except for the
-// zero-coefficient drop in ArithmeticSolver::evaluate (arithmetic.rs:217-221). The planner replays the
-// assigned-set bookkeeping once ("generic" instance: no known multiplicand of an unknown is zero), folds
-// every constant divisor (-(sum / coeff), arithmetic.rs:56,86,120) into the gate's coefficients and
-// levelises the dependency DAG. Instances that leave the generic path are detected on the device
-// (event word) and re-solved by the exact in-order kernel.
+// witness an opcode assigns depends only on WHICH witnesses are assigned, except for the zero-coefficient
+// drop in ArithmeticSolver::evaluate (arithmetic.rs:217-221). The planner replays the assigned-set
+// bookkeeping once ("generic" instance: no known multiplicand of an unknown is zero, every opcode succeeds),
+// folds every constant divisor (-(sum / coeff), arithmetic.rs:56,86,120) into the gate's coefficients and
+// levelises the dependency DAG (memory blocks are chained in program order). Instances that leave the generic
+// path -- a failing opcode included -- are detected on the device (event word) and re-solved by the exact
+// in-order kernels from the event opcode on.
+//
+// Two device programs come out of it:
+//   * the in-order program `prog`: one record per opcode, original expressions, executed by the exact
+//     kernels (ExactPolicy) and, for every non-Arithmetic opcode, also by the level kernels (FastPolicy);
+//   * the folded gate stream of the Arithmetic opcodes for arith_level_kernel / arith_dyn_level_kernel.
 #pragma once
 #include "circuit.hpp"
 #include <vector>
 
 namespace acvm {
 
-// coefficient encoding inside the gate stream
+// coefficient encoding inside the streams
 static constexpr uint32_t COEF_ONE = 0xFFFFFFFFu;
 static constexpr uint32_t COEF_MINUS_ONE = 0xFFFFFFFEu;
-static constexpr uint32_t COEF_ZERO = 0xFFFFFFFDu;  // only for the constant term
+static constexpr uint32_t COEF_ZERO = 0xFFFFFFFDu;  // only for the constant term / dropped terms
 
 enum GateKind : uint32_t { GATE_ASSERT = 0, GATE_SOLVE = 1, GATE_SOLVE_DYN = 2 };
 
-// Gate record in the u32 stream:
+// Gate record in the u32 stream (arith level kernels):
 //  w0 = kind | n_prod << 8 | n_lin << 16
 //  w1 = opcode index (program order)      w2 = output witness slot (SOLVE*)
 //  w3 = constant term (coef encoding)     w4 = denominator witness slot (SOLVE_DYN)
 //  then n_prod x {coef, a, b}, n_lin x {coef, a}
 static constexpr uint32_t GATE_HDR_WORDS = 5;
 
+// record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
+enum ProgKind : uint32_t {
+    PK_ARITH = 0, PK_RANGE = 1, PK_LOGIC = 2, PK_HASH = 3, PK_PEDERSEN = 4, PK_FIXED_BASE = 5, PK_SCHNORR = 6, PK_ZERO_OUT = 7,
+    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12
+};
+// kernel classes of the non-arithmetic records
+enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, N_CLS = 4 };
+
 struct Plan {
     uint32_t n_witnesses = 0;
     uint32_t n_opcodes = 0;
     std::vector<uint32_t> initial_ids;
-    // device program
+    // ---- arithmetic level program
     std::vector<uint32_t> gate_stream;          // all gate records
     std::vector<uint32_t> gate_offset;          // per scheduled ASSERT/SOLVE gate: offset into gate_stream (level-major)
     std::vector<uint32_t> level_start;          // size n_levels + 1, indexes gate_offset
     std::vector<uint32_t> dyn_offset;           // per scheduled SOLVE_DYN gate (needs a per-instance inversion), level-major
     std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
-    // bookkeeping for export / failure masking
-    std::vector<uint32_t> producer;             // per witness: opcode index that assigns it, 0xFFFFFFFF if none,
+    // ---- in-order program: one record per opcode
+    std::vector<uint32_t> prog;
+    std::vector<uint32_t> prog_offset;          // per opcode
+    std::vector<uint8_t> prog_class;            // per opcode: OpClass (Arithmetic = CLS_LIGHT)
+    std::vector<uint32_t> prog_scratch;         // per opcode: u32 words of per-instance scratch the record needs
+    // ---- non-arithmetic level program: per class, offsets into `prog` (level-major) + per-record scratch words
+    std::vector<uint32_t> cls_offset[N_CLS];
+    std::vector<uint32_t> cls_scratch[N_CLS];
+    std::vector<uint32_t> cls_level_start[N_CLS];  // size n_levels + 1
+    uint32_t n_levels = 0;
+    uint32_t mem_cells = 0;                     // cells of the per-instance memory table (all blocks)
+    std::vector<uint32_t> bytecode;             // Brillig programs (see plan.cpp emit_brillig)
+    // ---- bookkeeping for export / failure masking
+    std::vector<uint32_t> producer;             // per witness: opcode index that first assigns it, 0xFFFFFFFF if none,
                                                 // 0xFFFFFFFE if initial
-    // first opcode that the level kernels cannot execute for the generic instance (static failure or an opcode
-    // kind not yet on the fast path); 0xFFFFFFFF if the whole circuit is covered
+    // first opcode that the level kernels cannot execute for the generic instance (static failure); every instance
+    // is handed to the exact kernels from there. 0xFFFFFFFF if the whole circuit is covered
     uint32_t truncated_at = 0xFFFFFFFFu;
     // statistics
-    uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0;
+    uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0, n_other_records = 0;
     uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
+    uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0};
     double plan_ms = 0;
-    // in-order program for the exact kernel: per opcode offset into `slow_stream`
-    std::vector<uint32_t> slow_stream;
-    std::vector<uint32_t> slow_offset;
-    std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements yet
+    std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
+    bool needs_grumpkin = false;
 };
 
 Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial);

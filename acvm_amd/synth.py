@@ -126,3 +126,41 @@ def witness_batch(B, n_in=16, seed=0xAC1D0002, edge_cases=True, first_instance=0
             elif g == 7:
                 out[idx, :] = out[idx, 0]  # all inputs equal
     return out.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ other configs
+def be32(x: int) -> bytes:
+    return int(x % (1 << 256)).to_bytes(32, "big")
+
+
+def values_from_rows(rows) -> bytes:
+    """rows: per instance, list of ints (one per initial witness, in id order) -> [B][n][32] big-endian bytes."""
+    return b"".join(be32(v) for row in rows for v in row)
+
+
+def hash_circuit(n_msg=64, with_range=True):
+    """BASELINE config 3: n_msg byte-witnesses -> SHA256 -> 32 outputs; those 32 bytes + 32 more inputs ->
+    Keccak256 (64-byte message) -> 32 outputs; RANGE(8) on every input byte. Returns (Circuit, input ids)."""
+    from .acir import BlackBoxFuncCall as BB, FunctionInput as FI
+    n_in = n_msg + 32
+    ids = list(range(1, n_in + 1))
+    ops = []
+    if with_range:
+        ops += [BB("RANGE", {"input": FI(w, 8)}) for w in ids]
+    sha_out = list(range(n_in + 1, n_in + 33))
+    kec_out = list(range(n_in + 33, n_in + 65))
+    ops.append(BB("SHA256", {"inputs": [FI(w, 8) for w in ids[:n_msg]], "outputs": sha_out}))
+    ops.append(BB("Keccak256", {"inputs": [FI(w, 8) for w in sha_out + ids[n_msg:]], "outputs": kec_out}))
+    circ = Circuit(current_witness_index=kec_out[-1], opcodes=ops, private_parameters=ids, return_values=kec_out)
+    return circ, ids
+
+
+def byte_batch(B, n_in, seed=0xAC1D0003, first_instance=0):
+    """[B][n_in][32]: uniform bytes as field elements."""
+    with np.errstate(over="ignore"):
+        j = (np.arange(B, dtype=np.uint64) + np.uint64(first_instance))[:, None]
+        k = np.arange(n_in, dtype=np.uint64)[None, :]
+        v = _splitmix_vec(np.uint64(seed) ^ ((j << np.uint64(20)) | k))
+    out = np.zeros((B, n_in, 32), dtype=np.uint8)
+    out[:, :, 31] = (v & np.uint64(0xFF)).astype(np.uint8)
+    return out.tobytes()

@@ -1,0 +1,229 @@
+"""GPU parity of every non-arithmetic opcode kind against the CPU oracle (bit-exact: status, error kind, failing
+opcode, aux values, assigned set, every witness value), through the level kernels AND through the exact in-order
+kernels (force_slow), including the failure / edge cases the reference tests exercise."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from acvm_amd.acir import (P, BlackBoxFuncCall as BB, Brillig, Circuit, Expression as E, FunctionInput as FI, MemoryInit,
+                           MemoryOp, QuotientDirective, ToLeRadix)
+from acvm_amd.synth import values_from_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(oracle, circ, ids, rows, force_slow=False):
+    import acvm_amd
+    B = len(rows)
+    values = values_from_rows(rows)
+    data = circ.to_bytes()
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, values, B)
+    batch = acvm_amd.Batch(acvm_amd.Circuit(data), B, ids)
+    batch.set_force_slow_path(force_slow)
+    batch.set_initial_witness(values)
+    batch.solve()
+    gres = batch.results()
+    gasg, gvals = batch.witness_map()
+    stats = batch.stats()
+    batch.free()
+    for j in range(B):
+        assert gres[j].as_tuple() == ores[j].as_tuple(), f"instance {j}: gpu {gres[j].as_tuple()} oracle {ores[j].as_tuple()} (slow={force_slow})"
+        if ores[j].message:
+            assert gres[j].message == ores[j].message, (j, gres[j].message, ores[j].message)
+    nw = min(oasg.shape[1], gasg.shape[1])
+    assert np.array_equal(oasg[:, :nw], gasg[:, :nw]), f"assigned sets differ (slow={force_slow})"
+    bad = np.argwhere((ovals[:, :nw] != gvals[:, :nw]).any(axis=2))
+    assert bad.size == 0, f"witness values differ at (instance, witness) {bad[:8].tolist()} (slow={force_slow})"
+    return ores, stats
+
+
+def both_paths(oracle, circ, ids, rows):
+    ores, stats = run_both(oracle, circ, ids, rows, force_slow=False)
+    run_both(oracle, circ, ids, rows, force_slow=True)
+    return ores, stats
+
+
+def rnd(seed):
+    return random.Random(seed)
+
+
+def test_range_and_logic(oracle):
+    r = rnd(1)
+    ops = [BB("RANGE", {"input": FI(1, 8)}), BB("RANGE", {"input": FI(2, 64)}), BB("RANGE", {"input": FI(3, 254)}),
+           BB("AND", {"lhs": FI(1, 8), "rhs": FI(2, 8), "output": 5}), BB("XOR", {"lhs": FI(2, 64), "rhs": FI(3, 64), "output": 6}),
+           BB("XOR", {"lhs": FI(3, 254), "rhs": FI(4, 254), "output": 7}), BB("AND", {"lhs": FI(3, 256), "rhs": FI(4, 256), "output": 8}),
+           BB("AND", {"lhs": FI(3, 13), "rhs": FI(4, 13), "output": 9}), BB("XOR", {"lhs": FI(4, 0), "rhs": FI(3, 0), "output": 10})]
+    circ = Circuit(10, ops)
+    rows = []
+    for j in range(96):
+        a, b = r.randrange(256), r.randrange(1 << 64)
+        rows.append([a, b, r.randrange(P), r.randrange(P)])
+    rows[3][0] = 256            # RANGE(8) fails at opcode 0
+    rows[4][1] = 1 << 64        # RANGE(64) fails at opcode 1
+    rows[5][2] = P - 1          # 254 bits: passes
+    rows[6] = [255, (1 << 64) - 1, P - 1, P - 1]
+    rows[7] = [0, 0, 0, 0]
+    ores, _ = both_paths(oracle, circ, [1, 2, 3, 4], rows)
+    assert ores[3].status == 2 and ores[3].opcode_index == 0 and ores[4].opcode_index == 1 and ores[5].status == 0
+
+
+def test_logic_bit_mismatch_panics(oracle):
+    circ = Circuit(3, [BB("AND", {"lhs": FI(1, 8), "rhs": FI(2, 16), "output": 3})])
+    ores, _ = both_paths(oracle, circ, [1, 2], [[1, 2]] * 3)
+    assert ores[0].err == oracle.E_PANIC
+
+
+def test_output_conflict_and_missing_input(oracle):
+    # witness 3 is an input AND the output of XOR: insert_value conflict unless equal (pwg/mod.rs:338-357)
+    circ = Circuit(4, [BB("XOR", {"lhs": FI(1, 8), "rhs": FI(2, 8), "output": 3}), BB("RANGE", {"input": FI(4, 8)})])
+    rows = [[5, 3, 6], [5, 3, 7], [0, 0, 0]]
+    ores, _ = both_paths(oracle, circ, [1, 2, 3], rows)
+    assert ores[0].err == oracle.E_MISSING_ASSIGNMENT and ores[0].opcode_index == 1  # 5^3 == 6 passes, then w4 missing
+    assert ores[1].err == oracle.E_UNSATISFIED and ores[1].opcode_index == 0
+
+
+def test_directives(oracle):
+    r = rnd(2)
+    ops = [QuotientDirective(E.from_witness(1), E.from_witness(2), 4, 5),
+           QuotientDirective(E([(1, 1, 2)], [(3, 1)], 7), E([], [(1, 2), (1, 3)], 0), 6, 7, predicate=E.from_witness(3)),
+           ToLeRadix(E.from_witness(1), list(range(8, 8 + 32)), 256),
+           ToLeRadix(E.from_witness(2), list(range(40, 40 + 8)), 2),
+           ToLeRadix(E([], [(1, 2), (1, 3)], 5), list(range(48, 48 + 6)), 10),
+           ToLeRadix(E.from_witness(3), list(range(54, 54 + 3)), 16)]
+    circ = Circuit(57, ops)
+    rows = []
+    for j in range(64):
+        rows.append([r.randrange(P), r.randrange(256), r.randrange(2) * r.randrange(1 << 12)])
+    rows[0] = [P - 1, 0, 0]           # division by zero -> (0, 0)
+    rows[1] = [12345, 7, 1]
+    rows[2] = [0, 255, 4095]
+    rows[3] = [P - 1, 256, 1]         # radix 2 with 9 bits > 8 outputs -> Unsatisfied
+    rows[4] = [5, 200, 999999]        # radix 10 needs 7 digits > 6 outputs; radix 16 too
+    rows[5] = [1 << 200, 1, 4096]     # radix 16 needs 4 digits > 3
+    both_paths(oracle, circ, [1, 2, 3], rows)
+
+
+def test_memory_ops(oracle):
+    r = rnd(3)
+    n = 6
+    init_ws = list(range(1, n + 1))                 # inputs 1..6 = cells, 7 = index, 8 = predicate, 9 = value
+    ops = [MemoryInit(0, init_ws),
+           MemoryOp(0, E.constant(0), E.from_witness(7), E.from_witness(10)),                       # read  w10 = m[w7]
+           MemoryOp(0, E.constant(1), E([], [(1, 7)], 1), E.from_witness(9), predicate=E.from_witness(8)),  # m[w7+1] = w9 if w8
+           MemoryOp(0, E.constant(0), E([], [(1, 7)], 1), E.from_witness(11)),                      # read  w11 = m[w7+1]
+           MemoryOp(0, E.constant(0), E.constant(2), E.from_witness(12), predicate=E.from_witness(8)),  # w12 = m[2] or 0
+           MemoryInit(1, [10, 11]),
+           MemoryOp(1, E.constant(1), E.constant(0), E([(1, 10, 11)], [(2, 12)], 3)),               # m1[0] = w10*w11+2*w12+3
+           MemoryOp(1, E.constant(0), E.constant(0), E.from_witness(13)),
+           E([(1, 13, 13)], [(-1 % P, 14)], 0)]                                                      # w14 = w13^2
+    circ = Circuit(14, ops)
+    rows = []
+    for j in range(80):
+        rows.append([r.randrange(P) for _ in range(n)] + [r.randrange(n - 1), r.randrange(2), r.randrange(P)])
+    rows[0][6] = n - 1      # read ok, write index n -> IndexOutOfBounds when predicate set
+    rows[0][7] = 1
+    rows[1][6] = n - 1      # predicate 0: write skipped, the following read at n fails
+    rows[1][7] = 0
+    rows[2][6] = n + 3      # first read out of bounds
+    rows[3][6] = 1 << 70    # index does not fit u64 -> panic
+    rows[4][6] = (1 << 32) + 1  # `as u32` wraps to 1
+    ores, stats = both_paths(oracle, circ, list(range(1, 10)), rows)
+    assert ores[0].err == oracle.E_INDEX_OOB and ores[2].err == oracle.E_INDEX_OOB and ores[3].err == oracle.E_PANIC
+
+
+def test_memory_exact_replay_after_later_write(oracle):
+    """An instance that fails AFTER a memory write at an EARLIER level must see the pre-write cell again when the exact
+    path resumes at its event: the event opcode sits before the read in program order."""
+    ops = [MemoryInit(0, [1, 2]),
+           BB("RANGE", {"input": FI(3, 8)}),                                       # event for instances with w3 >= 256
+           MemoryOp(0, E.constant(0), E.constant(0), E.from_witness(5)),          # w5 = m[0]
+           MemoryOp(0, E.constant(1), E.constant(0), E.from_witness(4)),          # m[0] = w4
+           MemoryOp(0, E.constant(0), E.constant(0), E.from_witness(6))]          # w6 = m[0]
+    circ = Circuit(6, ops)
+    rows = [[11, 22, 5, 99], [11, 22, 300, 99], [1, 2, 255, 3]]
+    both_paths(oracle, circ, [1, 2, 3, 4], rows)
+
+
+def test_recursive_aggregation_zero_fill(oracle):
+    circ = Circuit(8, [BB("RecursiveAggregation", {"verification_key": [FI(1, 254)], "proof": [FI(2, 254)], "public_inputs": [FI(3, 254)],
+                                                   "key_hash": FI(4, 254), "input_aggregation_object": None,
+                                                   "output_aggregation_object": [5, 6, 7, 8]})])
+    both_paths(oracle, circ, [1, 2, 3, 4], [[1, 2, 3, 4], [0, 0, 0, 0]])
+
+
+def _hash_rows(r, B, n):
+    return [[r.randrange(256) for _ in range(n)] for _ in range(B)]
+
+
+@pytest.mark.parametrize("name,n", [("SHA256", 0), ("SHA256", 3), ("SHA256", 55), ("SHA256", 56), ("SHA256", 64), ("SHA256", 119), ("SHA256", 200),
+                                    ("Blake2s", 0), ("Blake2s", 1), ("Blake2s", 64), ("Blake2s", 65), ("Blake2s", 130),
+                                    ("Keccak256", 0), ("Keccak256", 1), ("Keccak256", 135), ("Keccak256", 136), ("Keccak256", 137), ("Keccak256", 300)])
+def test_hash_opcodes(oracle, name, n):
+    r = rnd(100 + n)
+    ids = list(range(1, n + 1))
+    outs = list(range(n + 1, n + 33))
+    circ = Circuit(n + 32, [BB(name, {"inputs": [FI(w, 8) for w in ids], "outputs": outs})])
+    rows = _hash_rows(r, 70, n)
+    ores, _ = both_paths(oracle, circ, ids, rows)
+    # independent anchor: hashlib for sha256 / blake2s
+    if name in ("SHA256", "Blake2s") and n:
+        import acvm_amd
+        data = circ.to_bytes()
+        batch = acvm_amd.Batch(acvm_amd.Circuit(data), len(rows), ids)
+        batch.set_initial_witness(values_from_rows(rows))
+        batch.solve()
+        _, vals = batch.witness_map()
+        h = hashlib.sha256 if name == "SHA256" else hashlib.blake2s
+        for j in (0, 33, 69):
+            assert bytes(vals[j, n + 1:n + 33, 31]) == h(bytes(rows[j])).digest()
+
+
+def test_hash_mixed_widths_and_field_inputs(oracle):
+    """fetch_nearest_bytes with num_bits != 8: multi-byte little-endian packing, truncation of wide values."""
+    r = rnd(7)
+    widths = [1, 8, 9, 16, 31, 32, 64, 128, 254, 256, 7, 24]
+    n = len(widths)
+    ids = list(range(1, n + 1))
+    ops = [BB("SHA256", {"inputs": [FI(w, b) for w, b in zip(ids, widths)], "outputs": list(range(20, 52))}),
+           BB("HashToField128Security", {"inputs": [FI(w, b) for w, b in zip(ids, widths)], "output": 60}),
+           BB("Keccak256", {"inputs": [FI(w, b) for w, b in zip(ids, widths)], "outputs": list(range(70, 102))})]
+    circ = Circuit(101, ops)
+    rows = [[r.randrange(P) for _ in range(n)] for _ in range(66)]
+    both_paths(oracle, circ, ids, rows)
+
+
+def test_keccak_variable_length(oracle):
+    r = rnd(8)
+    n = 150
+    ids = list(range(1, n + 2))  # last input = var_message_size
+    circ = Circuit(n + 40, [BB("Keccak256VariableLength", {"inputs": [FI(w, 8) for w in ids[:n]], "var_message_size": FI(n + 1, 32),
+                                                           "outputs": list(range(n + 2, n + 34))})])
+    rows = [[r.randrange(256) for _ in range(n)] + [r.randrange(n + 1)] for _ in range(70)]
+    rows[0][-1] = 0
+    rows[1][-1] = n
+    rows[2][-1] = n + 1          # more than the message -> BlackBoxFunctionFailed
+    rows[3][-1] = 135
+    rows[4][-1] = 136
+    rows[5][-1] = (1 << 64) + 5  # `to_u128() as usize` truncates to 5
+    rows[6][-1] = 1 << 40
+    ores, _ = both_paths(oracle, circ, ids, rows)
+    assert ores[2].err == oracle.E_BLACKBOX_FAILED and ores[6].err == oracle.E_BLACKBOX_FAILED and ores[5].status == 0
+
+
+def test_hash_wrong_output_count(oracle):
+    circ = Circuit(40, [BB("SHA256", {"inputs": [FI(1, 8)], "outputs": list(range(2, 33))})])
+    ores, _ = both_paths(oracle, circ, [1], [[3], [4]])
+    assert ores[0].err == oracle.E_BLACKBOX_FAILED
+
+
+def test_config3_hash_circuit(oracle):
+    from acvm_amd import synth
+    circ, ids = synth.hash_circuit()
+    B = 300
+    values = synth.byte_batch(B, len(ids))
+    rows = [[int.from_bytes(values[(j * len(ids) + k) * 32:(j * len(ids) + k + 1) * 32], "big") for k in range(len(ids))] for j in range(B)]
+    rows[5][3] = 256  # a RANGE(8) failure
+    ores, stats = both_paths(oracle, circ, ids, rows)
+    assert ores[5].status == 2 and ores[4].status == 0

@@ -21,7 +21,7 @@ STATUS_SOLVED, STATUS_IN_PROGRESS, STATUS_FAILURE, STATUS_REQUIRES_FOREIGN_CALL 
 # every symbol include/acvm_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "acvm_last_error", "acvm_abi_version", "acvm_device_count", "acvm_set_device", "acvm_device_synchronize",
-    "acvm_device_arch", "acvm_selftest", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
+    "acvm_device_arch", "acvm_selftest", "acvm_debug_grumpkin", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
     "acvm_circuit_num_witnesses", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
     "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_reset", "acvm_batch_set_force_slow_path",
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
@@ -69,6 +69,7 @@ def lib():
     L.acvm_last_error.restype = C.c_char_p
     L.acvm_device_arch.argtypes = [C.c_char_p, C.c_size_t]
     L.acvm_selftest.argtypes = [C.c_uint32, C.c_uint64]
+    L.acvm_debug_grumpkin.argtypes = [C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]
     L.acvm_circuit_from_bytes.restype = C.c_void_p
     L.acvm_circuit_from_bytes.argtypes = [C.c_char_p, C.c_size_t]
     L.acvm_circuit_free.argtypes = [C.c_void_p]
@@ -119,6 +120,14 @@ def device_arch():
     buf = C.create_string_buffer(64)
     _check(lib().acvm_device_arch(buf, 64))
     return buf.value.decode()
+
+
+def debug_grumpkin(what, param, inputs=()):
+    """Component probe of the Grumpkin kernels (see include/acvm_amd.h); returns (x, y) as ints."""
+    out = C.create_string_buffer(64)
+    data = b"".join(int(v).to_bytes(32, "big") for v in inputs)
+    _check(lib().acvm_debug_grumpkin(what, param, data, len(inputs), out))
+    return int.from_bytes(out.raw[:32], "big"), int.from_bytes(out.raw[32:], "big")
 
 
 class Circuit:

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacvm_amd.so")
-SOURCES = ["circuit.cpp", "plan.cpp", "batch.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_stub.hip"]
+SOURCES = ["circuit.cpp", "plan.cpp", "batch.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_grumpkin.hip", "grumpkin_host.cpp", "kernels_stub.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
          "-ffp-contract=off"]
@@ -30,18 +30,25 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     objs = []
+    jobs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".inc")))
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "acvm_amd.h")))
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(HERE, "build", s + ".o")
-        hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h")))
-        hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "acvm_amd.h")))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
         objs.append(obj)
+    if jobs:  # translation units are independent: compile them concurrently
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 6)) as ex:
+            list(ex.map(run, jobs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd))

@@ -133,6 +133,33 @@ int acvm_selftest(uint32_t n, uint64_t seed) {
     return (int)h;
 }
 
+// Component probes of the Grumpkin kernels for the parity tests: what = 0 host table point (param = table << 24 | index),
+// 1 device hash_single(in[0], parity = param), 2 device hash-ladder compress(in[0..n_in)), 3 device fixed_base_mul(table
+// base param, integer in[0]), 4 device table point. in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian.
+int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64) {
+    if (!out_be64) return set_err(ACVM_E_INVALID, "null argument");
+    if (what == 0) return grumpkin_host_point(param >> 24, param & 0xffffffu, out_be64) ? 0 : set_err(ACVM_E_INVALID, "bad table index");
+    const GrumpkinTables *t = grumpkin_tables();
+    if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+    std::vector<uint32_t> in(8 * (n_in ? n_in : 1), 0), out(16, 0);
+    for (uint32_t i = 0; i < n_in; i++)
+        for (int k = 0; k < 32; k++) in[8 * i + k / 4] |= (uint32_t)in_be32[32 * i + 31 - k] << (8 * (k % 4));
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_in, in.size() * 4));
+    HIPCHK(hipMalloc((void **)&d_out, 64));
+    HIPCHK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_out, 0, 64));
+    launch_grumpkin_probe(nullptr, *t, what, param, d_in, n_in, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out.data(), d_out, 64, hipMemcpyDeviceToHost));
+    hipFree(d_in);
+    hipFree(d_out);
+    for (int c = 0; c < 2; c++)
+        for (int k = 0; k < 32; k++) out_be64[32 * c + 31 - k] = (uint8_t)(out[8 * c + k / 4] >> (8 * (k % 4)));
+    return 0;
+}
+
 acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) {
     if (!bytes) { set_err(ACVM_E_INVALID, "null circuit bytes"); return nullptr; }
     if (!frh::self_check()) { set_err(ACVM_E_INVALID, "field constants self-check failed"); return nullptr; }
@@ -217,10 +244,11 @@ static int batch_init(acvm_batch *b) {
     b->dp.consts = b->d_consts;
     b->dp.bytecode = b->d_bytecode;
     b->dp.Mem = b->d_Mem;
-    b->dp.grumpkin = nullptr;
+    b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr};
     if (p.needs_grumpkin) {
-        b->dp.grumpkin = grumpkin_tables_device();
-        if (!b->dp.grumpkin) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+        const GrumpkinTables *t = grumpkin_tables();
+        if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+        b->dp.grumpkin = *t;
     }
     b->n_words = (p.n_witnesses + 31) / 32;
     if (int rc = upload(&b->d_producer, p.producer)) return rc;

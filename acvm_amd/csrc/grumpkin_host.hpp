@@ -1,0 +1,25 @@
+// grumpkin_host.hpp -- lookup tables of the Grumpkin kernels (built once on the host, see grumpkin_host.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace acvm {
+
+static constexpr uint32_t GRUMPKIN_N_GENERATORS = 30;
+static constexpr uint32_t GRUMPKIN_PED_ENTRIES = 512;     // k * D[i], k = 1..512
+static constexpr uint32_t GRUMPKIN_N_WINDOW_BASES = 4;    // G, D[0], D[3], D[6]
+static constexpr uint32_t GRUMPKIN_WIN_STRIDE = 32 * 255; // points per base: T[w][d-1] = d * 2^(8w) * P
+
+// device pointers; one affine point = 4 x uint4 (x limbs 0..7, y limbs 0..7, Montgomery form)
+struct GrumpkinTables {
+    const uint4 *ped;    // [30][512]
+    const uint4 *win;    // [4][32][255]
+    const uint4 *small;  // [3][15]: k * D[3j+1], k = 1..15
+    const uint4 *skew;   // [3]: D[3j+2]
+};
+
+// tables of the current device (built on first use), nullptr on failure
+const GrumpkinTables *grumpkin_tables();
+bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]);
+
+}  // namespace acvm

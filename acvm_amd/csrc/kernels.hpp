@@ -1,5 +1,6 @@
 // kernels.hpp -- host-visible launchers of the gfx950 kernels (kernels*.hip).
 #pragma once
+#include "grumpkin_host.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,11 +30,8 @@ struct DeviceProgram {
     const uint32_t *consts;       // circuit constants, 8 x u32 Montgomery each
     const uint32_t *bytecode;     // Brillig programs
     uint4 *Mem;                   // per-instance memory blocks, laid out like W
-    const void *grumpkin;         // GrumpkinTables (device), nullptr if the circuit has no Grumpkin opcode
+    GrumpkinTables grumpkin;      // device lookup tables (null pointers if the circuit has no Grumpkin opcode)
 };
-
-// Grumpkin lookup tables of the current device (built once per process and device), nullptr on failure
-const void *grumpkin_tables_device();
 
 void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in);
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
@@ -67,6 +65,7 @@ void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram
 void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
 void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
 void launch_exact_brillig(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
+void launch_grumpkin_probe(hipStream_t s, const GrumpkinTables &T, uint32_t what, uint32_t param, const uint32_t *in, uint32_t n_in, uint32_t *out);
 // InProgress -> Solved after the last opcode
 void launch_exact_finish(hipStream_t s, const ExactLanes &L);
 

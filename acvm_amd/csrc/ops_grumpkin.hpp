@@ -1,0 +1,349 @@
+// ops_grumpkin.hpp -- device routines of the three BlackBoxFunctionSolver functions (blackbox_solver/src/lib.rs:27-45)
+// that the reference delegates to barretenberg (barretenberg_blackbox_solver/src/{lib.rs:39-81, wasm/*.rs}); the
+// algorithms are the ones SURVEY.md Appendix A specifies and the reference's five golden vectors pin:
+//   FixedBaseScalarMul   acvm/src/pwg/blackbox/fixed_base_scalar_mul.rs:11-27, wasm/scalar_mul.rs:17-65
+//   Pedersen             acvm/src/pwg/blackbox/pedersen.rs:11-28, wasm/pedersen.rs:14-35 (plookup commitment)
+//   SchnorrVerify        acvm/src/pwg/blackbox/signature/schnorr.rs:13-35, lib.rs:40-58, wasm/schnorr.rs:68-103
+// Grumpkin is y^2 = x^3 - 17 over BN254-Fr, so point coordinates are this library's Fr; scalars are 256-bit integers
+// (8 x u32, canonical). One lane = one instance; table lookups are per-lane gathers from L2-resident tables
+// (grumpkin_host.cpp). Integer-ALU bound: ~700 field multiplications per Pedersen hash_pair, ~5000 per Schnorr verify.
+#pragma once
+#include "grumpkin_host.hpp"
+#include "ops_hash.hpp"
+
+namespace acvm {
+
+struct GAff { Fr x, y; };
+struct GJac { Fr X, Y, Z; };  // Z == 0 <=> point at infinity
+
+__device__ __forceinline__ GJac gj_inf() { return GJac{fr_one(), fr_one(), fr_zero()}; }
+__device__ __forceinline__ bool gj_is_inf(const GJac &p) { return fr_is_zero(p.Z); }
+__device__ __forceinline__ Fr fr_dbl(const Fr &a) { return fr_add(a, a); }
+
+__device__ __forceinline__ GAff gaff_load(const uint4 *tbl, uint32_t idx) {
+    const uint4 *p = tbl + (uint64_t)idx * 4;
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    GAff r;
+    r.x = Fr{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    r.y = Fr{{c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w}};
+    return r;
+}
+
+// dbl-2009-l (a = 0): 2M + 5S
+__device__ __forceinline__ GJac gj_dbl(const GJac &p) {
+    if (gj_is_inf(p) || fr_is_zero(p.Y)) return gj_inf();
+    const Fr A = fr_sqr(p.X), B = fr_sqr(p.Y), C = fr_sqr(B);
+    Fr t = fr_add(p.X, B);
+    t = fr_sub(fr_sub(fr_sqr(t), A), C);
+    const Fr D = fr_dbl(t), E = fr_add(fr_dbl(A), A), F = fr_sqr(E);
+    GJac r;
+    r.X = fr_sub(fr_sub(F, D), D);
+    r.Y = fr_sub(fr_mul(E, fr_sub(D, r.X)), fr_dbl(fr_dbl(fr_dbl(C))));
+    r.Z = fr_dbl(fr_mul(p.Y, p.Z));
+    return r;
+}
+// complete mixed addition (madd-2007-bl with the exceptional cases): 7M + 4S. q is a finite affine point.
+__device__ __forceinline__ GJac gj_add_aff(const GJac &p, const GAff &q) {
+    if (gj_is_inf(p)) return GJac{q.x, q.y, fr_one()};
+    const Fr Z1Z1 = fr_sqr(p.Z);
+    const Fr U2 = fr_mul(q.x, Z1Z1), S2 = fr_mul(fr_mul(q.y, p.Z), Z1Z1);
+    const Fr H = fr_sub(U2, p.X);
+    Fr r = fr_sub(S2, p.Y);
+    if (fr_is_zero(H)) {
+        if (fr_is_zero(r)) return gj_dbl(p);
+        return gj_inf();
+    }
+    const Fr HH = fr_sqr(H);
+    const Fr I = fr_dbl(fr_dbl(HH)), J = fr_mul(H, I);
+    r = fr_dbl(r);
+    const Fr V = fr_mul(p.X, I);
+    GJac o;
+    o.X = fr_sub(fr_sub(fr_sub(fr_sqr(r), J), V), V);
+    o.Y = fr_sub(fr_mul(r, fr_sub(V, o.X)), fr_dbl(fr_mul(p.Y, J)));
+    o.Z = fr_sub(fr_sub(fr_sqr(fr_add(p.Z, H)), Z1Z1), HH);
+    return o;
+}
+// complete Jacobian addition (add-2007-bl): 11M + 5S
+__device__ __forceinline__ GJac gj_add(const GJac &p, const GJac &q) {
+    if (gj_is_inf(p)) return q;
+    if (gj_is_inf(q)) return p;
+    const Fr Z1Z1 = fr_sqr(p.Z), Z2Z2 = fr_sqr(q.Z);
+    const Fr U1 = fr_mul(p.X, Z2Z2), U2 = fr_mul(q.X, Z1Z1);
+    const Fr S1 = fr_mul(fr_mul(p.Y, q.Z), Z2Z2), S2 = fr_mul(fr_mul(q.Y, p.Z), Z1Z1);
+    const Fr H = fr_sub(U2, U1);
+    Fr r = fr_sub(S2, S1);
+    if (fr_is_zero(H)) {
+        if (fr_is_zero(r)) return gj_dbl(p);
+        return gj_inf();
+    }
+    const Fr I = fr_sqr(fr_dbl(H)), J = fr_mul(H, I);
+    r = fr_dbl(r);
+    const Fr V = fr_mul(U1, I);
+    GJac o;
+    o.X = fr_sub(fr_sub(fr_sub(fr_sqr(r), J), V), V);
+    o.Y = fr_sub(fr_mul(r, fr_sub(V, o.X)), fr_dbl(fr_mul(S1, J)));
+    o.Z = fr_mul(fr_sub(fr_sub(fr_sqr(fr_add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
+    return o;
+}
+// affine coordinates; infinity -> (0, 0) with *inf set (the encoding the restated backend uses; unpinned by the reference)
+__device__ __forceinline__ GAff gj_to_aff(const GJac &p, bool *inf) {
+    *inf = gj_is_inf(p);
+    const Fr zi = fr_inv(p.Z);  // inverse(0) == 0 -> (0, 0)
+    const Fr zi2 = fr_sqr(zi);
+    GAff r;
+    r.x = fr_mul(p.X, zi2);
+    r.y = fr_mul(p.Y, fr_mul(zi2, zi));
+    return r;
+}
+
+// limb idx (wave-uniform or per-lane) of an 8-limb integer without dynamic register indexing
+__device__ __forceinline__ uint32_t limb_at(const Fr &v, uint32_t idx) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if ((uint32_t)k == idx) r = v.v[k];
+    return r;
+}
+// bits [pos, pos + n) of a 256-bit integer, zero beyond bit 255 (n <= 16)
+__device__ __forceinline__ uint32_t bits_at(const Fr &v, uint32_t pos, uint32_t n) {
+    const uint32_t lo = limb_at(v, pos >> 5), hi = limb_at(v, (pos >> 5) + 1);
+    const uint64_t two = (uint64_t)hi << 32 | lo;
+    return (uint32_t)(two >> (pos & 31)) & ((1u << n) - 1u);
+}
+
+// Grumpkin group order q = BN254 base-field modulus (scalar_mul.rs:42-45), little-endian limbs
+__device__ __forceinline__ Fr grumpkin_q() {
+    return Fr{{0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u}};
+}
+__device__ __forceinline__ bool int_geq(const Fr &a, const Fr &b) {
+    Fr d;
+    return fr_sub256(d, a, b) == 0;
+}
+__device__ __forceinline__ Fr reduce_mod_q(Fr k) {  // 2^256 / q < 6
+    for (int it = 0; it < 5; it++) {
+        Fr d;
+        if (!fr_sub256(d, k, grumpkin_q())) k = d;
+    }
+    return k;
+}
+
+// k * base for a 256-bit integer k with the 8-bit window table of `base_index` (0 = G, 1..3 = D[0], D[3], D[6])
+__device__ __forceinline__ GJac fixed_base_mul(const GrumpkinTables &T, uint32_t base_index, const Fr &k) {
+    GJac acc = gj_inf();
+    const uint4 *tbl = T.win + (uint64_t)base_index * GRUMPKIN_WIN_STRIDE * 4;
+    for (uint32_t w = 0; w < 32; w++) {
+        const uint32_t d = (limb_at(k, w >> 2) >> (8u * (w & 3u))) & 0xffu;
+        if (d) acc = gj_add_aff(acc, gaff_load(tbl, w * 255u + d - 1u));
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------ FixedBaseScalarMul
+// [K_FIXED_BASE, opcode, low, high, out_x, fx, out_y, fy]
+template <class P>
+__device__ __forceinline__ OpResult grumpkin_fixed_base_values(const Fr &low_m, const Fr &high_m, const GrumpkinTables &T, Fr &x, Fr &y) {
+    const Fr lo = fr_to_canonical(low_m), hi = fr_to_canonical(high_m);
+    if (lo.v[4] | lo.v[5] | lo.v[6] | lo.v[7]) return op_fail_msg(DE_BLACKBOX_FAILED, 10u, DM_LIMB_LOW);    // scalar_mul.rs:25-29
+    if (hi.v[4] | hi.v[5] | hi.v[6] | hi.v[7]) return op_fail_msg(DE_BLACKBOX_FAILED, 10u, DM_LIMB_HIGH);
+    const Fr k = Fr{{lo.v[0], lo.v[1], lo.v[2], lo.v[3], hi.v[0], hi.v[1], hi.v[2], hi.v[3]}};
+    if (int_geq(k, grumpkin_q())) return op_fail_msg(DE_BLACKBOX_FAILED, 10u, DM_SCALAR);                     // scalar_mul.rs:41-51
+    bool inf;
+    const GAff a = gj_to_aff(fixed_base_mul(T, 0, k), &inf);
+    x = a.x;
+    y = a.y;
+    return op_ok();
+}
+template <class P>
+__device__ __forceinline__ OpResult op_fixed_base(const P &p, const uint32_t *__restrict__ r, const GrumpkinTables &T) {
+    if (P::exact) {
+        if (!p.known(r[2])) return op_fail(DE_MISSING_ASSIGNMENT, r[2]);
+        if (!p.known(r[3])) return op_fail(DE_MISSING_ASSIGNMENT, r[3]);
+    }
+    Fr x, y;
+    const OpResult e = grumpkin_fixed_base_values<P>(p.load(r[2]), p.load(r[3]), T, x, y);
+    if (e.err) return e;
+    if (!p.insert(r[4], x, r[5])) return op_fail(DE_UNSATISFIED);
+    if (!p.insert(r[6], y, r[7])) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+// ------------------------------------------------------------------------------------------------ Pedersen (plookup)
+// hash_single: 9-bit slices of the canonical value alternate between two accumulators; slice s = 2i (resp.
+// 2i+1) adds (slice + 1) * D[off + i] to accumulator 0 (resp. 1, i < 14); accumulator 0 then takes the endomorphism
+// (x, y) -> (beta * x, y).
+__device__ __forceinline__ Fr grumpkin_beta() {  // cube root of unity in Fr, Montgomery form of 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    Fr c = Fr{{0xb99c90ddu, 0x8b17ea66u, 0x8d8daaa7u, 0x5bfc4108u, 0x41a91758u, 0xb3c4d79du, 0u, 0u}};
+    return fr_from_canonical(c);
+}
+__device__ __forceinline__ GJac pedersen_hash_single(const GrumpkinTables &T, const Fr &v_canon, uint32_t parity) {
+    GJac acc0 = gj_inf(), acc1 = gj_inf();
+    const uint32_t off = parity ? 15u : 0u;
+    for (uint32_t i = 0; i < 15; i++) {
+        const uint32_t a = bits_at(v_canon, 18u * i, 9);
+        acc0 = gj_add_aff(acc0, gaff_load(T.ped, (off + i) * GRUMPKIN_PED_ENTRIES + a));
+        if (i < 14) {
+            const uint32_t b = 18u * i + 9u < 256u ? bits_at(v_canon, 18u * i + 9u, 9) : 0u;
+            acc1 = gj_add_aff(acc1, gaff_load(T.ped, (off + i) * GRUMPKIN_PED_ENTRIES + b));
+        }
+    }
+    acc0.X = fr_mul(acc0.X, grumpkin_beta());
+    return gj_add(acc0, acc1);
+}
+// pedersen(inputs[0..n), hash_index): length-prefixed chain of hash_pairs; inputs are fetched through `get(i)` (Montgomery)
+template <class Get>
+__device__ __forceinline__ void grumpkin_pedersen(const GrumpkinTables &T, uint32_t n, uint32_t hash_index, Get get, Fr &x, Fr &y) {
+    if (n == 0) { x = fr_zero(); y = fr_zero(); return; }
+    Fr r = fr_one();  // IV[0].x = G.x = 1
+    if (hash_index != 0) {
+        Fr k = fr_zero();
+        k.v[0] = hash_index + 1u;
+        k.v[1] = hash_index == 0xFFFFFFFFu ? 1u : 0u;
+        bool inf;
+        r = gj_to_aff(fixed_base_mul(T, 0, k), &inf).x;
+    }
+    for (uint32_t step = 0; step <= n; step++) {
+        const Fr right = step == 0 ? fr_from_u32(n) : get(step - 1);
+        GJac s = gj_inf();
+        for (uint32_t parity = 0; parity < 2; parity++) {
+            const Fr v = fr_to_canonical(parity ? right : r);
+            s = gj_add(s, pedersen_hash_single(T, v, parity));
+        }
+        bool inf;
+        const GAff a = gj_to_aff(s, &inf);
+        r = a.x;
+        y = a.y;
+    }
+    x = r;
+}
+// [K_PEDERSEN, opcode, domain_separator, n_in, out_x, fx, out_y, fy, ws...]
+template <class P>
+__device__ __forceinline__ OpResult op_pedersen(const P &p, const uint32_t *__restrict__ r, const GrumpkinTables &T) {
+    const uint32_t n = r[3];
+    const uint32_t *ws = r + 8;
+    if (P::exact)
+        for (uint32_t i = 0; i < n; i++)
+            if (!p.known(ws[i])) return op_fail(DE_MISSING_ASSIGNMENT, ws[i]);
+    Fr x, y;
+    grumpkin_pedersen(T, n, r[2], [&](uint32_t i) { return p.load(ws[i]); }, x, y);
+    if (!p.insert(r[4], x, r[5])) return op_fail(DE_UNSATISFIED);
+    if (!p.insert(r[6], y, r[7])) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+// ------------------------------------------------------------------------------------------------ SchnorrVerify
+// H_j(v) of the hash-ladder Pedersen compress: v (made odd by +1 with a skew correction) = 16 * hi + lo with
+// lo odd in [-15, 15]; H_j = hi * D[3j] + lo * D[3j+1] (- D[3j+2] if v was even)
+__device__ __forceinline__ GJac ladder_term(const GrumpkinTables &T, const Fr &v_canon, uint32_t j) {
+    Fr V = v_canon;
+    const bool even = !(V.v[0] & 1u);
+    if (even) {  // V + 1 (v < p: no overflow)
+        Fr one = fr_zero();
+        one.v[0] = 1u;
+        fr_add256(V, V, one);
+    }
+    const int t = (int)((V.v[0] + 16u) & 31u);
+    const int lo = t < 16 ? t : t - 32;  // odd
+    Fr adj = fr_zero(), hi;
+    adj.v[0] = (uint32_t)(lo < 0 ? -lo : lo);
+    if (lo >= 0) fr_sub256(hi, V, adj);
+    else fr_add256(hi, V, adj);  // V < p < 2^254: no carry out
+#pragma unroll
+    for (int i = 0; i < 7; i++) hi.v[i] = hi.v[i] >> 4 | hi.v[i + 1] << 28;
+    hi.v[7] >>= 4;
+    GJac pnt = fixed_base_mul(T, 1u + j, hi);
+    GAff q = gaff_load(T.small, j * 15u + adj.v[0] - 1u);
+    if (lo < 0) q.y = fr_neg(q.y);
+    pnt = gj_add_aff(pnt, q);
+    if (even) {
+        GAff sk = gaff_load(T.skew, j);
+        sk.y = fr_neg(sk.y);
+        pnt = gj_add_aff(pnt, sk);
+    }
+    return pnt;
+}
+
+// verify_signature: pk on curve, s and e (mod q) nonzero, R = e * pk + s * G finite, and
+// blake2s(be32(compress(R.x, pk.x, pk.y)) || message) == the e bytes of the signature.
+// sig / msg bytes come through `sig_byte(i)` / `msg_byte(i)`; the challenge preimage is staged in `m`.
+template <class SigByte, class MsgByte>
+__device__ __forceinline__ bool grumpkin_schnorr_verify(const GrumpkinTables &T, const Fr &pkx, const Fr &pky, SigByte sig_byte, uint32_t n_msg,
+                                                        MsgByte msg_byte, MsgBuf &m) {
+    Fr s = fr_zero(), e = fr_zero();
+    for (uint32_t i = 0; i < 32; i++) {  // big-endian 32-byte integers
+        const uint32_t sb = sig_byte(i) & 0xffu, eb = sig_byte(32u + i) & 0xffu;
+        const uint32_t limb = 7u - (i >> 2), sh = 24u - 8u * (i & 3u);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((uint32_t)k == limb) { s.v[k] |= sb << sh; e.v[k] |= eb << sh; }
+    }
+    const Fr e_raw = e;
+    s = reduce_mod_q(s);
+    e = reduce_mod_q(e);
+    // on curve: y^2 == x^3 - 17
+    Fr seventeen = fr_from_u32(17u);
+    if (!fr_eq(fr_sqr(pky), fr_sub(fr_mul(fr_sqr(pkx), pkx), seventeen))) return false;
+    if (fr_is_zero(s) || fr_is_zero(e)) return false;
+    // e * pk: double-and-add, most significant bit first
+    GJac a = gj_inf();
+    const GAff pk{pkx, pky};
+    for (int i = 255; i >= 0; i--) {
+        a = gj_dbl(a);
+        if ((limb_at(e, (uint32_t)i >> 5) >> (i & 31)) & 1u) a = gj_add_aff(a, pk);
+    }
+    const GJac b = fixed_base_mul(T, 0, s);
+    const GJac rr = gj_add(a, b);
+    if (gj_is_inf(rr)) return false;
+    bool inf;
+    const GAff R = gj_to_aff(rr, &inf);
+    // compress(R.x, pk.x, pk.y)
+    GJac acc = gj_inf();
+    for (uint32_t j = 0; j < 3; j++) {
+        const Fr v = fr_to_canonical(j == 0 ? R.x : (j == 1 ? pkx : pky));
+        acc = gj_add(acc, ladder_term(T, v, j));
+    }
+    const Fr c = fr_to_canonical(gj_to_aff(acc, &inf).x);
+    m.begin();
+    for (uint32_t i = 0; i < 32; i++) m.put(limb_at(c, 7u - (i >> 2)) >> (24u - 8u * (i & 3u)));
+    for (uint32_t i = 0; i < n_msg; i++) m.put(msg_byte(i));
+    m.end();
+    const Digest d = blake2s_msg(m, 32u + n_msg);
+    // digest byte i == signature byte 32 + i, i.e. the big-endian bytes of e as given
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) diff |= bswap32(d.d[i]) ^ e_raw.v[7 - i];
+    return diff == 0;
+}
+
+// [K_SCHNORR, opcode, pkx, pky, n_sig, n_msg, out, flag, sig ws..., msg ws...]
+template <class P>
+__device__ __forceinline__ OpResult op_schnorr(const P &p, const uint32_t *__restrict__ r, const GrumpkinTables &T, uint32_t *scratch) {
+    const uint32_t n_sig = r[4], n_msg = r[5];
+    const uint32_t *sig = r + 8, *msg = sig + n_sig;
+    if (P::exact) {  // get_inputs_vec order: pkx, pky, signature, message
+        if (!p.known(r[2])) return op_fail(DE_MISSING_ASSIGNMENT, r[2]);
+        if (!p.known(r[3])) return op_fail(DE_MISSING_ASSIGNMENT, r[3]);
+        for (uint32_t i = 0; i < n_sig + n_msg; i++)
+            if (!p.known(sig[i])) return op_fail(DE_MISSING_ASSIGNMENT, sig[i]);
+    }
+    if (n_sig < 64u) return op_fail_msg(DE_PANIC, 5u, DM_SCHNORR_SIG_LEN, n_sig);        // lib.rs:50-52 slice panics
+    if (128u + n_msg >= 1024u) return op_fail_msg(DE_PANIC, 5u, DM_SCHNORR_MSG_LEN);      // wasm/schnorr.rs:79-82
+    MsgBuf m{scratch, p.Bp, p.j, 0u, 0u};
+    // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness
+    const bool ok = grumpkin_schnorr_verify(
+        T, p.load(r[2]), p.load(r[3]), [&](uint32_t i) { return fr_to_canonical(p.load(sig[i])).v[0]; }, n_msg,
+        [&](uint32_t i) { return fr_to_canonical(p.load(msg[i])).v[0]; }, m);
+    if (!p.insert(r[6], ok ? fr_one() : fr_zero(), r[7])) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+
+template <class P>
+__device__ __forceinline__ OpResult dispatch_grumpkin(const P &p, const uint32_t *__restrict__ r, const GrumpkinTables &T, uint32_t *scratch) {
+    switch (r[0]) {
+    case K_FIXED_BASE: return op_fixed_base(p, r, T);
+    case K_PEDERSEN: return op_pedersen(p, r, T);
+    case K_SCHNORR: return op_schnorr(p, r, T, scratch);
+    default: return op_fail_msg(DE_PANIC, 0, DM_NONE);
+    }
+}
+
+}  // namespace acvm

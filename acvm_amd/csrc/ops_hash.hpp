@@ -60,7 +60,7 @@ static __constant__ uint32_t SHA256_K[64] = {
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t n) { return __builtin_rotateright32(x, n); }
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 
-static __device__ __noinline__ Digest sha256_msg(const MsgBuf &m, uint32_t len) {
+static inline __device__ __noinline__ Digest sha256_msg(const MsgBuf &m, uint32_t len) {
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     const uint32_t n_blocks = (len + 9u + 63u) / 64u;
     for (uint32_t b = 0; b < n_blocks; b++) {
@@ -110,7 +110,7 @@ static __device__ __noinline__ Digest sha256_msg(const MsgBuf &m, uint32_t len) 
     a = a + b + (y); d = rotr32(d ^ a, 8);  \
     c = c + d; b = rotr32(b ^ c, 7);
 
-static __device__ __noinline__ Digest blake2s_msg(const MsgBuf &m, uint32_t len) {
+static inline __device__ __noinline__ Digest blake2s_msg(const MsgBuf &m, uint32_t len) {
     const uint32_t IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     uint32_t h[8];
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ __forceinline__ void keccak_f1600(uint64_t s[25]) {
     }
 }
 
-static __device__ __noinline__ Digest keccak256_msg(const MsgBuf &m, uint32_t len) {
+static inline __device__ __noinline__ Digest keccak256_msg(const MsgBuf &m, uint32_t len) {
     uint64_t s[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) s[i] = 0;

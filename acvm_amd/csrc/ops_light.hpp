@@ -70,7 +70,7 @@ __device__ __forceinline__ OpResult op_zero_out(const P &p, const uint32_t *__re
 }
 
 // 256-bit unsigned division of canonical integers (num-bigint semantics); b != 0
-static __device__ __noinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr &rem) {
+static inline __device__ __noinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr &rem) {
     q = fr_zero();
     rem = fr_zero();
     for (int i = 255; i >= 0; i--) {

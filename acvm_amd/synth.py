@@ -164,3 +164,54 @@ def byte_batch(B, n_in, seed=0xAC1D0003, first_instance=0):
     out = np.zeros((B, n_in, 32), dtype=np.uint8)
     out[:, :, 31] = (v & np.uint64(0xFF)).astype(np.uint8)
     return out.tobytes()
+
+
+Q_GRUMPKIN = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+
+def grumpkin_circuit(msg_len=10, n_pedersen_inputs=2):
+    """BASELINE config 4: Pedersen{[w1, w2], 0} -> FixedBaseScalarMul{low: w3, high: w4} -> SchnorrVerify
+    (pk = w5, w6; 64 signature bytes w7..w70; msg_len message bytes). Returns (Circuit, input ids)."""
+    from .acir import BlackBoxFuncCall as BB, FunctionInput as FI
+    n_in = n_pedersen_inputs + 2 + 2 + 64 + msg_len
+    ids = list(range(1, n_in + 1))
+    o = n_pedersen_inputs
+    ped_in, lo, hi, pkx, pky = ids[:o], ids[o], ids[o + 1], ids[o + 2], ids[o + 3]
+    sig, msg = ids[o + 4:o + 68], ids[o + 68:]
+    out = n_in + 1
+    ops = [BB("Pedersen", {"inputs": [FI(w, 254) for w in ped_in], "domain_separator": 0, "outputs": [out, out + 1]}),
+           BB("FixedBaseScalarMul", {"low": FI(lo, 128), "high": FI(hi, 128), "outputs": [out + 2, out + 3]}),
+           BB("SchnorrVerify", {"public_key_x": FI(pkx, 254), "public_key_y": FI(pky, 254), "signature": [FI(w, 8) for w in sig],
+                                "message": [FI(w, 8) for w in msg], "output": out + 4})]
+    circ = Circuit(current_witness_index=out + 4, opcodes=ops, private_parameters=ids, return_values=[out, out + 1, out + 2, out + 3, out + 4])
+    return circ, ids
+
+
+def grumpkin_rows(B, sign, msg_len=10, n_pedersen_inputs=2, seed=0xAC1D0004, first_instance=0, n_keys=16):
+    """Input rows for grumpkin_circuit. `sign(sk_be32, k_be32, msg) -> 128 bytes (pk || sig)` is the caller's signer (the
+    tests pass the CPU oracle's; the product has no signer). Signatures are made for n_keys distinct (key, message)
+    pairs and reused round-robin; odd instances get one flipped signature byte. Instances 0..7 of the global batch
+    violate the limb / modulus checks."""
+    rng = SplitMix64(seed)
+    signed = []
+    for _ in range(n_keys):
+        sk = rng.fr() % Q_GRUMPKIN or 1
+        k = rng.fr() % Q_GRUMPKIN or 1
+        msg = bytes(rng.below(256) for _ in range(msg_len))
+        signed.append((sign(be32(sk), be32(k), msg), msg))
+    rows = []
+    for t in range(B):
+        j = first_instance + t
+        r = SplitMix64(seed ^ (j * 0x9E3779B97F4A7C15 & MASK))
+        ped = [r.fr() for _ in range(n_pedersen_inputs)]
+        lo = r.next() | (r.next() << 64)
+        hi = (r.next() | (r.next() << 64)) >> 3  # < 2^125: the scalar is always below the group order
+        if j < 8:
+            lo, hi = [(1 << 128, 0), (0, 1 << 128), (Q_GRUMPKIN & ((1 << 128) - 1), Q_GRUMPKIN >> 128), (P - 1, 1), (0, 0), (1, 0),
+                      ((Q_GRUMPKIN - 1) & ((1 << 128) - 1), (Q_GRUMPKIN - 1) >> 128), (5, (1 << 128) - 1)][j]
+        pk_sig, msg = signed[j % n_keys]
+        sig = bytearray(pk_sig[64:128])
+        if j & 1:
+            sig[r.below(64)] ^= 1 << r.below(8)
+        rows.append(ped + [lo, hi, int.from_bytes(pk_sig[:32], "big"), int.from_bytes(pk_sig[32:64], "big")] + list(sig) + list(msg))
+    return rows

@@ -117,6 +117,13 @@ int acvm_device_arch(char *out, size_t out_len);
  * hand-scheduled routines disagree with the portable ones (0 = pass), or a negative error. */
 int acvm_selftest(uint32_t n, uint64_t seed);
 
+/* Component probes of the Grumpkin kernels (parity tests of barretenberg's building blocks against SURVEY Appendix A):
+ * what 0 = host table point (param = table << 24 | index; tables: 0 Pedersen k*D[i] at i*512+k-1, 1 8-bit windows,
+ * 2 ladder k*D[3j+1], 3 skew D[3j+2]); 1 = device hash_single(in[0], parity param); 2 = device hash-ladder
+ * compress(in[0..n_in)), 3 = device fixed-base product (window table param, 256-bit integer in[0]); 4 = device table point.
+ * in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian. */
+int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64);
+
 /* Circuit::read: gzip(bincode) or raw bincode bytes. */
 acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);
 void acvm_circuit_free(acvm_circuit_t *c);

@@ -1,0 +1,104 @@
+"""GPU parity of FixedBaseScalarMul / Pedersen / SchnorrVerify: the reference's own golden vectors
+(barretenberg_blackbox_solver/src/wasm/{scalar_mul.rs:72-97, pedersen.rs:38-54}, acvm_js/test/shared/{pedersen,
+schnorr_verify,fixed_base_scalar_mul}.ts as committed fixtures) and seeded batches against the CPU oracle."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from acvm_amd.acir import P, BlackBoxFuncCall as BB, Circuit, FunctionInput as FI
+from acvm_amd.synth import Q_GRUMPKIN, be32, grumpkin_circuit, grumpkin_rows, values_from_rows
+from test_gpu_opcodes import both_paths, run_both
+
+pytestmark = pytest.mark.gpu
+GY = 0x0000000000000002CF135E7506A45D632D270D45F1181294833FC48D823F272C
+
+
+def solve_one(circ_bytes, iw):
+    import acvm_amd
+    ids = sorted(iw)
+    batch = acvm_amd.Batch(acvm_amd.Circuit(circ_bytes), 1, ids)
+    batch.set_initial_witness(b"".join(be32(iw[i]) for i in ids))
+    n_bad = batch.solve()
+    asg, vals = batch.witness_map()
+    return n_bad, {w: int.from_bytes(vals[0, w].tobytes(), "big") for w in range(asg.shape[1]) if asg[0, w]}
+
+
+@pytest.mark.parametrize("name", ["fixed_base_scalar_mul", "pedersen", "schnorr_verify"])
+def test_acvm_js_fixture(golden, name):
+    fx = golden["acvm_js"][name]
+    iw = {int(k): int(v, 16) for k, v in fx["initialWitnessMap"].items()}
+    n_bad, got = solve_one(bytes(fx["bytecode"]), iw)
+    assert n_bad == 0
+    assert got == {int(k): int(v, 16) for k, v in fx["expectedWitnessMap"].items()}
+
+
+def test_rust_unit_vectors():
+    # scalar_mul.rs:72-97 and pedersen.rs:38-54
+    circ = Circuit(4, [BB("FixedBaseScalarMul", {"low": FI(1, 128), "high": FI(2, 128), "outputs": [3, 4]})]).to_bytes()
+    _, w = solve_one(circ, {1: 1, 2: 0})
+    assert (w[3], w[4]) == (1, GY)
+    _, w = solve_one(circ, {1: 1, 2: 2})
+    assert (w[3], w[4]) == (0x0702AB9C7038EEECC179B4F209991BCB68C7CB05BF4C532D804CCAC36199C9A9,
+                            0x23F10E9E43A3AE8D75D24154E796AAE12AE7AF546716E8F81A2564F1B5814130)
+    circ = Circuit(4, [BB("Pedersen", {"inputs": [FI(1, 254), FI(2, 254)], "domain_separator": 0, "outputs": [3, 4]})]).to_bytes()
+    _, w = solve_one(circ, {1: 0, 2: 1})
+    assert (w[3], w[4]) == (0x0C5E1DDECD49DE44ED5E5798D3F6FB7C71FE3D37F5BEE8664CF88A445B5BA0AF,
+                            0x230294A041E26FE80B827C2EF5CB8784642BBAA83842DA2714D62B1F3C4F9752)
+
+
+def test_fixed_base_batch_and_failures(oracle):
+    r = random.Random(11)
+    circ = Circuit(4, [BB("FixedBaseScalarMul", {"low": FI(1, 128), "high": FI(2, 128), "outputs": [3, 4]})])
+    rows = [[r.randrange(1 << 128), r.randrange(1 << 125)] for _ in range(72)]
+    rows[0] = [1 << 128, 0]
+    rows[1] = [0, 1 << 200]
+    rows[2] = [Q_GRUMPKIN & ((1 << 128) - 1), Q_GRUMPKIN >> 128]
+    rows[3] = [(Q_GRUMPKIN - 1) & ((1 << 128) - 1), (Q_GRUMPKIN - 1) >> 128]
+    rows[4] = [0, 0]
+    rows[5] = [P - 1, P - 1]
+    ores, _ = both_paths(oracle, circ, [1, 2], rows)
+    assert [ores[j].err for j in range(3)] == [oracle.E_BLACKBOX_FAILED] * 3 and ores[3].status == 0 and ores[4].status == 0
+
+
+@pytest.mark.parametrize("n,ds", [(1, 0), (2, 0), (3, 0), (5, 0), (2, 3), (0, 0)])
+def test_pedersen_batch(oracle, n, ds):
+    r = random.Random(20 + n + ds)
+    ids = list(range(1, n + 1))
+    circ = Circuit(n + 2, [BB("Pedersen", {"inputs": [FI(w, 254) for w in ids], "domain_separator": ds, "outputs": [n + 1, n + 2]})])
+    rows = [[r.randrange(P) for _ in range(n)] for _ in range(70)]
+    if n:
+        rows[0] = [0] * n
+        rows[1] = [P - 1] * n
+        rows[2] = [1] * n
+    both_paths(oracle, circ, ids, rows)
+
+
+def _signer(oracle):
+    def sign(sk, k, msg):
+        out = C.create_string_buffer(128)
+        assert oracle.lib().oracle_schnorr_sign(sk, k, msg, len(msg), out) == 0
+        return out.raw
+    return sign
+
+
+def test_config4_grumpkin_circuit(oracle):
+    circ, ids = grumpkin_circuit()
+    rows = grumpkin_rows(80, _signer(oracle))
+    # more rejecting shapes: public key off the curve, s = 0, e = 0
+    rows[10][4] = (rows[10][4] + 1) % P
+    for i in range(32):
+        rows[11][6 + i] = 0
+        rows[12][6 + 32 + i] = 0
+    ores, stats = run_both(oracle, circ, ids, rows)
+    run_both(oracle, circ, ids, rows[:40], force_slow=True)
+    assert sum(1 for j in range(80) if ores[j].status == 0) >= 70
+
+
+def test_schnorr_short_signature_panics(oracle):
+    circ = Circuit(70, [BB("SchnorrVerify", {"public_key_x": FI(1, 254), "public_key_y": FI(2, 254), "signature": [FI(w, 8) for w in range(3, 66)],
+                                            "message": [FI(66, 8)], "output": 67})])
+    rows = [[1, GY] + [0] * 63 + [7]] * 2
+    ores, _ = both_paths(oracle, circ, list(range(1, 67)), rows)
+    assert ores[0].err == oracle.E_PANIC

@@ -526,11 +526,6 @@ static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
 static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm_result_t &r) {
     const Plan &p = b->plan;
     const uint32_t *rec = sr.opcode_index < p.n_opcodes ? &p.prog[p.prog_offset[sr.opcode_index]] : nullptr;
-    auto hex_of = [&](uint32_t w, char out[65]) {
-        uint8_t be[32] = {0};
-        fetch_one(b, j, w, be);
-        for (int i = 0; i < 32; i++) snprintf(out + 2 * i, 3, "%02x", be[i]);
-    };
     char hx[65];
     switch (sr.msg) {
     case 1: snprintf(r.message, sizeof r.message, "Mul term in the arithmetic opcode must contain either zero or one term"); break;
@@ -549,31 +544,51 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
     case 6: snprintf(r.message, sizeof r.message, "called `Option::unwrap()` on a `None` value (memory index)"); break;
     case 7: snprintf(r.message, sizeof r.message, "Memory must be read into a specified witness index, encountered an Expression"); break;
     case 8: snprintf(r.message, sizeof r.message, "The radix must be within 2...256"); break;
-    case 9: case 10:
-        if (rec && rec[0] == PK_FIXED_BASE) {
-            hex_of(rec[sr.msg == 9 ? 2 : 3], hx);
-            snprintf(r.message, sizeof r.message, "Limb %s is not less than 2^128", hx);
+    case 9: case 10: case 11: {
+        // the offending value: a witness of the FixedBaseScalarMul opcode, or the VM register value the device quoted
+        const bool in_brillig = sr.err == ACVM_ERR_BRILLIG_FAILED;
+        uint8_t val[32] = {0};
+        if (in_brillig) {
+            for (int i = 0; i < 32; i++) val[31 - i] = (uint8_t)(sr.val[i / 4] >> (8 * (i % 4)));
+        } else if (rec && rec[0] == PK_FIXED_BASE) {
+            if (sr.msg == 11) {
+                uint8_t lo[32] = {0}, hi[32] = {0};
+                fetch_one(b, j, rec[2], lo);
+                fetch_one(b, j, rec[3], hi);
+                memcpy(val, hi + 16, 16);
+                memcpy(val + 16, lo + 16, 16);
+            } else fetch_one(b, j, rec[sr.msg == 9 ? 2 : 3], val);
         }
-        break;
-    case 11:
-        if (rec && rec[0] == PK_FIXED_BASE) {  // hex::encode(BigUint::to_bytes_be()) of high * 2^128 + low: minimal big-endian bytes
-            uint8_t lo[32] = {0}, hi[32] = {0}, k[32];
-            fetch_one(b, j, rec[2], lo);
-            fetch_one(b, j, rec[3], hi);
-            memcpy(k, hi + 16, 16);
-            memcpy(k + 16, lo + 16, 16);
+        char reason[160];
+        if (sr.msg == 11) {  // hex::encode(BigUint::to_bytes_be()) of high * 2^128 + low: minimal big-endian bytes
             int st = 0;
-            while (st < 31 && k[st] == 0) st++;
+            while (st < 31 && val[st] == 0) st++;
             char hexs[65];
-            for (int i = st; i < 32; i++) snprintf(hexs + 2 * (i - st), 3, "%02x", k[i]);
-            snprintf(r.message, sizeof r.message, "Value %s is not a valid grumpkin scalar", hexs);
+            for (int i = st; i < 32; i++) snprintf(hexs + 2 * (i - st), 3, "%02x", val[i]);
+            snprintf(reason, sizeof reason, "Value %s is not a valid grumpkin scalar", hexs);
+        } else {
+            for (int i = 0; i < 32; i++) snprintf(hx + 2 * i, 3, "%02x", val[i]);
+            snprintf(reason, sizeof reason, "Limb %s is not less than 2^128", hx);
         }
+        if (in_brillig) snprintf(r.message, sizeof r.message, "failed to solve blackbox function: fixed_base_scalar_mul, reason: %s", reason);
+        else snprintf(r.message, sizeof r.message, "%s", reason);
         break;
+    }
     case 12: snprintf(r.message, sizeof r.message, "range end index 64 out of range for slice of length %u", sr.x0); break;
     case 13: snprintf(r.message, sizeof r.message, "Message overran wasm scratch space"); break;
     case 14: snprintf(r.message, sizeof r.message, "explicit trap hit in brillig"); break;
     case 15: snprintf(r.message, sizeof r.message, "return opcode hit, but callstack already empty"); break;
-    case 16: snprintf(r.message, sizeof r.message, "brillig vm panic (code %u)", sr.x0); break;
+    case 16: {
+        static const char *texts[17] = {"", "Reading register past maximum!", "Writing register past maximum!", "register does not fit into u64",
+                                        "memory read out of range", "", "oracle: bit_size > 256 not supported", "attempt to subtract with overflow",
+                                        "attempt to divide by zero", "unsupported bit size for right shift",
+                                        "called `Option::unwrap()` on a `None` value", "bad int op", "index out of bounds: bytecode",
+                                        "bad brillig opcode", "", "index out of bounds: brillig memory", "bad black box op"};
+        if (sr.x0 == 100) snprintf(r.message, sizeof r.message, "range end index 64 out of range for slice of length %u", sr.x1);
+        else if (sr.x0 == 101) snprintf(r.message, sizeof r.message, "Message overran wasm scratch space");
+        else snprintf(r.message, sizeof r.message, "%s", sr.x0 < 17 ? texts[sr.x0] : "brillig vm panic");
+        break;
+    }
     case 17: snprintf(r.message, sizeof r.message, "brillig memory write at %u beyond the device capacity (set ACVM_BRILLIG_MEM_CELLS)", sr.x0); break;
     case 18: snprintf(r.message, sizeof r.message, "brillig step limit reached on the device"); break;
     case 19: snprintf(r.message, sizeof r.message, "failed to solve blackbox function inside brillig (code %u)", sr.x0); break;

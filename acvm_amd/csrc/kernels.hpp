@@ -12,6 +12,7 @@ struct SlowResult {
     uint32_t msg, x0, x1;  // DevMsg code + payload for the host-side message text
     uint32_t n_call_stack;
     uint32_t call_stack[16];
+    uint32_t val[8];       // a canonical field value quoted by the message (Brillig black-box limb checks)
 };
 
 // lanes of the exact path: flagged instances gathered through slow_ids

@@ -44,6 +44,7 @@ __global__ void exact_init_kernel(ExactLanes L) {
     r.status = 1u;  // InProgress
     r.err = r.opcode_index = r.aux0 = r.aux1 = r.msg = r.x0 = r.x1 = r.n_call_stack = 0u;
     for (int i = 0; i < 16; i++) r.call_stack[i] = 0u;
+    for (int i = 0; i < 8; i++) r.val[i] = 0u;
     L.results[t] = r;
 }
 __global__ void exact_finish_kernel(ExactLanes L) {

@@ -1,0 +1,438 @@
+// ops_brillig.hpp -- the Brillig register VM on the device, one lane per (instance, Opcode::Brillig):
+//   BrilligSolver::solve / zero_out_brillig_outputs   acvm/src/pwg/brillig.rs:20-150
+//   VM::process_opcode, registers, memory              brillig_vm/src/{lib.rs:61-390, registers.rs:4-43, memory.rs:4-45}
+//   field / fixed-width integer ALU                    brillig_vm/src/arithmetic.rs:7-98 (BigUint semantics, bit_size <= 256)
+//   black box ops                                      brillig_vm/src/black_box.rs:42-165
+// Registers and memory live in per-lane device scratch laid out like the witness table ([slot][half][instance]), the call
+// stack and the hash staging bytes behind them. Control flow is per lane (SIMT divergence does the masking). The device
+// adds two limits the reference does not have, both reported loudly as failures: a memory capacity (planner estimate,
+// ACVM_BRILLIG_MEM_CELLS) and a step limit (2^22 instructions), so that a runaway program cannot hang the GPU.
+#pragma once
+#include "kernels.hpp"
+#include "ops_grumpkin.hpp"
+#include "ops_light.hpp"
+
+namespace acvm {
+
+enum BrOp : uint32_t {
+    BRO_BINARY_FIELD_OP = 0, BRO_BINARY_INT_OP, BRO_JUMP_IF_NOT, BRO_JUMP_IF, BRO_JUMP, BRO_CALL, BRO_CONST, BRO_RETURN,
+    BRO_FOREIGN_CALL, BRO_MOV, BRO_LOAD, BRO_STORE, BRO_BLACK_BOX, BRO_TRAP, BRO_STOP
+};
+// panic codes (host: brillig_panic_text in batch.cpp)
+enum BrPanic : uint32_t {
+    BP_REG_READ = 1, BP_REG_WRITE = 2, BP_U64 = 3, BP_MEM_READ = 4, BP_BITS_256 = 6, BP_SUB_OVERFLOW = 7, BP_DIV_ZERO = 8, BP_SHIFT_BITS = 9,
+    BP_UNWRAP = 10, BP_BAD_INT_OP = 11, BP_BYTECODE_OOB = 12, BP_BAD_OPCODE = 13, BP_OUT_MEM_OOB = 15, BP_BAD_BB = 16
+};
+static constexpr uint32_t BRILLIG_STEP_LIMIT = 1u << 22;
+static constexpr uint32_t BRILLIG_CALL_STACK = 64;
+
+struct BrVm {
+    uint4 *slots;     // Fr slots: registers [0, n_regs), memory [n_regs, n_regs + mem_cap)
+    uint32_t *words;  // call stack (BRILLIG_CALL_STACK words) then hash staging, word w of the lane at words[w * Bp + j]
+    uint64_t Bp, j;
+    uint32_t n_regs, mem_cap, n_mem, n_cs, pc;
+    uint32_t status;  // 0 running, 1 finished, 2 failure (trap / return / black box), 4 panic, 5 device limit
+    uint32_t code, x0;
+    Fr val;
+
+    __device__ __forceinline__ void panic(uint32_t c) { if (!status) { status = 4; code = c; } }
+    __device__ __forceinline__ Fr reg_get(uint32_t r) {
+        if (r >= 65536u) { panic(BP_REG_READ); return fr_zero(); }
+        return fr_load(slots, r, Bp, j);
+    }
+    __device__ __forceinline__ void reg_set(uint32_t r, const Fr &v) {
+        if (r >= 65536u) { panic(BP_REG_WRITE); return; }
+        fr_store(slots, r, Bp, j, v);
+    }
+    // Value::to_usize (brillig/src/value.rs:46-49): panics above u64; device addresses are 32-bit, larger ones can only fail
+    __device__ __forceinline__ bool to_usize(const Fr &v, uint64_t &out) {
+        const Fr c = fr_to_canonical(v);
+        if (c.v[2] | c.v[3] | c.v[4] | c.v[5] | c.v[6] | c.v[7]) { panic(BP_U64); return false; }
+        out = (uint64_t)c.v[1] << 32 | c.v[0];
+        return true;
+    }
+    __device__ __forceinline__ bool mem_check_read(uint64_t ptr, uint64_t len) {
+        if (ptr > n_mem || len > n_mem - ptr) { panic(BP_MEM_READ); return false; }
+        return true;
+    }
+    __device__ __forceinline__ Fr mem_get(uint32_t cell) { return fr_load(slots, n_regs + cell, Bp, j); }
+    // memory.rs:32-39 write: grows with zeros
+    __device__ __forceinline__ bool mem_write(uint64_t ptr, const Fr &v) {
+        if (ptr >= mem_cap) {
+            if (!status) { status = 5; code = DM_BRILLIG_MEM_CAP; x0 = ptr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ptr; }
+            return false;
+        }
+        for (uint32_t c = n_mem; c < (uint32_t)ptr; c++) fr_store(slots, n_regs + c, Bp, j, fr_zero());
+        fr_store(slots, n_regs + (uint32_t)ptr, Bp, j, v);
+        if ((uint32_t)ptr + 1u > n_mem) n_mem = (uint32_t)ptr + 1u;
+        return true;
+    }
+};
+
+// ---- 256-bit helpers on canonical integers
+__device__ __forceinline__ Fr int_mask(const Fr &a, uint32_t bits) { return canon_mask(a, bits); }
+__device__ __forceinline__ int int_cmp(const Fr &a, const Fr &b) {
+    Fr d;
+    if (fr_sub256(d, a, b)) return -1;
+    return fr_is_zero(d) ? 0 : 1;
+}
+__device__ __forceinline__ Fr int_pow2(uint32_t bits) {  // 2^bits, bits < 256
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (bits >> 5) == (uint32_t)i ? 1u << (bits & 31u) : 0u;
+    return r;
+}
+__device__ __forceinline__ Fr int_neg(const Fr &a) {
+    Fr z = fr_zero(), r;
+    fr_sub256(r, z, a);
+    return r;
+}
+__device__ __forceinline__ Fr int_mul_lo(const Fr &a, const Fr &b) {  // low 256 bits of a * b
+    uint32_t r[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k + i < 8; k++) {
+            c += (uint64_t)a.v[i] * b.v[k] + r[i + k];
+            r[i + k] = (uint32_t)c;
+            c >>= 32;
+        }
+    }
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = r[i];
+    return o;
+}
+__device__ __forceinline__ uint32_t limb_or_zero(const Fr &a, int idx) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k == idx) r = a.v[k];
+    return r;
+}
+__device__ __forceinline__ Fr int_shl(const Fr &a, uint32_t s) {  // s < 256
+    const int q = (int)(s >> 5);
+    const uint32_t rs = s & 31u;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = limb_or_zero(a, i - q) << rs;
+        if (rs) v |= limb_or_zero(a, i - q - 1) >> (32u - rs);
+        r.v[i] = v;
+    }
+    return r;
+}
+__device__ __forceinline__ Fr int_shr(const Fr &a, uint32_t s) {  // s < 256
+    const int q = (int)(s >> 5);
+    const uint32_t rs = s & 31u;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = limb_or_zero(a, i + q) >> rs;
+        if (rs) v |= limb_or_zero(a, i + q + 1) << (32u - rs);
+        r.v[i] = v;
+    }
+    return r;
+}
+// two's complement view of SignedDiv (arithmetic.rs:84-98): a < 2^(bits-1) -> (+, a); a < 2^bits -> (-, 2^bits - a); else (+, a - 2^bits)
+__device__ __forceinline__ bool int_to_signed(const Fr &a, uint32_t bits, Fr &mag) {
+    if (int_cmp(a, int_pow2(bits - 1u)) < 0) { mag = a; return false; }
+    if (bits == 256u) { mag = int_neg(a); return true; }
+    const Fr full = int_pow2(bits);
+    if (int_cmp(a, full) < 0) { fr_sub256(mag, full, a); return true; }
+    fr_sub256(mag, a, full);
+    return false;
+}
+
+// evaluate_binary_bigint_op (arithmetic.rs:23-81) + the conversion back to a field element (from_be_bytes_reduce)
+static inline __device__ __noinline__ Fr brillig_int_op(BrVm &vm, uint32_t op, uint32_t bits, const Fr &fa, const Fr &fb) {
+    Fr a = fr_to_canonical(fa), b = fr_to_canonical(fb), r = fr_zero();
+    if (bits > 256u) { vm.panic(BP_BITS_256); return r; }
+    switch (op) {
+    case 0: fr_add256(r, a, b); r = int_mask(r, bits); break;  // a, b < 2^254: no carry out of 256 bits
+    case 1: {  // (2^bits + a - b) % 2^bits; BigUint underflow when b > 2^bits + a
+        const bool borrow = fr_sub256(r, a, b) != 0;
+        if (borrow && bits < 256u && int_cmp(int_neg(r), int_pow2(bits)) > 0) { vm.panic(BP_SUB_OVERFLOW); return fr_zero(); }
+        r = int_mask(r, bits);
+        break;
+    }
+    case 2: r = int_mask(int_mul_lo(a, b), bits); break;
+    case 3: {  // SignedDiv
+        if (bits == 0u) { vm.panic(BP_SUB_OVERFLOW); return r; }
+        Fr ma, mb, q, rem;
+        const bool sa = int_to_signed(a, bits, ma), sb = int_to_signed(b, bits, mb);
+        if (fr_is_zero(mb)) { vm.panic(BP_DIV_ZERO); return r; }
+        canon_divrem(ma, mb, q, rem);
+        if (!((sa != sb) && !fr_is_zero(q))) r = q;
+        else if (bits == 256u) r = int_neg(q);
+        else {
+            if (int_cmp(q, int_pow2(bits)) > 0) { vm.panic(BP_SUB_OVERFLOW); return r; }
+            fr_sub256(r, int_pow2(bits), q);
+        }
+        break;
+    }
+    case 4: {  // UnsignedDiv
+        a = int_mask(a, bits);
+        b = int_mask(b, bits);
+        if (fr_is_zero(b)) { vm.panic(BP_DIV_ZERO); return r; }
+        Fr rem;
+        canon_divrem(a, b, r, rem);
+        break;
+    }
+    case 5: case 6: case 7: {
+        const int c = int_cmp(int_mask(a, bits), int_mask(b, bits));
+        r.v[0] = op == 5u ? c == 0 : (op == 6u ? c < 0 : c <= 0);
+        break;
+    }
+    case 8: case 9: case 10:
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = op == 8u ? a.v[i] & b.v[i] : (op == 9u ? a.v[i] | b.v[i] : a.v[i] ^ b.v[i]);
+        r = int_mask(r, bits);
+        break;
+    case 11: case 12: {
+        if (bits > 128u) { vm.panic(BP_SHIFT_BITS); return r; }
+        if (b.v[4] | b.v[5] | b.v[6] | b.v[7]) { vm.panic(BP_UNWRAP); return r; }  // to_u128().unwrap()
+        const bool small = !(b.v[1] | b.v[2] | b.v[3]) && b.v[0] < 256u;
+        if (small) r = int_mask(op == 11u ? int_shl(a, b.v[0]) : int_shr(a, b.v[0]), bits);
+        break;
+    }
+    default: vm.panic(BP_BAD_INT_OP); return r;
+    }
+    return fr_from_canonical(canon_reduce(r));
+}
+
+// black_box.rs:42-165. Operand words: see plan.cpp (HeapVector = pointer reg + size reg, HeapArray = pointer reg + literal)
+static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t bbop, const uint32_t *__restrict__ w, const GrumpkinTables &T) {
+    MsgBuf m{vm.words + (uint64_t)BRILLIG_CALL_STACK * vm.Bp, vm.Bp, vm.j, 0u, 0u};
+    auto heap_vector = [&](uint32_t preg, uint32_t sreg, uint64_t &ptr, uint64_t &len) {
+        const Fr pv = vm.reg_get(preg), sv = vm.reg_get(sreg);
+        return !vm.status && vm.to_usize(pv, ptr) && vm.to_usize(sv, len);
+    };
+    auto mem_byte = [&](uint64_t ptr, uint32_t i) { return fr_to_canonical(vm.mem_get((uint32_t)ptr + i)).v[0] & 0xffu; };
+    uint64_t ptr = 0, len = 0, optr = 0;
+    switch (bbop) {
+    case 0: case 1: case 2: case 3: {  // Sha256, Blake2s, Keccak256, HashToField128Security
+        if (!heap_vector(w[0], w[1], ptr, len) || !vm.mem_check_read(ptr, len)) return;
+        m.begin();
+        for (uint32_t i = 0; i < (uint32_t)len; i++) m.put(mem_byte(ptr, i));
+        m.end();
+        const Digest d = bbop == 0u ? sha256_msg(m, (uint32_t)len) : (bbop == 2u ? keccak256_msg(m, (uint32_t)len) : blake2s_msg(m, (uint32_t)len));
+        if (bbop == 3u) { vm.reg_set(w[2], digest_to_field(d)); return; }
+        const Fr ov = vm.reg_get(w[2]);
+        if (vm.status || !vm.to_usize(ov, optr)) return;
+        for (uint32_t i = 0; i < 32u; i++)
+            if (!vm.mem_write(optr + i, fr_from_u32(d.byte(i)))) return;
+        return;
+    }
+    case 6: {  // SchnorrVerify: pkx, pky, message (ptr, size), signature (ptr, size), result
+        const Fr pkx = vm.reg_get(w[0]), pky = vm.reg_get(w[1]);
+        uint64_t mp = 0, ml = 0, sp = 0, sl = 0;
+        if (!heap_vector(w[2], w[3], mp, ml) || !vm.mem_check_read(mp, ml)) return;
+        if (!heap_vector(w[4], w[5], sp, sl) || !vm.mem_check_read(sp, sl)) return;
+        if (sl < 64u) { vm.status = 4; vm.code = 100u; vm.x0 = (uint32_t)sl; return; }      // lib.rs:50-52 slice panic
+        if (128u + ml >= 1024u) { vm.status = 4; vm.code = 101u; return; }                  // wasm/schnorr.rs:79-82
+        const bool ok = grumpkin_schnorr_verify(T, pkx, pky, [&](uint32_t i) { return mem_byte(sp, i); }, (uint32_t)ml,
+                                                [&](uint32_t i) { return mem_byte(mp, i); }, m);
+        vm.reg_set(w[6], ok ? fr_one() : fr_zero());
+        return;
+    }
+    case 7: {  // Pedersen: inputs (ptr, size), domain separator, output (ptr, literal)
+        if (!heap_vector(w[0], w[1], ptr, len) || !vm.mem_check_read(ptr, len)) return;
+        const Fr ds = fr_to_canonical(vm.reg_get(w[2]));
+        if (vm.status) return;
+        if (ds.v[1] | ds.v[2] | ds.v[3]) { vm.status = 2; vm.code = DM_PEDERSEN_DOMAIN; return; }  // to_u128().try_into::<u32>() fails
+        Fr x, y;
+        grumpkin_pedersen(T, (uint32_t)len, ds.v[0], [&](uint32_t i) { return vm.mem_get((uint32_t)ptr + i); }, x, y);
+        const Fr ov = vm.reg_get(w[3]);
+        if (vm.status || !vm.to_usize(ov, optr)) return;
+        if (vm.mem_write(optr, x)) vm.mem_write(optr + 1, y);
+        return;
+    }
+    case 8: {  // FixedBaseScalarMul: low, high, result (ptr, literal)
+        const Fr lo = vm.reg_get(w[0]), hi = vm.reg_get(w[1]);
+        if (vm.status) return;
+        Fr x, y;
+        const OpResult e = grumpkin_fixed_base_values<FastPolicy>(lo, hi, T, x, y);
+        if (e.err) {  // BlackBoxResolutionError::Failed -> the VM fails with its Display string
+            vm.status = 2;
+            vm.code = e.msg;
+            vm.val = fr_to_canonical(e.msg == DM_LIMB_HIGH ? hi : lo);
+            if (e.msg == DM_SCALAR) {
+                const Fr cl = fr_to_canonical(lo), ch = fr_to_canonical(hi);
+                vm.val = Fr{{cl.v[0], cl.v[1], cl.v[2], cl.v[3], ch.v[0], ch.v[1], ch.v[2], ch.v[3]}};
+            }
+            return;
+        }
+        const Fr ov = vm.reg_get(w[2]);
+        if (vm.status || !vm.to_usize(ov, optr)) return;
+        if (vm.mem_write(optr, x)) vm.mem_write(optr + 1, y);
+        return;
+    }
+    default: vm.panic(BP_BAD_BB); return;
+    }
+}
+
+// [K_BRILLIG, opcode, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap,
+//  E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
+template <class P>
+__device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__restrict__ r, const DeviceProgram &dp, uint32_t *scratch, SlowResult *res) {
+    const uint32_t has_pred = r[2], n_inputs = r[3], n_outputs = r[4], n_bc = r[6];
+    const uint32_t *__restrict__ bc = dp.bytecode + r[5];
+    const uint32_t *q = r + 9;
+    Fr pred = fr_one();
+    if (has_pred) {  // brillig.rs:28-31: get_value error passes through (MissingAssignment)
+        const OpResult e = expr_value(p, q, dp.consts, pred);
+        if (e.err) return e;
+        q += expr_len(q);
+    }
+    // locate the outputs behind the inputs
+    const uint32_t *inputs = q;
+    for (uint32_t i = 0; i < n_inputs; i++) {
+        const uint32_t n = q[1];
+        q += 2;
+        for (uint32_t k = 0; k < n; k++) q += expr_len(q);
+    }
+    const uint32_t *outputs = q;
+    if (fr_is_zero(pred)) {  // zero_out_brillig_outputs (brillig.rs:133-150)
+        q = outputs;
+        for (uint32_t i = 0; i < n_outputs; i++) {
+            const uint32_t n = q[1];
+            q += 2;
+            for (uint32_t k = 0; k < n; k++, q += 2)
+                if (!p.insert(q[0], fr_zero(), q[1])) return op_fail(DE_UNSATISFIED);
+        }
+        return op_ok();
+    }
+    BrVm vm;
+    vm.n_regs = r[7];
+    vm.mem_cap = r[8];
+    vm.slots = (uint4 *)scratch;
+    vm.words = scratch + (uint64_t)(vm.n_regs + vm.mem_cap) * 8u * p.Bp;
+    vm.Bp = p.Bp;
+    vm.j = p.j;
+    vm.n_mem = vm.n_cs = vm.pc = vm.status = vm.code = vm.x0 = 0u;
+    vm.val = fr_zero();
+    for (uint32_t i = 0; i < vm.n_regs; i++) fr_store(vm.slots, i, vm.Bp, vm.j, fr_zero());  // unset registers read 0 (registers.rs:25-33)
+    // inputs (brillig.rs:46-74): an expression that does not reduce to a constant is ExpressionHasTooManyUnknowns
+    q = inputs;
+    for (uint32_t i = 0; i < n_inputs; i++) {
+        const uint32_t is_array = q[0], n = q[1];
+        q += 2;
+        const uint32_t base = vm.n_mem;
+        for (uint32_t k = 0; k < n; k++) {
+            Fr v;
+            const OpResult e = expr_value(p, q, dp.consts, v);
+            if (e.err) return op_fail(DE_TOO_MANY_UNKNOWNS);
+            q += expr_len(q);
+            if (is_array) { if (!vm.mem_write(vm.n_mem, v)) return op_fail_msg(DE_PANIC, 0, DM_BRILLIG_MEM_CAP, vm.x0); }
+            else vm.reg_set(i, v);
+        }
+        if (is_array) vm.reg_set(i, fr_from_u32(base));
+    }
+    // process_opcodes (lib.rs:136-142)
+    if (n_bc == 0) vm.panic(BP_BYTECODE_OOB);
+    uint32_t steps = 0;
+    while (!vm.status) {
+        if (++steps > BRILLIG_STEP_LIMIT) { vm.status = 5; vm.code = DM_BRILLIG_STEP_LIMIT; break; }
+        const uint32_t *__restrict__ ins = bc + 8u * vm.pc;
+        const uint32_t op = ins[0], a = ins[1], b = ins[2], c = ins[3];
+        uint32_t next = vm.pc + 1u;
+        switch (op) {
+        case BRO_BINARY_FIELD_OP: {  // arithmetic.rs:7-20
+            const Fr x = vm.reg_get(b), y = vm.reg_get(c);
+            Fr v;
+            switch (ins[4] & 0xffu) {
+            case 0: v = fr_add(x, y); break;
+            case 1: v = fr_sub(x, y); break;
+            case 2: v = fr_mul(x, y); break;
+            case 3: v = fr_mul(x, fr_inv(y)); break;
+            default: v = fr_eq(x, y) ? fr_one() : fr_zero(); break;
+            }
+            vm.reg_set(a, v);
+            break;
+        }
+        case BRO_BINARY_INT_OP: {
+            const Fr x = vm.reg_get(b), y = vm.reg_get(c);
+            if (vm.status) break;
+            const Fr v = brillig_int_op(vm, ins[4] & 0xffu, ins[4] >> 8, x, y);
+            if (!vm.status) vm.reg_set(a, v);
+            break;
+        }
+        case BRO_JUMP: next = ins[5]; break;
+        case BRO_JUMP_IF: if (!fr_is_zero(vm.reg_get(a))) next = ins[5]; break;
+        case BRO_JUMP_IF_NOT: if (fr_is_zero(vm.reg_get(a))) next = ins[5]; break;
+        case BRO_RETURN:
+            if (vm.n_cs) next = vm.words[(uint64_t)(--vm.n_cs) * vm.Bp + vm.j] + 1u;
+            else { vm.status = 2; vm.code = DM_BRILLIG_RETURN; }
+            break;
+        case BRO_CALL:
+            if (vm.n_cs >= BRILLIG_CALL_STACK) { vm.status = 5; vm.code = DM_BRILLIG_STEP_LIMIT; break; }
+            vm.words[(uint64_t)(vm.n_cs++) * vm.Bp + vm.j] = vm.pc;
+            next = ins[5];
+            break;
+        case BRO_CONST: vm.reg_set(a, fr_const(dp.consts, ins[6])); break;
+        case BRO_MOV: vm.reg_set(a, vm.reg_get(b)); break;
+        case BRO_LOAD: {  // a = destination, b = source pointer
+            uint64_t u;
+            const Fr pv = vm.reg_get(b);
+            if (vm.status || !vm.to_usize(pv, u) || !vm.mem_check_read(u, 1)) break;
+            vm.reg_set(a, vm.mem_get((uint32_t)u));
+            break;
+        }
+        case BRO_STORE: {  // a = destination pointer, b = source
+            uint64_t u;
+            const Fr pv = vm.reg_get(a);
+            if (vm.status || !vm.to_usize(pv, u)) break;
+            const Fr v = vm.reg_get(b);
+            if (!vm.status) vm.mem_write(u, v);
+            break;
+        }
+        case BRO_TRAP: vm.status = 2; vm.code = DM_BRILLIG_TRAP; break;
+        case BRO_STOP: vm.status = 1; break;
+        case BRO_BLACK_BOX: brillig_black_box(vm, ins[4], dp.bytecode + ins[7], dp.grumpkin); break;
+        default: vm.panic(BP_BAD_OPCODE); break;
+        }
+        if (vm.status) break;
+        vm.pc = next;  // set_program_counter (lib.rs:322-329)
+        if (vm.pc >= n_bc) vm.status = 1;
+    }
+    if (vm.status == 1) {  // Finished (brillig.rs:95-111): register i -> output i
+        q = outputs;
+        for (uint32_t i = 0; i < n_outputs; i++) {
+            const uint32_t is_array = q[0], n = q[1];
+            q += 2;
+            const Fr rv = vm.reg_get(i);
+            if (!is_array) {
+                if (!p.insert(q[0], rv, q[1])) return op_fail(DE_UNSATISFIED);
+                q += 2;
+                continue;
+            }
+            const Fr cb = fr_to_canonical(rv);
+            if (cb.v[2] | cb.v[3] | cb.v[4] | cb.v[5] | cb.v[6] | cb.v[7]) return op_fail_msg(DE_PANIC, 0, DM_BRILLIG_PANIC, BP_U64);
+            const uint64_t base = (uint64_t)cb.v[1] << 32 | cb.v[0];
+            for (uint32_t k = 0; k < n; k++, q += 2) {
+                if (base + k >= vm.n_mem) return op_fail_msg(DE_PANIC, 0, DM_BRILLIG_PANIC, BP_OUT_MEM_OOB);
+                if (!p.insert(q[0], vm.mem_get((uint32_t)(base + k)), q[1])) return op_fail(DE_UNSATISFIED);
+            }
+        }
+        return op_ok();
+    }
+    if (vm.status == 2) {  // BrilligFunctionFailed { message, call_stack } (brillig.rs:113-125): call stack + failing pc
+        if (res) {
+            uint32_t n = 0;
+            for (uint32_t k = 0; k < vm.n_cs && n < 15u; k++) res->call_stack[n++] = vm.words[(uint64_t)k * vm.Bp + vm.j];
+            res->call_stack[n++] = vm.pc;
+            res->n_call_stack = n;
+#pragma unroll
+            for (int k = 0; k < 8; k++) res->val[k] = vm.val.v[k];
+        }
+        return op_fail_msg(DE_BRILLIG_FAILED, 0, vm.code);
+    }
+    if (vm.status == 5) return op_fail_msg(DE_PANIC, 0, vm.code, vm.x0);
+    return op_fail_msg(DE_PANIC, 0, DM_BRILLIG_PANIC, vm.code, vm.x0);
+}
+
+}  // namespace acvm

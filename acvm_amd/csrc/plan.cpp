@@ -271,7 +271,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
             case OP_BRILLIG: {
                 // [PK_BRILLIG, oi, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap,
-                //  inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)..., E(pred)?]
+                //  E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
                 const BrilligCall &b = *o.brillig;
                 p.prog_class[oi] = CLS_BRILLIG;
                 uint32_t bc_off = (uint32_t)p.bytecode.size();
@@ -337,6 +337,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 p.prog_scratch[oi] = (uint32_t)((n_regs + mem_cap) * 8 + 64 + (max_hash_hint ? mem_cap / 4 + 16 : 0));
                 s.insert(s.end(), {PK_BRILLIG, oi, b.has_predicate ? 1u : 0u, (uint32_t)b.inputs.size(), (uint32_t)b.outputs.size(), bc_off,
                                    (uint32_t)b.bytecode.size(), n_regs, (uint32_t)mem_cap});
+                if (b.has_predicate) emit_expr(s, pool, b.predicate);
                 for (auto &in : b.inputs) {
                     s.push_back(in.is_array ? 1u : 0u);
                     s.push_back(in.is_array ? (uint32_t)in.arr.size() : 1u);
@@ -349,7 +350,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     if (ot.is_array) for (uint32_t w : ot.arr) out(w);
                     else out(ot.w);
                 }
-                if (b.has_predicate) emit_expr(s, pool, b.predicate);
                 break;
             }
             default:

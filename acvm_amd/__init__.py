@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "acvm_circuit_num_witnesses", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
     "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_reset", "acvm_batch_set_force_slow_path",
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
-    "acvm_batch_set_profiling",
+    "acvm_batch_set_profiling", "acvm_batch_pending_foreign_call", "acvm_batch_pending_foreign_call_inputs",
+    "acvm_batch_resolve_foreign_call",
 ]
 
 
@@ -40,6 +41,11 @@ class Result(C.Structure):
 
     def as_tuple(self):
         return (self.status, self.err, self.opcode_index, self.aux0, self.aux1)
+
+
+class ForeignCallInfo(C.Structure):
+    _fields_ = [("opcode_index", C.c_uint32), ("brillig_index", C.c_uint32), ("n_inputs", C.c_uint32), ("n_values", C.c_uint32),
+                ("function", C.c_char * 64)]
 
 
 class Stats(C.Structure):
@@ -90,6 +96,9 @@ def lib():
     L.acvm_batch_witness.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.acvm_batch_witness_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.acvm_batch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.acvm_batch_pending_foreign_call.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ForeignCallInfo)]
+    L.acvm_batch_pending_foreign_call_inputs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.acvm_batch_resolve_foreign_call.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_char_p]
     _lib = L
     return L
 
@@ -206,6 +215,27 @@ class Batch:
         vals = np.zeros((n, self.nw, 32), dtype=np.uint8)
         _check(lib().acvm_batch_witness_map(self._h, first, n, asg.ctypes.data, vals.ctypes.data))
         return asg, vals
+
+    def get_pending_foreign_call(self, instance: int):
+        """ACVM::get_pending_foreign_call: None, or (function, [[int, ...] per input])."""
+        info = ForeignCallInfo()
+        if _check(lib().acvm_batch_pending_foreign_call(self._h, instance, C.byref(info))) == 0:
+            return None
+        lens = (C.c_uint32 * max(info.n_inputs, 1))()
+        vals = C.create_string_buffer(32 * max(info.n_values, 1))
+        _check(lib().acvm_batch_pending_foreign_call_inputs(self._h, instance, lens, vals))
+        out, k = [], 0
+        for i in range(info.n_inputs):
+            out.append([int.from_bytes(vals.raw[32 * (k + c):32 * (k + c + 1)], "big") for c in range(lens[i])])
+            k += lens[i]
+        return info.function.decode(), out
+
+    def resolve_pending_foreign_call(self, instance: int, values):
+        """values: list of int (Single) or list[int] (Array), like ForeignCallResult."""
+        is_arr = bytes(0 if isinstance(v, int) else 1 for v in values)
+        lens = (C.c_uint32 * max(len(values), 1))(*[1 if isinstance(v, int) else len(v) for v in values])
+        flat = b"".join(int(v).to_bytes(32, "big") if isinstance(v, int) else b"".join(int(x).to_bytes(32, "big") for x in v) for v in values)
+        _check(lib().acvm_batch_resolve_foreign_call(self._h, instance, len(values), is_arr, lens, flat))
 
     def stats(self) -> dict:
         s = Stats()

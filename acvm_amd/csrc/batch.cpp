@@ -66,6 +66,15 @@ struct acvm_batch {
     std::vector<hipEvent_t> ev_sync;
     uint4 *d_dyn_scratch = nullptr;
     uint32_t n_launches = 0;
+    // Brillig foreign-call round trip (exact lanes only)
+    struct FcValue { bool is_array; std::vector<FrH> vals; };
+    struct FcLaneState { uint32_t opcode = 0xFFFFFFFFu; std::vector<std::vector<FcValue>> results; bool resolved_new = false; };
+    std::vector<FcLaneState> fc_lane;
+    uint32_t *d_fc_res_opcode = nullptr, *d_fc_res_desc = nullptr, *d_fc_pend_desc = nullptr;
+    uint4 *d_fc_res_vals = nullptr, *d_fc_pend_vals = nullptr;
+    uint32_t fc_res_desc_words = 0, fc_res_vals_cap = 0, fc_pend_desc_words = 0, fc_pend_vals_cap = 0, fc_lanes_cap = 0;
+    std::vector<uint32_t> h_pend_desc, h_pend_vals;
+    bool pend_host_valid = false;
 
     ~acvm_batch() {
         hipSetDevice(device);
@@ -79,6 +88,8 @@ struct acvm_batch {
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
         if (d_dyn_scratch) hipFree(d_dyn_scratch);
+        for (void *p : {(void *)d_fc_res_opcode, (void *)d_fc_res_desc, (void *)d_fc_pend_desc, (void *)d_fc_res_vals, (void *)d_fc_pend_vals})
+            if (p) hipFree(p);
         if (stream_dyn) hipStreamDestroy(stream_dyn);
         if (ev_start) hipEventDestroy(ev_start);
         if (ev_end) hipEventDestroy(ev_end);
@@ -342,13 +353,136 @@ static int ensure_slow_capacity(acvm_batch *b, uint32_t n) {
 }
 
 static ExactLanes exact_lanes(acvm_batch *b, uint32_t n_slow) {
-    return ExactLanes{b->d_slow_ids, n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res};
+    FcLanes fc{b->d_fc_res_opcode, b->d_fc_res_desc, b->fc_res_desc_words, b->d_fc_res_vals, b->d_fc_pend_desc, b->fc_pend_desc_words,
+               b->d_fc_pend_vals, b->fc_pend_vals_cap};
+    return ExactLanes{b->d_slow_ids, n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res, fc};
+}
+
+// (re)build the device tables of the foreign-call round trip for the current exact lanes: the results the host resolved
+// (FcLanes::res_*) and the buffers a pending call's inputs are written to (FcLanes::pend_*)
+static int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
+    const Plan &p = b->plan;
+    if (!p.has_foreign_calls || !n_slow) return 0;
+    b->fc_lane.resize(n_slow);
+    uint32_t desc_words = 1, vals = 1;
+    for (auto &ls : b->fc_lane) {
+        uint32_t dw = 1, nv = 0;
+        for (auto &res : ls.results) {
+            dw += 1 + 2 * (uint32_t)res.size();
+            for (auto &v : res) nv += (uint32_t)v.vals.size();
+        }
+        desc_words = std::max(desc_words, dw);
+        vals = std::max(vals, nv);
+    }
+    const uint32_t pend_words = 1 + p.fc_max_inputs, pend_vals = (uint32_t)std::max<uint64_t>(1, p.fc_pending_vals);
+    if (n_slow > b->fc_lanes_cap || desc_words > b->fc_res_desc_words || vals > b->fc_res_vals_cap) {
+        for (void *q : {(void *)b->d_fc_res_opcode, (void *)b->d_fc_res_desc, (void *)b->d_fc_pend_desc, (void *)b->d_fc_res_vals, (void *)b->d_fc_pend_vals})
+            if (q) hipFree(q);
+        b->d_fc_res_opcode = b->d_fc_res_desc = b->d_fc_pend_desc = nullptr;
+        b->d_fc_res_vals = b->d_fc_pend_vals = nullptr;
+        b->fc_lanes_cap = n_slow;
+        b->fc_res_desc_words = desc_words + 16;
+        b->fc_res_vals_cap = vals + 64;
+        b->fc_pend_desc_words = pend_words;
+        b->fc_pend_vals_cap = pend_vals;
+        HIPCHK(hipMalloc((void **)&b->d_fc_res_opcode, (size_t)n_slow * 4));
+        HIPCHK(hipMalloc((void **)&b->d_fc_res_desc, (size_t)b->fc_res_desc_words * n_slow * 4));
+        HIPCHK(hipMalloc((void **)&b->d_fc_res_vals, (size_t)b->fc_res_vals_cap * 2 * n_slow * sizeof(uint4)));
+        HIPCHK(hipMalloc((void **)&b->d_fc_pend_desc, (size_t)b->fc_pend_desc_words * n_slow * 4));
+        HIPCHK(hipMalloc((void **)&b->d_fc_pend_vals, (size_t)b->fc_pend_vals_cap * 2 * n_slow * sizeof(uint4)));
+    }
+    std::vector<uint32_t> opc(n_slow), desc((size_t)b->fc_res_desc_words * n_slow, 0), vbuf((size_t)b->fc_res_vals_cap * 2 * n_slow * 4, 0);
+    for (uint32_t t = 0; t < n_slow; t++) {
+        const auto &ls = b->fc_lane[t];
+        opc[t] = ls.opcode;
+        uint32_t w = 0, vi = 0;
+        desc[(size_t)(w++) * n_slow + t] = (uint32_t)ls.results.size();
+        for (auto &res : ls.results) {
+            desc[(size_t)(w++) * n_slow + t] = (uint32_t)res.size();
+            for (auto &v : res) {
+                desc[(size_t)(w++) * n_slow + t] = v.is_array ? 1u : 0u;
+                desc[(size_t)(w++) * n_slow + t] = (uint32_t)v.vals.size();
+                for (auto &x : v.vals) {  // slot vi: halves at (2 vi) * n_slow + t and (2 vi + 1) * n_slow + t, 4 words each
+                    memcpy(&vbuf[((size_t)(2 * vi) * n_slow + t) * 4], &x.l[0], 16);
+                    memcpy(&vbuf[((size_t)(2 * vi + 1) * n_slow + t) * 4], &x.l[2], 16);
+                    vi++;
+                }
+            }
+        }
+    }
+    HIPCHK(hipMemcpyAsync(b->d_fc_res_opcode, opc.data(), opc.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_fc_res_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_fc_res_vals, vbuf.data(), vbuf.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+// run the exact in-order kernels over the current lanes from opcode min_start on and fetch the outcomes
+static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start) {
+    const Plan &p = b->plan;
+    hipStream_t s = b->stream;
+    const ExactLanes L = exact_lanes(b, n_slow);
+    // memory side effects of the opcodes before the earliest event are replayed by the span kernel, so start at the
+    // first segment that holds a memory opcode or the earliest event, whichever comes first
+    bool has_mem = p.mem_cells != 0;
+    for (const ExactSegment &seg : b->segments) {
+        if (seg.end <= min_start && !(has_mem && seg.cls == CLS_LIGHT)) continue;
+        switch (seg.cls) {
+        case CLS_LIGHT: launch_exact_span(s, b->d_W, b->Bp, b->dp, L, seg.begin, seg.end); break;
+        case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
+        case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
+        case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
+        }
+    }
+    launch_exact_finish(s, L);
+    HIPCHK(hipGetLastError());
+    b->slow_res.resize(n_slow);
+    HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
+    b->pend_host_valid = false;
+    return 0;
+}
+
+static int count_not_solved(acvm_batch *b) {
+    int n = 0;
+    for (auto &r : b->slow_res)
+        if (r.status != ACVM_STATUS_SOLVED) n++;
+    return n;
+}
+
+// continue the instances whose pending foreign call was resolved (ACVM::solve after resolve_pending_foreign_call)
+static int solve_resume(acvm_batch *b) {
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    uint32_t min_start = 0xFFFFFFFFu;
+    std::vector<uint32_t> resumed;
+    for (uint32_t t = 0; t < n_slow; t++)
+        if (b->slow_res[t].status == ACVM_STATUS_REQUIRES_FOREIGN_CALL && b->fc_lane[t].resolved_new) {
+            resumed.push_back(t);
+            b->fc_lane[t].resolved_new = false;
+            b->slow_start[t] = b->slow_res[t].opcode_index;
+            min_start = std::min(min_start, b->slow_start[t]);
+            b->slow_res[t].status = ACVM_STATUS_IN_PROGRESS;
+        }
+    if (resumed.empty()) return count_not_solved(b);
+    if (int rc = upload_fc_tables(b, n_slow)) return rc;
+    hipStream_t s = b->stream;
+    HIPCHK(hipEventRecord(b->ev_start, s));
+    HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_slow_res, b->slow_res.data(), (size_t)n_slow * sizeof(SlowResult), hipMemcpyHostToDevice, s));
+    if (int rc = run_exact_segments(b, n_slow, min_start)) return rc;
+    HIPCHK(hipEventRecord(b->ev_end, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev_start, b->ev_end));
+    b->solve_device_ms = ms;
+    b->slow_path_ms = ms;
+    return count_not_solved(b);
 }
 
 int acvm_batch_solve(acvm_batch_t *b) {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
     HIPCHK(hipSetDevice(b->device));
+    if (b->solved) return solve_resume(b);  // only resolved foreign calls can change anything
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
     hipStream_t s2 = b->stream_dyn;
@@ -458,25 +592,11 @@ int acvm_batch_solve(acvm_batch_t *b) {
         slow1 = next_event();
         hipEventRecord(slow0, s);
         launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
-        const ExactLanes L = exact_lanes(b, n_slow);
-        launch_exact_init(s, L);
-        // memory side effects of the opcodes before the earliest event are replayed by the span kernel, so start at the
-        // first segment that holds a memory opcode or the earliest event, whichever comes first
-        bool has_mem = p.mem_cells != 0;
-        for (const ExactSegment &seg : b->segments) {
-            if (seg.end <= min_start && !(has_mem && seg.cls == CLS_LIGHT)) continue;
-            switch (seg.cls) {
-            case CLS_LIGHT: launch_exact_span(s, b->d_W, b->Bp, b->dp, L, seg.begin, seg.end); break;
-            case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
-            case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
-            case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
-            }
-        }
-        launch_exact_finish(s, L);
+        b->fc_lane.assign(n_slow, acvm_batch::FcLaneState());
+        if (int rc = upload_fc_tables(b, n_slow)) return rc;
+        launch_exact_init(s, exact_lanes(b, n_slow));
+        if (int rc = run_exact_segments(b, n_slow, min_start)) return rc;
         hipEventRecord(slow1, s);
-        HIPCHK(hipGetLastError());
-        b->slow_res.resize(n_slow);
-        HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipEventRecord(b->ev_end, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -501,10 +621,93 @@ int acvm_batch_solve(acvm_batch_t *b) {
         b->slow_path_ms = t;
     }
     b->solved = true;
-    int not_solved = 0;
-    for (uint32_t t = 0; t < n_slow; t++)
-        if (b->slow_res[t].status != ACVM_STATUS_SOLVED) not_solved++;
-    return not_solved;
+    if (!n_slow) b->slow_res.clear();
+    return count_not_solved(b);
+}
+
+// ---- ACVM::get_pending_foreign_call / resolve_pending_foreign_call (pwg/mod.rs:203-228) per instance
+static int fetch_pending(acvm_batch *b) {
+    if (b->pend_host_valid) return 0;
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    b->h_pend_desc.assign((size_t)b->fc_pend_desc_words * n_slow, 0);
+    b->h_pend_vals.assign((size_t)b->fc_pend_vals_cap * 2 * n_slow * 4, 0);
+    if (n_slow && b->d_fc_pend_desc) {
+        HIPCHK(hipMemcpy(b->h_pend_desc.data(), b->d_fc_pend_desc, b->h_pend_desc.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b->h_pend_vals.data(), b->d_fc_pend_vals, b->h_pend_vals.size() * 4, hipMemcpyDeviceToHost));
+    }
+    b->pend_host_valid = true;
+    return 0;
+}
+static int waiting_lane(acvm_batch *b, uint32_t instance) {
+    if (!b->solved || instance >= b->B) return -1;
+    int32_t t = b->slow_index[instance];
+    if (t < 0 || b->slow_res[t].status != ACVM_STATUS_REQUIRES_FOREIGN_CALL) return -1;
+    return t;
+}
+
+int acvm_batch_pending_foreign_call(acvm_batch_t *b, uint32_t instance, acvm_foreign_call_info_t *info) {
+    if (!b || !info) return set_err(ACVM_E_INVALID, "null argument");
+    memset(info, 0, sizeof *info);
+    int t = waiting_lane(b, instance);
+    if (t < 0) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    if (int rc = fetch_pending(b)) return rc;
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    const SlowResult &sr = b->slow_res[t];
+    info->opcode_index = sr.opcode_index;
+    info->brillig_index = sr.x0;
+    info->n_inputs = b->h_pend_desc[t];
+    for (uint32_t i = 0; i < info->n_inputs; i++) info->n_values += b->h_pend_desc[(size_t)(1 + i) * n_slow + t];
+    auto it = b->plan.fc_function.find(((uint64_t)sr.opcode_index << 32) | sr.x0);
+    snprintf(info->function, sizeof info->function, "%s", it == b->plan.fc_function.end() ? "" : it->second.c_str());
+    return 1;
+}
+
+int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, uint32_t *lens, uint8_t *values_be32) {
+    if (!b || !lens || !values_be32) return set_err(ACVM_E_INVALID, "null argument");
+    int t = waiting_lane(b, instance);
+    if (t < 0) return set_err(ACVM_E_STATE, "instance is not waiting for a foreign call");
+    HIPCHK(hipSetDevice(b->device));
+    if (int rc = fetch_pending(b)) return rc;
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    const uint32_t n_in = b->h_pend_desc[t];
+    uint32_t vi = 0;
+    for (uint32_t i = 0; i < n_in; i++) {
+        lens[i] = b->h_pend_desc[(size_t)(1 + i) * n_slow + t];
+        for (uint32_t c = 0; c < lens[i]; c++, vi++) {
+            FrH m;
+            memcpy(&m.l[0], &b->h_pend_vals[((size_t)(2 * vi) * n_slow + t) * 4], 16);
+            memcpy(&m.l[2], &b->h_pend_vals[((size_t)(2 * vi + 1) * n_slow + t) * 4], 16);
+            uint64_t can[4];
+            frh::to_canonical(m, can);
+            for (int k = 0; k < 32; k++) values_be32[(size_t)vi * 32 + 31 - k] = (uint8_t)(can[k / 8] >> (8 * (k % 8)));
+        }
+    }
+    return 0;
+}
+
+int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t n_values, const uint8_t *is_array, const uint32_t *lens,
+                                    const uint8_t *values_be32) {
+    if (!b || (n_values && (!is_array || !lens || !values_be32))) return set_err(ACVM_E_INVALID, "null argument");
+    int t = waiting_lane(b, instance);
+    if (t < 0) return set_err(ACVM_E_STATE, "ACVM is not expecting a foreign call response as no call was made");  // mod.rs:215-217 panics
+    auto &ls = b->fc_lane[t];
+    const uint32_t opcode = b->slow_res[t].opcode_index;
+    if (ls.opcode != opcode) {  // results accumulate per Brillig opcode (brillig.foreign_call_results.push, mod.rs:223)
+        ls.results.clear();
+        ls.opcode = opcode;
+    }
+    if (ls.resolved_new) return set_err(ACVM_E_STATE, "this instance's pending foreign call was already resolved; call acvm_batch_solve");
+    std::vector<acvm_batch::FcValue> res(n_values);
+    size_t off = 0;
+    for (uint32_t i = 0; i < n_values; i++) {
+        res[i].is_array = is_array[i] != 0;
+        uint32_t n = res[i].is_array ? lens[i] : 1;
+        for (uint32_t c = 0; c < n; c++, off++) res[i].vals.push_back(frh::from_be_bytes32_reduce(values_be32 + off * 32, 32));
+    }
+    ls.results.push_back(std::move(res));
+    ls.resolved_new = true;
+    return 0;
 }
 
 // one witness of one instance as 32 canonical big-endian bytes (message texts only; rare)
@@ -586,6 +789,8 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
                                         "bad brillig opcode", "", "index out of bounds: brillig memory", "bad black box op"};
         if (sr.x0 == 100) snprintf(r.message, sizeof r.message, "range end index 64 out of range for slice of length %u", sr.x1);
         else if (sr.x0 == 101) snprintf(r.message, sizeof r.message, "Message overran wasm scratch space");
+        else if (sr.x0 == 102) snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode (expected 1 result)");
+        else if (sr.x0 == 103) snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode size");
         else snprintf(r.message, sizeof r.message, "%s", sr.x0 < 17 ? texts[sr.x0] : "brillig vm panic");
         break;
     }
@@ -593,6 +798,9 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
     case 18: snprintf(r.message, sizeof r.message, "brillig step limit reached on the device"); break;
     case 19: snprintf(r.message, sizeof r.message, "failed to solve blackbox function inside brillig (code %u)", sr.x0); break;
     case 20: snprintf(r.message, sizeof r.message, "failed to solve blackbox function: pedersen, reason: Invalid signature length"); break;
+    case 21: snprintf(r.message, sizeof r.message, "%u output values were provided as a foreign call result for %u destination slots", sr.x0, sr.val[0]); break;
+    case 22: snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode"); break;
+    case 23: snprintf(r.message, sizeof r.message, "foreign call inputs exceed the device staging buffer"); break;
     default: break;
     }
 }

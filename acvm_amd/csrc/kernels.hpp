@@ -15,6 +15,22 @@ struct SlowResult {
     uint32_t val[8];       // a canonical field value quoted by the message (Brillig black-box limb checks)
 };
 
+// Brillig foreign-call round trip of the exact lanes (ACVM::get_pending_foreign_call / resolve_pending_foreign_call,
+// pwg/mod.rs:203-228). Results the host resolved for the opcode a lane waits at: descriptor words
+// [n_results, (n_values, (is_array, n) x n_values) x n_results] at res_desc[w * n_slow + t], values at res_vals slot i.
+// Inputs of a pending call: pend_desc [n_inputs, len x n_inputs], values in pend_vals. Both value tables are laid out
+// like W with stride n_slow.
+struct FcLanes {
+    const uint32_t *res_opcode;  // per lane: the opcode its resolved results belong to
+    const uint32_t *res_desc;
+    uint32_t res_desc_words;
+    const uint4 *res_vals;
+    uint32_t *pend_desc;
+    uint32_t pend_desc_words;
+    uint4 *pend_vals;
+    uint32_t pend_vals_cap;
+};
+
 // lanes of the exact path: flagged instances gathered through slow_ids
 struct ExactLanes {
     const uint32_t *slow_ids;
@@ -22,6 +38,7 @@ struct ExactLanes {
     uint32_t *assigned;              // bit w of lane t at assigned[(w >> 5) * n_slow + t]
     const uint32_t *start_opcode;    // first opcode the lane executes (its event)
     SlowResult *results;
+    FcLanes fc;
 };
 
 // everything a record needs besides the witness table

@@ -6,8 +6,8 @@ namespace acvm {
 
 struct BrilligOp {
     template <class P>
-    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *scratch, SlowResult *res) {
-        return op_brillig(p, rec, dp, scratch, res);
+    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *scratch, SlowResult *res, const ExactLanes *L, uint32_t t) {
+        return op_brillig(p, rec, dp, scratch, res, L, t);
     }
 };
 

@@ -8,7 +8,7 @@ namespace acvm {
 
 struct GrumpkinOp {
     template <class P>
-    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *scratch, SlowResult *) {
+    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *scratch, SlowResult *, const ExactLanes *, uint32_t) {
         return dispatch_grumpkin(p, rec, dp.grumpkin, scratch);
     }
 };

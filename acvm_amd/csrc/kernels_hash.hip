@@ -7,7 +7,7 @@ namespace acvm {
 
 struct HashOp {
     template <class P>
-    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &, uint32_t *scratch, SlowResult *) {
+    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &, uint32_t *scratch, SlowResult *, const ExactLanes *, uint32_t) {
         return op_hash(p, rec, scratch);
     }
 };

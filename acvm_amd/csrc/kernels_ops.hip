@@ -9,7 +9,7 @@ namespace acvm {
 
 struct LightOp {
     template <class P>
-    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *, SlowResult *) {
+    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *, SlowResult *, const ExactLanes *, uint32_t) {
         return dispatch_light(p, rec, dp.consts, dp.Mem);
     }
 };
@@ -50,7 +50,11 @@ __global__ void exact_init_kernel(ExactLanes L) {
 __global__ void exact_finish_kernel(ExactLanes L) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= L.n_slow) return;
-    if (L.results[t].status == 1u) L.results[t].status = 0u;  // pwg/mod.rs:275-276
+    if (L.results[t].status == 1u) {  // pwg/mod.rs:275-276
+        L.results[t].status = 0u;
+        L.results[t].opcode_index = 0u;  // left over from an earlier RequiresForeignCall stop
+        L.results[t].x0 = 0u;
+    }
 }
 
 void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,

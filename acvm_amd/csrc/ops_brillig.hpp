@@ -275,13 +275,102 @@ static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t 
     }
 }
 
-// [K_BRILLIG, opcode, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap,
+// [K_BRILLIG, opcode, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap, fc_desc_off, fc_vals_off,
 //  E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
+// ForeignCall (brillig_vm/src/lib.rs:190-274). Results come first from the circuit (Brillig::foreign_call_results), then
+// from what the host resolved for this lane. Without a result the VM stops with status 3 and, on the exact path, hands
+// the resolved inputs to the host (ForeignCallWaitInfo, pwg/brillig.rs:157-163).
+static inline __device__ __noinline__ void brillig_foreign_call(BrVm &vm, const uint32_t *__restrict__ ex, const DeviceProgram &dp, uint32_t fc_desc_off,
+                                                                uint32_t fc_vals_off, uint32_t &fc_counter, uint32_t n_bc, uint32_t opcode, const ExactLanes *L, uint32_t t) {
+    const uint32_t n_dests = ex[0], n_in = ex[1];
+    const uint32_t *dests = ex + 2, *ins = dests + 3 * n_dests;
+    // locate result number fc_counter: static table first, then the lane's table
+    const uint32_t *sdesc = dp.bytecode + fc_desc_off;
+    const uint32_t n_static = sdesc[0];
+    const bool is_static = fc_counter < n_static;
+    const uint32_t n_slow = L ? L->n_slow : 0u;
+    auto desc = [&](uint32_t w) { return is_static ? sdesc[w] : L->fc.res_desc[(uint64_t)w * n_slow + t]; };
+    auto value = [&](uint32_t i) { return is_static ? fr_const(dp.consts, dp.bytecode[fc_vals_off + i]) : fr_load(L->fc.res_vals, i, n_slow, t); };
+    uint32_t k = fc_counter;
+    bool found = is_static;
+    if (!is_static) {
+        k -= n_static;
+        found = L && L->fc.res_desc && L->fc.res_opcode[t] == opcode && k < L->fc.res_desc[t];
+    }
+    if (!found) {
+        vm.status = 3;
+        if (!L) return;
+        // ForeignCallWaitInfo inputs: registers as one value, heap arrays / vectors as their memory slice
+        uint32_t nv = 0;
+        if (1u + n_in > L->fc.pend_desc_words) { vm.status = 5; vm.code = DM_FC_PENDING_CAP; return; }
+        L->fc.pend_desc[t] = n_in;
+        for (uint32_t i = 0; i < n_in; i++) {
+            const uint32_t kind = ins[3 * i], rg = ins[3 * i + 1], sz = ins[3 * i + 2];
+            uint64_t start = 0, size = 1;
+            if (kind != 0u) {
+                const Fr pv = vm.reg_get(rg);
+                if (vm.status == 4 || !vm.to_usize(pv, start)) return;
+                size = sz;
+                if (kind == 2u) {
+                    const Fr sv = vm.reg_get(sz);
+                    if (vm.status == 4 || !vm.to_usize(sv, size)) return;
+                }
+                if (!vm.mem_check_read(start, size)) return;
+            }
+            if (nv + size > L->fc.pend_vals_cap) { vm.status = 5; vm.code = DM_FC_PENDING_CAP; return; }
+            L->fc.pend_desc[(uint64_t)(1u + i) * n_slow + t] = (uint32_t)size;
+            for (uint32_t c = 0; c < (uint32_t)size; c++) {
+                const Fr v = kind == 0u ? vm.reg_get(rg) : vm.mem_get((uint32_t)start + c);
+                if (vm.status == 4) return;
+                fr_store(L->fc.pend_vals, nv++, n_slow, t, v);
+            }
+        }
+        return;
+    }
+    // walk to result k
+    uint32_t pos = 1, vpos = 0;
+    for (uint32_t rr = 0; rr < k; rr++) {
+        const uint32_t nvals = desc(pos++);
+        for (uint32_t v = 0; v < nvals; v++, pos += 2) vpos += desc(pos + 1);
+    }
+    const uint32_t n_res = desc(pos++);
+    bool invalid = false;
+    const uint32_t nz = n_dests < n_res ? n_dests : n_res;
+    for (uint32_t i = 0; i < nz; i++, pos += 2) {
+        const uint32_t is_array = desc(pos), n = desc(pos + 1);
+        const uint32_t kind = dests[3 * i], rg = dests[3 * i + 1], sz = dests[3 * i + 2];
+        if (kind == 0u) {
+            if (is_array) { vm.status = 4; vm.code = 102u; return; }  // "Function result size does not match brillig bytecode (expected 1 result)"
+            vm.reg_set(rg, value(vpos));
+        } else {
+            if (!is_array) { vm.status = 4; vm.code = 103u; return; }  // "Function result size does not match brillig bytecode size"
+            if (kind == 1u) {
+                if (n != sz) { invalid = true; break; }
+            } else vm.reg_set(sz, fr_from_u32(n));
+            uint64_t dst = 0;
+            const Fr pv = vm.reg_get(rg);
+            if (vm.status == 4 || !vm.to_usize(pv, dst)) return;
+            for (uint32_t c = 0; c < n; c++)
+                if (!vm.mem_write(dst + c, value(vpos + c))) return;
+        }
+        if (vm.status == 4) return;
+        vpos += n;
+    }
+    // lib.rs:262-270: both checks only record a failure; the program counter still advances
+    bool failed = false;
+    if (n_dests != n_res) { failed = true; vm.code = DM_FC_COUNT; vm.x0 = n_res; vm.val.v[0] = n_dests; }
+    if (invalid) { failed = true; vm.code = DM_FC_SIZE; }
+    fc_counter++;
+    if (failed) vm.status = vm.pc + 1u >= n_bc ? 1u : 2u;  // running off the end turns the failure into Finished
+}
+
 template <class P>
-__device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__restrict__ r, const DeviceProgram &dp, uint32_t *scratch, SlowResult *res) {
+__device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__restrict__ r, const DeviceProgram &dp, uint32_t *scratch, SlowResult *res,
+                                               const ExactLanes *L, uint32_t t) {
     const uint32_t has_pred = r[2], n_inputs = r[3], n_outputs = r[4], n_bc = r[6];
     const uint32_t *__restrict__ bc = dp.bytecode + r[5];
-    const uint32_t *q = r + 9;
+    const uint32_t *q = r + 11;
+    uint32_t fc_counter = 0;
     Fr pred = fr_one();
     if (has_pred) {  // brillig.rs:28-31: get_value error passes through (MissingAssignment)
         const OpResult e = expr_value(p, q, dp.consts, pred);
@@ -393,6 +482,7 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
         case BRO_TRAP: vm.status = 2; vm.code = DM_BRILLIG_TRAP; break;
         case BRO_STOP: vm.status = 1; break;
         case BRO_BLACK_BOX: brillig_black_box(vm, ins[4], dp.bytecode + ins[7], dp.grumpkin); break;
+        case BRO_FOREIGN_CALL: brillig_foreign_call(vm, dp.bytecode + ins[7], dp, r[9], r[10], fc_counter, n_bc, r[1], L, t); break;
         default: vm.panic(BP_BAD_OPCODE); break;
         }
         if (vm.status) break;
@@ -429,8 +519,9 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
 #pragma unroll
             for (int k = 0; k < 8; k++) res->val[k] = vm.val.v[k];
         }
-        return op_fail_msg(DE_BRILLIG_FAILED, 0, vm.code);
+        return op_fail_msg(DE_BRILLIG_FAILED, 0, vm.code, vm.x0);
     }
+    if (vm.status == 3) return op_fail_msg(DE_WAIT_FOREIGN_CALL, 0, 0, vm.pc);
     if (vm.status == 5) return op_fail_msg(DE_PANIC, 0, vm.code, vm.x0);
     return op_fail_msg(DE_PANIC, 0, DM_BRILLIG_PANIC, vm.code, vm.x0);
 }

@@ -26,14 +26,16 @@ enum RecKind : uint32_t {
 // error codes = ACVM_ERR_* of include/acvm_amd.h
 enum DevErr : uint32_t {
     DE_NONE = 0, DE_MISSING_ASSIGNMENT = 1, DE_TOO_MANY_UNKNOWNS = 2, DE_UNSUPPORTED_BLACKBOX = 3, DE_UNSATISFIED = 4,
-    DE_INDEX_OOB = 5, DE_BLACKBOX_FAILED = 6, DE_BRILLIG_FAILED = 7, DE_PANIC = 8
+    DE_INDEX_OOB = 5, DE_BLACKBOX_FAILED = 6, DE_BRILLIG_FAILED = 7, DE_PANIC = 8,
+    DE_WAIT_FOREIGN_CALL = 100  // not an error: Brillig needs a foreign call result (x0 = bytecode index of the ForeignCall)
 };
 // sub-codes carried in aux1 for errors whose message text is rebuilt on the host
 enum DevMsg : uint32_t {
     DM_NONE = 0, DM_TWO_MUL_TERMS = 1, DM_LOGIC_BITS = 2, DM_FETCH_BYTES = 3, DM_HASH_OUTPUTS = 4, DM_KECCAK_VAR_LEN = 5,
     DM_MEM_INDEX_U64 = 6, DM_MEM_READ_EXPR = 7, DM_RADIX = 8, DM_LIMB_LOW = 9, DM_LIMB_HIGH = 10, DM_SCALAR = 11,
     DM_SCHNORR_SIG_LEN = 12, DM_SCHNORR_MSG_LEN = 13, DM_BRILLIG_TRAP = 14, DM_BRILLIG_RETURN = 15, DM_BRILLIG_PANIC = 16,
-    DM_BRILLIG_MEM_CAP = 17, DM_BRILLIG_STEP_LIMIT = 18, DM_BRILLIG_BB_FAILED = 19, DM_PEDERSEN_DOMAIN = 20
+    DM_BRILLIG_MEM_CAP = 17, DM_BRILLIG_STEP_LIMIT = 18, DM_BRILLIG_BB_FAILED = 19, DM_PEDERSEN_DOMAIN = 20, DM_FC_COUNT = 21,
+    DM_FC_SIZE = 22, DM_FC_PENDING_CAP = 23
 };
 
 // err / aux0 / aux1 are the ABI's acvm_result_t fields; msg (DevMsg) and x0, x1 let the host rebuild the message text

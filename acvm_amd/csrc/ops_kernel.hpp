@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t 
     const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
     uint32_t *sc = scratch ? scratch + (uint64_t)scratch_off[blockIdx.y] * Bp : nullptr;
     FastPolicy p{W, Bp, j};
-    const OpResult r = Op::run(p, rec, dp, sc, (SlowResult *)nullptr);
+    const OpResult r = Op::run(p, rec, dp, sc, (SlowResult *)nullptr, (const ExactLanes *)nullptr, 0u);
     if (r.err) atomicMin(&event[j], rec[1]);
 }
 
@@ -43,8 +43,12 @@ __global__ void __launch_bounds__(BLOCK) record_exact_kernel(uint4 *W, uint64_t 
     if (L.results[t].status != 1u || L.start_opcode[t] > opcode) return;
     const uint32_t *__restrict__ rec = dp.prog + dp.prog_offset[opcode];
     ExactPolicy p{W, Bp, L.slow_ids[t], L.assigned, L.n_slow, t};
-    const OpResult r = Op::run(p, rec, dp, scratch, &L.results[t]);
-    if (r.err) exact_fail(L, t, opcode, r);
+    const OpResult r = Op::run(p, rec, dp, scratch, &L.results[t], &L, t);
+    if (r.err == DE_WAIT_FOREIGN_CALL) {  // ACVMStatus::RequiresForeignCall: the instruction pointer stays on this opcode
+        L.results[t].status = 3u;
+        L.results[t].opcode_index = opcode;
+        L.results[t].x0 = r.x0;
+    } else if (r.err) exact_fail(L, t, opcode, r);
 }
 
 template <class Op, int BLOCK>

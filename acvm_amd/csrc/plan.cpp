@@ -270,7 +270,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 break;
             }
             case OP_BRILLIG: {
-                // [PK_BRILLIG, oi, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap,
+                // [PK_BRILLIG, oi, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap, fc_desc_off, fc_vals_off,
                 //  E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
                 const BrilligCall &b = *o.brillig;
                 p.prog_class[oi] = CLS_BRILLIG;
@@ -310,7 +310,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                         max_hash_hint = 1;
                         break;
                     }
-                    case BR_FOREIGN_CALL: has_foreign = true; break;
+                    case BR_FOREIGN_CALL: has_foreign = true; break;  // operands: extra block, patched below
                     default: break;
                     }
                     p.bytecode.insert(p.bytecode.end(), w, w + 8);
@@ -327,16 +327,58 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     for (int i = 0; i < nwords[op.bbop]; i++)
                         p.bytecode.push_back(i < n_reg_words[op.bbop] ? reg(op.bb[i]) : (uint32_t)std::min<uint64_t>(op.bb[i], 0xFFFFFFFFull));
                 }
-                if (has_foreign) unsupported(oi, "Brillig ForeignCall");
+                // ForeignCall operands: [n_dests, n_inputs, (kind, reg, size) x n_dests, (kind, reg, size) x n_inputs];
+                // kind 0 register, 1 HeapArray (size literal), 2 HeapVector (size register)
+                uint64_t fc_pending_vals = 0;
+                for (size_t k = 0; k < b.bytecode.size(); k++) {
+                    const BrilligOp &op = b.bytecode[k];
+                    if (op.op != BR_FOREIGN_CALL) continue;
+                    p.bytecode[bc_off + 8 * k + 7] = (uint32_t)p.bytecode.size();
+                    p.bytecode.push_back((uint32_t)op.dests.size());
+                    p.bytecode.push_back((uint32_t)op.inputs.size());
+                    uint64_t vals = 0;
+                    for (const std::vector<RegOrMem> *v : {&op.dests, &op.inputs})
+                        for (const RegOrMem &m : *v) {
+                            p.bytecode.push_back(m.kind);
+                            p.bytecode.push_back(reg(m.reg));
+                            p.bytecode.push_back(m.kind == 2 ? reg(m.size) : (uint32_t)std::min<uint64_t>(m.size, 0xFFFFFFFFull));
+                            if (v == &op.inputs) vals += m.kind == 0 ? 1 : (m.kind == 1 ? std::min<uint64_t>(m.size, 1u << 20) : 0);
+                            if (m.kind == 1) mem_hint = std::max<uint64_t>(mem_hint, std::min<uint64_t>(m.size, 1u << 16));
+                        }
+                    fc_pending_vals = std::max(fc_pending_vals, vals);
+                    p.fc_function[((uint64_t)oi << 32) | (uint32_t)k] = op.function;
+                    p.fc_max_inputs = std::max<uint32_t>(p.fc_max_inputs, (uint32_t)op.inputs.size());
+                }
+                // results the circuit already carries (Brillig::foreign_call_results): descriptor
+                // [n_results, (n_values, (is_array, n) x n_values) x n_results] + one constant index per value
+                uint32_t fc_desc_off = 0xFFFFFFFFu, fc_vals_off = 0xFFFFFFFFu;
+                if (has_foreign) {
+                    std::vector<uint32_t> vals;
+                    fc_desc_off = (uint32_t)p.bytecode.size();
+                    p.bytecode.push_back((uint32_t)b.fc_results.size());
+                    for (auto &res : b.fc_results) {
+                        p.bytecode.push_back((uint32_t)res.values.size());
+                        for (auto &v : res.values) {
+                            p.bytecode.push_back(v.is_array ? 1u : 0u);
+                            p.bytecode.push_back(v.is_array ? (uint32_t)v.arr.size() : 1u);
+                            if (v.is_array) for (auto &x : v.arr) vals.push_back(pool.intern(x));
+                            else vals.push_back(pool.intern(v.single));
+                        }
+                    }
+                    fc_vals_off = (uint32_t)p.bytecode.size();
+                    p.bytecode.insert(p.bytecode.end(), vals.begin(), vals.end());
+                    p.has_foreign_calls = true;
+                }
                 if (has_grumpkin) p.needs_grumpkin = true;
-                uint64_t mem_cap = arr_cells + mem_hint + 64 + (max_hash_hint ? 64 : 0);
+                uint64_t mem_cap = arr_cells + mem_hint + 64 + (max_hash_hint ? 64 : 0) + (has_foreign ? 64 : 0);
                 if (const char *e = getenv("ACVM_BRILLIG_MEM_CELLS")) mem_cap = std::max<uint64_t>(mem_cap, strtoull(e, nullptr, 10));
                 mem_cap = std::min<uint64_t>(mem_cap, 1u << 20);
                 uint32_t n_regs = (uint32_t)std::max<uint64_t>(max_reg, 1);
                 // scratch: registers + memory cells (8 words each) + call stack (64 words) + byte staging for hashes
                 p.prog_scratch[oi] = (uint32_t)((n_regs + mem_cap) * 8 + 64 + (max_hash_hint ? mem_cap / 4 + 16 : 0));
+                p.fc_pending_vals = std::max<uint64_t>(p.fc_pending_vals, has_foreign ? fc_pending_vals + mem_cap : 0);
                 s.insert(s.end(), {PK_BRILLIG, oi, b.has_predicate ? 1u : 0u, (uint32_t)b.inputs.size(), (uint32_t)b.outputs.size(), bc_off,
-                                   (uint32_t)b.bytecode.size(), n_regs, (uint32_t)mem_cap});
+                                   (uint32_t)b.bytecode.size(), n_regs, (uint32_t)mem_cap, fc_desc_off, fc_vals_off});
                 if (b.has_predicate) emit_expr(s, pool, b.predicate);
                 for (auto &in : b.inputs) {
                     s.push_back(in.is_array ? 1u : 0u);

@@ -15,6 +15,8 @@
 //   * the folded gate stream of the Arithmetic opcodes for arith_level_kernel / arith_dyn_level_kernel.
 #pragma once
 #include "circuit.hpp"
+#include <map>
+#include <string>
 #include <vector>
 
 namespace acvm {
@@ -77,6 +79,11 @@ struct Plan {
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;
+    // Brillig foreign calls: function name per (opcode << 32 | bytecode index), buffer sizes of the wait / resolve round trip
+    bool has_foreign_calls = false;
+    std::map<uint64_t, std::string> fc_function;
+    uint32_t fc_max_inputs = 0;
+    uint64_t fc_pending_vals = 0;  // field elements one pending call can hand to the host (upper bound)
 };
 
 Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial);

@@ -153,6 +153,30 @@ int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uin
 /* full witness maps of instances [first, first+n): assigned [n][nw], values_be32 [n][nw][32] (zeros if unassigned) */
 int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *assigned, uint8_t *values_be32);
 int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out);
+
+/*
+ * Brillig foreign calls. An instance whose Brillig VM reaches a ForeignCall without a result stops with status
+ * ACVM_STATUS_REQUIRES_FOREIGN_CALL and its instruction pointer on that opcode (pwg/mod.rs:262-268).
+ *   acvm_batch_pending_foreign_call        = ACVM::get_pending_foreign_call (mod.rs:203-209): returns 1 and fills *info if
+ *                                            the instance waits, 0 if it does not
+ *   acvm_batch_pending_foreign_call_inputs = ForeignCallWaitInfo::inputs (pwg/brillig.rs:157-163): lens[n_inputs], then the
+ *                                            values of all inputs back to back, 32 bytes big-endian each (info.n_values)
+ *   acvm_batch_resolve_foreign_call        = ACVM::resolve_pending_foreign_call (mod.rs:214-228): one ForeignCallResult =
+ *                                            n_values outputs, output i a single value (is_array[i] == 0) or an array of
+ *                                            lens[i] values; values back to back. ACVM_E_STATE if the instance is not waiting
+ *                                            (the reference panics).
+ * After resolving any number of instances, acvm_batch_solve continues them (the opcode re-runs its VM with the results so far).
+ */
+typedef struct {
+    uint32_t opcode_index;   /* the Brillig opcode the instance waits at */
+    uint32_t brillig_index;  /* index of the ForeignCall inside its bytecode */
+    uint32_t n_inputs, n_values;
+    char function[64];
+} acvm_foreign_call_info_t;
+int acvm_batch_pending_foreign_call(acvm_batch_t *b, uint32_t instance, acvm_foreign_call_info_t *info);
+int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, uint32_t *lens, uint8_t *values_be32);
+int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t n_values, const uint8_t *is_array, const uint32_t *lens,
+                                    const uint8_t *values_be32);
 /* enable per-kernel HIP-event timing of the level kernels (small overhead) */
 int acvm_batch_set_profiling(acvm_batch_t *b, int on);
 

@@ -22,7 +22,7 @@ STATUS_SOLVED, STATUS_IN_PROGRESS, STATUS_FAILURE, STATUS_REQUIRES_FOREIGN_CALL 
 ABI_SYMBOLS = [
     "acvm_last_error", "acvm_abi_version", "acvm_device_count", "acvm_set_device", "acvm_device_synchronize",
     "acvm_device_arch", "acvm_selftest", "acvm_debug_grumpkin", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
-    "acvm_circuit_num_witnesses", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
+    "acvm_circuit_num_witnesses", "acvm_circuit_plan_stats", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
     "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_reset", "acvm_batch_set_force_slow_path",
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
     "acvm_batch_set_profiling", "acvm_batch_pending_foreign_call", "acvm_batch_pending_foreign_call_inputs",
@@ -55,10 +55,11 @@ class Stats(C.Structure):
                 ("algorithmic_bytes_per_instance", C.c_uint64), ("arith_algorithmic_bytes_per_instance", C.c_uint64),
                 ("plan_ms", C.c_double), ("solve_device_ms", C.c_double), ("arith_kernel_ms", C.c_double),
                 ("slow_path_ms", C.c_double), ("dyn_kernel_ms", C.c_double),
-                ("dyn_algorithmic_bytes_per_instance", C.c_uint64)]
+                ("dyn_algorithmic_bytes_per_instance", C.c_uint64), ("n_other_records", C.c_uint32), ("truncated_at", C.c_uint32),
+                ("class_algorithmic_bytes_per_instance", C.c_uint64 * 4), ("class_kernel_ms", C.c_double * 4)]
 
     def as_dict(self):
-        return {f: getattr(self, f) for f, _ in self._fields_}
+        return {f: (list(getattr(self, f)) if f.startswith("class_") else getattr(self, f)) for f, _ in self._fields_}
 
 
 _lib = None
@@ -83,6 +84,7 @@ def lib():
     L.acvm_circuit_num_opcodes.argtypes = [C.c_void_p]
     L.acvm_circuit_num_witnesses.restype = C.c_uint32
     L.acvm_circuit_num_witnesses.argtypes = [C.c_void_p]
+    L.acvm_circuit_plan_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Stats)]
     L.acvm_batch_new.restype = C.c_void_p
     L.acvm_batch_new.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.acvm_batch_free.argtypes = [C.c_void_p]
@@ -153,6 +155,14 @@ class Circuit:
         if getattr(self, "_h", None) and _lib is not None:
             _lib.acvm_circuit_free(self._h)
             self._h = None
+
+    def plan_stats(self, initial_ids) -> dict:
+        """Host-only levelisation (no device): statistics of the static plan; raises if an opcode has no kernel."""
+        ids = list(initial_ids)
+        arr = (C.c_uint32 * max(len(ids), 1))(*ids)
+        s = Stats()
+        _check(lib().acvm_circuit_plan_stats(self._h, arr, len(ids), C.byref(s)))
+        return s.as_dict()
 
 
 class Batch:

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -184,6 +185,33 @@ acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) {
 void acvm_circuit_free(acvm_circuit_t *c) { delete c; }
 uint32_t acvm_circuit_num_opcodes(const acvm_circuit_t *c) { return c ? (uint32_t)c->c->opcodes.size() : 0; }
 uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c) { return c ? c->c->max_witness + 1 : 0; }
+
+static void plan_stats(const Plan &p, acvm_stats_t *out) {
+    memset(out, 0, sizeof *out);
+    out->n_opcodes = p.n_opcodes;
+    out->n_witnesses = p.n_witnesses;
+    out->n_levels = p.n_levels;
+    out->n_fast_gates = p.n_fast_gates;
+    out->n_dyn_gates = p.n_dyn_gates;
+    out->max_level_width = p.max_level_width;
+    out->algorithmic_bytes_per_instance = p.algorithmic_bytes;
+    out->arith_algorithmic_bytes_per_instance = p.arith_algorithmic_bytes;
+    out->dyn_algorithmic_bytes_per_instance = p.dyn_algorithmic_bytes;
+    out->plan_ms = p.plan_ms;
+    out->n_other_records = p.n_other_records;
+    out->truncated_at = p.truncated_at;
+    for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
+}
+
+// Host-only: levelise the circuit against a set of initial witness ids without touching a device (plan statistics, and
+// whether the circuit holds an opcode no kernel implements). Returns 0, or ACVM_E_UNSUPPORTED with the reason as the error text.
+int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out) {
+    if (!c || !out || (n_initial && !initial_ids)) return set_err(ACVM_E_INVALID, "null argument");
+    Plan p = build_plan(*c->c, initial_ids, n_initial);
+    plan_stats(p, out);
+    if (!p.unsupported.empty()) return set_err(ACVM_E_UNSUPPORTED, p.unsupported);
+    return 0;
+}
 
 static int batch_init(acvm_batch *b) {
     HIPCHK(hipGetDevice(&b->device));
@@ -428,7 +456,7 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
     for (const ExactSegment &seg : b->segments) {
         if (seg.end <= min_start && !(has_mem && seg.cls == CLS_LIGHT)) continue;
         switch (seg.cls) {
-        case CLS_LIGHT: launch_exact_span(s, b->d_W, b->Bp, b->dp, L, seg.begin, seg.end); break;
+        case CLS_LIGHT: launch_exact_span(s, b->d_W, b->Bp, b->dp, L, seg.begin, seg.end, has_mem); break;
         case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
         case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
         case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
@@ -485,7 +513,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
     if (b->solved) return solve_resume(b);  // only resolved foreign calls can change anything
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
-    hipStream_t s2 = b->stream_dyn;
+    hipStream_t s2 = getenv("ACVM_NO_OVERLAP") ? b->stream : b->stream_dyn;  // measurement aid: serialise the two level kernels
     b->n_launches = 0;
     b->arith_kernel_ms = 0;
     b->dyn_kernel_ms = 0;
@@ -783,7 +811,7 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
     case 15: snprintf(r.message, sizeof r.message, "return opcode hit, but callstack already empty"); break;
     case 16: {
         static const char *texts[17] = {"", "Reading register past maximum!", "Writing register past maximum!", "register does not fit into u64",
-                                        "memory read out of range", "", "oracle: bit_size > 256 not supported", "attempt to subtract with overflow",
+                                        "memory read out of range", "", "bit_size > 256 is not supported", "attempt to subtract with overflow",
                                         "attempt to divide by zero", "unsupported bit size for right shift",
                                         "called `Option::unwrap()` on a `None` value", "bad int op", "index out of bounds: bytecode",
                                         "bad brillig opcode", "", "index out of bounds: brillig memory", "bad black box op"};
@@ -916,22 +944,13 @@ int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uin
 int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
     const Plan &p = b->plan;
-    memset(out, 0, sizeof *out);
-    out->n_opcodes = p.n_opcodes;
-    out->n_witnesses = p.n_witnesses;
-    out->n_levels = p.level_start.empty() ? 0 : (uint32_t)p.level_start.size() - 1;
-    out->n_fast_gates = p.n_fast_gates;
-    out->n_dyn_gates = p.n_dyn_gates;
-    out->max_level_width = p.max_level_width;
+    plan_stats(p, out);
     out->n_kernel_launches = b->n_launches;
     out->n_slow_instances = (uint32_t)b->slow_ids.size();
-    out->algorithmic_bytes_per_instance = p.algorithmic_bytes;
-    out->arith_algorithmic_bytes_per_instance = p.arith_algorithmic_bytes;
-    out->plan_ms = p.plan_ms;
     out->solve_device_ms = b->solve_device_ms;
     out->arith_kernel_ms = b->arith_kernel_ms;
     out->dyn_kernel_ms = b->dyn_kernel_ms;
-    out->dyn_algorithmic_bytes_per_instance = p.dyn_algorithmic_bytes;
+    for (int k = 0; k < 4; k++) out->class_kernel_ms[k] = b->cls_kernel_ms[k];
     out->slow_path_ms = b->slow_path_ms;
     return 0;
 }

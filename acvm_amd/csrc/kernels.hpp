@@ -78,7 +78,8 @@ void launch_brillig_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, cons
 // ---- exact in-order kernels (ExactPolicy): one lane per flagged instance
 void launch_exact_init(hipStream_t s, const ExactLanes &L);
 // opcodes [op_begin, op_end) of class CLS_LIGHT in program order
-void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end);
+void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end,
+                       bool replay_memory);
 // one opcode of a heavy class
 void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
 void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);

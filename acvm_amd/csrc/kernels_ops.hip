@@ -17,7 +17,8 @@ struct LightOp {
 // One lane per flagged instance. Opcodes before the lane's event ran generically on exact data: their witness outputs
 // are kept (init_assigned_kernel) and only their memory side effects are re-applied here, because a later opcode of
 // the level schedule may already have overwritten the cell.
-__global__ void __launch_bounds__(64) exact_span_kernel(uint4 *W, uint64_t Bp, DeviceProgram dp, ExactLanes L, uint32_t op_begin, uint32_t op_end) {
+__global__ void __launch_bounds__(64) exact_span_kernel(uint4 *W, uint64_t Bp, DeviceProgram dp, ExactLanes L, uint32_t op_begin, uint32_t op_end,
+                                                        uint32_t replay_memory) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= L.n_slow) return;
     if (L.results[t].status != 1u) return;
@@ -25,7 +26,8 @@ __global__ void __launch_bounds__(64) exact_span_kernel(uint4 *W, uint64_t Bp, D
     const uint32_t start = L.start_opcode[t];
     ExactPolicy p{W, Bp, j, L.assigned, L.n_slow, t};
     FastPolicy replay{W, Bp, j};
-    for (uint32_t oi = op_begin; oi < op_end; oi++) {
+    // without memory opcodes nothing before the lane's event has to be replayed
+    for (uint32_t oi = replay_memory || start < op_begin ? op_begin : start; oi < op_end; oi++) {
         const uint32_t *__restrict__ rec = dp.prog + dp.prog_offset[oi];
         if (oi < start) {
             if (rec[0] == K_MEM_INIT) op_mem_init(replay, rec, dp.Mem);
@@ -61,9 +63,10 @@ void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
                         uint32_t *event) {
     launch_record_level<LightOp, 256>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
 }
-void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end) {
+void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end,
+                       bool replay_memory) {
     if (!L.n_slow || op_begin >= op_end) return;
-    hipLaunchKernelGGL(exact_span_kernel, dim3((L.n_slow + 63) / 64), dim3(64), 0, s, W, Bp, dp, L, op_begin, op_end);
+    hipLaunchKernelGGL(exact_span_kernel, dim3((L.n_slow + 63) / 64), dim3(64), 0, s, W, Bp, dp, L, op_begin, op_end, replay_memory ? 1u : 0u);
 }
 void launch_exact_init(hipStream_t s, const ExactLanes &L) {
     if (!L.n_slow) return;

@@ -187,18 +187,20 @@ def grumpkin_circuit(msg_len=10, n_pedersen_inputs=2):
     return circ, ids
 
 
-def grumpkin_rows(B, sign, msg_len=10, n_pedersen_inputs=2, seed=0xAC1D0004, first_instance=0, n_keys=16):
-    """Input rows for grumpkin_circuit. `sign(sk_be32, k_be32, msg) -> 128 bytes (pk || sig)` is the caller's signer (the
-    tests pass the CPU oracle's; the product has no signer). Signatures are made for n_keys distinct (key, message)
-    pairs and reused round-robin; odd instances get one flipped signature byte. Instances 0..7 of the global batch
-    violate the limb / modulus checks."""
-    rng = SplitMix64(seed)
-    signed = []
-    for _ in range(n_keys):
-        sk = rng.fr() % Q_GRUMPKIN or 1
-        k = rng.fr() % Q_GRUMPKIN or 1
-        msg = bytes(rng.below(256) for _ in range(msg_len))
-        signed.append((sign(be32(sk), be32(k), msg), msg))
+def load_signed_fixture():
+    """(pk || sig, msg) tuples of tests/golden/schnorr_signed.json (data made by the generator script next to it)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "schnorr_signed.json")
+    with open(path) as f:
+        return [(bytes.fromhex(v["pk_sig"]), bytes.fromhex(v["msg"])) for v in json.load(f)["vectors"]]
+
+
+def grumpkin_rows(B, signed=None, n_pedersen_inputs=2, seed=0xAC1D0004, first_instance=0):
+    """Input rows for grumpkin_circuit. `signed`: list of (pk || sig (128 bytes), message) tuples, default the committed
+    fixture; they are reused round-robin and odd instances get one flipped signature bit. Instances 0..7 of the global
+    batch violate the limb / modulus checks."""
+    signed = signed or load_signed_fixture()
     rows = []
     for t in range(B):
         j = first_instance + t
@@ -209,9 +211,51 @@ def grumpkin_rows(B, sign, msg_len=10, n_pedersen_inputs=2, seed=0xAC1D0004, fir
         if j < 8:
             lo, hi = [(1 << 128, 0), (0, 1 << 128), (Q_GRUMPKIN & ((1 << 128) - 1), Q_GRUMPKIN >> 128), (P - 1, 1), (0, 0), (1, 0),
                       ((Q_GRUMPKIN - 1) & ((1 << 128) - 1), (Q_GRUMPKIN - 1) >> 128), (5, (1 << 128) - 1)][j]
-        pk_sig, msg = signed[j % n_keys]
+        pk_sig, msg = signed[j % len(signed)]
         sig = bytearray(pk_sig[64:128])
         if j & 1:
             sig[r.below(64)] ^= 1 << r.below(8)
         rows.append(ped + [lo, hi, int.from_bytes(pk_sig[:32], "big"), int.from_bytes(pk_sig[32:64], "big")] + list(sig) + list(msg))
     return rows
+
+
+def rows_to_bytes_fast(rows) -> bytes:
+    return values_from_rows(rows)
+
+
+def arith_pedersen_circuit(n_gates=10000, n_pedersen=8, n_in=16, seed=0xAC1D0006):
+    """The north-star circuit shape: a width-3 arithmetic circuit of n_gates gates with n_pedersen Pedersen commitments
+    (2 inputs each, taken from solved witnesses spread over the circuit) whose outputs feed later gates.
+    Returns (Circuit, input ids)."""
+    from .acir import BlackBoxFuncCall as BB, FunctionInput as FI
+    circ, ids = arithmetic_circuit(n_gates, n_in=n_in, seed=seed)
+    ops = list(circ.opcodes)
+    nw = circ.current_witness_index
+    rng = SplitMix64(seed ^ 0x5EED)
+    extra = []
+    for k in range(n_pedersen):
+        # inputs: two witnesses solved in the first (k+1)/(n_pedersen+1) part of the circuit
+        hi = n_in + max(2, (k + 1) * n_gates // (n_pedersen + 1))
+        a, b = 1 + rng.below(hi), 1 + rng.below(hi)
+        ox, oy = nw + 1, nw + 2
+        nw += 2
+        pos = hi - n_in  # insert right after the gate that solves witness `hi`
+        extra.append((pos, BB("Pedersen", {"inputs": [FI(a, 254), FI(b, 254)], "domain_separator": 0, "outputs": [ox, oy]})))
+        # one more gate that consumes the commitment: w = ox * oy + a
+        out = nw + 1
+        nw += 1
+        extra.append((pos, Expression([(1, ox, oy)], [(1, a), (P - 1, out)], 0)))
+    for pos, op in sorted(extra, key=lambda t: -t[0]):
+        ops.insert(pos, op)
+    # keep the relative order of the (Pedersen, consumer) pairs: sorted() is stable and both share `pos`, inserted in reverse
+    fixed = []
+    i = 0
+    while i < len(ops):
+        if i + 1 < len(ops) and isinstance(ops[i], Expression) and isinstance(ops[i + 1], BB) and ops[i + 1].name == "Pedersen" \
+                and any(t[1] in ops[i + 1].args["outputs"] or t[2] in ops[i + 1].args["outputs"] for t in ops[i].mul_terms):
+            fixed += [ops[i + 1], ops[i]]
+            i += 2
+        else:
+            fixed.append(ops[i])
+            i += 1
+    return Circuit(current_witness_index=nw, opcodes=fixed, private_parameters=ids, return_values=[nw]), ids

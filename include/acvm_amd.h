@@ -103,6 +103,11 @@ typedef struct {
     double slow_path_ms;
     double dyn_kernel_ms;   /* same for the batched-inversion level kernels (they overlap the former on a 2nd stream) */
     uint64_t dyn_algorithmic_bytes_per_instance;
+    /* non-arithmetic opcodes, by kernel class: 0 light (range / logic / directives / memory), 1 hashes, 2 Grumpkin, 3 Brillig */
+    uint32_t n_other_records;
+    uint32_t truncated_at; /* first opcode the generic instance cannot execute (all instances take the exact kernels from there), or 0xFFFFFFFF */
+    uint64_t class_algorithmic_bytes_per_instance[4];
+    double class_kernel_ms[4]; /* summed HIP-event durations of the class's level kernels of the last solve (profiling on) */
 } acvm_stats_t;
 
 const char *acvm_last_error(void);
@@ -129,6 +134,9 @@ acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);
 void acvm_circuit_free(acvm_circuit_t *c);
 uint32_t acvm_circuit_num_opcodes(const acvm_circuit_t *c);
 uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c); /* 1 + highest witness index referenced */
+/* Host-only levelisation against a set of initial witness ids (no device needed): plan statistics in *out. Returns 0, or
+ * ACVM_E_UNSUPPORTED (reason in acvm_last_error) if the circuit holds an opcode no kernel implements. */
+int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out);
 
 /*
  * ACVM::new for n_instances instances that all assign the same initial witness ids.

@@ -138,7 +138,7 @@ static void int_op(vm_t *vm, uint32_t op, uint32_t bits, const fr_t *fa, const f
     fr_to_canonical(fa, a);
     fr_to_canonical(fb, b);
     memset(r8, 0, sizeof r8);
-    if (bits > 256) { vm_panic(vm, "oracle: bit_size > 256 not supported"); return; }
+    if (bits > 256) { vm_panic(vm, "bit_size > 256 is not supported"); return; }
     switch (op) {
     case BI_ADD: {
         u128 c = 0;

@@ -75,17 +75,9 @@ def test_pedersen_batch(oracle, n, ds):
     both_paths(oracle, circ, ids, rows)
 
 
-def _signer(oracle):
-    def sign(sk, k, msg):
-        out = C.create_string_buffer(128)
-        assert oracle.lib().oracle_schnorr_sign(sk, k, msg, len(msg), out) == 0
-        return out.raw
-    return sign
-
-
 def test_config4_grumpkin_circuit(oracle):
     circ, ids = grumpkin_circuit()
-    rows = grumpkin_rows(80, _signer(oracle))
+    rows = grumpkin_rows(80)
     # more rejecting shapes: public key off the curve, s = 0, e = 0
     rows[10][4] = (rows[10][4] + 1) % P
     for i in range(32):

@@ -1,0 +1,71 @@
+"""Host logic without a GPU: the static planner (levelisation, gate classification, algorithmic-byte accounting of SURVEY 8d,
+refusal of opcodes without a kernel) through the host-only C-ABI entry acvm_circuit_plan_stats."""
+import pytest
+
+import acvm_amd
+from acvm_amd import synth
+from acvm_amd.acir import P, BlackBoxFuncCall as BB, Brillig, Circuit, Expression as E, FunctionInput as FI, MemoryInit, MemoryOp, PermutationSort
+
+
+def stats(circ, ids):
+    return acvm_amd.Circuit(circ.to_bytes()).plan_stats(ids)
+
+
+def test_arithmetic_mix_accounting():
+    circ, ids = synth.arithmetic_circuit(2000, seed=0xAC1D0002)
+    st = stats(circ, ids)
+    assert st["n_opcodes"] == 2000 and st["n_fast_gates"] + st["n_dyn_gates"] == 2000
+    assert 60 <= st["n_dyn_gates"] <= 140          # 5 % unknown-in-mul gates
+    assert st["truncated_at"] == 0xFFFFFFFF and st["n_other_records"] == 0
+    # 32 B x (distinct known operands + written witness): between 64 and 128 B per gate, about 102 B on this mix
+    per_gate = st["algorithmic_bytes_per_instance"] / 2000
+    assert 96 <= per_gate <= 108
+    assert st["algorithmic_bytes_per_instance"] == st["arith_algorithmic_bytes_per_instance"] + st["dyn_algorithmic_bytes_per_instance"]
+
+
+def test_chain_has_one_level_per_gate():
+    circ, ids = synth.arithmetic_circuit(200, seed=7, chain=True)
+    assert stats(circ, ids)["n_levels"] >= 200
+
+
+def test_exact_bytes_of_small_circuit():
+    # w3 = w1*w2 (reads 2, writes 1 = 96 B); assert w3 - w1*w2 == 0 (reads 3 = 96 B); RANGE(w3) 32 B; sha256 of 2 bytes: (2 + 32) x 32 B
+    ops = [E([(1, 1, 2)], [(P - 1, 3)], 0), E([(1, 1, 2)], [(P - 1, 3)], 0), BB("RANGE", {"input": FI(3, 200)}),
+           BB("SHA256", {"inputs": [FI(1, 8), FI(2, 8)], "outputs": list(range(4, 36))})]
+    st = stats(Circuit(35, ops), [1, 2])
+    assert st["algorithmic_bytes_per_instance"] == 96 + 96 + 32 + 34 * 32
+    assert st["class_algorithmic_bytes_per_instance"] == [32, 34 * 32, 0, 0]
+    assert st["n_levels"] == 2 and st["n_fast_gates"] == 2 and st["n_other_records"] == 2
+
+
+def test_memory_blocks_are_chained_in_program_order():
+    ops = [MemoryInit(0, [1, 2]), MemoryOp(0, E.constant(1), E.constant(0), E.from_witness(1)), MemoryOp(0, E.constant(0), E.constant(0), E.from_witness(3)),
+           MemoryOp(0, E.constant(1), E.constant(1), E.from_witness(3)), MemoryOp(0, E.constant(0), E.constant(1), E.from_witness(4))]
+    st = stats(Circuit(4, ops), [1, 2])
+    assert st["n_levels"] == 5 and st["truncated_at"] == 0xFFFFFFFF
+
+
+def test_generic_instance_failure_truncates_the_level_plan():
+    # opcode 1 needs w9, which nothing assigns: every instance is handed to the exact kernels from opcode 1 on
+    st = stats(Circuit(9, [E([], [(1, 1), (P - 1, 2)], 0), BB("RANGE", {"input": FI(9, 8)}), E([], [(1, 2), (P - 1, 3)], 0)]), [1])
+    assert st["truncated_at"] == 1 and st["n_fast_gates"] == 1
+    # two unknowns in one expression
+    st = stats(Circuit(4, [E([], [(1, 1), (1, 2), (1, 3)], 0)]), [1])
+    assert st["truncated_at"] == 0
+
+
+@pytest.mark.parametrize("op,what", [
+    (BB("EcdsaSecp256k1", {"public_key_x": [FI(1, 8)] * 32, "public_key_y": [FI(1, 8)] * 32, "signature": [FI(1, 8)] * 64,
+                           "hashed_message": [FI(1, 8)] * 32, "output": 2}), "ECDSA"),
+    (PermutationSort([[E.from_witness(1)]], 1, [2], [0]), "PermutationSort"),
+])
+def test_opcodes_without_a_kernel_are_refused_loudly(op, what):
+    with pytest.raises(acvm_amd.AcvmError) as e:
+        stats(Circuit(3, [op]), [1])
+    assert what in str(e.value)
+
+
+def test_brillig_and_foreign_calls_are_planned():
+    br = Brillig(inputs=[E.from_witness(1)], outputs=[2], bytecode=[("ForeignCall", "f", [("Register", 0)], [("Register", 0)]), ("Stop",)])
+    st = stats(Circuit(2, [br]), [1])
+    assert st["n_other_records"] == 1 and st["class_algorithmic_bytes_per_instance"][3] == 64

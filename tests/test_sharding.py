@@ -1,0 +1,24 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes exercise acvm_amd.shard (instance ranges, barrier, max / sum over
+ranks) exactly as bench.py uses them; the data path itself has no collective."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_single_process():
+    from acvm_amd import shard
+    assert shard.shard_range(0, 1, 65536) == (0, 65536)
+    assert [shard.shard_range(r, 8, 1 << 17) for r in (0, 7)] == [(0, 1 << 17), (7 << 17, 8 << 17)]
+    assert shard.split_total(1 << 20, 8)[-1] == (7 << 17, 1 << 20)
+    assert shard.max_over_ranks(3.5, None) == 3.5
+
+
+def test_world_size_2_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "_dist_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

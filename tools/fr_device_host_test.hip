@@ -46,9 +46,10 @@ int main() {
         if (!same(fr_add(da, db), frh::add(a, b))) { fails++; printf("add mismatch %d\n", it); }
         if (!same(fr_sub(da, db), frh::sub(a, b))) { fails++; printf("sub mismatch %d\n", it); }
         if (!same(fr_neg(da), frh::neg(a))) { fails++; printf("neg mismatch %d\n", it); }
-        if (it < 400) {
+        if (it < 3000) {
             Fr inv = fr_inv(da);
             if (!same(inv, frh::inverse(a))) { fails++; printf("inv mismatch %d\n", it); }
+            if (!same(fr_inv_eea(da), frh::inverse(a))) { fails++; printf("inv_eea mismatch %d\n", it); }
         }
         if (fr_is_zero(da) != a.is_zero()) { fails++; printf("is_zero mismatch %d\n", it); }
     }

@@ -71,5 +71,32 @@ def main(d):
         print(f"{k[:36]:36s} {n:8d} {rd / n:15.4f} {wr / n:16.4f} {(rd + wr) / n:16.4f} {rd + wr:13.3f}")
 
 
+def traffic_json(d, workload, alg=None):
+    """Per-kernel measured HBM bytes per launch for profiles/traffic.json (read by bench.py)."""
+    cal_f = read_pmc(os.path.join(d, "cal_fetch", "pmc_counter_collection.csv"), "FETCH_SIZE")
+    cal_w = read_pmc(os.path.join(d, "cal_write", "pmc_counter_collection.csv"), "WRITE_SIZE")
+    fcorr = (4 << 20) / (cal_f["copy_kernel"][1] / cal_f["copy_kernel"][0]) if cal_f.get("copy_kernel", [0])[0] else 2.0
+    wcorr = (4 << 20) / (cal_w["copy_kernel"][1] / cal_w["copy_kernel"][0]) if cal_w.get("copy_kernel", [0])[0] else 1.0
+    fetch = read_pmc(os.path.join(d, "pmc_fetch", "pmc_counter_collection.csv"), "FETCH_SIZE")
+    write = read_pmc(os.path.join(d, "pmc_write", "pmc_counter_collection.csv"), "WRITE_SIZE")
+    out = {}
+    for k in set(fetch) | set(write):
+        n = max(fetch[k][0], write[k][0]) or 1
+        out[k] = {"bytes_per_launch": (fetch[k][1] * fcorr + write[k][1] * wcorr) * 1024 / n, "launches_profiled": n,
+                  "read_correction": fcorr, "write_correction": wcorr, "source": f"{os.path.basename(d)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    return {workload: out}
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[2] == "--json":
+        import json
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+        try:
+            cur = json.load(open(path))
+        except (OSError, ValueError):
+            cur = {}
+        cur.update(traffic_json(sys.argv[1], sys.argv[3]))
+        json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+        print("updated", path)
+    else:
+        main(sys.argv[1])

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
 // 4 multiplications per gate. The prefix products are parked in a device scratch table laid out like W
 // ([gate in level][half][instance], 16 B per lane, coalesced); it stays L2/Infinity-Cache resident (<= 80 MB)
 // and, unlike an LDS stage, does not cap the number of resident waves of this latency-bound kernel.
-static constexpr int DYN_CHUNK = 8;
+static constexpr int DYN_CHUNK = 16;
 __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
                                                              const uint32_t *__restrict__ gate_stream,
                                                              const uint32_t *__restrict__ dyn_offset, uint32_t n_dyn,

@@ -224,7 +224,7 @@ static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t 
         const Fr ov = vm.reg_get(w[2]);
         if (vm.status || !vm.to_usize(ov, optr)) return;
         for (uint32_t i = 0; i < 32u; i++)
-            if (!vm.mem_write(optr + i, fr_from_u32(d.byte(i)))) return;
+            if (!vm.mem_write(optr + i, fr_from_byte(d.byte(i)))) return;
         return;
     }
     case 6: {  // SchnorrVerify: pkx, pky, message (ptr, size), signature (ptr, size), result

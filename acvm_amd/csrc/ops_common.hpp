@@ -76,6 +76,16 @@ __device__ __forceinline__ Fr fr_from_u32(uint32_t x) {
     c.v[0] = x;
     return fr_from_canonical(c);
 }
+// Montgomery form of a byte from a 8 KiB table (digest bytes and radix digits become one field element each): a 32-byte
+// gather instead of a Montgomery product
+static __constant__ uint32_t BYTE_MONT[256][8] = {
+#include "byte_mont_table.inc"
+};
+__device__ __forceinline__ Fr fr_from_byte(uint32_t d) {
+    const uint4 *p = (const uint4 *)BYTE_MONT[d & 0xffu];
+    const uint4 lo = p[0], hi = p[1];
+    return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+}
 // num_bits of a canonical integer (generic_ark.rs:214-221)
 __device__ __forceinline__ uint32_t canon_num_bits(const Fr &c) {
     uint32_t n = 0;

@@ -268,7 +268,7 @@ __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restri
     }
     if (n_out != 32u) return op_fail_msg(DE_BLACKBOX_FAILED, func == 12u ? 11u : func, DM_HASH_OUTPUTS, n_out);  // hash.rs:92-97
     for (uint32_t i = 0; i < 32u; i++)
-        if (!p.insert(outs[2 * i], fr_from_u32(d.byte(i)), outs[2 * i + 1])) return op_fail(DE_UNSATISFIED);
+        if (!p.insert(outs[2 * i], fr_from_byte(d.byte(i)), outs[2 * i + 1])) return op_fail(DE_UNSATISFIED);
     return op_ok();
 }
 

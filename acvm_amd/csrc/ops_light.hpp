@@ -69,22 +69,42 @@ __device__ __forceinline__ OpResult op_zero_out(const P &p, const uint32_t *__re
     return op_ok();
 }
 
-// 256-bit unsigned division of canonical integers (num-bigint semantics); b != 0
-static inline __device__ __noinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr &rem) {
+// 256-bit unsigned division of canonical integers (num-bigint semantics); b != 0. Register-resident: a divisor below 2^32
+// (the integer divisions of real circuits) takes eight 64-by-32 divisions, anything else a restoring division that starts
+// at the dividend's top bit.
+__device__ __forceinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr &rem) {
     q = fr_zero();
     rem = fr_zero();
-    for (int i = 255; i >= 0; i--) {
+    if ((b.v[1] | b.v[2] | b.v[3] | b.v[4] | b.v[5] | b.v[6] | b.v[7]) == 0u) {
+        const uint32_t d = b.v[0];
+        uint64_t r = 0;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            const uint64_t cur = r << 32 | a.v[k];
+            const uint64_t qq = cur / d;  // r < d, so the quotient fits 32 bits
+            q.v[k] = (uint32_t)qq;
+            r = cur - qq * d;
+        }
+        rem.v[0] = (uint32_t)r;
+        return;
+    }
+    const int top = (int)canon_num_bits(a) - 1;
+    for (int i = top; i >= 0; i--) {
+        const uint32_t limb = (uint32_t)i >> 5, sh = (uint32_t)i & 31u;
+        uint32_t abit = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((uint32_t)k == limb) abit = (a.v[k] >> sh) & 1u;
 #pragma unroll
         for (int k = 7; k > 0; k--) rem.v[k] = rem.v[k] << 1 | rem.v[k - 1] >> 31;
-        rem.v[0] = rem.v[0] << 1 | ((a.v[i >> 5] >> (i & 31)) & 1u);
-        Fr d;
-        const uint32_t borrow = fr_sub256(d, rem, b);
-        if (!borrow) {
-            rem = d;
-            uint32_t bit = 1u << (i & 31);
+        rem.v[0] = rem.v[0] << 1 | abit;
+        Fr dd;
+        const uint32_t borrow = fr_sub256(dd, rem, b);
+        const uint32_t bit = borrow ? 0u : 1u << sh;
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k == (i >> 5)) q.v[k] |= bit;
+        for (int k = 0; k < 8; k++) {
+            rem.v[k] = borrow ? rem.v[k] : dd.v[k];
+            if ((uint32_t)k == limb) q.v[k] |= bit;
         }
     }
 }
@@ -167,7 +187,7 @@ __device__ __forceinline__ OpResult op_to_le_radix(const P &p, const uint32_t *_
                 digit = (uint32_t)rem;
             }
         }
-        if (!p.insert(outs[2 * i], fr_from_u32(digit), outs[2 * i + 1])) return op_fail(DE_UNSATISFIED);
+        if (!p.insert(outs[2 * i], fr_from_byte(digit), outs[2 * i + 1])) return op_fail(DE_UNSATISFIED);
     }
     return op_ok();
 }

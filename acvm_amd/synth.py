@@ -259,3 +259,109 @@ def arith_pedersen_circuit(n_gates=10000, n_pedersen=8, n_in=16, seed=0xAC1D0006
             fixed.append(ops[i])
             i += 1
     return Circuit(current_witness_index=nw, opcodes=fixed, private_parameters=ids, return_values=[nw]), ids
+
+
+def mixed_circuit(n_gates=2000, n_in=16, seed=0xAC1D0005, heavy=True):
+    """BASELINE config 5 shape at a chosen size: ~94 % arithmetic gates of the config-2 mix, 3 % RANGE / AND / XOR,
+    1 % ToLeRadix / Quotient, 1 % MemoryOp on 4 blocks of 16 cells, 0.5 % stdlib-shaped Brillig (BinaryIntOp then Stop),
+    0.5 % hash / Pedersen black boxes. Every opcode's operands are witnesses solved earlier, outputs are fresh witnesses.
+    Returns (Circuit, input ids)."""
+    from .acir import BlackBoxFuncCall as BB, Brillig, FunctionInput as FI, MemoryInit, MemoryOp, QuotientDirective, ToLeRadix
+    rng = SplitMix64(seed)
+    ops = []
+    nw = n_in  # witnesses 1..nw are defined
+    small = []  # witnesses known to be < 2^8 (radix digits), usable as memory indices / hash bytes
+    wide = list(range(1, n_in + 1))  # inputs and arithmetic outputs: uniform-looking field elements (zero with negligible odds)
+
+    def pick():
+        return wide[rng.below(len(wide))]
+
+    def fresh(k=1):
+        nonlocal nw
+        out = list(range(nw + 1, nw + 1 + k))
+        nw += k
+        return out
+
+    blocks = 4
+    cells = 16
+    for blk in range(blocks):
+        ops.append(MemoryInit(blk, [pick() for _ in range(cells)]))
+    # a first radix decomposition so that small witnesses exist
+    src = pick()
+    d = fresh(32)
+    ops.append(ToLeRadix(Expression.from_witness(src), d, 256))
+    small += d
+    for i in range(n_gates):
+        r = rng.below(1000)
+        if r < 940:
+            a, b, c = pick(), pick(), pick()
+            out, = fresh()
+            qc = rng.coef() if rng.next() & 1 else 0
+            t = rng.below(100)
+            if t < 45:
+                e = Expression([(rng.coef(), a, b)], [(rng.coef(), out)], qc)
+            elif t < 75:
+                if a == b:
+                    b = wide[(wide.index(b) + 1) % len(wide)]
+                e = Expression([], [(rng.coef(), a), (rng.coef(), b), (rng.coef(), out)], qc)
+            elif t < 95:
+                e = Expression([(rng.coef(), a, b)], [(rng.coef(), c), (rng.coef(), out)], qc)
+            else:
+                e = Expression([(rng.coef(), a, out)], [(rng.coef(), c)], qc)
+            e.mul_terms.sort(key=lambda t: (min(t[1], t[2]), max(t[1], t[2])))
+            e.linear_combinations.sort(key=lambda t: t[1])
+            ops.append(e)
+            wide.append(out)
+        elif r < 970:
+            k = rng.below(3)
+            if k == 0:
+                ops.append(BB("RANGE", {"input": FI(small[rng.below(len(small))], 8)}))
+            else:
+                bits = [8, 32, 64, 254][rng.below(4)]
+                lhs, rhs = pick(), pick()
+                out, = fresh()
+                ops.append(BB("AND" if k == 1 else "XOR", {"lhs": FI(lhs, bits), "rhs": FI(rhs, bits), "output": out}))
+        elif r < 980:
+            if rng.next() & 1:
+                src = pick()
+                d = fresh(32)
+                ops.append(ToLeRadix(Expression.from_witness(src), d, 256))
+                small += d
+            else:
+                src = pick()
+                q, rem = fresh(2)
+                ops.append(QuotientDirective(Expression.from_witness(src), Expression.from_witness(small[rng.below(len(small))]), q, rem))
+        elif r < 990:
+            blk = rng.below(blocks)
+            idx = Expression.constant(rng.below(cells))
+            if rng.next() & 1:
+                out, = fresh()
+                ops.append(MemoryOp(blk, Expression.constant(0), idx, Expression.from_witness(out)))
+            else:
+                ops.append(MemoryOp(blk, Expression.constant(1), idx, Expression.from_witness(pick())))
+        elif r < 995:
+            op = ["Add", "Sub", "Mul", "UnsignedDiv"][rng.below(4)]
+            bits = [32, 64, 127][rng.below(3)]
+            lhs = pick()
+            rhs = small[rng.below(len(small))] if op == "UnsignedDiv" else pick()
+            out, = fresh()
+            # stdlib shape (blackbox_fallbacks/uint.rs): r0 op= r1 at a fixed width; division guarded against 0 by + 1
+            bc = [("Const", 2, 1), ("BinaryIntOp", 1, "Add", bits, 1, 2), ("BinaryIntOp", 0, op, bits, 0, 1), ("Stop",)] if op in ("UnsignedDiv", "Sub") \
+                else [("BinaryIntOp", 0, op, bits, 0, 1), ("Stop",)]
+            if op == "Sub":  # never underflows: (a mod 2^bits) - ((b + 1) mod 2^bits) wraps inside the VM
+                bc = [("BinaryIntOp", 0, "Sub", bits, 0, 1), ("Stop",)] if bits >= 254 else [("BinaryIntOp", 0, "Add", bits, 0, 1), ("Stop",)]
+            ops.append(Brillig(inputs=[Expression.from_witness(lhs), Expression.from_witness(rhs)], outputs=[out], bytecode=bc))
+        elif heavy:
+            k = rng.below(3)
+            if k == 0:
+                a, b = pick(), pick()
+                ox, oy = fresh(2)
+                ops.append(BB("Pedersen", {"inputs": [FI(a, 254), FI(b, 254)], "domain_separator": 0, "outputs": [ox, oy]}))
+            else:
+                n = 8 + rng.below(40)
+                ins = [FI(small[rng.below(len(small))], 8) for _ in range(n)]
+                outs = fresh(32)
+                ops.append(BB("SHA256" if k == 1 else "Keccak256", {"inputs": ins, "outputs": outs}))
+                small += outs
+    circ = Circuit(current_witness_index=nw, opcodes=ops, private_parameters=list(range(1, n_in + 1)), return_values=[nw])
+    return circ, list(range(1, n_in + 1))

@@ -7,6 +7,7 @@ resident in HBM (Montgomery SoA), witness map left in HBM. Other workloads (pari
     --workload hash            config 3: SHA256 + Keccak256 + RANGE circuit
     --workload grumpkin        config 4: Pedersen + FixedBaseScalarMul + SchnorrVerify circuit
     --workload arith_pedersen  the north-star shape: 10k arithmetic gates + 8 Pedersen commitments
+    --workload mixed           the config-5 opcode mix at --gates opcodes (every kernel class in one circuit)
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -54,6 +55,10 @@ def make_workload(args, rank, B):
         circ, ids = synth.arith_pedersen_circuit(args.gates, args.pedersen)
         values = synth.witness_batch(B, seed=0xAC1D0006, first_instance=first)
         name = f"{args.gates}-gate arithmetic + {args.pedersen} Pedersen ACIR, batch 2^{args.batch_log2} per GPU"
+    elif args.workload == "mixed":
+        circ, ids = synth.mixed_circuit(args.gates)
+        values = synth.witness_batch(B, seed=0xAC1D0005, first_instance=first)
+        name = f"{args.gates}-opcode mixed ACIR (config-5 mix: arithmetic, range/logic, directives, memory, Brillig, hashes, Pedersen), batch 2^{args.batch_log2} per GPU"
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     return circ, ids, values, name
@@ -76,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen"])
+    ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen", "mixed"])
     ap.add_argument("--gates", type=int, default=10000)
     ap.add_argument("--pedersen", type=int, default=8)
     ap.add_argument("--batch-log2", type=int, default=16, help="instances per GPU = 2^this")
@@ -140,7 +145,7 @@ def main():
         from oracle import binding as ob
         cores = os.cpu_count() or 1
         threads = min(cores, 64)
-        per = {"arith": 8, "hash": 64, "grumpkin": 2, "arith_pedersen": 4}[args.workload]
+        per = {"arith": 8, "hash": 64, "grumpkin": 2, "arith_pedersen": 4, "mixed": 4}[args.workload]
         sample = args.cpu_sample or min(B, max(64, per * threads))
         oc = ob.Circuit(data)
         sample_vals = values[: sample * len(ids) * 32]

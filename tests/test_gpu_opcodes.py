@@ -227,3 +227,17 @@ def test_config3_hash_circuit(oracle):
     rows[5][3] = 256  # a RANGE(8) failure
     ores, stats = both_paths(oracle, circ, ids, rows)
     assert ores[5].status == 2 and ores[4].status == 0
+
+
+def test_config5_mixed_circuit(oracle):
+    """The config-5 opcode mix (arithmetic + range / logic + directives + memory + Brillig + hashes + Pedersen) in one circuit:
+    level kernels of every class, the exact kernels for the edge-case instances, and every instance through the exact path."""
+    from acvm_amd import synth
+    circ, ids = synth.mixed_circuit(2500)
+    B = 200
+    values = synth.witness_batch(B, seed=0xAC1D0005)
+    rows = [[int.from_bytes(values[(j * len(ids) + k) * 32:(j * len(ids) + k + 1) * 32], "big") % P for k in range(len(ids))] for j in range(B)]
+    ores, stats = run_both(oracle, circ, ids, rows)
+    assert sum(1 for j in range(B) if ores[j].status == 0) >= B - 8
+    assert stats["n_slow_instances"] <= 8
+    run_both(oracle, circ, ids, rows[:48], force_slow=True)

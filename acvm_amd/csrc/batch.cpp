@@ -43,9 +43,9 @@ struct acvm_batch {
     uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
     uint32_t *d_prog = nullptr, *d_prog_offset = nullptr, *d_bytecode = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
     uint32_t *d_dyn_offset = nullptr, *d_slow_start = nullptr;
-    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<std::vector<LaunchChunk>> cls_chunks[N_CLS];  // per level
     std::vector<ExactSegment> segments;
     DeviceProgram dp{};
@@ -62,7 +62,7 @@ struct acvm_batch {
     hipEvent_t ev_start = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
-    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0};
+    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr;
     std::vector<hipEvent_t> ev_sync;
     uint4 *d_dyn_scratch = nullptr;
@@ -201,6 +201,7 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_other_records = p.n_other_records;
     out->truncated_at = p.truncated_at;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
+    out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN];
 }
 
 // Host-only: levelise the circuit against a set of initial witness ids without touching a device (plan statistics, and
@@ -573,6 +574,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
                     case CLS_HASH: launch_hash_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                     case CLS_GRUMPKIN: launch_grumpkin_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                     case CLS_BRILLIG: launch_brillig_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                    case CLS_PEDERSEN: launch_pedersen_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
                     }
                     if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); cls_pairs[k].push_back({e0, e1}); }
                     b->n_launches++;
@@ -951,6 +953,7 @@ int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     out->arith_kernel_ms = b->arith_kernel_ms;
     out->dyn_kernel_ms = b->dyn_kernel_ms;
     for (int k = 0; k < 4; k++) out->class_kernel_ms[k] = b->cls_kernel_ms[k];
+    out->class_kernel_ms[CLS_GRUMPKIN] += b->cls_kernel_ms[CLS_PEDERSEN];
     out->slow_path_ms = b->slow_path_ms;
     return 0;
 }

@@ -499,7 +499,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             p.algorithmic_bytes += bytes;
             p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
             p.n_other_records++;
-            records.push_back({lvl, p.prog_class[oi], oi});
+            records.push_back({lvl, o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi], oi});
             continue;
         }
         const Expr &e = o.expr;

@@ -41,7 +41,9 @@ enum ProgKind : uint32_t {
     PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12
 };
 // kernel classes of the non-arithmetic records
-enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, N_CLS = 4 };
+// CLS_PEDERSEN only exists in the level schedule (its own 4-waves-per-instance-group kernel); the exact path and the
+// statistics treat a Pedersen record as CLS_GRUMPKIN
+enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, N_CLS = 5 };
 
 struct Plan {
     uint32_t n_witnesses = 0;
@@ -75,7 +77,7 @@ struct Plan {
     // statistics
     uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0, n_other_records = 0;
     uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
-    uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0};
+    uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0};
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;

@@ -43,6 +43,76 @@ class Result(C.Structure):
         return (self.status, self.err, self.opcode_index, self.aux0, self.aux1)
 
 
+_SCHNORR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8),
+                          C.c_size_t, C.POINTER(C.c_uint8), C.c_void_p, C.c_size_t)
+_PEDERSEN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
+                           C.c_void_p, C.c_size_t)
+_FIXED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_void_p,
+                        C.c_size_t)
+
+
+class BbSolver(C.Structure):
+    """acvm_bb_solver_t: the BlackBoxFunctionSolver trait (blackbox_solver/src/lib.rs:27-45) as a vtable."""
+    _fields_ = [("ctx", C.c_void_p), ("schnorr_verify", _SCHNORR_FN), ("pedersen", _PEDERSEN_FN), ("fixed_base_scalar_mul", _FIXED_FN)]
+
+
+def make_solver(schnorr_verify, pedersen, fixed_base_scalar_mul):
+    """Wrap three Python callables as an acvm_bb_solver_t.
+    schnorr_verify(pkx: int, pky: int, sig: bytes, msg: bytes) -> bool
+    pedersen(inputs: list[int], domain_separator: int) -> (x, y)
+    fixed_base_scalar_mul(low: int, high: int) -> (x, y)
+    Raising BlackBoxFailed(msg) reports BlackBoxResolutionError::Failed, BlackBoxUnsupported reports Unsupported."""
+    def be(ptr, n=32):
+        return int.from_bytes(bytes(ptr[:n]), "big")
+
+    def put(ptr, v):
+        for i, byte in enumerate(int(v).to_bytes(32, "big")):
+            ptr[i] = byte
+
+    def guard(fn, err, err_len):
+        try:
+            fn()
+            return 0
+        except BlackBoxFailed as e:
+            msg = str(e).encode()[: max(err_len - 1, 0)]
+            if err:
+                C.memmove(err, msg + b"\0", len(msg) + 1)
+            return 1
+        except BlackBoxUnsupported:
+            return 2
+
+    def c_schnorr(ctx, pkx, pky, sig, sig_len, msg, msg_len, ok, err, err_len):
+        def run():
+            ok[0] = 1 if schnorr_verify(be(pkx), be(pky), bytes(sig[:sig_len]), bytes(msg[:msg_len])) else 0
+        return guard(run, err, err_len)
+
+    def c_pedersen(ctx, inputs, n, ds, x, y, err, err_len):
+        def run():
+            vals = [int.from_bytes(bytes(inputs[32 * i:32 * i + 32]), "big") for i in range(n)]
+            rx, ry = pedersen(vals, ds)
+            put(x, rx)
+            put(y, ry)
+        return guard(run, err, err_len)
+
+    def c_fixed(ctx, low, high, x, y, err, err_len):
+        def run():
+            rx, ry = fixed_base_scalar_mul(be(low), be(high))
+            put(x, rx)
+            put(y, ry)
+        return guard(run, err, err_len)
+
+    s = BbSolver(None, _SCHNORR_FN(c_schnorr), _PEDERSEN_FN(c_pedersen), _FIXED_FN(c_fixed))
+    return s
+
+
+class BlackBoxFailed(Exception):
+    pass
+
+
+class BlackBoxUnsupported(Exception):
+    pass
+
+
 class ForeignCallInfo(C.Structure):
     _fields_ = [("opcode_index", C.c_uint32), ("brillig_index", C.c_uint32), ("n_inputs", C.c_uint32), ("n_values", C.c_uint32),
                 ("function", C.c_char * 64)]
@@ -168,12 +238,13 @@ class Circuit:
 class Batch:
     """ACVM::new / solve / witness_map for n_instances instances of one circuit."""
 
-    def __init__(self, circuit: Circuit, n_instances: int, initial_ids):
+    def __init__(self, circuit: Circuit, n_instances: int, initial_ids, solver: "BbSolver" = None):
         self.circuit = circuit
         self.B = n_instances
         self.ids = list(initial_ids)
+        self._solver = solver  # keeps the callbacks alive: the vtable must outlive the batch
         arr = (C.c_uint32 * max(len(self.ids), 1))(*self.ids)
-        self._h = lib().acvm_batch_new(circuit._h, None, n_instances, arr, len(self.ids))
+        self._h = lib().acvm_batch_new(circuit._h, C.byref(solver) if solver is not None else None, n_instances, arr, len(self.ids))
         if not self._h:
             raise AcvmError(lib().acvm_last_error().decode())
         self.nw = self.stats()["n_witnesses"]

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -43,9 +44,9 @@ struct acvm_batch {
     uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
     uint32_t *d_prog = nullptr, *d_prog_offset = nullptr, *d_bytecode = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
     uint32_t *d_dyn_offset = nullptr, *d_slow_start = nullptr;
-    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<std::vector<LaunchChunk>> cls_chunks[N_CLS];  // per level
     std::vector<ExactSegment> segments;
     DeviceProgram dp{};
@@ -62,11 +63,15 @@ struct acvm_batch {
     hipEvent_t ev_start = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
-    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0};
+    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr;
     std::vector<hipEvent_t> ev_sync;
     uint4 *d_dyn_scratch = nullptr;
     uint32_t n_launches = 0;
+    // caller-supplied BlackBoxFunctionSolver
+    bool has_solver = false;
+    acvm_bb_solver_t solver{};
+    std::map<uint32_t, std::string> host_bb_msg;  // per instance: error text of a failing callback
     // Brillig foreign-call round trip (exact lanes only)
     struct FcValue { bool is_array; std::vector<FrH> vals; };
     struct FcLaneState { uint32_t opcode = 0xFFFFFFFFu; std::vector<std::vector<FcValue>> results; bool resolved_new = false; };
@@ -307,15 +312,19 @@ static int batch_init(acvm_batch *b) {
 
 acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances,
                              const uint32_t *initial_ids, uint32_t n_initial) {
-    (void)solver;
     if (!c || (n_initial && !initial_ids)) { set_err(ACVM_E_INVALID, "null argument"); return nullptr; }
+    if (solver && (!solver->schnorr_verify || !solver->pedersen || !solver->fixed_base_scalar_mul)) {
+        set_err(ACVM_E_INVALID, "acvm_bb_solver_t with a null function pointer");
+        return nullptr;
+    }
     {
         std::vector<uint32_t> ids(initial_ids, initial_ids + n_initial);
         std::sort(ids.begin(), ids.end());
         if (std::adjacent_find(ids.begin(), ids.end()) != ids.end()) { set_err(ACVM_E_INVALID, "duplicate initial witness id"); return nullptr; }
     }
     auto *b = new acvm_batch;
-    b->plan = build_plan(*c->c, initial_ids, n_initial);
+    if (solver) { b->has_solver = true; b->solver = *solver; }
+    b->plan = build_plan(*c->c, initial_ids, n_initial, solver != nullptr);
     if (!b->plan.unsupported.empty()) {
         set_err(ACVM_E_UNSUPPORTED, b->plan.unsupported);
         delete b;
@@ -446,6 +455,92 @@ static int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
     return 0;
 }
 
+// One Pedersen / FixedBaseScalarMul / SchnorrVerify opcode through the caller's BlackBoxFunctionSolver callbacks
+// (blackbox_solver/src/lib.rs:27-45) for the instances of the level schedule (exact == false, all B instances) or for the
+// exact lanes. Inputs leave the device as canonical big-endian bytes, outputs come back the same way.
+static int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_t n_slow) {
+    const Plan &p = b->plan;
+    hipStream_t s = b->stream;
+    const uint32_t *rec = &p.prog[p.prog_offset[opcode]];
+    std::vector<uint32_t> sel, outs;
+    uint32_t func = 0;
+    switch (rec[0]) {
+    case PK_FIXED_BASE: func = BB_FIXED_BASE_SCALAR_MUL; sel = {rec[2], rec[3]}; outs = {rec[4], rec[5], rec[6], rec[7]}; break;
+    case PK_PEDERSEN: func = BB_PEDERSEN; sel.assign(rec + 8, rec + 8 + rec[3]); outs = {rec[4], rec[5], rec[6], rec[7]}; break;
+    case PK_SCHNORR: func = BB_SCHNORR_VERIFY; sel = {rec[2], rec[3]}; sel.insert(sel.end(), rec + 8, rec + 8 + rec[4] + rec[5]); outs = {rec[6], rec[7]}; break;
+    default: return set_err(ACVM_E_INVALID, "not a black box function of the solver trait");
+    }
+    const uint32_t n_sel = (uint32_t)sel.size(), n_out = (uint32_t)outs.size() / 2;
+    const uint32_t n_total = exact ? n_slow : b->B;
+    if (!n_total) return 0;
+    uint32_t *d_sel = nullptr, *d_outs = nullptr;
+    uint8_t *d_active = nullptr, *d_in = nullptr, *d_rc = nullptr, *d_vals = nullptr;
+    std::vector<uint8_t> active(n_total, 1);
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_sel, (void *)d_outs, (void *)d_active, (void *)d_in, (void *)d_rc, (void *)d_vals})
+            if (q) hipFree(q);
+    };
+    const uint32_t chunk = std::min<uint32_t>(n_total, 8192);
+#define HB_CHK(expr)                                                                    \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) { cleanup(); return set_err(ACVM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); } \
+    } while (0)
+    HB_CHK(hipMalloc((void **)&d_sel, (size_t)std::max<uint32_t>(n_sel, 1) * 4));
+    HB_CHK(hipMalloc((void **)&d_outs, outs.size() * 4));
+    HB_CHK(hipMalloc((void **)&d_in, (size_t)chunk * std::max<uint32_t>(n_sel, 1) * 32));
+    HB_CHK(hipMalloc((void **)&d_rc, chunk));
+    HB_CHK(hipMalloc((void **)&d_vals, (size_t)chunk * n_out * 32));
+    if (n_sel) HB_CHK(hipMemcpyAsync(d_sel, sel.data(), (size_t)n_sel * 4, hipMemcpyHostToDevice, s));
+    HB_CHK(hipMemcpyAsync(d_outs, outs.data(), outs.size() * 4, hipMemcpyHostToDevice, s));
+    const ExactLanes L = exact_lanes(b, n_slow);
+    if (exact) {
+        HB_CHK(hipMalloc((void **)&d_active, n_total));
+        launch_hostbb_precheck(s, L, opcode, d_sel, n_sel, d_active);
+        HB_CHK(hipMemcpyAsync(active.data(), d_active, n_total, hipMemcpyDeviceToHost, s));
+    }
+    HB_CHK(hipStreamSynchronize(s));
+    std::vector<uint8_t> in((size_t)chunk * std::max<uint32_t>(n_sel, 1) * 32), rc(chunk), vals((size_t)chunk * n_out * 32);
+    char err[200];
+    for (uint32_t first = 0; first < n_total; first += chunk) {
+        const uint32_t m = std::min(chunk, n_total - first);
+        launch_hostbb_gather(s, b->d_W, b->Bp, exact ? b->d_slow_ids : nullptr, first, m, d_sel, n_sel, d_in);
+        if (n_sel) HB_CHK(hipMemcpyAsync(in.data(), d_in, (size_t)m * n_sel * 32, hipMemcpyDeviceToHost, s));
+        HB_CHK(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < m; i++) {
+            rc[i] = 255;
+            if (!active[first + i]) continue;
+            const uint8_t *a = &in[(size_t)i * n_sel * 32];
+            uint8_t *o = &vals[(size_t)i * n_out * 32];
+            memset(o, 0, (size_t)n_out * 32);
+            err[0] = 0;
+            int r = 0;
+            if (rec[0] == PK_FIXED_BASE) r = b->solver.fixed_base_scalar_mul(b->solver.ctx, a, a + 32, o, o + 32, err, sizeof err);
+            else if (rec[0] == PK_PEDERSEN) r = b->solver.pedersen(b->solver.ctx, a, rec[3], rec[2], o, o + 32, err, sizeof err);
+            else {  // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness
+                const uint32_t n_sig = rec[4], n_msg = rec[5];
+                std::vector<uint8_t> sig(n_sig + 1), msg(n_msg + 1);
+                for (uint32_t k = 0; k < n_sig; k++) sig[k] = a[(size_t)(2 + k) * 32 + 31];
+                for (uint32_t k = 0; k < n_msg; k++) msg[k] = a[(size_t)(2 + n_sig + k) * 32 + 31];
+                uint8_t ok = 0;
+                r = b->solver.schnorr_verify(b->solver.ctx, a, a + 32, sig.data(), n_sig, msg.data(), n_msg, &ok, err, sizeof err);
+                o[31] = ok ? 1 : 0;
+            }
+            rc[i] = (uint8_t)(r < 0 || r > 2 ? 3 : r);
+            if (r != 0) b->host_bb_msg[exact ? b->slow_ids[first + i] : first + i] = err;
+        }
+        HB_CHK(hipMemcpyAsync(d_rc, rc.data(), m, hipMemcpyHostToDevice, s));
+        HB_CHK(hipMemcpyAsync(d_vals, vals.data(), (size_t)m * n_out * 32, hipMemcpyHostToDevice, s));
+        if (exact) launch_hostbb_apply_exact(s, b->d_W, b->Bp, L, first, m, opcode, func, d_outs, n_out, d_active, d_rc, d_vals);
+        else launch_hostbb_apply_level(s, b->d_W, b->Bp, first, m, opcode, func, d_outs, n_out, d_rc, d_vals, b->d_event);
+        HB_CHK(hipGetLastError());
+        HB_CHK(hipStreamSynchronize(s));
+    }
+#undef HB_CHK
+    cleanup();
+    return 0;
+}
+
 // run the exact in-order kernels over the current lanes from opcode min_start on and fetch the outcomes
 static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start) {
     const Plan &p = b->plan;
@@ -461,6 +556,9 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
         case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
         case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
         case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
+        case CLS_HOSTBB:
+            if (int rc = run_host_blackbox(b, seg.begin, true, n_slow)) return rc;
+            break;
         }
     }
     launch_exact_finish(s, L);
@@ -516,6 +614,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
     hipStream_t s = b->stream;
     hipStream_t s2 = getenv("ACVM_NO_OVERLAP") ? b->stream : b->stream_dyn;  // measurement aid: serialise the two level kernels
     b->n_launches = 0;
+    b->host_bb_msg.clear();
     b->arith_kernel_ms = 0;
     b->dyn_kernel_ms = 0;
     b->slow_path_ms = 0;
@@ -575,6 +674,11 @@ int acvm_batch_solve(acvm_batch_t *b) {
                     case CLS_GRUMPKIN: launch_grumpkin_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                     case CLS_BRILLIG: launch_brillig_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                     case CLS_PEDERSEN: launch_pedersen_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                    case CLS_HOSTBB:  // host callbacks: everything launched so far on either stream must have finished
+                        if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
+                        for (uint32_t r = 0; r < ch.count; r++)
+                            if (int rc = run_host_blackbox(b, p.prog[p.cls_offset[k][ch.first + r] + 1], false, 0)) return rc;
+                        break;
                     }
                     if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); cls_pairs[k].push_back({e0, e1}); }
                     b->n_launches++;
@@ -831,6 +935,11 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
     case 21: snprintf(r.message, sizeof r.message, "%u output values were provided as a foreign call result for %u destination slots", sr.x0, sr.val[0]); break;
     case 22: snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode"); break;
     case 23: snprintf(r.message, sizeof r.message, "foreign call inputs exceed the device staging buffer"); break;
+    case 24: {
+        auto it = b->host_bb_msg.find(j);
+        snprintf(r.message, sizeof r.message, "%s", it == b->host_bb_msg.end() ? "" : it->second.c_str());
+        break;
+    }
     default: break;
     }
 }

@@ -59,6 +59,102 @@ __global__ void exact_finish_kernel(ExactLanes L) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- caller-supplied BlackBoxFunctionSolver
+// A Pedersen / FixedBaseScalarMul / SchnorrVerify record served by host callbacks (acvm_bb_solver_t): the inputs leave the
+// device through hostbb_gather_kernel, the callbacks run on the host, hostbb_apply_kernel inserts their outputs with the
+// reference's insert_value semantics. On the exact path hostbb_precheck_kernel first applies the all-inputs-assigned rule
+// (blackbox/mod.rs:55-62) and marks the lanes that really execute the opcode.
+__global__ void hostbb_precheck_kernel(ExactLanes L, uint32_t opcode, const uint32_t *__restrict__ sel, uint32_t n_sel, uint8_t *__restrict__ active) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L.n_slow) return;
+    active[t] = 0;
+    if (L.results[t].status != 1u || L.start_opcode[t] > opcode) return;
+    for (uint32_t i = 0; i < n_sel; i++) {
+        const uint32_t w = sel[i];
+        if (!((L.assigned[(uint64_t)(w >> 5) * L.n_slow + t] >> (w & 31)) & 1u)) {
+            exact_fail(L, t, opcode, op_fail(DE_MISSING_ASSIGNMENT, w));
+            return;
+        }
+    }
+    active[t] = 1;
+}
+// out: [n_lanes][n_sel][32] canonical big-endian; lane t reads instance ids[t] (or first + t when ids is null)
+__global__ void __launch_bounds__(256) hostbb_gather_kernel(const uint4 *__restrict__ W, uint64_t Bp, const uint32_t *__restrict__ ids, uint32_t first,
+                                                            uint32_t n_lanes, const uint32_t *__restrict__ sel, uint32_t n_sel, uint8_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = blockIdx.y;
+    if (t >= n_lanes) return;
+    const uint64_t j = ids ? ids[first + t] : first + t;
+    const Fr x = fr_to_canonical(fr_load(W, sel[k], Bp, j));
+    uint8_t *p = out + ((uint64_t)t * n_sel + k) * 32;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint8_t *q = p + 28 - 4 * i;
+        q[0] = (uint8_t)(x.v[i] >> 24); q[1] = (uint8_t)(x.v[i] >> 16); q[2] = (uint8_t)(x.v[i] >> 8); q[3] = (uint8_t)x.v[i];
+    }
+}
+__device__ __forceinline__ Fr fr_from_be32_reduce(const uint8_t *p) {
+    Fr x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *q = p + 28 - 4 * i;
+        x.v[i] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3];
+    }
+    return fr_from_canonical(canon_reduce(x));
+}
+// rc per lane: 0 Ok, 1 BlackBoxResolutionError::Failed, 2 Unsupported (blackbox_solver/src/lib.rs:15-21); 255 = lane not called
+template <class P>
+__device__ __forceinline__ OpResult hostbb_apply(const P &p, uint32_t func, uint32_t rc, const uint32_t *__restrict__ outs, uint32_t n_out,
+                                                 const uint8_t *__restrict__ vals) {
+    if (rc == 1u) return op_fail_msg(DE_BLACKBOX_FAILED, func, DM_HOST_MESSAGE);
+    if (rc == 2u) return op_fail(DE_UNSUPPORTED_BLACKBOX, func);
+    if (rc != 0u) return op_fail_msg(DE_PANIC, func, DM_HOST_MESSAGE);
+    for (uint32_t k = 0; k < n_out; k++)
+        if (!p.insert(outs[2 * k], fr_from_be32_reduce(vals + 32 * k), outs[2 * k + 1])) return op_fail(DE_UNSATISFIED);
+    return op_ok();
+}
+__global__ void __launch_bounds__(256) hostbb_apply_level_kernel(uint4 *W, uint64_t Bp, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
+                                                                 const uint32_t *__restrict__ outs, uint32_t n_out, const uint8_t *__restrict__ rc,
+                                                                 const uint8_t *__restrict__ vals, uint32_t *__restrict__ event) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_lanes) return;
+    const uint64_t j = first + t;
+    FastPolicy p{W, Bp, j};
+    const OpResult r = hostbb_apply(p, func, rc[t], outs, n_out, vals + (uint64_t)t * n_out * 32);
+    if (r.err) atomicMin(&event[j], opcode);
+}
+__global__ void __launch_bounds__(64) hostbb_apply_exact_kernel(uint4 *W, uint64_t Bp, ExactLanes L, uint32_t first, uint32_t n_lanes, uint32_t opcode,
+                                                                uint32_t func, const uint32_t *__restrict__ outs, uint32_t n_out,
+                                                                const uint8_t *__restrict__ active, const uint8_t *__restrict__ rc,
+                                                                const uint8_t *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lanes) return;
+    const uint32_t t = first + i;
+    if (!active[t]) return;
+    ExactPolicy p{W, Bp, L.slow_ids[t], L.assigned, L.n_slow, t};
+    const OpResult r = hostbb_apply(p, func, rc[i], outs, n_out, vals + (uint64_t)i * n_out * 32);
+    if (r.err) exact_fail(L, t, opcode, r);
+}
+void launch_hostbb_precheck(hipStream_t s, const ExactLanes &L, uint32_t opcode, const uint32_t *sel, uint32_t n_sel, uint8_t *active) {
+    if (!L.n_slow) return;
+    hipLaunchKernelGGL(hostbb_precheck_kernel, dim3((L.n_slow + 255) / 256), dim3(256), 0, s, L, opcode, sel, n_sel, active);
+}
+void launch_hostbb_gather(hipStream_t s, const uint4 *W, uint64_t Bp, const uint32_t *ids, uint32_t first, uint32_t n_lanes, const uint32_t *sel,
+                          uint32_t n_sel, uint8_t *out) {
+    if (!n_lanes || !n_sel) return;
+    hipLaunchKernelGGL(hostbb_gather_kernel, dim3((n_lanes + 255) / 256, n_sel), dim3(256), 0, s, W, Bp, ids, first, n_lanes, sel, n_sel, out);
+}
+void launch_hostbb_apply_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func, const uint32_t *outs,
+                               uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event) {
+    if (!n_lanes) return;
+    hipLaunchKernelGGL(hostbb_apply_level_kernel, dim3((n_lanes + 255) / 256), dim3(256), 0, s, W, Bp, first, n_lanes, opcode, func, outs, n_out, rc, vals, event);
+}
+void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const ExactLanes &L, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
+                               const uint32_t *outs, uint32_t n_out, const uint8_t *active, const uint8_t *rc, const uint8_t *vals) {
+    if (!n_lanes) return;
+    hipLaunchKernelGGL(hostbb_apply_exact_kernel, dim3((n_lanes + 63) / 64), dim3(64), 0, s, W, Bp, L, first, n_lanes, opcode, func, outs, n_out, active, rc, vals);
+}
+
 void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
                         uint32_t *event) {
     launch_record_level<LightOp, 256>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);

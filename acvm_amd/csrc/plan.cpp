@@ -100,7 +100,7 @@ uint32_t clamp_reg(uint64_t r) { return r > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint3
 
 }  // namespace
 
-Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial) {
+Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, bool host_blackbox) {
     auto t0 = std::chrono::steady_clock::now();
     Plan p;
     p.n_opcodes = (uint32_t)c.opcodes.size();
@@ -185,22 +185,22 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 }
                 case BB_PEDERSEN:
                     // [PK_PEDERSEN, oi, domain_separator, n_in, out_x, fx, out_y, fy, ws...]
-                    p.prog_class[oi] = CLS_GRUMPKIN;
-                    p.needs_grumpkin = true;
+                    p.prog_class[oi] = host_blackbox ? CLS_HOSTBB : CLS_GRUMPKIN;
+                    p.needs_grumpkin |= !host_blackbox;
                     s.insert(s.end(), {PK_PEDERSEN, oi, b.domain_separator, (uint32_t)b.in[0].size()});
                     out(b.out[0]); out(b.out[1]);
                     for (auto &in : b.in[0]) s.push_back(in.witness);
                     break;
                 case BB_FIXED_BASE_SCALAR_MUL:
-                    p.prog_class[oi] = CLS_GRUMPKIN;
-                    p.needs_grumpkin = true;
+                    p.prog_class[oi] = host_blackbox ? CLS_HOSTBB : CLS_GRUMPKIN;
+                    p.needs_grumpkin |= !host_blackbox;
                     s.insert(s.end(), {PK_FIXED_BASE, oi, b.in[0][0].witness, b.in[1][0].witness});
                     out(b.out[0]); out(b.out[1]);
                     break;
                 case BB_SCHNORR_VERIFY: {
                     // [PK_SCHNORR, oi, pkx, pky, n_sig, n_msg, out, flag, sig ws..., msg ws...]
-                    p.prog_class[oi] = CLS_GRUMPKIN;
-                    p.needs_grumpkin = true;
+                    p.prog_class[oi] = host_blackbox ? CLS_HOSTBB : CLS_GRUMPKIN;
+                    p.needs_grumpkin |= !host_blackbox;
                     p.prog_scratch[oi] = (uint32_t)((32 + b.in[3].size() + 3) / 4 + 1);
                     s.insert(s.end(), {PK_SCHNORR, oi, b.in[0][0].witness, b.in[1][0].witness, (uint32_t)b.in[2].size(),
                                        (uint32_t)b.in[3].size()});
@@ -370,6 +370,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     p.has_foreign_calls = true;
                 }
                 if (has_grumpkin) p.needs_grumpkin = true;
+                if (has_grumpkin && host_blackbox) unsupported(oi, "a caller-supplied BlackBoxFunctionSolver inside Brillig black-box ops");
                 uint64_t mem_cap = arr_cells + mem_hint + 64 + (max_hash_hint ? 64 : 0) + (has_foreign ? 64 : 0);
                 if (const char *e = getenv("ACVM_BRILLIG_MEM_CELLS")) mem_cap = std::max<uint64_t>(mem_cap, strtoull(e, nullptr, 10));
                 mem_cap = std::min<uint64_t>(mem_cap, 1u << 20);
@@ -499,7 +500,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             p.algorithmic_bytes += bytes;
             p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
             p.n_other_records++;
-            records.push_back({lvl, o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi], oi});
+            records.push_back({lvl, o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi], oi});
             continue;
         }
         const Expr &e = o.expr;

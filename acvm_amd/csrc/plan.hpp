@@ -43,7 +43,9 @@ enum ProgKind : uint32_t {
 // kernel classes of the non-arithmetic records
 // CLS_PEDERSEN only exists in the level schedule (its own 4-waves-per-instance-group kernel); the exact path and the
 // statistics treat a Pedersen record as CLS_GRUMPKIN
-enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, N_CLS = 5 };
+// CLS_HOSTBB: Pedersen / FixedBaseScalarMul / SchnorrVerify when the caller supplied its own BlackBoxFunctionSolver: the
+// record is executed by host callbacks between two small kernels (batch.cpp run_host_blackbox)
+enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, CLS_HOSTBB = 5, N_CLS = 6 };
 
 struct Plan {
     uint32_t n_witnesses = 0;
@@ -77,7 +79,7 @@ struct Plan {
     // statistics
     uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0, n_other_records = 0;
     uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
-    uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0};
+    uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0, 0};
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;
@@ -88,6 +90,7 @@ struct Plan {
     uint64_t fc_pending_vals = 0;  // field elements one pending call can hand to the host (upper bound)
 };
 
-Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial);
+// host_blackbox: the three BlackBoxFunctionSolver functions are served by caller-supplied host callbacks
+Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, bool host_blackbox = false);
 
 }  // namespace acvm

@@ -17,8 +17,13 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.split("(")[0]
-    return name.replace("acvm::", "")
+    name = name.split("(")[0].replace("acvm::", "").replace("void ", "")
+    for cls, nice in (("LightOp", "light"), ("HashOp", "hash"), ("GrumpkinOp", "grumpkin"), ("BrilligOp", "brillig")):
+        if name.startswith("record_level_kernel<" + cls):
+            return nice + "_level_kernel"
+        if name.startswith("record_exact_kernel<" + cls):
+            return nice + "_exact_kernel"
+    return name
 
 
 def read_pmc(path, counter):

@@ -44,9 +44,9 @@ struct acvm_batch {
     uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
     uint32_t *d_prog = nullptr, *d_prog_offset = nullptr, *d_bytecode = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
     uint32_t *d_dyn_offset = nullptr, *d_slow_start = nullptr;
-    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<std::vector<LaunchChunk>> cls_chunks[N_CLS];  // per level
     std::vector<ExactSegment> segments;
     DeviceProgram dp{};
@@ -63,7 +63,7 @@ struct acvm_batch {
     hipEvent_t ev_start = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
-    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0};
+    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr;
     std::vector<hipEvent_t> ev_sync;
     uint4 *d_dyn_scratch = nullptr;
@@ -206,7 +206,8 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_other_records = p.n_other_records;
     out->truncated_at = p.truncated_at;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
-    out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN];
+    out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
+                                                               p.cls_algorithmic_bytes[CLS_HOSTBB];
 }
 
 // Host-only: levelise the circuit against a set of initial witness ids without touching a device (plan statistics, and
@@ -556,6 +557,7 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
         case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
         case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
         case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
+        case CLS_ECDSA: launch_exact_ecdsa(s, b->d_W, b->Bp, b->dp, L, seg.begin); break;
         case CLS_HOSTBB:
             if (int rc = run_host_blackbox(b, seg.begin, true, n_slow)) return rc;
             break;
@@ -674,6 +676,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
                     case CLS_GRUMPKIN: launch_grumpkin_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                     case CLS_BRILLIG: launch_brillig_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                     case CLS_PEDERSEN: launch_pedersen_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                    case CLS_ECDSA: launch_ecdsa_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
                     case CLS_HOSTBB:  // host callbacks: everything launched so far on either stream must have finished
                         if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
                         for (uint32_t r = 0; r < ch.count; r++)
@@ -935,6 +938,20 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
     case 21: snprintf(r.message, sizeof r.message, "%u output values were provided as a foreign call result for %u destination slots", sr.x0, sr.val[0]); break;
     case 22: snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode"); break;
     case 23: snprintf(r.message, sizeof r.message, "foreign call inputs exceed the device staging buffer"); break;
+    case 25: {
+        static const char *what[3] = {"pubkey_x", "pubkey_y", "signature"};
+        snprintf(r.message, sizeof r.message, "expected %s size %u but received %u", what[sr.x0 < 3 ? sr.x0 : 0], sr.x0 == 2 ? 64u : 32u, sr.x1);
+        break;
+    }
+    case 26: {
+        static const char *texts[7] = {"", "ecdsa: signature scalars must be in [1, n-1] (Signature::try_from unwrap)",
+                                       "ecdsa: public key x is not on the curve (PublicKey::from_encoded_point unwrap)",
+                                       "ecdsa: hashed message must be 32 bytes (GenericArray::from_slice)",
+                                       "ecdsa: hashed message is not below the group order (Scalar::from_repr unwrap)",
+                                       "ecdsa: R is the identity (unreachable!)", "ecdsa: R.x is not below the group order (Scalar::from_repr unwrap)"};
+        snprintf(r.message, sizeof r.message, "%s", sr.x0 < 7 ? texts[sr.x0] : "");
+        break;
+    }
     case 24: {
         auto it = b->host_bb_msg.find(j);
         snprintf(r.message, sizeof r.message, "%s", it == b->host_bb_msg.end() ? "" : it->second.c_str());
@@ -1062,7 +1079,7 @@ int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     out->arith_kernel_ms = b->arith_kernel_ms;
     out->dyn_kernel_ms = b->dyn_kernel_ms;
     for (int k = 0; k < 4; k++) out->class_kernel_ms[k] = b->cls_kernel_ms[k];
-    out->class_kernel_ms[CLS_GRUMPKIN] += b->cls_kernel_ms[CLS_PEDERSEN];
+    out->class_kernel_ms[CLS_GRUMPKIN] += b->cls_kernel_ms[CLS_PEDERSEN] + b->cls_kernel_ms[CLS_ECDSA] + b->cls_kernel_ms[CLS_HOSTBB];
     out->slow_path_ms = b->slow_path_ms;
     return 0;
 }

@@ -222,8 +222,17 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     for (uint32_t w : b.out) out(w);
                     break;
                 }
+                case BB_ECDSA_SECP256K1: case BB_ECDSA_SECP256R1:
+                    // [PK_ECDSA, oi, curve, n_x, n_y, n_sig, n_msg, out, flag, ws: x..., y..., sig..., msg...]
+                    p.prog_class[oi] = CLS_ECDSA;
+                    s.insert(s.end(), {PK_ECDSA, oi, b.func == BB_ECDSA_SECP256R1 ? 1u : 0u, (uint32_t)b.in[0].size(), (uint32_t)b.in[1].size(),
+                                       (uint32_t)b.in[2].size(), (uint32_t)b.in[3].size()});
+                    out(b.out[0]);
+                    for (int g = 0; g < 4; g++)
+                        for (auto &in : b.in[g]) s.push_back(in.witness);
+                    break;
                 default:
-                    unsupported(oi, "black box function tag " + std::to_string(b.func) + " (ECDSA)");
+                    unsupported(oi, "black box function tag " + std::to_string(b.func));
                     s.insert(s.end(), {0xFFFFFFFFu, oi});
                 }
                 break;

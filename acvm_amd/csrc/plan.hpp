@@ -38,14 +38,14 @@ static constexpr uint32_t GATE_HDR_WORDS = 5;
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
 enum ProgKind : uint32_t {
     PK_ARITH = 0, PK_RANGE = 1, PK_LOGIC = 2, PK_HASH = 3, PK_PEDERSEN = 4, PK_FIXED_BASE = 5, PK_SCHNORR = 6, PK_ZERO_OUT = 7,
-    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12
+    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12, PK_ECDSA = 13
 };
 // kernel classes of the non-arithmetic records
 // CLS_PEDERSEN only exists in the level schedule (its own 4-waves-per-instance-group kernel); the exact path and the
 // statistics treat a Pedersen record as CLS_GRUMPKIN
 // CLS_HOSTBB: Pedersen / FixedBaseScalarMul / SchnorrVerify when the caller supplied its own BlackBoxFunctionSolver: the
 // record is executed by host callbacks between two small kernels (batch.cpp run_host_blackbox)
-enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, CLS_HOSTBB = 5, N_CLS = 6 };
+enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, CLS_HOSTBB = 5, CLS_ECDSA = 6, N_CLS = 7 };
 
 struct Plan {
     uint32_t n_witnesses = 0;
@@ -79,7 +79,7 @@ struct Plan {
     // statistics
     uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0, n_other_records = 0;
     uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
-    uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0, 0};
+    uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;

@@ -360,11 +360,30 @@ static int solve_blackbox(oracle_acvm_t *a, const bb_call_t *b) {
         if (pwg_insert_value(a, b->out[0], &x)) return 1;
         return pwg_insert_value(a, b->out[1], &y);
     }
-    case BB_ECDSA_SECP256K1: case BB_ECDSA_SECP256R1:
-        /* blackbox/signature/ecdsa.rs (k256/p256): NOT restated in this oracle (outside north_star's kernel
-         * set, SURVEY 8a footnote). Reported as unsupported so that it can never pass silently. */
-        pwg_fail(a, E_UNSUPPORTED_BLACKBOX, b->func, 0, "ecdsa not restated in oracle");
-        return 1;
+    case BB_ECDSA_SECP256K1: case BB_ECDSA_SECP256R1: { /* blackbox/signature/ecdsa.rs:12-91 */
+        /* hashed_message first, then pubkey_x / pubkey_y / signature with their length checks (ecdsa.rs:20-47) */
+        size_t nm = b->n_in[3];
+        uint8_t *msg = (uint8_t *)malloc(nm + 1), px[33], py[33], sg[65];
+        int rc = to_u8_vec(a, b->in[3], nm, msg);
+        static const char *what[3] = {"pubkey_x", "pubkey_y", "signature"};
+        static const size_t want[3] = {32, 32, 64};
+        uint8_t *dst[3] = {px, py, sg};
+        for (int g = 0; g < 3 && !rc; g++) {
+            if (b->n_in[g] != want[g]) {
+                char m[96];
+                snprintf(m, sizeof m, "expected %s size %zu but received %zu", what[g], want[g], b->n_in[g]);
+                pwg_fail(a, E_BLACKBOX_FAILED, b->func, 0, m);
+                rc = 1;
+            } else rc = to_u8_vec(a, b->in[g], b->n_in[g], dst[g]);
+        }
+        if (!rc) {
+            int v = oracle_ecdsa_verify(b->func == BB_ECDSA_SECP256R1, msg, nm, px, py, sg);
+            if (v < 0) { pwg_fail(a, E_PANIC, b->func, (uint32_t)(-v), oracle_ecdsa_panic_text(v)); rc = 1; }
+            else { fr_from_u64(&r, (uint64_t)v); rc = pwg_insert_value(a, b->out[0], &r); }
+        }
+        free(msg);
+        return rc;
+    }
     case BB_RECURSIVE_AGGREGATION: /* blackbox/mod.rs:154-161 */
         fr_zero(&r);
         for (size_t i = 0; i < b->n_out; i++)

@@ -94,6 +94,9 @@ int oracle_acvm_resolve_foreign_call(oracle_acvm_t *a, const fc_result_t *result
 int pwg_get_value(oracle_acvm_t *a, const expr_t *e, fr_t *out);       /* 0 ok, else sets a->res error */
 int pwg_insert_value(oracle_acvm_t *a, uint32_t w, const fr_t *v);      /* 0 ok, else E_UNSATISFIED */
 void pwg_fail(oracle_acvm_t *a, uint32_t err, uint32_t aux0, uint32_t aux1, const char *msg);
+/* ecdsa.c: 0 / 1, or a negative panic code (see oracle_ecdsa_panic_text); curve 0 = secp256k1, 1 = secp256r1 */
+int oracle_ecdsa_verify(int curve, const uint8_t *hashed_msg, size_t msg_len, const uint8_t pkx[32], const uint8_t pky[32], const uint8_t sig[64]);
+const char *oracle_ecdsa_panic_text(int code);
 /* brillig_vm.c */
 int brillig_solve(oracle_acvm_t *a, const brillig_t *b, size_t acir_index); /* 0 ok, 1 err (res set), 2 foreign call wait */
 

@@ -181,7 +181,9 @@ def main():
                 "other_kernels_ms_per_step": {k: v[0] / args.steps for k, v in cand.items() if k != dominant and v[0] > 0}}
         if tr:
             roof["traffic_source"] = tr.get("source")
-            roof["traffic_algorithmic_bytes_per_launch"] = tr.get("algorithmic_bytes_per_launch")
+            # the profile ran 3 timed + 1 warm-up solves: launches per solve = launches_profiled / 4
+            per_solve = max(1, tr.get("launches_profiled", 4) // 4)
+            roof["traffic_algorithmic_bytes_per_launch"] = k_bytes * B / per_solve
         if dominant == "grumpkin_level_kernel":
             roof["note"] = "integer-ALU bound (about 1e3 field multiplications per 128-256 B moved): the HBM fraction is for information"
         line = {

@@ -236,7 +236,10 @@ static int batch_init(acvm_batch *b) {
     if (int rc = upload(&b->d_gate_stream, p.gate_stream)) return rc;
     if (int rc = upload(&b->d_gate_offset, p.gate_offset)) return rc;
     std::vector<uint32_t> consts(p.constants.size() * 8);
-    for (size_t i = 0; i < p.constants.size(); i++) memcpy(&consts[8 * i], p.constants[i].l, 32);
+    for (size_t i = 0; i < p.constants.size(); i++) {
+        const FrH d = frh::to_device_form(p.constants[i]);
+        memcpy(&consts[8 * i], d.l, 32);
+    }
     if (int rc = upload(&b->d_consts, consts)) return rc;
     if (int rc = upload(&b->d_prog, p.prog)) return rc;
     if (int rc = upload(&b->d_prog_offset, p.prog_offset)) return rc;
@@ -441,7 +444,8 @@ static int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
             for (auto &v : res) {
                 desc[(size_t)(w++) * n_slow + t] = v.is_array ? 1u : 0u;
                 desc[(size_t)(w++) * n_slow + t] = (uint32_t)v.vals.size();
-                for (auto &x : v.vals) {  // slot vi: halves at (2 vi) * n_slow + t and (2 vi + 1) * n_slow + t, 4 words each
+                for (auto &xh : v.vals) {  // slot vi: halves at (2 vi) * n_slow + t and (2 vi + 1) * n_slow + t, 4 words each
+                    const FrH x = frh::to_device_form(xh);
                     memcpy(&vbuf[((size_t)(2 * vi) * n_slow + t) * 4], &x.l[0], 16);
                     memcpy(&vbuf[((size_t)(2 * vi + 1) * n_slow + t) * 4], &x.l[2], 16);
                     vi++;
@@ -816,7 +820,7 @@ int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, u
             memcpy(&m.l[0], &b->h_pend_vals[((size_t)(2 * vi) * n_slow + t) * 4], 16);
             memcpy(&m.l[2], &b->h_pend_vals[((size_t)(2 * vi + 1) * n_slow + t) * 4], 16);
             uint64_t can[4];
-            frh::to_canonical(m, can);
+            frh::to_canonical(frh::from_device_form(m), can);
             for (int k = 0; k < 32; k++) values_be32[(size_t)vi * 32 + 31 - k] = (uint8_t)(can[k / 8] >> (8 * (k % 8)));
         }
     }

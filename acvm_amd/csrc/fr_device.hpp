@@ -1,9 +1,14 @@
 // fr_device.hpp -- BN254-Fr arithmetic for gfx950 (CDNA4), the inner loop of every kernel.
 // Replaces acir_field::FieldElement add/sub/neg/mul/inverse (acir_field/src/generic_ark.rs:242-245,
-// 360-406; ark-ff Fp256<MontBackend<_,4>>). Representation: Montgomery form, R = 2^256, as 8 x 32-bit
-// limbs held in VGPRs (CDNA4 has no 64x64 multiplier; the 32x32->64 v_mad_u64_u32 is the native wide
-// multiply-add). Values are always fully reduced to [0, p), so equality / is_zero are limb compares,
-// matching the reference's canonical-bytes equality (generic_ark.rs:88-92,164-169).
+// 360-406; ark-ff Fp256<MontBackend<_,4>>).
+// Storage form `Fr`: the Montgomery representative x * R mod p with R = 2^261, as 8 x 32-bit limbs, always fully
+// reduced to [0, p), so equality / is_zero are limb compares, matching the reference's canonical-bytes equality
+// (generic_ark.rs:88-92,164-169). Working form `Fr29`: 9 limbs of 29 bits (R = 2^(9*29)): CDNA4 has no 64x64
+// multiplier, the native wide multiply-add is v_mad_u64_u32 (measured 4.6 cycles per wave64, tools/chainbench), and a
+// carry-out costs another v_addc_co_u32 (3.6 cycles) per product with 32-bit limbs. With 29-bit limbs a whole column of
+// a * b + m * p (<= 18 products of < 2^58) fits a 64-bit accumulator, so the product needs 162 multiply-adds and no
+// carry instruction at all: 905 cycles per wave-product against 1 164 for the 8 x 32 product-scanning form with carries
+// (tools/mul29bench). The seven spare bits of R also make the product tolerant of unreduced inputs (< 8p in, < 1.4p out).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,9 +42,9 @@ FR_HD __forceinline__ Fr fr_zero() {
     for (int i = 0; i < 8; i++) r.v[i] = 0;
     return r;
 }
-// R mod p (Montgomery one)
+// R mod p (Montgomery one), R = 2^261
 FR_HD __forceinline__ Fr fr_one() {
-    Fr r = {{0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u}};
+    Fr r = {{0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u}};
     return r;
 }
 FR_HD __forceinline__ bool fr_is_zero(const Fr &a) {
@@ -104,9 +109,93 @@ FR_HD __forceinline__ Fr fr_neg(const Fr &a) {
     return fr_sub(z, a);  // 0 - 0 = 0; else p - a
 }
 
-// Montgomery product a*b*R^-1 mod p, fully reduced. CIOS with the "no-carry" simplification that the
-// spare top bits of p allow (p < 2^254): two 32x32+64 multiply-adds per limb pair.
-FR_HD __forceinline__ Fr fr_mul_portable(const Fr &a, const Fr &b) {
+// ---- working form: 9 x 29-bit limbs
+struct Fr29 {
+    uint32_t v[9];
+};
+FR_HD __forceinline__ uint32_t fr_p29(int i) {
+    constexpr uint32_t P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    return P[i];
+}
+// 8 x 32 -> 9 x 29 (exact; limbs < 2^29, top limb < 2^24)
+FR_HD __forceinline__ Fr29 fr29_from(const Fr &a) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+        uint64_t two = a.v[w];
+        if (w + 1 < 8) two |= (uint64_t)a.v[w + 1] << 32;
+        r.v[i] = (uint32_t)(two >> sh) & 0x1fffffffu;
+    }
+    return r;
+}
+// 9 x 29 (limbs < 2^29, value < 2^256) -> 8 x 32
+FR_HD __forceinline__ Fr fr29_pack(const Fr29 &a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int bit = 32 * i, l = bit / 29, sh = bit - 29 * l;  // limb l holds bits [29 l, 29 l + 29)
+        uint64_t acc = (uint64_t)a.v[l] >> sh;
+        acc |= (uint64_t)a.v[l + 1] << (29 - sh);
+        if (l + 2 < 9 && 58 - sh < 32) acc |= (uint64_t)a.v[l + 2] << (58 - sh);
+        r.v[i] = (uint32_t)acc;
+    }
+    return r;
+}
+// Montgomery product a * b * 2^-261 mod p in the working form. Inputs: limbs < 2^29 (top limb < 2^28), values < 8p.
+// Output: limbs < 2^29, value < 1.4p (< 1.06p for inputs < 4p). Column k of a * b + m * p is summed in one 64-bit
+// accumulator (at most 18 products < 2^58 plus a 35-bit carry); m_k = column * (-p^-1) mod 2^29 zeroes the column's low
+// limb, and -p^-1 = 2^28 - 1, p_0 = 2^28 + 1 turn both of those multiplications into shifts.
+FR_HD __forceinline__ Fr29 fr29_mul(const Fr29 &a, const Fr29 &b) {
+    constexpr uint32_t M = 0x1fffffffu;
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fr29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        const uint32_t lo = (uint32_t)acc;
+        m[k] = (((lo & 1u) << 28) - lo) & M;
+        acc += ((uint64_t)m[k] << 28) + m[k];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        r.v[k - 9] = (uint32_t)acc & M;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+// value < 2p, limbs < 2^29 -> canonical [0, p)
+FR_HD __forceinline__ Fr29 fr29_cond_sub_p(const Fr29 &a) {
+    Fr29 d;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t t = (int32_t)a.v[i] - (int32_t)fr_p29(i) + borrow;
+        d.v[i] = (uint32_t)t & 0x1fffffffu;
+        borrow = t >> 29;  // 0 or -1
+    }
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+
+// Montgomery product on the storage form, fully reduced
+FR_HD __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) { return fr29_pack(fr29_cond_sub_p(fr29_mul(fr29_from(a), fr29_from(b)))); }
+
+// Independent reference for the self tests: the textbook 8 x 32-limb CIOS with R = 2^256, applied twice
+// (a * b * 2^-256, then * 2^251 * 2^-256 = * 2^-5) to land in the same R = 2^261 domain.
+FR_HD __forceinline__ Fr fr_cios256(const Fr &a, const Fr &b) {
     uint32_t t[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) t[i] = 0;
@@ -132,29 +221,17 @@ FR_HD __forceinline__ Fr fr_mul_portable(const Fr &a, const Fr &b) {
     for (int i = 0; i < 8; i++) r.v[i] = t[i];
     return fr_cond_sub_p(r);
 }
-
-// Montgomery product on gfx950 by finely-integrated product scanning (fr_mul_gfx950.inc, generated by
-// tools/gen_fr_mul.py): column k of a*b + m*p is summed in a 96-bit accumulator (lo: 64 bit, hi: 32 bit) with
-//     v_mad_u64_u32 lo, vcc, x, y, lo      ; lo += x*y, carry out of bit 64 in VCC
-//     v_addc_co_u32 hi, vcc, 0, hi, vcc    ; hi += carry
-// i.e. 2 instructions per 32x32 product and no register shuffling (hipcc's own lowering of the portable code
-// below spends ~4 extra moves/adds per product building 64-bit addend pairs). m_k = column * (-p^-1) mod 2^32
-// zeroes the column's low word, then the accumulator shifts down one limb. Modulus limbs are SGPR operands.
-// 128 x (v_mad_u64_u32 + v_addc_co_u32) + 8 v_mul_lo_u32 per product. The host pass (unit tests of this
-// header on the CPU) uses the portable version; acvm_selftest() checks both against each other on the GPU.
-FR_HD __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#include "fr_mul_gfx950.inc"
-#else
-    return fr_mul_portable(a, b);
-#endif
+FR_HD __forceinline__ Fr fr_mul_portable(const Fr &a, const Fr &b) {
+    Fr two251 = fr_zero();
+    two251.v[7] = 1u << 27;  // 2^251 < p
+    return fr_cios256(fr_cios256(a, b), two251);
 }
 
 FR_HD __forceinline__ Fr fr_sqr(const Fr &a) { return fr_mul(a, a); }
 
 // R^3 mod p: takes the integer inverse of a Montgomery representative back into Montgomery form
 FR_HD __forceinline__ Fr fr_r3() {
-    Fr r = {{0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu}};
+    Fr r = {{0x601fddb2u, 0xbafa616cu, 0x23e89803u, 0x29b4a83eu, 0x44d1496bu, 0x917ad601u, 0xfe59ed6du, 0x1baa96fcu}};
     return r;
 }
 

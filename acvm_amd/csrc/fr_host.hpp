@@ -136,6 +136,13 @@ inline FrH pow_pm2(const FrH &a) {  // a^(p-2): Fermat inverse (planner only; a 
     return r;
 }
 inline FrH inverse(const FrH &a) { return a.is_zero() ? a : pow_pm2(a); }  // inverse(0) == 0
+// The device keeps Montgomery representatives with R = 2^261 (fr_device.hpp); the planner computes with R = 2^256.
+// x * 2^261 mod p is the R = 2^256 representative of 32 x, and back.
+inline FrH to_device_form(const FrH &a) { return mul(a, from_u64(32)); }
+inline FrH from_device_form(const FrH &a) {
+    static const FrH inv32 = inverse(from_u64(32));
+    return mul(a, inv32);
+}
 inline bool self_check() {
     // R1 = 2^256 mod p, R2 = R1^2 mod p: verify by doubling
     uint64_t x[4] = {1, 0, 0, 0};

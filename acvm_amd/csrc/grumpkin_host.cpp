@@ -158,9 +158,10 @@ struct HostTables {
     bool ok = false;
 };
 
-void put_point(std::vector<uint32_t> &w, size_t idx, const Aff &p) {
-    memcpy(&w[idx * 16], p.x.l, 32);
-    memcpy(&w[idx * 16 + 8], p.y.l, 32);
+void put_point(std::vector<uint32_t> &w, size_t idx, const Aff &p) {  // device Montgomery form (R = 2^261)
+    const FrH x = frh::to_device_form(p.x), y = frh::to_device_form(p.y);
+    memcpy(&w[idx * 16], x.l, 32);
+    memcpy(&w[idx * 16 + 8], y.l, 32);
 }
 
 HostTables build_host_tables() {
@@ -289,7 +290,7 @@ bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]) {
         FrH v;
         memcpy(v.l, &g_host.words[idx * 16 + 8 * c], 32);
         uint64_t can[4];
-        frh::to_canonical(v, can);
+        frh::to_canonical(frh::from_device_form(v), can);
         for (int i = 0; i < 32; i++) out_be[32 * c + 31 - i] = (uint8_t)(can[i / 8] >> (8 * (i % 8)));
     }
     return true;

@@ -61,7 +61,7 @@ __device__ __forceinline__ Fr coef_value(uint32_t coef, const uint32_t *__restri
 }
 // R^2 mod p: to_montgomery(x) = mont_mul(x, R2)
 __device__ __forceinline__ Fr fr_r2() {
-    Fr r = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
+    Fr r = {{0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u, 0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu}};  // 2^522 mod p
     return r;
 }
 // Montgomery <-> canonical little-endian 8x32 integers

@@ -13,12 +13,14 @@ static uint64_t sm(uint64_t &s) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-static Fr to_dev(const FrH &a) {
+static Fr to_dev(const FrH &h) {  // device Montgomery form (R = 2^261) of the planner's value
+    const FrH a = frh::to_device_form(h);
     Fr r;
     for (int i = 0; i < 4; i++) { r.v[2 * i] = (uint32_t)a.l[i]; r.v[2 * i + 1] = (uint32_t)(a.l[i] >> 32); }
     return r;
 }
-static bool same(const Fr &d, const FrH &h) {
+static bool same(const Fr &d, const FrH &hh) {
+    const FrH h = frh::to_device_form(hh);
     for (int i = 0; i < 4; i++)
         if (d.v[2 * i] != (uint32_t)h.l[i] || d.v[2 * i + 1] != (uint32_t)(h.l[i] >> 32)) return false;
     return true;
@@ -43,6 +45,15 @@ int main() {
         }
         Fr da = to_dev(a), db = to_dev(b);
         if (!same(fr_mul(da, db), frh::mul(a, b))) { fails++; printf("mul mismatch %d\n", it); }
+        if (!fr_eq(fr_mul(da, db), fr_mul_portable(da, db))) { fails++; printf("mul vs cios mismatch %d\n", it); }
+        {   // working form with unreduced inputs: (a + b + a) * (b + b) through limb-wise sums
+            Fr29 x = fr29_from(da), y = fr29_from(db), sx, sy;
+            for (int i = 0; i < 9; i++) { sx.v[i] = 2 * x.v[i] + y.v[i]; sy.v[i] = 2 * y.v[i]; }
+            for (int i = 0; i < 8; i++) { sx.v[i + 1] += sx.v[i] >> 29; sx.v[i] &= 0x1fffffffu; sy.v[i + 1] += sy.v[i] >> 29; sy.v[i] &= 0x1fffffffu; }
+            Fr29 pr = fr29_cond_sub_p(fr29_mul(sx, sy));
+            FrH want = frh::mul(frh::add(frh::add(a, a), b), frh::add(b, b));
+            if (!same(fr29_pack(pr), want)) { fails++; printf("lazy mul mismatch %d\n", it); }
+        }
         if (!same(fr_add(da, db), frh::add(a, b))) { fails++; printf("add mismatch %d\n", it); }
         if (!same(fr_sub(da, db), frh::sub(a, b))) { fails++; printf("sub mismatch %d\n", it); }
         if (!same(fr_neg(da), frh::neg(a))) { fails++; printf("neg mismatch %d\n", it); }
@@ -56,7 +67,7 @@ int main() {
     // 5^-1 = 0x135b5294...6667 (acvm_js/test/shared/foreign_call.ts)
     {
         Fr one_c = fr_zero(); one_c.v[0] = 1;
-        Fr inv5 = fr_mul(fr_inv(to_dev(frh::from_u64(5))), one_c);
+        Fr inv5 = fr_mul(fr_inv(to_dev(frh::from_u64(5))), one_c);  // out of Montgomery form: the canonical integer
         const uint32_t expect[8] = {0xc6666667u, 0xe7f3fbd4u, 0xca4a2d06u, 0xa9ae5ce9u, 0x33cd568bu, 0x49b9b57cu, 0x5a13d9aau, 0x135b5294u};
         for (int i = 0; i < 8; i++) if (inv5.v[i] != expect[i]) { fails++; printf("inv5 limb %d mismatch\n", i); }
     }

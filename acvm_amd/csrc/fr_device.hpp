@@ -299,6 +299,16 @@ FR_HD inline __noinline__ Fr fr_inv_eea(const Fr &a) {
 struct FrS30 {
     int32_t v[9];
 };
+// a * b + c with a, b signed 32-bit: one v_mad_i64_i32 (hipcc otherwise widens the product to a 64 x 64 multiplication)
+FR_HD __forceinline__ int64_t fr_mad_i64(int32_t a, int32_t b, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return r;
+#else
+    return (int64_t)a * b + c;
+#endif
+}
 FR_HD __forceinline__ int32_t fr_p30(int i) {
     constexpr int32_t P30[9] = {0x30000001, 0x0f87d64f, 0x1b970914, 0x0cfa121e, 0x01585d28, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x3064};
     return P30[i];
@@ -344,19 +354,19 @@ FR_HD inline __noinline__ Fr fr_inv(const Fr &a) {
         {
             const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
             int32_t md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
-            int64_t cd = (int64_t)tu * d.v[0] + (int64_t)tv * e.v[0];
-            int64_t ce = (int64_t)tq * d.v[0] + (int64_t)tr * e.v[0];
+            int64_t cd = fr_mad_i64(tu, d.v[0], fr_mad_i64(tv, e.v[0], 0));
+            int64_t ce = fr_mad_i64(tq, d.v[0], fr_mad_i64(tr, e.v[0], 0));
             md -= (int32_t)((PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
             me -= (int32_t)((PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
-            cd += (int64_t)fr_p30(0) * md;
-            ce += (int64_t)fr_p30(0) * me;
+            cd = fr_mad_i64(fr_p30(0), md, cd);
+            ce = fr_mad_i64(fr_p30(0), me, ce);
             cd >>= 30;
             ce >>= 30;
 #pragma unroll
             for (int i = 1; i < 9; i++) {
                 const int32_t di = d.v[i], ei = e.v[i];
-                cd += (int64_t)tu * di + (int64_t)tv * ei + (int64_t)fr_p30(i) * md;
-                ce += (int64_t)tq * di + (int64_t)tr * ei + (int64_t)fr_p30(i) * me;
+                cd = fr_mad_i64(tu, di, fr_mad_i64(tv, ei, fr_mad_i64(fr_p30(i), md, cd)));
+                ce = fr_mad_i64(tq, di, fr_mad_i64(tr, ei, fr_mad_i64(fr_p30(i), me, ce)));
                 d.v[i - 1] = (int32_t)cd & M30;
                 e.v[i - 1] = (int32_t)ce & M30;
                 cd >>= 30;
@@ -367,15 +377,15 @@ FR_HD inline __noinline__ Fr fr_inv(const Fr &a) {
         }
         // ---- [f, g] <- t [f, g] / 2^30 (exact)
         {
-            int64_t cf = (int64_t)tu * f.v[0] + (int64_t)tv * g.v[0];
-            int64_t cg = (int64_t)tq * f.v[0] + (int64_t)tr * g.v[0];
+            int64_t cf = fr_mad_i64(tu, f.v[0], fr_mad_i64(tv, g.v[0], 0));
+            int64_t cg = fr_mad_i64(tq, f.v[0], fr_mad_i64(tr, g.v[0], 0));
             cf >>= 30;
             cg >>= 30;
 #pragma unroll
             for (int i = 1; i < 9; i++) {
                 const int32_t fi = f.v[i], gi = g.v[i];
-                cf += (int64_t)tu * fi + (int64_t)tv * gi;
-                cg += (int64_t)tq * fi + (int64_t)tr * gi;
+                cf = fr_mad_i64(tu, fi, fr_mad_i64(tv, gi, cf));
+                cg = fr_mad_i64(tq, fi, fr_mad_i64(tr, gi, cg));
                 f.v[i - 1] = (int32_t)cf & M30;
                 g.v[i - 1] = (int32_t)cg & M30;
                 cf >>= 30;

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
     for (uint32_t i = 0; i < n_prod; i++, t += 3) {
         Fr a = fr_load(W, t[1], Bp, j);
         Fr b = fr_load(W, t[2], Bp, j);
-        acc = fr_add(acc, apply_coef(fr_mul(a, b), t[0], consts));
+        acc = fr_add(acc, apply_coef_prod(a, b, t[0], consts));
     }
     for (uint32_t i = 0; i < n_lin; i++, t += 2) {
         Fr a = fr_load(W, t[1], Bp, j);
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__
         Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
         const uint32_t *__restrict__ t = g + 5;
         for (uint32_t k = 0; k < n_prod; k++, t += 3)
-            acc = fr_add(acc, apply_coef(fr_mul(fr_load(W, t[1], Bp, j), fr_load(W, t[2], Bp, j)), t[0], consts));
+            acc = fr_add(acc, apply_coef_prod(fr_load(W, t[1], Bp, j), fr_load(W, t[2], Bp, j), t[0], consts));
         for (uint32_t k = 0; k < n_lin; k++, t += 2) acc = fr_add(acc, apply_coef(fr_load(W, t[1], Bp, j), t[0], consts));
         fr_store(W, out, Bp, j, fr_mul(acc, inv_i));
     }

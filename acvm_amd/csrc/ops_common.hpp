@@ -53,6 +53,14 @@ __device__ __forceinline__ Fr apply_coef(const Fr &x, uint32_t coef, const uint3
     if (coef == K_COEF_MINUS_ONE) return fr_neg(x);
     return fr_mul(x, fr_const(consts, coef));
 }
+// coef * (a * b) and coef * x without leaving the 29-bit working form between the two products: the intermediate is
+// neither reduced nor repacked (the product tolerates inputs < 8p)
+__device__ __forceinline__ Fr apply_coef_prod(const Fr &a, const Fr &b, uint32_t coef, const uint32_t *__restrict__ consts) {
+    const Fr29 t = fr29_mul(fr29_from(a), fr29_from(b));
+    if (coef == K_COEF_ONE) return fr29_pack(fr29_cond_sub_p(t));
+    if (coef == K_COEF_MINUS_ONE) return fr_neg(fr29_pack(fr29_cond_sub_p(t)));
+    return fr29_pack(fr29_cond_sub_p(fr29_mul(t, fr29_from(fr_const(consts, coef)))));
+}
 __device__ __forceinline__ Fr coef_value(uint32_t coef, const uint32_t *__restrict__ consts) {
     if (coef == K_COEF_ONE) return fr_one();
     if (coef == K_COEF_MINUS_ONE) return fr_neg(fr_one());

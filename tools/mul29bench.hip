@@ -1,5 +1,4 @@
 #include "../acvm_amd/csrc/fr_device.hpp"
-#include "../acvm_amd/csrc/fr_device.hpp"
 #include <cstdio>
 using namespace acvm;
 __global__ void __launch_bounds__(256) k29(uint32_t *out, uint32_t seed, int iters) {
@@ -25,7 +24,8 @@ int main() {
     uint32_t *out; const int blocks = 256 * 8 * 4, it = 500; hipMalloc(&out, (size_t)blocks * 256 * 4);
     float m29 = t([&] { k29<<<blocks, 256>>>(out, 1, it); }), m32 = t([&] { k32<<<blocks, 256>>>(out, 1, it); });
     double n = (double)blocks * 256 * it * 2;
+    // history: the 8 x 32 product-scanning form with v_addc carries measured 1164 cycles/wave here (round 1, before the switch)
     printf("fr29_mul (9x29, no carries) %8.3f ms %8.2f G modmul/s  %.0f cycles/wave\n", m29, n / m29 / 1e6, 1024 * 2.4e9 / (n / 64 / (m29 / 1e3)));
-    printf("fr_mul   (8x32, mad+addc)   %8.3f ms %8.2f G modmul/s  %.0f cycles/wave\n", m32, n / m32 / 1e6, 1024 * 2.4e9 / (n / 64 / (m32 / 1e3)));
+    printf("fr_mul   (storage form)     %8.3f ms %8.2f G modmul/s  %.0f cycles/wave\n", m32, n / m32 / 1e6, 1024 * 2.4e9 / (n / 64 / (m32 / 1e3)));
     return 0;
 }

@@ -1,0 +1,91 @@
+"""Full-size runs (BASELINE config 2: 10k gates x 2^16 instances) checked through size-independent properties, since the
+CPU oracle cannot solve 65 536 instances in a test: (1) every solved instance satisfies every opcode of the circuit,
+re-evaluated here with Python big integers (independent of oracle and kernels) on a random sample; (2) an instance solved
+inside the big batch is bit-identical to the same instance solved in a small batch (no cross-instance coupling, no
+dependence on the batch size); (3) solving twice gives the same witness table (determinism); (4) the instances that fail
+are exactly the edge-case inputs."""
+import random
+
+import numpy as np
+import pytest
+
+import acvm_amd
+from acvm_amd import synth
+from acvm_amd.acir import P
+
+pytestmark = pytest.mark.gpu
+
+
+def check_arithmetic_satisfied(circ, wmap):
+    for k, e in enumerate(circ.opcodes):
+        acc = e.q_c
+        for c, l, r in e.mul_terms:
+            acc += c * wmap[l] * wmap[r]
+        for c, w in e.linear_combinations:
+            acc += c * wmap[w]
+        assert acc % P == 0, f"opcode {k} not satisfied"
+
+
+def test_config2_full_size_properties():
+    B = 1 << 16
+    circ, ids = synth.arithmetic_circuit(10000, seed=0xAC1D0002)
+    data = circ.to_bytes()
+    values = synth.witness_batch(B, seed=0xAC1D0002)
+    batch = acvm_amd.Batch(acvm_amd.Circuit(data), B, ids)
+    batch.set_initial_witness(values)
+    n_bad = batch.solve()
+    res = batch.results()
+    failed = [j for j in range(B) if res[j].status != acvm_amd.STATUS_SOLVED]
+    assert n_bad == len(failed) and set(failed) <= set(range(8)), failed[:16]  # only the edge-case inputs may fail
+    r = random.Random(7)
+    sample = sorted(r.sample(range(8, B), 24) + [8, B - 1])
+    # (1) constraint satisfaction, independent big-integer evaluation
+    for j in sample[:12]:
+        asg, vals = batch.witness_map(j, 1)
+        assert asg[0, 1:].all()
+        wmap = {w: int.from_bytes(vals[0, w].tobytes(), "big") for w in range(asg.shape[1])}
+        for k, w in enumerate(ids):
+            assert wmap[w] == int.from_bytes(values[(j * len(ids) + k) * 32:(j * len(ids) + k + 1) * 32], "big") % P
+        check_arithmetic_satisfied(circ, wmap)
+    # (2) batch-size independence: the same instances solved as a batch of 26
+    small_vals = b"".join(values[j * len(ids) * 32:(j + 1) * len(ids) * 32] for j in sample)
+    small = acvm_amd.Batch(acvm_amd.Circuit(data), len(sample), ids)
+    small.set_initial_witness(small_vals)
+    assert small.solve() == 0
+    sasg, svals = small.witness_map()
+    for i, j in enumerate(sample):
+        asg, vals = batch.witness_map(j, 1)
+        assert np.array_equal(asg[0], sasg[i]) and np.array_equal(vals[0], svals[i]), j
+    # (3) determinism: a second solve leaves every return witness unchanged
+    ret = circ.return_values[0]
+    v1, a1 = batch.witness(ret)
+    batch.reset()
+    assert batch.solve() == n_bad
+    v2, a2 = batch.witness(ret)
+    assert np.array_equal(v1, v2) and np.array_equal(a1, a2)
+    small.free()
+    batch.free()
+
+
+def test_mixed_circuit_full_batch_properties():
+    """Config-5 opcode mix at batch 2^14: batch-size independence against a small batch (which tests/test_gpu_opcodes.py
+    pins against the oracle) and determinism."""
+    B = 1 << 14
+    circ, ids = synth.mixed_circuit(2500)
+    data = circ.to_bytes()
+    values = synth.witness_batch(B, seed=0xAC1D0005)
+    batch = acvm_amd.Batch(acvm_amd.Circuit(data), B, ids)
+    batch.set_initial_witness(values)
+    n_bad = batch.solve()
+    assert n_bad <= 8
+    sample = [0, 3, 9, 100, 4097, B - 1]
+    small = acvm_amd.Batch(acvm_amd.Circuit(data), len(sample), ids)
+    small.set_initial_witness(b"".join(values[j * len(ids) * 32:(j + 1) * len(ids) * 32] for j in sample))
+    small.solve()
+    sres = small.results()
+    res = batch.results()
+    sasg, svals = small.witness_map()
+    for i, j in enumerate(sample):
+        assert res[j].as_tuple() == sres[i].as_tuple(), j
+        asg, vals = batch.witness_map(j, 1)
+        assert np.array_equal(asg[0], sasg[i]) and np.array_equal(vals[0], svals[i]), j

@@ -932,12 +932,25 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
         else if (sr.x0 == 101) snprintf(r.message, sizeof r.message, "Message overran wasm scratch space");
         else if (sr.x0 == 102) snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode (expected 1 result)");
         else if (sr.x0 == 103) snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode size");
+        else if (sr.x0 > 110 && sr.x0 < 117) {
+            static const char *et[7] = {"", "ecdsa: signature scalars must be in [1, n-1] (Signature::try_from unwrap)",
+                                        "ecdsa: public key x is not on the curve (PublicKey::from_encoded_point unwrap)",
+                                        "ecdsa: hashed message must be 32 bytes (GenericArray::from_slice)",
+                                        "ecdsa: hashed message is not below the group order (Scalar::from_repr unwrap)",
+                                        "ecdsa: R is the identity (unreachable!)", "ecdsa: R.x is not below the group order (Scalar::from_repr unwrap)"};
+            snprintf(r.message, sizeof r.message, "%s", et[sr.x0 - 110]);
+        }
         else snprintf(r.message, sizeof r.message, "%s", sr.x0 < 17 ? texts[sr.x0] : "brillig vm panic");
         break;
     }
     case 17: snprintf(r.message, sizeof r.message, "brillig memory write at %u beyond the device capacity (set ACVM_BRILLIG_MEM_CELLS)", sr.x0); break;
     case 18: snprintf(r.message, sizeof r.message, "brillig step limit reached on the device"); break;
-    case 19: snprintf(r.message, sizeof r.message, "failed to solve blackbox function inside brillig (code %u)", sr.x0); break;
+    case 19: {
+        static const char *what[3] = {"Invalid public key x length", "Invalid public key y length", "Invalid signature length"};
+        snprintf(r.message, sizeof r.message, "failed to solve blackbox function: %s, reason: %s", sr.x0 / 4 ? "ecdsa_secp256r1" : "ecdsa_secp256k1",
+                 what[sr.x0 % 4 < 3 ? sr.x0 % 4 : 0]);
+        break;
+    }
     case 20: snprintf(r.message, sizeof r.message, "failed to solve blackbox function: pedersen, reason: Invalid signature length"); break;
     case 21: snprintf(r.message, sizeof r.message, "%u output values were provided as a foreign call result for %u destination slots", sr.x0, sr.val[0]); break;
     case 22: snprintf(r.message, sizeof r.message, "Function result size does not match brillig bytecode"); break;

@@ -9,6 +9,7 @@
 // ACVM_BRILLIG_MEM_CELLS) and a step limit (2^22 instructions), so that a runaway program cannot hang the GPU.
 #pragma once
 #include "kernels.hpp"
+#include "ops_ecdsa.hpp"
 #include "ops_grumpkin.hpp"
 #include "ops_light.hpp"
 
@@ -225,6 +226,22 @@ static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t 
         if (vm.status || !vm.to_usize(ov, optr)) return;
         for (uint32_t i = 0; i < 32u; i++)
             if (!vm.mem_write(optr + i, fr_from_byte(d.byte(i)))) return;
+        return;
+    }
+    case 4: case 5: {  // EcdsaSecp256k1 / r1 (black_box.rs:74-131): hashed_msg (ptr, size), pkx / pky / signature (ptr, literal), result
+        uint64_t ap[3] = {0, 0, 0};
+        for (int g = 0; g < 3; g++) {
+            const Fr pv = vm.reg_get(w[2 + 2 * g]);
+            if (vm.status || !vm.to_usize(pv, ap[g]) || !vm.mem_check_read(ap[g], w[3 + 2 * g])) return;
+            if (w[3 + 2 * g] != (g == 2 ? 64u : 32u)) { vm.status = 2; vm.code = DM_BRILLIG_BB_FAILED; vm.x0 = (bbop - 4u) * 4u + (uint32_t)g; return; }
+        }
+        if (!heap_vector(w[0], w[1], ptr, len) || !vm.mem_check_read(ptr, len)) return;
+        uint32_t panic = 0;
+        const uint32_t ok = ecdsa_verify(
+            bbop - 4u, [&](uint32_t i) { return mem_byte(ap[0], i); }, [&](uint32_t i) { return mem_byte(ap[1], i); },
+            [&](uint32_t i) { return mem_byte(ap[2], i); }, (uint32_t)len, [&](uint32_t i) { return mem_byte(ptr, i); }, &panic);
+        if (panic) { vm.status = 4; vm.code = 110u + panic; return; }
+        vm.reg_set(w[8], ok ? fr_one() : fr_zero());
         return;
     }
     case 6: {  // SchnorrVerify: pkx, pky, message (ptr, size), signature (ptr, size), result
@@ -519,7 +536,7 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
 #pragma unroll
             for (int k = 0; k < 8; k++) res->val[k] = vm.val.v[k];
         }
-        return op_fail_msg(DE_BRILLIG_FAILED, 0, vm.code, vm.x0);
+        return op_fail_msg(DE_BRILLIG_FAILED, 0, vm.code, vm.x0, vm.val.v[0]);
     }
     if (vm.status == 3) return op_fail_msg(DE_WAIT_FOREIGN_CALL, 0, 0, vm.pc);
     if (vm.status == 5) return op_fail_msg(DE_PANIC, 0, vm.code, vm.x0);

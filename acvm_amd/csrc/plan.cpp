@@ -314,7 +314,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     case BR_BLACK_BOX: {
                         // operands go to an extra block behind the instruction array (patched below)
                         w[4] = op.bbop;
-                        if (op.bbop == 4 || op.bbop == 5) unsupported(oi, "Brillig ECDSA black box");
                         if (op.bbop >= 6) has_grumpkin = true;
                         max_hash_hint = 1;
                         break;
@@ -331,10 +330,11 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     // operand layout mirrors brillig/src/black_box.rs:7-53: HeapVector = (pointer reg, size reg),
                     // HeapArray = (pointer reg, literal size), RegisterIndex = reg. n_reg_words = leading register words.
                     static const int nwords[9] = {4, 4, 4, 3, 9, 9, 7, 5, 4};
-                    static const int n_reg_words[9] = {3, 3, 3, 3, 0, 0, 7, 4, 3};
+                    // bit i set: operand word i is a register (else a literal array size)
+                    static const uint32_t reg_mask[9] = {0x7, 0x7, 0x7, 0x7, 0x157, 0x157, 0x7f, 0xf, 0x7};
                     p.bytecode[bc_off + 8 * k + 7] = (uint32_t)p.bytecode.size();
                     for (int i = 0; i < nwords[op.bbop]; i++)
-                        p.bytecode.push_back(i < n_reg_words[op.bbop] ? reg(op.bb[i]) : (uint32_t)std::min<uint64_t>(op.bb[i], 0xFFFFFFFFull));
+                        p.bytecode.push_back((reg_mask[op.bbop] >> i) & 1 ? reg(op.bb[i]) : (uint32_t)std::min<uint64_t>(op.bb[i], 0xFFFFFFFFull));
                 }
                 // ForeignCall operands: [n_dests, n_inputs, (kind, reg, size) x n_dests, (kind, reg, size) x n_inputs];
                 // kind 0 register, 1 HeapArray (size literal), 2 HeapVector (size register)

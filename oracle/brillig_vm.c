@@ -292,9 +292,31 @@ static int vm_black_box(vm_t *vm, const brillig_op_t *o) {
         reg_set(vm, o->bb[2], &f);
         return 0;
     }
-    case BBOP_ECDSA_K1: case BBOP_ECDSA_R1:
-        vm_panic(vm, "oracle: ecdsa not restated");
+    case BBOP_ECDSA_K1: case BBOP_ECDSA_R1: { /* black_box.rs:74-131: hashed_msg vector, pkx / pky / signature arrays, result */
+        const char *fname = o->bbop == BBOP_ECDSA_K1 ? "ecdsa_secp256k1" : "ecdsa_secp256r1";
+        static const char *what[3] = {"Invalid public key x length", "Invalid public key y length", "Invalid signature length"};
+        static const uint64_t want[3] = {32, 32, 64};
+        uint8_t *arr[3] = {0, 0, 0};
+        for (int g = 0; g < 3; g++) {
+            uint64_t ap;
+            if (reg_usize(vm, o->bb[2 + 2 * g], &ap) || read_u8_vec(vm, ap, o->bb[3 + 2 * g], &arr[g])) { for (int k = 0; k < g; k++) free(arr[k]); return 0; }
+            if (o->bb[3 + 2 * g] != want[g]) {
+                snprintf(vm->msg, sizeof vm->msg, "failed to solve blackbox function: %s, reason: %s", fname, what[g]);
+                for (int k = 0; k <= g; k++) free(arr[k]);
+                return 1;
+            }
+        }
+        uint8_t *m;
+        if (heap_vector(vm, o->bb[0], o->bb[1], &ptr, &len) || read_u8_vec(vm, ptr, len, &m)) { for (int k = 0; k < 3; k++) free(arr[k]); return 0; }
+        int v = oracle_ecdsa_verify(o->bbop == BBOP_ECDSA_R1, m, len, arr[0], arr[1], arr[2]);
+        free(m);
+        for (int k = 0; k < 3; k++) free(arr[k]);
+        if (v < 0) { vm_panic(vm, oracle_ecdsa_panic_text(v)); return 0; }
+        fr_t r;
+        fr_from_u64(&r, (uint64_t)v);
+        reg_set(vm, o->bb[8], &r);
         return 0;
+    }
     case BBOP_SCHNORR: {
         fr_t pkx = reg_get(vm, o->bb[0]), pky = reg_get(vm, o->bb[1]);
         uint8_t *msg, *sig;

@@ -176,3 +176,32 @@ def test_grumpkin_black_box_ops(oracle):
     bad[20] ^= 1
     ores, _ = run_both(oracle, Circuit(90, [sch]), ids, [good, bad, good, bad])
     run_both(oracle, Circuit(90, [sch]), ids, [good, bad], force_slow=True)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ecdsa_black_box_ops(oracle, curve):
+    """BlackBoxOp::EcdsaSecp256k1 / r1 (brillig_vm/src/black_box.rs:74-131): digest vector + three arrays in VM memory."""
+    from ecdsa_ref import CURVES, public_key, sign
+    r = random.Random(60 + curve)
+    c = CURVES[curve]
+    be = lambda v: list(int(v).to_bytes(32, "big"))  # noqa: E731
+    name = "EcdsaSecp256k1" if curve == 0 else "EcdsaSecp256r1"
+    ids = list(range(1, 161))  # msg 32 | pkx 32 | pky 32 | sig 64
+    inputs = [[W(w) for w in ids[:32]], [W(w) for w in ids[32:64]], [W(w) for w in ids[64:96]], [W(w) for w in ids[96:160]]]
+    # registers after the inputs: r0..r3 = array pointers; r4 = 32 (message length)
+    bc = [("Const", 4, 32), ("BlackBox", name, 0, 4, 1, 32, 2, 32, 3, 64, 5), ("Mov", 0, 5), ("Stop",)]
+    circ = Circuit(170, [Brillig(inputs=inputs, outputs=[165], bytecode=bc)])
+    rows = []
+    for i in range(6):
+        sk, k, z = r.randrange(1, c["n"]), r.randrange(1, c["n"]), r.randrange(c["n"])
+        Q = public_key(curve, sk)
+        rr, ss = sign(curve, sk, k, z)
+        rows.append(be(z) + be(Q[0]) + be(Q[1]) + be(rr) + be(ss))
+        rows.append(be(z ^ 2) + be(Q[0]) + be(Q[1]) + be(rr) + be(ss))
+    rows.append(be(5) + be(c["p"]) + be(1) + be(1) + be(1))  # x >= p: the reference panics
+    ores, _ = both_paths(oracle, circ, ids, rows)
+    assert ores[0].status == 0 and ores[12].err == oracle.E_PANIC
+    # wrong array size -> BlackBoxResolutionError::Failed -> BrilligFunctionFailed
+    bad = [("Const", 4, 32), ("BlackBox", name, 0, 4, 1, 31, 2, 32, 3, 64, 5), ("Mov", 0, 5), ("Stop",)]
+    ores, _ = both_paths(oracle, Circuit(170, [Brillig(inputs=inputs, outputs=[165], bytecode=bad)]), ids, rows[:2])
+    assert ores[0].err == oracle.E_BRILLIG_FAILED

@@ -1,13 +1,16 @@
 // kernels_hash.hip -- SHA256 / Blake2s / Keccak256(+variable length) / HashToField128Security opcodes
-// (acvm/src/pwg/blackbox/hash.rs; device routines in ops_hash.hpp), level kernel + exact kernel.
+// (acvm/src/pwg/blackbox/hash.rs; device routines in ops_hash.hpp), level kernel + exact kernel. The same scratch-carrying
+// kernels also run Directive::PermutationSort (ops_sort.hpp), the other opcode that needs per-lane working memory.
 #include "ops_hash.hpp"
+#include "ops_sort.hpp"
 #include "ops_kernel.hpp"
 
 namespace acvm {
 
 struct HashOp {
     template <class P>
-    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &, uint32_t *scratch, SlowResult *, const ExactLanes *, uint32_t) {
+    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *scratch, SlowResult *, const ExactLanes *, uint32_t) {
+        if (rec[0] == K_PERM_SORT) return op_perm_sort(p, rec, dp.consts, scratch);
         return op_hash(p, rec, scratch);
     }
 };

@@ -253,8 +253,21 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     for (uint32_t w : d.bw) out(w);
                     emit_expr(s, pool, d.a);
                 } else {
-                    unsupported(oi, "Directive::PermutationSort");
-                    s.insert(s.end(), {0xFFFFFFFFu, oi});
+                    // [PK_PERM_SORT, oi, n, tuple, n_sort_by, n_bits, sort_by..., (bit witness, flag)..., E x (n * tuple)]
+                    // (runs in the scratch-carrying hash class kernel; see ops_sort.hpp for the scratch map)
+                    const uint32_t n = (uint32_t)d.sort_inputs.size();
+                    bool shape_ok = n < (1u << 16);
+                    for (auto &el : d.sort_inputs) shape_ok &= el.size() == d.tuple;
+                    if (!shape_ok) unsupported(oi, "Directive::PermutationSort with a malformed tuple shape");
+                    p.prog_class[oi] = CLS_HASH;
+                    uint32_t lg = 0;
+                    while ((1u << lg) < n) lg++;
+                    p.prog_scratch[oi] = 8 * n * d.tuple + 4 * n + n * (lg + 1) + 1 + 3 * 72 + (4 * n + 8) * (lg + 2) + 64;
+                    s.insert(s.end(), {PK_PERM_SORT, oi, n, d.tuple, (uint32_t)d.sort_by.size(), (uint32_t)d.bw.size()});
+                    s.insert(s.end(), d.sort_by.begin(), d.sort_by.end());
+                    for (uint32_t w : d.bw) out(w);
+                    for (auto &el : d.sort_inputs)
+                        for (auto &ex : el) emit_expr(s, pool, ex);
                 }
                 break;
             }
@@ -450,6 +463,11 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
             case OP_DIRECTIVE: {
                 const Directive &d = *o.dir;
+                if (d.kind == DIR_PERMUTATION_SORT) {
+                    for (auto &el : d.sort_inputs)
+                        for (auto &ex : el) rd.expr(ex);
+                    break;
+                }
                 rd.expr(d.a);
                 if (d.kind == DIR_QUOTIENT) { rd.expr(d.b); if (d.has_predicate) rd.expr(d.predicate); }
                 break;

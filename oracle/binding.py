@@ -83,6 +83,8 @@ def lib():
         L.oracle_fixed_base.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.oracle_schnorr_verify.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.oracle_schnorr_sign.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p]
+        L.oracle_sorting_route.restype = C.c_size_t
+        L.oracle_sorting_route.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_ecdsa_verify.restype = C.c_int
         L.oracle_ecdsa_verify.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p]
         assert L.oracle_result_size() == C.sizeof(Result)

@@ -469,10 +469,7 @@ static int solve_directive(oracle_acvm_t *a, const directive_t *d) {
         }
         return 0;
     }
-    /* PermutationSort (directives/sorting.rs) is sequential pointer-chasing kept on the CPU by SURVEY 7;
-     * not restated in this round. */
-    pwg_fail(a, E_PANIC, 0, 0, "PermutationSort not restated in oracle");
-    return 1;
+    return oracle_solve_permutation_sort(a, d); /* sorting.c */
 }
 
 /* ------------------------------------------------------------------ memory (memory_op.rs) */

@@ -97,6 +97,9 @@ void pwg_fail(oracle_acvm_t *a, uint32_t err, uint32_t aux0, uint32_t aux1, cons
 /* ecdsa.c: 0 / 1, or a negative panic code (see oracle_ecdsa_panic_text); curve 0 = secp256k1, 1 = secp256r1 */
 int oracle_ecdsa_verify(int curve, const uint8_t *hashed_msg, size_t msg_len, const uint8_t pkx[32], const uint8_t pky[32], const uint8_t sig[64]);
 const char *oracle_ecdsa_panic_text(int code);
+/* sorting.c: Directive::PermutationSort */
+int oracle_solve_permutation_sort(oracle_acvm_t *a, const directive_t *d);
+size_t oracle_sorting_route(const uint32_t *inputs, const uint32_t *outputs, uint32_t n, uint8_t *bits);
 /* brillig_vm.c */
 int brillig_solve(oracle_acvm_t *a, const brillig_t *b, size_t acir_index); /* 0 ok, 1 err (res set), 2 foreign call wait */
 

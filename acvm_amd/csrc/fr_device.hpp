@@ -190,6 +190,84 @@ FR_HD __forceinline__ Fr29 fr29_cond_sub_p(const Fr29 &a) {
     return r;
 }
 
+// ---- lazy arithmetic on the working form (the Grumpkin point formulas): values are non-negative integers below a small
+// multiple of p, limbs may exceed 29 bits between fr29_norm calls. A product needs normalised limbs and values < 16p.
+// k * p with every limb below the top raised by 2^29 (and the borrow taken from the next one), so that limb-wise
+// a + kp - b never goes negative below the top limb for a normalised b; the top limb may wrap, which cancels in fr29_norm.
+FR_HD __forceinline__ uint32_t fr_kp29_sub(int klog2, int i) {
+    constexpr uint32_t C[4][9] = {
+        {0x20000002u, 0x3e1f593eu, 0x3cb848a0u, 0x2fa121e5u, 0x2b0ba505u, 0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu},   // 2p
+        {0x20000004u, 0x3c3eb27du, 0x39709142u, 0x3f4243ccu, 0x36174a0bu, 0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u},   // 4p
+        {0x20000008u, 0x387d64fbu, 0x32e12286u, 0x3e84879au, 0x2c2e9418u, 0x36da0604u, 0x25370a07u, 0x32e1319fu, 0x01832272u},   // 8p
+        {0x20000010u, 0x30fac9f7u, 0x25c2450eu, 0x3d090f36u, 0x385d2832u, 0x2db40c09u, 0x2a6e1410u, 0x25c2633fu, 0x030644e6u}};  // 16p
+    return C[klog2 - 1][i];
+}
+FR_HD __forceinline__ uint32_t fr_kp29(int klog2, int i) {  // k * p, normalised limbs
+    constexpr uint32_t C[4][9] = {
+        {0x00000002u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu},
+        {0x00000004u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u},
+        {0x00000008u, 0x187d64fcu, 0x12e12287u, 0x1e84879bu, 0x0c2e9419u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u},
+        {0x00000010u, 0x10fac9f8u, 0x05c2450fu, 0x1d090f37u, 0x185d2833u, 0x0db40c0au, 0x0a6e1411u, 0x05c26340u, 0x030644e7u}};
+    return C[klog2 - 1][i];
+}
+FR_HD __forceinline__ Fr29 fr29_norm(const Fr29 &a) {  // carry propagation: limbs < 2^29 below the top one
+    Fr29 r = a;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i + 1] += r.v[i] >> 29;
+        r.v[i] &= 0x1fffffffu;
+    }
+    return r;
+}
+FR_HD __forceinline__ Fr29 fr29_addl(const Fr29 &a, const Fr29 &b) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+FR_HD __forceinline__ Fr29 fr29_dbll(const Fr29 &a) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] << 1;
+    return r;
+}
+// a + (2^klog2) p - b; b must be normalised and value(b) <= 2^klog2 p
+FR_HD __forceinline__ Fr29 fr29_subl(const Fr29 &a, const Fr29 &b, int klog2) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + fr_kp29_sub(klog2, i) - b.v[i];
+    return r;
+}
+// normalised a: a - (2^klog2) p if that is non-negative, else a
+FR_HD __forceinline__ Fr29 fr29_csub(const Fr29 &a, int klog2) {
+    Fr29 d;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t t = (int32_t)a.v[i] - (int32_t)(klog2 ? fr_kp29(klog2, i) : fr_p29(i)) + borrow;
+        d.v[i] = i < 8 ? ((uint32_t)t & 0x1fffffffu) : (uint32_t)t;
+        borrow = i < 8 ? (t >> 29) : (t >> 31);
+    }
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+// normalised value < 8p -> < 2p
+FR_HD __forceinline__ Fr29 fr29_lt2p(const Fr29 &a) { return fr29_csub(fr29_csub(a, 2), 1); }
+// normalised value < 8p -> canonical [0, p)
+FR_HD __forceinline__ Fr29 fr29_canon(const Fr29 &a) { return fr29_csub(fr29_lt2p(a), 0); }
+// normalised value < 2p: is it 0 mod p
+FR_HD __forceinline__ bool fr29_is_zero_mod_p(const Fr29 &a) {
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        z |= a.v[i];
+        e |= a.v[i] ^ fr_p29(i);
+    }
+    return z == 0u || e == 0u;
+}
+
 // Montgomery product on the storage form, fully reduced
 FR_HD __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) { return fr29_pack(fr29_cond_sub_p(fr29_mul(fr29_from(a), fr29_from(b)))); }
 

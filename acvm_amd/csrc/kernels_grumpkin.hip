@@ -32,7 +32,7 @@ void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DevicePro
 // the affine results are identical).
 __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
                                                                   uint32_t *__restrict__ event) {
-    __shared__ uint32_t lds_acc[4][24][64];  // [wave][limb of X, Y, Z][lane]
+    __shared__ uint32_t lds_acc[4][27][64];  // [wave][limb of X, Y, Z (9 x 29-bit each)][lane]
     __shared__ uint32_t lds_r[16][64];       // affine result of the step (Montgomery limbs of x, y)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
@@ -65,12 +65,12 @@ __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint
             const uint32_t pos = 18u * i + (odd ? 9u : 0u);
             acc = gj_add_aff(acc, gaff_load(T.ped, (gen0 + i) * GRUMPKIN_PED_ENTRIES + bits_at(v, pos, 9)));
         }
-        if (!odd) acc.X = fr_mul(acc.X, grumpkin_beta());  // endomorphism on the even-slice accumulator
+        if (!odd) acc.X = fr29_mul(acc.X, fr29_from(grumpkin_beta()));  // endomorphism on the even-slice accumulator
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 9; k++) {
             lds_acc[wave][k][lane] = acc.X.v[k];
-            lds_acc[wave][8 + k][lane] = acc.Y.v[k];
-            lds_acc[wave][16 + k][lane] = acc.Z.v[k];
+            lds_acc[wave][9 + k][lane] = acc.Y.v[k];
+            lds_acc[wave][18 + k][lane] = acc.Z.v[k];
         }
         __syncthreads();
         if (wave == 0) {
@@ -78,10 +78,10 @@ __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint
             for (uint32_t w2 = 1; w2 < 4; w2++) {
                 GJac o;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < 9; k++) {
                     o.X.v[k] = lds_acc[w2][k][lane];
-                    o.Y.v[k] = lds_acc[w2][8 + k][lane];
-                    o.Z.v[k] = lds_acc[w2][16 + k][lane];
+                    o.Y.v[k] = lds_acc[w2][9 + k][lane];
+                    o.Z.v[k] = lds_acc[w2][18 + k][lane];
                 }
                 s = gj_add(s, o);
             }

@@ -62,6 +62,22 @@ int main() {
             if (!same(inv, frh::inverse(a))) { fails++; printf("inv mismatch %d\n", it); }
             if (!same(fr_inv_eea(da), frh::inverse(a))) { fails++; printf("inv_eea mismatch %d\n", it); }
         }
+        {   // lazy working-form arithmetic at the edges of its contracts: x = a + a (< 2p), y = b + b
+            Fr29 x = fr29_norm(fr29_dbll(fr29_from(da))), y = fr29_norm(fr29_dbll(fr29_from(db)));
+            const FrH a2 = frh::add(a, a), b2 = frh::add(b, b);
+            // 8 (x * y) + 4p - y, reduced two ways
+            Fr29 m = fr29_mul(x, y);
+            Fr29 t = fr29_norm(fr29_subl(fr29_norm(fr29_dbll(fr29_dbll(fr29_dbll(m)))), y, 1));   // < 8 * 1.1 + 2 = 10.8p, limbs renormalised before the subtraction
+            Fr29 u = fr29_mul(t, x);                                                      // inputs < 16p
+            FrH want = frh::mul(frh::sub(frh::mul(frh::from_u64(8), frh::mul(a2, b2)), b2), a2);
+            if (!same(fr29_pack(fr29_canon(u)), want)) { fails++; printf("lazy chain mismatch %d\n", it); }
+            // subtraction below zero and back: (x - y + 2p) - x + 4p == 2p... == -y mod p
+            Fr29 d1 = fr29_norm(fr29_subl(x, y, 1));
+            Fr29 d2 = fr29_norm(fr29_subl(d1, x, 2));
+            if (!same(fr29_pack(fr29_canon(d2)), frh::neg(b2))) { fails++; printf("lazy sub mismatch %d\n", it); }
+            if (fr29_is_zero_mod_p(fr29_lt2p(fr29_norm(fr29_subl(x, x, 1)))) != true) { fails++; printf("zero test mismatch %d\n", it); }
+            if (fr29_is_zero_mod_p(fr29_mul(x, y)) != (a.is_zero() || b.is_zero())) { fails++; printf("zero test 2 mismatch %d\n", it); }
+        }
         if (fr_is_zero(da) != a.is_zero()) { fails++; printf("is_zero mismatch %d\n", it); }
     }
     // 5^-1 = 0x135b5294...6667 (acvm_js/test/shared/foreign_call.ts)

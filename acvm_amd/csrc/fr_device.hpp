@@ -268,6 +268,46 @@ FR_HD __forceinline__ bool fr29_is_zero_mod_p(const Fr29 &a) {
     return z == 0u || e == 0u;
 }
 
+// ---- sums of up to three products with ONE reduction: (sum_t a_t * b_t) * 2^-261 mod p. The arithmetic gate sum
+// q_m a b + sum q_i w_i + q_c (pwg/arithmetic.rs:27-127) pays one Montgomery reduction (half of a product's 162
+// multiply-adds) per three terms instead of one per term. Same column scan as fr29_mul: column k of sum a_t b_t + m p is
+// summed in one 64-bit accumulator ((N + 1) * 9 products < 2^58 plus a carry: N <= 6 would still fit). Operands: normalised
+// limbs, values < 4p. Output: normalised limbs, value < p + N * 1.06p * 4p / 2^261 < 1.04p.
+template <int N>
+FR_HD __forceinline__ Fr29 fr29_dot(const Fr29 (&a)[N], const Fr29 (&b)[N]) {
+    static_assert(N >= 1 && N <= 6, "column accumulator budget");
+    constexpr uint32_t M = 0x1fffffffu;
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fr29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int t = 0; t < N; t++)
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc += (uint64_t)a[t].v[i] * b[t].v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        const uint32_t lo = (uint32_t)acc;
+        m[k] = (((lo & 1u) << 28) - lo) & M;
+        acc += ((uint64_t)m[k] << 28) + m[k];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int t = 0; t < N; t++)
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (uint64_t)a[t].v[i] * b[t].v[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        r.v[k - 9] = (uint32_t)acc & M;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
 // Montgomery product on the storage form, fully reduced
 FR_HD __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) { return fr29_pack(fr29_cond_sub_p(fr29_mul(fr29_from(a), fr29_from(b)))); }
 

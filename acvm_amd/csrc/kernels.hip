@@ -76,24 +76,15 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
     const uint32_t *__restrict__ g = gate_stream + gate_offset[blockIdx.y];
-    const uint32_t w0 = g[0];
-    const uint32_t kind = w0 & 0xff, n_prod = (w0 >> 8) & 0xff, n_lin = (w0 >> 16) & 0xff;
-    const uint32_t opcode = g[1], out = g[2], qc = g[3];
-    Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
-    const uint32_t *__restrict__ t = g + 5;
-    for (uint32_t i = 0; i < n_prod; i++, t += 3) {
-        Fr a = fr_load(W, t[1], Bp, j);
-        Fr b = fr_load(W, t[2], Bp, j);
-        acc = fr_add(acc, apply_coef_prod(a, b, t[0], consts));
-    }
-    for (uint32_t i = 0; i < n_lin; i++, t += 2) {
-        Fr a = fr_load(W, t[1], Bp, j);
-        acc = fr_add(acc, apply_coef(a, t[0], consts));
-    }
+    const uint32_t kind = g[0] & 0xff, opcode = g[1], out = g[2];
+    const Fr29 acc = gate_sum_canon(gate_sum_lazy(W, Bp, j, g, consts));
     if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
-        if (!fr_is_zero(acc)) atomicMin(&event[j], opcode);
+        uint32_t z = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) z |= acc.v[i];
+        if (z) atomicMin(&event[j], opcode);
     } else {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
-        fr_store(W, out, Bp, j, acc);
+        fr_store(W, out, Bp, j, fr29_pack(acc));
     }
 }
 
@@ -103,7 +94,7 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
 // 4 multiplications per gate. The prefix products are parked in a device scratch table laid out like W
 // ([gate in level][half][instance], 16 B per lane, coalesced); it stays L2/Infinity-Cache resident (<= 80 MB)
 // and, unlike an LDS stage, does not cap the number of resident waves of this latency-bound kernel.
-static constexpr int DYN_CHUNK = 16;
+static constexpr uint32_t DYN_CHUNK = 32;  // measured on config 2: 8 -> 17.9 ms, 16 -> 17.5, 32 -> 17.1, 64 -> 17.3 per solve
 __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
                                                              const uint32_t *__restrict__ gate_stream,
                                                              const uint32_t *__restrict__ dyn_offset, uint32_t n_dyn,
@@ -116,8 +107,10 @@ __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__
     const uint64_t j = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= B) return;
     const uint32_t first = blockIdx.y * DYN_CHUNK;
-    const uint32_t n = n_dyn - first < (uint32_t)DYN_CHUNK ? n_dyn - first : (uint32_t)DYN_CHUNK;
-    Fr prefix = fr_one();
+    const uint32_t n = n_dyn - first < DYN_CHUNK ? n_dyn - first : DYN_CHUNK;
+    // prefix products and the running inverse stay in the 29-bit working form (values < 1.06p, never repacked between
+    // products); only the parked prefixes and the result are packed
+    Fr29 prefix = fr29_from(fr_one());
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t *__restrict__ g = gate_stream + dyn_offset[first + i];
         Fr den = fr_load(W, g[4], Bp, j);
@@ -125,27 +118,20 @@ __global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__
             atomicMin(&event[j], g[1]);
             den = fr_one();
         }
-        prefix = fr_mul(prefix, den);
-        fr_store(scratch, first + i, Bp, j, prefix);
+        prefix = fr29_mul(prefix, fr29_from(den));
+        fr_store(scratch, first + i, Bp, j, fr29_pack(prefix));
     }
-    Fr inv = fr_inv(prefix);  // 1 / (den_0 ... den_{n-1})
+    Fr29 inv = fr29_from(fr_inv(fr29_pack(fr29_cond_sub_p(prefix))));  // 1 / (den_0 ... den_{n-1})
     for (uint32_t i = n; i-- > 0;) {
         const uint32_t *__restrict__ g = gate_stream + dyn_offset[first + i];
-        const uint32_t w0 = g[0];
-        const uint32_t n_prod = (w0 >> 8) & 0xff, n_lin = (w0 >> 16) & 0xff, out = g[2], qc = g[3];
+        const uint32_t out = g[2];
         Fr den = fr_load(W, g[4], Bp, j);
         if (fr_is_zero(den)) den = fr_one();
-        Fr inv_i = inv;
-        if (i > 0) {
-            inv_i = fr_mul(inv, fr_load(scratch, first + i - 1, Bp, j));
-        }
-        inv = fr_mul(inv, den);
-        Fr acc = qc == K_COEF_ZERO ? fr_zero() : fr_const(consts, qc);
-        const uint32_t *__restrict__ t = g + 5;
-        for (uint32_t k = 0; k < n_prod; k++, t += 3)
-            acc = fr_add(acc, apply_coef_prod(fr_load(W, t[1], Bp, j), fr_load(W, t[2], Bp, j), t[0], consts));
-        for (uint32_t k = 0; k < n_lin; k++, t += 2) acc = fr_add(acc, apply_coef(fr_load(W, t[1], Bp, j), t[0], consts));
-        fr_store(W, out, Bp, j, fr_mul(acc, inv_i));
+        Fr29 inv_i = inv;
+        if (i > 0) inv_i = fr29_mul(inv, fr29_from(fr_load(scratch, first + i - 1, Bp, j)));
+        inv = fr29_mul(inv, fr29_from(den));
+        const GateSum num = gate_sum_lazy(W, Bp, j, g, consts);  // < 16p: a valid product operand as it is
+        fr_store(W, out, Bp, j, fr29_pack(fr29_cond_sub_p(fr29_mul(num.v, inv_i))));
     }
 }
 

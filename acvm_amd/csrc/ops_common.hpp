@@ -61,6 +61,120 @@ __device__ __forceinline__ Fr apply_coef_prod(const Fr &a, const Fr &b, uint32_t
     if (coef == K_COEF_MINUS_ONE) return fr_neg(fr29_pack(fr29_cond_sub_p(t)));
     return fr29_pack(fr29_cond_sub_p(fr29_mul(t, fr29_from(fr_const(consts, coef)))));
 }
+// ---- the folded gate sum of the level kernels: sum q_i a_i b_i + sum q_j w_j + q_c (gate record of plan.cpp). Terms with a
+// general coefficient are multiplied three at a time with ONE Montgomery reduction (fr29_dot); terms with coefficient +-1
+// and the constant skip the multiplier altogether: the planner lists them apart. Everything is summed limb-wise into the
+// lazy side sum h, whose bound is tracked in units of p/16 (wave-uniform, from the record's counts): a canonical witness or
+// constant weighs 16, a product or a reduced dot product 17 (< 1.06p), a subtracted term 33 (it is added as 2p - x <= 2p).
+// h's limbs stay below weight * 2^25 < 2^32; past GATE_H_MAX it is brought back below 2p.
+static constexpr uint32_t GATE_H_MAX = 111;
+struct GateSum {
+    Fr29 v;          // normalised limbs
+    uint32_t bound;  // value < bound * p / 16 (wave-uniform)
+};
+__device__ __forceinline__ Fr29 gate_load29(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, uint32_t slot) {
+    return fr29_from(fr_load(W, slot, Bp, j));
+}
+__device__ __forceinline__ void gate_h_room(Fr29 &h, uint32_t &hw, uint32_t weight) {
+    if (hw + weight > GATE_H_MAX) {  // rare: many terms in one gate
+        h = fr29_lt2p(fr29_norm(h));
+        hw = 32;
+    }
+    hw += weight;
+}
+__device__ __forceinline__ void gate_h_sub(Fr29 &h, const Fr29 &x) {  // h += 2p - x; x normalised, <= 2p
+#pragma unroll
+    for (int i = 0; i < 9; i++) h.v[i] += fr_kp29_sub(1, i) - x.v[i];
+}
+// k-th multiplied term of the record: the products come first (coef, a, b), then the linear terms (coef, w)
+__device__ __forceinline__ Fr29 gate_mac_operand(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ t0,
+                                                 uint32_t np_mac, uint32_t k, const uint32_t *__restrict__ consts, Fr29 &c) {
+    if (k < np_mac) {
+        const uint32_t *__restrict__ t = t0 + 3 * k;
+        c = fr29_from(fr_const(consts, t[0]));
+        return fr29_mul(gate_load29(W, Bp, j, t[1]), gate_load29(W, Bp, j, t[2]));
+    }
+    const uint32_t *__restrict__ t = t0 + 3 * np_mac + 2 * (k - np_mac);
+    c = fr29_from(fr_const(consts, t[0]));
+    return gate_load29(W, Bp, j, t[1]);
+}
+__device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ g,
+                                                 const uint32_t *__restrict__ consts) {
+    const uint32_t w0 = g[0], w5 = g[5], qc = g[3];
+    const uint32_t np_mac = (w0 >> 8) & 0xff, nl_mac = (w0 >> 16) & 0xff, n_mac = np_mac + nl_mac;
+    const uint32_t np_pos = w5 & 0xff, np_neg = (w5 >> 8) & 0xff, nl_pos = (w5 >> 16) & 0xff, nl_neg = w5 >> 24;
+    Fr29 h;
+    uint32_t hw = 0;
+    if (qc == K_COEF_ZERO) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) h.v[i] = 0;
+    } else {
+        h = fr29_from(fr_const(consts, qc));
+        hw = 16;
+    }
+    const uint32_t *__restrict__ t0 = g + 6;
+    for (uint32_t base = 0; base < n_mac; base += 3) {
+        const uint32_t rem = n_mac - base;
+        Fr29 c0, c1, c2, r;
+        const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, c0);
+        if (rem == 1) {
+            r = fr29_mul(x0, c0);
+        } else {
+            const Fr29 x1 = gate_mac_operand(W, Bp, j, t0, np_mac, base + 1, consts, c1);
+            if (rem == 2) {
+                const Fr29 l[2] = {x0, x1}, m[2] = {c0, c1};
+                r = fr29_dot<2>(l, m);
+            } else {
+                const Fr29 x2 = gate_mac_operand(W, Bp, j, t0, np_mac, base + 2, consts, c2);
+                const Fr29 l[3] = {x0, x1, x2}, m[3] = {c0, c1, c2};
+                r = fr29_dot<3>(l, m);
+            }
+        }
+        gate_h_room(h, hw, 17);
+        h = fr29_addl(h, r);
+    }
+    const uint32_t *__restrict__ t = t0 + 3 * np_mac + 2 * nl_mac;
+    for (uint32_t i = 0; i < np_pos; i++, t += 2) {
+        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0]), gate_load29(W, Bp, j, t[1]));
+        gate_h_room(h, hw, 17);
+        h = fr29_addl(h, x);
+    }
+    for (uint32_t i = 0; i < np_neg; i++, t += 2) {
+        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0]), gate_load29(W, Bp, j, t[1]));
+        gate_h_room(h, hw, 33);
+        gate_h_sub(h, x);
+    }
+    for (uint32_t i = 0; i < nl_pos; i++, t += 1) {
+        const Fr29 x = gate_load29(W, Bp, j, t[0]);
+        gate_h_room(h, hw, 16);
+        h = fr29_addl(h, x);
+    }
+    for (uint32_t i = 0; i < nl_neg; i++, t += 1) {
+        const Fr29 x = gate_load29(W, Bp, j, t[0]);
+        gate_h_room(h, hw, 33);
+        gate_h_sub(h, x);
+    }
+    GateSum r;
+    r.v = fr29_norm(h);
+    r.bound = hw;
+    return r;
+}
+// canonical value of a gate sum: conditional subtractions by the wave-uniform bound; the last step down from < ~1.1p is
+// taken only when some lane's top limb says it may be needed (p's top limb is reached by 2^-22 of the canonical values)
+__device__ __forceinline__ Fr29 gate_sum_canon(const GateSum &s) {
+    Fr29 v = s.v;
+    uint32_t b = s.bound;  // invariant: value < b p / 16
+    if (b > 64 + 2) { v = fr29_csub(v, 2); b = b - 64 > 64 ? b - 64 : 64; }
+    if (b > 32 + 2) { v = fr29_csub(v, 1); b = b - 32 > 32 ? b - 32 : 32; }
+    if (b > 16) { v = fr29_csub(v, 0); b = b - 16 > 16 ? b - 16 : 16; }
+    while (b > 16) {  // some lane may still hold a value in [p, b p / 16): then its top limb is >= p's
+        if (__builtin_amdgcn_ballot_w64(v.v[8] >= fr_p29(8)) == 0) break;
+        v = fr29_csub(v, 0);
+        b = b - 16 > 16 ? b - 16 : 16;
+    }
+    return v;
+}
+
 __device__ __forceinline__ Fr coef_value(uint32_t coef, const uint32_t *__restrict__ consts) {
     if (coef == K_COEF_ONE) return fr_one();
     if (coef == K_COEF_MINUS_ONE) return fr_neg(fr_one());

@@ -583,24 +583,37 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         // zero-coefficient products / linear terms contribute exactly 0: drop them from the device program
         auto sc = [&](const FrH &x) { return scaled ? frh::mul(x, scale) : x; };
-        std::vector<uint32_t> pw, lw;
+        // Record layout (consumed by gate_sum_lazy, ops_common.hpp): terms with a general coefficient go through the
+        // multiplied lists; terms with coefficient +1 / -1 are listed without a coefficient and are only added / subtracted
+        // on the device (up to 255 of each kind, the rest keep an explicit constant).
+        //   [kind | np_mac << 8 | nl_mac << 16, opcode, out, q_c, partner, np_pos | np_neg << 8 | nl_pos << 16 | nl_neg << 24,
+        //    np_mac x (coef, a, b), nl_mac x (coef, w), np_pos x (a, b), np_neg x (a, b), nl_pos x (w), nl_neg x (w)]
+        std::vector<uint32_t> pm, lm, pp, pn, lp, ln;
         uint32_t np = 0, nl = 0;
+        const FrH qc_scaled = sc(e.qc);
         for (auto &t : prods) {
             if (t.c.is_zero()) continue;
-            pw.push_back(pool.coef(sc(t.c))); pw.push_back(t.a); pw.push_back(t.b);
             np++;
+            const uint32_t c = pool.coef(sc(t.c));
+            if (c == COEF_ONE && pp.size() < 2 * 255) { pp.push_back(t.a); pp.push_back(t.b); }
+            else if (c == COEF_MINUS_ONE && pn.size() < 2 * 255) { pn.push_back(t.a); pn.push_back(t.b); }
+            else { pm.push_back(pool.intern(sc(t.c))); pm.push_back(t.a); pm.push_back(t.b); }
         }
         for (auto &t : lins) {
             if (t.c.is_zero()) continue;
-            lw.push_back(pool.coef(sc(t.c))); lw.push_back(t.a);
             nl++;
+            const uint32_t c = pool.coef(sc(t.c));
+            if (c == COEF_ONE && lp.size() < 255) lp.push_back(t.a);
+            else if (c == COEF_MINUS_ONE && ln.size() < 255) ln.push_back(t.a);
+            else { lm.push_back(pool.intern(sc(t.c))); lm.push_back(t.a); }
         }
-        if (np > 255 || nl > 255) { p.truncated_at = oi; break; }
+        if (pm.size() / 3 > 255 || lm.size() / 2 > 255) { p.truncated_at = oi; break; }
         g.level = lvl + 1;
-        g.words = {kind | np << 8 | nl << 16, oi, kind == GATE_ASSERT ? 0u : unk_w, pool.constant(sc(e.qc)),
-                   kind == GATE_SOLVE_DYN ? unk_partner : 0u};
-        g.words.insert(g.words.end(), pw.begin(), pw.end());
-        g.words.insert(g.words.end(), lw.begin(), lw.end());
+        g.words = {kind | (uint32_t)(pm.size() / 3) << 8 | (uint32_t)(lm.size() / 2) << 16, oi, kind == GATE_ASSERT ? 0u : unk_w,
+                   pool.constant(qc_scaled), kind == GATE_SOLVE_DYN ? unk_partner : 0u,
+                   (uint32_t)(pp.size() / 2) | (uint32_t)(pn.size() / 2) << 8 | (uint32_t)lp.size() << 16 | (uint32_t)ln.size() << 24};
+        for (auto *v : {&pm, &lm, &pp, &pn, &lp, &ln}) g.words.insert(g.words.end(), v->begin(), v->end());
+        (void)np; (void)nl;
         std::sort(reads.begin(), reads.end());
         reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
         uint64_t bytes = 32ull * (reads.size() + (kind == GATE_ASSERT ? 0 : 1));

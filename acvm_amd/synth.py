@@ -47,14 +47,15 @@ class SplitMix64:
                 return c
 
 
-def arithmetic_circuit(n_gates, n_in=16, seed=0xAC1D0002, chain=False, mix=(45, 30, 20, 5)):
-    """Returns (Circuit, input witness ids)."""
+def arithmetic_circuit(n_gates, n_in=16, seed=0xAC1D0002, chain=False, mix=(45, 30, 20, 5), hot_inputs=False):
+    """Returns (Circuit, input witness ids). hot_inputs: operands are drawn from the circuit inputs only (one level, operand
+    reads served by L2: the issue-bound variant used by tools/ to separate ALU time from HBM time)."""
     rng = SplitMix64(seed)
     ops = []
     defined = n_in  # witnesses 1..defined are known
     for i in range(n_gates):
         out = n_in + 1 + i
-        pick = lambda: 1 + rng.below(defined)  # noqa: E731
+        pick = lambda: 1 + rng.below(n_in if hot_inputs else defined)  # noqa: E731
         a, b, c = pick(), pick(), pick()
         if chain and i > 0:
             a = out - 1
@@ -76,6 +77,41 @@ def arithmetic_circuit(n_gates, n_in=16, seed=0xAC1D0002, chain=False, mix=(45, 
         defined += 1
     circ = Circuit(current_witness_index=n_in + n_gates, opcodes=ops, private_parameters=list(range(1, n_in + 1)),
                    return_values=[n_in + n_gates])
+    return circ, list(range(1, n_in + 1))
+
+
+def wide_gate_circuit(n_gates, n_in=16, seed=0xAC1D0A11, max_terms=12):
+    """Gates with up to max_terms mul terms and max_terms linear terms (Expression is not width-limited before the csat
+    transformer), coefficients from {1, -1, uniform}: more than six general coefficients per gate, unit-coefficient
+    terms beyond the device's side-sum budget, and every fourth gate followed by an assert-zero re-statement of it
+    (all witnesses known: arithmetic.rs:92-102). Returns (Circuit, input ids)."""
+    rng = SplitMix64(seed)
+    ops = []
+    defined = n_in
+    out = n_in
+    for i in range(n_gates):
+        out += 1
+        pick = lambda: 1 + rng.below(defined)  # noqa: E731
+        nm, nl = rng.below(max_terms + 1), rng.below(max_terms + 1)
+        unit_only = rng.below(3) == 0
+        coef = (lambda: (1 if rng.next() & 1 else P - 1)) if unit_only else rng.coef
+        mul = {}
+        for _ in range(nm):
+            a, b = pick(), pick()
+            mul[(min(a, b), max(a, b))] = coef()
+        lin = {}
+        for _ in range(nl):
+            lin[pick()] = coef()
+        lin[out] = coef()
+        qc = rng.coef() if rng.next() & 1 else 0
+        e = Expression(sorted((c, a, b) for (a, b), c in mul.items()), sorted((c, w) for w, c in lin.items()), qc)
+        e.mul_terms.sort(key=lambda t: (t[1], t[2]))
+        e.linear_combinations.sort(key=lambda t: t[1])
+        ops.append(e)
+        defined = out
+        if i % 4 == 3:
+            ops.append(Expression(list(e.mul_terms), list(e.linear_combinations), qc))
+    circ = Circuit(current_witness_index=out, opcodes=ops, private_parameters=list(range(1, n_in + 1)), return_values=[out])
     return circ, list(range(1, n_in + 1))
 
 

@@ -46,6 +46,18 @@ def test_arithmetic_circuit_parity(oracle, n_gates, B):
     assert stats["n_slow_instances"] <= 8
 
 
+@pytest.mark.parametrize("force_slow", [False, True])
+def test_wide_gate_parity(oracle, force_slow):
+    """Up to 12 mul + 12 linear terms per gate: several column carries of the device's sum-of-products accumulator, unit
+    coefficients beyond the side-sum budget, assert-zero gates."""
+    from acvm_amd import synth
+    circ, ids = synth.wide_gate_circuit(240)
+    values = synth.witness_batch(96, seed=0xAC1D0A11)
+    o, g, stats = _run_both(oracle, circ, ids, values, 96, force_slow=force_slow)
+    _assert_parity(o, g, 96)
+    assert sum(1 for j in range(96) if g[0][j].status == 0) >= 88
+
+
 def test_chain_circuit_parity(oracle):
     from acvm_amd import synth
     circ, ids = synth.arithmetic_circuit(300, seed=0xAC1D0077, chain=True)

@@ -78,6 +78,17 @@ int main() {
             if (fr29_is_zero_mod_p(fr29_lt2p(fr29_norm(fr29_subl(x, x, 1)))) != true) { fails++; printf("zero test mismatch %d\n", it); }
             if (fr29_is_zero_mod_p(fr29_mul(x, y)) != (a.is_zero() || b.is_zero())) { fails++; printf("zero test 2 mismatch %d\n", it); }
         }
+        {   // sums of products with one reduction: a*b + b*b + (a+a)*a and a*a + b*a
+            const Fr29 x = fr29_from(da), y = fr29_from(db), x2 = fr29_norm(fr29_dbll(x));
+            const Fr29 l3[3] = {x, y, x2}, r3[3] = {y, y, x};
+            FrH want = frh::add(frh::add(frh::mul(a, b), frh::mul(b, b)), frh::mul(frh::add(a, a), a));
+            if (!same(fr29_pack(fr29_canon(fr29_dot<3>(l3, r3))), want)) { fails++; printf("dot3 mismatch %d\n", it); }
+            const Fr29 l2[2] = {x, y}, r2[2] = {x, x};
+            want = frh::add(frh::mul(a, a), frh::mul(b, a));
+            if (!same(fr29_pack(fr29_canon(fr29_dot<2>(l2, r2))), want)) { fails++; printf("dot2 mismatch %d\n", it); }
+            const Fr29 l1[1] = {x}, r1[1] = {y};
+            if (!same(fr29_pack(fr29_canon(fr29_dot<1>(l1, r1))), frh::mul(a, b))) { fails++; printf("dot1 mismatch %d\n", it); }
+        }
         if (fr_is_zero(da) != a.is_zero()) { fails++; printf("is_zero mismatch %d\n", it); }
     }
     // 5^-1 = 0x135b5294...6667 (acvm_js/test/shared/foreign_call.ts)

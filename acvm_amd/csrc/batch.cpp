@@ -66,7 +66,7 @@ struct acvm_batch {
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr;
     std::vector<hipEvent_t> ev_sync;
-    uint4 *d_dyn_scratch = nullptr;
+    uint4 *d_inv = nullptr;  // inverse table: [plan.n_inverse_slots][2 halves][Bp] x 16 B
     uint32_t n_launches = 0;
     // caller-supplied BlackBoxFunctionSolver
     bool has_solver = false;
@@ -93,7 +93,7 @@ struct acvm_batch {
                 if (p) hipFree(p);
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
-        if (d_dyn_scratch) hipFree(d_dyn_scratch);
+        if (d_inv) hipFree(d_inv);
         for (void *p : {(void *)d_fc_res_opcode, (void *)d_fc_res_desc, (void *)d_fc_pend_desc, (void *)d_fc_res_vals, (void *)d_fc_pend_vals})
             if (p) hipFree(p);
         if (stream_dyn) hipStreamDestroy(stream_dyn);
@@ -302,11 +302,9 @@ static int batch_init(acvm_batch *b) {
     b->n_words = (p.n_witnesses + 31) / 32;
     if (int rc = upload(&b->d_producer, p.producer)) return rc;
     if (int rc = upload(&b->d_dyn_offset, p.dyn_offset)) return rc;
-    {   // prefix-product scratch of the batched inversions: [max dyn gates per level][2 halves][Bp] x 16 B
-        uint32_t max_dyn = 0;
-        for (size_t l = 0; l + 1 < p.dyn_level_start.size(); l++) max_dyn = std::max(max_dyn, p.dyn_level_start[l + 1] - p.dyn_level_start[l]);
-        size_t bytes = (size_t)max_dyn * 2 * b->Bp * sizeof(uint4);
-        HIPCHK(hipMalloc((void **)&b->d_dyn_scratch, bytes ? bytes : 16));
+    {
+        size_t bytes = (size_t)p.n_inverse_slots * 2 * b->Bp * sizeof(uint4);
+        HIPCHK(hipMalloc((void **)&b->d_inv, bytes ? bytes : 16));
     }
     HIPCHK(hipMalloc((void **)&b->d_event, (size_t)(b->B ? b->B : 1) * 4));
     b->h_event.assign(b->B, 0xFFFFFFFFu);
@@ -665,7 +663,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
             if (n) {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }
-                launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event);
+                launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event, b->d_inv);
                 if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); reg_pairs.push_back({e0, e1}); }
                 b->n_launches += (n + 65534) / 65535;
             }
@@ -695,8 +693,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
                 if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s2); }
-                launch_arith_dyn_level(s2, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_consts,
-                                       b->d_event, b->d_dyn_scratch);
+                launch_inverse_batch(s2, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_event);
                 if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s2); dyn_pairs.push_back({e0, e1}); }
                 b->n_launches++;
                 HIPCHK(hipEventRecord(b->ev_sync[2 * L + 1], s2));

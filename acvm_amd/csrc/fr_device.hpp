@@ -174,6 +174,41 @@ FR_HD __forceinline__ Fr29 fr29_mul(const Fr29 &a, const Fr29 &b) {
     r.v[8] = (uint32_t)acc;
     return r;
 }
+// a * a * 2^-261 mod p: the 36 cross products are taken once against the doubled limbs (45 + 81 multiply-adds instead of
+// 81 + 81). Same contract as fr29_mul.
+FR_HD __forceinline__ Fr29 fr29_sqr(const Fr29 &a) {
+    constexpr uint32_t M = 0x1fffffffu;
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fr29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        const uint32_t lo = (uint32_t)acc;
+        m[k] = (((lo & 1u) << 28) - lo) & M;
+        acc += ((uint64_t)m[k] << 28) + m[k];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        r.v[k - 9] = (uint32_t)acc & M;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
 // value < 2p, limbs < 2^29 -> canonical [0, p)
 FR_HD __forceinline__ Fr29 fr29_cond_sub_p(const Fr29 &a) {
     Fr29 d;

@@ -69,15 +69,22 @@ __global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__rest
 
 // ------------------------------------------------------------------------------------------ level kernel
 // grid = (ceil(B/256), gates in level). Lane = instance. The gate record is wave-uniform.
-__global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
-                                                          const uint32_t *__restrict__ gate_stream,
-                                                          const uint32_t *__restrict__ gate_offset,
-                                                          const uint32_t *__restrict__ consts, uint32_t *__restrict__ event) {
+__device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream,
+                                                 const uint32_t *__restrict__ gate_offset, const uint32_t *__restrict__ consts,
+                                                 uint32_t *__restrict__ event, const uint4 *__restrict__ Inv) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
     const uint32_t *__restrict__ g = gate_stream + gate_offset[blockIdx.y];
     const uint32_t kind = g[0] & 0xff, opcode = g[1], out = g[2];
-    const Fr29 acc = gate_sum_canon(gate_sum_lazy(W, Bp, j, g, consts));
+    const GateSum sum = gate_sum_lazy(W, Bp, j, g, consts);
+    if (kind == 2) {
+        // the unknown is multiplied by a known witness (arithmetic.rs:68-91): out = sum' / partner, and 1 / partner was put
+        // into the inverse table by an earlier inverse_batch_kernel. The lazy sum (< 8p) is a valid product operand as it is.
+        const Fr29 inv = fr29_from(fr_load(Inv, g[4], Bp, j));
+        fr_store(W, out, Bp, j, fr29_pack(fr29_cond_sub_p(fr29_mul(sum.v, inv))));
+        return;
+    }
+    const Fr29 acc = gate_sum_canon(sum);
     if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
         uint32_t z = 0;
 #pragma unroll
@@ -87,51 +94,46 @@ __global__ void __launch_bounds__(256) arith_level_kernel(uint4 *__restrict__ W,
         fr_store(W, out, Bp, j, fr29_pack(acc));
     }
 }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+arith_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream, const uint32_t *__restrict__ gate_offset,
+                   const uint32_t *__restrict__ consts, uint32_t *__restrict__ event, const uint4 *__restrict__ Inv) {
+    arith_level_body(W, Bp, B, gate_stream, gate_offset, consts, event, Inv);
+}
 
-// gates whose unknown is multiplied by a known witness (arithmetic.rs:68-91): out = acc' / partner needs a
-// per-instance inversion. One wave = 64 instances x up to DYN_CHUNK independent gates of one level; the
-// inversions of a lane are batched with Montgomery's trick, so a lane pays one field inversion per chunk plus
-// 4 multiplications per gate. The prefix products are parked in a device scratch table laid out like W
-// ([gate in level][half][instance], 16 B per lane, coalesced); it stays L2/Infinity-Cache resident (<= 80 MB)
-// and, unlike an LDS stage, does not cap the number of resident waves of this latency-bound kernel.
-static constexpr uint32_t DYN_CHUNK = 32;  // measured on config 2: 8 -> 17.9 ms, 16 -> 17.5, 32 -> 17.1, 64 -> 17.3 per solve
-__global__ void __launch_bounds__(64) arith_dyn_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
-                                                             const uint32_t *__restrict__ gate_stream,
-                                                             const uint32_t *__restrict__ dyn_offset, uint32_t n_dyn,
-                                                             const uint32_t *__restrict__ consts, uint32_t *__restrict__ event,
-                                                             uint4 *__restrict__ scratch) {
-    // These waves are the long pole of a level (one field inversion each) and run beside the HBM-bound gate kernel of the
-    // same level: raise their issue priority so that they finish in their own ~50 us instead of being time-sliced with
-    // seven streaming waves per SIMD, which then fill the stall slots.
-    __builtin_amdgcn_s_setprio(3);
+// Denominators of the gates whose unknown is multiplied by a known witness (arithmetic.rs:68-91): 1 / partner for a batch of
+// inversion jobs (plan.cpp schedules them ahead of their gates). One wave = 64 instances x up to INV_CHUNK jobs; the
+// inversions of a lane are batched with Montgomery's trick, so a lane pays one field inversion per chunk plus 3
+// multiplications per job. The prefix products are parked in the jobs' own rows of the inverse table (laid out like W,
+// [slot][half][instance], coalesced) and replaced by the inverses on the way back. Values stay in the 29-bit working form
+// between products (< 1.06p, never repacked); the table holds representatives < 2^256, not necessarily < p.
+static constexpr uint32_t INV_CHUNK = 64;
+__global__ void __launch_bounds__(64) inverse_batch_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ Inv, uint64_t Bp, uint32_t B,
+                                                           const uint32_t *__restrict__ gate_stream, const uint32_t *__restrict__ job_offset,
+                                                           uint32_t n_jobs, uint32_t *__restrict__ event) {
     const uint64_t j = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= B) return;
-    const uint32_t first = blockIdx.y * DYN_CHUNK;
-    const uint32_t n = n_dyn - first < DYN_CHUNK ? n_dyn - first : DYN_CHUNK;
-    // prefix products and the running inverse stay in the 29-bit working form (values < 1.06p, never repacked between
-    // products); only the parked prefixes and the result are packed
+    const uint32_t first = blockIdx.y * INV_CHUNK;
+    const uint32_t n = n_jobs - first < INV_CHUNK ? n_jobs - first : INV_CHUNK;
     Fr29 prefix = fr29_from(fr_one());
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t *__restrict__ g = gate_stream + dyn_offset[first + i];
-        Fr den = fr_load(W, g[4], Bp, j);
-        if (fr_is_zero(den)) {  // zero-coefficient drop (arithmetic.rs:217-221): this instance leaves the generic path
+        const uint32_t *__restrict__ g = gate_stream + job_offset[first + i];
+        Fr den = fr_load(W, g[0], Bp, j);
+        if (fr_is_zero(den)) {  // zero-coefficient drop (arithmetic.rs:217-221): this instance leaves the generic path at the gate
             atomicMin(&event[j], g[1]);
             den = fr_one();
         }
         prefix = fr29_mul(prefix, fr29_from(den));
-        fr_store(scratch, first + i, Bp, j, fr29_pack(prefix));
+        fr_store(Inv, g[2], Bp, j, fr29_pack(prefix));
     }
     Fr29 inv = fr29_from(fr_inv(fr29_pack(fr29_cond_sub_p(prefix))));  // 1 / (den_0 ... den_{n-1})
     for (uint32_t i = n; i-- > 0;) {
-        const uint32_t *__restrict__ g = gate_stream + dyn_offset[first + i];
-        const uint32_t out = g[2];
-        Fr den = fr_load(W, g[4], Bp, j);
+        const uint32_t *__restrict__ g = gate_stream + job_offset[first + i];
+        Fr den = fr_load(W, g[0], Bp, j);
         if (fr_is_zero(den)) den = fr_one();
         Fr29 inv_i = inv;
-        if (i > 0) inv_i = fr29_mul(inv, fr29_from(fr_load(scratch, first + i - 1, Bp, j)));
+        if (i > 0) inv_i = fr29_mul(inv, fr29_from(fr_load(Inv, gate_stream[job_offset[first + i - 1] + 2], Bp, j)));
         inv = fr29_mul(inv, fr29_from(den));
-        const GateSum num = gate_sum_lazy(W, Bp, j, g, consts);  // < 16p: a valid product operand as it is
-        fr_store(W, out, Bp, j, fr29_pack(fr29_cond_sub_p(fr29_mul(num.v, inv_i))));
+        fr_store(Inv, g[2], Bp, j, fr29_pack(inv_i));
     }
 }
 
@@ -216,19 +218,19 @@ void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, u
     hipLaunchKernelGGL(export_witness_kernel, dim3((n + 255) / 256, n_sel), dim3(256), 0, s, W, Bp, first, n, sel, n_sel, out);
 }
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
-                        uint32_t n_gates, const uint32_t *consts, uint32_t *event) {
+                        uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv) {
     // gridDim.y is limited to 65535
     for (uint32_t done = 0; done < n_gates;) {
         uint32_t n = n_gates - done > 65535u ? 65535u : n_gates - done;
-        hipLaunchKernelGGL(arith_level_kernel, dim3((B + 255) / 256, n), dim3(256), 0, s, W, Bp, B, gate_stream, gate_offset + done, consts, event);
+        hipLaunchKernelGGL(arith_level_kernel, dim3((B + 255) / 256, n), dim3(256), 0, s, W, Bp, B, gate_stream, gate_offset + done, consts, event, inv);
         done += n;
     }
 }
-void launch_arith_dyn_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *dyn_offset,
-                            uint32_t n_dyn, const uint32_t *consts, uint32_t *event, uint4 *scratch) {
-    if (!n_dyn || !B) return;
-    hipLaunchKernelGGL(arith_dyn_level_kernel, dim3((B + 63) / 64, (n_dyn + DYN_CHUNK - 1) / DYN_CHUNK), dim3(64), 0, s, W, Bp, B,
-                       gate_stream, dyn_offset, n_dyn, consts, event, scratch);
+void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
+                          const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event) {
+    if (!n_jobs || !B) return;
+    hipLaunchKernelGGL(inverse_batch_kernel, dim3((B + 63) / 64, (n_jobs + INV_CHUNK - 1) / INV_CHUNK), dim3(64), 0, s, W, inv, Bp, B,
+                       gate_stream, job_offset, n_jobs, event);
 }
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches) {
     if (!n) return;

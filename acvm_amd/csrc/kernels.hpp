@@ -55,9 +55,9 @@ void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
                    uint8_t *out);
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
-                        uint32_t n_gates, const uint32_t *consts, uint32_t *event);
-void launch_arith_dyn_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *dyn_offset,
-                            uint32_t n_dyn, const uint32_t *consts, uint32_t *event, uint4 *scratch);
+                        uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv);
+void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
+                          const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event);
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);

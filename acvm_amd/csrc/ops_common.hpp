@@ -62,7 +62,8 @@ __device__ __forceinline__ Fr apply_coef_prod(const Fr &a, const Fr &b, uint32_t
     return fr29_pack(fr29_cond_sub_p(fr29_mul(t, fr29_from(fr_const(consts, coef)))));
 }
 // ---- the folded gate sum of the level kernels: sum q_i a_i b_i + sum q_j w_j + q_c (gate record of plan.cpp). Terms with a
-// general coefficient are multiplied three at a time with ONE Montgomery reduction (fr29_dot); terms with coefficient +-1
+// general coefficient are multiplied two at a time with ONE Montgomery reduction (fr29_dot; three at a time costs 30 more
+// registers -- one wave less per SIMD -- for a case the width-3 gates of csat.rs never produce); terms with coefficient +-1
 // and the constant skip the multiplier altogether: the planner lists them apart. Everything is summed limb-wise into the
 // lazy side sum h, whose bound is tracked in units of p/16 (wave-uniform, from the record's counts): a canonical witness or
 // constant weighs 16, a product or a reduced dot product 17 (< 1.06p), a subtracted term 33 (it is added as 2p - x <= 2p).
@@ -113,22 +114,15 @@ __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, ui
         hw = 16;
     }
     const uint32_t *__restrict__ t0 = g + 6;
-    for (uint32_t base = 0; base < n_mac; base += 3) {
-        const uint32_t rem = n_mac - base;
-        Fr29 c0, c1, c2, r;
+    for (uint32_t base = 0; base < n_mac; base += 2) {
+        Fr29 c0, c1, r;
         const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, c0);
-        if (rem == 1) {
+        if (n_mac - base == 1) {
             r = fr29_mul(x0, c0);
         } else {
             const Fr29 x1 = gate_mac_operand(W, Bp, j, t0, np_mac, base + 1, consts, c1);
-            if (rem == 2) {
-                const Fr29 l[2] = {x0, x1}, m[2] = {c0, c1};
-                r = fr29_dot<2>(l, m);
-            } else {
-                const Fr29 x2 = gate_mac_operand(W, Bp, j, t0, np_mac, base + 2, consts, c2);
-                const Fr29 l[3] = {x0, x1, x2}, m[3] = {c0, c1, c2};
-                r = fr29_dot<3>(l, m);
-            }
+            const Fr29 l[2] = {x0, x1}, m[2] = {c0, c1};
+            r = fr29_dot<2>(l, m);
         }
         gate_h_room(h, hw, 17);
         h = fr29_addl(h, r);

@@ -44,12 +44,12 @@ __device__ __forceinline__ GAff gaff_load(const uint4 *tbl, uint32_t idx) {
 // dbl-2009-l (a = 0): 2M + 5S
 __device__ __forceinline__ GJac gj_dbl(const GJac &p) {
     if (gj_is_inf(p) || fr29_is_zero_mod_p(p.Y)) return gj_inf();
-    const Fr29 A = fr29_mul(p.X, p.X), B = fr29_mul(p.Y, p.Y), C = fr29_mul(B, B);           // < 1.03, 1.03, 1.01
+    const Fr29 A = fr29_sqr(p.X), B = fr29_sqr(p.Y), C = fr29_sqr(B);           // < 1.03, 1.03, 1.01
     const Fr29 t0 = fr29_norm(fr29_addl(p.X, B));                                              // < 3.03
-    const Fr29 t = g29_red(fr29_subl(fr29_subl(fr29_mul(t0, t0), A, 1), C, 1));                // 1.06 + 4 = 5.06 -> < 2
+    const Fr29 t = g29_red(fr29_subl(fr29_subl(fr29_sqr(t0), A, 1), C, 1));                // 1.06 + 4 = 5.06 -> < 2
     const Fr29 D = fr29_csub(fr29_norm(fr29_dbll(t)), 1);                                      // 2t < 4 -> < 2
     const Fr29 E = fr29_norm(fr29_addl(fr29_dbll(A), A));                                      // 3A < 3.09
-    const Fr29 F = fr29_mul(E, E);                                                             // < 1.06
+    const Fr29 F = fr29_sqr(E);                                                             // < 1.06
     GJac r;
     r.X = g29_red(fr29_subl(F, fr29_norm(fr29_dbll(D)), 2));                                   // 1.06 + 4 = 5.06 -> < 2
     const Fr29 m = fr29_mul(E, fr29_norm(fr29_subl(D, r.X, 1)));                               // E (< 3.09) * (< 4) -> < 1.08
@@ -62,21 +62,21 @@ __device__ __forceinline__ GJac gj_dbl(const GJac &p) {
 __device__ __forceinline__ GJac gj_add_aff(const GJac &p, const GAff &q) {
     const Fr29 x2 = fr29_from(q.x), y2 = fr29_from(q.y);                                       // < 1
     if (gj_is_inf(p)) return GJac{x2, y2, g29_one()};
-    const Fr29 Z1Z1 = fr29_mul(p.Z, p.Z);                                                      // < 1.03
+    const Fr29 Z1Z1 = fr29_sqr(p.Z);                                                      // < 1.03
     const Fr29 U2 = fr29_mul(x2, Z1Z1), S2 = fr29_mul(fr29_mul(y2, p.Z), Z1Z1);                // < 1.02
     const Fr29 H = fr29_norm(fr29_subl(U2, p.X, 1));                                           // < 3.02
     const Fr29 rr = fr29_norm(fr29_subl(S2, p.Y, 1));                                          // < 3.02
     const Fr29 r = fr29_norm(fr29_dbll(rr));                                                   // < 6.04
-    const Fr29 HH = fr29_mul(H, H);                                                            // < 1.06
+    const Fr29 HH = fr29_sqr(H);                                                            // < 1.06
     const Fr29 I = fr29_norm(fr29_dbll(fr29_dbll(HH)));                                        // < 4.22
     const Fr29 J = fr29_mul(H, I), V = fr29_mul(p.X, I);                                       // < 1.08, < 1.05
     GJac o;
-    o.X = g29_red(fr29_subl(fr29_subl(fr29_mul(r, r), J, 1), fr29_norm(fr29_dbll(V)), 2));     // 1.22 + 2 + 4 = 7.22 -> < 2
+    o.X = g29_red(fr29_subl(fr29_subl(fr29_sqr(r), J, 1), fr29_norm(fr29_dbll(V)), 2));     // 1.22 + 2 + 4 = 7.22 -> < 2
     const Fr29 m1 = fr29_mul(r, fr29_norm(fr29_subl(V, o.X, 1)));                              // r (< 6.04) * (< 3.05) -> < 1.11
     const Fr29 m2 = fr29_norm(fr29_dbll(fr29_mul(p.Y, J)));                                    // < 2.04
     o.Y = g29_red(fr29_subl(m1, m2, 2));                                                       // 1.11 + 4 -> < 2
     const Fr29 zh = fr29_norm(fr29_addl(p.Z, H));                                              // < 5.02
-    o.Z = g29_red(fr29_subl(fr29_subl(fr29_mul(zh, zh), Z1Z1, 1), HH, 1));                     // 1.15 + 4 -> < 2;  = 2 Z1 H
+    o.Z = g29_red(fr29_subl(fr29_subl(fr29_sqr(zh), Z1Z1, 1), HH, 1));                     // 1.15 + 4 -> < 2;  = 2 Z1 H
     if (fr29_is_zero_mod_p(o.Z)) {  // Z1 != 0, so H == 0: same x
         if (fr29_is_zero_mod_p(fr29_lt2p(rr))) return gj_dbl(p);
         return gj_inf();
@@ -87,22 +87,22 @@ __device__ __forceinline__ GJac gj_add_aff(const GJac &p, const GAff &q) {
 __device__ __forceinline__ GJac gj_add(const GJac &p, const GJac &q) {
     if (gj_is_inf(p)) return q;
     if (gj_is_inf(q)) return p;
-    const Fr29 Z1Z1 = fr29_mul(p.Z, p.Z), Z2Z2 = fr29_mul(q.Z, q.Z);                           // < 1.03
+    const Fr29 Z1Z1 = fr29_sqr(p.Z), Z2Z2 = fr29_sqr(q.Z);                           // < 1.03
     const Fr29 U1 = fr29_mul(p.X, Z2Z2), U2 = fr29_mul(q.X, Z1Z1);                             // < 1.02
     const Fr29 S1 = fr29_mul(fr29_mul(p.Y, q.Z), Z2Z2), S2 = fr29_mul(fr29_mul(q.Y, p.Z), Z1Z1);
     const Fr29 H = fr29_norm(fr29_subl(U2, U1, 1));                                            // < 3.02
     const Fr29 rr = fr29_norm(fr29_subl(S2, S1, 1));                                           // < 3.02
     const Fr29 r = fr29_norm(fr29_dbll(rr));                                                   // < 6.04
     const Fr29 H2 = fr29_norm(fr29_dbll(H));                                                   // < 6.04
-    const Fr29 I = fr29_mul(H2, H2);                                                           // < 1.22
+    const Fr29 I = fr29_sqr(H2);                                                           // < 1.22
     const Fr29 J = fr29_mul(H, I), V = fr29_mul(U1, I);                                        // < 1.03, < 1.01
     GJac o;
-    o.X = g29_red(fr29_subl(fr29_subl(fr29_mul(r, r), J, 1), fr29_norm(fr29_dbll(V)), 2));     // 1.22 + 2 + 4 -> < 2
+    o.X = g29_red(fr29_subl(fr29_subl(fr29_sqr(r), J, 1), fr29_norm(fr29_dbll(V)), 2));     // 1.22 + 2 + 4 -> < 2
     const Fr29 m1 = fr29_mul(r, fr29_norm(fr29_subl(V, o.X, 1)));                              // < 1.11
     const Fr29 m2 = fr29_norm(fr29_dbll(fr29_mul(S1, J)));                                     // < 2.02
     o.Y = g29_red(fr29_subl(m1, m2, 2));
     const Fr29 zz = fr29_norm(fr29_addl(p.Z, q.Z));                                            // < 4
-    const Fr29 T = fr29_norm(fr29_subl(fr29_subl(fr29_mul(zz, zz), Z1Z1, 1), Z2Z2, 1));        // 1.1 + 4 = 5.1;  = 2 Z1 Z2
+    const Fr29 T = fr29_norm(fr29_subl(fr29_subl(fr29_sqr(zz), Z1Z1, 1), Z2Z2, 1));        // 1.1 + 4 = 5.1;  = 2 Z1 Z2
     o.Z = fr29_mul(T, H);                                                                      // < 1.1
     if (fr29_is_zero_mod_p(o.Z)) {  // Z1 Z2 != 0, so H == 0
         if (fr29_is_zero_mod_p(fr29_lt2p(rr))) return gj_dbl(p);
@@ -115,7 +115,7 @@ __device__ __forceinline__ GJac gj_add(const GJac &p, const GJac &q) {
 __device__ __forceinline__ GAff gj_to_aff(const GJac &p, bool *inf) {
     *inf = gj_is_inf(p);
     const Fr29 zi = fr29_from(fr_inv(fr29_pack(fr29_canon(p.Z))));  // inverse(0) == 0 -> (0, 0)
-    const Fr29 zi2 = fr29_mul(zi, zi);
+    const Fr29 zi2 = fr29_sqr(zi);
     GAff r;
     r.x = fr29_pack(fr29_canon(fr29_mul(p.X, zi2)));
     r.y = fr29_pack(fr29_canon(fr29_mul(p.Y, fr29_mul(zi2, zi))));

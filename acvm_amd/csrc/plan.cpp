@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <map>
+#include <queue>
 
 namespace acvm {
 namespace {
@@ -54,6 +55,18 @@ struct PendingGate {
 struct PendingRecord {
     uint32_t level, cls, opcode;
 };
+// inversion of a SOLVE_DYN gate's denominator: runs beside level `level`, its result is read by gate `gate` at `use_level`
+struct PendingInverse {
+    uint32_t level, use_level, partner, opcode, gate;
+};
+// Denominators are inverted ahead of their gates, in batches: every INV_EPOCH-th level the inversion kernel takes all
+// denominators that became known since the last batch, so that one field inversion (Montgomery's trick) is shared by all of
+// them and its latency is off the path of the levels in between. A gate whose denominator is younger than the last batch
+// waits for the next one (at most INV_EPOCH levels).
+static uint32_t inv_epoch() {
+    static const uint32_t v = [] { const char *e = getenv("ACVM_INV_EPOCH"); const int x = e ? atoi(e) : 4; return (uint32_t)(x > 0 ? x : 4); }();
+    return v;
+}
 
 // Expression record: [n_mul, n_lin, qc, (coef, l, r) x n_mul, (coef, -1/coef, w) x n_lin]
 void emit_expr(std::vector<uint32_t> &s, ConstPool &pool, const Expr &e) {
@@ -118,6 +131,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     ConstPool pool(p.constants);
     std::vector<PendingGate> gates;
     std::vector<PendingRecord> records;
+    std::vector<PendingInverse> inverses;
     gates.reserve(c.opcodes.size());
 
     // memory blocks: cell ranges of the per-instance memory table + the program-order chain level
@@ -571,15 +585,20 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         auto rd = [&](uint32_t w) { lvl = std::max(lvl, level[w]); reads.push_back(w); };
         for (auto &t : prods) { rd(t.a); rd(t.b); }
         for (auto &t : lins) rd(t.a);
-        uint32_t kind = GATE_ASSERT;
+        uint32_t kind = GATE_ASSERT, inv_level = 0;
         FrH scale = frh::one();
         bool scaled = false;
         if (n_unknown == 1) {
             // out = -(sum)/coeff (arithmetic.rs:120) or -(sum)/(c*partner) (:86): fold -1/coeff into every coefficient
             scale = pool.neg_inv(unk_coef);
             scaled = true;
-            if (unk_is_folded) { kind = GATE_SOLVE_DYN; rd(unk_partner); }
-            else kind = GATE_SOLVE;
+            if (unk_is_folded) {
+                kind = GATE_SOLVE_DYN;
+                reads.push_back(unk_partner);
+                const uint32_t K = inv_epoch();
+                inv_level = 1 + ((level[unk_partner] + K - 1) / K) * K;  // first batch level after the denominator is known
+                lvl = std::max(lvl, inv_level);
+            } else kind = GATE_SOLVE;
         }
         // zero-coefficient products / linear terms contribute exactly 0: drop them from the device program
         auto sc = [&](const FrH &x) { return scaled ? frh::mul(x, scale) : x; };
@@ -618,38 +637,61 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
         uint64_t bytes = 32ull * (reads.size() + (kind == GATE_ASSERT ? 0 : 1));
         p.algorithmic_bytes += bytes;
-        (kind == GATE_SOLVE_DYN ? p.dyn_algorithmic_bytes : p.arith_algorithmic_bytes) += bytes;
+        // the denominator of a SOLVE_DYN gate is read by the inversion kernel, everything else by the gate kernel
+        p.arith_algorithmic_bytes += bytes - (kind == GATE_SOLVE_DYN ? 32 : 0);
+        if (kind == GATE_SOLVE_DYN) p.dyn_algorithmic_bytes += 32;
         if (kind != GATE_ASSERT) {
             known[unk_w] = 1;
             level[unk_w] = g.level;
             p.producer[unk_w] = oi;
         }
-        if (kind == GATE_SOLVE_DYN) p.n_dyn_gates++;
-        else p.n_fast_gates++;
+        if (kind == GATE_SOLVE_DYN) {
+            p.n_dyn_gates++;
+            inverses.push_back({inv_level, g.level, unk_partner, oi, (uint32_t)gates.size()});
+        } else p.n_fast_gates++;
         gates.push_back(std::move(g));
     }
 
+    // =========================================================================== inverse slots: a slot is reused once its gate ran
+    std::stable_sort(inverses.begin(), inverses.end(), [](const PendingInverse &a, const PendingInverse &b) { return a.level < b.level; });
+    {
+        std::priority_queue<std::pair<uint32_t, uint32_t>, std::vector<std::pair<uint32_t, uint32_t>>, std::greater<>> busy;  // (use_level, slot)
+        std::vector<uint32_t> free_slots;
+        for (auto &iv : inverses) {
+            while (!busy.empty() && busy.top().first < iv.level) { free_slots.push_back(busy.top().second); busy.pop(); }
+            uint32_t slot;
+            if (!free_slots.empty()) { slot = free_slots.back(); free_slots.pop_back(); }
+            else slot = p.n_inverse_slots++;
+            busy.push({iv.use_level, slot});
+            gates[iv.gate].words[4] = slot;
+            iv.gate = slot;  // from here on: the slot
+        }
+    }
     // =========================================================================== order by (level, program order), lay out
     std::stable_sort(gates.begin(), gates.end(), [](const PendingGate &a, const PendingGate &b) { return a.level < b.level; });
     std::stable_sort(records.begin(), records.end(), [](const PendingRecord &a, const PendingRecord &b) { return a.level < b.level; });
     uint32_t max_level = 0;
     for (auto &g : gates) max_level = std::max(max_level, g.level);
     for (auto &r : records) max_level = std::max(max_level, r.level);
+    for (auto &iv : inverses) max_level = std::max(max_level, iv.level);
     p.n_levels = max_level;
     p.level_start.assign(max_level + 1, 0);
     p.dyn_level_start.assign(max_level + 1, 0);
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k].assign(max_level + 1, 0);
-    size_t gi = 0, ri = 0;
+    size_t gi = 0, ri = 0, ii = 0;
     std::vector<uint32_t> width(max_level + 1, 0);
     for (uint32_t L = 1; L <= max_level; L++) {
         p.level_start[L - 1] = (uint32_t)p.gate_offset.size();
         p.dyn_level_start[L - 1] = (uint32_t)p.dyn_offset.size();
         for (int k = 0; k < N_CLS; k++) p.cls_level_start[k][L - 1] = (uint32_t)p.cls_offset[k].size();
         for (; gi < gates.size() && gates[gi].level == L; gi++) {
-            bool dyn = (gates[gi].words[0] & 0xff) == GATE_SOLVE_DYN;
-            (dyn ? p.dyn_offset : p.gate_offset).push_back((uint32_t)p.gate_stream.size());
+            p.gate_offset.push_back((uint32_t)p.gate_stream.size());
             p.gate_stream.insert(p.gate_stream.end(), gates[gi].words.begin(), gates[gi].words.end());
             width[L]++;
+        }
+        for (; ii < inverses.size() && inverses[ii].level == L; ii++) {  // inversion job: [denominator witness, opcode, inverse slot]
+            p.dyn_offset.push_back((uint32_t)p.gate_stream.size());
+            p.gate_stream.insert(p.gate_stream.end(), {inverses[ii].partner, inverses[ii].opcode, inverses[ii].gate});
         }
         for (; ri < records.size() && records[ri].level == L; ri++) {
             const PendingRecord &r = records[ri];

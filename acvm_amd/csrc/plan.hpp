@@ -28,11 +28,11 @@ static constexpr uint32_t COEF_ZERO = 0xFFFFFFFDu;  // only for the constant ter
 
 enum GateKind : uint32_t { GATE_ASSERT = 0, GATE_SOLVE = 1, GATE_SOLVE_DYN = 2 };
 
-// Gate record in the u32 stream (arith level kernels):
-//  w0 = kind | n_prod << 8 | n_lin << 16
-//  w1 = opcode index (program order)      w2 = output witness slot (SOLVE*)
-//  w3 = constant term (coef encoding)     w4 = denominator witness slot (SOLVE_DYN)
-//  then n_prod x {coef, a, b}, n_lin x {coef, a}
+// Gate record in the u32 stream (arith_level_kernel; layout and term lists: plan.cpp, consumed by gate_sum_lazy):
+//  w0 = kind | np_mac << 8 | nl_mac << 16   w1 = opcode index (program order)   w2 = output witness slot (SOLVE*)
+//  w3 = constant term (coef encoding)       w4 = slot of 1/denominator in the inverse table (SOLVE_DYN)
+//  w5 = counts of the unit-coefficient term lists, then the term lists
+// Inversion job (inverse_batch_kernel): [denominator witness, opcode index, inverse slot]
 static constexpr uint32_t GATE_HDR_WORDS = 5;
 
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
@@ -55,7 +55,7 @@ struct Plan {
     std::vector<uint32_t> gate_stream;          // all gate records
     std::vector<uint32_t> gate_offset;          // per scheduled ASSERT/SOLVE gate: offset into gate_stream (level-major)
     std::vector<uint32_t> level_start;          // size n_levels + 1, indexes gate_offset
-    std::vector<uint32_t> dyn_offset;           // per scheduled SOLVE_DYN gate (needs a per-instance inversion), level-major
+    std::vector<uint32_t> dyn_offset;           // per inversion job (denominator of a SOLVE_DYN gate), level-major
     std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
     // ---- in-order program: one record per opcode
@@ -78,6 +78,7 @@ struct Plan {
     uint32_t truncated_at = 0xFFFFFFFFu;
     // statistics
     uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0, n_other_records = 0;
+    uint32_t n_inverse_slots = 0;               // rows of the inverse table (slots are reused once their gate ran)
     uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
     uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     double plan_ms = 0;

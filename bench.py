@@ -167,7 +167,7 @@ def main():
         value = total_instances / elapsed
         # dominant kernel of the workload: the arithmetic level kernel, or the record class that took the most time
         cand = {"arith_level_kernel": (arith_ms, st["arith_algorithmic_bytes_per_instance"]),
-                "arith_dyn_level_kernel": (dyn_ms, st["dyn_algorithmic_bytes_per_instance"])}
+                "inverse_batch_kernel": (dyn_ms, st["dyn_algorithmic_bytes_per_instance"])}
         for k in range(4):
             cand[CLASS_KERNEL[k]] = (cls_ms[k], st["class_algorithmic_bytes_per_instance"][k])
         dominant = "arith_level_kernel" if args.workload == "arith" else max(cand, key=lambda k: cand[k][0])

@@ -78,6 +78,13 @@ int main() {
             if (fr29_is_zero_mod_p(fr29_lt2p(fr29_norm(fr29_subl(x, x, 1)))) != true) { fails++; printf("zero test mismatch %d\n", it); }
             if (fr29_is_zero_mod_p(fr29_mul(x, y)) != (a.is_zero() || b.is_zero())) { fails++; printf("zero test 2 mismatch %d\n", it); }
         }
+        {   // squaring, also of an unreduced operand (3a + b, limbs renormalised)
+            const Fr29 x = fr29_from(da), y = fr29_from(db);
+            if (!same(fr29_pack(fr29_canon(fr29_sqr(x))), frh::mul(a, a))) { fails++; printf("sqr mismatch %d\n", it); }
+            const Fr29 z = fr29_norm(fr29_addl(fr29_addl(fr29_dbll(x), x), y));
+            const FrH zh = frh::add(frh::add(frh::add(a, a), a), b);
+            if (!same(fr29_pack(fr29_canon(fr29_sqr(z))), frh::mul(zh, zh))) { fails++; printf("lazy sqr mismatch %d\n", it); }
+        }
         {   // sums of products with one reduction: a*b + b*b + (a+a)*a and a*a + b*a
             const Fr29 x = fr29_from(da), y = fr29_from(db), x2 = fr29_norm(fr29_dbll(x));
             const Fr29 l3[3] = {x, y, x2}, r3[3] = {y, y, x};

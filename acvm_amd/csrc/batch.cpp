@@ -293,9 +293,11 @@ static int batch_init(acvm_batch *b) {
     b->dp.consts = b->d_consts;
     b->dp.bytecode = b->d_bytecode;
     b->dp.Mem = b->d_Mem;
-    b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr};
+    b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (p.needs_grumpkin) {
-        const GrumpkinTables *t = grumpkin_tables();
+        // the level schedule's Pedersen kernel reads the 503 MB pair table (one mixed addition per 18 bits of input)
+        const bool pairs = !p.cls_offset[CLS_PEDERSEN].empty();
+        const GrumpkinTables *t = pairs ? grumpkin_pair_table() : grumpkin_tables();
         if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
         b->dp.grumpkin = *t;
     }

@@ -267,8 +267,28 @@ const GrumpkinTables *grumpkin_tables() {
     t.win = (const uint4 *)(d + g_host.win_off * 16);
     t.small = (const uint4 *)(d + g_host.small_off * 16);
     t.skew = (const uint4 *)(d + g_host.skew_off * 16);
+    t.ped2 = nullptr;
     auto ins = g_dev.emplace(dev, t);
     return &ins.first->second;
+}
+
+void launch_pedersen_pair_table(hipStream_t s, const GrumpkinTables &T, uint4 *out);  // kernels_grumpkin.hip
+
+const GrumpkinTables *grumpkin_pair_table() {
+    const GrumpkinTables *base = grumpkin_tables();
+    if (!base) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    GrumpkinTables &t = g_dev.find(dev)->second;
+    if (t.ped2) return &t;
+    uint4 *d = nullptr;
+    const size_t entries = (size_t)30 << GRUMPKIN_PED2_LOG2;
+    if (hipMalloc((void **)&d, entries * 64) != hipSuccess) return nullptr;
+    launch_pedersen_pair_table(nullptr, t, d);
+    if (hipDeviceSynchronize() != hipSuccess) { hipFree(d); return nullptr; }
+    t.ped2 = d;
+    return &t;
 }
 
 const void *grumpkin_tables_device() { return grumpkin_tables(); }

@@ -16,10 +16,17 @@ struct GrumpkinTables {
     const uint4 *win;    // [4][32][255]
     const uint4 *small;  // [3][15]: k * D[3j+1], k = 1..15
     const uint4 *skew;   // [3]: D[3j+2]
+    const uint4 *ped2;   // [30][512][512] pair table of the level Pedersen kernel (grumpkin_pair_table), else nullptr
 };
+static constexpr uint32_t GRUMPKIN_PED2_LOG2 = 18;  // entries per generator
 
 // tables of the current device (built on first use), nullptr on failure
 const GrumpkinTables *grumpkin_tables();
+// the same tables with ped2 built (503 MB of HBM, generated on the device on first use): entry [g][a][b] is
+// beta((a + 1) D[g]) + (b + 1) D[g], i.e. the contribution of two consecutive 9-bit slices of a plookup Pedersen
+// hash_single (the even slice goes through the endomorphism), so that the level kernel pays one mixed addition per 18 bits
+// instead of two. For the last generator of a value (g % 15 == 14, one slice only) the entry is beta((a + 1) D[g]).
+const GrumpkinTables *grumpkin_pair_table();
 bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]);
 
 }  // namespace acvm

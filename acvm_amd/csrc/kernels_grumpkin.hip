@@ -23,14 +23,15 @@ void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DevicePro
 
 // ---------------------------------------------------------------------------------------------- Pedersen, 4 waves per instance group
 // One Pedersen record is a chain of (n + 1) hash_pairs, each 2 x 29 dependent table additions plus a normalisation: a single
-// wave per 64 instances is issue-bound on that chain and a level rarely holds enough records to fill 1024 SIMDs. Here a
-// workgroup of four waves serves 64 instances: wave w accumulates one of the four independent sums of a hash_pair
-// (w >> 1 = left / right operand, w & 1 = even / odd 9-bit slices), the partial points meet in LDS, wave 0 adds them,
-// normalises (one inversion) and publishes the x coordinate that seeds the next hash_pair. The other waves wait at the
-// barrier and leave their issue slots to the rest of the chip. Result: the chain is ~2.8x shorter and 4x more waves are
-// resident. FastPolicy only (level schedule); flagged instances take the one-lane exact kernel (same group elements, so
-// the affine results are identical).
-__global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
+// wave per 64 instances is issue-bound on that chain and a level rarely holds enough records to fill 1024 SIMDs. Here
+//  * the pair table (GrumpkinTables::ped2, 503 MB of the 288 GB) holds, per generator, the sum of the two points that two
+//    consecutive 9-bit slices select (the even slice already through the endomorphism): 2 x 15 additions per hash_pair, and
+//  * a workgroup of four waves serves 64 instances: wave w accumulates generators [0, 8) or [8, 15) (w & 1) of the left or
+//    right operand (w >> 1), the partial points meet in LDS, one wave adds them, normalises (one inversion) and
+//    publishes the x coordinate that seeds the next hash_pair.
+// FastPolicy only (level schedule); flagged instances take the one-lane exact kernel on the small tables (same group
+// elements, so the affine results are identical).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
                                                                   uint32_t *__restrict__ event) {
     __shared__ uint32_t lds_acc[4][27][64];  // [wave][limb of X, Y, Z (9 x 29-bit each)][lane]
     __shared__ uint32_t lds_r[16][64];       // affine result of the step (Montgomery limbs of x, y)
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint
         if (wave == 0 && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) atomicMin(&event[j], rec[1]);
         return;
     }
-    const uint32_t parity = wave >> 1, odd = wave & 1u;
+    const uint32_t parity = wave >> 1, half = wave & 1u;
     Fr r = fr_one(), y = fr_zero();  // IV[0].x = G.x = 1
     if (hash_index != 0) {  // IV[hash_index] = (hash_index + 1) * G: wave-uniform, every lane computes it
         Fr k = fr_zero();
@@ -59,13 +60,13 @@ __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint
         Fr src = r;
         if (parity) src = step == 0 ? fr_from_u32(n) : (active ? p.load(ws[step - 1]) : fr_one());
         const Fr v = fr_to_canonical(src);
+        // generators [i0, i1) of this operand: one pair-table entry per 18 bits (even slice through the endomorphism + odd slice)
         GJac acc = gj_inf();
-        const uint32_t gen0 = parity ? 15u : 0u, n_slices = odd ? 14u : 15u;
-        for (uint32_t i = 0; i < n_slices; i++) {
-            const uint32_t pos = 18u * i + (odd ? 9u : 0u);
-            acc = gj_add_aff(acc, gaff_load(T.ped, (gen0 + i) * GRUMPKIN_PED_ENTRIES + bits_at(v, pos, 9)));
+        const uint32_t gen0 = parity ? 15u : 0u, i0 = half ? 8u : 0u, i1 = half ? 15u : 8u;
+        for (uint32_t i = i0; i < i1; i++) {
+            const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
+            acc = gj_add_aff(acc, gaff_load(T.ped2, ((gen0 + i) << GRUMPKIN_PED2_LOG2) | a << 9 | b));
         }
-        if (!odd) acc.X = fr29_mul(acc.X, fr29_from(grumpkin_beta()));  // endomorphism on the even-slice accumulator
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             lds_acc[wave][k][lane] = acc.X.v[k];
@@ -73,9 +74,13 @@ __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint
             lds_acc[wave][18 + k][lane] = acc.Z.v[k];
         }
         __syncthreads();
-        if (wave == 0) {
+        // The serial tail of the step (three additions, one inversion) rotates over the four waves: a block's wave w sits on
+        // SIMD w of its CU, and with a fixed leader SIMD 0 carried the tails of all four resident blocks while the other
+        // three idled (measured: 1.5x the balanced time).
+        if (wave == ((blockIdx.x + blockIdx.y + step) & 3u)) {
             GJac s = acc;
-            for (uint32_t w2 = 1; w2 < 4; w2++) {
+            for (uint32_t dw = 1; dw < 4; dw++) {
+                const uint32_t w2 = (wave + dw) & 3u;
                 GJac o;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
@@ -87,7 +92,6 @@ __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint
             }
             bool inf;
             const GAff a = gj_to_aff(s, &inf);
-            y = a.y;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 lds_r[k][lane] = a.x.v[k];
@@ -96,10 +100,34 @@ __global__ void __launch_bounds__(256) pedersen_quad_level_kernel(uint4 *W, uint
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 8; k++) r.v[k] = lds_r[k][lane];
+        for (int k = 0; k < 8; k++) {
+            r.v[k] = lds_r[k][lane];
+            y.v[k] = lds_r[8 + k][lane];
+        }
         __syncthreads();  // lds_r / lds_acc are rewritten by the next step
     }
     if (wave == 0 && active && (!p.insert(rec[4], r, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
+}
+
+// pair table of the level Pedersen kernel (grumpkin_host.hpp GrumpkinTables::ped2): one lane per entry
+__global__ void __launch_bounds__(64) pedersen_pair_table_kernel(GrumpkinTables T, uint4 *__restrict__ out) {
+    const uint32_t e = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t gen = e >> GRUMPKIN_PED2_LOG2, a = (e >> 9) & 511u, b = e & 511u;
+    GAff pa = gaff_load(T.ped, gen * GRUMPKIN_PED_ENTRIES + a);
+    pa.x = fr_mul(pa.x, grumpkin_beta());  // (x, y) -> (beta x, y)
+    GAff r = pa;
+    if (gen % 15u != 14u) {
+        bool inf;
+        r = gj_to_aff(gj_add_aff(gj_add_aff(gj_inf(), pa), gaff_load(T.ped, gen * GRUMPKIN_PED_ENTRIES + b)), &inf);
+    }
+    uint4 *p = out + (uint64_t)e * 4;
+    p[0] = make_uint4(r.x.v[0], r.x.v[1], r.x.v[2], r.x.v[3]);
+    p[1] = make_uint4(r.x.v[4], r.x.v[5], r.x.v[6], r.x.v[7]);
+    p[2] = make_uint4(r.y.v[0], r.y.v[1], r.y.v[2], r.y.v[3]);
+    p[3] = make_uint4(r.y.v[4], r.y.v[5], r.y.v[6], r.y.v[7]);
+}
+void launch_pedersen_pair_table(hipStream_t s, const GrumpkinTables &T, uint4 *out) {
+    hipLaunchKernelGGL(pedersen_pair_table_kernel, dim3((30u << GRUMPKIN_PED2_LOG2) / 64), dim3(64), 0, s, T, out);
 }
 
 void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,

@@ -145,7 +145,7 @@ def main():
         from oracle import binding as ob
         cores = os.cpu_count() or 1
         threads = min(cores, 64)
-        per = {"arith": 8, "hash": 64, "grumpkin": 2, "arith_pedersen": 4, "mixed": 4}[args.workload]
+        per = {"arith": 24, "hash": 1024, "grumpkin": 256, "arith_pedersen": 16, "mixed": 16}[args.workload]  # a few seconds of all host cores
         sample = args.cpu_sample or min(B, max(64, per * threads))
         oc = ob.Circuit(data)
         sample_vals = values[: sample * len(ids) * 32]

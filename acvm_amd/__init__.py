@@ -26,7 +26,8 @@ ABI_SYMBOLS = [
     "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_reset", "acvm_batch_set_force_slow_path",
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
     "acvm_batch_set_profiling", "acvm_batch_pending_foreign_call", "acvm_batch_pending_foreign_call_inputs",
-    "acvm_batch_resolve_foreign_call",
+    "acvm_batch_resolve_foreign_call", "acvm_circuit_assert_message", "acvm_circuit_witness_set", "acvm_batch_error_string",
+    "acvm_batch_extract_witnesses",
 ]
 
 
@@ -171,6 +172,10 @@ def lib():
     L.acvm_batch_pending_foreign_call.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ForeignCallInfo)]
     L.acvm_batch_pending_foreign_call_inputs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.acvm_batch_resolve_foreign_call.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_char_p]
+    L.acvm_circuit_assert_message.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.acvm_circuit_witness_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
+    L.acvm_batch_error_string.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.acvm_batch_extract_witnesses.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L
     return L
 
@@ -225,6 +230,22 @@ class Circuit:
         if getattr(self, "_h", None) and _lib is not None:
             _lib.acvm_circuit_free(self._h)
             self._h = None
+
+    LOCATION_ACIR = 0xFFFFFFFF
+    SETS = {"private_parameters": 0, "public_parameters": 1, "return_values": 2, "public_inputs": 3, "circuit_arguments": 4}
+
+    def get_assert_message(self, acir_index: int, brillig_index: int = None):
+        """Circuit::get_assert_message (circuit/mod.rs:43-51) for OpcodeLocation::Acir / ::Brillig; None if there is none."""
+        buf = C.create_string_buffer(4096)
+        n = lib().acvm_circuit_assert_message(self._h, acir_index, self.LOCATION_ACIR if brillig_index is None else brillig_index, buf, 4096)
+        return None if n < 0 else buf.value.decode()
+
+    def witness_set(self, which: str):
+        """private_parameters / public_parameters / return_values / public_inputs() / circuit_arguments() (circuit/mod.rs:25-32,109-121)."""
+        n = _check(lib().acvm_circuit_witness_set(self._h, self.SETS[which], None, 0))
+        arr = (C.c_uint32 * max(n, 1))()
+        _check(lib().acvm_circuit_witness_set(self._h, self.SETS[which], arr, n))
+        return list(arr[:n])
 
     def plan_stats(self, initial_ids) -> dict:
         """Host-only levelisation (no device): statistics of the static plan; raises if an opcode has no kernel."""
@@ -296,6 +317,23 @@ class Batch:
         vals = np.zeros((n, self.nw, 32), dtype=np.uint8)
         _check(lib().acvm_batch_witness_map(self._h, first, n, asg.ctypes.data, vals.ctypes.data))
         return asg, vals
+
+    def error_string(self, instance: int) -> str:
+        """The string acvm_js reports for a failed instance (execute.rs:79-108): assert message or the error's Display text."""
+        buf = C.create_string_buffer(1024)
+        _check(lib().acvm_batch_error_string(self._h, self.circuit._h, instance, buf, 1024))
+        return buf.value.decode()
+
+    def extract(self, witnesses, first=0, n=None):
+        """extract_indices (public_witness.rs:10-21) for instances [first, first + n): uint8 array [n][len(witnesses)][32];
+        raises if a witness is unassigned. Use with Circuit.witness_set("return_values" | "public_parameters" | "public_inputs")."""
+        import numpy as np
+        n = self.B - first if n is None else n
+        ws = list(witnesses)
+        arr = (C.c_uint32 * max(len(ws), 1))(*ws)
+        vals = np.zeros((n, len(ws), 32), dtype=np.uint8)
+        _check(lib().acvm_batch_extract_witnesses(self._h, arr, len(ws), first, n, vals.ctypes.data))
+        return vals
 
     def get_pending_foreign_call(self, instance: int):
         """ACVM::get_pending_foreign_call: None, or (function, [[int, ...] per input])."""

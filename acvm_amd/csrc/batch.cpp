@@ -977,21 +977,89 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
     }
 }
 
+static void fill_result(acvm_batch *b, uint32_t j, acvm_result_t &r) {
+    memset(&r, 0, sizeof r);
+    if (b->plan.n_opcodes == 0 || b->slow_index[j] < 0) { r.status = ACVM_STATUS_SOLVED; return; }
+    const SlowResult &sr = b->slow_res[b->slow_index[j]];
+    r.status = sr.status; r.err = sr.err; r.opcode_index = sr.opcode_index; r.aux0 = sr.aux0; r.aux1 = sr.aux1;
+    r.n_call_stack = sr.n_call_stack > 16 ? 16 : sr.n_call_stack;
+    for (uint32_t k = 0; k < r.n_call_stack; k++) r.call_stack[k] = sr.call_stack[k];
+    if (sr.status == ACVM_STATUS_FAILURE && sr.msg) format_message(b, j, sr, r);
+}
+
 int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out) {
     if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     HIPCHK(hipSetDevice(b->device));
-    for (uint32_t j = 0; j < b->B; j++) {
-        acvm_result_t &r = out[j];
-        memset(&r, 0, sizeof r);
-        if (b->plan.n_opcodes == 0 || b->slow_index[j] < 0) { r.status = ACVM_STATUS_SOLVED; continue; }
-        const SlowResult &sr = b->slow_res[b->slow_index[j]];
-        r.status = sr.status; r.err = sr.err; r.opcode_index = sr.opcode_index; r.aux0 = sr.aux0; r.aux1 = sr.aux1;
-        r.n_call_stack = sr.n_call_stack > 16 ? 16 : sr.n_call_stack;
-        for (uint32_t k = 0; k < r.n_call_stack; k++) r.call_stack[k] = sr.call_stack[k];
-        if (sr.status == ACVM_STATUS_FAILURE && sr.msg) format_message(b, j, sr, r);
-    }
+    for (uint32_t j = 0; j < b->B; j++) fill_result(b, j, out[j]);
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- after solve
+int acvm_circuit_assert_message(const acvm_circuit_t *c, uint32_t acir_index, uint32_t brillig_index, char *out, size_t cap) {
+    if (!c) return set_err(ACVM_E_INVALID, "null argument");
+    const bool want_brillig = brillig_index != ACVM_LOCATION_ACIR;
+    for (const AssertMessage &m : c->c->assert_messages) {  // first match, like the reference's linear find
+        if (m.is_brillig != want_brillig || m.acir_index != acir_index || (want_brillig && m.brillig_index != brillig_index)) continue;
+        if (out && cap) snprintf(out, cap, "%s", m.message.c_str());
+        return (int)m.message.size();
+    }
+    if (out && cap) out[0] = 0;
+    return -1;
+}
+
+int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, uint32_t cap) {
+    if (!c) return set_err(ACVM_E_INVALID, "null argument");
+    const Circuit &k = *c->c;
+    std::vector<uint32_t> v;
+    switch (which) {
+    case ACVM_SET_PRIVATE_PARAMETERS: v = k.private_parameters; break;
+    case ACVM_SET_PUBLIC_PARAMETERS: v = k.public_parameters; break;
+    case ACVM_SET_RETURN_VALUES: v = k.return_values; break;
+    case ACVM_SET_PUBLIC_INPUTS: v = k.public_parameters; v.insert(v.end(), k.return_values.begin(), k.return_values.end()); break;
+    case ACVM_SET_CIRCUIT_ARGUMENTS: v = k.private_parameters; v.insert(v.end(), k.public_parameters.begin(), k.public_parameters.end()); break;
+    default: return set_err(ACVM_E_INVALID, "unknown witness set");
+    }
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    for (uint32_t i = 0; i < v.size() && i < cap && out; i++) out[i] = v[i];
+    return (int)v.size();
+}
+
+int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap) {
+    if (!b || !out || !cap) return set_err(ACVM_E_INVALID, "null argument");
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if (instance >= b->B) return set_err(ACVM_E_INVALID, "instance out of range");
+    HIPCHK(hipSetDevice(b->device));
+    acvm_result_t r;
+    fill_result(b, instance, r);
+    out[0] = 0;
+    if (r.status != ACVM_STATUS_FAILURE) return 0;
+    static const char *bb_name[BB_COUNT] = {"and", "xor", "range", "sha256", "blake2s", "schnorr_verify", "pedersen", "hash_to_field_128_security",
+                                           "ecdsa_secp256k1", "ecdsa_secp256r1", "fixed_base_scalar_mul", "keccak256", "keccak256",
+                                           "recursive_aggregation"};
+    const char *func = r.aux0 < BB_COUNT ? bb_name[r.aux0] : "?";
+    char msg[512];
+    int have = -1;
+    if (c) {
+        if (r.err == ACVM_ERR_UNSATISFIED || r.err == ACVM_ERR_INDEX_OOB)
+            have = acvm_circuit_assert_message(c, r.opcode_index, ACVM_LOCATION_ACIR, msg, sizeof msg);
+        else if (r.err == ACVM_ERR_BRILLIG_FAILED && r.n_call_stack)
+            have = acvm_circuit_assert_message(c, r.opcode_index, r.call_stack[r.n_call_stack - 1], msg, sizeof msg);
+    }
+    if (have >= 0) return snprintf(out, cap, "Assertion failed: %s", msg);
+    switch (r.err) {
+    case ACVM_ERR_MISSING_ASSIGNMENT: return snprintf(out, cap, "Cannot solve opcode: missing assignment for witness index %u", r.aux0);
+    case ACVM_ERR_TOO_MANY_UNKNOWNS: return snprintf(out, cap, "Cannot solve opcode: expression has too many unknowns");
+    case ACVM_ERR_UNSUPPORTED_BLACKBOX:
+        return snprintf(out, cap, "Backend does not currently support the %s opcode. ACVM does not currently have a fallback for this opcode.", func);
+    case ACVM_ERR_UNSATISFIED: return snprintf(out, cap, "Cannot satisfy constraint");
+    case ACVM_ERR_INDEX_OOB: return snprintf(out, cap, "Index out of bounds, array has size %u, but index was %u", r.aux1, r.aux0);
+    case ACVM_ERR_BLACKBOX_FAILED: return snprintf(out, cap, "Failed to solve blackbox function: %s, reason: %s", func, r.message);
+    case ACVM_ERR_BRILLIG_FAILED: return snprintf(out, cap, "Failed to solve brillig function, reason: %s", r.message);
+    case ACVM_ERR_PANIC: return snprintf(out, cap, "panicked: %s", r.message);
+    default: return snprintf(out, cap, "unknown error %u", r.err);
+    }
 }
 
 // assigned flags of instance j over all witnesses (host side bookkeeping + slow-path bitmap)
@@ -1051,6 +1119,46 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     for (size_t i = 0; i < (size_t)n * nw; i++)
         if (!assigned[i]) memset(values_be32 + i * 32, 0, 32);
     return 0;
+}
+
+int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,
+                                 uint8_t *values_be32) {
+    if (!b || (n_witnesses && (!witnesses || !values_be32))) return set_err(ACVM_E_INVALID, "null argument");
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
+    if (!n || !n_witnesses) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    const uint32_t nw = b->plan.n_witnesses;
+    char text[160];
+    for (uint32_t k = 0; k < n_witnesses; k++)
+        if (witnesses[k] >= nw) {
+            snprintf(text, sizeof text, "Failed to extract witness %u from witness map. Witness not found. (instance %u)", witnesses[k], first);
+            return set_err(ACVM_E_STATE, text);
+        }
+    std::vector<uint8_t> assigned((size_t)n * nw);
+    if (int rc = fetch_assigned(b, first, n, assigned.data())) return rc;
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t k = 0; k < n_witnesses; k++)
+            if (!assigned[(size_t)i * nw + witnesses[k]]) {
+                snprintf(text, sizeof text, "Failed to extract witness %u from witness map. Witness not found. (instance %u)", witnesses[k], first + i);
+                return set_err(ACVM_E_STATE, text);
+            }
+    uint32_t *d_sel = nullptr;
+    uint8_t *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_sel, (size_t)n_witnesses * 4));
+    hipError_t e = hipMemcpy(d_sel, witnesses, (size_t)n_witnesses * 4, hipMemcpyHostToDevice);
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)n_witnesses * 32));
+    if (chunk > n) chunk = n;
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)chunk * n_witnesses * 32);
+    for (uint32_t done = 0; done < n && e == hipSuccess; done += chunk) {
+        const uint32_t m = std::min(chunk, n - done);
+        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, n_witnesses, d_out);
+        e = hipMemcpyAsync(values_be32 + (size_t)done * n_witnesses * 32, d_out, (size_t)m * n_witnesses * 32, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    }
+    if (d_out) hipFree(d_out);
+    if (d_sel) hipFree(d_sel);
+    return e == hipSuccess ? 0 : set_err(ACVM_E_DEVICE, hipGetErrorString(e));
 }
 
 int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uint8_t *assigned) {

@@ -188,6 +188,40 @@ int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t
 /* enable per-kernel HIP-event timing of the level kernels (small overhead) */
 int acvm_batch_set_profiling(acvm_batch_t *b, int on);
 
+/*
+ * What a caller does right after solve.
+ *
+ * Circuit::get_assert_message (acir/src/circuit/mod.rs:43-51) for OpcodeLocation::Acir(acir_index) (brillig_index =
+ * ACVM_LOCATION_ACIR) or OpcodeLocation::Brillig{acir_index, brillig_index}. Copies the NUL-terminated message (truncated to
+ * cap) and returns its full length, or returns -1 when the location has no message.
+ */
+#define ACVM_LOCATION_ACIR 0xFFFFFFFFu
+int acvm_circuit_assert_message(const acvm_circuit_t *c, uint32_t acir_index, uint32_t brillig_index, char *out, size_t cap);
+/*
+ * Witness sets of the circuit, ascending (they are BTreeSets in the reference): private_parameters, public_parameters,
+ * return_values (circuit/mod.rs:25-32), public_inputs() = public_parameters U return_values (:115-121),
+ * circuit_arguments() = private U public parameters (:109-113). Writes up to cap indices, returns the size of the set.
+ */
+enum { ACVM_SET_PRIVATE_PARAMETERS = 0, ACVM_SET_PUBLIC_PARAMETERS = 1, ACVM_SET_RETURN_VALUES = 2, ACVM_SET_PUBLIC_INPUTS = 3,
+       ACVM_SET_CIRCUIT_ARGUMENTS = 4 };
+int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, uint32_t cap);
+/*
+ * The error string acvm_js reports for a failed instance (acvm_js/src/execute.rs:79-108): "Assertion failed: <message>" when
+ * the failing location -- the opcode of UnsatisfiedConstrain / IndexOutOfBounds, the last call-stack entry of
+ * BrilligFunctionFailed -- has an assert message in `c`, else the Display text of the OpcodeResolutionError
+ * (acvm/src/pwg/mod.rs:100-114). Returns the full length; 0 and an empty string for an instance that did not fail.
+ * (ExpressionHasTooManyUnknowns is reported without the expression text.)
+ */
+int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap);
+/*
+ * extract_indices (acvm_js/src/public_witness.rs:10-21; getReturnWitness / getPublicParametersWitness / getPublicWitness
+ * with the sets above): values of the listed witnesses for instances [first, first + n), values_be32 = [n][n_witnesses][32].
+ * Fails with ACVM_E_STATE and "Failed to extract witness W from witness map. Witness not found." (instance appended) when
+ * one of them is unassigned in one of the instances.
+ */
+int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,
+                                 uint8_t *values_be32);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+"""What a caller does right after solve, on solved batches: the error string of acvm_js/src/execute.rs:79-108
+(assert message for the failing location, else the Display text of OpcodeResolutionError, acvm/src/pwg/mod.rs:100-114) and
+extract_indices / getReturnWitness / getPublicWitness (acvm_js/src/public_witness.rs)."""
+import numpy as np
+import pytest
+
+import acvm_amd
+from acvm_amd.acir import P, BlackBoxFuncCall as BB, Circuit, Expression as E, FunctionInput as FI, MemoryInit, MemoryOp
+from acvm_amd.synth import be32
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(circ, ids, rows):
+    c = acvm_amd.Circuit(circ.to_bytes())
+    b = acvm_amd.Batch(c, len(rows), ids)
+    b.set_initial_witness(b"".join(be32(v) for row in rows for v in row))
+    b.solve()
+    return c, b
+
+
+def test_error_strings_and_assert_messages():
+    # opcode 0: w3 = w1 * w2; opcode 1: assert w3 == w4 (message); opcode 2: RANGE(w1, 8) (no message); opcode 3: memory read
+    ops = [E([(1, 1, 2)], [(P - 1, 3)], 0), E([], [(1, 3), (P - 1, 4)], 0), BB("RANGE", {"input": FI(1, 8)}), MemoryInit(0, [1, 2]),
+           MemoryOp(0, E.constant(0), E.from_witness(5), E.from_witness(6))]
+    circ = Circuit(6, ops, private_parameters=[1, 2, 4, 5], return_values=[3],
+                   assert_messages=[(1, "product check failed"), (4, "index in range")])
+    rows = [[3, 5, 15, 1], [3, 5, 16, 0], [300, 1, 300, 0], [3, 5, 15, 2]]
+    c, b = solve(circ, [1, 2, 4, 5], rows)
+    res = b.results()
+    assert [r.status for r in res] == [0, 2, 2, 2]
+    assert b.error_string(0) == ""
+    assert b.error_string(1) == "Assertion failed: product check failed"
+    assert b.error_string(2) == "Cannot satisfy constraint"                       # RANGE at opcode 2 has no message
+    assert b.error_string(3) == "Assertion failed: index in range"                # IndexOutOfBounds at opcode 4
+    # without the message table the Display text of the error is reported
+    plain = Circuit(6, ops, private_parameters=[1, 2, 4, 5], return_values=[3])
+    c2, b2 = solve(plain, [1, 2, 4, 5], rows)
+    assert b2.error_string(1) == "Cannot satisfy constraint"
+    assert b2.error_string(3) == "Index out of bounds, array has size 2, but index was 2"
+
+
+def test_missing_assignment_and_blackbox_failure_text():
+    circ = Circuit(9, [BB("RANGE", {"input": FI(9, 8)})])
+    c, b = solve(circ, [1], [[1]])
+    assert b.error_string(0) == "Cannot solve opcode: missing assignment for witness index 9"
+    circ = Circuit(4, [BB("FixedBaseScalarMul", {"low": FI(1, 128), "high": FI(2, 128), "outputs": [3, 4]})])
+    c, b = solve(circ, [1, 2], [[1 << 128, 0]])
+    assert b.error_string(0) == ("Failed to solve blackbox function: fixed_base_scalar_mul, reason: Limb "
+                                 "0000000000000000000000000000000100000000000000000000000000000000 is not less than 2^128")
+
+
+def test_extract_return_and_public_witnesses():
+    ops = [E([(1, 1, 2)], [(P - 1, 4)], 0), E([], [(1, 4), (1, 3), (P - 1, 5)], 0)]
+    circ = Circuit(5, ops, private_parameters=[1, 2], public_parameters=[3], return_values=[5])
+    rows = [[2, 3, 4], [5, 6, 7], [P - 1, 2, 1]]
+    c, b = solve(circ, [1, 2, 3], rows)
+    ret = b.extract(c.witness_set("return_values"))
+    assert [int.from_bytes(ret[j, 0].tobytes(), "big") for j in range(3)] == [(r[0] * r[1] + r[2]) % P for r in rows]
+    pub = b.extract(c.witness_set("public_inputs"), first=1, n=2)
+    assert pub.shape == (2, 2, 32) and int.from_bytes(pub[0, 0].tobytes(), "big") == 7
+    asg, full = b.witness_map()
+    assert np.array_equal(pub[1, 1], full[2, 5])
+    # a failed instance leaves the return value unassigned: extract_indices reports the witness
+    bad = Circuit(5, [E([], [(1, 1), (P - 1, 2)], 0)] + ops, private_parameters=[1, 2], public_parameters=[3], return_values=[5])
+    c, b = solve(bad, [1, 2, 3], [[2, 2, 4], [2, 3, 4]])
+    assert b.results()[1].status == 2
+    b.extract([5], first=0, n=1)
+    with pytest.raises(acvm_amd.AcvmError, match="Failed to extract witness 4 from witness map. Witness not found."):
+        b.extract([4, 5])

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
     "acvm_batch_set_profiling", "acvm_batch_pending_foreign_call", "acvm_batch_pending_foreign_call_inputs",
     "acvm_batch_resolve_foreign_call", "acvm_circuit_assert_message", "acvm_circuit_witness_set", "acvm_batch_error_string",
-    "acvm_batch_extract_witnesses",
+    "acvm_batch_extract_witnesses", "acvm_witness_map_decode", "acvm_witness_map_encode", "acvm_batch_witness_map_bytes",
 ]
 
 
@@ -176,6 +176,11 @@ def lib():
     L.acvm_circuit_witness_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
     L.acvm_batch_error_string.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
     L.acvm_batch_extract_witnesses.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    for f in (L.acvm_witness_map_decode, L.acvm_witness_map_encode, L.acvm_batch_witness_map_bytes):
+        f.restype = C.c_longlong
+    L.acvm_witness_map_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.acvm_witness_map_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -214,6 +219,26 @@ def debug_grumpkin(what, param, inputs=()):
     data = b"".join(int(v).to_bytes(32, "big") for v in inputs)
     _check(lib().acvm_debug_grumpkin(what, param, data, len(inputs), out))
     return int.from_bytes(out.raw[:32], "big"), int.from_bytes(out.raw[32:], "big")
+
+
+def decompress_witness(data: bytes) -> dict:
+    """WitnessMap::try_from(&[u8]) (witness_map.rs:135-146; acvm_js decompressWitness): {witness index: int}."""
+    n = _check(lib().acvm_witness_map_decode(data, len(data), None, None, 0))
+    ids = (C.c_uint32 * max(n, 1))()
+    vals = C.create_string_buffer(32 * max(n, 1))
+    _check(lib().acvm_witness_map_decode(data, len(data), ids, vals, n))
+    return {ids[i]: int.from_bytes(vals.raw[32 * i:32 * i + 32], "big") for i in range(n)}
+
+
+def compress_witness(witness_map: dict) -> bytes:
+    """Vec<u8>::try_from(WitnessMap) (witness_map.rs:108-119; acvm_js compressWitness)."""
+    items = sorted(witness_map.items())
+    ids = (C.c_uint32 * max(len(items), 1))(*[k for k, _ in items])
+    vals = b"".join(int(v).to_bytes(32, "big") for _, v in items)
+    n = _check(lib().acvm_witness_map_encode(ids, vals, len(items), None, 0))
+    out = C.create_string_buffer(max(n, 1))
+    _check(lib().acvm_witness_map_encode(ids, vals, len(items), out, n))
+    return out.raw[:n]
 
 
 class Circuit:
@@ -334,6 +359,13 @@ class Batch:
         vals = np.zeros((n, len(ws), 32), dtype=np.uint8)
         _check(lib().acvm_batch_extract_witnesses(self._h, arr, len(ws), first, n, vals.ctypes.data))
         return vals
+
+    def witness_map_bytes(self, instance: int) -> bytes:
+        """The instance's WitnessMap in the reference's wire format (finalize() + compressWitness)."""
+        n = _check(lib().acvm_batch_witness_map_bytes(self._h, instance, None, 0))
+        out = C.create_string_buffer(max(n, 1))
+        _check(lib().acvm_batch_witness_map_bytes(self._h, instance, out, n))
+        return out.raw[:n]
 
     def get_pending_foreign_call(self, instance: int):
         """ACVM::get_pending_foreign_call: None, or (function, [[int, ...] per input])."""

@@ -1161,6 +1161,45 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
     return e == hipSuccess ? 0 : set_err(ACVM_E_DEVICE, hipGetErrorString(e));
 }
 
+long long acvm_witness_map_decode(const uint8_t *bytes, size_t len, uint32_t *ids, uint8_t *values_be32, uint32_t cap) {
+    if (!bytes) return set_err(ACVM_E_INVALID, "null argument");
+    std::vector<uint32_t> id;
+    std::vector<uint8_t> val;
+    std::string err;
+    if (!witness_map_from_bytes(bytes, len, id, val, err)) return set_err(ACVM_E_MALFORMED, err.c_str());
+    for (size_t i = 0; i < id.size() && i < cap; i++) {
+        if (ids) ids[i] = id[i];
+        if (values_be32) memcpy(values_be32 + 32 * i, val.data() + 32 * i, 32);
+    }
+    return (long long)id.size();
+}
+
+long long acvm_witness_map_encode(const uint32_t *ids, const uint8_t *values_be32, uint32_t n, uint8_t *out, size_t cap) {
+    if (n && (!ids || !values_be32)) return set_err(ACVM_E_INVALID, "null argument");
+    std::vector<uint8_t> bytes;
+    std::string err;
+    if (!witness_map_to_bytes(ids, values_be32, n, bytes, err)) return set_err(ACVM_E_INVALID, err.c_str());
+    if (out && bytes.size() <= cap) memcpy(out, bytes.data(), bytes.size());
+    return (long long)bytes.size();
+}
+
+long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8_t *out, size_t cap) {
+    if (!b) return set_err(ACVM_E_INVALID, "null argument");
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if (instance >= b->B) return set_err(ACVM_E_INVALID, "instance out of range");
+    const uint32_t nw = b->plan.n_witnesses;
+    std::vector<uint8_t> assigned(nw ? nw : 1), values((size_t)(nw ? nw : 1) * 32);
+    if (int rc = acvm_batch_witness_map(b, instance, 1, assigned.data(), values.data())) return rc;
+    std::vector<uint32_t> ids;
+    std::vector<uint8_t> vals;
+    for (uint32_t w = 0; w < nw; w++)
+        if (assigned[w]) {
+            ids.push_back(w);
+            vals.insert(vals.end(), values.begin() + (size_t)w * 32, values.begin() + (size_t)w * 32 + 32);
+        }
+    return acvm_witness_map_encode(ids.data(), vals.data(), (uint32_t)ids.size(), out, cap);
+}
+
 int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uint8_t *assigned) {
     if (!b || !out_be32 || !assigned) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");

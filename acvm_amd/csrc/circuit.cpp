@@ -2,6 +2,7 @@
 // (fixint little-endian, u64 lengths, u32 enum tags, u8 Option tag; FieldElement = hex String,
 // acir_field/src/generic_ark.rs:114-134, parsed like from_hex :263-267, i.e. reduced mod p).
 #include "circuit.hpp"
+#include <map>
 #include <stdexcept>
 #include <zlib.h>
 
@@ -321,6 +322,62 @@ std::unique_ptr<Circuit> circuit_from_bytes(const uint8_t *buf, size_t len, std:
         err = std::string("malformed circuit: ") + e.what();
         return nullptr;
     }
+}
+
+bool witness_map_from_bytes(const uint8_t *buf, size_t len, std::vector<uint32_t> &ids, std::vector<uint8_t> &values_be32, std::string &err) {
+    std::vector<uint8_t> inflated;
+    if (len >= 2 && buf[0] == 0x1f && buf[1] == 0x8b) {
+        if (!gunzip(buf, len, inflated)) { err = "gzip stream is corrupt"; return false; }
+        buf = inflated.data();
+        len = inflated.size();
+    }
+    try {
+        Reader r{buf, buf + len};
+        const uint64_t n = r.u64();
+        if (n > len) throw std::runtime_error("witness map length exceeds the buffer");
+        ids.clear();
+        values_be32.clear();
+        for (uint64_t i = 0; i < n; i++) {
+            ids.push_back(r.u32());
+            const FrH v = r.fr();
+            uint64_t can[4];
+            frh::to_canonical(v, can);
+            for (int k = 0; k < 32; k++) values_be32.push_back((uint8_t)(can[(31 - k) / 8] >> (8 * ((31 - k) % 8))));
+        }
+        if (r.p != r.end) throw std::runtime_error("trailing bytes after the witness map");
+    } catch (const std::exception &e) {
+        err = e.what();
+        return false;
+    }
+    return true;
+}
+
+bool witness_map_to_bytes(const uint32_t *ids, const uint8_t *values_be32, size_t n, std::vector<uint8_t> &out, std::string &err) {
+    // BTreeMap order: ascending witness index; a repeated index keeps its last value (map insert)
+    std::map<uint32_t, const uint8_t *> m;
+    for (size_t i = 0; i < n; i++) m[ids[i]] = values_be32 + 32 * i;
+    std::vector<uint8_t> raw;
+    auto put64 = [&](uint64_t v) { for (int k = 0; k < 8; k++) raw.push_back((uint8_t)(v >> (8 * k))); };
+    put64(m.size());
+    static const char *hex = "0123456789abcdef";
+    for (auto &kv : m) {
+        for (int k = 0; k < 4; k++) raw.push_back((uint8_t)(kv.first >> (8 * k)));
+        put64(64);
+        for (int k = 0; k < 32; k++) { raw.push_back((uint8_t)hex[kv.second[k] >> 4]); raw.push_back((uint8_t)hex[kv.second[k] & 15]); }
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, Z_BEST_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK) { err = "deflateInit2 failed"; return false; }
+    out.resize(deflateBound(&zs, (uLong)raw.size()) + 32);
+    zs.next_in = raw.data();
+    zs.avail_in = (uInt)raw.size();
+    zs.next_out = out.data();
+    zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    out.resize(out.size() - zs.avail_out);
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) { err = "deflate failed"; return false; }
+    return true;
 }
 
 }  // namespace acvm

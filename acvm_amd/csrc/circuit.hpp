@@ -104,4 +104,9 @@ struct Circuit {
 // Circuit::read. Accepts gzip(bincode) or raw bincode. Returns nullptr and fills err on malformed input.
 std::unique_ptr<Circuit> circuit_from_bytes(const uint8_t *buf, size_t len, std::string &err);
 
+// WitnessMap <-> bytes (acir/src/native_types/witness_map.rs:108-146): gzip(bincode(BTreeMap<Witness(u32), FieldElement>)),
+// a FieldElement being its 64-character hex string. Values are canonical 32-byte big-endian (reduced on read).
+bool witness_map_from_bytes(const uint8_t *buf, size_t len, std::vector<uint32_t> &ids, std::vector<uint8_t> &values_be32, std::string &err);
+bool witness_map_to_bytes(const uint32_t *ids, const uint8_t *values_be32, size_t n, std::vector<uint8_t> &out, std::string &err);
+
 }  // namespace acvm

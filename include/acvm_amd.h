@@ -222,6 +222,20 @@ int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t i
 int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,
                                  uint8_t *values_be32);
 
+/*
+ * WitnessMap wire format (acir/src/native_types/witness_map.rs:108-146; acvm_js compressWitness / decompressWitness):
+ * gzip(bincode(BTreeMap<Witness, FieldElement>)), a FieldElement being its 64-character hex string.
+ * decode: writes up to cap (index, canonical 32-byte big-endian value) pairs in ascending index order, returns the number of
+ *         entries of the map (values are reduced like FieldElement::from_hex). Raw bincode without the gzip layer is accepted.
+ * encode: returns the number of bytes of the serialised map (written if it fits cap). Same map, same bincode bytes as the
+ *         reference; the gzip layer is zlib's at level 9 (any inflater reads it; the compressed bytes are not pinned).
+ * acvm_batch_witness_map_bytes: the witness map of one instance as it stands (finalize() for a solved instance, the partial
+ *         map otherwise), serialised.
+ */
+long long acvm_witness_map_decode(const uint8_t *bytes, size_t len, uint32_t *ids, uint8_t *values_be32, uint32_t cap);
+long long acvm_witness_map_encode(const uint32_t *ids, const uint8_t *values_be32, uint32_t n, uint8_t *out, size_t cap);
+long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8_t *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

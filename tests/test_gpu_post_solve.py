@@ -68,3 +68,19 @@ def test_extract_return_and_public_witnesses():
     b.extract([5], first=0, n=1)
     with pytest.raises(acvm_amd.AcvmError, match="Failed to extract witness 4 from witness map. Witness not found."):
         b.extract([4, 5])
+
+
+def test_solved_witness_map_in_the_wire_format(golden):
+    """finalize() + compressWitness: the reference's addition circuit (acvm_js/test/shared/addition.ts) solved on the device,
+    its witness map serialised like acir's WitnessMap and read back."""
+    fx = golden["acvm_js"]["addition"]
+    c = acvm_amd.Circuit(bytes(fx["bytecode"]))
+    iw = {int(k): int(v, 16) for k, v in fx["initialWitnessMap"].items()}
+    ids = sorted(iw)
+    b = acvm_amd.Batch(c, 2, ids)
+    b.set_initial_witness(b"".join(be32(iw[i]) for i in ids) * 2)
+    assert b.solve() == 0
+    got = acvm_amd.decompress_witness(b.witness_map_bytes(1))
+    asg, vals = b.witness_map(1, 1)
+    assert got == {w: int.from_bytes(vals[0, w].tobytes(), "big") for w in range(asg.shape[1]) if asg[0, w]}
+    assert got[fx["resultWitness"]] == int(fx["expectedResult"], 16) and all(got[k] == v for k, v in iw.items())

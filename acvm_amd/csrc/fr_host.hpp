@@ -135,7 +135,47 @@ inline FrH pow_pm2(const FrH &a) {  // a^(p-2): Fermat inverse (planner only; a 
     }
     return r;
 }
-inline FrH inverse(const FrH &a) { return a.is_zero() ? a : pow_pm2(a); }  // inverse(0) == 0
+// Binary extended Euclid on the Montgomery representative u = aR (an integer below p): u^-1 = a^-1 R^-1, and one Montgomery
+// product with R^3 returns a^-1 R. ~4x faster than the Fermat power, which matters because the planner folds -1/coefficient
+// into every solved gate (one inversion per distinct coefficient; 1 M-gate circuits plan in seconds instead of half a minute).
+inline FrH inverse(const FrH &a) {  // inverse(0) == 0
+    if (a.is_zero()) return a;
+    uint64_t u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+    memcpy(u, a.l, 32);
+    memcpy(v, P, 32);
+    auto is_one = [](const uint64_t x[4]) { return x[0] == 1 && !(x[1] | x[2] | x[3]); };
+    auto halve = [](uint64_t x[4]) {
+        for (int i = 0; i < 3; i++) x[i] = x[i] >> 1 | x[i + 1] << 63;
+        x[3] >>= 1;
+    };
+    auto halve_mod = [&](uint64_t x[4]) {  // x / 2 mod p; x + p < 2^255
+        if (x[0] & 1) add4(x, x, P);
+        halve(x);
+    };
+    auto geq = [](const uint64_t x[4], const uint64_t y[4]) {
+        for (int i = 3; i >= 0; i--) {
+            if (x[i] > y[i]) return true;
+            if (x[i] < y[i]) return false;
+        }
+        return true;
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u[0] & 1)) { halve(u); halve_mod(x1); }
+        while (!(v[0] & 1)) { halve(v); halve_mod(x2); }
+        if (geq(u, v)) {
+            sub4(u, u, v);
+            if (sub4(x1, x1, x2)) add4(x1, x1, P);
+        } else {
+            sub4(v, v, u);
+            if (sub4(x2, x2, x1)) add4(x2, x2, P);
+        }
+    }
+    FrH r, r2, r3;
+    memcpy(r.l, is_one(u) ? x1 : x2, 32);
+    memcpy(r2.l, R2, 32);
+    r3 = mul(r2, r2);  // R^2 * R^2 * R^-1 = R^3
+    return mul(r, r3);
+}
 // The device keeps Montgomery representatives with R = 2^261 (fr_device.hpp); the planner computes with R = 2^256.
 // x * 2^261 mod p is the R = 2^256 representative of 32 x, and back.
 inline FrH to_device_form(const FrH &a) { return mul(a, from_u64(32)); }
@@ -154,7 +194,15 @@ inline bool self_check() {
     if (memcmp(x, R1, 32)) return false;
     for (int i = 0; i < 256; i++) dbl();
     if (memcmp(x, R2, 32)) return false;
-    return (uint64_t)(P[0] * (0 - N0INV)) == 1;
+    if ((uint64_t)(P[0] * (0 - N0INV)) != 1) return false;
+    // the Euclidean inverse against the Fermat power on a few values, and a * a^-1 == 1
+    FrH t = from_u64(5);
+    for (int i = 0; i < 8; i++) {
+        const FrH inv = inverse(t), fermat = pow_pm2(t), prod = mul(t, inv);
+        if (memcmp(inv.l, fermat.l, 32) || memcmp(prod.l, R1, 32)) return false;
+        t = add(mul(t, t), from_u64(0x9E3779B97F4A7C15ULL + i));
+    }
+    return true;
 }
 }  // namespace frh
 }  // namespace acvm

@@ -6,14 +6,20 @@
 #include <cstdlib>
 #include <map>
 #include <queue>
+#include <unordered_map>
 
 namespace acvm {
 namespace {
 
 struct ConstPool {
     std::vector<FrH> &pool;
-    std::map<std::array<uint64_t, 4>, uint32_t> index;
-    std::map<std::array<uint64_t, 4>, FrH> neg_inv_cache;
+    struct KeyHash {
+        size_t operator()(const std::array<uint64_t, 4> &k) const {
+            return (size_t)((k[0] * 0x9E3779B97F4A7C15ULL) ^ (k[1] * 0xC2B2AE3D27D4EB4FULL) ^ (k[2] << 1) ^ k[3]);
+        }
+    };
+    std::unordered_map<std::array<uint64_t, 4>, uint32_t, KeyHash> index;
+    std::unordered_map<std::array<uint64_t, 4>, FrH, KeyHash> neg_inv_cache;
     FrH one = frh::one(), minus_one = frh::neg(frh::one());
     explicit ConstPool(std::vector<FrH> &p) : pool(p) {}
     uint32_t coef(const FrH &c) {  // multiplicative coefficient
@@ -34,6 +40,28 @@ struct ConstPool {
         pool.push_back(c);
         index.emplace(k, id);
         return id;
+    }
+    // -1/c for a whole set of coefficients with ONE field inversion (Montgomery's trick): the planner needs -1/c of every
+    // coefficient of every Arithmetic opcode (gate folding, and the exact kernels' records), and a host inversion costs
+    // as much as 300 products
+    void prefill_neg_inv(const std::vector<FrH> &coefs) {
+        std::vector<FrH> todo, prefix;
+        for (const FrH &c : coefs) {
+            if (c.is_zero() || c == one || c == minus_one) continue;
+            std::array<uint64_t, 4> k = {c.l[0], c.l[1], c.l[2], c.l[3]};
+            if (neg_inv_cache.emplace(k, frh::zero()).second) todo.push_back(c);  // placeholder until the batch is done
+        }
+        if (todo.empty()) return;
+        prefix.resize(todo.size());
+        FrH acc = frh::one();
+        for (size_t i = 0; i < todo.size(); i++) { acc = frh::mul(acc, todo[i]); prefix[i] = acc; }
+        FrH inv = frh::inverse(acc);
+        for (size_t i = todo.size(); i-- > 0;) {
+            const FrH inv_i = i ? frh::mul(inv, prefix[i - 1]) : inv;
+            inv = frh::mul(inv, todo[i]);
+            std::array<uint64_t, 4> k = {todo[i].l[0], todo[i].l[1], todo[i].l[2], todo[i].l[3]};
+            neg_inv_cache[k] = frh::neg(inv_i);
+        }
     }
     // -1/c, memoised (real circuits repeat a handful of coefficients)
     FrH neg_inv(const FrH &c) {
@@ -129,6 +157,15 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         p.producer[initial_ids[i]] = 0xFFFFFFFEu;
     }
     ConstPool pool(p.constants);
+    {
+        std::vector<FrH> coefs;
+        for (const Opcode &o : c.opcodes)
+            if (o.kind == OP_ARITHMETIC) {
+                for (auto &t : o.expr.mul) coefs.push_back(t.c);
+                for (auto &t : o.expr.lin) coefs.push_back(t.c);
+            }
+        pool.prefill_neg_inv(coefs);
+    }
     std::vector<PendingGate> gates;
     std::vector<PendingRecord> records;
     std::vector<PendingInverse> inverses;

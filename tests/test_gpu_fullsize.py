@@ -89,3 +89,33 @@ def test_mixed_circuit_full_batch_properties():
         assert res[j].as_tuple() == sres[i].as_tuple(), j
         asg, vals = batch.witness_map(j, 1)
         assert np.array_equal(asg[0], sasg[i]) and np.array_equal(vals[0], svals[i]), j
+
+
+def test_hundred_thousand_gate_circuit(oracle):
+    """Towards config 5's circuit size: 100 000 gates x 2 048 instances (6.5 GB witness table, 52 levels of up to 7 000
+    gates). Four instances are checked bit for bit against the CPU oracle, a sample re-evaluates every constraint with
+    Python integers, and only the edge-case inputs may fail."""
+    B, G = 2048, 100000
+    circ, ids = synth.arithmetic_circuit(G, seed=0xAC1D0005)
+    data = circ.to_bytes()
+    values = synth.witness_batch(B, seed=0xAC1D0005)
+    gc = acvm_amd.Circuit(data)
+    batch = acvm_amd.Batch(gc, B, ids)
+    batch.set_initial_witness(values)
+    n_bad = batch.solve()
+    res = batch.results()
+    failed = [j for j in range(B) if res[j].status != acvm_amd.STATUS_SOLVED]
+    assert n_bad == len(failed) and set(failed) <= set(range(8)), failed[:16]
+    st = batch.stats()
+    assert st["n_opcodes"] == G and st["n_fast_gates"] + st["n_dyn_gates"] == G and st["truncated_at"] == 0xFFFFFFFF
+    picks = [0, 5, 8, B - 1]
+    sub = b"".join(values[j * len(ids) * 32:(j + 1) * len(ids) * 32] for j in picks)
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, sub, len(picks))
+    for i, j in enumerate(picks):
+        assert res[j].as_tuple() == ores[i].as_tuple(), j
+        asg, vals = batch.witness_map(j, 1)
+        nw = min(asg.shape[1], oasg.shape[1])
+        assert np.array_equal(asg[0, :nw], oasg[i, :nw]) and np.array_equal(vals[0, :nw], ovals[i, :nw]), j
+    asg, vals = batch.witness_map(777, 1)
+    check_arithmetic_satisfied(circ, {w: int.from_bytes(vals[0, w].tobytes(), "big") for w in range(asg.shape[1])})
+    batch.free()

@@ -243,10 +243,14 @@ __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restri
     // get_hash_input (hash.rs:51-86): fetch_nearest_bytes = low ceil(num_bits / 8) bytes, least significant first
     MsgBuf m{scratch, p.Bp, p.j, 0u, 0u};
     m.begin();
+    // the next witness is requested before the current one is converted and staged (two loads in flight per lane)
+    Fr next = n_in ? p.load(ins[0]) : fr_zero();
     for (uint32_t i = 0; i < n_in; i++) {
         const uint32_t nb = (ins[2 * i + 1] + 7u) / 8u;
         if (nb > 32u) return op_fail_msg(DE_PANIC, 0, DM_FETCH_BYTES);  // slice end out of range (generic_ark.rs:316)
-        const Fr c = fr_to_canonical(p.load(ins[2 * i]));
+        const Fr cur = next;
+        if (i + 1 < n_in) next = p.load(ins[2 * (i + 1)]);
+        const Fr c = fr_to_canonical(cur);
 #pragma unroll
         for (int k = 0; k < 32; k++)
             if ((uint32_t)k < nb) m.put(c.v[k >> 2] >> (8 * (k & 3)));

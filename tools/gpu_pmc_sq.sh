@@ -14,7 +14,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_SMEM SQ_INSTS_VMEM_R
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/$name" -o pmc -- $BENCH > "$OUT/$name.log" 2>&1
 done
 find "$OUT" -name '*.db' -delete
-python - "$OUT" <<'PY'
+python - "$OUT" > "$OUT/summary.txt" <<'PY'
 import csv, glob, sys, os
 from collections import defaultdict
 tot = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
@@ -22,7 +22,16 @@ for f in glob.glob(os.path.join(sys.argv[1], "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0][-40:]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
-for k in tot:
-    if "arith" in k or "level" in k:
-        print(k, {c: (round(v / cnt[k][c]), cnt[k][c]) for c, v in tot[k].items()})
+print("# per-launch averages of the SQ counters (rocprofv3 --pmc, one pass per group of three, kernel-trace only) of")
+print("# `python bench.py --steps 2 --warmup 1 --no-cpu-baseline <args>`; the last column of each pair is the number of launches seen")
+for k in sorted(tot):
+    if "arith" in k or "level" in k or "inverse" in k:
+        c = tot[k]; n = cnt[k]
+        print(k)
+        for name in sorted(c):
+            print(f"    {name:24s} {c[name] / n[name]:16.0f}   ({n[name]} launches)")
+        if "SQ_WAVES" in c and "SQ_INSTS_VALU" in c:
+            w = c["SQ_WAVES"] / n["SQ_WAVES"]
+            print(f"    -> per wave: VALU {c['SQ_INSTS_VALU'] / n['SQ_INSTS_VALU'] / w:.0f}, SALU {c['SQ_INSTS_SALU'] / n['SQ_INSTS_SALU'] / w:.0f}")
 PY
+cat "$OUT/summary.txt"

@@ -127,7 +127,8 @@ class Stats(C.Structure):
                 ("plan_ms", C.c_double), ("solve_device_ms", C.c_double), ("arith_kernel_ms", C.c_double),
                 ("slow_path_ms", C.c_double), ("dyn_kernel_ms", C.c_double),
                 ("dyn_algorithmic_bytes_per_instance", C.c_uint64), ("n_other_records", C.c_uint32), ("truncated_at", C.c_uint32),
-                ("class_algorithmic_bytes_per_instance", C.c_uint64 * 4), ("class_kernel_ms", C.c_double * 4)]
+                ("class_algorithmic_bytes_per_instance", C.c_uint64 * 4), ("class_kernel_ms", C.c_double * 4),
+                ("n_gate_pairs", C.c_uint32), ("n_inverse_slots", C.c_uint32)]
 
     def as_dict(self):
         return {f: (list(getattr(self, f)) if f.startswith("class_") else getattr(self, f)) for f, _ in self._fields_}

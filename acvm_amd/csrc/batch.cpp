@@ -205,6 +205,8 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->plan_ms = p.plan_ms;
     out->n_other_records = p.n_other_records;
     out->truncated_at = p.truncated_at;
+    out->n_gate_pairs = p.n_gate_pairs;
+    out->n_inverse_slots = p.n_inverse_slots;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
                                                                p.cls_algorithmic_bytes[CLS_HOSTBB];

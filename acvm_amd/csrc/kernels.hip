@@ -75,23 +75,29 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
     const uint32_t *__restrict__ g = gate_stream + gate_offset[blockIdx.y];
-    const uint32_t kind = g[0] & 0xff, opcode = g[1], out = g[2];
-    const GateSum sum = gate_sum_lazy(W, Bp, j, g, consts);
-    if (kind == 2) {
-        // the unknown is multiplied by a known witness (arithmetic.rs:68-91): out = sum' / partner, and 1 / partner was put
-        // into the inverse table by an earlier inverse_batch_kernel. The lazy sum (< 8p) is a valid product operand as it is.
-        const Fr29 inv = fr29_from(fr_load(Inv, g[4], Bp, j));
-        fr_store(W, out, Bp, j, fr29_pack(fr29_cond_sub_p(fr29_mul(sum.v, inv))));
-        return;
-    }
-    const Fr29 acc = gate_sum_canon(sum);
-    if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
-        uint32_t z = 0;
+    Fr29 local = fr29_from(fr_zero());
+    for (;;) {  // the record, then the record fused behind it (it reads this one's output as GATE_LOCAL)
+        const uint32_t w0 = g[0], kind = w0 & 0xff, opcode = g[1], out = g[2];
+        const GateSum sum = gate_sum_lazy(W, Bp, j, g, consts, local);
+        Fr29 acc;
+        if (kind == 2) {
+            // the unknown is multiplied by a known witness (arithmetic.rs:68-91): out = sum' / partner, and 1 / partner was put
+            // into the inverse table by an earlier inverse_batch_kernel. The lazy sum (< 8p) is a valid product operand as it is.
+            acc = fr29_cond_sub_p(fr29_mul(sum.v, fr29_from(fr_load(Inv, g[4], Bp, j))));
+        } else {
+            acc = gate_sum_canon(sum);
+        }
+        if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
+            uint32_t z = 0;
 #pragma unroll
-        for (int i = 0; i < 9; i++) z |= acc.v[i];
-        if (z) atomicMin(&event[j], opcode);
-    } else {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
-        fr_store(W, out, Bp, j, fr29_pack(acc));
+            for (int i = 0; i < 9; i++) z |= acc.v[i];
+            if (z) atomicMin(&event[j], opcode);
+        } else {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
+            fr_store(W, out, Bp, j, fr29_pack(acc));
+        }
+        if (!(w0 & GATE_TAIL_FLAG)) break;
+        local = acc;
+        g += gate_record_words(g);
     }
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))

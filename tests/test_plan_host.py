@@ -23,6 +23,19 @@ def test_arithmetic_mix_accounting():
     assert st["algorithmic_bytes_per_instance"] == st["arith_algorithmic_bytes_per_instance"] + st["dyn_algorithmic_bytes_per_instance"]
 
 
+def test_gate_pairs_and_inverse_slots():
+    """Config-2 shape: about 30 % of the gates run as the tail of their producer (one tail per host; only SOLVE hosts, no
+    inversion gates), and the inverse table needs far fewer rows than there are inversion gates (rows are reused)."""
+    circ, ids = synth.arithmetic_circuit(10000, seed=0xAC1D0002)
+    st = stats(circ, ids)
+    assert 2500 <= st["n_gate_pairs"] <= 4000
+    assert 0 < st["n_inverse_slots"] < st["n_dyn_gates"] // 2
+    # a chain cannot pair: every gate's only fresh operand is its predecessor, but the predecessor may host one tail, so
+    # every second gate is a tail
+    chain, cids = synth.arithmetic_circuit(200, seed=7, chain=True, mix=(47, 32, 21, 0))
+    assert stats(chain, cids)["n_gate_pairs"] >= 60
+
+
 def test_chain_has_one_level_per_gate():
     circ, ids = synth.arithmetic_circuit(200, seed=7, chain=True)
     assert stats(circ, ids)["n_levels"] >= 200

@@ -100,7 +100,10 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
         g += gate_record_words(g);
     }
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+#ifndef ARITH_BLOCK
+#define ARITH_BLOCK 256
+#endif
+__global__ void __launch_bounds__(ARITH_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
 arith_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream, const uint32_t *__restrict__ gate_offset,
                    const uint32_t *__restrict__ consts, uint32_t *__restrict__ event, const uint4 *__restrict__ Inv) {
     arith_level_body(W, Bp, B, gate_stream, gate_offset, consts, event, Inv);
@@ -228,7 +231,7 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
     // gridDim.y is limited to 65535
     for (uint32_t done = 0; done < n_gates;) {
         uint32_t n = n_gates - done > 65535u ? 65535u : n_gates - done;
-        hipLaunchKernelGGL(arith_level_kernel, dim3((B + 255) / 256, n), dim3(256), 0, s, W, Bp, B, gate_stream, gate_offset + done, consts, event, inv);
+        hipLaunchKernelGGL(arith_level_kernel, dim3((B + ARITH_BLOCK - 1) / ARITH_BLOCK, n), dim3(ARITH_BLOCK), 0, s, W, Bp, B, gate_stream, gate_offset + done, consts, event, inv);
         done += n;
     }
 }

@@ -122,3 +122,30 @@ def test_device_field_selftest():
     """hand-scheduled gfx950 field routines against the portable ones on 2^18 random operand pairs"""
     import acvm_amd
     assert acvm_amd.selftest(1 << 18, 7) == 0
+
+
+def test_config1_fixture():
+    """BASELINE config 1 on the device, as a batch of one and inside a batch of 70: against tests/golden/config1.json
+    (independent Python big-integer solve, tests/golden/make_config1_fixture.py)."""
+    import hashlib
+    import json
+    import os
+    import acvm_amd
+    from acvm_amd import synth
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1.json")))
+    circ, ids = synth.arithmetic_circuit(fx["gates"], seed=fx["seed"])
+    row = bytes.fromhex(fx["inputs_be32_hex"])
+    nw = fx["n_witnesses"]
+    for B, at in ((1, 0), (70, 37)):
+        values = bytearray(synth.witness_batch(B, seed=fx["seed"]))
+        values[at * len(row):(at + 1) * len(row)] = row
+        batch = acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), B, ids)
+        batch.set_initial_witness(bytes(values))
+        batch.solve()
+        assert batch.results()[at].status == 0
+        asg, vals = batch.witness_map(at, 1)
+        assert asg[0, 1:nw + 1].all()
+        assert hashlib.sha256(vals[0, 1:nw + 1].tobytes()).hexdigest() == fx["sha256_of_witnesses_1_to_n"]
+        for w, v in fx["witnesses"].items():
+            assert vals[0, int(w)].tobytes().hex() == v
+        batch.free()

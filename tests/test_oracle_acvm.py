@@ -260,3 +260,19 @@ def test_acvm_js_fixtures(oracle, golden):
             assert wm == {int(k): int(v, 16) for k, v in fx["expectedWitnessMap"].items()}, name
         else:
             assert wm[fx["resultWitness"]] == int(fx["expectedResult"], 16)
+
+
+def test_config1_fixture(oracle):
+    """BASELINE config 1 (1 000 gates, one instance): the oracle against tests/golden/config1.json, which was produced by an
+    independent Python big-integer solve (tests/golden/make_config1_fixture.py)."""
+    import hashlib
+    import json
+    import os
+    from acvm_amd import synth
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1.json")))
+    circ, ids = synth.arithmetic_circuit(fx["gates"], seed=fx["seed"])
+    res, asg, vals = oracle.solve_batch(oracle.Circuit(circ.to_bytes()), ids, bytes.fromhex(fx["inputs_be32_hex"]), 1)
+    assert res[0].status == 0 and asg[0, 1:fx["n_witnesses"] + 1].all()
+    assert hashlib.sha256(vals[0, 1:fx["n_witnesses"] + 1].tobytes()).hexdigest() == fx["sha256_of_witnesses_1_to_n"]
+    for w, v in fx["witnesses"].items():
+        assert vals[0, int(w)].tobytes().hex() == v

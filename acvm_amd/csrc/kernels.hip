@@ -76,7 +76,8 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
     if (j >= B) return;
     const uint32_t *__restrict__ g = gate_stream + gate_offset[blockIdx.y];
     Fr29 local = fr29_from(fr_zero());
-    for (;;) {  // the record, then the record fused behind it (it reads this one's output as GATE_LOCAL)
+    bool host = true;
+    for (;;) {  // the record, then the records fused behind it (they read this one's output as GATE_LOCAL)
         const uint32_t w0 = g[0], kind = w0 & 0xff, opcode = g[1], out = g[2];
         const GateSum sum = gate_sum_lazy(W, Bp, j, g, consts, local);
         Fr29 acc;
@@ -96,7 +97,8 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
             fr_store(W, out, Bp, j, fr29_pack(acc));
         }
         if (!(w0 & GATE_TAIL_FLAG)) break;
-        local = acc;
+        if (host) local = acc;  // every tail reads the host's output
+        host = false;
         g += gate_record_words(g);
     }
 }

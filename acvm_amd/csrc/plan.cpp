@@ -80,7 +80,8 @@ struct PendingGate {
     uint32_t level;
     std::vector<uint32_t> words;
     std::vector<uint32_t> reads;     // distinct operand witnesses
-    uint32_t tail = 0xFFFFFFFFu;     // index of the gate fused behind this one (runs in the same wave, reads this output from registers)
+    uint32_t n_tails = 0;            // gates fused behind this one (they run in the same wave and read this output from registers)
+    size_t last_w0 = 0;              // position in `words` of the header of the last record of the chain
     bool fused = false;              // this gate runs as the tail of another one
 };
 static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;   // w0: another record follows and reads this gate's output as GATE_LOCAL
@@ -707,17 +708,19 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
 
     // =========================================================================== gate pairs
     // A gate whose only operand from the previous level is the output of a SOLVE gate, and whose other operands are older,
-    // runs as the TAIL of that gate: same wave, the intermediate witness comes from registers instead of HBM (it is still
-    // written: it is a witness). One tail per host; on config 2, 3 079 of the 10 000 gates run as tails: the level kernels move
-    // 10 % fewer bytes than the algorithmic count and launch 31 % fewer waves.
+    // runs as a TAIL of that gate: same wave, one level early, the intermediate witness comes from registers instead of HBM
+    // (it is still written: it is a witness). Up to GATE_MAX_TAILS tails per host, all reading the host's output; a tail
+    // does not host tails itself (its own consumers were levelled against its nominal level).
+    static constexpr uint32_t GATE_MAX_TAILS = 3;
     if (!getenv("ACVM_NO_PAIRS")) {
+        const uint32_t max_tails = getenv("ACVM_MAX_TAILS") ? (uint32_t)atoi(getenv("ACVM_MAX_TAILS")) : GATE_MAX_TAILS;
         std::vector<uint32_t> producer_gate(nw, 0xFFFFFFFFu);
         for (uint32_t gi = 0; gi < gates.size(); gi++)
             if ((gates[gi].words[0] & 0xff) == GATE_SOLVE) producer_gate[gates[gi].words[2]] = gi;
         for (uint32_t ci = 0; ci < gates.size(); ci++) {
             PendingGate &cg = gates[ci];
             const uint32_t kind = cg.words[0] & 0xff;
-            if (kind == GATE_SOLVE_DYN || cg.level < 2) continue;
+            if (kind == GATE_SOLVE_DYN || cg.level < 2 || cg.n_tails) continue;
             uint32_t crit = 0xFFFFFFFFu, n_crit = 0;
             for (uint32_t w : cg.reads)
                 if (level[w] + 1 == cg.level) { crit = w; n_crit++; }
@@ -725,12 +728,13 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             const uint32_t hi = producer_gate[crit];
             if (hi == 0xFFFFFFFFu || hi == ci) continue;
             PendingGate &hg = gates[hi];
-            if (hg.tail != 0xFFFFFFFFu || hg.fused || hg.level + 1 != cg.level) continue;
-            hg.tail = ci;
+            if (hg.n_tails >= max_tails || hg.fused || hg.level + 1 != cg.level) continue;
             cg.fused = true;
             for_each_operand_word(cg.words, [&](uint32_t &slot) { if (slot == crit) slot = GATE_LOCAL; });
-            hg.words[0] |= GATE_TAIL_FLAG;
+            hg.words[hg.last_w0] |= GATE_TAIL_FLAG;
+            hg.last_w0 = hg.words.size();
             hg.words.insert(hg.words.end(), cg.words.begin(), cg.words.end());
+            hg.n_tails++;
             p.n_gate_pairs++;
         }
     }

@@ -66,6 +66,7 @@ struct acvm_batch {
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr;
     std::vector<hipEvent_t> ev_sync;
+    uint32_t *d_ped_seed = nullptr;  // seed table of the level Pedersen kernel (one row per Pedersen record)
     uint4 *d_inv = nullptr;  // inverse table: [plan.n_inverse_slots][2 halves][Bp] x 16 B
     uint32_t n_launches = 0;
     // caller-supplied BlackBoxFunctionSolver
@@ -94,6 +95,7 @@ struct acvm_batch {
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
         if (d_inv) hipFree(d_inv);
+        if (d_ped_seed) hipFree(d_ped_seed);
         for (void *p : {(void *)d_fc_res_opcode, (void *)d_fc_res_desc, (void *)d_fc_pend_desc, (void *)d_fc_res_vals, (void *)d_fc_pend_vals})
             if (p) hipFree(p);
         if (stream_dyn) hipStreamDestroy(stream_dyn);
@@ -296,12 +298,24 @@ static int batch_init(acvm_batch *b) {
     b->dp.bytecode = b->d_bytecode;
     b->dp.Mem = b->d_Mem;
     b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr};
+    b->dp.ped_seed = nullptr;
     if (p.needs_grumpkin) {
         // the level schedule's Pedersen kernel reads the 503 MB pair table (one mixed addition per 18 bits of input)
         const bool pairs = !p.cls_offset[CLS_PEDERSEN].empty();
         const GrumpkinTables *t = pairs ? grumpkin_pair_table() : grumpkin_tables();
         if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
         b->dp.grumpkin = *t;
+        if (!p.pedersen_seeds.empty()) {  // x of the instance-independent first hash_pair of every Pedersen record
+            std::vector<uint32_t> keys;
+            for (auto &k : p.pedersen_seeds) { keys.push_back(k.first); keys.push_back(k.second); }
+            uint32_t *d_keys = nullptr;
+            if (int rc = upload(&d_keys, keys)) return rc;
+            HIPCHK(hipMalloc((void **)&b->d_ped_seed, p.pedersen_seeds.size() * 32));
+            launch_pedersen_seeds(b->stream, *t, d_keys, (uint32_t)p.pedersen_seeds.size(), b->d_ped_seed);
+            HIPCHK(hipStreamSynchronize(b->stream));
+            hipFree(d_keys);
+        }
+        b->dp.ped_seed = b->d_ped_seed;
     }
     b->n_words = (p.n_witnesses + 31) / 32;
     if (int rc = upload(&b->d_producer, p.producer)) return rc;

@@ -49,6 +49,7 @@ struct DeviceProgram {
     const uint32_t *bytecode;     // Brillig programs
     uint4 *Mem;                   // per-instance memory blocks, laid out like W
     GrumpkinTables grumpkin;      // device lookup tables (null pointers if the circuit has no Grumpkin opcode)
+    const uint32_t *ped_seed;     // per Pedersen record: x of hash_pair(IV[domain separator], n), 8 x u32 Montgomery
 };
 
 void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in);
@@ -73,6 +74,7 @@ void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const D
 void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                            const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
 // Pedersen records: 4 waves per group of 64 instances, one accumulator chain each (kernels_grumpkin.hip)
+void launch_pedersen_seeds(hipStream_t s, const GrumpkinTables &T, const uint32_t *keys, uint32_t n, uint32_t *out);
 void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
                            uint32_t *event);
 void launch_brillig_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
     const bool active = j < B;
     const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
-    const uint32_t n = rec[3], hash_index = rec[2];
+    const uint32_t n = rec[3];
     const uint32_t *ws = rec + 8;
     const GrumpkinTables &T = dp.grumpkin;
     FastPolicy p{W, Bp, j};
@@ -48,17 +48,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         return;
     }
     const uint32_t parity = wave >> 1, half = wave & 1u;
-    Fr r = fr_one(), y = fr_zero();  // IV[0].x = G.x = 1
-    if (hash_index != 0) {  // IV[hash_index] = (hash_index + 1) * G: wave-uniform, every lane computes it
-        Fr k = fr_zero();
-        k.v[0] = hash_index + 1u;
-        k.v[1] = hash_index == 0xFFFFFFFFu ? 1u : 0u;
-        bool inf;
-        r = gj_to_aff(fixed_base_mul(T, 0, k), &inf).x;
-    }
-    for (uint32_t step = 0; step <= n; step++) {
+    // the first link, hash_pair(IV[domain separator], n), is the same for every instance: its x comes from the seed table
+    // (pedersen_seed_kernel, once per batch); the chain starts at the first input
+    Fr r = fr_const(dp.ped_seed, ws[n]), y = fr_zero();
+    for (uint32_t step = 1; step <= n; step++) {
         Fr src = r;
-        if (parity) src = step == 0 ? fr_from_u32(n) : (active ? p.load(ws[step - 1]) : fr_one());
+        if (parity) src = active ? p.load(ws[step - 1]) : fr_one();
         const Fr v = fr_to_canonical(src);
         // generators [i0, i1) of this operand: one pair-table entry per 18 bits (even slice through the endomorphism + odd slice)
         GJac acc = gj_inf();
@@ -107,6 +102,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         __syncthreads();  // lds_r / lds_acc are rewritten by the next step
     }
     if (wave == 0 && active && (!p.insert(rec[4], r, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
+}
+
+// seed table of the level Pedersen kernel: one lane per Pedersen record, keys = (n, domain separator) pairs
+__global__ void __launch_bounds__(64) pedersen_seed_kernel(GrumpkinTables T, const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t n_in = keys[2 * i], hash_index = keys[2 * i + 1];
+    const GAff a = pedersen_hash_pair(T, pedersen_iv_x(T, hash_index), fr_from_u32(n_in));
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[8 * i + k] = a.x.v[k];
+}
+void launch_pedersen_seeds(hipStream_t s, const GrumpkinTables &T, const uint32_t *keys, uint32_t n, uint32_t *out) {
+    if (n) hipLaunchKernelGGL(pedersen_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, T, keys, n, out);
 }
 
 // pair table of the level Pedersen kernel (grumpkin_host.hpp GrumpkinTables::ped2): one lane per entry

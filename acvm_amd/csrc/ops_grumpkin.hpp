@@ -215,27 +215,32 @@ __device__ __forceinline__ GJac pedersen_hash_single(const GrumpkinTables &T, co
     acc0.X = fr29_mul(acc0.X, fr29_from(grumpkin_beta()));
     return gj_add(acc0, acc1);
 }
+// x coordinate of IV[hash_index] = (hash_index + 1) * G; IV[0].x = G.x = 1
+__device__ __forceinline__ Fr pedersen_iv_x(const GrumpkinTables &T, uint32_t hash_index) {
+    if (hash_index == 0) return fr_one();
+    Fr k = fr_zero();
+    k.v[0] = hash_index + 1u;
+    k.v[1] = hash_index == 0xFFFFFFFFu ? 1u : 0u;
+    bool inf;
+    return gj_to_aff(fixed_base_mul(T, 0, k), &inf).x;
+}
+// one link of the chain: hash_pair(left, right) as an affine point (Montgomery coordinates)
+__device__ __forceinline__ GAff pedersen_hash_pair(const GrumpkinTables &T, const Fr &left, const Fr &right) {
+    GJac s = gj_inf();
+    for (uint32_t parity = 0; parity < 2; parity++) {
+        const Fr v = fr_to_canonical(parity ? right : left);
+        s = gj_add(s, pedersen_hash_single(T, v, parity));
+    }
+    bool inf;
+    return gj_to_aff(s, &inf);
+}
 // pedersen(inputs[0..n), hash_index): length-prefixed chain of hash_pairs; inputs are fetched through `get(i)` (Montgomery)
 template <class Get>
 __device__ __forceinline__ void grumpkin_pedersen(const GrumpkinTables &T, uint32_t n, uint32_t hash_index, Get get, Fr &x, Fr &y) {
     if (n == 0) { x = fr_zero(); y = fr_zero(); return; }
-    Fr r = fr_one();  // IV[0].x = G.x = 1
-    if (hash_index != 0) {
-        Fr k = fr_zero();
-        k.v[0] = hash_index + 1u;
-        k.v[1] = hash_index == 0xFFFFFFFFu ? 1u : 0u;
-        bool inf;
-        r = gj_to_aff(fixed_base_mul(T, 0, k), &inf).x;
-    }
+    Fr r = pedersen_iv_x(T, hash_index);
     for (uint32_t step = 0; step <= n; step++) {
-        const Fr right = step == 0 ? fr_from_u32(n) : get(step - 1);
-        GJac s = gj_inf();
-        for (uint32_t parity = 0; parity < 2; parity++) {
-            const Fr v = fr_to_canonical(parity ? right : r);
-            s = gj_add(s, pedersen_hash_single(T, v, parity));
-        }
-        bool inf;
-        const GAff a = gj_to_aff(s, &inf);
+        const GAff a = pedersen_hash_pair(T, r, step == 0 ? fr_from_u32(n) : get(step - 1));
         r = a.x;
         y = a.y;
     }

@@ -251,12 +251,16 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     break;
                 }
                 case BB_PEDERSEN:
-                    // [PK_PEDERSEN, oi, domain_separator, n_in, out_x, fx, out_y, fy, ws...]
+                    // [PK_PEDERSEN, oi, domain_separator, n_in, out_x, fx, out_y, fy, ws..., seed row]
                     p.prog_class[oi] = host_blackbox ? CLS_HOSTBB : CLS_GRUMPKIN;
                     p.needs_grumpkin |= !host_blackbox;
                     s.insert(s.end(), {PK_PEDERSEN, oi, b.domain_separator, (uint32_t)b.in[0].size()});
                     out(b.out[0]); out(b.out[1]);
                     for (auto &in : b.in[0]) s.push_back(in.witness);
+                    // trailing word: row of the seed table (batch.cpp): the first hash_pair of the chain, hash_pair(IV, n), does
+                    // not depend on the instance and is computed once per batch for the level kernel
+                    s.push_back((uint32_t)p.pedersen_seeds.size());
+                    p.pedersen_seeds.push_back({(uint32_t)b.in[0].size(), b.domain_separator});
                     break;
                 case BB_FIXED_BASE_SCALAR_MUL:
                     p.prog_class[oi] = host_blackbox ? CLS_HOSTBB : CLS_GRUMPKIN;

@@ -17,6 +17,7 @@
 #include "circuit.hpp"
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace acvm {
@@ -85,6 +86,7 @@ struct Plan {
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;
+    std::vector<std::pair<uint32_t, uint32_t>> pedersen_seeds;  // per Pedersen record: (number of inputs, domain separator)
     // Brillig foreign calls: function name per (opcode << 32 | bytecode index), buffer sizes of the wait / resolve round trip
     bool has_foreign_calls = false;
     std::map<uint64_t, std::string> fc_function;

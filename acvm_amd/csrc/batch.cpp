@@ -305,12 +305,12 @@ static int batch_init(acvm_batch *b) {
         const GrumpkinTables *t = pairs ? grumpkin_pair_table() : grumpkin_tables();
         if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
         b->dp.grumpkin = *t;
-        if (!p.pedersen_seeds.empty()) {  // x of the instance-independent first hash_pair of every Pedersen record
+        if (!p.pedersen_seeds.empty()) {  // the instance-independent head of every Pedersen chain (kernels_grumpkin.hip)
             std::vector<uint32_t> keys;
             for (auto &k : p.pedersen_seeds) { keys.push_back(k.first); keys.push_back(k.second); }
             uint32_t *d_keys = nullptr;
             if (int rc = upload(&d_keys, keys)) return rc;
-            HIPCHK(hipMalloc((void **)&b->d_ped_seed, p.pedersen_seeds.size() * 32));
+            HIPCHK(hipMalloc((void **)&b->d_ped_seed, p.pedersen_seeds.size() * 64));
             launch_pedersen_seeds(b->stream, *t, d_keys, (uint32_t)p.pedersen_seeds.size(), b->d_ped_seed);
             HIPCHK(hipStreamSynchronize(b->stream));
             hipFree(d_keys);

@@ -49,7 +49,7 @@ struct DeviceProgram {
     const uint32_t *bytecode;     // Brillig programs
     uint4 *Mem;                   // per-instance memory blocks, laid out like W
     GrumpkinTables grumpkin;      // device lookup tables (null pointers if the circuit has no Grumpkin opcode)
-    const uint32_t *ped_seed;     // per Pedersen record: x of hash_pair(IV[domain separator], n), 8 x u32 Montgomery
+    const uint32_t *ped_seed;     // per Pedersen record: hash_single(x of hash_pair(IV[domain separator], n), 0), affine, 16 x u32
 };
 
 void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in);

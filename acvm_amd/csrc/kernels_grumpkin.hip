@@ -47,17 +47,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         if (wave == 0 && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) atomicMin(&event[j], rec[1]);
         return;
     }
-    const uint32_t parity = wave >> 1, half = wave & 1u;
-    // the first link, hash_pair(IV[domain separator], n), is the same for every instance: its x comes from the seed table
-    // (pedersen_seed_kernel, once per batch); the chain starts at the first input
-    Fr r = fr_const(dp.ped_seed, ws[n]), y = fr_zero();
+    // The first link of the chain, hash_pair(IV[domain separator], n), is the same for every instance, and so is the left half
+    // of the second one, hash_single(x of the first link): the seed table (pedersen_seed_kernel, once per batch) holds that
+    // point. Step 1 therefore only walks the 15 generators of the first input (4, 4, 4, 3 per wave) and adds the seed point;
+    // from step 2 on, wave w takes generators [0, 8) or [8, 15) (w & 1) of the running value or of the next input (w >> 1).
+    Fr r = fr_zero(), y = fr_zero();
     for (uint32_t step = 1; step <= n; step++) {
+        const uint32_t parity = step == 1 ? 1u : wave >> 1;
+        const uint32_t i0 = step == 1 ? 4u * wave : (wave & 1u ? 8u : 0u), i1 = step == 1 ? (wave == 3 ? 15u : 4u * wave + 4u) : (wave & 1u ? 15u : 8u);
         Fr src = r;
         if (parity) src = active ? p.load(ws[step - 1]) : fr_one();
         const Fr v = fr_to_canonical(src);
-        // generators [i0, i1) of this operand: one pair-table entry per 18 bits (even slice through the endomorphism + odd slice)
+        // one pair-table entry per 18 bits (even slice through the endomorphism + odd slice)
         GJac acc = gj_inf();
-        const uint32_t gen0 = parity ? 15u : 0u, i0 = half ? 8u : 0u, i1 = half ? 15u : 8u;
+        const uint32_t gen0 = parity ? 15u : 0u;
         for (uint32_t i = i0; i < i1; i++) {
             const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
             acc = gj_add_aff(acc, gaff_load(T.ped2, ((gen0 + i) << GRUMPKIN_PED2_LOG2) | a << 9 | b));
@@ -69,11 +72,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             lds_acc[wave][18 + k][lane] = acc.Z.v[k];
         }
         __syncthreads();
-        // The serial tail of the step (three additions, one inversion) rotates over the four waves: a block's wave w sits on
-        // SIMD w of its CU, and with a fixed leader SIMD 0 carried the tails of all four resident blocks while the other
-        // three idled (measured: 1.5x the balanced time).
+        // the serial tail of the step (three additions, one inversion) rotates over the four waves
         if (wave == ((blockIdx.x + blockIdx.y + step) & 3u)) {
             GJac s = acc;
+            if (step == 1) s = gj_add_aff(s, GAff{fr_const(dp.ped_seed, 2 * ws[n]), fr_const(dp.ped_seed, 2 * ws[n] + 1)});
             for (uint32_t dw = 1; dw < 4; dw++) {
                 const uint32_t w2 = (wave + dw) & 3u;
                 GJac o;
@@ -104,14 +106,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     if (wave == 0 && active && (!p.insert(rec[4], r, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
 }
 
-// seed table of the level Pedersen kernel: one lane per Pedersen record, keys = (n, domain separator) pairs
+// seed table of the level Pedersen kernel: one lane per Pedersen record, keys = (n, domain separator) pairs; a row is the
+// affine point hash_single(x of hash_pair(IV, n), parity 0), 16 x u32
 __global__ void __launch_bounds__(64) pedersen_seed_kernel(GrumpkinTables T, const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ out) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const uint32_t n_in = keys[2 * i], hash_index = keys[2 * i + 1];
-    const GAff a = pedersen_hash_pair(T, pedersen_iv_x(T, hash_index), fr_from_u32(n_in));
+    const GAff first = pedersen_hash_pair(T, pedersen_iv_x(T, hash_index), fr_from_u32(n_in));
+    bool inf;
+    const GAff a = gj_to_aff(pedersen_hash_single(T, fr_to_canonical(first.x), 0), &inf);  // left half of the second link
 #pragma unroll
-    for (int k = 0; k < 8; k++) out[8 * i + k] = a.x.v[k];
+    for (int k = 0; k < 8; k++) {
+        out[16 * i + k] = a.x.v[k];
+        out[16 * i + 8 + k] = a.y.v[k];
+    }
 }
 void launch_pedersen_seeds(hipStream_t s, const GrumpkinTables &T, const uint32_t *keys, uint32_t n, uint32_t *out) {
     if (n) hipLaunchKernelGGL(pedersen_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, T, keys, n, out);

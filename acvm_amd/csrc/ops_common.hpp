@@ -83,7 +83,7 @@ __device__ __forceinline__ Fr29 gate_load29(const uint4 *__restrict__ W, uint64_
 // words of a gate record
 __device__ __forceinline__ uint32_t gate_record_words(const uint32_t *__restrict__ g) {
     const uint32_t w0 = g[0], w5 = g[5];
-    return 6u + 3u * ((w0 >> 8) & 0xff) + 2u * ((w0 >> 16) & 0xff) + 2u * ((w5 & 0xff) + ((w5 >> 8) & 0xff)) + ((w5 >> 16) & 0xff) + (w5 >> 24);
+    return 6u + 10u * ((w0 >> 8) & 0xff) + 9u * ((w0 >> 16) & 0xff) + 2u * ((w5 & 0xff) + ((w5 >> 8) & 0xff)) + ((w5 >> 16) & 0xff) + (w5 >> 24);
 }
 __device__ __forceinline__ void gate_h_room(Fr29 &h, uint32_t &hw, uint32_t weight) {
     if (hw + weight > GATE_H_MAX) {  // rare: many terms in one gate
@@ -96,17 +96,17 @@ __device__ __forceinline__ void gate_h_sub(Fr29 &h, const Fr29 &x) {  // h += 2p
 #pragma unroll
     for (int i = 0; i < 9; i++) h.v[i] += fr_kp29_sub(1, i) - x.v[i];
 }
-// k-th multiplied term of the record: the products come first (coef, a, b), then the linear terms (coef, w)
+// k-th multiplied term of the record: the products come first (coef[8], a, b), then the linear terms (coef[8], w)
 __device__ __forceinline__ Fr29 gate_mac_operand(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ t0,
                                                  uint32_t np_mac, uint32_t k, const uint32_t *__restrict__ consts, const Fr29 &local, Fr29 &c) {
     if (k < np_mac) {
-        const uint32_t *__restrict__ t = t0 + 3 * k;
-        c = fr29_from(fr_const(consts, t[0]));
-        return fr29_mul(gate_load29(W, Bp, j, t[1], local), gate_load29(W, Bp, j, t[2], local));
+        const uint32_t *__restrict__ t = t0 + 10 * k;
+        c = fr29_from(fr_const(t, 0));
+        return fr29_mul(gate_load29(W, Bp, j, t[8], local), gate_load29(W, Bp, j, t[9], local));
     }
-    const uint32_t *__restrict__ t = t0 + 3 * np_mac + 2 * (k - np_mac);
-    c = fr29_from(fr_const(consts, t[0]));
-    return gate_load29(W, Bp, j, t[1], local);
+    const uint32_t *__restrict__ t = t0 + 10 * np_mac + 9 * (k - np_mac);
+    c = fr29_from(fr_const(t, 0));
+    return gate_load29(W, Bp, j, t[8], local);
 }
 __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ g,
                                                  const uint32_t *__restrict__ consts, const Fr29 &local) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, ui
         gate_h_room(h, hw, 17);
         h = fr29_addl(h, r);
     }
-    const uint32_t *__restrict__ t = t0 + 3 * np_mac + 2 * nl_mac;
+    const uint32_t *__restrict__ t = t0 + 10 * np_mac + 9 * nl_mac;
     for (uint32_t i = 0; i < np_pos; i++, t += 2) {
         const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0], local), gate_load29(W, Bp, j, t[1], local));
         gate_h_room(h, hw, 17);

@@ -92,8 +92,8 @@ static void for_each_operand_word(std::vector<uint32_t> &w, F fn) {
     const uint32_t np_mac = (w[0] >> 8) & 0xff, nl_mac = (w[0] >> 16) & 0xff;
     const uint32_t np_pos = w[5] & 0xff, np_neg = (w[5] >> 8) & 0xff, nl_pos = (w[5] >> 16) & 0xff, nl_neg = w[5] >> 24;
     size_t t = 6;
-    for (uint32_t i = 0; i < np_mac; i++, t += 3) { fn(w[t + 1]); fn(w[t + 2]); }
-    for (uint32_t i = 0; i < nl_mac; i++, t += 2) fn(w[t + 1]);
+    for (uint32_t i = 0; i < np_mac; i++, t += 10) { fn(w[t + 8]); fn(w[t + 9]); }
+    for (uint32_t i = 0; i < nl_mac; i++, t += 9) fn(w[t + 8]);
     for (uint32_t i = 0; i < 2 * (np_pos + np_neg) + nl_pos + nl_neg; i++, t++) fn(w[t]);
 }
 struct PendingRecord {
@@ -663,8 +663,14 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         // multiplied lists; terms with coefficient +1 / -1 are listed without a coefficient and are only added / subtracted
         // on the device (up to 255 of each kind, the rest keep an explicit constant).
         //   [kind | np_mac << 8 | nl_mac << 16, opcode, out, q_c, partner, np_pos | np_neg << 8 | nl_pos << 16 | nl_neg << 24,
-        //    np_mac x (coef, a, b), nl_mac x (coef, w), np_pos x (a, b), np_neg x (a, b), nl_pos x (w), nl_neg x (w)]
+        //    np_mac x (coef[8], a, b), nl_mac x (coef[8], w), np_pos x (a, b), np_neg x (a, b), nl_pos x (w), nl_neg x (w)]
         std::vector<uint32_t> pm, lm, pp, pn, lp, ln;
+        // general coefficients travel inline (8 words, the device's Montgomery form): the wave reaches them with the record
+        // itself instead of one more dependent scalar load through the constant pool
+        auto push_coef = [](std::vector<uint32_t> &v, const FrH &c) {
+            const FrH d = frh::to_device_form(c);
+            for (int i = 0; i < 4; i++) { v.push_back((uint32_t)d.l[i]); v.push_back((uint32_t)(d.l[i] >> 32)); }
+        };
         uint32_t np = 0, nl = 0;
         const FrH qc_scaled = sc(e.qc);
         for (auto &t : prods) {
@@ -673,7 +679,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             const uint32_t c = pool.coef(sc(t.c));
             if (c == COEF_ONE && pp.size() < 2 * 255) { pp.push_back(t.a); pp.push_back(t.b); }
             else if (c == COEF_MINUS_ONE && pn.size() < 2 * 255) { pn.push_back(t.a); pn.push_back(t.b); }
-            else { pm.push_back(pool.intern(sc(t.c))); pm.push_back(t.a); pm.push_back(t.b); }
+            else { push_coef(pm, sc(t.c)); pm.push_back(t.a); pm.push_back(t.b); }
         }
         for (auto &t : lins) {
             if (t.c.is_zero()) continue;
@@ -681,11 +687,11 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             const uint32_t c = pool.coef(sc(t.c));
             if (c == COEF_ONE && lp.size() < 255) lp.push_back(t.a);
             else if (c == COEF_MINUS_ONE && ln.size() < 255) ln.push_back(t.a);
-            else { lm.push_back(pool.intern(sc(t.c))); lm.push_back(t.a); }
+            else { push_coef(lm, sc(t.c)); lm.push_back(t.a); }
         }
-        if (pm.size() / 3 > 255 || lm.size() / 2 > 255) { p.truncated_at = oi; break; }
+        if (pm.size() / 10 > 255 || lm.size() / 9 > 255) { p.truncated_at = oi; break; }
         g.level = lvl + 1;
-        g.words = {kind | (uint32_t)(pm.size() / 3) << 8 | (uint32_t)(lm.size() / 2) << 16, oi, kind == GATE_ASSERT ? 0u : unk_w,
+        g.words = {kind | (uint32_t)(pm.size() / 10) << 8 | (uint32_t)(lm.size() / 9) << 16, oi, kind == GATE_ASSERT ? 0u : unk_w,
                    pool.constant(qc_scaled), kind == GATE_SOLVE_DYN ? unk_partner : 0u,
                    (uint32_t)(pp.size() / 2) | (uint32_t)(pn.size() / 2) << 8 | (uint32_t)lp.size() << 16 | (uint32_t)ln.size() << 24};
         for (auto *v : {&pm, &lm, &pp, &pn, &lp, &ln}) g.words.insert(g.words.end(), v->begin(), v->end());

@@ -177,13 +177,15 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": tr["bytes_per_launch"] if tr else None, "kernel": dominant,
                 "kernel_ms_per_step": k_ms / args.steps, "algorithmic_bytes_per_step": k_bytes * B,
-                "launches_per_step": st["n_kernel_launches"],
+                "launches_per_step_all_kernels": st["n_kernel_launches"],
                 "other_kernels_ms_per_step": {k: v[0] / args.steps for k, v in cand.items() if k != dominant and v[0] > 0}}
         if tr:
             roof["traffic_source"] = tr.get("source")
             # the profile ran 3 timed + 1 warm-up solves: launches per solve = launches_profiled / 4
             per_solve = max(1, tr.get("launches_profiled", 4) // 4)
             roof["traffic_algorithmic_bytes_per_launch"] = k_bytes * B / per_solve
+            roof["kernel_launches_per_step"] = per_solve
+            roof["kernel_avg_launch_ms"] = k_ms / args.steps / per_solve
         if dominant == "grumpkin_level_kernel":
             roof["note"] = "integer-ALU bound (about 1e3 field multiplications per 128-256 B moved): the HBM fraction is for information"
         line = {

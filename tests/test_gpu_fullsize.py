@@ -119,3 +119,29 @@ def test_hundred_thousand_gate_circuit(oracle):
     asg, vals = batch.witness_map(777, 1)
     check_arithmetic_satisfied(circ, {w: int.from_bytes(vals[0, w].tobytes(), "big") for w in range(asg.shape[1])})
     batch.free()
+
+
+def test_tiled_solve_matches_one_batch():
+    """Tiles inside one device (acvm_amd/tiling.py): 700 instances in tiles of 256 (the last one partial) give the
+    same per-instance results and return witnesses as one batch of 700, failing edge-case instances included."""
+    from acvm_amd.tiling import solve_tiled
+    circ, ids = synth.mixed_circuit(1200)
+    data = circ.to_bytes()
+    B = 700
+    values = synth.witness_batch(B, seed=0xAC1D0005)
+    gc = acvm_amd.Circuit(data)
+    ret = gc.witness_set("return_values")
+    assert ret
+    res_t, vals_t = solve_tiled(gc, ids, values, B, 256, ret)
+    batch = acvm_amd.Batch(gc, B, ids)
+    batch.set_initial_witness(values)
+    batch.solve()
+    res = batch.results()
+    assert [r.as_tuple() for r in res_t] == [r.as_tuple() for r in res]
+    for j in range(B):
+        if res[j].status == 0:
+            assert np.array_equal(vals_t[j], batch.extract(ret, j, 1)[0]), j
+        else:
+            assert not vals_t[j].any()
+    assert sum(1 for r in res if r.status != 0) <= 8
+    batch.free()

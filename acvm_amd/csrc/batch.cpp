@@ -671,13 +671,21 @@ int acvm_batch_solve(acvm_batch_t *b) {
             HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
         }
         hipEvent_t last_reg = nullptr, last_dyn = nullptr;
+        uint32_t waited_inverse_level = 0;
         for (size_t L = 0; L < n_levels; L++) {
             uint32_t n = p.level_start[L + 1] - p.level_start[L];
             uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
             hipEvent_t prev_reg = last_reg, prev_dyn = last_dyn;
             bool s_work = n != 0;
             for (int k = 0; k < (int)N_CLS; k++) s_work |= !b->cls_chunks[k][L].empty();
-            if (s_work && prev_dyn) HIPCHK(hipStreamWaitEvent(s, prev_dyn, 0));
+            // the level waits for an inversion batch only if one of its gates reads that batch's rows (the planner put those
+            // gates after the batch, usually several levels after): the batch runs beside all the levels in between
+            const uint32_t need = p.level_needs_inverse[L + 1];  // 1-based inversion level, 0 = none
+            if (s_work && need > waited_inverse_level) {
+                HIPCHK(hipStreamWaitEvent(s, b->ev_sync[2 * (need - 1) + 1], 0));
+                waited_inverse_level = need;
+            }
+            (void)prev_dyn;
             if (n) {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }

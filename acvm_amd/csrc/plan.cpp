@@ -773,6 +773,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     for (auto &iv : inverses) max_level = std::max(max_level, iv.level);
     p.n_levels = max_level;
     p.level_start.assign(max_level + 1, 0);
+    p.level_needs_inverse.assign(max_level + 1, 0);
+    for (auto &iv : inverses) p.level_needs_inverse[iv.use_level] = std::max(p.level_needs_inverse[iv.use_level], iv.level);
     p.dyn_level_start.assign(max_level + 1, 0);
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k].assign(max_level + 1, 0);
     size_t gi = 0, ri = 0, ii = 0;

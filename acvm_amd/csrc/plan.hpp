@@ -58,6 +58,7 @@ struct Plan {
     std::vector<uint32_t> level_start;          // size n_levels + 1, indexes gate_offset
     std::vector<uint32_t> dyn_offset;           // per inversion job (denominator of a SOLVE_DYN gate), level-major
     std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
+    std::vector<uint32_t> level_needs_inverse;  // size n_levels + 1: the latest inversion level (1-based) whose results a gate of level L (1-based index) reads, 0 = none
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
     // ---- in-order program: one record per opcode
     std::vector<uint32_t> prog;

@@ -149,3 +149,29 @@ def test_config1_fixture():
         for w, v in fx["witnesses"].items():
             assert vals[0, int(w)].tobytes().hex() == v
         batch.free()
+
+
+def test_random_circuit_shapes(oracle):
+    """Seeded sweep over circuit shapes the planner treats differently: gate mixes with up to 40 % inversion gates (long
+    chains of early inversion batches, inverse-row reuse), chains (every level one gate: pairs, batches nobody waits for),
+    wide gates, tiny and ragged batch sizes. Each against the oracle, bit for bit."""
+    import random
+    from acvm_amd import synth
+    r = random.Random(0xAC1D)
+    for case in range(36):
+        n_gates = r.choice([1, 2, 7, 60, 150, 400])
+        dyn = r.choice([0, 5, 20, 40])
+        rest = 100 - dyn
+        a = r.randrange(0, rest + 1)
+        b = r.randrange(0, rest - a + 1)
+        mix = (a, b, rest - a - b, dyn)
+        chain = r.random() < 0.3
+        B = r.choice([1, 2, 63, 64, 65, 130])
+        seed = 0xAC1D1000 + case
+        if case % 6 == 5:
+            circ, ids = synth.wide_gate_circuit(n_gates, seed=seed, max_terms=r.choice([3, 8, 15]))
+        else:
+            circ, ids = synth.arithmetic_circuit(n_gates, seed=seed, chain=chain, mix=mix)
+        values = synth.witness_batch(B, seed=seed, edge_cases=(case % 2 == 0))
+        o, g, stats = _run_both(oracle, circ, ids, values, B)
+        _assert_parity(o, g, B)

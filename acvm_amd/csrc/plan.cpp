@@ -765,7 +765,13 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
     }
     // =========================================================================== order by (level, program order), lay out
-    std::stable_sort(gates.begin(), gates.end(), [](const PendingGate &a, const PendingGate &b) { return a.level < b.level; });
+    // within a level the longest wave programs (hosts with tails, many terms) go first: blocks are dispatched in grid order,
+    // and a level ends when its last wave ends
+    // (config 2: 15.6 -> 15.5 ms per solve)
+    std::stable_sort(gates.begin(), gates.end(), [](const PendingGate &a, const PendingGate &b) {
+        if (a.level != b.level) return a.level < b.level;
+        return a.words.size() > b.words.size();
+    });
     std::stable_sort(records.begin(), records.end(), [](const PendingRecord &a, const PendingRecord &b) { return a.level < b.level; });
     uint32_t max_level = 0;
     for (auto &g : gates) max_level = std::max(max_level, g.level);

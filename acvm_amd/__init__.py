@@ -128,7 +128,8 @@ class Stats(C.Structure):
                 ("slow_path_ms", C.c_double), ("dyn_kernel_ms", C.c_double),
                 ("dyn_algorithmic_bytes_per_instance", C.c_uint64), ("n_other_records", C.c_uint32), ("truncated_at", C.c_uint32),
                 ("class_algorithmic_bytes_per_instance", C.c_uint64 * 4), ("class_kernel_ms", C.c_double * 4),
-                ("n_gate_pairs", C.c_uint32), ("n_inverse_slots", C.c_uint32)]
+                ("n_gate_pairs", C.c_uint32), ("n_inverse_slots", C.c_uint32),
+                ("n_scaled_witnesses", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         return {f: (list(getattr(self, f)) if f.startswith("class_") else getattr(self, f)) for f, _ in self._fields_}

@@ -66,6 +66,8 @@ struct acvm_batch {
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr;
     std::vector<hipEvent_t> ev_sync;
+    uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
+    Unscale unscale{};
     uint32_t *d_ped_seed = nullptr;  // seed table of the level Pedersen kernel (one row per Pedersen record)
     uint4 *d_inv = nullptr;  // inverse table: [plan.n_inverse_slots][2 halves][Bp] x 16 B
     uint32_t n_launches = 0;
@@ -95,6 +97,8 @@ struct acvm_batch {
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
         if (d_inv) hipFree(d_inv);
+        for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_scaled_ids})
+            if (p) hipFree(p);
         if (d_ped_seed) hipFree(d_ped_seed);
         for (void *p : {(void *)d_fc_res_opcode, (void *)d_fc_res_desc, (void *)d_fc_pend_desc, (void *)d_fc_res_vals, (void *)d_fc_pend_vals})
             if (p) hipFree(p);
@@ -209,6 +213,7 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->truncated_at = p.truncated_at;
     out->n_gate_pairs = p.n_gate_pairs;
     out->n_inverse_slots = p.n_inverse_slots;
+    out->n_scaled_witnesses = (uint32_t)p.scaled_ids.size();
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
                                                                p.cls_algorithmic_bytes[CLS_HOSTBB];
@@ -245,6 +250,16 @@ static int batch_init(acvm_batch *b) {
         memcpy(&consts[8 * i], d.l, 32);
     }
     if (int rc = upload(&b->d_consts, consts)) return rc;
+    if (!p.scaled_ids.empty()) {
+        std::vector<uint32_t> uc(p.unscale.size() * 8);
+        for (size_t i = 0; i < p.unscale.size(); i++) {
+            const FrH d = frh::to_device_form(p.unscale[i]);
+            memcpy(&uc[8 * i], d.l, 32);
+        }
+        if (int rc = upload(&b->d_unscale_consts, uc)) return rc;
+        if (int rc = upload(&b->d_unscale_index, p.unscale_index)) return rc;
+        if (int rc = upload(&b->d_scaled_ids, p.scaled_ids)) return rc;
+    }
     if (int rc = upload(&b->d_prog, p.prog)) return rc;
     if (int rc = upload(&b->d_prog_offset, p.prog_offset)) return rc;
     if (int rc = upload(&b->d_bytecode, p.bytecode)) return rc;
@@ -325,6 +340,7 @@ static int batch_init(acvm_batch *b) {
         HIPCHK(hipMalloc((void **)&b->d_inv, bytes ? bytes : 16));
     }
     HIPCHK(hipMalloc((void **)&b->d_event, (size_t)(b->B ? b->B : 1) * 4));
+    b->unscale = Unscale{b->d_unscale_index, b->d_unscale_consts, b->d_scaled_ids, (uint32_t)p.scaled_ids.size(), b->d_event};
     b->h_event.assign(b->B, 0xFFFFFFFFu);
     b->slow_index.assign(b->B, -1);
     return 0;
@@ -755,6 +771,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
         slow0 = next_event();
         slow1 = next_event();
         hipEventRecord(slow0, s);
+        launch_unscale_slow(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->unscale);  // the exact kernels work on plain values
         launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
         b->fc_lane.assign(n_slow, acvm_batch::FcLaneState());
         if (int rc = upload_fc_tables(b, n_slow)) return rc;
@@ -881,7 +898,7 @@ static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
     bool ok = hipMalloc((void **)&d_sel, 4) == hipSuccess && hipMalloc((void **)&d_out, 32) == hipSuccess &&
               hipMemcpy(d_sel, &w, 4, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
-        launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out);
+        launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out, b->unscale);
         ok = hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, b->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
     }
     if (d_sel) hipFree(d_sel);
@@ -1132,7 +1149,7 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     int rc = 0;
     for (uint32_t done = 0; done < n && !rc; done += chunk) {
         uint32_t m = std::min(chunk, n - done);
-        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, nw, d_out);
+        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, nw, d_out, b->unscale);
         e = hipMemcpyAsync(values_be32 + (size_t)done * nw * 32, d_out, (size_t)m * nw * 32, hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
         if (e != hipSuccess) rc = set_err(ACVM_E_DEVICE, hipGetErrorString(e));
@@ -1176,7 +1193,7 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)chunk * n_witnesses * 32);
     for (uint32_t done = 0; done < n && e == hipSuccess; done += chunk) {
         const uint32_t m = std::min(chunk, n - done);
-        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, n_witnesses, d_out);
+        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, n_witnesses, d_out, b->unscale);
         e = hipMemcpyAsync(values_be32 + (size_t)done * n_witnesses * 32, d_out, (size_t)m * n_witnesses * 32, hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     }
@@ -1236,7 +1253,7 @@ int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uin
     HIPCHK(hipMemcpy(d_sel, &witness, 4, hipMemcpyHostToDevice));
     hipError_t e = hipMalloc((void **)&d_out, (size_t)b->B * 32);
     if (e != hipSuccess) { hipFree(d_sel); return set_err(ACVM_E_DEVICE, hipGetErrorString(e)); }
-    launch_export(b->stream, b->d_W, b->Bp, 0, b->B, d_sel, 1, d_out);
+    launch_export(b->stream, b->d_W, b->Bp, 0, b->B, d_sel, 1, d_out, b->unscale);
     e = hipMemcpyAsync(out_be32, d_out, (size_t)b->B * 32, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     hipFree(d_out);

@@ -46,16 +46,21 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------ export
-// out: [n][n_sel][32] big-endian for instances [first, first+n) and witness list sel.
+// out: [n][n_sel][32] big-endian for instances [first, first+n) and witness list sel. A witness the level kernels keep scaled
+// (plan.cpp "projective witnesses") is multiplied by 1 / scale here, unless the instance went through the exact path, whose
+// columns unscale_slow_kernel already restored.
 __global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first,
                                                              uint32_t n, const uint32_t *__restrict__ sel, uint32_t n_sel,
-                                                             uint8_t *__restrict__ out) {
+                                                             uint8_t *__restrict__ out, const Unscale u, uint32_t k0) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t k = blockIdx.y;
+    uint32_t k = k0 + blockIdx.y;
     if (t >= n) return;
     Fr one = fr_zero();
     one.v[0] = 1;
-    Fr x = fr_mul(fr_load(W, sel[k], Bp, first + t), one);  // out of Montgomery form
+    Fr x = fr_load(W, sel[k], Bp, first + t);
+    const uint32_t ui = u.index ? u.index[sel[k]] : 0xFFFFFFFFu;
+    if (ui != 0xFFFFFFFFu && u.event[first + t] == 0xFFFFFFFFu) x = fr_mul(x, fr_const(u.consts, ui));
+    x = fr_mul(x, one);  // out of Montgomery form
     uint8_t *p = out + ((uint64_t)t * n_sel + k) * 32;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -65,6 +70,17 @@ __global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__rest
         q[2] = (uint8_t)(x.v[i] >> 8);
         q[3] = (uint8_t)x.v[i];
     }
+}
+// columns of the instances that continue on the exact path: every scaled witness back to its plain Montgomery value
+__global__ void __launch_bounds__(256) unscale_slow_kernel(uint4 *__restrict__ W, uint64_t Bp, const uint32_t *__restrict__ slow_ids,
+                                                           uint32_t n_slow, const uint32_t *__restrict__ scaled_ids, uint32_t n_scaled,
+                                                           const uint32_t *__restrict__ consts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n_slow * n_scaled) return;
+    const uint32_t k = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
+    const uint64_t j = slow_ids[t];
+    const uint32_t w = scaled_ids[k];
+    fr_store(W, w, Bp, j, fr_mul(fr_load(W, w, Bp, j), fr_const(consts, k)));
 }
 
 // ------------------------------------------------------------------------------------------ level kernel
@@ -224,9 +240,20 @@ void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8
     if (!B || !n_in) return;
     hipLaunchKernelGGL(import_witness_kernel, dim3((B + 255) / 256, n_in), dim3(256), 0, s, W, Bp, B, in, ids, n_in);
 }
-void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out) {
+void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out,
+                   const Unscale &u) {
     if (!n || !n_sel) return;
-    hipLaunchKernelGGL(export_witness_kernel, dim3((n + 255) / 256, n_sel), dim3(256), 0, s, W, Bp, first, n, sel, n_sel, out);
+    // gridDim.y is limited to 65535
+    for (uint32_t done = 0; done < n_sel; done += 65535u) {
+        const uint32_t m = n_sel - done > 65535u ? 65535u : n_sel - done;
+        hipLaunchKernelGGL(export_witness_kernel, dim3((n + 255) / 256, m), dim3(256), 0, s, W, Bp, first, n, sel, n_sel, out, u, done);
+    }
+}
+void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u) {
+    const uint64_t n = (uint64_t)n_slow * u.n_scaled;
+    if (!n) return;
+    hipLaunchKernelGGL(unscale_slow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, Bp, slow_ids, n_slow, u.scaled_ids, u.n_scaled,
+                       u.consts);
 }
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv) {

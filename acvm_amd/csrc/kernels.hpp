@@ -52,9 +52,19 @@ struct DeviceProgram {
     const uint32_t *ped_seed;     // per Pedersen record: hash_single(x of hash_pair(IV[domain separator], n), 0), affine, 16 x u32
 };
 
+// projective witnesses (plan.cpp): device tables behind the export and the hand-over to the exact path
+struct Unscale {
+    const uint32_t *index;       // per witness: row of consts, 0xFFFFFFFF = stored as is (null: no witness is scaled)
+    const uint32_t *consts;      // 1 / scale, 8 x u32 each (device Montgomery form)
+    const uint32_t *scaled_ids;  // the scaled witnesses, in row order
+    uint32_t n_scaled;
+    const uint32_t *event;       // per instance: 0xFFFFFFFF = solved by the level kernels (its column is still scaled)
+};
+
 void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in);
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
-                   uint8_t *out);
+                   uint8_t *out, const Unscale &u);
+void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u);
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv);
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,

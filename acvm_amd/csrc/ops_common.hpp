@@ -123,7 +123,18 @@ __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, ui
         hw = 16;
     }
     const uint32_t *__restrict__ t0 = g + 6;
-    for (uint32_t base = 0; base < n_mac; base += 2) {
+    const uint32_t *__restrict__ t = t0 + 10 * np_mac + 9 * nl_mac;
+    // a product with coefficient +1 (the planner's projective witnesses make that the common product, plan.cpp) shares its
+    // reduction with a multiplied term: a b + c x is one fr29_dot<2>
+    uint32_t base = 0, iu = 0;
+    for (; iu < np_pos && base < n_mac; iu++, base++, t += 2) {
+        Fr29 c0;
+        const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, local, c0);
+        const Fr29 l[2] = {gate_load29(W, Bp, j, t[0], local), x0}, m[2] = {gate_load29(W, Bp, j, t[1], local), c0};
+        gate_h_room(h, hw, 17);
+        h = fr29_addl(h, fr29_dot<2>(l, m));
+    }
+    for (; base < n_mac; base += 2) {
         Fr29 c0, c1, r;
         const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, local, c0);
         if (n_mac - base == 1) {
@@ -136,8 +147,7 @@ __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, ui
         gate_h_room(h, hw, 17);
         h = fr29_addl(h, r);
     }
-    const uint32_t *__restrict__ t = t0 + 10 * np_mac + 9 * nl_mac;
-    for (uint32_t i = 0; i < np_pos; i++, t += 2) {
+    for (; iu < np_pos; iu++, t += 2) {
         const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0], local), gate_load29(W, Bp, j, t[1], local));
         gate_h_room(h, hw, 17);
         h = fr29_addl(h, x);

@@ -518,6 +518,63 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             if (known[slot.second]) lvl = std::max(lvl, level[slot.second]);
         return lvl;
     };
+    // =========================================================================== projective witnesses
+    // A witness that only Arithmetic opcodes touch may be kept as scale_w * value: the gate that solves it picks scale_w so that
+    // its most expensive coefficient becomes 1 (q_M a b + q_1 c + q_c over q_o: the product needs no coefficient multiplication
+    // and shares one Montgomery reduction with q_1' c), and every later gate divides its coefficients by the scales of its
+    // operands -- all on the host, field arithmetic is exact, so the canonical value scale_w^-1 * stored is bit-identical.
+    // Pinned (scale 1): initial witnesses and everything a non-Arithmetic opcode mentions. Export and the exact path unscale.
+    std::vector<uint8_t> pinned(nw, 0), is_scaled(nw, 0);
+    const bool scaling_on = !getenv("ACVM_NO_SCALE");
+    {
+        auto pin = [&](uint32_t w) { if (w < nw) pinned[w] = 1; };
+        auto pin_expr = [&](const Expr &e) {
+            for (auto &t : e.mul) { pin(t.l); pin(t.r); }
+            for (auto &t : e.lin) pin(t.w);
+        };
+        for (uint32_t i = 0; i < n_initial; i++) pin(initial_ids[i]);
+        for (uint32_t oi = 0; oi < c.opcodes.size(); oi++) {
+            const Opcode &o = c.opcodes[oi];
+            if (o.kind == OP_ARITHMETIC) continue;
+            for (auto &slot : out_slots[oi]) pin(slot.second);
+            switch (o.kind) {
+            case OP_BLACKBOX:
+                for (int g = 0; g < 4; g++)
+                    for (auto &in : o.bb->in[g]) pin(in.witness);
+                for (auto &in : o.bb->in_agg) pin(in.witness);
+                for (uint32_t w : o.bb->out) pin(w);
+                break;
+            case OP_DIRECTIVE:
+                pin_expr(o.dir->a); pin_expr(o.dir->b); pin_expr(o.dir->predicate);
+                pin(o.dir->q); pin(o.dir->r);
+                for (uint32_t w : o.dir->bw) pin(w);
+                for (auto &el : o.dir->sort_inputs)
+                    for (auto &ex : el) pin_expr(ex);
+                break;
+            case OP_MEMORY_INIT:
+                for (uint32_t w : o.init) pin(w);
+                break;
+            case OP_MEMORY_OP:
+                pin_expr(o.mem_operation); pin_expr(o.mem_index); pin_expr(o.mem_value); pin_expr(o.predicate);
+                break;
+            case OP_BRILLIG:
+                pin_expr(o.brillig->predicate);
+                for (auto &in : o.brillig->inputs) {
+                    pin_expr(in.single);
+                    for (auto &e : in.arr) pin_expr(e);
+                }
+                for (auto &ot : o.brillig->outputs) {
+                    pin(ot.w);
+                    for (uint32_t w : ot.arr) pin(w);
+                }
+                break;
+            default: break;
+            }
+        }
+    }
+    std::vector<FrH> ws, wsi;  // scale and 1 / scale of the scaled witnesses (indexed through scale_slot)
+    std::vector<uint32_t> scale_slot(nw, 0xFFFFFFFFu);
+    const FrH f_one = frh::one(), f_minus_one = frh::neg(frh::one());
     for (uint32_t oi = 0; oi < c.opcodes.size() && p.truncated_at == 0xFFFFFFFFu; oi++) {
         const Opcode &o = c.opcodes[oi];
         if (o.kind != OP_ARITHMETIC) {
@@ -658,8 +715,53 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 lvl = std::max(lvl, inv_level);
             } else kind = GATE_SOLVE;
         }
-        // zero-coefficient products / linear terms contribute exactly 0: drop them from the device program
-        auto sc = [&](const FrH &x) { return scaled ? frh::mul(x, scale) : x; };
+        // zero-coefficient products / linear terms contribute exactly 0: drop them from the device program.
+        // Effective coefficient of a term on the STORED operands: base * c / (scale_a scale_b), base = -1/coeff of the unknown
+        // (times the denominator's scale for SOLVE_DYN: the inverse table holds 1 / stored denominator), then times the
+        // multiplier m this gate chooses for its own output (scale_out = m) -- or for the whole sum of an ASSERT gate.
+        struct Term { bool prod; uint32_t a, b; FrH c, pe; };
+        std::vector<Term> terms;
+        FrH base = scaled ? scale : f_one, inv_base = scaled ? frh::neg(unk_coef) : f_one;
+        if (kind == GATE_SOLVE_DYN && is_scaled[unk_partner]) {
+            base = frh::mul(base, ws[scale_slot[unk_partner]]);
+            inv_base = frh::mul(inv_base, wsi[scale_slot[unk_partner]]);
+        }
+        auto over_scale = [&](FrH x, uint32_t w) { return is_scaled[w] ? frh::mul(x, wsi[scale_slot[w]]) : x; };
+        auto times_scale = [&](FrH x, uint32_t w) { return is_scaled[w] ? frh::mul(x, ws[scale_slot[w]]) : x; };
+        for (auto &t : prods)
+            if (!t.c.is_zero()) terms.push_back({true, t.a, t.b, t.c, over_scale(over_scale(frh::mul(base, t.c), t.a), t.b)});
+        for (auto &t : lins)
+            if (!t.c.is_zero()) terms.push_back({false, t.a, 0, t.c, over_scale(frh::mul(base, t.c), t.a)});
+        // multiply-adds of the device's gate sum for a multiplier m (ops_common.hpp gate_sum_lazy): a product with a general
+        // coefficient is a product (153) and then a dot participant, a +1 product and a general linear term are dot
+        // participants (two share one reduction: 234, a single one 153), a -1 product is a product
+        auto gate_cost = [&](const FrH *m) {
+            uint32_t n_dot = 0, cost = 0;
+            for (auto &t : terms) {
+                const FrH e = m ? frh::mul(t.pe, *m) : t.pe;
+                const bool is_one = e == f_one, is_m1 = e == f_minus_one;
+                if (t.prod) {
+                    if (is_m1) cost += 153;
+                    else { n_dot++; if (!is_one) cost += 153; }
+                } else if (!is_one && !is_m1) n_dot++;
+            }
+            return cost + 234 * (n_dot / 2) + 153 * (n_dot & 1);
+        };
+        FrH m = f_one, m_inv = f_one;
+        bool have_m = false;
+        if (scaling_on && !terms.empty() && (kind == GATE_ASSERT || !pinned[unk_w])) {
+            uint32_t best = gate_cost(nullptr);
+            for (size_t t = 0; t < terms.size() && t < 4 && best > 0; t++) {
+                if (terms[t].pe == f_one) continue;
+                // 1 / pe_t without an inversion: every factor's inverse is at hand
+                FrH cand = frh::mul(inv_base, frh::neg(pool.neg_inv(terms[t].c)));
+                cand = times_scale(cand, terms[t].a);
+                if (terms[t].prod) cand = times_scale(cand, terms[t].b);
+                const uint32_t cst = gate_cost(&cand);
+                if (cst < best) { best = cst; m = cand; m_inv = terms[t].pe; have_m = true; }
+            }
+        }
+        auto sc = [&](const FrH &pe) { return have_m ? frh::mul(pe, m) : pe; };
         // Record layout (consumed by gate_sum_lazy, ops_common.hpp): terms with a general coefficient go through the
         // multiplied lists; terms with coefficient +1 / -1 are listed without a coefficient and are only added / subtracted
         // on the device (up to 255 of each kind, the rest keep an explicit constant).
@@ -672,23 +774,19 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             const FrH d = frh::to_device_form(c);
             for (int i = 0; i < 4; i++) { v.push_back((uint32_t)d.l[i]); v.push_back((uint32_t)(d.l[i] >> 32)); }
         };
-        uint32_t np = 0, nl = 0;
-        const FrH qc_scaled = sc(e.qc);
-        for (auto &t : prods) {
-            if (t.c.is_zero()) continue;
-            np++;
-            const uint32_t c = pool.coef(sc(t.c));
-            if (c == COEF_ONE && pp.size() < 2 * 255) { pp.push_back(t.a); pp.push_back(t.b); }
-            else if (c == COEF_MINUS_ONE && pn.size() < 2 * 255) { pn.push_back(t.a); pn.push_back(t.b); }
-            else { push_coef(pm, sc(t.c)); pm.push_back(t.a); pm.push_back(t.b); }
-        }
-        for (auto &t : lins) {
-            if (t.c.is_zero()) continue;
-            nl++;
-            const uint32_t c = pool.coef(sc(t.c));
-            if (c == COEF_ONE && lp.size() < 255) lp.push_back(t.a);
-            else if (c == COEF_MINUS_ONE && ln.size() < 255) ln.push_back(t.a);
-            else { push_coef(lm, sc(t.c)); lm.push_back(t.a); }
+        const FrH qc_scaled = sc(frh::mul(base, e.qc));
+        for (auto &t : terms) {
+            const FrH e_t = sc(t.pe);
+            const uint32_t cc = pool.coef(e_t);
+            if (t.prod) {
+                if (cc == COEF_ONE && pp.size() < 2 * 255) { pp.push_back(t.a); pp.push_back(t.b); }
+                else if (cc == COEF_MINUS_ONE && pn.size() < 2 * 255) { pn.push_back(t.a); pn.push_back(t.b); }
+                else { push_coef(pm, e_t); pm.push_back(t.a); pm.push_back(t.b); }
+            } else {
+                if (cc == COEF_ONE && lp.size() < 255) lp.push_back(t.a);
+                else if (cc == COEF_MINUS_ONE && ln.size() < 255) ln.push_back(t.a);
+                else { push_coef(lm, e_t); lm.push_back(t.a); }
+            }
         }
         if (pm.size() / 10 > 255 || lm.size() / 9 > 255) { p.truncated_at = oi; break; }
         g.level = lvl + 1;
@@ -696,7 +794,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                    pool.constant(qc_scaled), kind == GATE_SOLVE_DYN ? unk_partner : 0u,
                    (uint32_t)(pp.size() / 2) | (uint32_t)(pn.size() / 2) << 8 | (uint32_t)lp.size() << 16 | (uint32_t)ln.size() << 24};
         for (auto *v : {&pm, &lm, &pp, &pn, &lp, &ln}) g.words.insert(g.words.end(), v->begin(), v->end());
-        (void)np; (void)nl;
         std::sort(reads.begin(), reads.end());
         reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
         g.reads = reads;
@@ -709,6 +806,12 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             known[unk_w] = 1;
             level[unk_w] = g.level;
             p.producer[unk_w] = oi;
+            if (have_m) {  // stored = m * value
+                is_scaled[unk_w] = 1;
+                scale_slot[unk_w] = (uint32_t)ws.size();
+                ws.push_back(m);
+                wsi.push_back(m_inv);
+            }
         }
         if (kind == GATE_SOLVE_DYN) {
             p.n_dyn_gates++;
@@ -717,6 +820,13 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         gates.push_back(std::move(g));
     }
 
+    p.unscale_index.assign(nw, 0xFFFFFFFFu);
+    for (uint32_t w = 0; w < nw; w++)
+        if (is_scaled[w]) {
+            p.unscale_index[w] = (uint32_t)p.scaled_ids.size();
+            p.scaled_ids.push_back(w);
+            p.unscale.push_back(wsi[scale_slot[w]]);
+        }
     // =========================================================================== gate pairs
     // A gate whose only operand from the previous level is the output of a SOLVE gate, and whose other operands are older,
     // runs as a TAIL of that gate: same wave, one level early, the intermediate witness comes from registers instead of HBM

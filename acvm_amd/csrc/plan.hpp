@@ -60,6 +60,11 @@ struct Plan {
     std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
     std::vector<uint32_t> level_needs_inverse;  // size n_levels + 1: the latest inversion level (1-based) whose results a gate of level L (1-based index) reads, 0 = none
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
+    // ---- projective witnesses (plan.cpp): the level kernels keep witness w as scale_w * value wherever only Arithmetic
+    // gates touch it, so that a gate's most expensive coefficient becomes 1. Export and the exact path multiply by 1 / scale.
+    std::vector<uint32_t> scaled_ids;           // witnesses stored scaled
+    std::vector<FrH> unscale;                   // 1 / scale, same order
+    std::vector<uint32_t> unscale_index;        // per witness: index into `unscale`, 0xFFFFFFFF = stored as is
     // ---- in-order program: one record per opcode
     std::vector<uint32_t> prog;
     std::vector<uint32_t> prog_offset;          // per opcode

@@ -110,6 +110,8 @@ typedef struct {
     double class_kernel_ms[4]; /* summed HIP-event durations of the class's level kernels of the last solve (profiling on) */
     uint32_t n_gate_pairs;     /* arithmetic gates that run in their producer's wave and take its output from registers */
     uint32_t n_inverse_slots;  /* rows of the inverse table (denominators of the n_dyn_gates gates, rows reused) */
+    uint32_t n_scaled_witnesses; /* witnesses the level kernels keep as scale x value (unscaled on export and for the exact path) */
+    uint32_t reserved0;
 } acvm_stats_t;
 
 const char *acvm_last_error(void);

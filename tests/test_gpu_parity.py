@@ -175,3 +175,46 @@ def test_random_circuit_shapes(oracle):
         values = synth.witness_batch(B, seed=seed, edge_cases=(case % 2 == 0))
         o, g, stats = _run_both(oracle, circ, ids, values, B)
         _assert_parity(o, g, B)
+
+
+def test_projective_witnesses_hand_over(oracle):
+    """plan.cpp keeps arithmetic-only witnesses as scale x value. Checked here where the scaled columns meet everything else:
+    a constraint on scaled witnesses that fails for some instances in mid-circuit (those columns are unscaled for the exact
+    kernels, the others on export), an inversion gate whose denominator and numerator are scaled, and a black-box opcode
+    reading a witness between scaled ones (pinned to scale 1)."""
+    from acvm_amd.acir import BlackBoxFuncCall as BB, Circuit, Expression as E, FunctionInput as FI, P
+    import acvm_amd
+    ops = [
+        E([(5, 1, 2)], [(P - 1, 3)], 11),                  # w3 = 5 w1 w2 + 11                (scaled)
+        E([(7, 3, 1)], [(3, 2), (P - 9, 4)], 0),           # 9 w4 = 7 w3 w1 + 3 w2            (scaled, reads a scaled witness)
+        E([(2, 4, 5)], [(13, 3)], 1),                      # 2 w4 w5 + 13 w3 + 1 = 0          (inversion gate, scaled denominator)
+        E([], [(1, 5), (P - 1, 6)], 0),                    # w6 = w5                          (read by RANGE below: pinned)
+        BB("RANGE", {"input": FI(6, 254)}),
+        E([(3, 5, 6)], [(P - 1, 7)], 0),                   # w7 = 3 w5 w6
+        E([(1, 7, 7)], [(P - 4, 8)], 5),                   # 4 w8 = w7^2 + 5
+        E([], [(6, 8), (P - 6, 9)], 0),                    # constraint on scaled witnesses: fails unless w9 == w8
+        E([(11, 8, 3)], [(P - 1, 10)], 0),                 # after the failing opcode
+    ]
+    circ = Circuit(10, ops)
+    ids = [1, 2, 9]
+    B = 96
+    # solve once on the oracle with a dummy w9 to learn w8, then feed w9 = w8 to every instance but each 5th
+    rng = np.random.default_rng(7)
+    rows = [[int.from_bytes(rng.bytes(31), "big") for _ in range(2)] for _ in range(B)]
+    rows[3] = [0, 5]      # w3 = 11, w4 = 15/9, fine; zero products
+    rows[4] = [1, 0]
+    rows[6] = [1, (-77 * pow(38, -1, P)) % P]   # makes w4 = 0: the inversion gate's (scaled) denominator vanishes at opcode 2
+    probe = b"".join(b"".join(v.to_bytes(32, "big") for v in r + [0]) for r in rows)
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(circ.to_bytes()), ids, probe, B)
+    w8 = [int.from_bytes(bytes(ovals[j, 8]), "big") for j in range(B)]
+    values = b"".join(b"".join(v.to_bytes(32, "big") for v in rows[j] + [w8[j] if j % 5 else (w8[j] + 1) % P]) for j in range(B))
+    for force_slow in (False, True):
+        o, g, stats = _run_both(oracle, circ, ids, values, B, force_slow=force_slow)
+        _assert_parity(o, g, B)
+        failed = [j for j in range(B) if g[0][j].status != 0]
+        assert set(range(0, B, 5)) <= set(failed)
+        for j in range(0, B, 5):
+            assert g[0][j].as_tuple()[:3] == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_UNSATISFIED, 7)
+        assert g[0][6].as_tuple()[:3] == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_UNSATISFIED, 2)
+        if not force_slow:
+            assert stats["n_scaled_witnesses"] >= 4

@@ -82,3 +82,17 @@ def test_brillig_and_foreign_calls_are_planned():
     br = Brillig(inputs=[E.from_witness(1)], outputs=[2], bytecode=[("ForeignCall", "f", [("Register", 0)], [("Register", 0)]), ("Stop",)])
     st = stats(Circuit(2, [br]), [1])
     assert st["n_other_records"] == 1 and st["class_algorithmic_bytes_per_instance"][3] == 64
+
+
+def test_projective_witnesses_only_where_arithmetic_gates_are_the_only_users():
+    """plan.cpp keeps a witness as scale x value when that makes its gate cheaper -- but never an initial witness and never one a
+    non-Arithmetic opcode mentions (those kernels read plain values)."""
+    circ, ids = synth.arithmetic_circuit(2000, seed=0xAC1D0002)
+    st = stats(circ, ids)
+    assert 1500 <= st["n_scaled_witnesses"] <= 2000          # random coefficients: almost every gate has one to remove
+    # all coefficients +-1: nothing to gain, nothing is scaled
+    ops = [E([(1, 1, 2)], [(P - 1, 3)], 0), E([], [(1, 3), (1, 1), (P - 1, 4)], 0), E([(P - 1, 3, 4)], [(1, 5)], 7)]
+    assert stats(Circuit(5, ops), [1, 2])["n_scaled_witnesses"] == 0
+    # w3 = 5 w1 w2 would be scaled, but RANGE reads it; w4 = 3 w3 + 7 w1 has no other user and is scaled
+    ops = [E([(5, 1, 2)], [(P - 1, 3)], 0), BB("RANGE", {"input": FI(3, 200)}), E([], [(3, 3), (7, 1), (P - 1, 4)], 0)]
+    assert stats(Circuit(4, ops), [1, 2])["n_scaled_witnesses"] == 1

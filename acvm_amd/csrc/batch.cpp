@@ -64,7 +64,8 @@ struct acvm_batch {
     std::vector<hipEvent_t> ev_pool;
     double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
-    hipStream_t stream_dyn = nullptr;
+    hipStream_t stream_dyn = nullptr, stream_heavy = nullptr;
+    std::vector<hipEvent_t> ev_heavy;  // per level: the heavy-class records of the level have run (stream_heavy)
     std::vector<hipEvent_t> ev_sync;
     uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
     Unscale unscale{};
@@ -96,6 +97,8 @@ struct acvm_batch {
                 if (p) hipFree(p);
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
+        for (auto e : ev_heavy) hipEventDestroy(e);
+        if (stream_heavy) hipStreamDestroy(stream_heavy);
         if (d_inv) hipFree(d_inv);
         for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_scaled_ids})
             if (p) hipFree(p);
@@ -237,6 +240,7 @@ static int batch_init(acvm_batch *b) {
         return set_err(ACVM_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&b->stream_dyn, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&b->stream_heavy, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&b->ev_start));
     HIPCHK(hipEventCreate(&b->ev_end));
     const Plan &p = b->plan;
@@ -681,19 +685,35 @@ int acvm_batch_solve(acvm_batch_t *b) {
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             b->ev_sync.push_back(e);
         }
-        bool any_dyn = !p.dyn_offset.empty();
-        if (any_dyn) {
-            HIPCHK(hipEventRecord(b->ev_sync[2 * n_levels], s));
-            HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
+        // Record classes that are bound by the integer pipe or by latency (hashes, Grumpkin, Pedersen, ECDSA, Brillig) run on a
+        // third stream beside the HBM-bound gate levels: level L's heavy records start when level L-1 of the main stream is done,
+        // and a later level (or inversion batch) waits for them only if it reads one of their outputs (plan.level_needs_heavy).
+        auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA; };
+        // (measured, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms; a circuit of heavy records
+        // only gains nothing from a second queue -- config 4 4.3 -> 4.6 ms -- and keeps everything on one stream)
+        bool any_heavy = false, any_main = !p.gate_offset.empty() || !p.cls_offset[CLS_LIGHT].empty();
+        for (int k = 0; k < (int)N_CLS; k++) any_heavy |= heavy_cls(k) && !p.cls_offset[k].empty();
+        hipStream_t s3 = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || !any_main ? s : b->stream_heavy;
+        while (any_heavy && b->ev_heavy.size() < n_levels) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            b->ev_heavy.push_back(e);
         }
-        hipEvent_t last_reg = nullptr, last_dyn = nullptr;
-        uint32_t waited_inverse_level = 0;
+        bool any_dyn = !p.dyn_offset.empty();
+        const bool any_async = any_dyn || any_heavy;
+        if (any_async) {
+            HIPCHK(hipEventRecord(b->ev_sync[2 * n_levels], s));
+            if (any_dyn) HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
+            if (any_heavy) HIPCHK(hipStreamWaitEvent(s3, b->ev_sync[2 * n_levels], 0));
+        }
+        hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_heavy = nullptr;
+        uint32_t waited_inverse_level = 0, waited_heavy_level = 0;
         for (size_t L = 0; L < n_levels; L++) {
             uint32_t n = p.level_start[L + 1] - p.level_start[L];
             uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
-            hipEvent_t prev_reg = last_reg, prev_dyn = last_dyn;
-            bool s_work = n != 0;
-            for (int k = 0; k < (int)N_CLS; k++) s_work |= !b->cls_chunks[k][L].empty();
+            hipEvent_t prev_reg = last_reg;
+            bool s_work = n != 0, h_work = false;
+            for (int k = 0; k < (int)N_CLS; k++) (heavy_cls(k) ? h_work : s_work) |= !b->cls_chunks[k][L].empty();
             // the level waits for an inversion batch only if one of its gates reads that batch's rows (the planner put those
             // gates after the batch, usually several levels after): the batch runs beside all the levels in between
             const uint32_t need = p.level_needs_inverse[L + 1];  // 1-based inversion level, 0 = none
@@ -701,7 +721,11 @@ int acvm_batch_solve(acvm_batch_t *b) {
                 HIPCHK(hipStreamWaitEvent(s, b->ev_sync[2 * (need - 1) + 1], 0));
                 waited_inverse_level = need;
             }
-            (void)prev_dyn;
+            const uint32_t need_h = p.level_needs_heavy[L + 1];  // 1-based level of heavy records, 0 = none
+            if (s_work && need_h > waited_heavy_level) {
+                HIPCHK(hipStreamWaitEvent(s, b->ev_heavy[need_h - 1], 0));
+                waited_heavy_level = need_h;
+            }
             if (n) {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }
@@ -709,30 +733,35 @@ int acvm_batch_solve(acvm_batch_t *b) {
                 if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); reg_pairs.push_back({e0, e1}); }
                 b->n_launches += (n + 65534) / 65535;
             }
+            if (h_work && prev_reg) HIPCHK(hipStreamWaitEvent(s3, prev_reg, 0));  // inputs: levels < L of the main stream
             for (int k = 0; k < (int)N_CLS; k++)
                 for (const LaunchChunk &ch : b->cls_chunks[k][L]) {
+                    hipStream_t sk = heavy_cls(k) ? s3 : s;
                     hipEvent_t e0 = nullptr, e1 = nullptr;
-                    if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }
+                    if (b->profiling) { e0 = next_event(); hipEventRecord(e0, sk); }
                     const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + ch.first;
                     switch (k) {
-                    case CLS_LIGHT: launch_light_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                    case CLS_HASH: launch_hash_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                    case CLS_GRUMPKIN: launch_grumpkin_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                    case CLS_BRILLIG: launch_brillig_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                    case CLS_PEDERSEN: launch_pedersen_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                    case CLS_ECDSA: launch_ecdsa_level(s, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                    case CLS_HOSTBB:  // host callbacks: everything launched so far on either stream must have finished
+                    case CLS_LIGHT: launch_light_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                    case CLS_HASH: launch_hash_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                    case CLS_GRUMPKIN: launch_grumpkin_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                    case CLS_BRILLIG: launch_brillig_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                    case CLS_PEDERSEN: launch_pedersen_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                    case CLS_ECDSA: launch_ecdsa_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                    case CLS_HOSTBB:  // host callbacks: everything launched so far on any stream must have finished
                         if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
+                        if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
                         for (uint32_t r = 0; r < ch.count; r++)
                             if (int rc = run_host_blackbox(b, p.prog[p.cls_offset[k][ch.first + r] + 1], false, 0)) return rc;
                         break;
                     }
-                    if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); cls_pairs[k].push_back({e0, e1}); }
+                    if (b->profiling) { e1 = next_event(); hipEventRecord(e1, sk); cls_pairs[k].push_back({e0, e1}); }
                     b->n_launches++;
                 }
-            if (s_work && any_dyn) { HIPCHK(hipEventRecord(b->ev_sync[2 * L], s)); last_reg = b->ev_sync[2 * L]; }
+            if (h_work) { HIPCHK(hipEventRecord(b->ev_heavy[L], s3)); last_heavy = b->ev_heavy[L]; }
+            if (s_work && any_async) { HIPCHK(hipEventRecord(b->ev_sync[2 * L], s)); last_reg = b->ev_sync[2 * L]; }
             if (nd) {
                 if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
+                if (p.inv_needs_heavy[L + 1]) HIPCHK(hipStreamWaitEvent(s2, b->ev_heavy[p.inv_needs_heavy[L + 1] - 1], 0));
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s2); }
                 launch_inverse_batch(s2, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_event);
@@ -742,6 +771,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
                 last_dyn = b->ev_sync[2 * L + 1];
             }
         }
+        if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
         if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
         if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
     }

@@ -501,7 +501,11 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     }
 
     // =========================================================================== generic-instance replay + levels
-    auto assign_out = [&](uint32_t oi, uint32_t lvl) {
+    // witnesses produced by a record of a heavy class (those run on their own stream, batch.cpp): level of the record, else 0
+    std::vector<uint32_t> heavy_level(nw, 0);
+    auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA; };
+    std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, heavy level it reads)
+    auto assign_out = [&](uint32_t oi, uint32_t lvl, bool heavy) {
         // insert_value (pwg/mod.rs:338-357) for the outputs of opcode oi, in record order
         for (auto &slot : out_slots[oi]) {
             uint32_t w = slot.second;
@@ -510,6 +514,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 known[w] = 1;
                 level[w] = lvl;
                 p.producer[w] = oi;
+                if (heavy) heavy_level[w] = lvl;
             }
         }
     };
@@ -650,13 +655,21 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             if (!rd.ok) { p.truncated_at = oi; break; }
             uint32_t lvl = std::max(rd.lvl, extra_level);
             lvl = out_levels(oi, lvl) + 1;
-            assign_out(oi, lvl);
+            const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi];
+            if (!is_heavy(rec_cls)) {  // a main-stream record: which heavy records does it wait for (compared outputs are reads too)
+                uint32_t h = 0;
+                for (uint32_t w : rd.ws) h = std::max(h, heavy_level[w]);
+                for (auto &slot : out_slots[oi])
+                    if (known[slot.second]) h = std::max(h, heavy_level[slot.second]);
+                if (h) heavy_reads.push_back({lvl, h});
+            }
+            assign_out(oi, lvl, is_heavy(rec_cls));
             if (o.kind == OP_MEMORY_INIT || o.kind == OP_MEMORY_OP) blocks[o.block_id].level = lvl;
             uint64_t bytes = 32ull * (rd.distinct() + bytes_written);
             p.algorithmic_bytes += bytes;
             p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
             p.n_other_records++;
-            records.push_back({lvl, o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi], oi});
+            records.push_back({lvl, rec_cls, oi});
             continue;
         }
         const Expr &e = o.expr;
@@ -891,6 +904,16 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     p.level_start.assign(max_level + 1, 0);
     p.level_needs_inverse.assign(max_level + 1, 0);
     for (auto &iv : inverses) p.level_needs_inverse[iv.use_level] = std::max(p.level_needs_inverse[iv.use_level], iv.level);
+    // heavy record classes run on a third stream beside the levels (batch.cpp): a level of the main stream (gates, light
+    // records) or an inversion batch waits for the heavy records of level h only if it reads one of their outputs
+    p.level_needs_heavy.assign(max_level + 1, 0);
+    p.inv_needs_heavy.assign(max_level + 1, 0);
+    for (auto &g : gates) {
+        const uint32_t eff = g.fused ? g.level - 1 : g.level;  // a tail runs in its host's wave, one level early
+        for (uint32_t w : g.reads) p.level_needs_heavy[eff] = std::max(p.level_needs_heavy[eff], heavy_level[w]);
+    }
+    for (auto &hr : heavy_reads) p.level_needs_heavy[hr.first] = std::max(p.level_needs_heavy[hr.first], hr.second);
+    for (auto &iv : inverses) p.inv_needs_heavy[iv.level] = std::max(p.inv_needs_heavy[iv.level], heavy_level[iv.partner]);
     p.dyn_level_start.assign(max_level + 1, 0);
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k].assign(max_level + 1, 0);
     size_t gi = 0, ri = 0, ii = 0;

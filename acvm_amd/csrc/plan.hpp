@@ -59,6 +59,8 @@ struct Plan {
     std::vector<uint32_t> dyn_offset;           // per inversion job (denominator of a SOLVE_DYN gate), level-major
     std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
     std::vector<uint32_t> level_needs_inverse;  // size n_levels + 1: the latest inversion level (1-based) whose results a gate of level L (1-based index) reads, 0 = none
+    std::vector<uint32_t> level_needs_heavy;    // size n_levels + 1: the latest level (1-based) of heavy-class records whose outputs the main stream's level L reads, 0 = none
+    std::vector<uint32_t> inv_needs_heavy;      // same for the inversion batch of level L
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
     // ---- projective witnesses (plan.cpp): the level kernels keep witness w as scale_w * value wherever only Arithmetic
     // gates touch it, so that a gate's most expensive coefficient becomes 1. Export and the exact path multiply by 1 / scale.

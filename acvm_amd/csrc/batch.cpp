@@ -1192,6 +1192,37 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     return 0;
 }
 
+// per-instance digest of the solved witness map (definition: kernels_hash.hip, include/acvm_amd.h)
+int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32) {
+    if (!b || (n && !out32)) return set_err(ACVM_E_INVALID, "null argument");
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
+    if (!n) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    const Plan &p = b->plan;
+    const uint32_t n_seg = digest_segments(p.n_witnesses), n_slow = (uint32_t)b->slow_ids.size();
+    int32_t *d_slow_index = nullptr;
+    uint32_t *d_leaves = nullptr;
+    uint8_t *d_out = nullptr;
+    auto cleanup = [&]() { hipFree(d_slow_index); hipFree(d_leaves); hipFree(d_out); };
+    hipError_t e = hipMalloc((void **)&d_slow_index, (size_t)b->B * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_slow_index, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice);
+    // instances in slices whose leaf scratch stays below 1 GiB
+    const uint32_t slice = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(64, (1ull << 30) / ((uint64_t)std::max(n_seg, 1u) * 32)));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_leaves, (size_t)std::max(n_seg, 1u) * 32 * slice);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)slice * 32);
+    for (uint32_t done = 0; done < n && e == hipSuccess; done += slice) {
+        const uint32_t m = std::min(slice, n - done);
+        launch_digest(b->stream, b->d_W, b->Bp, first + done, m, p.n_witnesses, b->d_producer, b->unscale, d_slow_index, b->d_assigned, n_slow, d_leaves, d_out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out32 + (size_t)done * 32, d_out, (size_t)m * 32, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    }
+    cleanup();
+    if (e != hipSuccess) return set_err(ACVM_E_DEVICE, hipGetErrorString(e));
+    return 0;
+}
+
 int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,
                                  uint8_t *values_be32) {
     if (!b || (n_witnesses && (!witnesses || !values_be32))) return set_err(ACVM_E_INVALID, "null argument");

@@ -111,6 +111,10 @@ void launch_hostbb_apply_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t fi
                                uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event);
 void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const ExactLanes &L, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
                                const uint32_t *outs, uint32_t n_out, const uint8_t *active, const uint8_t *rc, const uint8_t *vals);
+// per-instance digest of the witness map (kernels_hash.hip): leaves = scratch of digest_segments(n_witnesses) x 8 x n words
+uint32_t digest_segments(uint32_t n_witnesses);
+void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
+                   const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out);
 // InProgress -> Solved after the last opcode
 void launch_exact_finish(hipStream_t s, const ExactLanes &L);
 

@@ -110,53 +110,98 @@ static inline __device__ __noinline__ Digest sha256_msg(const MsgBuf &m, uint32_
     a = a + b + (y); d = rotr32(d ^ a, 8);  \
     c = c + d; b = rotr32(b ^ c, 7);
 
-static inline __device__ __noinline__ Digest blake2s_msg(const MsgBuf &m, uint32_t len) {
+// one compression: h <- F(h, 16 little-endian message words, byte counter t, final-block flag)
+static inline __device__ __noinline__ void blake2s_compress(uint32_t (&h)[8], const uint32_t (&w)[16], uint32_t t, bool last) {
     const uint32_t IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    uint32_t h[8];
+    uint32_t v[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = IV[i]; }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+    // fully unrolled: the message schedule indices are compile-time constants, w[] stays in registers
+    constexpr uint8_t SIGMA[10][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = w[SIGMA[r][i]];
+        B2S_G(v[0], v[4], v[8], v[12], x[0], x[1]);
+        B2S_G(v[1], v[5], v[9], v[13], x[2], x[3]);
+        B2S_G(v[2], v[6], v[10], v[14], x[4], x[5]);
+        B2S_G(v[3], v[7], v[11], v[15], x[6], x[7]);
+        B2S_G(v[0], v[5], v[10], v[15], x[8], x[9]);
+        B2S_G(v[1], v[6], v[11], v[12], x[10], x[11]);
+        B2S_G(v[2], v[7], v[8], v[13], x[12], x[13]);
+        B2S_G(v[3], v[4], v[9], v[14], x[14], x[15]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+}
+__device__ __forceinline__ void blake2s_init(uint32_t (&h)[8]) {
+    const uint32_t IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
 #pragma unroll
     for (int i = 0; i < 8; i++) h[i] = IV[i];
     h[0] ^= 0x01010020u;  // digest length 32, no key, fanout 1, depth 1
+}
+static inline __device__ __noinline__ Digest blake2s_msg(const MsgBuf &m, uint32_t len) {
+    uint32_t h[8];
+    blake2s_init(h);
     const uint32_t n_blocks = len == 0 ? 1u : (len + 63u) / 64u;
     for (uint32_t b = 0; b < n_blocks; b++) {
         uint32_t w[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) w[i] = m.word_le(16u * b + i, len);
         const bool last = b == n_blocks - 1;
-        const uint32_t t = last ? len : 64u * (b + 1);
-        uint32_t v[16];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = IV[i]; }
-        v[12] ^= t;
-        if (last) v[14] = ~v[14];
-        // fully unrolled: the message schedule indices are compile-time constants, w[] stays in registers
-        constexpr uint8_t SIGMA[10][16] = {
-            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
-            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
-            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
-            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
-            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
-#pragma unroll
-        for (int r = 0; r < 10; r++) {
-            uint32_t x[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) x[i] = w[SIGMA[r][i]];
-            B2S_G(v[0], v[4], v[8], v[12], x[0], x[1]);
-            B2S_G(v[1], v[5], v[9], v[13], x[2], x[3]);
-            B2S_G(v[2], v[6], v[10], v[14], x[4], x[5]);
-            B2S_G(v[3], v[7], v[11], v[15], x[6], x[7]);
-            B2S_G(v[0], v[5], v[10], v[15], x[8], x[9]);
-            B2S_G(v[1], v[6], v[11], v[12], x[10], x[11]);
-            B2S_G(v[2], v[7], v[8], v[13], x[12], x[13]);
-            B2S_G(v[3], v[4], v[9], v[14], x[14], x[15]);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+        blake2s_compress(h, w, last ? len : 64u * (b + 1), last);
     }
     Digest out;
 #pragma unroll
     for (int i = 0; i < 8; i++) out.d[i] = h[i];  // little-endian words
     return out;
 }
+// Blake2s-256 over a stream of 32-byte pieces whose number is only known at the end (the witness-map digest of
+// kernels_hash.hip): a full block is held back until more data arrives, because the last block is compressed differently
+struct Blake2sPieces {
+    uint32_t h[8], pend[16], lo[8];
+    uint32_t n;  // pieces absorbed
+    bool pend_full, have_lo;
+    __device__ __forceinline__ void begin() { blake2s_init(h); n = 0; pend_full = false; have_lo = false; }
+    __device__ __forceinline__ void put(const uint32_t (&x)[8]) {
+        if (!have_lo) {
+            if (pend_full) { blake2s_compress(h, pend, 32u * n, false); pend_full = false; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) lo[i] = x[i];
+            have_lo = true;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { pend[i] = lo[i]; pend[8 + i] = x[i]; }
+            pend_full = true;
+            have_lo = false;
+        }
+        n++;
+    }
+    __device__ __forceinline__ void finish(uint32_t (&out)[8]) {
+        if (have_lo) {
+            if (pend_full) blake2s_compress(h, pend, 32u * (n - 1), false);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { pend[i] = lo[i]; pend[8 + i] = 0u; }
+            blake2s_compress(h, pend, 32u * n, true);
+        } else if (pend_full) {
+            blake2s_compress(h, pend, 32u * n, true);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) pend[i] = 0u;
+            blake2s_compress(h, pend, 0u, true);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = h[i];
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ Keccak-256
 static __constant__ uint64_t KECCAK_RC[24] = {

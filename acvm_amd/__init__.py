@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
     "acvm_batch_set_profiling", "acvm_batch_pending_foreign_call", "acvm_batch_pending_foreign_call_inputs",
     "acvm_batch_resolve_foreign_call", "acvm_circuit_assert_message", "acvm_circuit_witness_set", "acvm_batch_error_string",
-    "acvm_batch_extract_witnesses", "acvm_witness_map_decode", "acvm_witness_map_encode", "acvm_batch_witness_map_bytes",
+    "acvm_batch_extract_witnesses", "acvm_batch_digest", "acvm_witness_map_decode", "acvm_witness_map_encode", "acvm_batch_witness_map_bytes",
 ]
 
 
@@ -178,6 +178,7 @@ def lib():
     L.acvm_circuit_witness_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
     L.acvm_batch_error_string.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
     L.acvm_batch_extract_witnesses.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.acvm_batch_digest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     for f in (L.acvm_witness_map_decode, L.acvm_witness_map_encode, L.acvm_batch_witness_map_bytes):
         f.restype = C.c_longlong
     L.acvm_witness_map_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -361,6 +362,14 @@ class Batch:
         vals = np.zeros((n, len(ws), 32), dtype=np.uint8)
         _check(lib().acvm_batch_extract_witnesses(self._h, arr, len(ws), first, n, vals.ctypes.data))
         return vals
+
+    def digest(self, first=0, n=None):
+        """Per-instance 32-byte digest of the witness map (acvm_batch_digest): uint8 array [n][32]."""
+        import numpy as np
+        n = self.B - first if n is None else n
+        out = np.zeros((n, 32), dtype=np.uint8)
+        _check(lib().acvm_batch_digest(self._h, first, n, out.ctypes.data))
+        return out
 
     def witness_map_bytes(self, instance: int) -> bytes:
         """The instance's WitnessMap in the reference's wire format (finalize() + compressWitness)."""

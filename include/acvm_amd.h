@@ -218,6 +218,16 @@ int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, 
  */
 int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap);
 /*
+ * Per-instance 32-byte digest of the solved witness map for instances [first, first + n), out32 = [n][32] (SURVEY 8d, config 5:
+ * callers that keep only the return witnesses use it to compare whole maps without moving them -- the map of the reference is
+ * what ACVM::finalize returns, acvm/src/pwg/mod.rs:176-181). Definition: take the ASSIGNED witnesses in ascending index, each as
+ * its 32-byte big-endian canonical value (FieldElement::to_be_bytes, acir_field/src/generic_ark.rs:269-277); leaf_k =
+ * Blake2s-256 of those with index in [256 k, 256 k + 256), in order (an empty segment hashes the empty string);
+ * digest = Blake2s-256(leaf_0 || leaf_1 || ... || leaf_{ceil(n_witnesses / 256) - 1}). Works for solved, failed and waiting
+ * instances alike (the map as it stands).
+ */
+int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32);
+/*
  * extract_indices (acvm_js/src/public_witness.rs:10-21; getReturnWitness / getPublicParametersWitness / getPublicWitness
  * with the sets above): values of the listed witnesses for instances [first, first + n), values_be32 = [n][n_witnesses][32].
  * Fails with ACVM_E_STATE and "Failed to extract witness W from witness map. Witness not found." (instance appended) when

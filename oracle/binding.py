@@ -186,3 +186,14 @@ def solve_batch(circuit: Circuit, ids, values_be: bytes, B: int, want_witness=Tr
                              assigned.ctypes.data if want_witness else None,
                              vals.ctypes.data if want_witness else None, nw, n_threads)
     return res, assigned, vals
+
+
+def witness_map_digest(assigned, values) -> bytes:
+    """CPU restatement (Python hashlib) of the definition of acvm_batch_digest in include/acvm_amd.h, for ONE instance -- checker only:
+    assigned[w] truthy, values[w] = 32 big-endian bytes."""
+    import hashlib
+    nw = len(assigned)
+    leaves = []
+    for k in range(0, nw, 256):
+        leaves.append(hashlib.blake2s(b"".join(bytes(values[w]) for w in range(k, min(k + 256, nw)) if assigned[w])).digest())
+    return hashlib.blake2s(b"".join(leaves)).digest()

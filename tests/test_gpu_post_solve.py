@@ -84,3 +84,46 @@ def test_solved_witness_map_in_the_wire_format(golden):
     asg, vals = b.witness_map(1, 1)
     assert got == {w: int.from_bytes(vals[0, w].tobytes(), "big") for w in range(asg.shape[1]) if asg[0, w]}
     assert got[fx["resultWitness"]] == int(fx["expectedResult"], 16) and all(got[k] == v for k, v in iw.items())
+
+
+@pytest.mark.parametrize("n_gates,force_slow", [(3, False), (300, False), (300, True), (700, False)])
+def test_witness_map_digest(oracle, n_gates, force_slow):
+    """acvm_batch_digest against its definition evaluated with hashlib over the ORACLE's witness map: solved instances (scaled
+    columns, the planner's assigned set), failing instances (per-instance assigned set, the map as it stands at the failure),
+    every instance through the exact kernels, odd and even numbers of assigned witnesses per segment, several segments."""
+    import acvm_amd
+    from acvm_amd import synth
+    circ, ids = synth.arithmetic_circuit(n_gates, seed=0xD16E57 + n_gates)
+    B = 70
+    values = synth.witness_batch(B, seed=0xD16E57 + n_gates)   # instances 0..7 are edge cases, some of them fail
+    oc = oracle.Circuit(circ.to_bytes())
+    ores, oasg, ovals = oracle.solve_batch(oc, ids, values, B)
+    batch = acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), B, ids)
+    batch.set_force_slow_path(force_slow)
+    batch.set_initial_witness(values)
+    batch.solve()
+    got = batch.digest()
+    part = batch.digest(first=5, n=9)
+    batch.free()
+    assert n_gates < 100 or any(r.status != 0 for r in ores)
+    for j in range(B):
+        assert bytes(got[j]) == oracle.witness_map_digest(oasg[j], ovals[j]), f"instance {j} (status {ores[j].status})"
+    assert np.array_equal(part, got[5:14])
+
+
+def test_witness_map_digest_with_black_box_outputs(oracle):
+    """Digest over a map that holds pinned (hash in / out) and scaled witnesses side by side, and an empty circuit."""
+    import acvm_amd
+    from acvm_amd import synth
+    circ, ids = synth.mixed_circuit(400, seed=0xD16E58)
+    B = 66
+    values = synth.witness_batch(B, n_in=len(ids), seed=0xD16E58)
+    oc = oracle.Circuit(circ.to_bytes())
+    ores, oasg, ovals = oracle.solve_batch(oc, ids, values, B)
+    batch = acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), B, ids)
+    batch.set_initial_witness(values)
+    batch.solve()
+    got = batch.digest()
+    batch.free()
+    for j in range(B):
+        assert bytes(got[j]) == oracle.witness_map_digest(oasg[j], ovals[j]), f"instance {j} (status {ores[j].status})"

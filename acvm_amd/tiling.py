@@ -9,10 +9,12 @@ import numpy as np
 from . import Batch
 
 
-def solve_tiled(circuit, initial_ids, values_be: bytes, n_instances: int, tile: int, keep_witnesses, solver=None):
+def solve_tiled(circuit, initial_ids, values_be: bytes, n_instances: int, tile: int, keep_witnesses, solver=None, digests=None):
     """Solves n_instances instances (values_be = [n_instances][len(initial_ids)][32] big-endian) in tiles of `tile`.
     Returns (results, values): results = list of per-instance Result, values = uint8 array [n_instances][len(keep)][32] with
-    zeros for instances that did not solve (their return witnesses may be unassigned)."""
+    zeros for instances that did not solve (their return witnesses may be unassigned). `digests`: optional uint8 array
+    [n_instances][32] that receives the per-instance digest of the full witness map (Batch.digest) -- what SURVEY 8d keeps of a
+    config-5 tile besides the return witnesses."""
     ids = list(initial_ids)
     keep = list(keep_witnesses)
     row = len(ids) * 32
@@ -32,6 +34,8 @@ def solve_tiled(circuit, initial_ids, values_be: bytes, n_instances: int, tile: 
             batch.solve()
             res = batch.results()[:n]
             results.extend(res)
+            if digests is not None:
+                digests[first:first + n] = batch.digest(0, n)
             if keep:
                 asg, vals = None, None
                 solved = [i for i in range(n) if res[i].status == 0]

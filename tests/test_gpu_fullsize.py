@@ -132,11 +132,13 @@ def test_tiled_solve_matches_one_batch():
     gc = acvm_amd.Circuit(data)
     ret = gc.witness_set("return_values")
     assert ret
-    res_t, vals_t = solve_tiled(gc, ids, values, B, 256, ret)
+    dig_t = np.zeros((B, 32), dtype=np.uint8)
+    res_t, vals_t = solve_tiled(gc, ids, values, B, 256, ret, digests=dig_t)
     batch = acvm_amd.Batch(gc, B, ids)
     batch.set_initial_witness(values)
     batch.solve()
     res = batch.results()
+    assert np.array_equal(dig_t, batch.digest())
     assert [r.as_tuple() for r in res_t] == [r.as_tuple() for r in res]
     for j in range(B):
         if res[j].status == 0:

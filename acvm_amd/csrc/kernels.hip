@@ -113,7 +113,7 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
             fr_store(W, out, Bp, j, fr29_pack(acc));
         }
         if (!(w0 & GATE_TAIL_FLAG)) break;
-        if (host) local = acc;  // every tail reads the host's output
+        if (host || (w0 & GATE_SETLOCAL_FLAG)) local = acc;  // the tails read the host's output until a record takes `local` over
         host = false;
         g += gate_record_words(g);
     }

@@ -76,6 +76,7 @@ struct GateSum {
 // operand slot GATE_LOCAL: the output of the record that ran before this one in the same wave (plan.cpp "gate pairs")
 static constexpr uint32_t GATE_LOCAL = 0xFFFFFFFFu;
 static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;
+static constexpr uint32_t GATE_SETLOCAL_FLAG = 1u << 25;  // this record's output becomes GATE_LOCAL of the records behind it
 __device__ __forceinline__ Fr29 gate_load29(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, uint32_t slot, const Fr29 &local) {
     if (slot == GATE_LOCAL) return local;  // wave-uniform
     return fr29_from(fr_load(W, slot, Bp, j));

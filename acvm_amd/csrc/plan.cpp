@@ -83,8 +83,11 @@ struct PendingGate {
     uint32_t n_tails = 0;            // gates fused behind this one (they run in the same wave and read this output from registers)
     size_t last_w0 = 0;              // position in `words` of the header of the last record of the chain
     bool fused = false;              // this gate runs as the tail of another one
+    uint32_t run_level = 0;          // the level whose launch executes it (its wave's host's level)
+    uint32_t owner = 0, last_gate = 0;  // host only: the gate whose output the wave's `local` registers hold at the end of the program, and the last record
 };
-static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;   // w0: another record follows and reads this gate's output as GATE_LOCAL
+static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;   // w0: another record follows in the same wave
+static constexpr uint32_t GATE_SETLOCAL_FLAG = 1u << 25;  // w0: this record's output replaces the wave's `local` registers (GATE_LOCAL of the records behind it)
 static constexpr uint32_t GATE_LOCAL = 0xFFFFFFFFu;    // operand slot: the output of the preceding record of the same wave
 // operand words of a gate record (layout in build_plan)
 template <class F>
@@ -840,34 +843,55 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             p.scaled_ids.push_back(w);
             p.unscale.push_back(wsi[scale_slot[w]]);
         }
-    // =========================================================================== gate pairs
-    // A gate whose only operand from the previous level is the output of a SOLVE gate, and whose other operands are older,
-    // runs as a TAIL of that gate: same wave, one level early, the intermediate witness comes from registers instead of HBM
-    // (it is still written: it is a witness). Up to GATE_MAX_TAILS tails per host, all reading the host's output; a tail
-    // does not host tails itself (its own consumers were levelled against its nominal level).
-    static constexpr uint32_t GATE_MAX_TAILS = 3;
+    // =========================================================================== gate pairs / wave programs
+    // A gate whose only operand from the previous level is the output of a SOLVE gate, and whose other operands are older than
+    // that gate's whole wave, runs BEHIND it in the same wave: the intermediate witness comes from registers (`local`) instead
+    // of HBM (it is still written: it is a witness). A wave program is the host and up to max_tails records. The records read
+    // `local`: the host's output at first; a record may take `local` over (GATE_SETLOCAL_FLAG) when its first consumer is
+    // appended directly behind it, so chains host -> tail -> tail's consumer run in one wave as well (the records that read the
+    // previous owner are all in front of it by then).
+    static constexpr uint32_t GATE_MAX_TAILS = 5;
+    for (uint32_t gi = 0; gi < gates.size(); gi++) {
+        gates[gi].run_level = gates[gi].level;
+        gates[gi].owner = gates[gi].last_gate = gi;
+    }
     if (!getenv("ACVM_NO_PAIRS")) {
         const uint32_t max_tails = getenv("ACVM_MAX_TAILS") ? (uint32_t)atoi(getenv("ACVM_MAX_TAILS")) : GATE_MAX_TAILS;
-        std::vector<uint32_t> producer_gate(nw, 0xFFFFFFFFu);
+        const bool chains = !getenv("ACVM_NO_CHAINS");
+        std::vector<uint32_t> producer_gate(nw, 0xFFFFFFFFu), root_of(gates.size(), 0xFFFFFFFFu);
         for (uint32_t gi = 0; gi < gates.size(); gi++)
             if ((gates[gi].words[0] & 0xff) == GATE_SOLVE) producer_gate[gates[gi].words[2]] = gi;
         for (uint32_t ci = 0; ci < gates.size(); ci++) {
             PendingGate &cg = gates[ci];
             const uint32_t kind = cg.words[0] & 0xff;
-            if (kind == GATE_SOLVE_DYN || cg.level < 2 || cg.n_tails) continue;
+            if (kind == GATE_SOLVE_DYN || cg.level < 2) continue;
             uint32_t crit = 0xFFFFFFFFu, n_crit = 0;
             for (uint32_t w : cg.reads)
                 if (level[w] + 1 == cg.level) { crit = w; n_crit++; }
             if (n_crit != 1) continue;
-            const uint32_t hi = producer_gate[crit];
-            if (hi == 0xFFFFFFFFu || hi == ci) continue;
+            const uint32_t pi = producer_gate[crit];
+            if (pi == 0xFFFFFFFFu || pi == ci) continue;
+            const uint32_t hi = gates[pi].fused ? root_of[pi] : pi;
+            if (hi != pi && !chains) continue;
             PendingGate &hg = gates[hi];
-            if (hg.n_tails >= max_tails || hg.fused || hg.level + 1 != cg.level) continue;
+            if (hg.n_tails >= max_tails) continue;
+            bool older = true;  // everything else must be known before the wave's level runs
+            for (uint32_t w : cg.reads)
+                if (w != crit && level[w] + 1 > hg.level) older = false;
+            if (!older) continue;
+            if (pi != hg.owner) {
+                if (pi != hg.last_gate) continue;  // a record in between still reads the current `local`
+                hg.words[hg.last_w0] |= GATE_SETLOCAL_FLAG;
+                hg.owner = pi;
+            }
             cg.fused = true;
+            cg.run_level = hg.level;
+            root_of[ci] = hi;
             for_each_operand_word(cg.words, [&](uint32_t &slot) { if (slot == crit) slot = GATE_LOCAL; });
             hg.words[hg.last_w0] |= GATE_TAIL_FLAG;
             hg.last_w0 = hg.words.size();
             hg.words.insert(hg.words.end(), cg.words.begin(), cg.words.end());
+            hg.last_gate = ci;
             hg.n_tails++;
             p.n_gate_pairs++;
         }
@@ -909,7 +933,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     p.level_needs_heavy.assign(max_level + 1, 0);
     p.inv_needs_heavy.assign(max_level + 1, 0);
     for (auto &g : gates) {
-        const uint32_t eff = g.fused ? g.level - 1 : g.level;  // a tail runs in its host's wave, one level early
+        const uint32_t eff = g.run_level;  // a tail runs in its host's wave, at least one level early
         for (uint32_t w : g.reads) p.level_needs_heavy[eff] = std::max(p.level_needs_heavy[eff], heavy_level[w]);
     }
     for (auto &hr : heavy_reads) p.level_needs_heavy[hr.first] = std::max(p.level_needs_heavy[hr.first], hr.second);

@@ -157,6 +157,7 @@ void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 }
 
 // ---- component probes for the parity tests (acvm_debug_grumpkin): in / out are canonical 8 x u32 little-endian
+static __device__ uint32_t g_probe_window_table[15 * 27];
 __global__ void grumpkin_probe_kernel(GrumpkinTables T, uint32_t what, uint32_t param, const uint32_t *in, uint32_t n_in, uint32_t *out) {
     if (threadIdx.x || blockIdx.x) return;
     auto ld = [&](uint32_t i) { Fr c; for (int k = 0; k < 8; k++) c.v[k] = in[8 * i + k]; return c; };
@@ -186,6 +187,10 @@ __global__ void grumpkin_probe_kernel(GrumpkinTables T, uint32_t what, uint32_t 
         GJac a = gj_add_aff(gj_inf(), p0), b = gj_add_aff(gj_add_aff(gj_inf(), p1), p0);
         GAff r = gj_to_aff(gj_add(a, b), &inf);
         st(0, r.x); st(1, r.y);
+    } else if (what == 8 || what == 9) {  // in[0] * (in[1], in[2]): 8 = GLV + window table (SchnorrVerify's path), 9 = double-and-add
+        const GAff pt{fr_from_canonical(ld(1)), fr_from_canonical(ld(2))};
+        GAff a = gj_to_aff(grumpkin_var_base_mul(pt, ld(0), what == 8 ? g_probe_window_table : nullptr, 1, 0), &inf);
+        st(0, a.x); st(1, a.y);
     } else if (what == 4) {
         GAff a = gaff_load(param >> 24 == 0 ? T.ped : param >> 24 == 1 ? T.win : param >> 24 == 2 ? T.small : T.skew, param & 0xffffffu);
         st(0, a.x); st(1, a.y);

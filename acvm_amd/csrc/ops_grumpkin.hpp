@@ -296,11 +296,93 @@ __device__ __forceinline__ GJac ladder_term(const GrumpkinTables &T, const Fr &v
 // verify_signature: pk on curve, s and e (mod q) nonzero, R = e * pk + s * G finite, and
 // blake2s(be32(compress(R.x, pk.x, pk.y)) || message) == the e bytes of the signature.
 // sig / msg bytes come through `sig_byte(i)` / `msg_byte(i)`; the challenge preimage is staged in `m`.
-// e * P for a per-lane affine point P. With a window table (15 x 27 words per lane in device scratch, word-major like every
-// per-lane buffer): 4-bit fixed windows, 64 x (4 doublings + 1 addition of the lane's own table entry) -- the instruction
-// stream is the same on every lane, whereas bit-serial double-and-add makes the whole wave pay the addition on every bit
-// (some lane always has the bit set): 0.89 M instead of 1.4 M instructions per verification. Without a table (Brillig's
-// black-box op): double-and-add.
+//
+// ---- e * P for a per-lane affine point P.
+// Schoolbook product of two little-endian 32-bit-limb integers (once per lane: the scalar split below)
+template <int N, int M>
+__device__ __forceinline__ void bn_mul(const uint32_t (&a)[N], const uint32_t (&b)[M], uint32_t (&r)[N + M]) {
+#pragma unroll
+    for (int i = 0; i < N + M; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            const uint64_t t = (uint64_t)a[i] * b[j] + r[i + j] + c;
+            r[i + j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        r[i + M] = (uint32_t)c;
+    }
+}
+// GLV split for Grumpkin (j-invariant 0): lambda * (x, y) = (beta x, y) with lambda^2 + lambda + 1 = 0 (mod q),
+// lambda = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe and beta = grumpkin_beta(). The lattice of (u, v) with
+// u + v lambda = 0 (mod q) has the reduced basis (A, -B), (B', A) with determinant q (A = 0x89d3256894d213e2,
+// B = 0x6f4d8248eeb859fc8211bbeb7d4f1129, B' = B + 0x89d3256894d213e2 = 0x6f4d...250b). For k < q:
+//   c1 = floor(k g1 / 2^384), g1 = floor(2^384 A / q);   c2 = floor(k g2 / 2^384), g2 = floor(2^384 B / q)
+//   k1 = k - c1 A - c2 B',   k2 = c1 B - c2 A            =>  k1 + k2 lambda = k (mod q) for ANY integers c1, c2,
+// and with these c1, c2 (each within 1 of the exact quotient) |k1|, |k2| < |A| + |B'| < 2^127. Returns the magnitudes
+// (4 limbs each) and the signs. Checked against a big-integer model over random and edge scalars (tests/test_gpu_grumpkin.py
+// drives it through SchnorrVerify against the oracle's plain double-and-add).
+struct GlvSplit {
+    uint32_t k1[4], k2[4];
+    bool neg1, neg2;
+};
+__device__ __forceinline__ GlvSplit glv_split(const Fr &k) {
+    const uint32_t g1[7] = {0xc85147d0u, 0x5236df9eu, 0x539a2471u, 0x247280eeu, 0xc7e0b3d2u, 0xd91d232eu, 0x00000002u};
+    const uint32_t g2[9] = {0x6972c2b8u, 0xa08c1126u, 0x5eaa26e6u, 0xa5e38cfbu, 0x391eb18du, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x00000002u};
+    const uint32_t A[2] = {0x94d213e2u, 0x89d32568u};
+    const uint32_t B[4] = {0x7d4f1129u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};
+    const uint32_t Bp[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+    uint32_t kk[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) kk[i] = k.v[i];
+    uint32_t p1[15], p2[17];
+    bn_mul<8, 7>(kk, g1, p1);
+    bn_mul<8, 9>(kk, g2, p2);
+    const uint32_t c1[2] = {p1[12], p1[13]}, c2[4] = {p2[12], p2[13], p2[14], p2[15]};
+    uint32_t c1A[4], c2Bp[8], c1B[6], c2A[6];
+    bn_mul<2, 2>(c1, A, c1A);
+    bn_mul<4, 4>(c2, Bp, c2Bp);
+    bn_mul<2, 4>(c1, B, c1B);
+    bn_mul<4, 2>(c2, A, c2A);
+    auto widen = [](const uint32_t *x, int n) {
+        Fr r = fr_zero();
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i < n) r.v[i] = x[i];
+        return r;
+    };
+    Fr k1, k2, t;
+    fr_sub256(t, k, widen(c1A, 4));
+    fr_sub256(k1, t, widen(c2Bp, 8));   // two's complement mod 2^256
+    fr_sub256(k2, widen(c1B, 6), widen(c2A, 6));
+    GlvSplit r;
+    r.neg1 = (k1.v[7] >> 31) != 0;
+    r.neg2 = (k2.v[7] >> 31) != 0;
+    Fr n1, n2;
+    fr_sub256(n1, fr_zero(), k1);
+    fr_sub256(n2, fr_zero(), k2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r.k1[i] = r.neg1 ? n1.v[i] : k1.v[i];
+        r.k2[i] = r.neg2 ? n2.v[i] : k2.v[i];
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t nibble128(const uint32_t (&k)[4], uint32_t w) {  // 4-bit window w of a 128-bit integer
+    uint32_t limb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if ((uint32_t)i == (w >> 3)) limb = k[i];
+    return (limb >> (4u * (w & 7u))) & 15u;
+}
+// With a window table (15 x 27 words per lane in device scratch, word-major like every per-lane buffer): e = k1 + k2 lambda
+// (GLV, |k1|, |k2| < 2^127), then 32 joint 4-bit windows: 4 doublings + the lane's table entry |k1|_w * P + the entry
+// |k2|_w * P mapped through (X, Y, Z) -> (beta X, Y, Z); a negative half negates Y. The instruction stream is the same on every
+// lane (bit-serial double-and-add makes the whole wave pay the addition on every bit: some lane always has the bit set), and
+// the split halves the doublings: 128 doublings + 64 additions instead of 256 + 64. Without a table (Brillig's black-box op):
+// double-and-add.
 __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e, uint32_t *tbl, uint64_t Bp, uint64_t j) {
     GJac a = gj_inf();
     if (!tbl) {
@@ -326,18 +408,27 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
         q = gj_add_aff(q, P);
         put(d, q);
     }
-    for (int w = 63; w >= 0; w--) {
+    const GlvSplit sp = glv_split(e);
+    const Fr29 beta = fr29_from(grumpkin_beta());
+    for (int w = 31; w >= 0; w--) {
         a = gj_dbl(gj_dbl(gj_dbl(gj_dbl(a))));
-        const uint32_t d = (limb_at(e, (uint32_t)w >> 3) >> (4u * ((uint32_t)w & 7u))) & 15u;
-        if (d) {  // per lane: its own table row
-            GJac o;
+        for (uint32_t half = 0; half < 2; half++) {  // wave-uniform
+            const uint32_t d = half ? nibble128(sp.k2, (uint32_t)w) : nibble128(sp.k1, (uint32_t)w);
+            const bool neg = half ? sp.neg2 : sp.neg1;
+            if (d) {  // per lane: its own table row
+                GJac o;
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                o.X.v[k] = tbl[(uint64_t)((d - 1u) * 27u + k) * Bp + j];
-                o.Y.v[k] = tbl[(uint64_t)((d - 1u) * 27u + 9 + k) * Bp + j];
-                o.Z.v[k] = tbl[(uint64_t)((d - 1u) * 27u + 18 + k) * Bp + j];
+                for (int k = 0; k < 9; k++) {
+                    o.X.v[k] = tbl[(uint64_t)((d - 1u) * 27u + k) * Bp + j];
+                    o.Y.v[k] = tbl[(uint64_t)((d - 1u) * 27u + 9 + k) * Bp + j];
+                    o.Z.v[k] = tbl[(uint64_t)((d - 1u) * 27u + 18 + k) * Bp + j];
+                }
+                if (half) o.X = fr29_mul(o.X, beta);                       // lambda * (X, Y, Z) = (beta X, Y, Z); < 1.4
+                const Fr29 ny = fr29_norm(fr29_subl(g29_zero(), o.Y, 1));  // 2p - Y: in (0, 2p) since Y != 0 (mod p) on this curve
+#pragma unroll
+                for (int k = 0; k < 9; k++) o.Y.v[k] = neg ? ny.v[k] : o.Y.v[k];
+                a = gj_add(a, o);
             }
-            a = gj_add(a, o);
         }
     }
     return a;

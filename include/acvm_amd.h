@@ -129,7 +129,8 @@ int acvm_selftest(uint32_t n, uint64_t seed);
 /* Component probes of the Grumpkin kernels (parity tests of barretenberg's building blocks against SURVEY Appendix A):
  * what 0 = host table point (param = table << 24 | index; tables: 0 Pedersen k*D[i] at i*512+k-1, 1 8-bit windows,
  * 2 ladder k*D[3j+1], 3 skew D[3j+2]); 1 = device hash_single(in[0], parity param); 2 = device hash-ladder
- * compress(in[0..n_in)), 3 = device fixed-base product (window table param, 256-bit integer in[0]); 4 = device table point.
+ * compress(in[0..n_in)), 3 = device fixed-base product (window table param, 256-bit integer in[0]); 4 = device table point;
+ * 8 / 9 = in[0] * (in[1], in[2]) for a 256-bit integer and an affine point: 8 through SchnorrVerify's GLV + window-table path, 9 by double-and-add.
  * in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian. */
 int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64);
 

@@ -66,3 +66,33 @@ def test_point_arithmetic_against_affine_formulas():
         assert g[0] == v * BETA % P and g[1] == BETA
     p0, p1 = tbl(0), tbl(512)
     assert acvm_amd.debug_grumpkin(7, 0) == aff_add(p0, aff_add(p1, p0))
+
+
+def test_var_base_mul_glv_against_affine_double_and_add():
+    """e * P as SchnorrVerify computes it (GLV split e = k1 + k2 lambda, joint 4-bit windows over the lane's table; probe 8)
+    against the device's plain double-and-add (probe 9) and against affine arithmetic in Python, on scalars that exercise the
+    split: 0, 1, q - 1, multiples of lambda (k1 = 0), negative halves, 2^127 boundaries, random."""
+    Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    LAM = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
+
+    def mul(k, pt):
+        acc = None
+        while k:
+            if k & 1:
+                acc = aff_add(acc, pt)
+            pt = aff_add(pt, pt)
+            k >>= 1
+        return acc
+
+    g = acvm_amd.debug_grumpkin(3, 0, [1])                 # the generator through the fixed-base path
+    assert mul(LAM, g) == (g[0] * BETA % P, g[1])          # the endomorphism pair the split relies on
+    pts = [g, mul(0xC0FFEE1234567, g)]
+    r = random.Random(11)
+    scalars = [0, 1, 2, 15, 16, Q - 1, Q - 2, LAM, LAM + 1, LAM - 1, Q - LAM, 2 * LAM % Q, 7 * LAM % Q, (Q - 3 * LAM) % Q, 1 << 127, (1 << 127) - 1,
+               (1 << 128) + 5, 1 << 253, Q // 2, Q // 3] + [r.randrange(Q) for _ in range(12)]
+    for pt in pts:
+        for k in scalars:
+            want = mul(k, pt) or (0, 0)                    # infinity is exported as (0, 0)
+            assert acvm_amd.debug_grumpkin(8, 0, [k, pt[0], pt[1]]) == want, hex(k)
+        for k in scalars[:8] + scalars[-2:]:
+            assert acvm_amd.debug_grumpkin(9, 0, [k, pt[0], pt[1]]) == (mul(k, pt) or (0, 0)), hex(k)

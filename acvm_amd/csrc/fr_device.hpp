@@ -174,6 +174,28 @@ FR_HD __forceinline__ Fr29 fr29_mul(const Fr29 &a, const Fr29 &b) {
     r.v[8] = (uint32_t)acc;
     return r;
 }
+// Low 29 bits of the canonical value of a fully reduced Montgomery representative: a * 2^-261 mod p = (a + m p) / 2^261 is
+// already < p for a < p (it can only reach p for a = 0, which gives 0), so its low limb is column 9 of the reduction and the
+// upper seven columns are never formed: 44 multiply-adds instead of 72 + conditional subtraction + repack. For the byte-sized
+// inputs of the hash black boxes (fetch_nearest_bytes of an 8-bit witness, generic_ark.rs:305-317).
+FR_HD __forceinline__ uint32_t fr29_redc_low(const Fr29 &a) {
+    constexpr uint32_t M = 0x1fffffffu;
+    uint64_t acc = 0;
+    uint32_t m[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        acc += a.v[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        const uint32_t lo = (uint32_t)acc;
+        m[k] = (((lo & 1u) << 28) - lo) & M;
+        acc += ((uint64_t)m[k] << 28) + m[k];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int i = 1; i < 9; i++) acc += (uint64_t)m[i] * fr_p29(9 - i);
+    return (uint32_t)acc & M;
+}
 // a * a * 2^-261 mod p: the 36 cross products are taken once against the doubled limbs (45 + 81 multiply-adds instead of
 // 81 + 81). Same contract as fr29_mul.
 FR_HD __forceinline__ Fr29 fr29_sqr(const Fr29 &a) {

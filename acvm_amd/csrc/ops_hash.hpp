@@ -295,6 +295,11 @@ __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restri
         if (nb > 32u) return op_fail_msg(DE_PANIC, 0, DM_FETCH_BYTES);  // slice end out of range (generic_ark.rs:316)
         const Fr cur = next;
         if (i + 1 < n_in) next = p.load(ins[2 * (i + 1)]);
+        if (nb <= 3u) {  // byte arrays: only the low limb of the canonical value is formed (fr29_redc_low)
+            const uint32_t low = fr29_redc_low(fr29_from(cur));
+            for (uint32_t k = 0; k < nb; k++) m.put(low >> (8u * k));
+            continue;
+        }
         const Fr c = fr_to_canonical(cur);
 #pragma unroll
         for (int k = 0; k < 32; k++)

@@ -54,6 +54,11 @@ int main() {
             FrH want = frh::mul(frh::add(frh::add(a, a), b), frh::add(b, b));
             if (!same(fr29_pack(pr), want)) { fails++; printf("lazy mul mismatch %d\n", it); }
         }
+        {   // truncated reduction: low 29 bits of the canonical value
+            Fr one_c = fr_zero(); one_c.v[0] = 1;
+            const Fr c = fr_mul(da, one_c);
+            if (fr29_redc_low(fr29_from(da)) != (c.v[0] & 0x1fffffffu)) { fails++; printf("redc_low mismatch %d\n", it); }
+        }
         if (!same(fr_add(da, db), frh::add(a, b))) { fails++; printf("add mismatch %d\n", it); }
         if (!same(fr_sub(da, db), frh::sub(a, b))) { fails++; printf("sub mismatch %d\n", it); }
         if (!same(fr_neg(da), frh::neg(a))) { fails++; printf("neg mismatch %d\n", it); }

@@ -707,13 +707,21 @@ int acvm_batch_solve(acvm_batch_t *b) {
             if (any_heavy) HIPCHK(hipStreamWaitEvent(s3, b->ev_sync[2 * n_levels], 0));
         }
         hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_heavy = nullptr;
+        bool main_dirty = false;  // the main stream has launches behind last_reg
         uint32_t waited_inverse_level = 0, waited_heavy_level = 0;
         for (size_t L = 0; L < n_levels; L++) {
             uint32_t n = p.level_start[L + 1] - p.level_start[L];
             uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
-            hipEvent_t prev_reg = last_reg;
             bool s_work = n != 0, h_work = false;
             for (int k = 0; k < (int)N_CLS; k++) (heavy_cls(k) ? h_work : s_work) |= !b->cls_chunks[k][L].empty();
+            // "levels < L of the main stream are done": recorded only where another stream is about to wait for it (an event
+            // between two gate launches costs more than the launch gap itself)
+            if ((nd || h_work) && main_dirty) {
+                HIPCHK(hipEventRecord(b->ev_sync[2 * L], s));
+                last_reg = b->ev_sync[2 * L];
+                main_dirty = false;
+            }
+            hipEvent_t prev_reg = last_reg;
             // the level waits for an inversion batch only if one of its gates reads that batch's rows (the planner put those
             // gates after the batch, usually several levels after): the batch runs beside all the levels in between
             const uint32_t need = p.level_needs_inverse[L + 1];  // 1-based inversion level, 0 = none
@@ -758,7 +766,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
                     b->n_launches++;
                 }
             if (h_work) { HIPCHK(hipEventRecord(b->ev_heavy[L], s3)); last_heavy = b->ev_heavy[L]; }
-            if (s_work && any_async) { HIPCHK(hipEventRecord(b->ev_sync[2 * L], s)); last_reg = b->ev_sync[2 * L]; }
+            main_dirty |= s_work;
             if (nd) {
                 if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
                 if (p.inv_needs_heavy[L + 1]) HIPCHK(hipStreamWaitEvent(s2, b->ev_heavy[p.inv_needs_heavy[L + 1] - 1], 0));

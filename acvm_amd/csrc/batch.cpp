@@ -67,7 +67,7 @@ struct acvm_batch {
     hipStream_t stream_dyn = nullptr, stream_heavy = nullptr;
     std::vector<hipEvent_t> ev_heavy;  // per level: the heavy-class records of the level have run (stream_heavy)
     std::vector<hipEvent_t> ev_sync;
-    uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
+    uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_unscale_plain = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
     Unscale unscale{};
     uint32_t *d_ped_seed = nullptr;  // seed table of the level Pedersen kernel (one row per Pedersen record)
     uint4 *d_inv = nullptr;  // inverse table: [plan.n_inverse_slots][2 halves][Bp] x 16 B
@@ -100,7 +100,7 @@ struct acvm_batch {
         for (auto e : ev_heavy) hipEventDestroy(e);
         if (stream_heavy) hipStreamDestroy(stream_heavy);
         if (d_inv) hipFree(d_inv);
-        for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_scaled_ids})
+        for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_unscale_plain, (void *)d_scaled_ids})
             if (p) hipFree(p);
         if (d_ped_seed) hipFree(d_ped_seed);
         for (void *p : {(void *)d_fc_res_opcode, (void *)d_fc_res_desc, (void *)d_fc_pend_desc, (void *)d_fc_res_vals, (void *)d_fc_pend_vals})
@@ -261,6 +261,12 @@ static int batch_init(acvm_batch *b) {
             memcpy(&uc[8 * i], d.l, 32);
         }
         if (int rc = upload(&b->d_unscale_consts, uc)) return rc;
+        for (size_t i = 0; i < p.unscale.size(); i++) {
+            uint64_t c[4];
+            frh::to_canonical(p.unscale[i], c);
+            memcpy(&uc[8 * i], c, 32);
+        }
+        if (int rc = upload(&b->d_unscale_plain, uc)) return rc;
         if (int rc = upload(&b->d_unscale_index, p.unscale_index)) return rc;
         if (int rc = upload(&b->d_scaled_ids, p.scaled_ids)) return rc;
     }
@@ -344,7 +350,7 @@ static int batch_init(acvm_batch *b) {
         HIPCHK(hipMalloc((void **)&b->d_inv, bytes ? bytes : 16));
     }
     HIPCHK(hipMalloc((void **)&b->d_event, (size_t)(b->B ? b->B : 1) * 4));
-    b->unscale = Unscale{b->d_unscale_index, b->d_unscale_consts, b->d_scaled_ids, (uint32_t)p.scaled_ids.size(), b->d_event};
+    b->unscale = Unscale{b->d_unscale_index, b->d_unscale_consts, b->d_unscale_plain, b->d_scaled_ids, (uint32_t)p.scaled_ids.size(), b->d_event};
     b->h_event.assign(b->B, 0xFFFFFFFFu);
     b->slow_index.assign(b->B, -1);
     return 0;

@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__rest
     one.v[0] = 1;
     Fr x = fr_load(W, sel[k], Bp, first + t);
     const uint32_t ui = u.index ? u.index[sel[k]] : 0xFFFFFFFFu;
-    if (ui != 0xFFFFFFFFu && u.event[first + t] == 0xFFFFFFFFu) x = fr_mul(x, fr_const(u.consts, ui));
-    x = fr_mul(x, one);  // out of Montgomery form
+    // out of Montgomery form; a scaled column leaves it through the canonical integer 1 / scale instead of 1
+    x = fr_mul(x, ui != 0xFFFFFFFFu && u.event[first + t] == 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);
     uint8_t *p = out + ((uint64_t)t * n_sel + k) * 32;
 #pragma unroll
     for (int i = 0; i < 8; i++) {

@@ -56,6 +56,7 @@ struct DeviceProgram {
 struct Unscale {
     const uint32_t *index;       // per witness: row of consts, 0xFFFFFFFF = stored as is (null: no witness is scaled)
     const uint32_t *consts;      // 1 / scale, 8 x u32 each (device Montgomery form)
+    const uint32_t *consts_plain; // 1 / scale as a canonical integer: the Montgomery product with it is the canonical VALUE (unscale and leave Montgomery form in one)
     const uint32_t *scaled_ids;  // the scaled witnesses, in row order
     uint32_t n_scaled;
     const uint32_t *event;       // per instance: 0xFFFFFFFF = solved by the level kernels (its column is still scaled)

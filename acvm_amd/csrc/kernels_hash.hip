@@ -45,11 +45,10 @@ __global__ void __launch_bounds__(128) digest_leaf_kernel(const uint4 *__restric
         const bool present = generic ? producer[w] != 0xFFFFFFFFu : ((assigned[(uint64_t)(w >> 5) * n_slow + lane] >> (w & 31)) & 1u) != 0u;
         if (!present) continue;
         Fr x = fr_load(W, w, Bp, j);
-        if (generic && u.index) {
-            const uint32_t ui = u.index[w];
-            if (ui != 0xFFFFFFFFu) x = fr_mul(x, fr_const(u.consts, ui));
-        }
-        x = fr_to_canonical(x);
+        const uint32_t ui = generic && u.index ? u.index[w] : 0xFFFFFFFFu;  // wave-uniform unless the wave holds flagged instances
+        Fr one = fr_zero();
+        one.v[0] = 1;
+        x = fr_mul(x, ui != 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);  // canonical value (unscaled where the column is scaled)
         uint32_t m[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) m[i] = bswap32(x.v[7 - i]);  // big-endian bytes as little-endian message words

@@ -51,6 +51,24 @@ def main(d):
             print(f"{short(row['Name'])[:36]:36s} {int(row['Calls']):6d} {float(row['TotalDurationNs']) / 1e6:10.3f} "
                   f"{float(row['AverageNs']) / 1e3:10.2f} {float(row['MinNs']) / 1e3:9.2f} {float(row['MaxNs']) / 1e3:9.2f} "
                   f"{float(row['Percentage']):6.2f}")
+    # the --stats average mixes the warm-up solve (first touch of a fresh witness table) with the timed ones: per solve, from the trace
+    trace = os.path.join(d, "trace", "trace_kernel_trace.csv")
+    if os.path.exists(trace):
+        per = defaultdict(list)
+        with open(trace) as f:
+            for row in csv.DictReader(f):
+                per[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+        print("\n== average launch duration per solve (same kernel trace; solve 0 = warm-up, 1..3 = timed steps; bench.py's HIP events bracket the last one)")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
+            if len(v) < 8 or len(v) % 4:
+                continue
+            v.sort()
+            n = len(v) // 4
+            cells = []
+            for i in range(4):
+                seg = v[i * n:(i + 1) * n]
+                cells.append(f"{sum(e - s for s, e in seg) / n / 1e3:9.2f} us x {n}")
+            print(f"{k[:36]:36s} " + "   ".join(cells))
     cal_f = read_pmc(os.path.join(d, "cal_fetch", "pmc_counter_collection.csv"), "FETCH_SIZE")
     cal_w = read_pmc(os.path.join(d, "cal_write", "pmc_counter_collection.csv"), "WRITE_SIZE")
     fcorr, wcorr = 2.0, 1.0

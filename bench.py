@@ -79,8 +79,8 @@ def load_traffic(workload, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)  # the device reaches its clocks after about two solves (profiles/README.md)
     ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen", "mixed"])
     ap.add_argument("--gates", type=int, default=10000)
     ap.add_argument("--pedersen", type=int, default=8)

@@ -161,6 +161,12 @@ def main():
         parity = {"checked_instances": sample, "bit_exact": ok}
         cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "kind": "port",
                "sample": f"{sample} instances of the same circuit, oracle/liboracle.so, {threads} threads, {cpu_s:.2f} s"}
+        # SURVEY 8d asks for one core as well: a few seconds of the same oracle on one thread
+        one = max(1, min(sample, int(round(3.0 * sample / (cpu_s * threads)))))
+        c1 = time.perf_counter()
+        ob.solve_batch(oc, ids, values[: one * len(ids) * 32], one, want_witness=False, n_threads=1)
+        one_s = time.perf_counter() - c1
+        cpu["single_thread"] = {"value": one / one_s, "unit": "witnesses/s", "sample": f"{one} instances, 1 thread, {one_s:.2f} s"}
         if not ok:
             print(json.dumps({"error": "parity check failed; the measurement is void", "parity": parity}), flush=True)
             raise SystemExit(2)

@@ -288,14 +288,25 @@ __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restri
     // get_hash_input (hash.rs:51-86): fetch_nearest_bytes = low ceil(num_bits / 8) bytes, least significant first
     MsgBuf m{scratch, p.Bp, p.j, 0u, 0u};
     m.begin();
-    // the next witness is requested before the current one is converted and staged (two loads in flight per lane)
-    Fr next = n_in ? p.load(ins[0]) : fr_zero();
-    for (uint32_t i = 0; i < n_in; i++) {
+    for (uint32_t i = 0; i < n_in;) {
         const uint32_t nb = (ins[2 * i + 1] + 7u) / 8u;
         if (nb > 32u) return op_fail_msg(DE_PANIC, 0, DM_FETCH_BYTES);  // slice end out of range (generic_ark.rs:316)
-        const Fr cur = next;
-        if (i + 1 < n_in) next = p.load(ins[2 * (i + 1)]);
-        if (nb <= 3u) {  // byte arrays: only the low limb of the canonical value is formed (fr29_redc_low)
+        // byte arrays, four witnesses at a time: four rows in flight and four independent reductions for the one wave a SIMD
+        // holds at these batch sizes; only the low limb of each canonical value is formed (fr29_redc_low)
+        if (nb == 1u && i + 4u <= n_in && (ins[2 * i + 3] + 7u) / 8u == 1u && (ins[2 * i + 5] + 7u) / 8u == 1u && (ins[2 * i + 7] + 7u) / 8u == 1u) {
+            const Fr a0 = p.load(ins[2 * i]), a1 = p.load(ins[2 * i + 2]), a2 = p.load(ins[2 * i + 4]), a3 = p.load(ins[2 * i + 6]);
+            const uint32_t l0 = fr29_redc_low(fr29_from(a0)), l1 = fr29_redc_low(fr29_from(a1)), l2 = fr29_redc_low(fr29_from(a2)),
+                           l3 = fr29_redc_low(fr29_from(a3));
+            m.put(l0);
+            m.put(l1);
+            m.put(l2);
+            m.put(l3);
+            i += 4u;
+            continue;
+        }
+        const Fr cur = p.load(ins[2 * i]);
+        i++;
+        if (nb <= 3u) {
             const uint32_t low = fr29_redc_low(fr29_from(cur));
             for (uint32_t k = 0; k < nb; k++) m.put(low >> (8u * k));
             continue;

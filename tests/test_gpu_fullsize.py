@@ -63,8 +63,25 @@ def test_config2_full_size_properties():
     assert batch.solve() == n_bad
     v2, a2 = batch.witness(ret)
     assert np.array_equal(v1, v2) and np.array_equal(a1, a2)
+    # (5) a checksum of checksums over EVERY instance: the per-instance digest of the whole witness map (acvm_batch_digest) is the
+    # same when the 65 536 instances are solved as eight tiles of 8 192 through one reused handle -- (2) for all instances, not a
+    # sample -- and equals the digest computed with hashlib over the CPU oracle's map for the sampled instances
+    from acvm_amd.tiling import solve_tiled
+    from oracle import binding as oracle
+    dig = batch.digest()
     small.free()
     batch.free()
+    dig_t = np.zeros((B, 32), dtype=np.uint8)
+    res_t, _ = solve_tiled(acvm_amd.Circuit(data), ids, values, B, 8192, [], digests=dig_t)
+    assert [r.as_tuple() for r in res_t] == [r.as_tuple() for r in res]
+    assert np.array_equal(dig, dig_t)
+    assert len({bytes(d) for d in dig[8:]}) == B - 8                      # distinct inputs, distinct maps
+    picks = sample[:6] + [0, 3]
+    sub = b"".join(values[j * len(ids) * 32:(j + 1) * len(ids) * 32] for j in picks)
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, sub, len(picks))
+    for i, j in enumerate(picks):
+        assert ores[i].as_tuple() == res[j].as_tuple()
+        assert bytes(dig[j]) == oracle.witness_map_digest(oasg[i], ovals[i]), j
 
 
 def test_mixed_circuit_full_batch_properties():

@@ -88,8 +88,29 @@ __device__ __forceinline__ void canon_divrem(const Fr &a, const Fr &b, Fr &q, Fr
         rem.v[0] = (uint32_t)r;
         return;
     }
-    const int top = (int)canon_num_bits(a) - 1;
-    for (int i = top; i >= 0; i--) {
+    // The first bits(b) - 1 steps of the restoring division only shift dividend bits into the remainder (it stays below
+    // 2^(bits(b) - 1) <= b, nothing can be subtracted): start with those bits in place. Two full-width operands, the common
+    // large-divisor case, then take 1-2 steps instead of 254.
+    const int na = (int)canon_num_bits(a), nb = (int)canon_num_bits(b);
+    if (na < nb) {  // a < b
+        rem = a;
+        return;
+    }
+    const uint32_t s = (uint32_t)(na - (nb - 1));  // bits of a still to be processed, 1 <= s <= 256
+    {   // rem = a >> s (s = 256 only for b = 1, which took the small-divisor path above)
+        const uint32_t ws = s >> 5, bs = s & 31u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                if ((uint32_t)m == (uint32_t)k + ws) lo = a.v[m];
+                if ((uint32_t)m == (uint32_t)k + ws + 1u) hi = a.v[m];
+            }
+            rem.v[k] = bs ? (lo >> bs | hi << (32u - bs)) : lo;
+        }
+    }
+    for (int i = (int)s - 1; i >= 0; i--) {
         const uint32_t limb = (uint32_t)i >> 5, sh = (uint32_t)i & 31u;
         uint32_t abit = 0;
 #pragma unroll

@@ -38,6 +38,7 @@ out = {"opcodes": G, "tile": tile, "witnesses_per_instance": st0["n_witnesses"],
 first_vals = None
 for k in range(n_tiles):
     values = synth.witness_batch(tile, seed=0xAC1D0005, first_instance=k * tile)
+    batch.set_profiling(k == n_tiles - 1 and n_tiles > 1)  # per-kernel HIP events on the last tile only (they cost time)
     batch.set_initial_witness(values)
     w0 = time.time()
     n_bad = batch.solve()
@@ -51,6 +52,9 @@ for k in range(n_tiles):
     out["tiles"].append({"not_solved": n_bad, "solve_device_ms": round(st["solve_device_ms"], 1), "solve_wall_ms": round((w1 - w0) * 1e3, 1),
                          "digest_wall_ms": round((w2 - w1) * 1e3, 1), "launches": st["n_kernel_launches"], "slow_instances": st["n_slow_instances"],
                          "witnesses_per_s": round(tile / (w2 - w0), 1)})
+    if k == n_tiles - 1 and n_tiles > 1:
+        out["tiles"][-1]["kernel_ms"] = {"arith": round(st["arith_kernel_ms"], 1), "inverse_batch": round(st["dyn_kernel_ms"], 1),
+                                         "light/hash/grumpkin/brillig": [round(x, 1) for x in st["class_kernel_ms"]]}
     if k == 0:
         picks = sorted(set([0, 5] + [int(x) for x in np.linspace(8, tile - 1, max(audit - 2, 1))]))[:audit]
         sub = b"".join(values[j * row:(j + 1) * row] for j in picks)

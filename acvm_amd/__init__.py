@@ -28,6 +28,11 @@ ABI_SYMBOLS = [
     "acvm_batch_set_profiling", "acvm_batch_pending_foreign_call", "acvm_batch_pending_foreign_call_inputs",
     "acvm_batch_resolve_foreign_call", "acvm_circuit_assert_message", "acvm_circuit_witness_set", "acvm_batch_error_string",
     "acvm_batch_extract_witnesses", "acvm_batch_digest", "acvm_witness_map_decode", "acvm_witness_map_encode", "acvm_batch_witness_map_bytes",
+    "acvm_device_malloc", "acvm_device_free", "acvm_device_upload", "acvm_batch_solve_opcode", "acvm_bb_stubbed", "acvm_bb_dummy",
+    "acvm_new", "acvm_free", "acvm_solve", "acvm_solve_opcode", "acvm_get_status", "acvm_instruction_pointer", "acvm_witness_map", "acvm_finalize",
+    "acvm_get_pending_foreign_call", "acvm_pending_foreign_call_inputs", "acvm_resolve_pending_foreign_call",
+    "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
+    "acvm_multi_witness_map", "acvm_multi_locate",
 ]
 
 
@@ -52,9 +57,18 @@ _FIXED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c
                         C.c_size_t)
 
 
+_SCHNORR_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t,
+                                C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_void_p, C.c_size_t)
+_PEDERSEN_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8),
+                                 C.POINTER(C.c_uint8), C.c_void_p, C.c_size_t)
+_FIXED_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_void_p, C.c_size_t)
+
+
 class BbSolver(C.Structure):
-    """acvm_bb_solver_t: the BlackBoxFunctionSolver trait (blackbox_solver/src/lib.rs:27-45) as a vtable."""
-    _fields_ = [("ctx", C.c_void_p), ("schnorr_verify", _SCHNORR_FN), ("pedersen", _PEDERSEN_FN), ("fixed_base_scalar_mul", _FIXED_FN)]
+    """acvm_bb_solver_t: the BlackBoxFunctionSolver trait (blackbox_solver/src/lib.rs:27-45) as a vtable; the *_batch members
+    are optional (NULL: the per-instance functions are called once per instance)."""
+    _fields_ = [("ctx", C.c_void_p), ("schnorr_verify", _SCHNORR_FN), ("pedersen", _PEDERSEN_FN), ("fixed_base_scalar_mul", _FIXED_FN),
+                ("schnorr_verify_batch", _SCHNORR_BATCH_FN), ("pedersen_batch", _PEDERSEN_BATCH_FN), ("fixed_base_scalar_mul_batch", _FIXED_BATCH_FN)]
 
 
 def make_solver(schnorr_verify, pedersen, fixed_base_scalar_mul):
@@ -106,6 +120,59 @@ def make_solver(schnorr_verify, pedersen, fixed_base_scalar_mul):
     return s
 
 
+def make_batched_solver(pedersen_batch=None, fixed_base_batch=None, schnorr_batch=None, fallback: "BbSolver" = None):
+    """An acvm_bb_solver_t whose *_batch members are Python callables over the whole batch (one call per opcode):
+    pedersen_batch(inputs: list[list[int]], domain_separator) -> list[(x, y)]
+    fixed_base_batch(pairs: list[(low, high)]) -> list[(x, y)]
+    schnorr_batch(items: list[(pkx, pky, sig: bytes, msg: bytes)]) -> list[bool]
+    The per-instance members come from `fallback` (default: the stubbed vtable, so a missing batch member panics)."""
+    fb = fallback if fallback is not None else bb_stubbed()
+
+    def put(ptr, off, v):
+        for i, byte in enumerate(int(v).to_bytes(32, "big")):
+            ptr[off + i] = byte
+
+    def c_ped(ctx, n, inputs, k, ds, xy, rc, err, stride):
+        rows = [[int.from_bytes(bytes(inputs[(q * k + i) * 32:(q * k + i + 1) * 32]), "big") for i in range(k)] for q in range(n)]
+        for q, (x, y) in enumerate(pedersen_batch(rows, ds)):
+            put(xy, 64 * q, x)
+            put(xy, 64 * q + 32, y)
+            rc[q] = 0
+        return 0
+
+    def c_fixed(ctx, n, lh, xy, rc, err, stride):
+        pairs = [(int.from_bytes(bytes(lh[64 * q:64 * q + 32]), "big"), int.from_bytes(bytes(lh[64 * q + 32:64 * q + 64]), "big")) for q in range(n)]
+        for q, (x, y) in enumerate(fixed_base_batch(pairs)):
+            put(xy, 64 * q, x)
+            put(xy, 64 * q + 32, y)
+            rc[q] = 0
+        return 0
+
+    def c_schnorr(ctx, n, pk, sig, sig_len, msg, msg_len, ok, rc, err, stride):
+        items = [(int.from_bytes(bytes(pk[64 * q:64 * q + 32]), "big"), int.from_bytes(bytes(pk[64 * q + 32:64 * q + 64]), "big"),
+                  bytes(sig[q * sig_len:(q + 1) * sig_len]), bytes(msg[q * msg_len:(q + 1) * msg_len])) for q in range(n)]
+        for q, v in enumerate(schnorr_batch(items)):
+            ok[q] = 1 if v else 0
+            rc[q] = 0
+        return 0
+
+    s = BbSolver(None, fb.schnorr_verify, fb.pedersen, fb.fixed_base_scalar_mul,
+                 _SCHNORR_BATCH_FN(c_schnorr) if schnorr_batch else _SCHNORR_BATCH_FN(), _PEDERSEN_BATCH_FN(c_ped) if pedersen_batch else _PEDERSEN_BATCH_FN(),
+                 _FIXED_BATCH_FN(c_fixed) if fixed_base_batch else _FIXED_BATCH_FN())
+    s._keep = fb
+    return s
+
+
+def bb_stubbed() -> "BbSolver":
+    """StubbedBackend (acvm/tests/solver.rs:20-46) as shipped by the library."""
+    return C.cast(lib().acvm_bb_stubbed(), C.POINTER(BbSolver)).contents
+
+
+def bb_dummy() -> "BbSolver":
+    """DummyBlackBoxSolver (brillig_vm/src/lib.rs:392-420) as shipped by the library."""
+    return C.cast(lib().acvm_bb_dummy(), C.POINTER(BbSolver)).contents
+
+
 class BlackBoxFailed(Exception):
     pass
 
@@ -129,7 +196,7 @@ class Stats(C.Structure):
                 ("dyn_algorithmic_bytes_per_instance", C.c_uint64), ("n_other_records", C.c_uint32), ("truncated_at", C.c_uint32),
                 ("class_algorithmic_bytes_per_instance", C.c_uint64 * 4), ("class_kernel_ms", C.c_double * 4),
                 ("n_gate_pairs", C.c_uint32), ("n_inverse_slots", C.c_uint32),
-                ("n_scaled_witnesses", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("n_scaled_witnesses", C.c_uint32), ("n_arith_launches", C.c_uint32)]
 
     def as_dict(self):
         return {f: (list(getattr(self, f)) if f.startswith("class_") else getattr(self, f)) for f, _ in self._fields_}
@@ -184,6 +251,40 @@ def lib():
     L.acvm_witness_map_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
     L.acvm_witness_map_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.acvm_device_malloc.restype = C.c_void_p
+    L.acvm_device_malloc.argtypes = [C.c_size_t]
+    L.acvm_device_free.argtypes = [C.c_void_p]
+    L.acvm_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.acvm_batch_solve_opcode.argtypes = [C.c_void_p]
+    L.acvm_bb_stubbed.restype = C.c_void_p
+    L.acvm_bb_dummy.restype = C.c_void_p
+    L.acvm_new.restype = C.c_void_p
+    L.acvm_new.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32]
+    for f in (L.acvm_free, L.acvm_solve, L.acvm_solve_opcode):
+        f.argtypes = [C.c_void_p]
+    L.acvm_free.restype = None
+    L.acvm_get_status.argtypes = [C.c_void_p, C.POINTER(Result)]
+    L.acvm_instruction_pointer.restype = C.c_uint32
+    L.acvm_instruction_pointer.argtypes = [C.c_void_p]
+    for f in (L.acvm_witness_map, L.acvm_finalize):
+        f.restype = C.c_longlong
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.acvm_get_pending_foreign_call.argtypes = [C.c_void_p, C.POINTER(ForeignCallInfo)]
+    L.acvm_pending_foreign_call_inputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.acvm_resolve_pending_foreign_call.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_char_p]
+    L.acvm_multi_new.restype = C.c_void_p
+    L.acvm_multi_new.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p]
+    L.acvm_multi_free.restype = None
+    L.acvm_multi_free.argtypes = [C.c_void_p]
+    L.acvm_multi_num_groups.restype = C.c_uint32
+    L.acvm_multi_num_groups.argtypes = [C.c_void_p]
+    L.acvm_multi_num_witnesses.restype = C.c_uint32
+    L.acvm_multi_num_witnesses.argtypes = [C.c_void_p]
+    L.acvm_multi_solve.argtypes = [C.c_void_p]
+    L.acvm_multi_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.acvm_multi_witness_map.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.acvm_multi_locate.restype = C.c_void_p
+    L.acvm_multi_locate.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -317,6 +418,14 @@ class Batch:
     def solve(self) -> int:
         return _check(lib().acvm_batch_solve(self._h))
 
+    def solve_opcode(self) -> int:
+        """ACVM::solve_opcode for the batch (see include/acvm_amd.h): one opcode, returns the number of instances not Solved."""
+        return _check(lib().acvm_batch_solve_opcode(self._h))
+
+    def set_initial_witness_device(self, d_ptr: int):
+        """values already resident on the device (same layout as set_initial_witness), e.g. a slice of a DeviceBuffer."""
+        _check(lib().acvm_batch_set_initial_witness_device(self._h, d_ptr))
+
     def reset(self):
         _check(lib().acvm_batch_reset(self._h))
 
@@ -403,3 +512,141 @@ class Batch:
         s = Stats()
         _check(lib().acvm_batch_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes on the current device (acvm_device_malloc): inputs a caller keeps resident in HBM."""
+
+    def __init__(self, data: bytes = None, size: int = None):
+        self.size = len(data) if data is not None else size
+        self.ptr = lib().acvm_device_malloc(self.size)
+        if not self.ptr:
+            raise AcvmError(lib().acvm_last_error().decode())
+        if data is not None:
+            self.upload(data)
+
+    def upload(self, data, offset=0):
+        import numpy as np
+        buf = np.frombuffer(data, dtype=np.uint8)
+        if offset + buf.size > self.size:
+            raise ValueError("upload past the end of the device buffer")
+        _check(lib().acvm_device_upload(self.ptr + offset, buf.ctypes.data, buf.size))
+
+    def free(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.acvm_device_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
+class Acvm:
+    """struct ACVM (acvm/src/pwg/mod.rs:129-304) for one instance: the acvm_new / acvm_solve / acvm_finalize shim."""
+
+    def __init__(self, circuit: Circuit, initial_witness: dict, backend: "BbSolver" = None):
+        self.circuit = circuit
+        self._backend = backend
+        items = list(initial_witness.items())
+        ids = (C.c_uint32 * max(len(items), 1))(*[k for k, _ in items])
+        vals = b"".join(int(v % (1 << 256)).to_bytes(32, "big") for _, v in items)
+        self._h = lib().acvm_new(circuit._h, C.byref(backend) if backend is not None else None, ids, vals, len(items))
+        if not self._h:
+            raise AcvmError(lib().acvm_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.acvm_free(self._h)
+            self._h = None
+
+    def solve(self) -> int:
+        return _check(lib().acvm_solve(self._h))
+
+    def solve_opcode(self) -> int:
+        return _check(lib().acvm_solve_opcode(self._h))
+
+    def status(self) -> Result:
+        r = Result()
+        _check(lib().acvm_get_status(self._h, C.byref(r)))
+        return r
+
+    def instruction_pointer(self) -> int:
+        return lib().acvm_instruction_pointer(self._h)
+
+    def _pairs(self, fn):
+        n = fn(self._h, None, None, 0)
+        if n < 0:
+            raise AcvmError(f"acvm_amd error {n}: {lib().acvm_last_error().decode()}")
+        ids = (C.c_uint32 * max(n, 1))()
+        vals = C.create_string_buffer(32 * max(n, 1))
+        _check(fn(self._h, ids, vals, n))
+        return {ids[i]: int.from_bytes(vals.raw[32 * i:32 * i + 32], "big") for i in range(n)}
+
+    def witness_map(self) -> dict:
+        return self._pairs(lib().acvm_witness_map)
+
+    def finalize(self) -> dict:
+        """ACVM::finalize: raises unless the status is Solved (the reference panics)."""
+        return self._pairs(lib().acvm_finalize)
+
+    def get_pending_foreign_call(self):
+        info = ForeignCallInfo()
+        if _check(lib().acvm_get_pending_foreign_call(self._h, C.byref(info))) == 0:
+            return None
+        lens = (C.c_uint32 * max(info.n_inputs, 1))()
+        vals = C.create_string_buffer(32 * max(info.n_values, 1))
+        _check(lib().acvm_pending_foreign_call_inputs(self._h, lens, vals))
+        out, k = [], 0
+        for i in range(info.n_inputs):
+            out.append([int.from_bytes(vals.raw[32 * (k + c):32 * (k + c + 1)], "big") for c in range(lens[i])])
+            k += lens[i]
+        return info.function.decode(), out
+
+    def resolve_pending_foreign_call(self, values):
+        is_arr = bytes(0 if isinstance(v, int) else 1 for v in values)
+        lens = (C.c_uint32 * max(len(values), 1))(*[1 if isinstance(v, int) else len(v) for v in values])
+        flat = b"".join(int(v).to_bytes(32, "big") if isinstance(v, int) else b"".join(int(x).to_bytes(32, "big") for x in v) for v in values)
+        _check(lib().acvm_resolve_pending_foreign_call(self._h, len(values), is_arr, lens, flat))
+
+
+class MultiBatch:
+    """acvm_multi_*: instances whose initial witness maps assign different id sets (list of {witness: int} dicts)."""
+
+    def __init__(self, circuit: Circuit, initial_maps, solver: "BbSolver" = None):
+        import numpy as np
+        self.circuit = circuit
+        self._solver = solver
+        self.n = len(initial_maps)
+        offsets = np.zeros(self.n + 1, dtype=np.uint64)
+        ids, vals = [], []
+        for i, m in enumerate(initial_maps):
+            for k, v in m.items():
+                ids.append(k)
+                vals.append(int(v % (1 << 256)).to_bytes(32, "big"))
+            offsets[i + 1] = len(ids)
+        ids_arr = np.asarray(ids if ids else [0], dtype=np.uint32)
+        self._h = lib().acvm_multi_new(circuit._h, C.byref(solver) if solver is not None else None, self.n, offsets.ctypes.data, ids_arr.ctypes.data,
+                                       b"".join(vals))
+        if not self._h:
+            raise AcvmError(lib().acvm_last_error().decode())
+        self.n_groups = lib().acvm_multi_num_groups(self._h)
+        self.nw = lib().acvm_multi_num_witnesses(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.acvm_multi_free(self._h)
+            self._h = None
+
+    def solve(self) -> int:
+        return _check(lib().acvm_multi_solve(self._h))
+
+    def results(self):
+        out = (Result * max(self.n, 1))()
+        _check(lib().acvm_multi_results(self._h, C.cast(out, C.c_void_p)))
+        return out
+
+    def witness_map(self, instance: int):
+        import numpy as np
+        asg = np.zeros((self.nw,), dtype=np.uint8)
+        vals = np.zeros((self.nw, 32), dtype=np.uint8)
+        _check(lib().acvm_multi_witness_map(self._h, instance, asg.ctypes.data, vals.ctypes.data))
+        return asg, vals

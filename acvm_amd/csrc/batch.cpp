@@ -10,6 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -26,6 +29,14 @@ static int set_err(int code, const std::string &msg) {
         if (_e != hipSuccess)                                                                             \
             return set_err(ACVM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
     } while (0)
+
+// Nothing unwinds through the extern "C" boundary: entry points that allocate by input-dependent sizes are function-try-blocks
+#define ABI_CATCH                                                                                          \
+    catch (const std::bad_alloc &) { return set_err(ACVM_E_NOMEM, "out of host memory"); }                 \
+    catch (const std::exception &e) { return set_err(ACVM_E_INVALID, std::string("internal error: ") + e.what()); }
+#define ABI_CATCH_PTR                                                                                      \
+    catch (const std::bad_alloc &) { set_err(ACVM_E_NOMEM, "out of host memory"); return nullptr; }        \
+    catch (const std::exception &e) { set_err(ACVM_E_INVALID, std::string("internal error: ") + e.what()); return nullptr; }
 
 struct acvm_circuit {
     std::unique_ptr<Circuit> c;
@@ -85,6 +96,11 @@ struct acvm_batch {
     uint32_t fc_res_desc_words = 0, fc_res_vals_cap = 0, fc_pend_desc_words = 0, fc_pend_vals_cap = 0, fc_lanes_cap = 0;
     std::vector<uint32_t> h_pend_desc, h_pend_vals;
     bool pend_host_valid = false;
+    // grow-only device staging arena of the entry points that move data in or out (no hipMalloc / hipFree per call)
+    uint8_t *d_stage = nullptr;
+    size_t stage_cap = 0;
+    // acvm_batch_solve_opcode: every instance is an exact lane, slow_start[t] is its instruction pointer
+    bool stepping = false;
 
     ~acvm_batch() {
         hipSetDevice(device);
@@ -103,6 +119,7 @@ struct acvm_batch {
         for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_unscale_plain, (void *)d_scaled_ids})
             if (p) hipFree(p);
         if (d_ped_seed) hipFree(d_ped_seed);
+        if (d_stage) hipFree(d_stage);
         for (void *p : {(void *)d_fc_res_opcode, (void *)d_fc_res_desc, (void *)d_fc_pend_desc, (void *)d_fc_res_vals, (void *)d_fc_pend_vals})
             if (p) hipFree(p);
         if (stream_dyn) hipStreamDestroy(stream_dyn);
@@ -119,6 +136,17 @@ static int upload(T **dst, const std::vector<T> &src) {
     if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
+
+// staging arena: `bytes` of device memory valid until the next stage_reserve of this batch (256-byte aligned carving by the caller)
+static int stage_reserve(acvm_batch *b, size_t bytes) {
+    if (bytes <= b->stage_cap) return 0;
+    if (b->d_stage) { hipFree(b->d_stage); b->d_stage = nullptr; b->stage_cap = 0; }
+    const size_t cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+    HIPCHK(hipMalloc((void **)&b->d_stage, cap));
+    b->stage_cap = cap;
+    return 0;
+}
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" {
 
@@ -147,6 +175,22 @@ int acvm_device_arch(char *out, size_t out_len) {
     return 0;
 }
 
+void *acvm_device_malloc(size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { set_err(ACVM_E_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+int acvm_device_free(void *p) {
+    if (p) HIPCHK(hipFree(p));
+    return 0;
+}
+int acvm_device_upload(void *dst_device, const void *src_host, size_t bytes) {
+    if (bytes && (!dst_device || !src_host)) return set_err(ACVM_E_INVALID, "null argument");
+    if (bytes) HIPCHK(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int acvm_selftest(uint32_t n, uint64_t seed) {
     uint32_t *d = nullptr, h = 0;
     HIPCHK(hipMalloc((void **)&d, 4));
@@ -162,7 +206,7 @@ int acvm_selftest(uint32_t n, uint64_t seed) {
 // Component probes of the Grumpkin kernels for the parity tests: what = 0 host table point (param = table << 24 | index),
 // 1 device hash_single(in[0], parity = param), 2 device hash-ladder compress(in[0..n_in)), 3 device fixed_base_mul(table
 // base param, integer in[0]), 4 device table point. in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian.
-int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64) {
+int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64) try {
     if (!out_be64) return set_err(ACVM_E_INVALID, "null argument");
     if (what == 0) return grumpkin_host_point(param >> 24, param & 0xffffffu, out_be64) ? 0 : set_err(ACVM_E_INVALID, "bad table index");
     const GrumpkinTables *t = grumpkin_tables();
@@ -184,9 +228,9 @@ int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, u
     for (int c = 0; c < 2; c++)
         for (int k = 0; k < 32; k++) out_be64[32 * c + 31 - k] = (uint8_t)(out[8 * c + k / 4] >> (8 * (k % 4)));
     return 0;
-}
+} ABI_CATCH
 
-acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) {
+acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) try {
     if (!bytes) { set_err(ACVM_E_INVALID, "null circuit bytes"); return nullptr; }
     if (!frh::self_check()) { set_err(ACVM_E_INVALID, "field constants self-check failed"); return nullptr; }
     std::string err;
@@ -195,7 +239,7 @@ acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) {
     auto *h = new acvm_circuit;
     h->c = std::move(c);
     return h;
-}
+} ABI_CATCH_PTR
 void acvm_circuit_free(acvm_circuit_t *c) { delete c; }
 uint32_t acvm_circuit_num_opcodes(const acvm_circuit_t *c) { return c ? (uint32_t)c->c->opcodes.size() : 0; }
 uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c) { return c ? c->c->max_witness + 1 : 0; }
@@ -217,6 +261,7 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_gate_pairs = p.n_gate_pairs;
     out->n_inverse_slots = p.n_inverse_slots;
     out->n_scaled_witnesses = (uint32_t)p.scaled_ids.size();
+    for (uint32_t L = 0; L + 1 < p.level_start.size(); L++) out->n_arith_launches += (p.level_start[L + 1] - p.level_start[L] + 65534) / 65535;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
                                                                p.cls_algorithmic_bytes[CLS_HOSTBB];
@@ -224,13 +269,13 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
 
 // Host-only: levelise the circuit against a set of initial witness ids without touching a device (plan statistics, and
 // whether the circuit holds an opcode no kernel implements). Returns 0, or ACVM_E_UNSUPPORTED with the reason as the error text.
-int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out) {
+int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out) try {
     if (!c || !out || (n_initial && !initial_ids)) return set_err(ACVM_E_INVALID, "null argument");
     Plan p = build_plan(*c->c, initial_ids, n_initial);
     plan_stats(p, out);
     if (!p.unsupported.empty()) return set_err(ACVM_E_UNSUPPORTED, p.unsupported);
     return 0;
-}
+} ABI_CATCH
 
 static int batch_init(acvm_batch *b) {
     HIPCHK(hipGetDevice(&b->device));
@@ -279,7 +324,7 @@ static int batch_init(acvm_batch *b) {
         HIPCHK(hipMalloc((void **)&b->d_Mem, bytes ? bytes : 16));
     }
     // non-arithmetic record classes: per level, launch chunks whose per-instance scratch fits the class's scratch buffer
-    const uint64_t scratch_cap_words = std::max<uint64_t>(1, (1ull << 30) / (b->Bp * 4));  // 1 GiB per class
+    const uint64_t scratch_cap_words = std::max<uint64_t>(1, (1ull << 30) / (std::max<uint64_t>(b->Bp, 64) * 4));  // 1 GiB per class (an empty batch is allowed)
     for (int k = 0; k < (int)N_CLS; k++) {
         const size_t n_levels = p.n_levels;
         b->cls_chunks[k].assign(n_levels, {});
@@ -357,7 +402,7 @@ static int batch_init(acvm_batch *b) {
 }
 
 acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances,
-                             const uint32_t *initial_ids, uint32_t n_initial) {
+                             const uint32_t *initial_ids, uint32_t n_initial) try {
     if (!c || (n_initial && !initial_ids)) { set_err(ACVM_E_INVALID, "null argument"); return nullptr; }
     if (solver && (!solver->schnorr_verify || !solver->pedersen || !solver->fixed_base_scalar_mul)) {
         set_err(ACVM_E_INVALID, "acvm_bb_solver_t with a null function pointer");
@@ -368,22 +413,21 @@ acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *so
         std::sort(ids.begin(), ids.end());
         if (std::adjacent_find(ids.begin(), ids.end()) != ids.end()) { set_err(ACVM_E_INVALID, "duplicate initial witness id"); return nullptr; }
     }
-    auto *b = new acvm_batch;
+    auto b = std::make_unique<acvm_batch>();
     if (solver) { b->has_solver = true; b->solver = *solver; }
     b->plan = build_plan(*c->c, initial_ids, n_initial, solver != nullptr);
     if (!b->plan.unsupported.empty()) {
         set_err(ACVM_E_UNSUPPORTED, b->plan.unsupported);
-        delete b;
         return nullptr;
     }
     b->B = n_instances;
     b->Bp = ((uint64_t)n_instances + 63) / 64 * 64;
-    if (batch_init(b) != 0) { delete b; return nullptr; }
-    return b;
-}
+    if (batch_init(b.get()) != 0) return nullptr;
+    return b.release();
+} ABI_CATCH_PTR
 void acvm_batch_free(acvm_batch_t *b) { delete b; }
 
-int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32) {
+int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     HIPCHK(hipSetDevice(b->device));
     launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->d_init_ids, (uint32_t)b->plan.initial_ids.size());
@@ -391,21 +435,19 @@ int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_
     HIPCHK(hipStreamSynchronize(b->stream));
     b->inputs_set = true;
     b->solved = false;
+    b->stepping = false;
     return 0;
-}
+} ABI_CATCH
 
-int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32) {
+int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     size_t bytes = (size_t)b->B * b->plan.initial_ids.size() * 32;
     if (bytes && !values_be32) return set_err(ACVM_E_INVALID, "null values");
     HIPCHK(hipSetDevice(b->device));
-    uint8_t *d_in = nullptr;
-    HIPCHK(hipMalloc((void **)&d_in, bytes ? bytes : 1));
-    hipError_t e = bytes ? hipMemcpy(d_in, values_be32, bytes, hipMemcpyHostToDevice) : hipSuccess;
-    int rc = e == hipSuccess ? acvm_batch_set_initial_witness_device(b, d_in) : set_err(ACVM_E_DEVICE, hipGetErrorString(e));
-    hipFree(d_in);
-    return rc;
-}
+    if (int rc = stage_reserve(b, bytes)) return rc;
+    if (bytes) HIPCHK(hipMemcpyAsync(b->d_stage, values_be32, bytes, hipMemcpyHostToDevice, b->stream));
+    return acvm_batch_set_initial_witness_device(b, b->d_stage);
+} ABI_CATCH
 
 int acvm_batch_set_force_slow_path(acvm_batch_t *b, int on) {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
@@ -420,6 +462,7 @@ int acvm_batch_set_profiling(acvm_batch_t *b, int on) {
 int acvm_batch_reset(acvm_batch_t *b) {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     b->solved = false;
+    b->stepping = false;
     return 0;
 }
 
@@ -504,7 +547,9 @@ static int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
 
 // One Pedersen / FixedBaseScalarMul / SchnorrVerify opcode through the caller's BlackBoxFunctionSolver callbacks
 // (blackbox_solver/src/lib.rs:27-45) for the instances of the level schedule (exact == false, all B instances) or for the
-// exact lanes. Inputs leave the device as canonical big-endian bytes, outputs come back the same way.
+// exact lanes. Inputs leave the device as canonical big-endian bytes, outputs come back the same way. All instances are
+// gathered ONCE (one kernel, one copy), the callbacks run in one loop -- or in ONE call when the vtable has the *_batch
+// member -- and the results are scattered once; a pass is capped at 2^18 instances only to bound the staging buffers.
 static int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_t n_slow) {
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
@@ -520,86 +565,125 @@ static int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_
     const uint32_t n_sel = (uint32_t)sel.size(), n_out = (uint32_t)outs.size() / 2;
     const uint32_t n_total = exact ? n_slow : b->B;
     if (!n_total) return 0;
-    uint32_t *d_sel = nullptr, *d_outs = nullptr;
-    uint8_t *d_active = nullptr, *d_in = nullptr, *d_rc = nullptr, *d_vals = nullptr;
+    const uint32_t chunk = std::min<uint32_t>(n_total, 1u << 18);
+    const size_t in_row = (size_t)std::max<uint32_t>(n_sel, 1) * 32, out_row = (size_t)n_out * 32;
+    // arena: sel | outs | active | in | rc | vals
+    const size_t o_sel = 0, o_outs = o_sel + align256((size_t)std::max<uint32_t>(n_sel, 1) * 4), o_active = o_outs + align256(outs.size() * 4),
+                 o_in = o_active + align256(n_total), o_rc = o_in + align256(chunk * in_row), o_vals = o_rc + align256(chunk);
+    if (int rc = stage_reserve(b, o_vals + align256(chunk * out_row))) return rc;
+    uint32_t *d_sel = (uint32_t *)(b->d_stage + o_sel), *d_outs = (uint32_t *)(b->d_stage + o_outs);
+    uint8_t *d_active = b->d_stage + o_active, *d_in = b->d_stage + o_in, *d_rc = b->d_stage + o_rc, *d_vals = b->d_stage + o_vals;
     std::vector<uint8_t> active(n_total, 1);
-    auto cleanup = [&]() {
-        for (void *q : {(void *)d_sel, (void *)d_outs, (void *)d_active, (void *)d_in, (void *)d_rc, (void *)d_vals})
-            if (q) hipFree(q);
-    };
-    const uint32_t chunk = std::min<uint32_t>(n_total, 8192);
-#define HB_CHK(expr)                                                                    \
-    do {                                                                                \
-        hipError_t _e = (expr);                                                         \
-        if (_e != hipSuccess) { cleanup(); return set_err(ACVM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); } \
-    } while (0)
-    HB_CHK(hipMalloc((void **)&d_sel, (size_t)std::max<uint32_t>(n_sel, 1) * 4));
-    HB_CHK(hipMalloc((void **)&d_outs, outs.size() * 4));
-    HB_CHK(hipMalloc((void **)&d_in, (size_t)chunk * std::max<uint32_t>(n_sel, 1) * 32));
-    HB_CHK(hipMalloc((void **)&d_rc, chunk));
-    HB_CHK(hipMalloc((void **)&d_vals, (size_t)chunk * n_out * 32));
-    if (n_sel) HB_CHK(hipMemcpyAsync(d_sel, sel.data(), (size_t)n_sel * 4, hipMemcpyHostToDevice, s));
-    HB_CHK(hipMemcpyAsync(d_outs, outs.data(), outs.size() * 4, hipMemcpyHostToDevice, s));
+    if (n_sel) HIPCHK(hipMemcpyAsync(d_sel, sel.data(), (size_t)n_sel * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_outs, outs.data(), outs.size() * 4, hipMemcpyHostToDevice, s));
     const ExactLanes L = exact_lanes(b, n_slow);
     if (exact) {
-        HB_CHK(hipMalloc((void **)&d_active, n_total));
         launch_hostbb_precheck(s, L, opcode, d_sel, n_sel, d_active);
-        HB_CHK(hipMemcpyAsync(active.data(), d_active, n_total, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(active.data(), d_active, n_total, hipMemcpyDeviceToHost, s));
     }
-    HB_CHK(hipStreamSynchronize(s));
-    std::vector<uint8_t> in((size_t)chunk * std::max<uint32_t>(n_sel, 1) * 32), rc(chunk), vals((size_t)chunk * n_out * 32);
-    char err[200];
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<uint8_t> in(chunk * in_row), rc(chunk), vals(chunk * out_row);
+    static constexpr size_t ERR_STRIDE = 200;
+    const acvm_bb_solver_t &sv = b->solver;
     for (uint32_t first = 0; first < n_total; first += chunk) {
         const uint32_t m = std::min(chunk, n_total - first);
         launch_hostbb_gather(s, b->d_W, b->Bp, exact ? b->d_slow_ids : nullptr, first, m, d_sel, n_sel, d_in);
-        if (n_sel) HB_CHK(hipMemcpyAsync(in.data(), d_in, (size_t)m * n_sel * 32, hipMemcpyDeviceToHost, s));
-        HB_CHK(hipStreamSynchronize(s));
+        if (n_sel) HIPCHK(hipMemcpyAsync(in.data(), d_in, (size_t)m * n_sel * 32, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::fill(vals.begin(), vals.end(), 0);
+        // the instances that really call the solver, packed
+        std::vector<uint32_t> who;
         for (uint32_t i = 0; i < m; i++) {
             rc[i] = 255;
-            if (!active[first + i]) continue;
-            const uint8_t *a = &in[(size_t)i * n_sel * 32];
-            uint8_t *o = &vals[(size_t)i * n_out * 32];
-            memset(o, 0, (size_t)n_out * 32);
-            err[0] = 0;
-            int r = 0;
-            if (rec[0] == PK_FIXED_BASE) r = b->solver.fixed_base_scalar_mul(b->solver.ctx, a, a + 32, o, o + 32, err, sizeof err);
-            else if (rec[0] == PK_PEDERSEN) r = b->solver.pedersen(b->solver.ctx, a, rec[3], rec[2], o, o + 32, err, sizeof err);
-            else {  // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness
-                const uint32_t n_sig = rec[4], n_msg = rec[5];
-                std::vector<uint8_t> sig(n_sig + 1), msg(n_msg + 1);
-                for (uint32_t k = 0; k < n_sig; k++) sig[k] = a[(size_t)(2 + k) * 32 + 31];
-                for (uint32_t k = 0; k < n_msg; k++) msg[k] = a[(size_t)(2 + n_sig + k) * 32 + 31];
-                uint8_t ok = 0;
-                r = b->solver.schnorr_verify(b->solver.ctx, a, a + 32, sig.data(), n_sig, msg.data(), n_msg, &ok, err, sizeof err);
-                o[31] = ok ? 1 : 0;
-            }
-            rc[i] = (uint8_t)(r < 0 || r > 2 ? 3 : r);
-            if (r != 0) b->host_bb_msg[exact ? b->slow_ids[first + i] : first + i] = err;
+            if (active[first + i]) who.push_back(i);
         }
-        HB_CHK(hipMemcpyAsync(d_rc, rc.data(), m, hipMemcpyHostToDevice, s));
-        HB_CHK(hipMemcpyAsync(d_vals, vals.data(), (size_t)m * n_out * 32, hipMemcpyHostToDevice, s));
+        const bool batched = (rec[0] == PK_FIXED_BASE && sv.fixed_base_scalar_mul_batch) || (rec[0] == PK_PEDERSEN && sv.pedersen_batch) ||
+                             (rec[0] == PK_SCHNORR && sv.schnorr_verify_batch);
+        auto instance_of = [&](uint32_t i) { return exact ? b->slow_ids[first + i] : first + i; };
+        if (batched && !who.empty()) {
+            const size_t n = who.size();
+            std::vector<uint8_t> brc(n, 0), bout(n * 64, 0);
+            std::vector<char> berr(n * ERR_STRIDE, 0);
+            int r = 0;
+            if (rec[0] == PK_FIXED_BASE) {
+                std::vector<uint8_t> lh(n * 64);
+                for (size_t q = 0; q < n; q++) memcpy(&lh[q * 64], &in[(size_t)who[q] * in_row], 64);
+                r = sv.fixed_base_scalar_mul_batch(sv.ctx, n, lh.data(), bout.data(), brc.data(), berr.data(), ERR_STRIDE);
+            } else if (rec[0] == PK_PEDERSEN) {
+                const size_t k = rec[3];
+                std::vector<uint8_t> pin(n * std::max<size_t>(k, 1) * 32);
+                for (size_t q = 0; q < n; q++) memcpy(&pin[q * k * 32], &in[(size_t)who[q] * in_row], k * 32);
+                r = sv.pedersen_batch(sv.ctx, n, pin.data(), k, rec[2], bout.data(), brc.data(), berr.data(), ERR_STRIDE);
+            } else {  // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness
+                const uint32_t n_sig = rec[4], n_msg = rec[5];
+                std::vector<uint8_t> pk(n * 64), sig(n * std::max<uint32_t>(n_sig, 1)), msg(n * std::max<uint32_t>(n_msg, 1)), ok(n, 0);
+                for (size_t q = 0; q < n; q++) {
+                    const uint8_t *a = &in[(size_t)who[q] * in_row];
+                    memcpy(&pk[q * 64], a, 64);
+                    for (uint32_t k = 0; k < n_sig; k++) sig[q * n_sig + k] = a[(size_t)(2 + k) * 32 + 31];
+                    for (uint32_t k = 0; k < n_msg; k++) msg[q * n_msg + k] = a[(size_t)(2 + n_sig + k) * 32 + 31];
+                }
+                r = sv.schnorr_verify_batch(sv.ctx, n, pk.data(), sig.data(), n_sig, msg.data(), n_msg, ok.data(), brc.data(), berr.data(), ERR_STRIDE);
+                for (size_t q = 0; q < n; q++) bout[q * 64 + 31] = ok[q] ? 1 : 0;
+            }
+            for (size_t q = 0; q < n; q++) {
+                const uint32_t i = who[q];
+                const int ri = r != 0 ? 3 : brc[q];  // a failing batch call fails every instance of it like a panic
+                rc[i] = (uint8_t)(ri > 2 ? 3 : ri);
+                memcpy(&vals[(size_t)i * out_row], &bout[q * 64], out_row);
+                if (rc[i] != 0) {
+                    berr[q * ERR_STRIDE + ERR_STRIDE - 1] = 0;
+                    b->host_bb_msg[instance_of(i)] = r != 0 ? "batched BlackBoxFunctionSolver call failed" : &berr[q * ERR_STRIDE];
+                }
+            }
+        } else {
+            char err[ERR_STRIDE];
+            for (uint32_t i : who) {
+                const uint8_t *a = &in[(size_t)i * in_row];
+                uint8_t *o = &vals[(size_t)i * out_row];
+                err[0] = 0;
+                int r = 0;
+                if (rec[0] == PK_FIXED_BASE) r = sv.fixed_base_scalar_mul(sv.ctx, a, a + 32, o, o + 32, err, sizeof err);
+                else if (rec[0] == PK_PEDERSEN) r = sv.pedersen(sv.ctx, a, rec[3], rec[2], o, o + 32, err, sizeof err);
+                else {  // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness
+                    const uint32_t n_sig = rec[4], n_msg = rec[5];
+                    std::vector<uint8_t> sig(n_sig + 1), msg(n_msg + 1);
+                    for (uint32_t k = 0; k < n_sig; k++) sig[k] = a[(size_t)(2 + k) * 32 + 31];
+                    for (uint32_t k = 0; k < n_msg; k++) msg[k] = a[(size_t)(2 + n_sig + k) * 32 + 31];
+                    uint8_t ok = 0;
+                    r = sv.schnorr_verify(sv.ctx, a, a + 32, sig.data(), n_sig, msg.data(), n_msg, &ok, err, sizeof err);
+                    o[31] = ok ? 1 : 0;
+                }
+                rc[i] = (uint8_t)(r < 0 || r > 2 ? 3 : r);
+                if (r != 0) b->host_bb_msg[instance_of(i)] = err;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(d_rc, rc.data(), m, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_vals, vals.data(), (size_t)m * out_row, hipMemcpyHostToDevice, s));
         if (exact) launch_hostbb_apply_exact(s, b->d_W, b->Bp, L, first, m, opcode, func, d_outs, n_out, d_active, d_rc, d_vals);
         else launch_hostbb_apply_level(s, b->d_W, b->Bp, first, m, opcode, func, d_outs, n_out, d_rc, d_vals, b->d_event);
-        HB_CHK(hipGetLastError());
-        HB_CHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
     }
-#undef HB_CHK
-    cleanup();
     return 0;
 }
 
 // run the exact in-order kernels over the current lanes from opcode min_start on and fetch the outcomes
-static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start) {
+// (stepping: the lanes executed every earlier opcode themselves, nothing is replayed; only opcodes [min_start, end_opcode) run)
+static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start, bool replay = true, uint32_t end_opcode = 0xFFFFFFFFu) {
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
     const ExactLanes L = exact_lanes(b, n_slow);
     // memory side effects of the opcodes before the earliest event are replayed by the span kernel, so start at the
     // first segment that holds a memory opcode or the earliest event, whichever comes first
-    bool has_mem = p.mem_cells != 0;
+    bool has_mem = replay && p.mem_cells != 0;
     for (const ExactSegment &seg : b->segments) {
         if (seg.end <= min_start && !(has_mem && seg.cls == CLS_LIGHT)) continue;
+        if (seg.begin >= end_opcode) break;
         switch (seg.cls) {
-        case CLS_LIGHT: launch_exact_span(s, b->d_W, b->Bp, b->dp, L, seg.begin, seg.end, has_mem); break;
+        case CLS_LIGHT:
+            launch_exact_span(s, b->d_W, b->Bp, b->dp, L, replay ? seg.begin : std::max(seg.begin, min_start), std::min(seg.end, end_opcode), has_mem);
+            break;
         case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
         case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
         case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
@@ -609,7 +693,7 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
             break;
         }
     }
-    launch_exact_finish(s, L);
+    launch_exact_finish(s, L, b->stepping ? p.n_opcodes : 0u);
     HIPCHK(hipGetLastError());
     b->slow_res.resize(n_slow);
     HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
@@ -653,11 +737,98 @@ static int solve_resume(acvm_batch *b) {
     return count_not_solved(b);
 }
 
-int acvm_batch_solve(acvm_batch_t *b) {
+// acvm_batch_solve_opcode (one == true: ACVM::solve_opcode, pwg/mod.rs:243-303) and acvm_batch_solve after some steps
+// (one == false: the loop of ACVM::solve :236-241 over what is left). Every instance is an exact lane whose instruction
+// pointer is slow_start[t]; see include/acvm_amd.h for the batch semantics.
+static int solve_stepping(acvm_batch *b, bool one) {
+    const Plan &p = b->plan;
+    hipStream_t s = b->stream;
+    const uint32_t n_slow = b->B;
+    if (!b->stepping) {
+        b->slow_ids.resize(n_slow);
+        for (uint32_t j = 0; j < n_slow; j++) { b->slow_ids[j] = j; b->slow_index[j] = (int32_t)j; }
+        b->slow_start.assign(n_slow, 0);
+        std::fill(b->h_event.begin(), b->h_event.end(), 0u);
+        b->host_bb_msg.clear();
+        b->stepping = true;
+        b->solved = true;
+        SlowResult fresh;
+        memset(&fresh, 0, sizeof fresh);
+        fresh.status = ACVM_STATUS_IN_PROGRESS;
+        b->slow_res.assign(n_slow, fresh);
+        if (!n_slow) return 0;
+        if (int rc = ensure_slow_capacity(b, n_slow)) return rc;
+        launch_fill_u32(s, b->d_event, 0u, b->B);  // no column is scaled: the exact kernels write plain values
+        HIPCHK(hipMemcpyAsync(b->d_slow_ids, b->slow_ids.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
+        b->fc_lane.assign(n_slow, acvm_batch::FcLaneState());
+        if (int rc = upload_fc_tables(b, n_slow)) return rc;
+        launch_exact_init(s, exact_lanes(b, n_slow));
+    } else {
+        bool any = false;
+        for (uint32_t t = 0; t < n_slow; t++)
+            if (b->slow_res[t].status == ACVM_STATUS_REQUIRES_FOREIGN_CALL && b->fc_lane[t].resolved_new) {
+                b->fc_lane[t].resolved_new = false;
+                b->slow_start[t] = b->slow_res[t].opcode_index;  // the opcode re-runs its VM (mod.rs:220-227)
+                b->slow_res[t].status = ACVM_STATUS_IN_PROGRESS;
+                any = true;
+            }
+        if (any) {
+            if (int rc = upload_fc_tables(b, n_slow)) return rc;
+            HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(b->d_slow_res, b->slow_res.data(), (size_t)n_slow * sizeof(SlowResult), hipMemcpyHostToDevice, s));
+        }
+    }
+    if (!n_slow) return 0;
+    uint32_t ip = 0xFFFFFFFFu;
+    for (uint32_t t = 0; t < n_slow; t++)
+        if (b->slow_res[t].status == ACVM_STATUS_IN_PROGRESS) ip = std::min(ip, b->slow_start[t]);
+    if (ip == 0xFFFFFFFFu) return count_not_solved(b);
+    const uint32_t end = one ? std::min(ip + 1, p.n_opcodes) : p.n_opcodes;
+    if (one) {  // advance the instruction pointers on the host between the opcode and the Solved test
+        if (ip < p.n_opcodes)
+            if (int rc = run_exact_segments(b, n_slow, ip, false, end)) return rc;
+        b->slow_res.resize(n_slow);
+        HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (uint32_t t = 0; t < n_slow; t++)
+            if (b->slow_res[t].status == ACVM_STATUS_IN_PROGRESS && b->slow_start[t] <= ip) b->slow_start[t] = end;
+        HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        launch_exact_finish(s, exact_lanes(b, n_slow), p.n_opcodes);
+        HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
+    } else {
+        if (int rc = run_exact_segments(b, n_slow, ip, false)) return rc;  // ends with the Solved test of the lanes still running
+        for (uint32_t t = 0; t < n_slow; t++)
+            if (b->slow_start[t] < p.n_opcodes) b->slow_start[t] = p.n_opcodes;
+        // (run_exact_segments finishes only lanes whose pointer is at the end: publish the pointers first)
+        HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        launch_exact_finish(s, exact_lanes(b, n_slow), p.n_opcodes);
+        HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    b->pend_host_valid = false;
+    for (uint32_t t = 0; t < n_slow; t++) {
+        SlowResult &r = b->slow_res[t];
+        if (r.status == ACVM_STATUS_IN_PROGRESS) r.opcode_index = b->slow_start[t];  // ACVM::instruction_pointer
+        else if (r.status == ACVM_STATUS_REQUIRES_FOREIGN_CALL || r.status == ACVM_STATUS_FAILURE) b->slow_start[t] = r.opcode_index;
+    }
+    return count_not_solved(b);
+}
+
+int acvm_batch_solve_opcode(acvm_batch_t *b) try {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
+    if (b->solved && !b->stepping) return set_err(ACVM_E_STATE, "acvm_batch_solve_opcode after acvm_batch_solve: reset the batch first");
+    HIPCHK(hipSetDevice(b->device));
+    return solve_stepping(b, true);
+} ABI_CATCH
+
+int acvm_batch_solve(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
     HIPCHK(hipSetDevice(b->device));
-    if (b->solved) return solve_resume(b);  // only resolved foreign calls can change anything
+    if (b->solved) return b->stepping ? solve_stepping(b, false) : solve_resume(b);  // only resolved foreign calls can change anything
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
     hipStream_t s2 = getenv("ACVM_NO_OVERLAP") ? b->stream : b->stream_dyn;  // measurement aid: serialise the two level kernels
@@ -848,7 +1019,7 @@ int acvm_batch_solve(acvm_batch_t *b) {
     b->solved = true;
     if (!n_slow) b->slow_res.clear();
     return count_not_solved(b);
-}
+} ABI_CATCH
 
 // ---- ACVM::get_pending_foreign_call / resolve_pending_foreign_call (pwg/mod.rs:203-228) per instance
 static int fetch_pending(acvm_batch *b) {
@@ -870,7 +1041,7 @@ static int waiting_lane(acvm_batch *b, uint32_t instance) {
     return t;
 }
 
-int acvm_batch_pending_foreign_call(acvm_batch_t *b, uint32_t instance, acvm_foreign_call_info_t *info) {
+int acvm_batch_pending_foreign_call(acvm_batch_t *b, uint32_t instance, acvm_foreign_call_info_t *info) try {
     if (!b || !info) return set_err(ACVM_E_INVALID, "null argument");
     memset(info, 0, sizeof *info);
     int t = waiting_lane(b, instance);
@@ -886,9 +1057,9 @@ int acvm_batch_pending_foreign_call(acvm_batch_t *b, uint32_t instance, acvm_for
     auto it = b->plan.fc_function.find(((uint64_t)sr.opcode_index << 32) | sr.x0);
     snprintf(info->function, sizeof info->function, "%s", it == b->plan.fc_function.end() ? "" : it->second.c_str());
     return 1;
-}
+} ABI_CATCH
 
-int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, uint32_t *lens, uint8_t *values_be32) {
+int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, uint32_t *lens, uint8_t *values_be32) try {
     if (!b || !lens || !values_be32) return set_err(ACVM_E_INVALID, "null argument");
     int t = waiting_lane(b, instance);
     if (t < 0) return set_err(ACVM_E_STATE, "instance is not waiting for a foreign call");
@@ -909,10 +1080,10 @@ int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, u
         }
     }
     return 0;
-}
+} ABI_CATCH
 
 int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t n_values, const uint8_t *is_array, const uint32_t *lens,
-                                    const uint8_t *values_be32) {
+                                    const uint8_t *values_be32) try {
     if (!b || (n_values && (!is_array || !lens || !values_be32))) return set_err(ACVM_E_INVALID, "null argument");
     int t = waiting_lane(b, instance);
     if (t < 0) return set_err(ACVM_E_STATE, "ACVM is not expecting a foreign call response as no call was made");  // mod.rs:215-217 panics
@@ -933,21 +1104,17 @@ int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t
     ls.results.push_back(std::move(res));
     ls.resolved_new = true;
     return 0;
-}
+} ABI_CATCH
 
 // one witness of one instance as 32 canonical big-endian bytes (message texts only; rare)
 static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
-    uint32_t *d_sel = nullptr;
-    uint8_t *d_out = nullptr;
-    bool ok = hipMalloc((void **)&d_sel, 4) == hipSuccess && hipMalloc((void **)&d_out, 32) == hipSuccess &&
-              hipMemcpy(d_sel, &w, 4, hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) {
-        launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out, b->unscale);
-        ok = hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, b->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
-    }
-    if (d_sel) hipFree(d_sel);
-    if (d_out) hipFree(d_out);
-    return ok;
+    if (stage_reserve(b, 512) != 0) return false;
+    uint32_t *d_sel = (uint32_t *)b->d_stage;
+    uint8_t *d_out = b->d_stage + 256;
+    if (hipMemcpyAsync(d_sel, &w, 4, hipMemcpyHostToDevice, b->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return false;  // &w is a stack address
+    launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out, b->unscale);
+    return hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, b->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
 }
 
 // message text of a failure, rebuilt from the device's DevMsg code (ops_common.hpp) + payload
@@ -1053,6 +1220,7 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
         snprintf(r.message, sizeof r.message, "%s", sr.x0 < 7 ? texts[sr.x0] : "");
         break;
     }
+    case 27: snprintf(r.message, sizeof r.message, "index out of bounds: the len is %u but the index is %u", sr.x0, sr.x1); break;
     case 24: {
         auto it = b->host_bb_msg.find(j);
         snprintf(r.message, sizeof r.message, "%s", it == b->host_bb_msg.end() ? "" : it->second.c_str());
@@ -1072,13 +1240,13 @@ static void fill_result(acvm_batch *b, uint32_t j, acvm_result_t &r) {
     if (sr.status == ACVM_STATUS_FAILURE && sr.msg) format_message(b, j, sr, r);
 }
 
-int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out) {
+int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out) try {
     if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     HIPCHK(hipSetDevice(b->device));
     for (uint32_t j = 0; j < b->B; j++) fill_result(b, j, out[j]);
     return 0;
-}
+} ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------- after solve
 int acvm_circuit_assert_message(const acvm_circuit_t *c, uint32_t acir_index, uint32_t brillig_index, char *out, size_t cap) {
@@ -1093,7 +1261,7 @@ int acvm_circuit_assert_message(const acvm_circuit_t *c, uint32_t acir_index, ui
     return -1;
 }
 
-int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, uint32_t cap) {
+int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, uint32_t cap) try {
     if (!c) return set_err(ACVM_E_INVALID, "null argument");
     const Circuit &k = *c->c;
     std::vector<uint32_t> v;
@@ -1109,9 +1277,9 @@ int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, 
     v.erase(std::unique(v.begin(), v.end()), v.end());
     for (uint32_t i = 0; i < v.size() && i < cap && out; i++) out[i] = v[i];
     return (int)v.size();
-}
+} ABI_CATCH
 
-int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap) {
+int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap) try {
     if (!b || !out || !cap) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if (instance >= b->B) return set_err(ACVM_E_INVALID, "instance out of range");
@@ -1145,7 +1313,7 @@ int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t i
     case ACVM_ERR_PANIC: return snprintf(out, cap, "panicked: %s", r.message);
     default: return snprintf(out, cap, "unknown error %u", r.err);
     }
-}
+} ABI_CATCH
 
 // assigned flags of instance j over all witnesses (host side bookkeeping + slow-path bitmap)
 static int fetch_assigned(acvm_batch *b, uint32_t first, uint32_t n, uint8_t *assigned) {
@@ -1171,7 +1339,7 @@ static int fetch_assigned(acvm_batch *b, uint32_t first, uint32_t n, uint8_t *as
     return 0;
 }
 
-int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *assigned, uint8_t *values_be32) {
+int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *assigned, uint8_t *values_be32) try {
     if (!b || !assigned || !values_be32) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
@@ -1181,33 +1349,27 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     if (int rc = fetch_assigned(b, first, n, assigned)) return rc;
     std::vector<uint32_t> sel(nw);
     for (uint32_t w = 0; w < nw; w++) sel[w] = w;
-    uint32_t *d_sel = nullptr;
-    HIPCHK(hipMalloc((void **)&d_sel, (size_t)nw * 4));
-    HIPCHK(hipMemcpy(d_sel, sel.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
-    // stage through a bounded device buffer
+    // stage through a bounded slice of the arena
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)nw * 32));
     if (chunk > n) chunk = n;
-    uint8_t *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_out, (size_t)chunk * nw * 32);
-    if (e != hipSuccess) { hipFree(d_sel); return set_err(ACVM_E_DEVICE, hipGetErrorString(e)); }
-    int rc = 0;
-    for (uint32_t done = 0; done < n && !rc; done += chunk) {
+    const size_t sel_bytes = align256((size_t)nw * 4);
+    if (int rc = stage_reserve(b, sel_bytes + (size_t)chunk * nw * 32)) return rc;
+    uint32_t *d_sel = (uint32_t *)b->d_stage;
+    uint8_t *d_out = b->d_stage + sel_bytes;
+    HIPCHK(hipMemcpyAsync(d_sel, sel.data(), (size_t)nw * 4, hipMemcpyHostToDevice, b->stream));
+    for (uint32_t done = 0; done < n; done += chunk) {
         uint32_t m = std::min(chunk, n - done);
         launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, nw, d_out, b->unscale);
-        e = hipMemcpyAsync(values_be32 + (size_t)done * nw * 32, d_out, (size_t)m * nw * 32, hipMemcpyDeviceToHost, b->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-        if (e != hipSuccess) rc = set_err(ACVM_E_DEVICE, hipGetErrorString(e));
+        HIPCHK(hipMemcpyAsync(values_be32 + (size_t)done * nw * 32, d_out, (size_t)m * nw * 32, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
     }
-    hipFree(d_out);
-    hipFree(d_sel);
-    if (rc) return rc;
     for (size_t i = 0; i < (size_t)n * nw; i++)
         if (!assigned[i]) memset(values_be32 + i * 32, 0, 32);
     return 0;
-}
+} ABI_CATCH
 
 // per-instance digest of the solved witness map (definition: kernels_hash.hip, include/acvm_amd.h)
-int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32) {
+int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32) try {
     if (!b || (n && !out32)) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
@@ -1215,30 +1377,26 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
     HIPCHK(hipSetDevice(b->device));
     const Plan &p = b->plan;
     const uint32_t n_seg = digest_segments(p.n_witnesses), n_slow = (uint32_t)b->slow_ids.size();
-    int32_t *d_slow_index = nullptr;
-    uint32_t *d_leaves = nullptr;
-    uint8_t *d_out = nullptr;
-    auto cleanup = [&]() { hipFree(d_slow_index); hipFree(d_leaves); hipFree(d_out); };
-    hipError_t e = hipMalloc((void **)&d_slow_index, (size_t)b->B * 4);
-    if (e == hipSuccess) e = hipMemcpy(d_slow_index, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice);
     // instances in slices whose leaf scratch stays below 1 GiB
     const uint32_t slice = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(64, (1ull << 30) / ((uint64_t)std::max(n_seg, 1u) * 32)));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_leaves, (size_t)std::max(n_seg, 1u) * 32 * slice);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)slice * 32);
-    for (uint32_t done = 0; done < n && e == hipSuccess; done += slice) {
+    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)std::max(n_seg, 1u) * 32 * slice);
+    if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + (size_t)slice * 32)) return rc;
+    int32_t *d_slow_index = (int32_t *)b->d_stage;
+    uint32_t *d_leaves = (uint32_t *)(b->d_stage + idx_bytes);
+    uint8_t *d_out = b->d_stage + idx_bytes + leaf_bytes;
+    HIPCHK(hipMemcpyAsync(d_slow_index, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice, b->stream));
+    for (uint32_t done = 0; done < n; done += slice) {
         const uint32_t m = std::min(slice, n - done);
         launch_digest(b->stream, b->d_W, b->Bp, first + done, m, p.n_witnesses, b->d_producer, b->unscale, d_slow_index, b->d_assigned, n_slow, d_leaves, d_out);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(out32 + (size_t)done * 32, d_out, (size_t)m * 32, hipMemcpyDeviceToHost, b->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out32 + (size_t)done * 32, d_out, (size_t)m * 32, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
     }
-    cleanup();
-    if (e != hipSuccess) return set_err(ACVM_E_DEVICE, hipGetErrorString(e));
     return 0;
-}
+} ABI_CATCH
 
 int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,
-                                 uint8_t *values_be32) {
+                                 uint8_t *values_be32) try {
     if (!b || (n_witnesses && (!witnesses || !values_be32))) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
@@ -1259,25 +1417,23 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
                 snprintf(text, sizeof text, "Failed to extract witness %u from witness map. Witness not found. (instance %u)", witnesses[k], first + i);
                 return set_err(ACVM_E_STATE, text);
             }
-    uint32_t *d_sel = nullptr;
-    uint8_t *d_out = nullptr;
-    HIPCHK(hipMalloc((void **)&d_sel, (size_t)n_witnesses * 4));
-    hipError_t e = hipMemcpy(d_sel, witnesses, (size_t)n_witnesses * 4, hipMemcpyHostToDevice);
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)n_witnesses * 32));
     if (chunk > n) chunk = n;
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)chunk * n_witnesses * 32);
-    for (uint32_t done = 0; done < n && e == hipSuccess; done += chunk) {
+    const size_t sel_bytes = align256((size_t)n_witnesses * 4);
+    if (int rc = stage_reserve(b, sel_bytes + (size_t)chunk * n_witnesses * 32)) return rc;
+    uint32_t *d_sel = (uint32_t *)b->d_stage;
+    uint8_t *d_out = b->d_stage + sel_bytes;
+    HIPCHK(hipMemcpyAsync(d_sel, witnesses, (size_t)n_witnesses * 4, hipMemcpyHostToDevice, b->stream));
+    for (uint32_t done = 0; done < n; done += chunk) {
         const uint32_t m = std::min(chunk, n - done);
         launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, n_witnesses, d_out, b->unscale);
-        e = hipMemcpyAsync(values_be32 + (size_t)done * n_witnesses * 32, d_out, (size_t)m * n_witnesses * 32, hipMemcpyDeviceToHost, b->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        HIPCHK(hipMemcpyAsync(values_be32 + (size_t)done * n_witnesses * 32, d_out, (size_t)m * n_witnesses * 32, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
     }
-    if (d_out) hipFree(d_out);
-    if (d_sel) hipFree(d_sel);
-    return e == hipSuccess ? 0 : set_err(ACVM_E_DEVICE, hipGetErrorString(e));
-}
+    return 0;
+} ABI_CATCH
 
-long long acvm_witness_map_decode(const uint8_t *bytes, size_t len, uint32_t *ids, uint8_t *values_be32, uint32_t cap) {
+long long acvm_witness_map_decode(const uint8_t *bytes, size_t len, uint32_t *ids, uint8_t *values_be32, uint32_t cap) try {
     if (!bytes) return set_err(ACVM_E_INVALID, "null argument");
     std::vector<uint32_t> id;
     std::vector<uint8_t> val;
@@ -1288,18 +1444,18 @@ long long acvm_witness_map_decode(const uint8_t *bytes, size_t len, uint32_t *id
         if (values_be32) memcpy(values_be32 + 32 * i, val.data() + 32 * i, 32);
     }
     return (long long)id.size();
-}
+} ABI_CATCH
 
-long long acvm_witness_map_encode(const uint32_t *ids, const uint8_t *values_be32, uint32_t n, uint8_t *out, size_t cap) {
+long long acvm_witness_map_encode(const uint32_t *ids, const uint8_t *values_be32, uint32_t n, uint8_t *out, size_t cap) try {
     if (n && (!ids || !values_be32)) return set_err(ACVM_E_INVALID, "null argument");
     std::vector<uint8_t> bytes;
     std::string err;
     if (!witness_map_to_bytes(ids, values_be32, n, bytes, err)) return set_err(ACVM_E_INVALID, err.c_str());
     if (out && bytes.size() <= cap) memcpy(out, bytes.data(), bytes.size());
     return (long long)bytes.size();
-}
+} ABI_CATCH
 
-long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8_t *out, size_t cap) {
+long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8_t *out, size_t cap) try {
     if (!b) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if (instance >= b->B) return set_err(ACVM_E_INVALID, "instance out of range");
@@ -1314,26 +1470,21 @@ long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8
             vals.insert(vals.end(), values.begin() + (size_t)w * 32, values.begin() + (size_t)w * 32 + 32);
         }
     return acvm_witness_map_encode(ids.data(), vals.data(), (uint32_t)ids.size(), out, cap);
-}
+} ABI_CATCH
 
-int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uint8_t *assigned) {
+int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uint8_t *assigned) try {
     if (!b || !out_be32 || !assigned) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if (witness >= b->plan.n_witnesses) { memset(assigned, 0, b->B); memset(out_be32, 0, (size_t)b->B * 32); return 0; }
     HIPCHK(hipSetDevice(b->device));
     if (!b->B) return 0;
-    uint32_t *d_sel = nullptr;
-    uint8_t *d_out = nullptr;
-    HIPCHK(hipMalloc((void **)&d_sel, 4));
-    HIPCHK(hipMemcpy(d_sel, &witness, 4, hipMemcpyHostToDevice));
-    hipError_t e = hipMalloc((void **)&d_out, (size_t)b->B * 32);
-    if (e != hipSuccess) { hipFree(d_sel); return set_err(ACVM_E_DEVICE, hipGetErrorString(e)); }
+    if (int rc = stage_reserve(b, 256 + (size_t)b->B * 32)) return rc;
+    uint32_t *d_sel = (uint32_t *)b->d_stage;
+    uint8_t *d_out = b->d_stage + 256;
+    HIPCHK(hipMemcpyAsync(d_sel, &witness, 4, hipMemcpyHostToDevice, b->stream));
     launch_export(b->stream, b->d_W, b->Bp, 0, b->B, d_sel, 1, d_out, b->unscale);
-    e = hipMemcpyAsync(out_be32, d_out, (size_t)b->B * 32, hipMemcpyDeviceToHost, b->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    hipFree(d_out);
-    hipFree(d_sel);
-    if (e != hipSuccess) return set_err(ACVM_E_DEVICE, hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(out_be32, d_out, (size_t)b->B * 32, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     std::vector<uint32_t> bitmap;
     uint32_t n_slow = (uint32_t)b->slow_ids.size();
     if (n_slow) {
@@ -1346,7 +1497,7 @@ int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uin
         if (!assigned[j]) memset(out_be32 + (size_t)j * 32, 0, 32);
     }
     return 0;
-}
+} ABI_CATCH
 
 int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");

@@ -2,6 +2,7 @@
 // (fixint little-endian, u64 lengths, u32 enum tags, u8 Option tag; FieldElement = hex String,
 // acir_field/src/generic_ark.rs:114-134, parsed like from_hex :263-267, i.e. reduced mod p).
 #include "circuit.hpp"
+#include <algorithm>
 #include <map>
 #include <stdexcept>
 #include <zlib.h>
@@ -36,14 +37,15 @@ struct Reader {
         const uint8_t *s = p;
         p += n;
         if (n >= 2 && s[0] == '0' && s[1] == 'x') { s += 2; n -= 2; }
-        if (n % 2 || n > 64) throw std::runtime_error("bad field element hex");
-        uint8_t b[32];
+        // from_hex (generic_ark.rs:263-267): hex::decode of any even length, then from_be_bytes_reduce
+        if (n % 2) throw std::runtime_error("bad field element hex");
+        std::vector<uint8_t> b(n / 2);
         for (size_t i = 0; i < n / 2; i++) {
             int h = hexval(s[2 * i]), l = hexval(s[2 * i + 1]);
             if (h < 0 || l < 0) throw std::runtime_error("bad field element hex");
             b[i] = (uint8_t)(h * 16 + l);
         }
-        return frh::from_be_bytes32_reduce(b, n / 2);
+        return frh::from_be_bytes_reduce(b.data(), b.size());
     }
     std::string str() {
         size_t n = len(1);
@@ -270,17 +272,25 @@ bool gunzip(const uint8_t *buf, size_t len, std::vector<uint8_t> &out) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;
-    out.resize(len * 8 + 1024);
-    zs.next_in = (Bytef *)buf;
-    zs.avail_in = (uInt)len;
-    size_t have = 0;
+    out.resize(std::min<size_t>(len * 8 + 1024, (size_t)256 << 20));
+    // zlib counts in uInt: feed and drain in chunks of at most 1 GiB so that inputs of 4 GiB and more are not truncated
+    const size_t CHUNK = (size_t)1 << 30;
+    size_t fed = 0, have = 0;
     int rc;
     do {
+        if (zs.avail_in == 0 && fed < len) {
+            const size_t m = std::min(CHUNK, len - fed);
+            zs.next_in = (Bytef *)buf + fed;
+            zs.avail_in = (uInt)m;
+            fed += m;
+        }
         if (have == out.size()) out.resize(out.size() * 2);
+        const size_t room = std::min(CHUNK, out.size() - have);
         zs.next_out = out.data() + have;
-        zs.avail_out = (uInt)(out.size() - have);
+        zs.avail_out = (uInt)room;
         rc = inflate(&zs, Z_NO_FLUSH);
-        have = out.size() - zs.avail_out;
+        have += room - zs.avail_out;
+        if (rc == Z_BUF_ERROR && (zs.avail_in == 0 ? fed < len : zs.avail_out == 0)) rc = Z_OK;  // needs more input / more room
     } while (rc == Z_OK);
     inflateEnd(&zs);
     out.resize(have);
@@ -368,6 +378,7 @@ bool witness_map_to_bytes(const uint32_t *ids, const uint8_t *values_be32, size_
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (deflateInit2(&zs, Z_BEST_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK) { err = "deflateInit2 failed"; return false; }
+    if (raw.size() >= ((size_t)1 << 31)) { deflateEnd(&zs); err = "witness map above 2 GiB"; return false; }  // zlib counts in uInt
     out.resize(deflateBound(&zs, (uLong)raw.size()) + 32);
     zs.next_in = raw.data();
     zs.avail_in = (uInt)raw.size();

@@ -126,6 +126,15 @@ inline FrH from_be_bytes32_reduce(const uint8_t *b, size_t len) {
     while (geq_p(v)) sub4(v, v, P);
     return from_canonical(v);
 }
+// from_be_bytes_reduce for any length (generic_ark.rs:281-283): Horner over 32-byte blocks, most significant first
+inline FrH from_be_bytes_reduce(const uint8_t *b, size_t len) {
+    if (len <= 32) return from_be_bytes32_reduce(b, len);
+    const size_t head = len % 32 ? len % 32 : 32;
+    FrH acc = from_be_bytes32_reduce(b, head);
+    const FrH r2{{R2[0], R2[1], R2[2], R2[3]}};  // Montgomery form of R = 2^256
+    for (size_t off = head; off < len; off += 32) acc = add(mul(acc, r2), from_be_bytes32_reduce(b + off, 32));
+    return acc;
+}
 inline FrH pow_pm2(const FrH &a) {  // a^(p-2): Fermat inverse (planner only; a handful of calls per circuit)
     uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
     FrH r = one();

@@ -117,6 +117,6 @@ uint32_t digest_segments(uint32_t n_witnesses);
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
                    const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out);
 // InProgress -> Solved after the last opcode
-void launch_exact_finish(hipStream_t s, const ExactLanes &L);
+void launch_exact_finish(hipStream_t s, const ExactLanes &L, uint32_t min_ip = 0);
 
 }  // namespace acvm

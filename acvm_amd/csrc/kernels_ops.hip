@@ -49,10 +49,11 @@ __global__ void exact_init_kernel(ExactLanes L) {
     for (int i = 0; i < 8; i++) r.val[i] = 0u;
     L.results[t] = r;
 }
-__global__ void exact_finish_kernel(ExactLanes L) {
+// min_ip: only lanes whose instruction pointer (start_opcode) reached it are done (acvm_batch_solve_opcode; 0 otherwise)
+__global__ void exact_finish_kernel(ExactLanes L, uint32_t min_ip) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= L.n_slow) return;
-    if (L.results[t].status == 1u) {  // pwg/mod.rs:275-276
+    if (L.results[t].status == 1u && L.start_opcode[t] >= min_ip) {  // pwg/mod.rs:275-276
         L.results[t].status = 0u;
         L.results[t].opcode_index = 0u;  // left over from an earlier RequiresForeignCall stop
         L.results[t].x0 = 0u;
@@ -168,9 +169,9 @@ void launch_exact_init(hipStream_t s, const ExactLanes &L) {
     if (!L.n_slow) return;
     hipLaunchKernelGGL(exact_init_kernel, dim3((L.n_slow + 255) / 256), dim3(256), 0, s, L);
 }
-void launch_exact_finish(hipStream_t s, const ExactLanes &L) {
+void launch_exact_finish(hipStream_t s, const ExactLanes &L, uint32_t min_ip) {
     if (!L.n_slow) return;
-    hipLaunchKernelGGL(exact_finish_kernel, dim3((L.n_slow + 255) / 256), dim3(256), 0, s, L);
+    hipLaunchKernelGGL(exact_finish_kernel, dim3((L.n_slow + 255) / 256), dim3(256), 0, s, L, min_ip);
 }
 
 }  // namespace acvm

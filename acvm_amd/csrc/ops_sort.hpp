@@ -49,7 +49,8 @@ __device__ __forceinline__ OpResult op_perm_sort(const P &p, const uint32_t *__r
             for (uint32_t s = 0; s < n_sort_by && !cmp; s++) {
                 const uint32_t col = sort_by[s];
                 if (col == tuple) { cmp = (prev > cur) - (prev < cur); continue; }
-                if (col > tuple) continue;
+                // a[*i as usize] on a Vec of tuple + 1 elements (mod.rs:102-105): the comparator panics when it reaches the column
+                if (col > tuple) return op_fail_msg(DE_PANIC, 0, DM_SORT_TUPLE, tuple + 1, col);
                 for (int k = 7; k >= 0 && !cmp; k--) {
                     const uint32_t x = S.get(o_vals + 8 * (prev * tuple + col) + k), y = S.get(o_vals + 8 * (cur * tuple + col) + k);
                     cmp = (x > y) - (x < y);

@@ -164,8 +164,17 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     auto t0 = std::chrono::steady_clock::now();
     Plan p;
     p.n_opcodes = (uint32_t)c.opcodes.size();
-    uint32_t nw = c.max_witness + 1;
-    for (uint32_t i = 0; i < n_initial; i++) nw = std::max(nw, initial_ids[i] + 1);
+    // The witness table is dense (slot = witness index); the reference's BTreeMap takes any u32 index. Circuit bytes are
+    // untrusted input: an index near 2^32 must neither wrap `max + 1` nor make the planner allocate per-witness vectors of
+    // many GB, so indices above PLAN_MAX_WITNESSES - 1 are refused (ACVM_E_UNSUPPORTED at acvm_batch_new / plan_stats).
+    uint64_t nw64 = (uint64_t)c.max_witness + 1;
+    for (uint32_t i = 0; i < n_initial; i++) nw64 = std::max<uint64_t>(nw64, (uint64_t)initial_ids[i] + 1);
+    if (nw64 > PLAN_MAX_WITNESSES) {
+        p.unsupported = "witness index " + std::to_string(nw64 - 1) + " exceeds the dense witness table (at most " +
+                        std::to_string(PLAN_MAX_WITNESSES) + " witnesses per circuit)";
+        return p;
+    }
+    const uint32_t nw = (uint32_t)nw64;
     p.n_witnesses = nw;
     p.initial_ids.assign(initial_ids, initial_ids + n_initial);
     p.producer.assign(nw, 0xFFFFFFFFu);

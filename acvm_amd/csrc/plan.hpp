@@ -102,6 +102,9 @@ struct Plan {
     uint64_t fc_pending_vals = 0;  // field elements one pending call can hand to the host (upper bound)
 };
 
+// largest dense witness table the planner accepts (witness indices 0 .. PLAN_MAX_WITNESSES - 1)
+static constexpr uint64_t PLAN_MAX_WITNESSES = 1ull << 27;
+
 // host_blackbox: the three BlackBoxFunctionSolver functions are served by caller-supplied host callbacks
 Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, bool host_blackbox = false);
 

@@ -61,3 +61,45 @@ def sum_over_ranks(value: float, dist) -> float:
     t = torch.tensor([value], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ---- digest of digests: proof that the ranks solved disjoint shards of ONE global batch (independent of the number of ranks
+# and of the tile size). The per-instance map digests (acvm_batch_digest) of DIGEST_CHUNK consecutive instances of the global
+# batch are hashed into one chunk digest; the digest of digests is Blake2s-256 over the chunk digests in global order. Shards
+# are multiples of the chunk, so every rank produces whole chunks and rank 0 only concatenates them.
+DIGEST_CHUNK = 1 << 12
+
+
+def chunk_digests(instance_digests, chunk=DIGEST_CHUNK):
+    """instance_digests: uint8 array [n][32] of consecutive instances starting at a multiple of `chunk` -> list of 32-byte chunk
+    digests (the last one may cover fewer instances)."""
+    import hashlib
+    import numpy as np
+    d = np.ascontiguousarray(instance_digests, dtype=np.uint8)
+    return [hashlib.blake2s(d[i:i + chunk].tobytes()).digest() for i in range(0, d.shape[0], chunk)]
+
+
+def digest_of_digests(chunks) -> str:
+    import hashlib
+    return hashlib.blake2s(b"".join(chunks)).hexdigest()
+
+
+def gather_bytes(payload: bytes, dist):
+    """all ranks' byte strings (equal length on every rank), in rank order; [payload] when single-process"""
+    if dist is None:
+        return [payload]
+    import torch
+    t = torch.tensor(list(payload), dtype=torch.uint8)
+    got = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    return [bytes(g.tolist()) for g in got]
+
+
+def gather_floats(value: float, dist):
+    if dist is None:
+        return [value]
+    import torch
+    t = torch.tensor([value], dtype=torch.float64)
+    got = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    return [float(g.item()) for g in got]

@@ -6,7 +6,58 @@ Footprint of a handle = 32 B x witnesses x tile: a 10^6-opcode circuit runs with
 instances of different tiles are independent, exactly like the instances of different GPUs (acvm_amd/shard.py)."""
 import numpy as np
 
-from . import Batch
+from . import Batch, DeviceBuffer
+
+
+class ResidentShard:
+    """One rank's shard of a global batch with its inputs resident in HBM (SURVEY 8d timing protocol: H2D outside the timed
+    region): `n` instances, values_be = [n][len(ids)][32], solved as consecutive tiles of `tile` instances through ONE reused
+    batch handle (acvm_batch_set_initial_witness_device on a slice of the resident buffer, then acvm_batch_solve). When tile
+    does not divide n the last tile starts at n - tile and overlaps its predecessor (independent instances: solving one twice
+    changes nothing)."""
+
+    def __init__(self, circuit, initial_ids, values_be, n: int, tile: int, solver=None, resident=True):
+        self.ids = list(initial_ids)
+        self.row = len(self.ids) * 32
+        self.n = n
+        self.tile = max(1, min(tile, n))
+        self.host = np.frombuffer(values_be, dtype=np.uint8)
+        if self.host.size != n * self.row:
+            raise ValueError("values_be has the wrong size")
+        self.batch = Batch(circuit, self.tile, self.ids, solver)
+        self.buf = DeviceBuffer(self.host) if resident else None
+        self.starts = list(range(0, n - self.tile + 1, self.tile))
+        if self.starts[-1] + self.tile < n:
+            self.starts.append(n - self.tile)
+
+    def load_tile(self, k: int):
+        """ACVM::new for tile k from the resident buffer"""
+        self.batch.set_initial_witness_device(self.buf.ptr + self.starts[k] * self.row)
+
+    def solve_pass(self, on_tile=None):
+        """one pass over the shard; on_tile(k, first_new, first_in_tile) runs after tile k's solve, while its table is live:
+        instances [first_new, start + tile) of the shard are the ones this tile solved for the first time"""
+        done = 0
+        for k, start in enumerate(self.starts):
+            self.load_tile(k)
+            self.batch.solve()
+            if on_tile is not None:
+                on_tile(k, done, start)
+            done = start + self.tile
+
+    def digests(self):
+        """uint8 [n][32]: per-instance digests of the solved witness maps (one extra pass)"""
+        out = np.zeros((self.n, 32), dtype=np.uint8)
+
+        def grab(k, first_new, start):
+            out[first_new:start + self.tile] = self.batch.digest(first_new - start, start + self.tile - first_new)
+        self.solve_pass(grab)
+        return out
+
+    def free(self):
+        self.batch.free()
+        if self.buf is not None:
+            self.buf.free()
 
 
 def solve_tiled(circuit, initial_ids, values_be: bytes, n_instances: int, tile: int, keep_witnesses, solver=None, digests=None):

@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- witnesses solved / second on MI355X for the batched ACIR witness solver.
 
-Default workload = BASELINE.json configs[1]: 10k-gate arithmetic-only ACIR, batch 2^16 instances per GPU, synthetic
-circuit and inputs from acvm_amd.synth. A "step" = ACVM::solve() of the whole per-GPU batch, inputs already
-resident in HBM (Montgomery SoA), witness map left in HBM. Other workloads (parity-test configs, measured for DESIGN.md):
+Default workload = BASELINE.json's metric: 10k-gate arithmetic-only ACIR, batch 2^20 witnesses over the whole node
+(synthetic circuit and inputs from acvm_amd.synth). The global batch is sharded contiguously over the ranks (strong
+scaling: 2^20 / N instances per GPU, no data-path collective); a rank solves its shard in tiles of 2^--tile-log2 instances
+through one reused batch handle (the 335 GB witness table of 2^20 instances does not fit one GPU's 288 GB: SURVEY 8e). The
+inputs of the whole shard are resident in HBM before the timed region starts; a "step" = ACVM::new + ACVM::solve of every
+instance of the global batch (per tile: import of the resident inputs, then the level kernels), witness maps left in HBM.
+Other workloads (parity-test configs, measured for DESIGN.md; 2^16 instances per GPU unless --total-log2 is given):
     --workload hash            config 3: SHA256 + Keccak256 + RANGE circuit
     --workload grumpkin        config 4: Pedersen + FixedBaseScalarMul + SchnorrVerify circuit
     --workload arith_pedersen  the north-star shape: 10k arithmetic gates + 8 Pedersen commitments
     --workload mixed           the config-5 opcode mix at --gates opcodes (every kernel class in one circuit)
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without a launcher: spawns the N ranks itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU, instances sharded contiguously (acvm_amd.shard), no data-path collective (weak scaling: the per-GPU
-batch is fixed). Rank 0 prints ONE JSON line. The roofline entry is for the workload's dominant kernel: achieved =
-algorithmic bytes of all its launches in a solve / their summed HIP-event durations (events on the batch's own streams,
-inside the timed region). The cpu_baseline entry times the CPU oracle (a port of the reference's in-order solver) on a
-bounded sample of the same workload; the same sample is the bit-exact parity check of the run.
+One process per GPU. Rank 0 prints ONE JSON line: whole-job witnesses/s (max-over-ranks time), per-rank rates, the digest of
+digests over the per-instance witness-map digests of ALL ranks (identical for every N and tile size: the ranks provably solved
+disjoint shards of one batch), `roofline` of the dominant kernel (algorithmic bytes of its launches / their HIP-event durations,
+events on the batch's own streams), `end_to_end` (H2D of the inputs + solve + D2H of the return witnesses), and `cpu_baseline`
+(the CPU oracle -- a port of the reference's in-order solver -- timed on a bounded sample of the same workload, which is also the
+bit-exact parity check of the run; variants of BASELINE.md section 2).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,198 +37,335 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLASS_KERNEL = ["light_level_kernel", "hash_level_kernel", "grumpkin_level_kernel", "brillig_level_kernel"]
+# substring of the kernel's symbol in the rocprofv3 output
+KERNEL_SYMBOL = {"light_level_kernel": "record_level_kernel<acvm::LightOp", "hash_level_kernel": "record_level_kernel<acvm::HashOp",
+                 "grumpkin_level_kernel": "record_level_kernel<acvm::GrumpkinOp", "brillig_level_kernel": "record_level_kernel<acvm::BrilligOp"}
+# FETCH_SIZE reports half the bytes of a 16 B/lane coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section); both factors
+# were re-derived on this part from a 4 GiB copy (profiles/traffic.json: x1.99998 / x1.00000)
+PMC_READ_CORRECTION, PMC_WRITE_CORRECTION = 2.0, 1.0
 
 
-def make_workload(args, rank, B):
+def make_workload(args, first, n):
+    """(circuit, initial ids, values of instances [first, first + n) of the global batch, name)"""
     from acvm_amd import synth
-    first = rank * B
     if args.workload == "arith":
         circ, ids = synth.arithmetic_circuit(args.gates, seed=0xAC1D0002)
-        values = synth.witness_batch(B, seed=0xAC1D0002, first_instance=first)
-        name = f"{args.gates}-gate arithmetic-only ACIR, batch 2^{args.batch_log2} witnesses per GPU"
+        values = synth.witness_batch(n, seed=0xAC1D0002, first_instance=first)
+        name = f"{args.gates}-gate arithmetic-only ACIR"
     elif args.workload == "hash":
         circ, ids = synth.hash_circuit()
-        values = synth.byte_batch(B, len(ids), first_instance=first)
-        name = f"sha256 + keccak256 (64-byte messages) + 96 RANGE(8) ACIR, batch 2^{args.batch_log2} per GPU"
+        values = synth.byte_batch(n, len(ids), first_instance=first)
+        name = "sha256 + keccak256 (64-byte messages) + 96 RANGE(8) ACIR"
     elif args.workload == "grumpkin":
         circ, ids = synth.grumpkin_circuit()
         # the edge-case / flipped-signature pattern repeats every 1024 instances (row generation is host Python)
         import numpy as np
-        base = synth.grumpkin_rows(min(B, 1024), first_instance=0)
+        base = synth.grumpkin_rows(min(n, 1024), first_instance=0)
         arr = np.frombuffer(synth.values_from_rows(base), dtype=np.uint8).reshape(len(base), -1)
-        values = arr[(first + np.arange(B)) % len(base)].tobytes()
-        name = f"Pedersen + FixedBaseScalarMul + SchnorrVerify ACIR, batch 2^{args.batch_log2} per GPU"
+        values = arr[(first + np.arange(n)) % len(base)].tobytes()
+        name = "Pedersen + FixedBaseScalarMul + SchnorrVerify ACIR"
     elif args.workload == "arith_pedersen":
         circ, ids = synth.arith_pedersen_circuit(args.gates, args.pedersen)
-        values = synth.witness_batch(B, seed=0xAC1D0006, first_instance=first)
-        name = f"{args.gates}-gate arithmetic + {args.pedersen} Pedersen ACIR, batch 2^{args.batch_log2} per GPU"
+        values = synth.witness_batch(n, seed=0xAC1D0006, first_instance=first)
+        name = f"{args.gates}-gate arithmetic + {args.pedersen} Pedersen ACIR"
     elif args.workload == "mixed":
         circ, ids = synth.mixed_circuit(args.gates)
-        values = synth.witness_batch(B, seed=0xAC1D0005, first_instance=first)
-        name = f"{args.gates}-opcode mixed ACIR (config-5 mix: arithmetic, range/logic, directives, memory, Brillig, hashes, Pedersen), batch 2^{args.batch_log2} per GPU"
+        values = synth.witness_batch(n, seed=0xAC1D0005, first_instance=first)
+        name = f"{args.gates}-opcode mixed ACIR (config-5 mix: arithmetic, range/logic, directives, memory, Brillig, hashes, Pedersen)"
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     return circ, ids, values, name
 
 
-def load_traffic(workload, kernel):
-    """Measured HBM bytes per launch of `kernel` from the committed PMC profile of this workload (profiles/traffic.json,
-    written by tools/prof_summary.py --json from separate --pmc FETCH_SIZE / WRITE_SIZE passes), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)
-        e = t.get(workload, {}).get(kernel)
-        return e
-    except (OSError, ValueError):
+def spawn_ranks(n):
+    """--gpus N without a launcher: start the N ranks (one per GPU) and relay their output"""
+    import acvm_amd
+    have = acvm_amd.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} HIP device(s) visible; refusing to label a {have}-GPU run as {n}")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def measure_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured in THIS run: two rocprofv3 passes (FETCH_SIZE,
+    WRITE_SIZE separately, kernel-trace only) over a one-tile run of this script. None if rocprofv3 is missing or fails."""
+    import csv
+    import shutil
+    import tempfile
+    if os.environ.get("ACVM_BENCH_NO_PMC") or not shutil.which("rocprofv3"):
         return None
+    inner = [sys.executable, os.path.abspath(__file__), "--inner", "--workload", args.workload, "--gates", str(args.gates), "--pedersen", str(args.pedersen),
+             "--total-log2", str(args.tile_log2), "--tile-log2", str(args.tile_log2), "--steps", "1", "--warmup", "1"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="acvm_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + inner
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return None
+            n, total = 0, 0.0
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, f)) as fh:
+                            for row in csv.DictReader(fh):
+                                if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                                    n += 1
+                                    total += float(row["Counter_Value"])
+            if not n:
+                return None
+            out[counter] = (total / n, n)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd = out["FETCH_SIZE"][0] * 1024 * PMC_READ_CORRECTION
+    wr = out["WRITE_SIZE"][0] * 1024 * PMC_WRITE_CORRECTION
+    return {"bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "launches_counted": out["FETCH_SIZE"][1],
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a one-tile run inside this bench run; "
+                      "KiB x 1024, reads x2 (gfx950 correction of MI355X_MICROARCH.md), writes x1"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)  # the device reaches its clocks after about two solves (profiles/README.md)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)  # a step is 16 solves at N = 1: the device reaches its clocks within the first
     ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen", "mixed"])
     ap.add_argument("--gates", type=int, default=10000)
     ap.add_argument("--pedersen", type=int, default=8)
-    ap.add_argument("--batch-log2", type=int, default=16, help="instances per GPU = 2^this")
+    ap.add_argument("--total-log2", type=int, default=None, help="global batch = 2^this (default: 20 for arith = the metric; 16 per GPU otherwise)")
+    ap.add_argument("--tile-log2", type=int, default=16, help="instances per batch handle = 2^this (10k gates x 2^16 = 21 GB of witness table)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-digest", action="store_true", help="skip the digest-of-digests pass")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the one-tile run the PMC passes profile
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inner:
+        spawn_ranks(args.gpus)
 
     import numpy as np
     import acvm_amd
-    from acvm_amd import shard
+    from acvm_amd import shard, tiling
 
     rank, local_rank, world = shard.env_rank()
-    # timing barrier / max only; the data path has no exchange step, so a CPU (gloo) group is enough and keeps
+    # timing barrier / reductions only; the data path has no exchange step, so a CPU (gloo) group is enough and keeps
     # torch's bundled HIP runtime out of this process (the kernels run on the system ROCm runtime of libacvm_amd.so)
     dist = shard.init_group(rank, world)
-
-    if acvm_amd.device_count() < 1:
+    n_dev = acvm_amd.device_count()
+    if n_dev < 1:
         raise SystemExit("bench.py: no HIP device visible; this benchmark has no CPU fallback")
-    acvm_amd.set_device(local_rank % max(acvm_amd.device_count(), 1))
+    if world > 1 and n_dev < world and os.environ.get("LOCAL_WORLD_SIZE", str(world)) == str(world) and not os.environ.get("ACVM_BENCH_SHARE_GPU"):
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} HIP device(s) visible (set ACVM_BENCH_SHARE_GPU=1 to let ranks share a GPU in tests)")
+    acvm_amd.set_device(local_rank % n_dev)
 
-    B = 1 << args.batch_log2
-    circ, ids, values, workload_name = make_workload(args, rank, B)
+    strong = args.workload == "arith" or args.total_log2 is not None
+    total = 1 << (args.total_log2 if args.total_log2 is not None else (20 if args.workload == "arith" else 16)) if strong else (1 << 16) * world
+    if total % world or (total // world) % shard.DIGEST_CHUNK:
+        raise SystemExit(f"bench.py: the global batch {total} must split into {world} shards that are multiples of {shard.DIGEST_CHUNK}")
+    n_rank = total // world
+    first = rank * n_rank
+    tile = min(1 << args.tile_log2, n_rank)
+    circ, ids, values, workload_name = make_workload(args, first, n_rank)
     data = circ.to_bytes()
     gc = acvm_amd.Circuit(data)
-    batch = acvm_amd.Batch(gc, B, ids)
-    batch.set_initial_witness(values)  # H2D + Montgomery import: outside the timed region
-    batch.set_profiling(True)
+    row = len(ids) * 32
+
+    t_h2d0 = time.perf_counter()
+    sh = tiling.ResidentShard(gc, ids, values, n_rank, tile)  # H2D of the whole shard: outside the timed region
+    acvm_amd.synchronize()
+    h2d_resident_s = time.perf_counter() - t_h2d0  # includes the batch handle (plan + table allocation)
+    batch = sh.batch
+    n_tiles = len(sh.starts)
 
     def barrier():
         shard.barrier(dist)
         acvm_amd.synchronize()
 
-    for _ in range(args.warmup):  # with per-launch events, so that the event pool exists before the timed region
-        batch.reset()
-        batch.solve()
+    batch.set_profiling(True)  # warm-up with per-launch events, so that the event pool exists before the timed region
+    for _ in range(args.warmup):
+        sh.solve_pass()
+    batch.set_profiling(False)
     barrier()
     t0 = time.perf_counter()
     arith_ms = dyn_ms = dev_ms = 0.0
     cls_ms = [0.0] * 4
+    n_failed = 0
     for i in range(args.steps):
-        # per-launch HIP events (two per launch) cost 3 % of a solve: they bracket every launch of the LAST timed step only
-        batch.set_profiling(i == args.steps - 1)
-        batch.reset()
-        batch.solve()
-        st = batch.stats()
-        dev_ms += st["solve_device_ms"]
-        if i == args.steps - 1:
-            arith_ms = st["arith_kernel_ms"]
-            dyn_ms = st["dyn_kernel_ms"]
-            cls_ms = list(st["class_kernel_ms"])
+        for k in range(n_tiles):
+            # per-launch HIP events (two per launch) cost 3 % of a solve: they bracket the launches of the LAST tile of the LAST step only
+            last = i == args.steps - 1 and k == n_tiles - 1
+            if last:
+                batch.set_profiling(True)
+            sh.load_tile(k)
+            n_failed += batch.solve()
+            if i == args.steps - 1:
+                dev_ms += batch.stats()["solve_device_ms"]
     acvm_amd.synchronize()
-    elapsed = time.perf_counter() - t0
+    my_elapsed = time.perf_counter() - t0
     barrier()
-    elapsed = shard.max_over_ranks(elapsed, dist)
-
+    elapsed = shard.max_over_ranks(my_elapsed, dist)
     st = batch.stats()
-    results = batch.results()
-    n_solved = sum(1 for r in results if r.status == 0)
+    arith_ms, dyn_ms, cls_ms = st["arith_kernel_ms"], st["dyn_kernel_ms"], list(st["class_kernel_ms"])
+    batch.set_profiling(False)
+    results = batch.results()  # of the last tile
+    rank_rates = shard.gather_floats(n_rank * args.steps / my_elapsed, dist)
 
-    # ---- CPU baseline + parity on a bounded sample (rank 0 only)
-    cpu = None
-    parity = None
+    if args.inner:  # the profiled one-tile run: nothing to report
+        sh.free()
+        return
+
+    # ---- digest of digests: every rank hashes the witness maps of its shard (one more pass, untimed), rank 0 combines
+    dod = None
+    if not args.no_digest:
+        d0 = time.perf_counter()
+        inst_digests = sh.digests()
+        chunks = shard.chunk_digests(inst_digests)
+        digest_s = time.perf_counter() - d0
+        all_chunks = shard.gather_bytes(b"".join(chunks), dist)
+        dod = {"value": shard.digest_of_digests(all_chunks), "chunk_instances": shard.DIGEST_CHUNK, "chunks": sum(len(c) for c in all_chunks) // 32,
+               "per_rank": [shard.digest_of_digests([c]) for c in all_chunks], "pass_s_rank0": round(digest_s, 3),
+               "definition": "Blake2s-256 over the chunk digests in global instance order; chunk digest = Blake2s-256 over the acvm_batch_digest "
+                             "values of its instances: the same value for every number of ranks and every tile size"}
+
+    # ---- end to end: H2D of the inputs + import + solve + D2H of the return witnesses, tile by tile from host memory (per rank)
+    e2e = None
+    if not args.no_end_to_end:
+        ret = gc.witness_set("return_values")
+        host = np.frombuffer(values, dtype=np.uint8)
+        ph = [0.0, 0.0, 0.0]
+        barrier()
+        e0 = time.perf_counter()
+        for k, start in enumerate(sh.starts):
+            a = time.perf_counter()
+            sh.buf.upload(host[start * row:(start + tile) * row], offset=start * row)  # pageable host memory -> HBM
+            b_ = time.perf_counter()
+            sh.load_tile(k)
+            batch.solve()
+            c = time.perf_counter()
+            if ret:
+                # extract_indices refuses unsolved instances: the edge-case instances of the synthetic batch fail by design
+                res_k = batch.results()
+                if all(res_k[j].status == 0 for j in range(tile)):
+                    batch.extract(ret, 0, tile)
+                else:
+                    batch.witness(ret[-1])
+            d = time.perf_counter()
+            ph[0] += b_ - a
+            ph[1] += c - b_
+            ph[2] += d - c
+        e2e_s = shard.max_over_ranks(time.perf_counter() - e0, dist)
+        e2e = {"value": total / e2e_s, "unit": "witnesses/s", "total_ms": e2e_s * 1e3, "h2d_ms_rank0": ph[0] * 1e3, "solve_ms_rank0": ph[1] * 1e3,
+               "d2h_return_ms_rank0": ph[2] * 1e3, "input_bytes_per_witness": row, "return_witnesses": len(ret),
+               "note": "pageable host buffers over PCIe, one tile at a time, nothing overlapped; `value` of the line keeps inputs resident"}
+
+    # ---- CPU baseline + parity on a bounded sample of tile 0 (rank 0 only)
+    cpu = parity = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import binding as ob
         cores = os.cpu_count() or 1
         threads = min(cores, 64)
-        per = {"arith": 24, "hash": 1024, "grumpkin": 256, "arith_pedersen": 16, "mixed": 16}[args.workload]  # a few seconds of all host cores
-        sample = args.cpu_sample or min(B, max(64, per * threads))
+        per = {"arith": 96, "hash": 1024, "grumpkin": 256, "arith_pedersen": 48, "mixed": 32}[args.workload]  # a few seconds of all host cores
+        sample = args.cpu_sample or min(tile, max(64, per * threads))
+        sh.load_tile(0)
+        batch.solve()
+        results0 = batch.results()
         oc = ob.Circuit(data)
-        sample_vals = values[: sample * len(ids) * 32]
+        sample_vals = values[: sample * row]
         c0 = time.perf_counter()
-        ores, oasg, ovals = ob.solve_batch(oc, ids, sample_vals, sample, want_witness=True, n_threads=threads)
+        ores, oasg, ovals = ob.solve_batch(oc, ids, sample_vals, sample, want_witness=True, n_threads=threads, mode=ob.MODE_CACHE_INV)
         cpu_s = time.perf_counter() - c0
         gasg, gvals = batch.witness_map(0, sample)
-        ok = all(results[j].as_tuple() == ores[j].as_tuple() for j in range(sample))
+        ok = all(results0[j].as_tuple() == ores[j].as_tuple() for j in range(sample))
         ok = ok and bool(np.array_equal(gasg, oasg[:, : gasg.shape[1]])) and bool(np.array_equal(gvals, ovals[:, : gvals.shape[1]]))
-        parity = {"checked_instances": sample, "bit_exact": ok}
-        cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "kind": "port",
-               "sample": f"{sample} instances of the same circuit, oracle/liboracle.so, {threads} threads, {cpu_s:.2f} s"}
-        # SURVEY 8d asks for one core as well: a few seconds of the same oracle on one thread
+        n_dig = min(sample, 16)
+        if not args.no_digest:  # the digests that feed the digest of digests, against hashlib over the oracle's maps
+            ok = ok and all(bytes(inst_digests[j]) == ob.witness_map_digest(oasg[j], ovals[j]) for j in range(n_dig))
+        parity = {"checked_instances": sample, "bit_exact": ok, "digests_checked": 0 if args.no_digest else n_dig}
+        cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "kind": "port", "variant": "cpu_ref_dense_mt",
+               "sample": f"{sample} instances of the same circuit, oracle/liboracle.so (dense witness vector, constant divisors inverted once), "
+                         f"{threads} threads, {cpu_s:.2f} s"}
+        # BASELINE.md section 2: the two single-core variants, a few seconds each
         one = max(1, min(sample, int(round(3.0 * sample / (cpu_s * threads)))))
         c1 = time.perf_counter()
-        ob.solve_batch(oc, ids, values[: one * len(ids) * 32], one, want_witness=False, n_threads=1)
+        ob.solve_batch(oc, ids, values[: one * row], one, want_witness=False, n_threads=1, mode=ob.MODE_CACHE_INV)
         one_s = time.perf_counter() - c1
-        cpu["single_thread"] = {"value": one / one_s, "unit": "witnesses/s", "sample": f"{one} instances, 1 thread, {one_s:.2f} s"}
+        cpu["cpu_ref_dense"] = {"value": one / one_s, "unit": "witnesses/s", "cores": 1, "sample": f"{one} instances, {one_s:.2f} s"}
+        few = max(1, one // 6)
+        c2 = time.perf_counter()
+        ob.solve_batch(oc, ids, values[: few * row], few, want_witness=False, n_threads=1, mode=ob.MODE_SPARSE_MAP)
+        few_s = time.perf_counter() - c2
+        cpu["cpu_ref_faithful"] = {"value": few / few_s, "unit": "witnesses/s", "cores": 1,
+                                   "sample": f"{few} instances, {few_s:.2f} s; BTreeMap-shaped witness map, one field inversion per solved witness (the reference's data structures)"}
         if not ok:
             print(json.dumps({"error": "parity check failed; the measurement is void", "parity": parity}), flush=True)
             raise SystemExit(2)
 
     if rank == 0:
-        total_instances = B * world * args.steps
-        value = total_instances / elapsed
+        value = total * args.steps / elapsed
         # dominant kernel of the workload: the arithmetic level kernel, or the record class that took the most time
-        cand = {"arith_level_kernel": (arith_ms, st["arith_algorithmic_bytes_per_instance"]),
-                "inverse_batch_kernel": (dyn_ms, st["dyn_algorithmic_bytes_per_instance"])}
+        cand = {"arith_level_kernel": (arith_ms, st["arith_algorithmic_bytes_per_instance"], st["n_arith_launches"]),
+                "inverse_batch_kernel": (dyn_ms, st["dyn_algorithmic_bytes_per_instance"], 0)}
         for k in range(4):
-            cand[CLASS_KERNEL[k]] = (cls_ms[k], st["class_algorithmic_bytes_per_instance"][k])
+            cand[CLASS_KERNEL[k]] = (cls_ms[k], st["class_algorithmic_bytes_per_instance"][k], 0)
         dominant = "arith_level_kernel" if args.workload == "arith" else max(cand, key=lambda k: cand[k][0])
-        k_ms, k_bytes = cand[dominant]
-        achieved = k_bytes * B / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
-        # the committed PMC profile is of the default size of the workload: quote it only for that size
-        default_size = args.gates == 10000 and args.batch_log2 == 16 and args.pedersen == 8
-        tr = load_traffic(args.workload, dominant) if default_size else None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": tr["bytes_per_launch"] if tr else None, "kernel": dominant,
-                "kernel_ms_per_step": k_ms, "algorithmic_bytes_per_step": k_bytes * B,
-                "kernel_timing": f"HIP events around every launch of timed step {args.steps} of {args.steps} (on the launching stream)",
-                "launches_per_step_all_kernels": st["n_kernel_launches"],
-                "other_kernels_ms_per_step": {k: v[0] for k, v in cand.items() if k != dominant and v[0] > 0}}
-        if tr:
-            roof["traffic_source"] = tr.get("source")
-            # the profile ran 3 timed + 1 warm-up solves: launches per solve = launches_profiled / 4
-            per_solve = max(1, tr.get("launches_profiled", 4) // 4)
-            roof["traffic_algorithmic_bytes_per_launch"] = k_bytes * B / per_solve
-            roof["kernel_launches_per_step"] = per_solve
-            roof["kernel_avg_launch_ms"] = k_ms / per_solve
+        k_ms, k_bytes, k_launches = cand[dominant]
+        achieved = k_bytes * tile / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": dominant, "kernel_ms_per_tile": k_ms, "algorithmic_bytes_per_tile": k_bytes * tile,
+                "kernel_timing": f"HIP events around every launch of the last tile of timed step {args.steps} of {args.steps} (on the launching stream)",
+                "launches_per_tile_all_kernels": st["n_kernel_launches"],
+                "other_kernels_ms_per_tile": {k: v[0] for k, v in cand.items() if k != dominant and v[0] > 0}}
+        if k_launches:
+            roof["kernel_launches_per_tile"] = k_launches
+            roof["kernel_avg_launch_ms"] = k_ms / k_launches
+            roof["algorithmic_bytes_per_launch"] = k_bytes * tile / k_launches
+        if world == 1:
+            tr = measure_traffic(args, KERNEL_SYMBOL.get(dominant, dominant))
+            if tr:
+                roof["traffic"] = tr["bytes_per_launch"]
+                roof["traffic_detail"] = tr
         if dominant == "grumpkin_level_kernel":
             roof["note"] = "integer-ALU bound (about 1e3 field multiplications per 128-256 B moved): the HBM fraction is for information"
         line = {
             "metric": "witnesses solved/sec (whole node)",
             "value": value,
             "unit": "witnesses/s",
-            "n_gpus": args.gpus,
+            "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u256 (8x u32 limbs, BN254-Fr Montgomery)",
             "data": "synthetic",
-            "config": {"workload": workload_name, "opcodes": st["n_opcodes"], "instances_per_gpu": B, "levels": st["n_levels"],
-                       "solved_instances_rank0": n_solved, "slow_path_instances_rank0": st["n_slow_instances"],
+            "config": {"workload": f"{workload_name}, batch 2^{total.bit_length() - 1} witnesses over {world} GPU(s)", "opcodes": st["n_opcodes"],
+                       "global_batch": total, "instances_per_gpu": n_rank, "tile_instances": tile, "tiles_per_gpu_per_step": n_tiles, "levels": st["n_levels"],
+                       "not_solved_rank0_all_steps": n_failed, "slow_path_instances_last_tile": st["n_slow_instances"],
                        "algorithmic_bytes_per_witness": st["algorithmic_bytes_per_instance"],
-                       "device_ms_per_step": dev_ms / args.steps, "parallelism": f"instances sharded x{world}, no collectives"},
+                       "device_ms_per_step_rank0": dev_ms, "inputs_resident_setup_s_rank0": round(h2d_resident_s, 3),
+                       "parallelism": f"instances sharded x{world}, no collectives"},
+            "per_rank_witnesses_per_s": rank_rates,
+            "digest_of_digests": dod,
             "roofline": roof,
+            "end_to_end": e2e,
             "cpu_baseline": cpu,
             "parity": parity,
         }
         print(json.dumps(line), flush=True)
+    sh.free()
     if dist is not None:
         dist.destroy_process_group()
 

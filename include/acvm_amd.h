@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ACVM_AMD_ABI_VERSION 1
+#define ACVM_AMD_ABI_VERSION 2
 
 /* library-level error codes */
 enum {
@@ -43,7 +43,8 @@ enum {
     ACVM_E_MALFORMED = -2,   /* circuit bytes do not decode (the reference would panic in bincode::deserialize) */
     ACVM_E_UNSUPPORTED = -3, /* opcode outside the accelerated set -- refused at batch creation */
     ACVM_E_DEVICE = -4,      /* no gfx950 device / HIP runtime error */
-    ACVM_E_STATE = -5        /* call not valid in the current state (reference: panic) */
+    ACVM_E_STATE = -5,       /* call not valid in the current state (reference: panic) */
+    ACVM_E_NOMEM = -6        /* host allocation failed (nothing unwinds through this ABI) */
 };
 
 /* ACVMStatus (acvm/src/pwg/mod.rs:33-51) */
@@ -75,8 +76,14 @@ typedef struct {
 
 /*
  * BlackBoxFunctionSolver (blackbox_solver/src/lib.rs:27-45) as a vtable. Field elements cross as 32-byte
- * canonical big-endian. Return 0 = Ok, 1 = BlackBoxResolutionError::Failed(err text), 2 = Unsupported.
+ * canonical big-endian. Return 0 = Ok, 1 = BlackBoxResolutionError::Failed(err text), 2 = Unsupported, 3 = the
+ * implementation panicked (err text; the instance fails with ACVM_ERR_PANIC -- what StubbedBackend does).
  * A NULL solver selects the built-in HIP implementation of barretenberg's three functions.
+ *
+ * The *_batch members are optional (NULL = call the per-instance function n times): one call serves the n instances of a
+ * batch that reach the opcode. Arrays are instance-major host memory; rc[i] uses the return codes above, err is
+ * [n][err_stride] NUL-terminated texts. They are what a backend that is itself batched (a GPU backend, a thread pool)
+ * implements; the library gathers all instances once, makes ONE call per opcode and scatters the results once.
  */
 typedef struct {
     void *ctx;
@@ -86,7 +93,22 @@ typedef struct {
                     uint8_t y[32], char *err, size_t err_len);
     int (*fixed_base_scalar_mul)(void *ctx, const uint8_t low[32], const uint8_t high[32], uint8_t x[32], uint8_t y[32],
                                  char *err, size_t err_len);
+    /* pk_be32 [n][2][32], sig [n][sig_len], msg [n][msg_len], ok [n] */
+    int (*schnorr_verify_batch)(void *ctx, size_t n, const uint8_t *pk_be32, const uint8_t *sig, size_t sig_len, const uint8_t *msg,
+                                size_t msg_len, uint8_t *ok, uint8_t *rc, char *err, size_t err_stride);
+    /* inputs_be32 [n][n_inputs][32], xy_be32 [n][2][32] */
+    int (*pedersen_batch)(void *ctx, size_t n, const uint8_t *inputs_be32, size_t n_inputs, uint32_t domain_separator, uint8_t *xy_be32,
+                          uint8_t *rc, char *err, size_t err_stride);
+    /* low_high_be32 [n][2][32], xy_be32 [n][2][32] */
+    int (*fixed_base_scalar_mul_batch)(void *ctx, size_t n, const uint8_t *low_high_be32, uint8_t *xy_be32, uint8_t *rc, char *err,
+                                       size_t err_stride);
 } acvm_bb_solver_t;
+
+/* The two fakes of the reference's own tests as ready-made vtables (static storage, never freed):
+ *   acvm_bb_stubbed  StubbedBackend       acvm/tests/solver.rs:20-46      every function panics "Path not trodden by this test"
+ *   acvm_bb_dummy    DummyBlackBoxSolver  brillig_vm/src/lib.rs:392-420   schnorr_verify = true, pedersen = (2, 3), fixed_base = (4, 5) */
+const acvm_bb_solver_t *acvm_bb_stubbed(void);
+const acvm_bb_solver_t *acvm_bb_dummy(void);
 
 typedef struct acvm_circuit acvm_circuit_t;
 typedef struct acvm_batch acvm_batch_t;
@@ -111,7 +133,7 @@ typedef struct {
     uint32_t n_gate_pairs;     /* arithmetic gates that run in their producer's wave and take its output from registers */
     uint32_t n_inverse_slots;  /* rows of the inverse table (denominators of the n_dyn_gates gates, rows reused) */
     uint32_t n_scaled_witnesses; /* witnesses the level kernels keep as scale x value (unscaled on export and for the exact path) */
-    uint32_t reserved0;
+    uint32_t n_arith_launches; /* launches of arith_level_kernel per solve (levels that hold gates) */
 } acvm_stats_t;
 
 const char *acvm_last_error(void);
@@ -154,8 +176,23 @@ void acvm_batch_free(acvm_batch_t *b);
 int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32);
 /* same, from a device-resident buffer of the same layout (no PCIe in the call) */
 int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32);
+/* Device buffers for callers that keep their inputs resident (acvm_batch_set_initial_witness_device): plain hipMalloc / hipFree /
+ * hipMemcpy on the current device, so that a caller needs no HIP headers. */
+void *acvm_device_malloc(size_t bytes);
+int acvm_device_free(void *p);
+int acvm_device_upload(void *dst_device, const void *src_host, size_t bytes);
 /* ACVM::solve for every instance. Returns the number of instances not Solved, or a negative error. */
 int acvm_batch_solve(acvm_batch_t *b);
+/*
+ * ACVM::solve_opcode (acvm/src/pwg/mod.rs:243-303) for the batch: executes ONE opcode -- the one at the smallest instruction
+ * pointer among the instances that are InProgress -- for every InProgress instance standing on it, through the exact in-order
+ * kernels (one lane per instance). Instances only ever differ in their instruction pointer after a foreign call: one that
+ * waited is behind the others once it is resolved, and catches up one call at a time. Starts from a batch whose initial
+ * witness was just set (or acvm_batch_reset); ACVM_E_STATE after a plain acvm_batch_solve. acvm_batch_solve after some steps
+ * runs the rest. Returns the number of instances not Solved; acvm_batch_results gives status and instruction pointer
+ * (InProgress instances report the opcode they stand on).
+ */
+int acvm_batch_solve_opcode(acvm_batch_t *b);
 /* back to the state right after set_initial_witness (same inputs, nothing solved) */
 int acvm_batch_reset(acvm_batch_t *b);
 /* force every instance through the exact in-order kernel instead of the level-parallel one (validation) */
@@ -250,6 +287,51 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
 long long acvm_witness_map_decode(const uint8_t *bytes, size_t len, uint32_t *ids, uint8_t *values_be32, uint32_t cap);
 long long acvm_witness_map_encode(const uint32_t *ids, const uint8_t *values_be32, uint32_t n, uint8_t *out, size_t cap);
 long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8_t *out, size_t cap);
+
+
+/*
+ * The Rust call shape for ONE instance: struct ACVM (acvm/src/pwg/mod.rs:129-143) as a handle over a batch of one,
+ * so that an `impl` of ACVM in Rust forwards method by method.
+ *   acvm_new                      ACVM::new(backend, opcodes, initial_witness)  mod.rs:146-156 (opcodes = the circuit's)
+ *   acvm_solve / acvm_solve_opcode  ACVM::solve :236-241 / ::solve_opcode :243-303; both return the ACVM_STATUS_* reached
+ *   acvm_get_status               the ACVMStatus incl. the OpcodeResolutionError (acvm_result_t)
+ *   acvm_instruction_pointer      :171
+ *   acvm_witness_map              ACVM::witness_map :161: up to cap (index, 32-byte big-endian value) pairs ascending; returns the map's size
+ *   acvm_finalize                 ACVM::finalize :176-181: the same, but ACVM_E_STATE unless the status is Solved (the reference panics)
+ *   acvm_get_pending_foreign_call / acvm_resolve_pending_foreign_call   :203-228, same conventions as the batch calls
+ */
+typedef struct acvm_instance acvm_t;
+acvm_t *acvm_new(const acvm_circuit_t *c, const acvm_bb_solver_t *backend, const uint32_t *initial_ids, const uint8_t *values_be32,
+                 uint32_t n_initial);
+void acvm_free(acvm_t *a);
+int acvm_solve(acvm_t *a);
+int acvm_solve_opcode(acvm_t *a);
+int acvm_get_status(acvm_t *a, acvm_result_t *out);
+uint32_t acvm_instruction_pointer(acvm_t *a);
+long long acvm_witness_map(acvm_t *a, uint32_t *ids, uint8_t *values_be32, uint32_t cap);
+long long acvm_finalize(acvm_t *a, uint32_t *ids, uint8_t *values_be32, uint32_t cap);
+int acvm_get_pending_foreign_call(acvm_t *a, acvm_foreign_call_info_t *info);
+int acvm_pending_foreign_call_inputs(acvm_t *a, uint32_t *lens, uint8_t *values_be32);
+int acvm_resolve_pending_foreign_call(acvm_t *a, uint32_t n_values, const uint8_t *is_array, const uint32_t *lens, const uint8_t *values_be32);
+
+/*
+ * ACVM::new takes ANY WitnessMap (mod.rs:146); acvm_batch_new wants one id set for all instances because the circuit is
+ * levelised against it. acvm_multi_* lifts that: instance i assigns the ids[offsets[i] .. offsets[i + 1]) (values_be32 in the
+ * same order, 32 bytes each); instances with the same id SET share one levelised batch, results come back in the caller's
+ * instance order. Everything else is the batch API with an instance index.
+ */
+typedef struct acvm_multi acvm_multi_t;
+acvm_multi_t *acvm_multi_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances, const uint64_t *offsets /*[n + 1]*/,
+                             const uint32_t *ids, const uint8_t *values_be32);
+void acvm_multi_free(acvm_multi_t *m);
+uint32_t acvm_multi_num_groups(const acvm_multi_t *m);
+int acvm_multi_solve(acvm_multi_t *m); /* number of instances not Solved */
+int acvm_multi_results(acvm_multi_t *m, acvm_result_t *out /*[n_instances]*/);
+/* witness map of one instance: assigned [n_witnesses], values_be32 [n_witnesses][32]; n_witnesses = acvm_multi_num_witnesses */
+uint32_t acvm_multi_num_witnesses(const acvm_multi_t *m);
+int acvm_multi_witness_map(acvm_multi_t *m, uint32_t instance, uint8_t *assigned, uint8_t *values_be32);
+/* the batch handle and the index inside it that serve `instance` (foreign calls, digests, ... go through the batch API) */
+acvm_batch_t *acvm_multi_locate(acvm_multi_t *m, uint32_t instance, uint32_t *index_in_batch);
 
 #ifdef __cplusplus
 }

@@ -104,12 +104,14 @@ typedef struct {
     acvm_result_t *results;
     uint8_t *assigned, *out_values;
     uint32_t nw;
+    int mode;
 } job_t;
 
 static void *job_run(void *p) {
     job_t *j = (job_t *)p;
+    oracle_inv_cache_t *cache = (j->mode & ORACLE_MODE_CACHE_INV) ? oracle_inv_cache_new(j->c) : NULL;
     for (size_t i = j->lo; i < j->hi; i++) {
-        oracle_acvm_t *a = oracle_acvm_new(j->c, j->be, j->n_in, j->ids, j->values + i * j->n_in * 32);
+        oracle_acvm_t *a = oracle_acvm_new_mode(j->c, j->be, j->n_in, j->ids, j->values + i * j->n_in * 32, j->mode, cache);
         oracle_acvm_solve(a);
         if (j->results) j->results[i] = a->res;
         if (j->assigned) {
@@ -127,13 +129,23 @@ static void *job_run(void *p) {
         }
         oracle_acvm_free(a);
     }
+    oracle_inv_cache_free(cache);
     return NULL;
 }
 
 /* values_be32: [B][n_in][32]; results: [B] or NULL; assigned: [B][nw] or NULL; out_values: [B][nw][32] or NULL */
+int oracle_solve_batch_mode(const circuit_t *c, int backend, size_t B, size_t n_in, const uint32_t *ids,
+                            const uint8_t *values_be32, acvm_result_t *results, uint8_t *assigned, uint8_t *out_values,
+                            uint32_t nw, int n_threads, int mode);
 int oracle_solve_batch(const circuit_t *c, int backend, size_t B, size_t n_in, const uint32_t *ids,
                        const uint8_t *values_be32, acvm_result_t *results, uint8_t *assigned, uint8_t *out_values,
                        uint32_t nw, int n_threads) {
+    return oracle_solve_batch_mode(c, backend, B, n_in, ids, values_be32, results, assigned, out_values, nw, n_threads, 0);
+}
+/* mode: ORACLE_MODE_* timing modes of the CPU baseline (pwg.h); results are identical in every mode */
+int oracle_solve_batch_mode(const circuit_t *c, int backend, size_t B, size_t n_in, const uint32_t *ids,
+                            const uint8_t *values_be32, acvm_result_t *results, uint8_t *assigned, uint8_t *out_values,
+                            uint32_t nw, int n_threads, int mode) {
     if (n_threads < 1) n_threads = 1;
     if ((size_t)n_threads > B) n_threads = (int)(B ? B : 1);
     job_t *jobs = (job_t *)calloc((size_t)n_threads, sizeof(job_t));
@@ -144,7 +156,7 @@ int oracle_solve_batch(const circuit_t *c, int backend, size_t B, size_t n_in, c
         j->lo = B * (size_t)t / (size_t)n_threads;
         j->hi = B * (size_t)(t + 1) / (size_t)n_threads;
         j->n_in = n_in; j->ids = ids; j->values = values_be32;
-        j->results = results; j->assigned = assigned; j->out_values = out_values; j->nw = nw;
+        j->results = results; j->assigned = assigned; j->out_values = out_values; j->nw = nw; j->mode = mode;
         if (n_threads == 1) job_run(j);
         else pthread_create(&th[t], NULL, job_run, j);
     }

@@ -67,6 +67,9 @@ def lib():
         L.oracle_solve_batch.restype = C.c_int
         L.oracle_solve_batch.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.oracle_solve_batch_mode.restype = C.c_int
+        L.oracle_solve_batch_mode.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         L.oracle_fr_op.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p]
         L.oracle_fr_num_bits.restype = C.c_uint32
         L.oracle_fr_num_bits.argtypes = [C.c_char_p]
@@ -168,9 +171,14 @@ class ACVM:
             raise RuntimeError("ACVM is not expecting a foreign call response as no call was made")
 
 
+MODE_SPARSE_MAP, MODE_CACHE_INV = 1, 2  # ORACLE_MODE_* of pwg.h: timing modes of the CPU baseline, results identical
+
+
 def solve_batch(circuit: Circuit, ids, values_be: bytes, B: int, want_witness=True, backend=BACKEND_BARRETENBERG,
-                n_threads=1):
-    """values_be: B * len(ids) * 32 bytes, instance-major. Returns (results[B], assigned bytes, values bytes)."""
+                n_threads=1, mode=0):
+    """values_be: B * len(ids) * 32 bytes, instance-major. Returns (results[B], assigned bytes, values bytes).
+    mode: MODE_SPARSE_MAP (every witness access also walks a BTreeMap-shaped tree: the reference's data structure) and / or
+    MODE_CACHE_INV (constant divisors inverted once per circuit and thread instead of once per solved witness)."""
     import numpy as np
     n_in = len(ids)
     nw = circuit.num_witnesses
@@ -182,9 +190,9 @@ def solve_batch(circuit: Circuit, ids, values_be: bytes, B: int, want_witness=Tr
     vals = np.zeros((B, nw, 32), dtype=np.uint8) if want_witness else None
     buf = np.frombuffer(values_be, dtype=np.uint8)
     assert buf.size == B * n_in * 32
-    lib().oracle_solve_batch(circuit._h, backend, B, n_in, arr, buf.ctypes.data, C.cast(res, C.c_void_p),
-                             assigned.ctypes.data if want_witness else None,
-                             vals.ctypes.data if want_witness else None, nw, n_threads)
+    lib().oracle_solve_batch_mode(circuit._h, backend, B, n_in, arr, buf.ctypes.data, C.cast(res, C.c_void_p),
+                                  assigned.ctypes.data if want_witness else None,
+                                  vals.ctypes.data if want_witness else None, nw, n_threads, mode)
     return res, assigned, vals
 
 

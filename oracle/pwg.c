@@ -16,7 +16,10 @@ void pwg_fail(oracle_acvm_t *a, uint32_t err, uint32_t aux0, uint32_t aux1, cons
     if (msg) snprintf(a->res.message, sizeof a->res.message, "%s", msg);
 }
 
-static int known(const oracle_acvm_t *a, uint32_t w) { return w < a->nw && a->assigned[w]; }
+static int known(const oracle_acvm_t *a, uint32_t w) {
+    if (a->index) return oracle_btree_contains(a->index, w); /* WitnessMap::get = BTreeMap::get (witness_map.rs:47-49) */
+    return w < a->nw && a->assigned[w];
+}
 
 /* pwg/mod.rs:338-357 insert_value: insert first, then compare with the displaced value */
 int pwg_insert_value(oracle_acvm_t *a, uint32_t w, const fr_t *v) {
@@ -27,6 +30,7 @@ int pwg_insert_value(oracle_acvm_t *a, uint32_t w, const fr_t *v) {
         memset(a->assigned + a->nw, 0, nn - a->nw);
         a->nw = nn;
     }
+    if (a->index) oracle_btree_insert(a->index, w); /* BTreeMap::insert (witness_map.rs:51-53) */
     if (a->assigned[w]) {
         fr_t old = a->val[w];
         a->val[w] = *v;
@@ -39,6 +43,18 @@ int pwg_insert_value(oracle_acvm_t *a, uint32_t w, const fr_t *v) {
     a->val[w] = *v;
     a->assigned[w] = 1;
     return 0;
+}
+
+/* total / coeff for the constant divisor of opcode a->ip; with ORACLE_MODE_CACHE_INV the inverse is kept per opcode */
+static void div_const(oracle_acvm_t *a, fr_t *out, const fr_t *total, const fr_t *coeff) {
+    oracle_inv_cache_t *k = a->inv_cache;
+    if (!k || a->ip >= a->c->n_opcodes) { fr_div(out, total, coeff); return; }
+    if (!k->have[a->ip] || !fr_eq(&k->coeff[a->ip], coeff)) {
+        k->coeff[a->ip] = *coeff;
+        fr_inverse(&k->inv[a->ip], coeff);
+        k->have[a->ip] = 1;
+    }
+    fr_mul(out, total, &k->inv[a->ip]);
 }
 
 /* pwg/mod.rs:309-317 witness_to_value */
@@ -205,7 +221,7 @@ static int solve_arithmetic(oracle_acvm_t *a, const expr_t *expr) {
         if (fr_is_zero(&f_coeff)) {
             if (!fr_is_zero(&total)) { pwg_fail(a, E_UNSATISFIED, 0, 0, NULL); rc = 1; }
         } else {
-            fr_div(&assignment, &total, &f_coeff);
+            div_const(a, &assignment, &total, &f_coeff); /* a / b = a * inverse(b) (generic_ark.rs:375-381): same value */
             fr_neg(&assignment, &assignment);
             rc = pwg_insert_value(a, f_w, &assignment);
         }
@@ -554,9 +570,27 @@ static int solve_memory_op(oracle_acvm_t *a, const opcode_t *o) { /* :62-124 */
 }
 
 /* ------------------------------------------------------------------ ACVM */
+oracle_inv_cache_t *oracle_inv_cache_new(const circuit_t *c) {
+    oracle_inv_cache_t *k = (oracle_inv_cache_t *)calloc(1, sizeof *k);
+    k->coeff = (fr_t *)calloc(c->n_opcodes + 1, sizeof(fr_t));
+    k->inv = (fr_t *)calloc(c->n_opcodes + 1, sizeof(fr_t));
+    k->have = (uint8_t *)calloc(c->n_opcodes + 1, 1);
+    return k;
+}
+void oracle_inv_cache_free(oracle_inv_cache_t *k) {
+    if (!k) return;
+    free(k->coeff); free(k->inv); free(k->have); free(k);
+}
 oracle_acvm_t *oracle_acvm_new(const circuit_t *c, const backend_t *backend, size_t n_initial,
                                const uint32_t *ids, const uint8_t *values_be32) {
+    return oracle_acvm_new_mode(c, backend, n_initial, ids, values_be32, 0, NULL);
+}
+oracle_acvm_t *oracle_acvm_new_mode(const circuit_t *c, const backend_t *backend, size_t n_initial, const uint32_t *ids,
+                                    const uint8_t *values_be32, int mode, oracle_inv_cache_t *cache) {
     oracle_acvm_t *a = (oracle_acvm_t *)calloc(1, sizeof *a);
+    a->mode = mode;
+    a->index = (mode & ORACLE_MODE_SPARSE_MAP) ? oracle_btree_new() : NULL;
+    a->inv_cache = (mode & ORACLE_MODE_CACHE_INV) ? cache : NULL;
     a->c = c;
     a->backend = backend ? backend : oracle_backend(0);
     uint32_t nw = c->max_witness + 1;
@@ -568,6 +602,7 @@ oracle_acvm_t *oracle_acvm_new(const circuit_t *c, const backend_t *backend, siz
     for (size_t i = 0; i < n_initial; i++) {
         fr_from_be_bytes_reduce(&a->val[ids[i]], values_be32 + 32 * i, 32);
         a->assigned[ids[i]] = 1;
+        if (a->index) oracle_btree_insert(a->index, ids[i]);
     }
     a->res.status = c->n_opcodes == 0 ? ST_SOLVED : ST_IN_PROGRESS; /* pwg/mod.rs:147 */
     a->extra_fc = (fc_result_t **)calloc(c->n_opcodes + 1, sizeof(fc_result_t *));
@@ -597,6 +632,7 @@ void oracle_acvm_free(oracle_acvm_t *a) {
     free(a->extra_fc); free(a->n_extra_fc);
     free_pending(a);
     free(a->val); free(a->assigned);
+    oracle_btree_free(a->index);
     free(a);
 }
 

@@ -66,9 +66,30 @@ typedef struct {
     fr_t **inputs; size_t *input_len; size_t n_inputs;
 } foreign_call_wait_t;
 
+/* btree.c: ordered u32 set shaped like Rust's BTreeMap nodes (the sparse-map cost model of the faithful CPU baseline) */
+typedef struct oracle_btree oracle_btree_t;
+oracle_btree_t *oracle_btree_new(void);
+void oracle_btree_free(oracle_btree_t *t);
+int oracle_btree_contains(const oracle_btree_t *t, uint32_t k);
+int oracle_btree_insert(oracle_btree_t *t, uint32_t k);
+size_t oracle_btree_len(const oracle_btree_t *t);
+
+/* timing modes of the CPU baseline; results are bit-identical in every mode:
+ *   ORACLE_MODE_SPARSE_MAP  every witness lookup / insert also descends a BTreeMap-shaped tree (cpu_ref_faithful)
+ *   ORACLE_MODE_CACHE_INV   -1/coeff of an Arithmetic opcode's constant divisor is computed once per circuit and host thread
+ *                           instead of once per solved witness (cpu_ref_dense: "best reasonable CPU") */
+enum { ORACLE_MODE_SPARSE_MAP = 1, ORACLE_MODE_CACHE_INV = 2 };
+typedef struct {
+    fr_t *coeff, *inv; /* per opcode: the divisor last seen and its inverse */
+    uint8_t *have;
+} oracle_inv_cache_t;
+
 typedef struct {
     const circuit_t *c;
     const backend_t *backend;
+    int mode;
+    oracle_btree_t *index;          /* ORACLE_MODE_SPARSE_MAP: the assigned witness ids */
+    oracle_inv_cache_t *inv_cache;  /* ORACLE_MODE_CACHE_INV: shared by the instances of one host thread (not owned) */
     uint32_t nw;
     fr_t *val;
     uint8_t *assigned;
@@ -83,6 +104,11 @@ typedef struct {
 /* ACVM::new (pwg/mod.rs:146-156). values_be32: n_initial x 32 bytes big-endian, reduced mod p. */
 oracle_acvm_t *oracle_acvm_new(const circuit_t *c, const backend_t *backend, size_t n_initial,
                                const uint32_t *ids, const uint8_t *values_be32);
+/* same with a timing mode; cache may be NULL unless ORACLE_MODE_CACHE_INV is set */
+oracle_acvm_t *oracle_acvm_new_mode(const circuit_t *c, const backend_t *backend, size_t n_initial, const uint32_t *ids,
+                                    const uint8_t *values_be32, int mode, oracle_inv_cache_t *cache);
+oracle_inv_cache_t *oracle_inv_cache_new(const circuit_t *c);
+void oracle_inv_cache_free(oracle_inv_cache_t *k);
 void oracle_acvm_free(oracle_acvm_t *a);
 /* ACVM::solve (pwg/mod.rs:236-241), ACVM::solve_opcode (:243-303) */
 uint32_t oracle_acvm_solve(oracle_acvm_t *a);

@@ -11,6 +11,7 @@
  * (tests/test_oracle_sorting.py).
  */
 #include "pwg.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -142,19 +143,32 @@ int oracle_solve_permutation_sort(oracle_acvm_t *a, const directive_t *d) {
                 int cmp = 0;
                 for (size_t s = 0; s < d->n_sort_by && !cmp; s++) {
                     uint32_t col = d->sort_by[s];
-                    if (col > tuple) { cmp = 0; continue; } /* column `tuple` is the index itself */
+                    /* a[*i as usize] on a Vec of tuple + 1 elements (mod.rs:102-105) panics once the comparator reaches a column
+                     * beyond it: with the bad column FIRST in sort_by that is the first comparison of any sort of n >= 2 elements
+                     * (the case the tests pin); behind other columns it needs a compared pair that ties on all of them, and which
+                     * pairs Rust's sort compares is its implementation's business -- here it is this insertion sort's pairs. */
+                    if (col > tuple) {
+                        char msg[96];
+                        snprintf(msg, sizeof msg, "index out of bounds: the len is %u but the index is %u", (unsigned)(tuple + 1), (unsigned)col);
+                        pwg_fail(a, E_PANIC, 0, 0, msg);
+                        rc = 1;
+                        break;
+                    }
                     uint64_t x[4], y[4];
-                    if (col == tuple) { cmp = (order[j - 1] > cur) - (order[j - 1] < cur); continue; }
+                    if (col == tuple) /* column `tuple` is the index itself */ { cmp = (order[j - 1] > cur) - (order[j - 1] < cur); continue; }
                     fr_to_canonical(&vals[order[j - 1] * tuple + col], x);
                     fr_to_canonical(&vals[cur * tuple + col], y);
                     for (int k = 3; k >= 0 && !cmp; k--) cmp = (x[k] > y[k]) - (x[k] < y[k]);
                 }
-                if (cmp <= 0) break;
+                if (rc || cmp <= 0) break;
                 order[j] = order[j - 1];
                 j--;
             }
+            if (rc) break;
             order[j] = cur;
         }
+    }
+    if (!rc) {
         uint8_t *bits = (uint8_t *)calloc(n * 32 + 8, 1);
         size_t nb = 0;
         route(base, order, (uint32_t)n, (uint32_t)n + 1, bits, &nb);

@@ -54,3 +54,15 @@ def test_sort_inside_a_circuit(oracle):
     rows = [[r.randrange(P) for _ in range(n)] for _ in range(40)]
     rows[0] = [0] * n
     both_paths(oracle, circ, list(range(1, n + 1)), rows)
+
+
+def test_sort_column_beyond_the_tuple_panics(oracle):
+    """a[*i as usize] (directives/mod.rs:102-105) with sort_by = [tuple + 1]: the reference panics on the first comparison; n == 1
+    never compares and solves"""
+    w = E.from_witness
+    circ = Circuit(8, [PermutationSort([[w(1)], [w(2)], [w(3)]], 1, [4, 5, 6], [2])])
+    ores, _ = both_paths(oracle, circ, [1, 2, 3], [[3, 2, 1], [1, 1, 1], [0, 5, P - 1]])  # (both_paths compares the message texts too)
+    assert all(r.err == 8 and r.message == b"index out of bounds: the len is 2 but the index is 2" for r in ores)
+    one = Circuit(3, [PermutationSort([[w(1)]], 1, [], [5])])
+    ores, _ = both_paths(oracle, one, [1], [[3], [0]])
+    assert all(r.status == 0 for r in ores)

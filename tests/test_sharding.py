@@ -22,3 +22,19 @@ def test_world_size_2_gloo():
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_digest_of_digests_is_independent_of_the_sharding():
+    """what bench.py's ranks compute: chunk digests per shard, concatenated in rank order = the chunk digests of the whole batch"""
+    import numpy as np
+    from acvm_amd import shard
+    rng = np.random.default_rng(7)
+    d = rng.integers(0, 256, size=(4 * shard.DIGEST_CHUNK, 32), dtype=np.uint8)
+    whole = shard.digest_of_digests(shard.chunk_digests(d))
+    for world in (2, 4):
+        per = d.shape[0] // world
+        parts = [b"".join(shard.chunk_digests(d[r * per:(r + 1) * per])) for r in range(world)]
+        assert shard.digest_of_digests(parts) == whole
+    d2 = d.copy()
+    d2[-1, 0] ^= 1
+    assert shard.digest_of_digests(shard.chunk_digests(d2)) != whole

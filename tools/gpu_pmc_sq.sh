@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/sq_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --inner --total-log2 16 $*"
 cd /tmp
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   name=$(echo $set | tr ' ' '_')
@@ -23,7 +23,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "*", "*counter_collection.csv")):
         k = r["Kernel_Name"].split("(")[0][-40:]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 print("# per-launch averages of the SQ counters (rocprofv3 --pmc, one pass per group of three, kernel-trace only) of")
-print("# `python bench.py --steps 2 --warmup 1 --no-cpu-baseline <args>`; the last column of each pair is the number of launches seen")
+print("# `python bench.py --steps 2 --warmup 1 --inner --total-log2 16 <args>`; the last column of each pair is the number of launches seen")
 for k in sorted(tot):
     if "arith" in k or "level" in k or "inverse" in k:
         c = tot[k]; n = cnt[k]

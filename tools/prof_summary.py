@@ -42,7 +42,7 @@ def read_pmc(path, counter):
 
 def main(d):
     print(f"# source: {d} (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE: three separate runs of")
-    print("#         `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`)")
+    print("#         `python bench.py --steps 3 --warmup 1 --inner --total-log2 16` = one tile of 2^16 instances per step)")
     stats = os.path.join(d, "trace", "trace_kernel_stats.csv")
     print("\n== kernel stats (rocprofv3 --kernel-trace --stats)")
     print(f"{'kernel':36s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")

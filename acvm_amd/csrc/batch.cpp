@@ -75,8 +75,10 @@ struct acvm_batch {
     std::vector<hipEvent_t> ev_pool;
     double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
-    hipStream_t stream_dyn = nullptr, stream_heavy = nullptr;
-    std::vector<hipEvent_t> ev_heavy;  // per level: the heavy-class records of the level have run (stream_heavy)
+    hipStream_t stream_dyn = nullptr, stream_heavy = nullptr, stream_heavy2 = nullptr, stream_heavy3 = nullptr;
+    hipGraphExec_t graph_exec = nullptr;  // the level schedule as one graph (solve_graph)
+    uint32_t graph_launches = 0;
+    std::vector<hipEvent_t> ev_heavy;  // per level 4 events: [4L] the heavy batch of the level has run (stream_heavy); [4L+1..3] fork / joins of its side lanes
     std::vector<hipEvent_t> ev_sync;
     uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_unscale_plain = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
     Unscale unscale{};
@@ -114,7 +116,10 @@ struct acvm_batch {
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
         for (auto e : ev_heavy) hipEventDestroy(e);
+        if (graph_exec) hipGraphExecDestroy(graph_exec);
         if (stream_heavy) hipStreamDestroy(stream_heavy);
+        if (stream_heavy2) hipStreamDestroy(stream_heavy2);
+        if (stream_heavy3) hipStreamDestroy(stream_heavy3);
         if (d_inv) hipFree(d_inv);
         for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_unscale_plain, (void *)d_scaled_ids})
             if (p) hipFree(p);
@@ -286,6 +291,8 @@ static int batch_init(acvm_batch *b) {
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&b->stream_dyn, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&b->stream_heavy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&b->stream_heavy2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&b->stream_heavy3, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&b->ev_start));
     HIPCHK(hipEventCreate(&b->ev_end));
     const Plan &p = b->plan;
@@ -824,6 +831,198 @@ int acvm_batch_solve_opcode(acvm_batch_t *b) try {
     return solve_stepping(b, true);
 } ABI_CATCH
 
+// per-launch HIP-event pairs of one solve (profiling on)
+struct LaunchTimers {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> reg_pairs, dyn_pairs, cls_pairs[N_CLS];
+    size_t ev_used = 0;
+};
+
+// The level schedule of one solve, enqueued on the batch's streams: the gate levels and the light records on the main stream,
+// the inversion batches on a second one, the heavy record classes on the heavy stream(s). Called directly, or under stream
+// capture (solve_graph: the launches and their cross-stream dependencies become ONE hipGraph that later solves replay).
+static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
+    const Plan &p = b->plan;
+    hipStream_t s = b->stream;
+    hipStream_t s2 = getenv("ACVM_NO_OVERLAP") ? b->stream : b->stream_dyn;  // measurement aid: serialise the two level kernels
+    auto next_event = [&]() -> hipEvent_t {
+        if (tm->ev_used == b->ev_pool.size()) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            b->ev_pool.push_back(e);
+        }
+        return b->ev_pool[tm->ev_used++];
+    };
+    const bool prof = tm != nullptr;
+    launch_fill_u32(s, b->d_event, 0xFFFFFFFFu, b->B);
+    // Per level the constant-coefficient gates and the other record classes (stream s) and the gates that need a
+    // per-instance inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of
+    // either stream waits for level L of both.
+    const size_t n_levels = p.n_levels;
+    while (b->ev_sync.size() < 2 * n_levels + 1) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->ev_sync.push_back(e);
+    }
+    // Record classes that are bound by the integer pipe or by latency (hashes, Grumpkin, Pedersen, ECDSA, Brillig) run on the heavy
+    // stream beside the HBM-bound gate levels: the heavy batch of level L (plan.cpp launches them every HEAVY_EPOCH-th level) starts
+    // when level L-1 of the main stream is done, and a later level (or inversion batch) waits for it only if it reads one of its
+    // outputs (plan.level_needs_heavy; the planner puts those readers HEAVY_LATENCY levels behind the batch).
+    auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA; };
+    // (measured, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms; a circuit of heavy records
+    // only gains nothing from a second queue -- config 4 4.3 -> 4.6 ms -- and keeps everything on one stream)
+    bool any_heavy = false, any_main = !p.gate_offset.empty() || !p.cls_offset[CLS_LIGHT].empty();
+    for (int k = 0; k < (int)N_CLS; k++) any_heavy |= heavy_cls(k) && !p.cls_offset[k].empty();
+    hipStream_t s3 = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || !any_main ? s : b->stream_heavy;
+    // the classes of one heavy batch beside each other: Pedersen | Brillig | everything else, joined again on s3 (the batches
+    // themselves stay in order). Each is latency-bound at small tiles: the batch takes the longest class, not the sum.
+    const bool split_heavy = s3 != s && !getenv("ACVM_NO_HEAVY_SPLIT");
+    auto heavy_lane = [](int k) { return k == CLS_PEDERSEN ? 1 : k == CLS_BRILLIG ? 2 : 0; };
+    while (any_heavy && b->ev_heavy.size() < 4 * n_levels) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->ev_heavy.push_back(e);
+    }
+    bool any_dyn = !p.dyn_offset.empty();
+    const bool any_async = any_dyn || any_heavy;
+    if (any_async) {
+        HIPCHK(hipEventRecord(b->ev_sync[2 * n_levels], s));
+        if (any_dyn) HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
+        if (any_heavy) HIPCHK(hipStreamWaitEvent(s3, b->ev_sync[2 * n_levels], 0));
+    }
+    hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_heavy = nullptr;
+    bool main_dirty = false;  // the main stream has launches behind last_reg
+    uint32_t waited_inverse_level = 0, waited_heavy_level = 0;
+    for (size_t L = 0; L < n_levels; L++) {
+        uint32_t n = p.level_start[L + 1] - p.level_start[L];
+        uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
+        bool s_work = n != 0, h_work = false;
+        bool lane_used[3] = {false, false, false};
+        for (int k = 0; k < (int)N_CLS; k++) {
+            (heavy_cls(k) ? h_work : s_work) |= !b->cls_chunks[k][L].empty();
+            if (heavy_cls(k) && !b->cls_chunks[k][L].empty()) lane_used[heavy_lane(k)] = true;
+        }
+        // "levels < L of the main stream are done": recorded only where another stream is about to wait for it (an event
+        // between two gate launches costs more than the launch gap itself)
+        if ((nd || h_work) && main_dirty) {
+            HIPCHK(hipEventRecord(b->ev_sync[2 * L], s));
+            last_reg = b->ev_sync[2 * L];
+            main_dirty = false;
+        }
+        hipEvent_t prev_reg = last_reg;
+        // the level waits for an inversion batch only if one of its gates reads that batch's rows (the planner put those
+        // gates after the batch, usually several levels after): the batch runs beside all the levels in between
+        const uint32_t need = p.level_needs_inverse[L + 1];  // 1-based inversion level, 0 = none
+        if (s_work && need > waited_inverse_level) {
+            HIPCHK(hipStreamWaitEvent(s, b->ev_sync[2 * (need - 1) + 1], 0));
+            waited_inverse_level = need;
+        }
+        const uint32_t need_h = p.level_needs_heavy[L + 1];  // 1-based level of heavy records, 0 = none
+        if (s_work && need_h > waited_heavy_level) {
+            HIPCHK(hipStreamWaitEvent(s, b->ev_heavy[4 * (need_h - 1)], 0));
+            waited_heavy_level = need_h;
+        }
+        if (n) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (prof) { e0 = next_event(); hipEventRecord(e0, s); }
+            launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event, b->d_inv);
+            if (prof) { e1 = next_event(); hipEventRecord(e1, s); tm->reg_pairs.push_back({e0, e1}); }
+            b->n_launches += (n + 65534) / 65535;
+        }
+        if (h_work && prev_reg) HIPCHK(hipStreamWaitEvent(s3, prev_reg, 0));  // inputs: levels < L of the main stream
+        // fork the side lanes of the heavy batch off s3 (which is in order behind the previous batch)
+        const bool fork = split_heavy && h_work && (int)lane_used[0] + (int)lane_used[1] + (int)lane_used[2] > 1;
+        hipStream_t lane_stream[3] = {s3, fork && lane_used[1] ? b->stream_heavy2 : s3, fork && lane_used[2] ? b->stream_heavy3 : s3};
+        if (fork) {
+            HIPCHK(hipEventRecord(b->ev_heavy[4 * L + 1], s3));
+            for (int q = 1; q < 3; q++)
+                if (lane_stream[q] != s3) HIPCHK(hipStreamWaitEvent(lane_stream[q], b->ev_heavy[4 * L + 1], 0));
+        }
+        for (int k = 0; k < (int)N_CLS; k++)
+            for (const LaunchChunk &ch : b->cls_chunks[k][L]) {
+                hipStream_t sk = heavy_cls(k) ? lane_stream[heavy_lane(k)] : s;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (prof) { e0 = next_event(); hipEventRecord(e0, sk); }
+                const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + ch.first;
+                switch (k) {
+                case CLS_LIGHT: launch_light_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                case CLS_HASH: launch_hash_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                case CLS_GRUMPKIN: launch_grumpkin_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                case CLS_BRILLIG: launch_brillig_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                case CLS_PEDERSEN: launch_pedersen_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                case CLS_ECDSA: launch_ecdsa_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                case CLS_HOSTBB:  // host callbacks: everything launched so far on any stream must have finished
+                    if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
+                    if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
+                    for (uint32_t r = 0; r < ch.count; r++)
+                        if (int rc = run_host_blackbox(b, p.prog[p.cls_offset[k][ch.first + r] + 1], false, 0)) return rc;
+                    break;
+                }
+                if (prof) { e1 = next_event(); hipEventRecord(e1, sk); tm->cls_pairs[k].push_back({e0, e1}); }
+                b->n_launches++;
+            }
+        if (fork)
+            for (int q = 1; q < 3; q++)
+                if (lane_stream[q] != s3) {
+                    HIPCHK(hipEventRecord(b->ev_heavy[4 * L + 1 + q], lane_stream[q]));
+                    HIPCHK(hipStreamWaitEvent(s3, b->ev_heavy[4 * L + 1 + q], 0));
+                }
+        if (h_work) { HIPCHK(hipEventRecord(b->ev_heavy[4 * L], s3)); last_heavy = b->ev_heavy[4 * L]; }
+        main_dirty |= s_work;
+        if (nd) {
+            if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
+            if (p.inv_needs_heavy[L + 1]) HIPCHK(hipStreamWaitEvent(s2, b->ev_heavy[4 * (p.inv_needs_heavy[L + 1] - 1)], 0));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (prof) { e0 = next_event(); hipEventRecord(e0, s2); }
+            launch_inverse_batch(s2, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_event);
+            if (prof) { e1 = next_event(); hipEventRecord(e1, s2); tm->dyn_pairs.push_back({e0, e1}); }
+            b->n_launches++;
+            HIPCHK(hipEventRecord(b->ev_sync[2 * L + 1], s2));
+            last_dyn = b->ev_sync[2 * L + 1];
+        }
+    }
+    if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
+    if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
+    if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
+    return 0;
+}
+
+// The same schedule as ONE hipGraph: captured from the streams at the first solve that qualifies, replayed by every later solve
+// of the batch (tiles of a shard, steps of the bench). A circuit of thousands of small levels is bound by launch and
+// cross-stream event latency, not by its kernels; the graph keeps the dependencies and drops the per-launch host work.
+// the cross-stream events of the schedule exist before anything is enqueued (nothing is created under stream capture)
+static int ensure_level_events(acvm_batch *b) {
+    const size_t n_levels = b->plan.n_levels;
+    while (b->ev_sync.size() < 2 * n_levels + 1 || b->ev_heavy.size() < 4 * n_levels) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        (b->ev_sync.size() < 2 * n_levels + 1 ? b->ev_sync : b->ev_heavy).push_back(e);
+    }
+    return 0;
+}
+static bool graph_eligible(const acvm_batch *b) {
+    if (b->profiling || b->force_slow || !b->plan.cls_offset[CLS_HOSTBB].empty()) return false;
+    if (const char *e = getenv("ACVM_GRAPH")) return atoi(e) != 0;
+    return b->plan.n_levels >= 64;  // a few dozen launches gain nothing
+}
+static int solve_graph(acvm_batch *b) {
+    hipStream_t s = b->stream;
+    if (!b->graph_exec) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_level_schedule(b, nullptr);
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return set_err(ACVM_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) { b->graph_exec = nullptr; return set_err(ACVM_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        b->graph_launches = b->n_launches;
+    }
+    b->n_launches = b->graph_launches;
+    HIPCHK(hipGraphLaunch(b->graph_exec, s));
+    return 0;
+}
+
 int acvm_batch_solve(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
@@ -831,134 +1030,30 @@ int acvm_batch_solve(acvm_batch_t *b) try {
     if (b->solved) return b->stepping ? solve_stepping(b, false) : solve_resume(b);  // only resolved foreign calls can change anything
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
-    hipStream_t s2 = getenv("ACVM_NO_OVERLAP") ? b->stream : b->stream_dyn;  // measurement aid: serialise the two level kernels
     b->n_launches = 0;
     b->host_bb_msg.clear();
     b->arith_kernel_ms = 0;
     b->dyn_kernel_ms = 0;
     b->slow_path_ms = 0;
     for (int k = 0; k < (int)N_CLS; k++) b->cls_kernel_ms[k] = 0;
-    size_t ev_used = 0;
+    LaunchTimers tm;
     auto next_event = [&]() -> hipEvent_t {
-        if (ev_used == b->ev_pool.size()) {
+        if (tm.ev_used == b->ev_pool.size()) {
             hipEvent_t e;
             hipEventCreate(&e);
             b->ev_pool.push_back(e);
         }
-        return b->ev_pool[ev_used++];
+        return b->ev_pool[tm.ev_used++];
     };
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> reg_pairs, dyn_pairs, cls_pairs[N_CLS];
+    if (!b->force_slow)
+        if (int rc = ensure_level_events(b)) return rc;
     HIPCHK(hipEventRecord(b->ev_start, s));
     if (b->force_slow) {
         launch_fill_u32(s, b->d_event, 0u, b->B);
+    } else if (graph_eligible(b)) {
+        if (int rc = solve_graph(b)) return rc;
     } else {
-        launch_fill_u32(s, b->d_event, 0xFFFFFFFFu, b->B);
-        // Per level the constant-coefficient gates and the other record classes (stream s) and the gates that need a
-        // per-instance inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of
-        // either stream waits for level L of both.
-        const size_t n_levels = p.n_levels;
-        while (b->ev_sync.size() < 2 * n_levels + 1) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            b->ev_sync.push_back(e);
-        }
-        // Record classes that are bound by the integer pipe or by latency (hashes, Grumpkin, Pedersen, ECDSA, Brillig) run on a
-        // third stream beside the HBM-bound gate levels: level L's heavy records start when level L-1 of the main stream is done,
-        // and a later level (or inversion batch) waits for them only if it reads one of their outputs (plan.level_needs_heavy).
-        auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA; };
-        // (measured, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms; a circuit of heavy records
-        // only gains nothing from a second queue -- config 4 4.3 -> 4.6 ms -- and keeps everything on one stream)
-        bool any_heavy = false, any_main = !p.gate_offset.empty() || !p.cls_offset[CLS_LIGHT].empty();
-        for (int k = 0; k < (int)N_CLS; k++) any_heavy |= heavy_cls(k) && !p.cls_offset[k].empty();
-        hipStream_t s3 = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || !any_main ? s : b->stream_heavy;
-        while (any_heavy && b->ev_heavy.size() < n_levels) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            b->ev_heavy.push_back(e);
-        }
-        bool any_dyn = !p.dyn_offset.empty();
-        const bool any_async = any_dyn || any_heavy;
-        if (any_async) {
-            HIPCHK(hipEventRecord(b->ev_sync[2 * n_levels], s));
-            if (any_dyn) HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
-            if (any_heavy) HIPCHK(hipStreamWaitEvent(s3, b->ev_sync[2 * n_levels], 0));
-        }
-        hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_heavy = nullptr;
-        bool main_dirty = false;  // the main stream has launches behind last_reg
-        uint32_t waited_inverse_level = 0, waited_heavy_level = 0;
-        for (size_t L = 0; L < n_levels; L++) {
-            uint32_t n = p.level_start[L + 1] - p.level_start[L];
-            uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
-            bool s_work = n != 0, h_work = false;
-            for (int k = 0; k < (int)N_CLS; k++) (heavy_cls(k) ? h_work : s_work) |= !b->cls_chunks[k][L].empty();
-            // "levels < L of the main stream are done": recorded only where another stream is about to wait for it (an event
-            // between two gate launches costs more than the launch gap itself)
-            if ((nd || h_work) && main_dirty) {
-                HIPCHK(hipEventRecord(b->ev_sync[2 * L], s));
-                last_reg = b->ev_sync[2 * L];
-                main_dirty = false;
-            }
-            hipEvent_t prev_reg = last_reg;
-            // the level waits for an inversion batch only if one of its gates reads that batch's rows (the planner put those
-            // gates after the batch, usually several levels after): the batch runs beside all the levels in between
-            const uint32_t need = p.level_needs_inverse[L + 1];  // 1-based inversion level, 0 = none
-            if (s_work && need > waited_inverse_level) {
-                HIPCHK(hipStreamWaitEvent(s, b->ev_sync[2 * (need - 1) + 1], 0));
-                waited_inverse_level = need;
-            }
-            const uint32_t need_h = p.level_needs_heavy[L + 1];  // 1-based level of heavy records, 0 = none
-            if (s_work && need_h > waited_heavy_level) {
-                HIPCHK(hipStreamWaitEvent(s, b->ev_heavy[need_h - 1], 0));
-                waited_heavy_level = need_h;
-            }
-            if (n) {
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s); }
-                launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event, b->d_inv);
-                if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s); reg_pairs.push_back({e0, e1}); }
-                b->n_launches += (n + 65534) / 65535;
-            }
-            if (h_work && prev_reg) HIPCHK(hipStreamWaitEvent(s3, prev_reg, 0));  // inputs: levels < L of the main stream
-            for (int k = 0; k < (int)N_CLS; k++)
-                for (const LaunchChunk &ch : b->cls_chunks[k][L]) {
-                    hipStream_t sk = heavy_cls(k) ? s3 : s;
-                    hipEvent_t e0 = nullptr, e1 = nullptr;
-                    if (b->profiling) { e0 = next_event(); hipEventRecord(e0, sk); }
-                    const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + ch.first;
-                    switch (k) {
-                    case CLS_LIGHT: launch_light_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                    case CLS_HASH: launch_hash_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                    case CLS_GRUMPKIN: launch_grumpkin_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                    case CLS_BRILLIG: launch_brillig_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                    case CLS_PEDERSEN: launch_pedersen_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                    case CLS_ECDSA: launch_ecdsa_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                    case CLS_HOSTBB:  // host callbacks: everything launched so far on any stream must have finished
-                        if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
-                        if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
-                        for (uint32_t r = 0; r < ch.count; r++)
-                            if (int rc = run_host_blackbox(b, p.prog[p.cls_offset[k][ch.first + r] + 1], false, 0)) return rc;
-                        break;
-                    }
-                    if (b->profiling) { e1 = next_event(); hipEventRecord(e1, sk); cls_pairs[k].push_back({e0, e1}); }
-                    b->n_launches++;
-                }
-            if (h_work) { HIPCHK(hipEventRecord(b->ev_heavy[L], s3)); last_heavy = b->ev_heavy[L]; }
-            main_dirty |= s_work;
-            if (nd) {
-                if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
-                if (p.inv_needs_heavy[L + 1]) HIPCHK(hipStreamWaitEvent(s2, b->ev_heavy[p.inv_needs_heavy[L + 1] - 1], 0));
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (b->profiling) { e0 = next_event(); hipEventRecord(e0, s2); }
-                launch_inverse_batch(s2, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_event);
-                if (b->profiling) { e1 = next_event(); hipEventRecord(e1, s2); dyn_pairs.push_back({e0, e1}); }
-                b->n_launches++;
-                HIPCHK(hipEventRecord(b->ev_sync[2 * L + 1], s2));
-                last_dyn = b->ev_sync[2 * L + 1];
-            }
-        }
-        if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
-        if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
-        if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
+        if (int rc = enqueue_level_schedule(b, b->profiling ? &tm : nullptr)) return rc;
     }
     HIPCHK(hipGetLastError());
     if (b->B) HIPCHK(hipMemcpyAsync(b->h_event.data(), b->d_event, (size_t)b->B * 4, hipMemcpyDeviceToHost, s));
@@ -1008,9 +1103,9 @@ int acvm_batch_solve(acvm_batch_t *b) try {
         }
         return total;
     };
-    b->arith_kernel_ms = sum_pairs(reg_pairs);
-    b->dyn_kernel_ms = sum_pairs(dyn_pairs);
-    for (int k = 0; k < (int)N_CLS; k++) b->cls_kernel_ms[k] = sum_pairs(cls_pairs[k]);
+    b->arith_kernel_ms = sum_pairs(tm.reg_pairs);
+    b->dyn_kernel_ms = sum_pairs(tm.dyn_pairs);
+    for (int k = 0; k < (int)N_CLS; k++) b->cls_kernel_ms[k] = sum_pairs(tm.cls_pairs[k]);
     if (n_slow) {
         float t = 0;
         hipEventElapsedTime(&t, slow0, slow1);
@@ -1409,14 +1504,44 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
             snprintf(text, sizeof text, "Failed to extract witness %u from witness map. Witness not found. (instance %u)", witnesses[k], first);
             return set_err(ACVM_E_STATE, text);
         }
-    std::vector<uint8_t> assigned((size_t)n * nw);
-    if (int rc = fetch_assigned(b, first, n, assigned.data())) return rc;
-    for (uint32_t i = 0; i < n; i++)
-        for (uint32_t k = 0; k < n_witnesses; k++)
-            if (!assigned[(size_t)i * nw + witnesses[k]]) {
-                snprintf(text, sizeof text, "Failed to extract witness %u from witness map. Witness not found. (instance %u)", witnesses[k], first + i);
-                return set_err(ACVM_E_STATE, text);
+    // assigned? An instance the level kernels solved has exactly the planner's set (producer[]); an instance of the exact path
+    // has its bitmap. Only the listed witnesses are looked at: O(n + n_slow x n_witnesses), not O(n x all witnesses).
+    {
+        const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+        uint32_t first_fast = 0xFFFFFFFFu;  // first instance of the range that is not an exact lane
+        std::vector<uint32_t> lanes;        // exact lanes of the range
+        for (uint32_t i = 0; i < n; i++) {
+            const int32_t si = b->slow_index[first + i];
+            if (si >= 0) lanes.push_back((uint32_t)si);
+            else if (first_fast == 0xFFFFFFFFu) first_fast = first + i;
+        }
+        uint32_t bad_w = 0, bad_j = 0xFFFFFFFFu;
+        std::vector<uint32_t> word(n_slow);
+        for (uint32_t k = 0; k < n_witnesses; k++) {
+            const uint32_t w = witnesses[k];
+            if (first_fast != 0xFFFFFFFFu && b->plan.producer[w] == 0xFFFFFFFFu && first_fast < bad_j) { bad_j = first_fast; bad_w = w; }
+            if (!lanes.empty()) {
+                HIPCHK(hipMemcpy(word.data(), b->d_assigned + (size_t)(w >> 5) * n_slow, (size_t)n_slow * 4, hipMemcpyDeviceToHost));
+                for (uint32_t t : lanes)
+                    if (!((word[t] >> (w & 31)) & 1u) && b->slow_ids[t] < bad_j) { bad_j = b->slow_ids[t]; bad_w = w; }
             }
+        }
+        if (bad_j != 0xFFFFFFFFu) {
+            for (uint32_t k = 0; k < n_witnesses; k++) {  // the first missing witness of that instance, in the caller's order
+                const uint32_t w = witnesses[k];
+                const int32_t si = b->slow_index[bad_j];
+                bool have = si < 0 ? b->plan.producer[w] != 0xFFFFFFFFu : true;
+                if (si >= 0) {
+                    uint32_t bits = 0;
+                    HIPCHK(hipMemcpy(&bits, b->d_assigned + (size_t)(w >> 5) * n_slow + si, 4, hipMemcpyDeviceToHost));
+                    have = (bits >> (w & 31)) & 1u;
+                }
+                if (!have) { bad_w = w; break; }
+            }
+            snprintf(text, sizeof text, "Failed to extract witness %u from witness map. Witness not found. (instance %u)", bad_w, bad_j);
+            return set_err(ACVM_E_STATE, text);
+        }
+    }
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)n_witnesses * 32));
     if (chunk > n) chunk = n;
     const size_t sel_bytes = align256((size_t)n_witnesses * 4);

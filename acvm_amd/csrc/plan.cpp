@@ -115,6 +115,24 @@ static uint32_t inv_epoch() {
     return v;
 }
 
+// Records of the heavy classes (hashes, Grumpkin / Pedersen, ECDSA, Brillig: bound by the integer pipe or by latency) run on their
+// own stream beside the levels of the main stream. Two scheduling rules keep the two streams from stalling each other (measured on
+// the config-5 mix, 250 k opcodes, tile of 4 096 instances: the main queue idled 32 of 57 ms waiting for the heavy records of the
+// level before, and the heavy stream spent its time in launches of one or two latency-bound records):
+//   * EPOCH: heavy records are launched only every HEAVY_EPOCH-th level, all that became ready since the last batch together
+//     (like the inversion batches): fewer, fatter launches;
+//   * LATENCY: the main stream may read the outputs of the heavy batch of level L from level L + HEAVY_LATENCY + 1 on, i.e. the
+//     planner prices a heavy batch at HEAVY_LATENCY levels of main-stream work and puts the consumers behind it instead of
+//     letting the whole level wait. Heavy records that read heavy outputs (same stream, in order) only need a later batch.
+static uint32_t heavy_epoch() {
+    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_EPOCH"); const int x = e ? atoi(e) : 4; return (uint32_t)(x > 0 ? x : 1); }();
+    return v;
+}
+static uint32_t heavy_latency() {
+    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_LATENCY"); const int x = e ? atoi(e) : 4; return (uint32_t)(x >= 0 ? x : 0); }();
+    return v;
+}
+
 // Expression record: [n_mul, n_lin, qc, (coef, l, r) x n_mul, (coef, -1/coef, w) x n_lin]
 void emit_expr(std::vector<uint32_t> &s, ConstPool &pool, const Expr &e) {
     s.push_back((uint32_t)e.mul.size());
@@ -200,7 +218,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     gates.reserve(c.opcodes.size());
 
     // memory blocks: cell ranges of the per-instance memory table + the program-order chain level
-    struct Block { uint32_t base = 0, cap = 0, len = 0, readable = 0, level = 0; bool seen = false; };
+    // level = level of the last write (MemoryInit included), rlevel = latest level of a read since that write: reads of a block
+    // between two writes have no order among themselves and may share a level; a write comes after every earlier access
+    struct Block { uint32_t base = 0, cap = 0, len = 0, readable = 0, level = 0, rlevel = 0; bool seen = false; };
     std::map<uint32_t, Block> blocks;
     for (auto &o : c.opcodes)
         if (o.kind == OP_MEMORY_INIT) {
@@ -515,6 +535,10 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // =========================================================================== generic-instance replay + levels
     // witnesses produced by a record of a heavy class (those run on their own stream, batch.cpp): level of the record, else 0
     std::vector<uint32_t> heavy_level(nw, 0);
+    // hlevel[w]: the level from which the HEAVY stream may read w (level[w] is the main stream's; they differ for the outputs of
+    // heavy records: the heavy stream is in order, the main stream sees them HEAVY_LATENCY levels later)
+    std::vector<uint32_t> hlevel(nw, 0);
+    const uint32_t K_heavy = heavy_epoch(), D_heavy = heavy_latency();
     auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA; };
     std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, heavy level it reads)
     auto assign_out = [&](uint32_t oi, uint32_t lvl, bool heavy) {
@@ -524,15 +548,15 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             if (known[w]) p.prog[slot.first] = 1;  // compare, never overwrite
             else {
                 known[w] = 1;
-                level[w] = lvl;
+                level[w] = hlevel[w] = lvl;
                 p.producer[w] = oi;
-                if (heavy) heavy_level[w] = lvl;
+                if (heavy) { heavy_level[w] = lvl; level[w] = lvl + D_heavy; }
             }
         }
     };
-    auto out_levels = [&](uint32_t oi, uint32_t lvl) {  // an already-assigned output is read (compared)
+    auto out_levels = [&](uint32_t oi, uint32_t lvl, bool heavy) {  // an already-assigned output is read (compared)
         for (auto &slot : out_slots[oi])
-            if (known[slot.second]) lvl = std::max(lvl, level[slot.second]);
+            if (known[slot.second]) lvl = std::max(lvl, heavy ? hlevel[slot.second] : level[slot.second]);
         return lvl;
     };
     // =========================================================================== projective witnesses
@@ -595,8 +619,11 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     for (uint32_t oi = 0; oi < c.opcodes.size() && p.truncated_at == 0xFFFFFFFFu; oi++) {
         const Opcode &o = c.opcodes[oi];
         if (o.kind != OP_ARITHMETIC) {
-            Reads rd(known, level);
+            const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi];
+            const bool rec_heavy = is_heavy(rec_cls);
+            Reads rd(known, rec_heavy ? hlevel : level);
             uint32_t extra_level = 0;
+            int mem_access = 0;  // 1 read, 2 write
             uint64_t bytes_written = out_slots[oi].size();
             switch (o.kind) {
             case OP_BLACKBOX: {
@@ -621,7 +648,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             case OP_MEMORY_INIT: {
                 Block &b = blocks[o.block_id];
                 for (uint32_t w : o.init) rd.witness(w);
-                extra_level = b.level;
+                extra_level = std::max(b.level, b.rlevel);
+                mem_access = 2;
                 bytes_written = o.init.size();
                 break;
             }
@@ -630,7 +658,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 rd.expr(o.mem_operation);
                 rd.expr(o.mem_index);
                 if (o.has_predicate) rd.expr(o.predicate);
-                extra_level = b.level;
                 // read or write is decided by the VALUE of `operation` (memory_op.rs:91); static only if it is a constant
                 uint32_t off = p.prog_offset[oi];
                 const Expr &op = o.mem_operation;
@@ -646,10 +673,14 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     p.prog[off + 7] = v.lin[0].w;
                     out_slots[oi].push_back({off + 8, v.lin[0].w});
                     bytes_written = 1;
+                    extra_level = b.level;
+                    mem_access = 1;
                 } else {
                     rd.expr(o.mem_value);
                     p.prog[off + 6] = 0;
                     bytes_written = 1;
+                    extra_level = std::max(b.level, b.rlevel);
+                    mem_access = 2;
                 }
                 break;
             }
@@ -666,17 +697,18 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
             if (!rd.ok) { p.truncated_at = oi; break; }
             uint32_t lvl = std::max(rd.lvl, extra_level);
-            lvl = out_levels(oi, lvl) + 1;
-            const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi];
-            if (!is_heavy(rec_cls)) {  // a main-stream record: which heavy records does it wait for (compared outputs are reads too)
+            lvl = out_levels(oi, lvl, rec_heavy) + 1;
+            if (rec_heavy) lvl = (lvl + K_heavy - 1) / K_heavy * K_heavy;  // the next heavy batch
+            if (!rec_heavy) {  // a main-stream record: which heavy records does it wait for (compared outputs are reads too)
                 uint32_t h = 0;
                 for (uint32_t w : rd.ws) h = std::max(h, heavy_level[w]);
                 for (auto &slot : out_slots[oi])
                     if (known[slot.second]) h = std::max(h, heavy_level[slot.second]);
                 if (h) heavy_reads.push_back({lvl, h});
             }
-            assign_out(oi, lvl, is_heavy(rec_cls));
-            if (o.kind == OP_MEMORY_INIT || o.kind == OP_MEMORY_OP) blocks[o.block_id].level = lvl;
+            assign_out(oi, lvl, rec_heavy);
+            if (mem_access == 1) blocks[o.block_id].rlevel = std::max(blocks[o.block_id].rlevel, lvl);
+            else if (mem_access == 2) { blocks[o.block_id].level = lvl; blocks[o.block_id].rlevel = 0; }
             uint64_t bytes = 32ull * (rd.distinct() + bytes_written);
             p.algorithmic_bytes += bytes;
             p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
@@ -829,7 +861,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         if (kind == GATE_SOLVE_DYN) p.dyn_algorithmic_bytes += 32;
         if (kind != GATE_ASSERT) {
             known[unk_w] = 1;
-            level[unk_w] = g.level;
+            level[unk_w] = hlevel[unk_w] = g.level;
             p.producer[unk_w] = oi;
             if (have_m) {  // stored = m * value
                 is_scaled[unk_w] = 1;

@@ -297,19 +297,31 @@ def arith_pedersen_circuit(n_gates=10000, n_pedersen=8, n_in=16, seed=0xAC1D0006
     return Circuit(current_witness_index=nw, opcodes=fixed, private_parameters=ids, return_values=[nw]), ids
 
 
-def mixed_circuit(n_gates=2000, n_in=16, seed=0xAC1D0005, heavy=True):
-    """BASELINE config 5 shape at a chosen size: ~94 % arithmetic gates of the config-2 mix, 3 % RANGE / AND / XOR,
-    1 % ToLeRadix / Quotient, 1 % MemoryOp on 4 blocks of 16 cells, 0.5 % stdlib-shaped Brillig (BinaryIntOp then Stop),
-    0.5 % hash / Pedersen black boxes. Every opcode's operands are witnesses solved earlier, outputs are fresh witnesses.
+def mixed_circuit(n_gates=2000, n_in=16, seed=0xAC1D0005, heavy=True, blocks=16, cells=64):
+    """BASELINE config 5 shape at a chosen size: 94 % arithmetic gates of the config-2 mix whose operands are drawn
+    uniformly from ALL witnesses defined so far (outputs of every opcode kind included), 3 % RANGE / AND / XOR, 1 % ToLeRadix(256,
+    4 limbs) / Quotient, 1 % MemoryOp on `blocks` blocks of `cells` cells with a per-instance DYNAMIC index (a witness below
+    `cells`), 0.5 % stdlib-shaped Brillig (BinaryIntOp then Stop), 0.5 % hash / Pedersen black boxes. Every opcode's outputs are
+    fresh witnesses.
+
+    Value classes the generator tracks so that the generic instance stays on the level kernels: `small` (< 2^8: radix digits, hash
+    outputs), `w32` (< 2^32: results of 32-bit logic, the only sources ToLeRadix(256, 4) accepts), `idx` (< cells: AND of a byte with
+    the constant cells - 1), `wide` (inputs and arithmetic outputs that are zero only with negligible odds: the multiplicand of an
+    unknown-in-mul gate comes from here, a zero multiplicand sends an instance to the exact path, arithmetic.rs:217-221).
     Returns (Circuit, input ids)."""
     from .acir import BlackBoxFuncCall as BB, Brillig, FunctionInput as FI, MemoryInit, MemoryOp, QuotientDirective, ToLeRadix
+    assert cells & (cells - 1) == 0 and cells <= 256
     rng = SplitMix64(seed)
     ops = []
     nw = n_in  # witnesses 1..nw are defined
-    small = []  # witnesses known to be < 2^8 (radix digits), usable as memory indices / hash bytes
-    wide = list(range(1, n_in + 1))  # inputs and arithmetic outputs: uniform-looking field elements (zero with negligible odds)
+    small, w32, idx = [], [], []
+    wide = list(range(1, n_in + 1))
+    is_wide = set(wide)
 
-    def pick():
+    def pick():  # any defined witness
+        return 1 + rng.below(nw)
+
+    def pick_wide():
         return wide[rng.below(len(wide))]
 
     def fresh(k=1):
@@ -318,15 +330,21 @@ def mixed_circuit(n_gates=2000, n_in=16, seed=0xAC1D0005, heavy=True):
         nw += k
         return out
 
-    blocks = 4
-    cells = 16
-    for blk in range(blocks):
-        ops.append(MemoryInit(blk, [pick() for _ in range(cells)]))
-    # a first radix decomposition so that small witnesses exist
-    src = pick()
-    d = fresh(32)
-    ops.append(ToLeRadix(Expression.from_witness(src), d, 256))
+    def logic(kind, lhs, rhs, bits):
+        out, = fresh()
+        ops.append(BB(kind, {"lhs": FI(lhs, bits), "rhs": FI(rhs, bits), "output": out}))
+        return out
+
+    # the constant cells - 1 as a witness (a gate without operands), a first 32-bit value, its four bytes, a first index
+    cmask, = fresh()
+    ops.append(Expression([], [(1, cmask)], P - (cells - 1)))
+    w32.append(logic("AND", 1, 2, 32))
+    d = fresh(4)
+    ops.append(ToLeRadix(Expression.from_witness(w32[0]), d, 256))
     small += d
+    idx.append(logic("AND", small[0], cmask, 8))
+    for blk in range(blocks):
+        ops.append(MemoryInit(blk, [pick_wide() for _ in range(cells)]))
     for i in range(n_gates):
         r = rng.below(1000)
         if r < 940:
@@ -336,45 +354,55 @@ def mixed_circuit(n_gates=2000, n_in=16, seed=0xAC1D0005, heavy=True):
             t = rng.below(100)
             if t < 45:
                 e = Expression([(rng.coef(), a, b)], [(rng.coef(), out)], qc)
+                used = (a, b)
             elif t < 75:
                 if a == b:
-                    b = wide[(wide.index(b) + 1) % len(wide)]
+                    b = 1 + (b % (nw - 1))
                 e = Expression([], [(rng.coef(), a), (rng.coef(), b), (rng.coef(), out)], qc)
+                used = (a, b)
             elif t < 95:
                 e = Expression([(rng.coef(), a, b)], [(rng.coef(), c), (rng.coef(), out)], qc)
+                used = (a, b, c)
             else:
-                e = Expression([(rng.coef(), a, out)], [(rng.coef(), c)], qc)
+                a = pick_wide()  # the known multiplicand of the unknown
+                e = Expression([(rng.coef(), a, out)], [(rng.coef(), c)], qc if qc else rng.coef())
+                used = ()
+                qc = 1
             e.mul_terms.sort(key=lambda t: (min(t[1], t[2]), max(t[1], t[2])))
             e.linear_combinations.sort(key=lambda t: t[1])
             ops.append(e)
-            wide.append(out)
+            if qc or all(u in is_wide for u in used):
+                wide.append(out)
+                is_wide.add(out)
         elif r < 970:
-            k = rng.below(3)
+            k = rng.below(4)
             if k == 0:
                 ops.append(BB("RANGE", {"input": FI(small[rng.below(len(small))], 8)}))
+            elif k == 1:  # a memory index: byte AND (cells - 1)
+                idx.append(logic("AND", small[rng.below(len(small))], cmask, 8))
             else:
                 bits = [8, 32, 64, 254][rng.below(4)]
-                lhs, rhs = pick(), pick()
-                out, = fresh()
-                ops.append(BB("AND" if k == 1 else "XOR", {"lhs": FI(lhs, bits), "rhs": FI(rhs, bits), "output": out}))
+                out = logic("AND" if k == 2 else "XOR", pick(), pick(), bits)
+                if bits == 32:
+                    w32.append(out)
+                elif bits == 8:
+                    small.append(out)
         elif r < 980:
             if rng.next() & 1:
-                src = pick()
-                d = fresh(32)
-                ops.append(ToLeRadix(Expression.from_witness(src), d, 256))
+                d = fresh(4)
+                ops.append(ToLeRadix(Expression.from_witness(w32[rng.below(len(w32))]), d, 256))
                 small += d
             else:
-                src = pick()
                 q, rem = fresh(2)
-                ops.append(QuotientDirective(Expression.from_witness(src), Expression.from_witness(small[rng.below(len(small))]), q, rem))
+                ops.append(QuotientDirective(Expression.from_witness(pick()), Expression.from_witness(small[rng.below(len(small))]), q, rem))
         elif r < 990:
             blk = rng.below(blocks)
-            idx = Expression.constant(rng.below(cells))
+            index = Expression.from_witness(idx[rng.below(len(idx))])
             if rng.next() & 1:
                 out, = fresh()
-                ops.append(MemoryOp(blk, Expression.constant(0), idx, Expression.from_witness(out)))
+                ops.append(MemoryOp(blk, Expression.constant(0), index, Expression.from_witness(out)))
             else:
-                ops.append(MemoryOp(blk, Expression.constant(1), idx, Expression.from_witness(pick())))
+                ops.append(MemoryOp(blk, Expression.constant(1), index, Expression.from_witness(pick())))
         elif r < 995:
             op = ["Add", "Sub", "Mul", "UnsignedDiv"][rng.below(4)]
             bits = [32, 64, 127][rng.below(3)]
@@ -387,6 +415,8 @@ def mixed_circuit(n_gates=2000, n_in=16, seed=0xAC1D0005, heavy=True):
             if op == "Sub":  # never underflows: (a mod 2^bits) - ((b + 1) mod 2^bits) wraps inside the VM
                 bc = [("BinaryIntOp", 0, "Sub", bits, 0, 1), ("Stop",)] if bits >= 254 else [("BinaryIntOp", 0, "Add", bits, 0, 1), ("Stop",)]
             ops.append(Brillig(inputs=[Expression.from_witness(lhs), Expression.from_witness(rhs)], outputs=[out], bytecode=bc))
+            if bits == 32:
+                w32.append(out)
         elif heavy:
             k = rng.below(3)
             if k == 0:

@@ -1,0 +1,46 @@
+"""BASELINE config 5 at circuit size in the driver-run suite: the 10^6-opcode mixed circuit of acvm_amd.synth
+(16 memory blocks x 64 cells with per-instance dynamic indices, ToLeRadix(256, 4 limbs), every opcode class), ONE tile of 4 096
+instances through the level kernels (the hipGraph path), per-instance digests of the witness maps, and an audit sample re-solved
+by the CPU oracle: status tuples, return witnesses and digests (hashlib over the oracle's full map) bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import acvm_amd
+from acvm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_million_opcode_tile_against_oracle_audit(oracle):
+    G, tile = 1_000_000, 4096
+    circ, ids = synth.mixed_circuit(G)
+    data = circ.to_bytes()
+    gc = acvm_amd.Circuit(data)
+    assert gc.num_opcodes >= G
+    ret = gc.witness_set("return_values")
+    batch = acvm_amd.Batch(gc, tile, ids)
+    st0 = batch.stats()
+    assert st0["truncated_at"] == 0xFFFFFFFF and st0["n_levels"] >= 64  # the whole circuit is on the level path, as one graph
+    values = synth.witness_batch(tile, seed=0xAC1D0005)
+    batch.set_initial_witness(values)
+    n_bad = batch.solve()
+    res = batch.results()
+    assert n_bad == sum(1 for r in res if r.status != 0) <= 8  # only the edge-case inputs of the synthetic batch may fail
+    dig = batch.digest()
+    # a second solve of the same tile replays the captured graph: same digests
+    batch.reset()
+    batch.solve()
+    assert np.array_equal(dig, batch.digest())
+    picks = [0, 5, 9, 1000, tile - 1]
+    row = len(ids) * 32
+    sub = b"".join(values[j * row:(j + 1) * row] for j in picks)
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, sub, len(picks), n_threads=min(len(picks), os.cpu_count() or 1))
+    for i, j in enumerate(picks):
+        assert res[j].as_tuple() == ores[i].as_tuple(), j
+        assert bytes(dig[j]) == oracle.witness_map_digest(oasg[i], ovals[i]), j
+        if ores[i].status == 0:
+            got = batch.extract(ret, j, 1)[0]
+            assert all(bytes(got[n]) == bytes(ovals[i][w]) for n, w in enumerate(ret)), j
+    batch.free()

@@ -63,6 +63,8 @@ def test_batch_against_oracle(oracle, curve):
              row(be(Q[0]), be(Q[1]), be(1) + be(1), be(c["n"]))]
     rows.append([300 + b for b in rows[0]])  # witnesses above 255: only the last byte of each counts (to_u8_vec)
     circ, ids = ecdsa_circuit(curve)
+    # the panic paths (rows 40..44): status, error kind and opcode are pinned by the call sites of blackbox_solver/src/lib.rs:120-129;
+    # the message TEXT both sides report is UNPINNED (the reference's is k256 / p256's unwrap text)
     ores, _ = both_paths(oracle, circ, ids, rows)
     assert ores[0].status == 0 and ores[40].err == oracle.E_PANIC and ores[44].err == oracle.E_PANIC
 

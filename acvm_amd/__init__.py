@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "acvm_new", "acvm_free", "acvm_solve", "acvm_solve_opcode", "acvm_get_status", "acvm_instruction_pointer", "acvm_witness_map", "acvm_finalize",
     "acvm_get_pending_foreign_call", "acvm_pending_foreign_call_inputs", "acvm_resolve_pending_foreign_call",
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
-    "acvm_multi_witness_map", "acvm_multi_locate",
+    "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate",
 ]
 
 
@@ -251,6 +251,7 @@ def lib():
     L.acvm_witness_map_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
     L.acvm_witness_map_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.acvm_debug_modmul_rate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.acvm_device_malloc.restype = C.c_void_p
     L.acvm_device_malloc.argtypes = [C.c_size_t]
     L.acvm_device_free.argtypes = [C.c_void_p]
@@ -309,6 +310,19 @@ def synchronize():
 
 def selftest(n=1 << 16, seed=1):
     return _check(lib().acvm_selftest(n, seed))
+
+
+def modmul_rate(iters=400, waves_per_simd=8):
+    """(modmul/s, products per launch) of the back-to-back fr29_mul probe: the peak of the ALU roofline"""
+    r, n = C.c_double(), C.c_uint64()
+    _check(lib().acvm_debug_modmul_rate(iters, waves_per_simd, C.byref(r), C.byref(n)))
+    return r.value, n.value
+
+
+def modmul_probe_cus():
+    """compute units the probe's grid is sized by (blocks = CUs x waves_per_simd): products per launch / (256 x waves x iters x 2)"""
+    _, n = modmul_rate(1, 1)
+    return n // 512
 
 
 def device_arch():

@@ -91,11 +91,22 @@ struct acvm_batch {
     std::map<uint32_t, std::string> host_bb_msg;  // per instance: error text of a failing callback
     // Brillig foreign-call round trip (exact lanes only)
     struct FcValue { bool is_array; std::vector<FrH> vals; };
-    struct FcLaneState { uint32_t opcode = 0xFFFFFFFFu; std::vector<std::vector<FcValue>> results; bool resolved_new = false; };
-    std::vector<FcLaneState> fc_lane;
-    uint32_t *d_fc_res_opcode = nullptr, *d_fc_res_desc = nullptr, *d_fc_pend_desc = nullptr;
-    uint4 *d_fc_res_vals = nullptr, *d_fc_pend_vals = nullptr;
-    uint32_t fc_res_desc_words = 0, fc_res_vals_cap = 0, fc_pend_desc_words = 0, fc_pend_vals_cap = 0, fc_lanes_cap = 0;
+    struct FcLaneState { bool resolved_new = false; };
+    std::vector<FcLaneState> fc_lane;  // per exact lane: the host answered its pending call since the last solve
+    // results the host resolved, per Brillig opcode with a ForeignCall (plan.fc_slot_opcode) and per INSTANCE: they accumulate like
+    // Brillig::foreign_call_results (pwg/mod.rs:220-224) and serve the level kernels and the exact kernels alike
+    struct FcSlot {
+        std::map<uint32_t, std::vector<std::vector<FcValue>>> inst;  // instance -> results so far
+        uint32_t desc_words = 0, vals_cap = 0;
+        uint32_t *d_desc = nullptr;
+        uint4 *d_vals = nullptr;
+        bool dirty = false;
+    };
+    std::vector<FcSlot> fc_slots;
+    FcStoreSlot *d_fc_store = nullptr;
+    uint32_t *d_fc_pend_desc = nullptr;
+    uint4 *d_fc_pend_vals = nullptr;
+    uint32_t fc_pend_desc_words = 0, fc_pend_vals_cap = 0, fc_lanes_cap = 0;
     std::vector<uint32_t> h_pend_desc, h_pend_vals;
     bool pend_host_valid = false;
     // grow-only device staging arena of the entry points that move data in or out (no hipMalloc / hipFree per call)
@@ -125,8 +136,11 @@ struct acvm_batch {
             if (p) hipFree(p);
         if (d_ped_seed) hipFree(d_ped_seed);
         if (d_stage) hipFree(d_stage);
-        for (void *p : {(void *)d_fc_res_opcode, (void *)d_fc_res_desc, (void *)d_fc_pend_desc, (void *)d_fc_res_vals, (void *)d_fc_pend_vals})
+        for (void *p : {(void *)d_fc_store, (void *)d_fc_pend_desc, (void *)d_fc_pend_vals})
             if (p) hipFree(p);
+        for (auto &sl : fc_slots)
+            for (void *p : {(void *)sl.d_desc, (void *)sl.d_vals})
+                if (p) hipFree(p);
         if (stream_dyn) hipStreamDestroy(stream_dyn);
         if (ev_start) hipEventDestroy(ev_start);
         if (ev_end) hipEventDestroy(ev_end);
@@ -152,6 +166,12 @@ static int stage_reserve(acvm_batch *b, size_t bytes) {
     return 0;
 }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// forget every resolved result (a new ACVM: set_initial_witness / reset)
+static void clear_fc_store(acvm_batch *b) {
+    for (auto &sl : b->fc_slots)
+        if (!sl.inst.empty()) { sl.inst.clear(); sl.dirty = true; }
+}
+
 
 extern "C" {
 
@@ -206,6 +226,39 @@ int acvm_selftest(uint32_t n, uint64_t seed) {
     HIPCHK(hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost));
     hipFree(d);
     return (int)h;
+}
+
+// Peak of the ALU roofline: back-to-back Montgomery products on every SIMD, `waves_per_simd` chains interleaved.
+int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modmul_per_s, uint64_t *n_modmul) {
+    if (!modmul_per_s || !iters || !waves_per_simd) return set_err(ACVM_E_INVALID, "bad argument");
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    const uint32_t blocks = (uint32_t)prop.multiProcessorCount * waves_per_simd;  // 256 threads = one wave per SIMD of a CU
+    uint32_t *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, (size_t)blocks * 256 * 4));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 4; r++) {  // the first run warms the clocks up
+        hipEventRecord(e0, nullptr);
+        launch_modmul_rate(nullptr, d, blocks, iters);
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r && ms < best) best = ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d);
+    HIPCHK(hipGetLastError());
+    const double n = (double)blocks * 256.0 * iters * 2.0;
+    *modmul_per_s = n / (best * 1e-3);
+    if (n_modmul) *n_modmul = (uint64_t)n;
+    return 0;
 }
 
 // Component probes of the Grumpkin kernels for the parity tests: what = 0 host table point (param = table << 24 | index),
@@ -376,6 +429,13 @@ static int batch_init(acvm_batch *b) {
     b->dp.Mem = b->d_Mem;
     b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr};
     b->dp.ped_seed = nullptr;
+    b->dp.fc_store = nullptr;
+    if (!p.fc_slot_opcode.empty()) {
+        b->fc_slots.resize(p.fc_slot_opcode.size());
+        std::vector<FcStoreSlot> tab(b->fc_slots.size(), FcStoreSlot{nullptr, nullptr});
+        if (int rc = upload(&b->d_fc_store, tab)) return rc;
+        b->dp.fc_store = b->d_fc_store;
+    }
     if (p.needs_grumpkin) {
         // the level schedule's Pedersen kernel reads the 503 MB pair table (one mixed addition per 18 bits of input)
         const bool pairs = !p.cls_offset[CLS_PEDERSEN].empty();
@@ -443,6 +503,7 @@ int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_
     b->inputs_set = true;
     b->solved = false;
     b->stepping = false;
+    clear_fc_store(b);
     return 0;
 } ABI_CATCH
 
@@ -470,6 +531,7 @@ int acvm_batch_reset(acvm_batch_t *b) {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     b->solved = false;
     b->stepping = false;
+    clear_fc_store(b);
     return 0;
 }
 
@@ -487,71 +549,84 @@ static int ensure_slow_capacity(acvm_batch *b, uint32_t n) {
 }
 
 static ExactLanes exact_lanes(acvm_batch *b, uint32_t n_slow) {
-    FcLanes fc{b->d_fc_res_opcode, b->d_fc_res_desc, b->fc_res_desc_words, b->d_fc_res_vals, b->d_fc_pend_desc, b->fc_pend_desc_words,
-               b->d_fc_pend_vals, b->fc_pend_vals_cap};
+    FcLanes fc{b->d_fc_pend_desc, b->fc_pend_desc_words, b->d_fc_pend_vals, b->fc_pend_vals_cap};
     return ExactLanes{b->d_slow_ids, n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res, fc};
 }
 
-// (re)build the device tables of the foreign-call round trip for the current exact lanes: the results the host resolved
-// (FcLanes::res_*) and the buffers a pending call's inputs are written to (FcLanes::pend_*)
+// Foreign-call round trip, device side: the buffers a pending call's inputs are written to (per exact lane, FcLanes::pend_*) and
+// the store of the results the host resolved (per opcode slot and instance, FcStoreSlot): dirty slots are rebuilt and uploaded.
 static int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
     const Plan &p = b->plan;
-    if (!p.has_foreign_calls || !n_slow) return 0;
+    if (!p.has_foreign_calls) return 0;
     b->fc_lane.resize(n_slow);
-    uint32_t desc_words = 1, vals = 1;
-    for (auto &ls : b->fc_lane) {
-        uint32_t dw = 1, nv = 0;
-        for (auto &res : ls.results) {
-            dw += 1 + 2 * (uint32_t)res.size();
-            for (auto &v : res) nv += (uint32_t)v.vals.size();
-        }
-        desc_words = std::max(desc_words, dw);
-        vals = std::max(vals, nv);
-    }
     const uint32_t pend_words = 1 + p.fc_max_inputs, pend_vals = (uint32_t)std::max<uint64_t>(1, p.fc_pending_vals);
-    if (n_slow > b->fc_lanes_cap || desc_words > b->fc_res_desc_words || vals > b->fc_res_vals_cap) {
-        for (void *q : {(void *)b->d_fc_res_opcode, (void *)b->d_fc_res_desc, (void *)b->d_fc_pend_desc, (void *)b->d_fc_res_vals, (void *)b->d_fc_pend_vals})
+    if (n_slow > b->fc_lanes_cap) {
+        for (void *q : {(void *)b->d_fc_pend_desc, (void *)b->d_fc_pend_vals})
             if (q) hipFree(q);
-        b->d_fc_res_opcode = b->d_fc_res_desc = b->d_fc_pend_desc = nullptr;
-        b->d_fc_res_vals = b->d_fc_pend_vals = nullptr;
+        b->d_fc_pend_desc = nullptr;
+        b->d_fc_pend_vals = nullptr;
         b->fc_lanes_cap = n_slow;
-        b->fc_res_desc_words = desc_words + 16;
-        b->fc_res_vals_cap = vals + 64;
         b->fc_pend_desc_words = pend_words;
         b->fc_pend_vals_cap = pend_vals;
-        HIPCHK(hipMalloc((void **)&b->d_fc_res_opcode, (size_t)n_slow * 4));
-        HIPCHK(hipMalloc((void **)&b->d_fc_res_desc, (size_t)b->fc_res_desc_words * n_slow * 4));
-        HIPCHK(hipMalloc((void **)&b->d_fc_res_vals, (size_t)b->fc_res_vals_cap * 2 * n_slow * sizeof(uint4)));
-        HIPCHK(hipMalloc((void **)&b->d_fc_pend_desc, (size_t)b->fc_pend_desc_words * n_slow * 4));
-        HIPCHK(hipMalloc((void **)&b->d_fc_pend_vals, (size_t)b->fc_pend_vals_cap * 2 * n_slow * sizeof(uint4)));
+        HIPCHK(hipMalloc((void **)&b->d_fc_pend_desc, (size_t)pend_words * n_slow * 4));
+        HIPCHK(hipMalloc((void **)&b->d_fc_pend_vals, (size_t)pend_vals * 2 * n_slow * sizeof(uint4)));
     }
-    std::vector<uint32_t> opc(n_slow), desc((size_t)b->fc_res_desc_words * n_slow, 0), vbuf((size_t)b->fc_res_vals_cap * 2 * n_slow * 4, 0);
-    for (uint32_t t = 0; t < n_slow; t++) {
-        const auto &ls = b->fc_lane[t];
-        opc[t] = ls.opcode;
-        uint32_t w = 0, vi = 0;
-        desc[(size_t)(w++) * n_slow + t] = (uint32_t)ls.results.size();
-        for (auto &res : ls.results) {
-            desc[(size_t)(w++) * n_slow + t] = (uint32_t)res.size();
-            for (auto &v : res) {
-                desc[(size_t)(w++) * n_slow + t] = v.is_array ? 1u : 0u;
-                desc[(size_t)(w++) * n_slow + t] = (uint32_t)v.vals.size();
-                for (auto &xh : v.vals) {  // slot vi: halves at (2 vi) * n_slow + t and (2 vi + 1) * n_slow + t, 4 words each
-                    const FrH x = frh::to_device_form(xh);
-                    memcpy(&vbuf[((size_t)(2 * vi) * n_slow + t) * 4], &x.l[0], 16);
-                    memcpy(&vbuf[((size_t)(2 * vi + 1) * n_slow + t) * 4], &x.l[2], 16);
-                    vi++;
+    bool any = false;
+    for (size_t si = 0; si < b->fc_slots.size(); si++) {
+        auto &sl = b->fc_slots[si];
+        if (!sl.dirty) continue;
+        sl.dirty = false;
+        any = true;
+        uint32_t desc_words = 1, vals = 1;
+        for (auto &kv : sl.inst) {
+            uint32_t dw = 1, nv = 0;
+            for (auto &res : kv.second) {
+                dw += 1 + 2 * (uint32_t)res.size();
+                for (auto &v : res) nv += (uint32_t)v.vals.size();
+            }
+            desc_words = std::max(desc_words, dw);
+            vals = std::max(vals, nv);
+        }
+        if (desc_words > sl.desc_words || vals > sl.vals_cap) {
+            for (void *q : {(void *)sl.d_desc, (void *)sl.d_vals})
+                if (q) hipFree(q);
+            sl.d_desc = nullptr;
+            sl.d_vals = nullptr;
+            sl.desc_words = desc_words + 8;
+            sl.vals_cap = vals + 8;
+            HIPCHK(hipMalloc((void **)&sl.d_desc, (size_t)sl.desc_words * b->Bp * 4));
+            HIPCHK(hipMalloc((void **)&sl.d_vals, (size_t)sl.vals_cap * 2 * b->Bp * sizeof(uint4)));
+        }
+        // word w of instance j at desc[w * Bp + j]; value i: halves at (2 i) * Bp + j and (2 i + 1) * Bp + j, 4 words each
+        std::vector<uint32_t> desc((size_t)sl.desc_words * b->Bp, 0), vbuf((size_t)sl.vals_cap * 2 * b->Bp * 4, 0);
+        for (auto &kv : sl.inst) {
+            const uint64_t j = kv.first;
+            uint32_t w = 0, vi = 0;
+            desc[(size_t)(w++) * b->Bp + j] = (uint32_t)kv.second.size();
+            for (auto &res : kv.second) {
+                desc[(size_t)(w++) * b->Bp + j] = (uint32_t)res.size();
+                for (auto &v : res) {
+                    desc[(size_t)(w++) * b->Bp + j] = v.is_array ? 1u : 0u;
+                    desc[(size_t)(w++) * b->Bp + j] = (uint32_t)v.vals.size();
+                    for (auto &xh : v.vals) {
+                        const FrH x = frh::to_device_form(xh);
+                        memcpy(&vbuf[((size_t)(2 * vi) * b->Bp + j) * 4], &x.l[0], 16);
+                        memcpy(&vbuf[((size_t)(2 * vi + 1) * b->Bp + j) * 4], &x.l[2], 16);
+                        vi++;
+                    }
                 }
             }
         }
+        HIPCHK(hipMemcpy(sl.d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sl.d_vals, vbuf.data(), vbuf.size() * 4, hipMemcpyHostToDevice));
     }
-    HIPCHK(hipMemcpyAsync(b->d_fc_res_opcode, opc.data(), opc.size() * 4, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_fc_res_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_fc_res_vals, vbuf.data(), vbuf.size() * 4, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    if (any && b->d_fc_store) {  // the kernels reach the tables through this array: the pointers may have moved
+        std::vector<FcStoreSlot> tab(b->fc_slots.size());
+        for (size_t si = 0; si < tab.size(); si++) tab[si] = FcStoreSlot{b->fc_slots[si].d_desc, b->fc_slots[si].d_vals};
+        HIPCHK(hipMemcpy(b->d_fc_store, tab.data(), tab.size() * sizeof(FcStoreSlot), hipMemcpyHostToDevice));
+    }
     return 0;
 }
-
 // One Pedersen / FixedBaseScalarMul / SchnorrVerify opcode through the caller's BlackBoxFunctionSolver callbacks
 // (blackbox_solver/src/lib.rs:27-45) for the instances of the level schedule (exact == false, all B instances) or for the
 // exact lanes. Inputs leave the device as canonical big-endian bytes, outputs come back the same way. All instances are
@@ -1027,9 +1102,23 @@ int acvm_batch_solve(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
     HIPCHK(hipSetDevice(b->device));
-    if (b->solved) return b->stepping ? solve_stepping(b, false) : solve_resume(b);  // only resolved foreign calls can change anything
     const Plan &p = b->plan;
+    if (b->solved) {  // only resolved foreign calls can change anything
+        if (b->stepping) return solve_stepping(b, false);
+        // A few resumed instances continue on the exact in-order kernels from their Brillig opcode on. When a sizeable part of the
+        // batch was answered (the usual case: every instance reaches the same oracle call), the whole LEVEL schedule runs again
+        // instead: the answers are in the result store, the Brillig level kernel finds them, and the opcodes behind the call
+        // run level-parallel for everybody (instances still waiting, or waiting at the next call, are flagged again there).
+        uint32_t n_resolved = 0;
+        for (uint32_t t = 0; t < b->slow_ids.size() && t < b->fc_lane.size(); t++)
+            n_resolved += b->slow_res[t].status == ACVM_STATUS_REQUIRES_FOREIGN_CALL && b->fc_lane[t].resolved_new;
+        const char *e = getenv("ACVM_FC_RELEVEL");
+        const bool relevel = n_resolved && (e ? atoi(e) != 0 : (uint64_t)n_resolved * 16 >= b->B);
+        if (!relevel) return solve_resume(b);
+        b->solved = false;
+    }
     hipStream_t s = b->stream;
+    if (int rc = upload_fc_tables(b, 0)) return rc;  // the level kernels read the resolved results too
     b->n_launches = 0;
     b->host_bb_msg.clear();
     b->arith_kernel_ms = 0;
@@ -1184,11 +1273,10 @@ int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t
     if (t < 0) return set_err(ACVM_E_STATE, "ACVM is not expecting a foreign call response as no call was made");  // mod.rs:215-217 panics
     auto &ls = b->fc_lane[t];
     const uint32_t opcode = b->slow_res[t].opcode_index;
-    if (ls.opcode != opcode) {  // results accumulate per Brillig opcode (brillig.foreign_call_results.push, mod.rs:223)
-        ls.results.clear();
-        ls.opcode = opcode;
-    }
     if (ls.resolved_new) return set_err(ACVM_E_STATE, "this instance's pending foreign call was already resolved; call acvm_batch_solve");
+    const auto &slots = b->plan.fc_slot_opcode;
+    const size_t si = (size_t)(std::find(slots.begin(), slots.end(), opcode) - slots.begin());
+    if (si >= b->fc_slots.size()) return set_err(ACVM_E_STATE, "the instance does not wait at a Brillig opcode with a foreign call");
     std::vector<acvm_batch::FcValue> res(n_values);
     size_t off = 0;
     for (uint32_t i = 0; i < n_values; i++) {
@@ -1196,7 +1284,9 @@ int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t
         uint32_t n = res[i].is_array ? lens[i] : 1;
         for (uint32_t c = 0; c < n; c++, off++) res[i].vals.push_back(frh::from_be_bytes32_reduce(values_be32 + off * 32, 32));
     }
-    ls.results.push_back(std::move(res));
+    // results accumulate per Brillig opcode and instance (brillig.foreign_call_results.push, mod.rs:223)
+    b->fc_slots[si].inst[instance].push_back(std::move(res));
+    b->fc_slots[si].dirty = true;
     ls.resolved_new = true;
     return 0;
 } ABI_CATCH

@@ -206,6 +206,32 @@ __global__ void __launch_bounds__(256) fr_selftest_kernel(uint64_t seed, uint32_
     if (bad) atomicAdd(mismatches, 1u);
 }
 
+// ------------------------------------------------------------------------------------------ modmul rate probe
+// The ALU roofline of the integer-bound kernels (Grumpkin / Pedersen / ECDSA; SURVEY 8d: "report modmul/s against a measured
+// back-to-back fr_mul microbenchmark peak"): every lane runs a chain of 2 * iters Montgomery products in the 29-bit working form;
+// with several waves per SIMD the chains of different waves interleave and the rate is the part's modmul throughput.
+__global__ void __launch_bounds__(256) modmul_rate_kernel(uint32_t *__restrict__ out, uint32_t seed, uint32_t iters) {
+    Fr29 a, b;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        a.v[i] = ((threadIdx.x + 1) * 2654435761u + seed + i) & 0x1fffffffu;
+        b.v[i] = (a.v[i] ^ 0x5bd1e995u) & 0x1fffffffu;
+    }
+    a.v[8] &= 0xfffffu;
+    b.v[8] &= 0xfffffu;
+    for (uint32_t i = 0; i < iters; i++) {
+        a = fr29_mul(a, b);
+        b = fr29_mul(b, a);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) s += a.v[i] ^ b.v[i];
+    out[(uint64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+void launch_modmul_rate(hipStream_t s, uint32_t *out, uint32_t blocks, uint32_t iters) {
+    hipLaunchKernelGGL(modmul_rate_kernel, dim3(blocks), dim3(256), 0, s, out, 1u, iters);
+}
+
 // ------------------------------------------------------------------------------------------ helpers
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -15,16 +15,17 @@ struct SlowResult {
     uint32_t val[8];       // a canonical field value quoted by the message (Brillig black-box limb checks)
 };
 
-// Brillig foreign-call round trip of the exact lanes (ACVM::get_pending_foreign_call / resolve_pending_foreign_call,
-// pwg/mod.rs:203-228). Results the host resolved for the opcode a lane waits at: descriptor words
-// [n_results, (n_values, (is_array, n) x n_values) x n_results] at res_desc[w * n_slow + t], values at res_vals slot i.
-// Inputs of a pending call: pend_desc [n_inputs, len x n_inputs], values in pend_vals. Both value tables are laid out
-// like W with stride n_slow.
+// Brillig foreign-call round trip (ACVM::get_pending_foreign_call / resolve_pending_foreign_call, pwg/mod.rs:203-228).
+// Results the host resolved live in a batch-wide store, one slot per Brillig opcode that holds a ForeignCall, keyed by the
+// INSTANCE (so the level kernels and the exact kernels read the same tables): descriptor words
+// [n_results, (n_values, (is_array, n) x n_values) x n_results] of instance j at desc[w * Bp + j], values laid out like W.
+struct FcStoreSlot {
+    const uint32_t *desc;  // null: nothing resolved for this opcode yet
+    const uint4 *vals;
+};
+// Inputs of a pending call of the exact lanes: pend_desc [n_inputs, len x n_inputs], values in pend_vals, laid out like W with
+// stride n_slow.
 struct FcLanes {
-    const uint32_t *res_opcode;  // per lane: the opcode its resolved results belong to
-    const uint32_t *res_desc;
-    uint32_t res_desc_words;
-    const uint4 *res_vals;
     uint32_t *pend_desc;
     uint32_t pend_desc_words;
     uint4 *pend_vals;
@@ -50,6 +51,7 @@ struct DeviceProgram {
     uint4 *Mem;                   // per-instance memory blocks, laid out like W
     GrumpkinTables grumpkin;      // device lookup tables (null pointers if the circuit has no Grumpkin opcode)
     const uint32_t *ped_seed;     // per Pedersen record: hash_single(x of hash_pair(IV[domain separator], n), 0), affine, 16 x u32
+    const FcStoreSlot *fc_store;  // device array, one entry per Brillig opcode with a ForeignCall (null: the circuit has none)
 };
 
 // projective witnesses (plan.cpp): device tables behind the export and the hand-over to the exact path
@@ -70,6 +72,7 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv);
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
                           const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event);
+void launch_modmul_rate(hipStream_t s, uint32_t *out, uint32_t blocks, uint32_t iters);
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);

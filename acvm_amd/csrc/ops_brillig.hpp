@@ -292,27 +292,30 @@ static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t 
     }
 }
 
-// [K_BRILLIG, opcode, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap, fc_desc_off, fc_vals_off,
+// [K_BRILLIG, opcode, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap, fc_desc_off, fc_vals_off, fc_slot,
 //  E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
 // ForeignCall (brillig_vm/src/lib.rs:190-274). Results come first from the circuit (Brillig::foreign_call_results), then
-// from what the host resolved for this lane. Without a result the VM stops with status 3 and, on the exact path, hands
-// the resolved inputs to the host (ForeignCallWaitInfo, pwg/brillig.rs:157-163).
+// from what the host resolved for this instance and opcode (the batch-wide store, kernels.hpp FcStoreSlot: level kernels and
+// exact kernels alike). Without a result the VM stops with status 3 and, on the exact path, hands the resolved inputs to the
+// host (ForeignCallWaitInfo, pwg/brillig.rs:157-163).
 static inline __device__ __noinline__ void brillig_foreign_call(BrVm &vm, const uint32_t *__restrict__ ex, const DeviceProgram &dp, uint32_t fc_desc_off,
-                                                                uint32_t fc_vals_off, uint32_t &fc_counter, uint32_t n_bc, uint32_t opcode, const ExactLanes *L, uint32_t t) {
+                                                                uint32_t fc_vals_off, uint32_t &fc_counter, uint32_t n_bc, uint32_t fc_slot, const ExactLanes *L, uint32_t t) {
     const uint32_t n_dests = ex[0], n_in = ex[1];
     const uint32_t *dests = ex + 2, *ins = dests + 3 * n_dests;
-    // locate result number fc_counter: static table first, then the lane's table
+    // locate result number fc_counter: static table first, then the instance's table
     const uint32_t *sdesc = dp.bytecode + fc_desc_off;
     const uint32_t n_static = sdesc[0];
     const bool is_static = fc_counter < n_static;
     const uint32_t n_slow = L ? L->n_slow : 0u;
-    auto desc = [&](uint32_t w) { return is_static ? sdesc[w] : L->fc.res_desc[(uint64_t)w * n_slow + t]; };
-    auto value = [&](uint32_t i) { return is_static ? fr_const(dp.consts, dp.bytecode[fc_vals_off + i]) : fr_load(L->fc.res_vals, i, n_slow, t); };
+    FcStoreSlot st{nullptr, nullptr};
+    if (!is_static && dp.fc_store && fc_slot != K_NONE) st = dp.fc_store[fc_slot];
+    auto desc = [&](uint32_t w) { return is_static ? sdesc[w] : st.desc[(uint64_t)w * vm.Bp + vm.j]; };
+    auto value = [&](uint32_t i) { return is_static ? fr_const(dp.consts, dp.bytecode[fc_vals_off + i]) : fr_load(st.vals, i, vm.Bp, vm.j); };
     uint32_t k = fc_counter;
     bool found = is_static;
     if (!is_static) {
         k -= n_static;
-        found = L && L->fc.res_desc && L->fc.res_opcode[t] == opcode && k < L->fc.res_desc[t];
+        found = st.desc && k < st.desc[vm.j];
     }
     if (!found) {
         vm.status = 3;
@@ -386,7 +389,7 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
                                                const ExactLanes *L, uint32_t t) {
     const uint32_t has_pred = r[2], n_inputs = r[3], n_outputs = r[4], n_bc = r[6];
     const uint32_t *__restrict__ bc = dp.bytecode + r[5];
-    const uint32_t *q = r + 11;
+    const uint32_t *q = r + 12;
     uint32_t fc_counter = 0;
     Fr pred = fr_one();
     if (has_pred) {  // brillig.rs:28-31: get_value error passes through (MissingAssignment)
@@ -499,7 +502,7 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
         case BRO_TRAP: vm.status = 2; vm.code = DM_BRILLIG_TRAP; break;
         case BRO_STOP: vm.status = 1; break;
         case BRO_BLACK_BOX: brillig_black_box(vm, ins[4], dp.bytecode + ins[7], dp.grumpkin); break;
-        case BRO_FOREIGN_CALL: brillig_foreign_call(vm, dp.bytecode + ins[7], dp, r[9], r[10], fc_counter, n_bc, r[1], L, t); break;
+        case BRO_FOREIGN_CALL: brillig_foreign_call(vm, dp.bytecode + ins[7], dp, r[9], r[10], fc_counter, n_bc, r[11], L, t); break;
         default: vm.panic(BP_BAD_OPCODE); break;
         }
         if (vm.status) break;

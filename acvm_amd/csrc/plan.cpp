@@ -116,20 +116,22 @@ static uint32_t inv_epoch() {
 }
 
 // Records of the heavy classes (hashes, Grumpkin / Pedersen, ECDSA, Brillig: bound by the integer pipe or by latency) run on their
-// own stream beside the levels of the main stream. Two scheduling rules keep the two streams from stalling each other (measured on
-// the config-5 mix, 250 k opcodes, tile of 4 096 instances: the main queue idled 32 of 57 ms waiting for the heavy records of the
-// level before, and the heavy stream spent its time in launches of one or two latency-bound records):
-//   * EPOCH: heavy records are launched only every HEAVY_EPOCH-th level, all that became ready since the last batch together
+// own stream beside the levels of the main stream. Two scheduling knobs exist for circuits whose main stream stalls on them:
+//   * ACVM_HEAVY_EPOCH = K: heavy records are launched only every K-th level, all that became ready since the last batch together
 //     (like the inversion batches): fewer, fatter launches;
-//   * LATENCY: the main stream may read the outputs of the heavy batch of level L from level L + HEAVY_LATENCY + 1 on, i.e. the
-//     planner prices a heavy batch at HEAVY_LATENCY levels of main-stream work and puts the consumers behind it instead of
-//     letting the whole level wait. Heavy records that read heavy outputs (same stream, in order) only need a later batch.
+//   * ACVM_HEAVY_LATENCY = D: the main stream may read the outputs of the heavy batch of level L from level L + D + 1 on, i.e. the
+//     planner prices a heavy batch at D levels of main-stream work and puts the consumers behind it instead of letting the whole
+//     level wait. Heavy records that read heavy outputs (same stream, in order) only need a later batch.
+// Measured on the config-5 mix at 250 k opcodes, tile of 4 096 instances (profiles/r02_config5_schedule.txt): when only a few records
+// read heavy outputs (round 1's generator) K = D = 4 takes a tile from 46.5 to 43.5 ms; when every tenth witness is a heavy output
+// and gates read them everywhere (the SURVEY 8d generator) the same setting stretches the DAG from 180 to 529 levels and the tile
+// from 54 to 69 ms. The default is therefore K = 1, D = 0: every record at its earliest level.
 static uint32_t heavy_epoch() {
-    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_EPOCH"); const int x = e ? atoi(e) : 4; return (uint32_t)(x > 0 ? x : 1); }();
+    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_EPOCH"); const int x = e ? atoi(e) : 1; return (uint32_t)(x > 0 ? x : 1); }();
     return v;
 }
 static uint32_t heavy_latency() {
-    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_LATENCY"); const int x = e ? atoi(e) : 4; return (uint32_t)(x >= 0 ? x : 0); }();
+    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_LATENCY"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 0 ? x : 0); }();
     return v;
 }
 
@@ -397,7 +399,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
             case OP_BRILLIG: {
                 // [PK_BRILLIG, oi, has_pred, n_inputs, n_outputs, bc_offset, n_bytecode, n_regs, mem_cap, fc_desc_off, fc_vals_off,
-                //  E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
+                //  fc_slot, E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
                 const BrilligCall &b = *o.brillig;
                 p.prog_class[oi] = CLS_BRILLIG;
                 uint32_t bc_off = (uint32_t)p.bytecode.size();
@@ -504,8 +506,10 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 // scratch: registers + memory cells (8 words each) + call stack (64 words) + byte staging for hashes
                 p.prog_scratch[oi] = (uint32_t)((n_regs + mem_cap) * 8 + 64 + (max_hash_hint ? mem_cap / 4 + 16 : 0));
                 p.fc_pending_vals = std::max<uint64_t>(p.fc_pending_vals, has_foreign ? fc_pending_vals + mem_cap : 0);
+                uint32_t fc_slot = 0xFFFFFFFFu;
+                if (has_foreign) { fc_slot = (uint32_t)p.fc_slot_opcode.size(); p.fc_slot_opcode.push_back(oi); }
                 s.insert(s.end(), {PK_BRILLIG, oi, b.has_predicate ? 1u : 0u, (uint32_t)b.inputs.size(), (uint32_t)b.outputs.size(), bc_off,
-                                   (uint32_t)b.bytecode.size(), n_regs, (uint32_t)mem_cap, fc_desc_off, fc_vals_off});
+                                   (uint32_t)b.bytecode.size(), n_regs, (uint32_t)mem_cap, fc_desc_off, fc_vals_off, fc_slot});
                 if (b.has_predicate) emit_expr(s, pool, b.predicate);
                 for (auto &in : b.inputs) {
                     s.push_back(in.is_array ? 1u : 0u);

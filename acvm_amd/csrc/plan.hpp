@@ -98,6 +98,7 @@ struct Plan {
     // Brillig foreign calls: function name per (opcode << 32 | bytecode index), buffer sizes of the wait / resolve round trip
     bool has_foreign_calls = false;
     std::map<uint64_t, std::string> fc_function;
+    std::vector<uint32_t> fc_slot_opcode;       // per slot of the foreign-call result store: the Brillig opcode (kernels.hpp FcStoreSlot)
     uint32_t fc_max_inputs = 0;
     uint64_t fc_pending_vals = 0;  // field elements one pending call can hand to the host (upper bound)
 };

@@ -352,26 +352,27 @@ def mixed_circuit(n_gates=2000, n_in=16, seed=0xAC1D0005, heavy=True, blocks=16,
             out, = fresh()
             qc = rng.coef() if rng.next() & 1 else 0
             t = rng.below(100)
+            # `terms`: the operand sets of the known terms; the output is zero only by coincidence ("wide") if the constant is a
+            # random field element or some term has only wide operands -- unit coefficients on small operands DO cancel (1 * 1 - 1)
             if t < 45:
                 e = Expression([(rng.coef(), a, b)], [(rng.coef(), out)], qc)
-                used = (a, b)
+                terms = [(a, b)]
             elif t < 75:
                 if a == b:
                     b = 1 + (b % (nw - 1))
                 e = Expression([], [(rng.coef(), a), (rng.coef(), b), (rng.coef(), out)], qc)
-                used = (a, b)
+                terms = [(a,), (b,)]
             elif t < 95:
                 e = Expression([(rng.coef(), a, b)], [(rng.coef(), c), (rng.coef(), out)], qc)
-                used = (a, b, c)
+                terms = [(a, b), (c,)]
             else:
                 a = pick_wide()  # the known multiplicand of the unknown
-                e = Expression([(rng.coef(), a, out)], [(rng.coef(), c)], qc if qc else rng.coef())
-                used = ()
-                qc = 1
+                e = Expression([(rng.coef(), a, out)], [(rng.coef(), c)], qc)
+                terms = [(c,)]
             e.mul_terms.sort(key=lambda t: (min(t[1], t[2]), max(t[1], t[2])))
             e.linear_combinations.sort(key=lambda t: t[1])
             ops.append(e)
-            if qc or all(u in is_wide for u in used):
+            if qc not in (0, 1, P - 1) or any(all(u in is_wide for u in term) for term in terms):
                 wide.append(out)
                 is_wide.add(out)
         elif r < 970:

@@ -92,9 +92,9 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def measure_traffic(args, kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the PMC counters, measured in THIS run: two rocprofv3 passes (FETCH_SIZE,
-    WRITE_SIZE separately, kernel-trace only) over a one-tile run of this script. None if rocprofv3 is missing or fails."""
+def pmc_pass(args, counter):
+    """One rocprofv3 pass (`--pmc <counter> --kernel-trace`, nothing else) over a one-tile run of this script: {kernel symbol: [sum of
+    the counter over its launches, launches]}, or None if rocprofv3 is missing or fails."""
     import csv
     import shutil
     import tempfile
@@ -102,33 +102,51 @@ def measure_traffic(args, kernel_substr):
         return None
     inner = [sys.executable, os.path.abspath(__file__), "--inner", "--workload", args.workload, "--gates", str(args.gates), "--pedersen", str(args.pedersen),
              "--total-log2", str(args.tile_log2), "--tile-log2", str(args.tile_log2), "--steps", "1", "--warmup", "1"]
-    out = {}
     tmp = tempfile.mkdtemp(prefix="acvm_pmc_", dir="/tmp")
+    per = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + inner
-            env = dict(os.environ, TMPDIR="/tmp")
-            env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
-            if r.returncode != 0:
-                return None
-            n, total = 0, 0.0
-            for root, _, files in os.walk(d):
-                for f in files:
-                    if f.endswith("counter_collection.csv"):
-                        with open(os.path.join(root, f)) as fh:
-                            for row in csv.DictReader(fh):
-                                if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
-                                    n += 1
-                                    total += float(row["Counter_Value"])
-            if not n:
-                return None
-            out[counter] = (total / n, n)
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--"] + inner
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return None
+        for root, _, files in os.walk(tmp):
+            for f in files:
+                if f.endswith("counter_collection.csv"):
+                    with open(os.path.join(root, f)) as fh:
+                        for row in csv.DictReader(fh):
+                            if row["Counter_Name"] == counter:
+                                e = per.setdefault(row["Kernel_Name"], [0.0, 0])
+                                e[0] += float(row["Counter_Value"])
+                                e[1] += 1
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return per or None
+
+
+def pick(per, substrs):
+    """[sum, launches] over the kernels whose symbol holds one of substrs"""
+    tot, n = 0.0, 0
+    for name, (v, k) in (per or {}).items():
+        if any(x in name for x in substrs):
+            tot += v
+            n += k
+    return tot, n
+
+
+def measure_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured in THIS run: two rocprofv3 passes (FETCH_SIZE,
+    WRITE_SIZE separately, kernel-trace only) over a one-tile run of this script. None if rocprofv3 is missing or fails."""
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tot, n = pick(pmc_pass(args, counter), [kernel_substr])
+        if not n:
+            return None
+        out[counter] = (tot / n, n)
     rd = out["FETCH_SIZE"][0] * 1024 * PMC_READ_CORRECTION
     wr = out["WRITE_SIZE"][0] * 1024 * PMC_WRITE_CORRECTION
     return {"bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "launches_counted": out["FETCH_SIZE"][1],
@@ -136,11 +154,36 @@ def measure_traffic(args, kernel_substr):
                       "KiB x 1024, reads x2 (gfx950 correction of MI355X_MICROARCH.md), writes x1"}
 
 
+# kernels of the integer-bound record classes (judged against an ALU roofline, not HBM)
+ALU_KERNELS = {"grumpkin_level_kernel": ["record_level_kernel<acvm::GrumpkinOp", "pedersen_quad_level_kernel", "record_level_kernel<acvm::EcdsaOp"],
+               "hash_level_kernel": ["record_level_kernel<acvm::HashOp"], "brillig_level_kernel": ["record_level_kernel<acvm::BrilligOp"]}
+
+
+def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
+    """ALU roofline of an integer-bound kernel class, in modmul-equivalents: the VALU instructions its launches execute (PMC
+    SQ_INSTS_VALU, own pass) divided by the VALU instructions of ONE Montgomery product (the same counter over the library's
+    back-to-back fr29_mul probe, whose product count is known), per second of the class's HIP-event time, against the probe's rate."""
+    per = pmc_pass(args, "SQ_INSTS_VALU")
+    v_probe, n_probe = pick(per, ["modmul_rate_kernel"])
+    v_cls, n_cls = pick(per, ALU_KERNELS[cls_kernel])
+    if not n_probe or not n_cls or cls_ms_per_tile <= 0:
+        return None
+    valu_per_modmul = (v_probe / n_probe) / probe_modmuls  # wave instructions per lane product (x 64 lanes = per wave product)
+    solves = 2  # the profiled inner run: one warm-up and one timed solve of one tile
+    equiv = v_cls / solves / valu_per_modmul
+    achieved = equiv / (cls_ms_per_tile / 1e3)
+    return {"bound": "valu", "unit": "modmul/s", "achieved": achieved, "peak": peak, "frac": achieved / peak,
+            "modmul_equivalents_per_tile": equiv, "valu_wave_insts_per_tile": v_cls / solves, "valu_wave_insts_per_wave_modmul": valu_per_modmul * 64,
+            "kernel_ms_per_tile": cls_ms_per_tile, "kernels": ALU_KERNELS[cls_kernel],
+            "definition": "modmul-equivalents = SQ_INSTS_VALU of the class's launches / SQ_INSTS_VALU per product of the back-to-back fr29_mul probe "
+                          "(acvm_debug_modmul_rate: 8 interleaved chains per SIMD); peak = that probe's measured modmul/s in this run"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)  # a step is 16 solves at N = 1: the device reaches its clocks within the first
+    ap.add_argument("--warmup", type=int, default=2)  # the device reaches its clocks after about two solves (profiles/README.md)
     ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen", "mixed"])
     ap.add_argument("--gates", type=int, default=10000)
     ap.add_argument("--pedersen", type=int, default=8)
@@ -222,7 +265,8 @@ def main():
     results = batch.results()  # of the last tile
     rank_rates = shard.gather_floats(n_rank * args.steps / my_elapsed, dist)
 
-    if args.inner:  # the profiled one-tile run: nothing to report
+    if args.inner:  # the profiled one-tile run: nothing to report; the modmul probe runs so that the PMC passes see it
+        acvm_amd.modmul_rate(100, 8)
         sh.free()
         return
 
@@ -335,8 +379,11 @@ def main():
             if tr:
                 roof["traffic"] = tr["bytes_per_launch"]
                 roof["traffic_detail"] = tr
-        if dominant == "grumpkin_level_kernel":
-            roof["note"] = "integer-ALU bound (about 1e3 field multiplications per 128-256 B moved): the HBM fraction is for information"
+        alu = None
+        if world == 1 and dominant in ALU_KERNELS:
+            peak, probe_n = acvm_amd.modmul_rate(400, 8)
+            alu = measure_alu(args, dominant, k_ms, peak, 8 * 100 * 2 * 256 * acvm_amd.modmul_probe_cus()) or {"bound": "valu", "unit": "modmul/s", "peak": peak, "achieved": None, "frac": None}
+            roof["note"] = "integer-ALU bound class: the HBM fraction is for information, see alu_roofline"
         line = {
             "metric": "witnesses solved/sec (whole node)",
             "value": value,
@@ -359,6 +406,7 @@ def main():
             "per_rank_witnesses_per_s": rank_rates,
             "digest_of_digests": dod,
             "roofline": roof,
+            "alu_roofline": alu,
             "end_to_end": e2e,
             "cpu_baseline": cpu,
             "parity": parity,

@@ -156,6 +156,11 @@ int acvm_selftest(uint32_t n, uint64_t seed);
  * in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian. */
 int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64);
 
+/* Peak of the ALU roofline of the integer-bound kernels: back-to-back Montgomery products (fr29_mul, the product every
+ * kernel uses) on every SIMD, waves_per_simd dependent chains of 2 * iters products interleaved per SIMD; the best of three timed
+ * launches as modmul/s, and the number of products one launch executes. */
+int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modmul_per_s, uint64_t *n_modmul);
+
 /* Circuit::read: gzip(bincode) or raw bincode bytes. */
 acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);
 void acvm_circuit_free(acvm_circuit_t *c);

@@ -78,7 +78,7 @@ struct acvm_batch {
     hipStream_t stream_dyn = nullptr, stream_heavy = nullptr, stream_heavy2 = nullptr, stream_heavy3 = nullptr;
     hipGraphExec_t graph_exec = nullptr;  // the level schedule as one graph (solve_graph)
     uint32_t graph_launches = 0;
-    std::vector<hipEvent_t> ev_heavy;  // per level 4 events: [4L] the heavy batch of the level has run (stream_heavy); [4L+1..3] fork / joins of its side lanes
+    std::vector<hipEvent_t> ev_heavy;  // per level 4 events: [4L + q] the records of heavy lane q at the level have run (q < 3)
     std::vector<hipEvent_t> ev_sync;
     uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_unscale_plain = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
     Unscale unscale{};
@@ -938,40 +938,39 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         b->ev_sync.push_back(e);
     }
-    // Record classes that are bound by the integer pipe or by latency (hashes, Grumpkin, Pedersen, ECDSA, Brillig) run on the heavy
-    // stream beside the HBM-bound gate levels: the heavy batch of level L (plan.cpp launches them every HEAVY_EPOCH-th level) starts
-    // when level L-1 of the main stream is done, and a later level (or inversion batch) waits for it only if it reads one of its
-    // outputs (plan.level_needs_heavy; the planner puts those readers HEAVY_LATENCY levels behind the batch).
+    // Record classes that are bound by the integer pipe or by latency run beside the HBM-bound gate levels on three lanes of their own
+    // (plan.hpp heavy_lane: Pedersen | Brillig | hashes, Grumpkin, ECDSA), each a stream in order. The records of lane q at level L
+    // start when level L-1 of the main stream is done and the levels of the OTHER lanes whose outputs they read are done
+    // (plan.lane_needs_lane); a level of the main stream (or an inversion batch) waits for a lane only up to the level whose outputs
+    // it reads (plan.level_needs_heavy[lane]): a level that reads a hash output does not wait for the Pedersen launch beside it.
     auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA; };
     // (measured, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms; a circuit of heavy records
     // only gains nothing from a second queue -- config 4 4.3 -> 4.6 ms -- and keeps everything on one stream)
     bool any_heavy = false, any_main = !p.gate_offset.empty() || !p.cls_offset[CLS_LIGHT].empty();
-    for (int k = 0; k < (int)N_CLS; k++) any_heavy |= heavy_cls(k) && !p.cls_offset[k].empty();
-    hipStream_t s3 = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || !any_main ? s : b->stream_heavy;
-    // the classes of one heavy batch beside each other: Pedersen | Brillig | everything else, joined again on s3 (the batches
-    // themselves stay in order). Each is latency-bound at small tiles: the batch takes the longest class, not the sum.
-    const bool split_heavy = s3 != s && !getenv("ACVM_NO_HEAVY_SPLIT");
-    auto heavy_lane = [](int k) { return k == CLS_PEDERSEN ? 1 : k == CLS_BRILLIG ? 2 : 0; };
-    while (any_heavy && b->ev_heavy.size() < 4 * n_levels) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        b->ev_heavy.push_back(e);
-    }
+    bool lane_any[N_HEAVY_LANES] = {false, false, false};  // a lane without records never joins the schedule (nor a capture)
+    for (int k = 0; k < (int)N_CLS; k++)
+        if (heavy_cls(k) && !p.cls_offset[k].empty()) { any_heavy = true; lane_any[heavy_lane(k)] = true; }
+    const bool one_stream = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || !any_main;
+    const bool split_heavy = !one_stream && !getenv("ACVM_NO_HEAVY_SPLIT");
+    hipStream_t lane_stream[N_HEAVY_LANES] = {one_stream ? s : b->stream_heavy, one_stream ? s : (split_heavy ? b->stream_heavy2 : b->stream_heavy),
+                                              one_stream ? s : (split_heavy ? b->stream_heavy3 : b->stream_heavy)};
     bool any_dyn = !p.dyn_offset.empty();
     const bool any_async = any_dyn || any_heavy;
     if (any_async) {
         HIPCHK(hipEventRecord(b->ev_sync[2 * n_levels], s));
         if (any_dyn) HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
-        if (any_heavy) HIPCHK(hipStreamWaitEvent(s3, b->ev_sync[2 * n_levels], 0));
+        if (any_heavy && !one_stream)
+            for (int q = 0; q < N_HEAVY_LANES; q++)
+                if (lane_any[q]) HIPCHK(hipStreamWaitEvent(lane_stream[q], b->ev_sync[2 * n_levels], 0));
     }
-    hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_heavy = nullptr;
+    hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_lane[N_HEAVY_LANES] = {nullptr, nullptr, nullptr};
     bool main_dirty = false;  // the main stream has launches behind last_reg
-    uint32_t waited_inverse_level = 0, waited_heavy_level = 0;
+    uint32_t waited_inverse_level = 0, waited_heavy[N_HEAVY_LANES] = {0, 0, 0}, lane_waited[N_HEAVY_LANES][N_HEAVY_LANES] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (size_t L = 0; L < n_levels; L++) {
         uint32_t n = p.level_start[L + 1] - p.level_start[L];
         uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
         bool s_work = n != 0, h_work = false;
-        bool lane_used[3] = {false, false, false};
+        bool lane_used[N_HEAVY_LANES] = {false, false, false};
         for (int k = 0; k < (int)N_CLS; k++) {
             (heavy_cls(k) ? h_work : s_work) |= !b->cls_chunks[k][L].empty();
             if (heavy_cls(k) && !b->cls_chunks[k][L].empty()) lane_used[heavy_lane(k)] = true;
@@ -991,10 +990,12 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
             HIPCHK(hipStreamWaitEvent(s, b->ev_sync[2 * (need - 1) + 1], 0));
             waited_inverse_level = need;
         }
-        const uint32_t need_h = p.level_needs_heavy[L + 1];  // 1-based level of heavy records, 0 = none
-        if (s_work && need_h > waited_heavy_level) {
-            HIPCHK(hipStreamWaitEvent(s, b->ev_heavy[4 * (need_h - 1)], 0));
-            waited_heavy_level = need_h;
+        for (int q = 0; q < N_HEAVY_LANES; q++) {
+            const uint32_t need_h = p.level_needs_heavy[q][L + 1];  // 1-based level of the lane's records, 0 = none
+            if (s_work && need_h > waited_heavy[q]) {
+                if (!one_stream) HIPCHK(hipStreamWaitEvent(s, b->ev_heavy[4 * (need_h - 1) + q], 0));
+                waited_heavy[q] = need_h;
+            }
         }
         if (n) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1003,15 +1004,19 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
             if (prof) { e1 = next_event(); hipEventRecord(e1, s); tm->reg_pairs.push_back({e0, e1}); }
             b->n_launches += (n + 65534) / 65535;
         }
-        if (h_work && prev_reg) HIPCHK(hipStreamWaitEvent(s3, prev_reg, 0));  // inputs: levels < L of the main stream
-        // fork the side lanes of the heavy batch off s3 (which is in order behind the previous batch)
-        const bool fork = split_heavy && h_work && (int)lane_used[0] + (int)lane_used[1] + (int)lane_used[2] > 1;
-        hipStream_t lane_stream[3] = {s3, fork && lane_used[1] ? b->stream_heavy2 : s3, fork && lane_used[2] ? b->stream_heavy3 : s3};
-        if (fork) {
-            HIPCHK(hipEventRecord(b->ev_heavy[4 * L + 1], s3));
-            for (int q = 1; q < 3; q++)
-                if (lane_stream[q] != s3) HIPCHK(hipStreamWaitEvent(lane_stream[q], b->ev_heavy[4 * L + 1], 0));
-        }
+        // what the lanes wait for: levels < L of the main stream, and the other lanes as far as they read them
+        if (!one_stream)
+            for (int q = 0; q < N_HEAVY_LANES; q++) {
+                if (!lane_used[q]) continue;
+                if (prev_reg) HIPCHK(hipStreamWaitEvent(lane_stream[q], prev_reg, 0));
+                for (int q2 = 0; q2 < N_HEAVY_LANES; q2++) {
+                    const uint32_t need_l = p.lane_needs_lane[q][q2][L + 1];
+                    if (q2 != q && lane_stream[q2] != lane_stream[q] && need_l > lane_waited[q][q2]) {
+                        HIPCHK(hipStreamWaitEvent(lane_stream[q], b->ev_heavy[4 * (need_l - 1) + q2], 0));
+                        lane_waited[q][q2] = need_l;
+                    }
+                }
+            }
         for (int k = 0; k < (int)N_CLS; k++)
             for (const LaunchChunk &ch : b->cls_chunks[k][L]) {
                 hipStream_t sk = heavy_cls(k) ? lane_stream[heavy_lane(k)] : s;
@@ -1027,7 +1032,8 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 case CLS_ECDSA: launch_ecdsa_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
                 case CLS_HOSTBB:  // host callbacks: everything launched so far on any stream must have finished
                     if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
-                    if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
+                    for (int q = 0; q < N_HEAVY_LANES; q++)
+                        if (last_lane[q]) HIPCHK(hipStreamWaitEvent(s, last_lane[q], 0));
                     for (uint32_t r = 0; r < ch.count; r++)
                         if (int rc = run_host_blackbox(b, p.prog[p.cls_offset[k][ch.first + r] + 1], false, 0)) return rc;
                     break;
@@ -1035,17 +1041,18 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 if (prof) { e1 = next_event(); hipEventRecord(e1, sk); tm->cls_pairs[k].push_back({e0, e1}); }
                 b->n_launches++;
             }
-        if (fork)
-            for (int q = 1; q < 3; q++)
-                if (lane_stream[q] != s3) {
-                    HIPCHK(hipEventRecord(b->ev_heavy[4 * L + 1 + q], lane_stream[q]));
-                    HIPCHK(hipStreamWaitEvent(s3, b->ev_heavy[4 * L + 1 + q], 0));
+        if (!one_stream)
+            for (int q = 0; q < N_HEAVY_LANES; q++)
+                if (lane_used[q]) {
+                    HIPCHK(hipEventRecord(b->ev_heavy[4 * L + q], lane_stream[q]));
+                    last_lane[q] = b->ev_heavy[4 * L + q];
                 }
-        if (h_work) { HIPCHK(hipEventRecord(b->ev_heavy[4 * L], s3)); last_heavy = b->ev_heavy[4 * L]; }
         main_dirty |= s_work;
         if (nd) {
             if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
-            if (p.inv_needs_heavy[L + 1]) HIPCHK(hipStreamWaitEvent(s2, b->ev_heavy[4 * (p.inv_needs_heavy[L + 1] - 1)], 0));
+            if (!one_stream)
+                for (int q = 0; q < N_HEAVY_LANES; q++)
+                    if (p.inv_needs_heavy[q][L + 1]) HIPCHK(hipStreamWaitEvent(s2, b->ev_heavy[4 * (p.inv_needs_heavy[q][L + 1] - 1) + q], 0));
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (prof) { e0 = next_event(); hipEventRecord(e0, s2); }
             launch_inverse_batch(s2, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_event);
@@ -1055,15 +1062,13 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
             last_dyn = b->ev_sync[2 * L + 1];
         }
     }
-    if (last_heavy) HIPCHK(hipStreamWaitEvent(s, last_heavy, 0));
+    for (int q = 0; q < N_HEAVY_LANES; q++)
+        if (last_lane[q]) HIPCHK(hipStreamWaitEvent(s, last_lane[q], 0));
     if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
     if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
     return 0;
 }
 
-// The same schedule as ONE hipGraph: captured from the streams at the first solve that qualifies, replayed by every later solve
-// of the batch (tiles of a shard, steps of the bench). A circuit of thousands of small levels is bound by launch and
-// cross-stream event latency, not by its kernels; the graph keeps the dependencies and drops the per-launch host work.
 // the cross-stream events of the schedule exist before anything is enqueued (nothing is created under stream capture)
 static int ensure_level_events(acvm_batch *b) {
     const size_t n_levels = b->plan.n_levels;
@@ -1074,21 +1079,31 @@ static int ensure_level_events(acvm_batch *b) {
     }
     return 0;
 }
+// The same schedule as ONE hipGraph (opt-in: ACVM_GRAPH=1): captured from the streams at the first solve, replayed by every later
+// solve of the batch. Measured on the config-5 mix at 250 k opcodes (tile of 4 096 instances, 748 launches, three streams): 54.0 ->
+// 52.7 ms per tile -- the circuit is bound by the work of its kernels, not by launch latency. It stays off by
+// default because ROCm 7.2's hipStreamEndCapture recurses without bound on the five-stream schedule of a circuit that size (the
+// capture of a 120 k-opcode circuit, 499 launches, ran out of stack; with an unlimited stack it took the whole box down).
 static bool graph_eligible(const acvm_batch *b) {
     if (b->profiling || b->force_slow || !b->plan.cls_offset[CLS_HOSTBB].empty()) return false;
-    if (const char *e = getenv("ACVM_GRAPH")) return atoi(e) != 0;
-    return b->plan.n_levels >= 64;  // a few dozen launches gain nothing
+    const char *e = getenv("ACVM_GRAPH");
+    return e && atoi(e) != 0;
 }
 static int solve_graph(acvm_batch *b) {
     hipStream_t s = b->stream;
     if (!b->graph_exec) {
         hipGraph_t g = nullptr;
+        const bool dbg = getenv("ACVM_GRAPH_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[acvm] capture begin\n");
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         const int rc = enqueue_level_schedule(b, nullptr);
+        if (dbg) fprintf(stderr, "[acvm] enqueued rc=%d launches=%u\n", rc, b->n_launches);
         hipError_t e = hipStreamEndCapture(s, &g);
+        if (dbg) fprintf(stderr, "[acvm] capture end: %s\n", hipGetErrorString(e));
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return set_err(ACVM_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         e = hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0);
+        if (dbg) fprintf(stderr, "[acvm] instantiate: %s\n", hipGetErrorString(e));
         hipGraphDestroy(g);
         if (e != hipSuccess) { b->graph_exec = nullptr; return set_err(ACVM_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
         b->graph_launches = b->n_launches;

@@ -101,6 +101,7 @@ static void for_each_operand_word(std::vector<uint32_t> &w, F fn) {
 }
 struct PendingRecord {
     uint32_t level, cls, opcode;
+    std::vector<uint32_t> reads;  // witnesses it reads (compared outputs included)
 };
 // inversion of a SOLVE_DYN gate's denominator: runs beside level `level`, its result is read by gate `gate` at `use_level`
 struct PendingInverse {
@@ -132,6 +133,13 @@ static uint32_t heavy_epoch() {
 }
 static uint32_t heavy_latency() {
     static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_LATENCY"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 0 ? x : 0); }();
+    return v;
+}
+// The same slack for the Pedersen records alone: a commitment is a serial chain of ~45 point additions and two inversions, 0.2-0.5 ms
+// of latency for one launch however few records it holds, while its two outputs are a vanishing share of the witnesses: pricing it at
+// a few levels costs the DAG next to nothing (unlike the 32 outputs of every hash) and frees every level from waiting for it.
+static uint32_t pedersen_latency() {
+    static const uint32_t v = [] { const char *e = getenv("ACVM_PEDERSEN_LATENCY"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 0 ? x : 0); }();
     return v;
 }
 
@@ -539,12 +547,15 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // =========================================================================== generic-instance replay + levels
     // witnesses produced by a record of a heavy class (those run on their own stream, batch.cpp): level of the record, else 0
     std::vector<uint32_t> heavy_level(nw, 0);
+    std::vector<uint8_t> wlane(nw, 0);  // 1 + heavy lane of the record that produces w, 0 = not a heavy output
     // hlevel[w]: the level from which the HEAVY stream may read w (level[w] is the main stream's; they differ for the outputs of
     // heavy records: the heavy stream is in order, the main stream sees them HEAVY_LATENCY levels later)
     std::vector<uint32_t> hlevel(nw, 0);
     const uint32_t K_heavy = heavy_epoch(), D_heavy = heavy_latency();
     auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA; };
-    std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, heavy level it reads)
+    std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, witness of a heavy record it reads)
+    uint32_t out_latency = 0;  // levels of slack of the record whose outputs are being assigned
+    uint8_t out_lane = 0;
     auto assign_out = [&](uint32_t oi, uint32_t lvl, bool heavy) {
         // insert_value (pwg/mod.rs:338-357) for the outputs of opcode oi, in record order
         for (auto &slot : out_slots[oi]) {
@@ -554,7 +565,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 known[w] = 1;
                 level[w] = hlevel[w] = lvl;
                 p.producer[w] = oi;
-                if (heavy) { heavy_level[w] = lvl; level[w] = lvl + D_heavy; }
+                if (heavy) { heavy_level[w] = lvl; level[w] = lvl + out_latency; wlane[w] = out_lane; }
             }
         }
     };
@@ -703,13 +714,14 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             uint32_t lvl = std::max(rd.lvl, extra_level);
             lvl = out_levels(oi, lvl, rec_heavy) + 1;
             if (rec_heavy) lvl = (lvl + K_heavy - 1) / K_heavy * K_heavy;  // the next heavy batch
-            if (!rec_heavy) {  // a main-stream record: which heavy records does it wait for (compared outputs are reads too)
-                uint32_t h = 0;
-                for (uint32_t w : rd.ws) h = std::max(h, heavy_level[w]);
-                for (auto &slot : out_slots[oi])
-                    if (known[slot.second]) h = std::max(h, heavy_level[slot.second]);
-                if (h) heavy_reads.push_back({lvl, h});
-            }
+            std::vector<uint32_t> rec_reads = rd.ws;  // compared outputs are reads too
+            for (auto &slot : out_slots[oi])
+                if (known[slot.second]) rec_reads.push_back(slot.second);
+            if (!rec_heavy)  // a main-stream record: which heavy records does it wait for
+                for (uint32_t w : rec_reads)
+                    if (heavy_level[w]) heavy_reads.push_back({lvl, w});
+            out_latency = rec_cls == CLS_PEDERSEN ? std::max(D_heavy, pedersen_latency()) : D_heavy;
+            out_lane = (uint8_t)(1 + heavy_lane(rec_cls));
             assign_out(oi, lvl, rec_heavy);
             if (mem_access == 1) blocks[o.block_id].rlevel = std::max(blocks[o.block_id].rlevel, lvl);
             else if (mem_access == 2) { blocks[o.block_id].level = lvl; blocks[o.block_id].rlevel = 0; }
@@ -717,7 +729,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             p.algorithmic_bytes += bytes;
             p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
             p.n_other_records++;
-            records.push_back({lvl, rec_cls, oi});
+            records.push_back({lvl, rec_cls, oi, std::move(rec_reads)});
             continue;
         }
         const Expr &e = o.expr;
@@ -956,6 +968,54 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             iv.gate = slot;  // from here on: the slot
         }
     }
+    // =========================================================================== heavy records: fewer, fatter launches within their slack
+    // A heavy record launched at its earliest level usually shares the launch with one or two others, and at small tiles such a
+    // launch costs the latency of the record's serial chain however few records it holds (a Pedersen commitment: 75 us for one
+    // record of a 4 096-instance tile, 6 ns per instance when a launch is full). Its outputs are rarely needed at once: every
+    // reader has a level of its own, and the record may run anywhere before the earliest of them without delaying anything. The
+    // records are therefore moved, inside [earliest level, earliest reader - 1 - margin], onto as few launch levels as possible:
+    // processed by descending earliest level (readers before producers, so a moved record hands its slack on to the records it
+    // reads), a record joins a launch level already opened inside its window, else it opens one at its earliest level -- the
+    // mirror image of the classic interval-stabbing greedy, which is optimal in the number of points. Readers keep their levels.
+    if (!getenv("ACVM_NO_HEAVY_SLACK") && !records.empty()) {
+        const uint32_t margin = getenv("ACVM_HEAVY_MARGIN") ? (uint32_t)atoi(getenv("ACVM_HEAVY_MARGIN")) : 2u;
+        uint32_t last_level = 0;
+        for (auto &g : gates) last_level = std::max(last_level, g.level);
+        for (auto &r : records) last_level = std::max(last_level, r.level);
+        for (auto &iv : inverses) last_level = std::max(last_level, iv.level);
+        std::vector<uint32_t> deadline(nw, 0xFFFFFFFFu);  // the latest level whose records may still produce w
+        auto reader = [&](uint32_t w, uint32_t lvl) { if (lvl && lvl - 1 < deadline[w]) deadline[w] = lvl - 1; };
+        for (auto &g : gates)
+            for (uint32_t w : g.reads) reader(w, g.run_level);  // a tail reads in its host's wave
+        for (auto &iv : inverses) reader(iv.partner, iv.level);
+        std::vector<uint32_t> order;
+        for (uint32_t ri = 0; ri < records.size(); ri++) {
+            if (is_heavy(records[ri].cls)) order.push_back(ri);
+            else for (uint32_t w : records[ri].reads) reader(w, records[ri].level);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return records[a].level > records[b].level; });
+        std::vector<uint8_t> is_launch(last_level + 2, 0);
+        uint32_t moved = 0;
+        for (uint32_t ri : order) {
+            PendingRecord &r = records[ri];
+            uint32_t hi = last_level;
+            for (auto &slot : out_slots[r.opcode])
+                if (p.producer[slot.second] == r.opcode) hi = std::min(hi, deadline[slot.second]);
+            hi = hi > r.level + margin ? hi - margin : r.level;  // leave the launch a few levels to finish before it is read
+            uint32_t at = r.level;
+            for (uint32_t L = r.level; L <= hi; L++)
+                if (is_launch[L]) { at = L; break; }
+            is_launch[at] = 1;
+            if (at != r.level) {
+                moved++;
+                r.level = at;
+                for (auto &slot : out_slots[r.opcode])
+                    if (p.producer[slot.second] == r.opcode) { heavy_level[slot.second] = at; hlevel[slot.second] = at; }
+            }
+            for (uint32_t w : r.reads) reader(w, r.level);
+        }
+        (void)moved;
+    }
     // =========================================================================== order by (level, program order), lay out
     // within a level the longest wave programs (hosts with tails, many terms) go first: blocks are dispatched in grid order,
     // and a level ends when its last wave ends
@@ -975,14 +1035,24 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     for (auto &iv : inverses) p.level_needs_inverse[iv.use_level] = std::max(p.level_needs_inverse[iv.use_level], iv.level);
     // heavy record classes run on a third stream beside the levels (batch.cpp): a level of the main stream (gates, light
     // records) or an inversion batch waits for the heavy records of level h only if it reads one of their outputs
-    p.level_needs_heavy.assign(max_level + 1, 0);
-    p.inv_needs_heavy.assign(max_level + 1, 0);
+    for (int q = 0; q < N_HEAVY_LANES; q++) {
+        p.level_needs_heavy[q].assign(max_level + 1, 0);
+        p.inv_needs_heavy[q].assign(max_level + 1, 0);
+        for (int q2 = 0; q2 < N_HEAVY_LANES; q2++) p.lane_needs_lane[q][q2].assign(max_level + 1, 0);
+    }
+    auto needs = [&](std::vector<uint32_t> (&tab)[3], uint32_t at, uint32_t w) {
+        if (wlane[w]) tab[wlane[w] - 1][at] = std::max(tab[wlane[w] - 1][at], heavy_level[w]);
+    };
     for (auto &g : gates) {
         const uint32_t eff = g.run_level;  // a tail runs in its host's wave, at least one level early
-        for (uint32_t w : g.reads) p.level_needs_heavy[eff] = std::max(p.level_needs_heavy[eff], heavy_level[w]);
+        for (uint32_t w : g.reads) needs(p.level_needs_heavy, eff, w);
     }
-    for (auto &hr : heavy_reads) p.level_needs_heavy[hr.first] = std::max(p.level_needs_heavy[hr.first], hr.second);
-    for (auto &iv : inverses) p.inv_needs_heavy[iv.level] = std::max(p.inv_needs_heavy[iv.level], heavy_level[iv.partner]);
+    for (auto &hr : heavy_reads) needs(p.level_needs_heavy, hr.first, hr.second);
+    for (auto &iv : inverses) needs(p.inv_needs_heavy, iv.level, iv.partner);
+    for (auto &r : records)
+        if (is_heavy(r.cls))
+            for (uint32_t w : r.reads)
+                if (wlane[w] && wlane[w] - 1 != heavy_lane(r.cls)) needs(p.lane_needs_lane[heavy_lane(r.cls)], r.level, w);
     p.dyn_level_start.assign(max_level + 1, 0);
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k].assign(max_level + 1, 0);
     size_t gi = 0, ri = 0, ii = 0;

@@ -59,8 +59,11 @@ struct Plan {
     std::vector<uint32_t> dyn_offset;           // per inversion job (denominator of a SOLVE_DYN gate), level-major
     std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
     std::vector<uint32_t> level_needs_inverse;  // size n_levels + 1: the latest inversion level (1-based) whose results a gate of level L (1-based index) reads, 0 = none
-    std::vector<uint32_t> level_needs_heavy;    // size n_levels + 1: the latest level (1-based) of heavy-class records whose outputs the main stream's level L reads, 0 = none
-    std::vector<uint32_t> inv_needs_heavy;      // same for the inversion batch of level L
+    // The heavy record classes run on N_HEAVY_LANES lanes of their own (heavy_lane(): Pedersen | Brillig | hashes, Grumpkin, ECDSA), each
+    // in order. Sizes n_levels + 1, values = a 1-based level of that lane, 0 = none:
+    std::vector<uint32_t> level_needs_heavy[3];   // [lane]: the latest level of the lane whose outputs the main stream's level L reads
+    std::vector<uint32_t> inv_needs_heavy[3];     // same for the inversion batch of level L
+    std::vector<uint32_t> lane_needs_lane[3][3];  // [q][q']: the latest level of lane q' whose outputs the records of lane q at level L read
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
     // ---- projective witnesses (plan.cpp): the level kernels keep witness w as scale_w * value wherever only Arithmetic
     // gates touch it, so that a gate's most expensive coefficient becomes 1. Export and the exact path multiply by 1 / scale.
@@ -105,6 +108,9 @@ struct Plan {
 
 // largest dense witness table the planner accepts (witness indices 0 .. PLAN_MAX_WITNESSES - 1)
 static constexpr uint64_t PLAN_MAX_WITNESSES = 1ull << 27;
+
+static constexpr int N_HEAVY_LANES = 3;
+inline int heavy_lane(uint32_t cls) { return cls == CLS_PEDERSEN ? 1 : cls == CLS_BRILLIG ? 2 : 0; }
 
 // host_blackbox: the three BlackBoxFunctionSolver functions are served by caller-supplied host callbacks
 Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, bool host_blackbox = false);

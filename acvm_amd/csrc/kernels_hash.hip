@@ -77,6 +77,67 @@ __global__ void __launch_bounds__(128) digest_root_kernel(const uint32_t *__rest
 #pragma unroll
         for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(d[i] >> (8 * k));
 }
+// The same leaf DURING the solve (PlanOpts::fold_digest): one record per segment ([PK_DIGEST_LEAF, segment, n, (witness, row of unscale
+// or NONE) x n], the planner's assigned set = the generic instance), scheduled right behind the last witness of the segment. Reads the
+// table through the row map of slot reuse. Instances that leave the generic path get their leaves from the exact path's map afterwards.
+__global__ void __launch_bounds__(128) digest_fold_level_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ prog,
+                                                                const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ slot_of,
+                                                                const uint32_t *__restrict__ unscale_plain, uint32_t *__restrict__ leaves) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    const uint32_t *__restrict__ r = prog + offsets[blockIdx.y];
+    const uint32_t seg = r[1], n = r[2];
+    Blake2sPieces st;
+    st.begin();
+    Fr one = fr_zero();
+    one.v[0] = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t w = r[3 + 2 * i], ui = r[4 + 2 * i];
+        Fr x = fr_load(W, slot_of ? slot_of[w] : w, Bp, j);
+        x = fr_mul(x, ui != 0xFFFFFFFFu ? fr_const(unscale_plain, ui) : one);  // canonical value (unscaled where the column is scaled)
+        uint32_t m[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] = bswap32(x.v[7 - k]);
+        st.put(m);
+    }
+    uint32_t d[8];
+    st.finish(d);
+#pragma unroll
+    for (int k = 0; k < 8; k++) leaves[((uint64_t)seg * 8 + k) * Bp + j] = d[k];
+}
+void launch_digest_fold_level(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
+                              const uint32_t *unscale_plain, uint32_t *leaves) {
+    if (!n || !B) return;
+    for (uint32_t done = 0; done < n; done += 65535u) {
+        const uint32_t m = n - done > 65535u ? 65535u : n - done;
+        hipLaunchKernelGGL(digest_fold_level_kernel, dim3((B + 127) / 128, m), dim3(128), 0, s, W, Bp, B, dp.prog, offsets + done, dp.slot_of, unscale_plain, leaves);
+    }
+}
+// the root over leaves laid out [seg][8][stride] (the folded digest keeps them at the batch's stride)
+void launch_digest_root(hipStream_t s, const uint32_t *leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg, uint8_t *out);
+__global__ void __launch_bounds__(128) digest_root_strided_kernel(const uint32_t *__restrict__ leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg,
+                                                                  uint8_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Blake2sPieces st;
+    st.begin();
+    for (uint32_t seg = 0; seg < n_seg; seg++) {
+        uint32_t m[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[i] = leaves[((uint64_t)seg * 8 + i) * stride + first + t];
+        st.put(m);
+    }
+    uint32_t d[8];
+    st.finish(d);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(d[i] >> (8 * k));
+}
+void launch_digest_root(hipStream_t s, const uint32_t *leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg, uint8_t *out) {
+    if (!n) return;
+    hipLaunchKernelGGL(digest_root_strided_kernel, dim3((n + 127) / 128), dim3(128), 0, s, leaves, stride, first, n, n_seg, out);
+}
 uint32_t digest_segments(uint32_t n_witnesses) { return (n_witnesses + DIGEST_SEG - 1) / DIGEST_SEG; }
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
                    const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out) {

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(64) exact_span_kernel(uint4 *W, uint64_t Bp, D
     const uint64_t j = L.slow_ids[t];
     const uint32_t start = L.start_opcode[t];
     ExactPolicy p{W, Bp, j, L.assigned, L.n_slow, t};
-    FastPolicy replay{W, Bp, j};
+    FastPolicy replay{W, Bp, j, nullptr};  // the exact path addresses its table by witness index
     // without memory opcodes nothing before the lane's event has to be replayed
     for (uint32_t oi = replay_memory || start < op_begin ? op_begin : start; oi < op_end; oi++) {
         const uint32_t *__restrict__ rec = dp.prog + dp.prog_offset[oi];
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) hostbb_apply_level_kernel(uint4 *W, uint6
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
     const uint64_t j = first + t;
-    FastPolicy p{W, Bp, j};
+    FastPolicy p{W, Bp, j, nullptr};
     const OpResult r = hostbb_apply(p, func, rc[t], outs, n_out, vals + (uint64_t)t * n_out * 32);
     if (r.err) atomicMin(&event[j], opcode);
 }

@@ -243,13 +243,15 @@ __device__ __forceinline__ Fr canon_reduce(Fr x) {
 struct FastPolicy {
     uint4 *W;
     uint64_t Bp, j;
+    const uint32_t *__restrict__ slot_of = nullptr;  // witness -> row of the table (plan.cpp slot reuse); null: the witness index
     static constexpr bool exact = false;
+    __device__ __forceinline__ uint32_t row(uint32_t w) const { return slot_of ? slot_of[w] : w; }
     __device__ __forceinline__ bool known(uint32_t) const { return true; }
-    __device__ __forceinline__ Fr load(uint32_t w) const { return fr_load(W, w, Bp, j); }
+    __device__ __forceinline__ Fr load(uint32_t w) const { return fr_load(W, row(w), Bp, j); }
     // insert_value (pwg/mod.rs:338-357). `was_assigned` is the planner's static knowledge. Returns false on conflict.
     __device__ __forceinline__ bool insert(uint32_t w, const Fr &v, uint32_t was_assigned) const {
-        if (was_assigned) return fr_eq(fr_load(W, w, Bp, j), v);  // never overwrite: the exact kernel needs the old value
-        fr_store(W, w, Bp, j, v);
+        if (was_assigned) return fr_eq(fr_load(W, row(w), Bp, j), v);  // never overwrite: the exact kernel needs the old value
+        fr_store(W, row(w), Bp, j, v);
         return true;
     }
 };

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t 
     if (j >= B) return;
     const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
     uint32_t *sc = scratch ? scratch + (uint64_t)scratch_off[blockIdx.y] * Bp : nullptr;
-    FastPolicy p{W, Bp, j};
+    FastPolicy p{W, Bp, j, dp.slot_of};
     const OpResult r = Op::run(p, rec, dp, sc, (SlowResult *)nullptr, (const ExactLanes *)nullptr, 0u);
     if (r.err) atomicMin(&event[j], rec[1]);
 }

@@ -188,7 +188,8 @@ uint32_t clamp_reg(uint64_t r) { return r > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint3
 
 }  // namespace
 
-Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, bool host_blackbox) {
+Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
+    const bool host_blackbox = opts.host_blackbox;
     auto t0 = std::chrono::steady_clock::now();
     Plan p;
     p.n_opcodes = (uint32_t)c.opcodes.size();
@@ -552,7 +553,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // heavy records: the heavy stream is in order, the main stream sees them HEAVY_LATENCY levels later)
     std::vector<uint32_t> hlevel(nw, 0);
     const uint32_t K_heavy = heavy_epoch(), D_heavy = heavy_latency();
-    auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA; };
+    auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA || cls == CLS_DIGEST; };
     std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, witness of a heavy record it reads)
     uint32_t out_latency = 0;  // levels of slack of the record whose outputs are being assigned
     uint8_t out_lane = 0;
@@ -1016,6 +1017,41 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         (void)moved;
     }
+    // =========================================================================== digest leaves folded into the solve
+    // wdef[w]: the level whose launches write w (a fused gate writes in its host's wave; 0 = initial witness)
+    std::vector<uint32_t> wdef(nw, 0);
+    for (auto &g : gates)
+        if ((g.words[0] & 0xff) != GATE_ASSERT) wdef[g.words[2]] = g.run_level;
+    for (auto &r : records)
+        for (auto &slot : out_slots[r.opcode])
+            if (p.producer[slot.second] == r.opcode) wdef[slot.second] = r.level;
+    if (opts.fold_digest && p.truncated_at == 0xFFFFFFFFu) {
+        // record: [PK_DIGEST_LEAF, segment, n, (witness, row of `unscale` or NONE) x n]: Blake2s-256 over the canonical values of the
+        // ASSIGNED witnesses of the segment in ascending index (include/acvm_amd.h acvm_batch_digest), for the generic instance
+        // A leaf is a serial Blake2s chain over up to 256 witnesses (0.65 ms of latency for ONE launch of a 4 096-instance tile however
+        // few leaves it holds), so the leaves are launched in epochs: every DIGEST_EPOCH-th level all segments completed since the last
+        // one (measured at 250 k opcodes: a launch per level 164 ms per tile, epochs of 16 levels: see DESIGN.md section 7)
+        const uint32_t K_dig = getenv("ACVM_DIGEST_EPOCH") ? std::max(1, atoi(getenv("ACVM_DIGEST_EPOCH"))) : 16u;
+        const uint32_t n_seg = (nw + 255) / 256;
+        p.n_digest_segments = n_seg;
+        for (uint32_t k = 0; k < n_seg; k++) {
+            PendingRecord r;
+            r.cls = CLS_DIGEST;
+            r.opcode = (uint32_t)p.prog.size();  // offset of the record: digest records have no opcode
+            r.level = 1;
+            p.prog.insert(p.prog.end(), {PK_DIGEST_LEAF, k, 0u});
+            for (uint32_t w = 256 * k; w < std::min(nw, 256 * k + 256); w++) {
+                if (p.producer[w] == 0xFFFFFFFFu) continue;
+                p.prog.push_back(w);
+                p.prog.push_back(p.unscale_index[w]);
+                r.reads.push_back(w);
+                r.level = std::max(r.level, wdef[w] + 1);
+            }
+            p.prog[r.opcode + 2] = (uint32_t)r.reads.size();
+            r.level = (r.level + K_dig - 1) / K_dig * K_dig;
+            records.push_back(std::move(r));
+        }
+    }
     // =========================================================================== order by (level, program order), lay out
     // within a level the longest wave programs (hosts with tails, many terms) go first: blocks are dispatched in grid order,
     // and a level ends when its last wave ends
@@ -1040,7 +1076,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         p.inv_needs_heavy[q].assign(max_level + 1, 0);
         for (int q2 = 0; q2 < N_HEAVY_LANES; q2++) p.lane_needs_lane[q][q2].assign(max_level + 1, 0);
     }
-    auto needs = [&](std::vector<uint32_t> (&tab)[3], uint32_t at, uint32_t w) {
+    auto needs = [&](std::vector<uint32_t> (&tab)[N_HEAVY_LANES], uint32_t at, uint32_t w) {
         if (wlane[w]) tab[wlane[w] - 1][at] = std::max(tab[wlane[w] - 1][at], heavy_level[w]);
     };
     for (auto &g : gates) {
@@ -1053,6 +1089,97 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         if (is_heavy(r.cls))
             for (uint32_t w : r.reads)
                 if (wlane[w] && wlane[w] - 1 != heavy_lane(r.cls)) needs(p.lane_needs_lane[heavy_lane(r.cls)], r.level, w);
+    // =========================================================================== witness-slot liveness reuse
+    // A witness occupies a row of the table from the level that writes it to the level of its last reader; the rows of dead
+    // witnesses go to a FIFO and are handed to the witnesses the MAIN stream defines later (gates, light records). The main stream
+    // runs its levels in order, so a recycled row is safe against every earlier reader on that stream; a reader (or an asynchronous
+    // writer: the outputs of heavy records) on another stream -- inversion batches, the heavy lanes, the digest leaves -- becomes one
+    // more dependency of the level that recycles the row (level_needs_inverse / level_needs_heavy: usually long satisfied, the FIFO
+    // keeps a row out of use for as long as it can). Heavy outputs always take fresh rows (their lanes have no edge from the other
+    // asynchronous streams), the initial witnesses and `keep` are never released. The digest leaves are readers like any other:
+    // a row is hashed before it is recycled.
+    if (opts.reuse_slots) {
+        if (p.truncated_at != 0xFFFFFFFFu || p.has_foreign_calls) {
+            p.unsupported = "slot reuse needs a circuit the level kernels cover entirely and no foreign calls";
+            return p;
+        }
+        constexpr int N_ASYNC = 1 + N_HEAVY_LANES;  // 0 = inversion batches, 1 + q = heavy lane q
+        std::vector<uint32_t> last_any(nw, 0), last_on[N_ASYNC];
+        for (auto &v : last_on) v.assign(nw, 0);
+        auto note = [&](uint32_t w, uint32_t lvl, int async) {  // async < 0: the main stream
+            last_any[w] = std::max(last_any[w], lvl);
+            if (async >= 0) last_on[async][w] = std::max(last_on[async][w], lvl);
+        };
+        std::vector<std::vector<uint32_t>> def_main(max_level + 1), def_heavy(max_level + 1);
+        for (auto &g : gates) {
+            for (uint32_t w : g.reads) note(w, g.run_level, -1);
+            if ((g.words[0] & 0xff) != GATE_ASSERT) def_main[g.run_level].push_back(g.words[2]);
+        }
+        for (auto &iv : inverses) note(iv.partner, iv.level, 0);
+        for (auto &r : records) {
+            const bool heavy = is_heavy(r.cls);
+            const int async = heavy ? 1 + heavy_lane(r.cls) : -1;
+            if (!(r.cls == CLS_DIGEST && getenv("ACVM_REUSE_IGNORE_DIGEST")))  // (measurement only: rows as if no digest were kept)
+                for (uint32_t w : r.reads) note(w, r.level, async);
+            if (r.cls == CLS_DIGEST) continue;
+            for (auto &slot : out_slots[r.opcode])
+                if (p.producer[slot.second] == r.opcode) {
+                    (heavy ? def_heavy : def_main)[r.level].push_back(slot.second);
+                    if (heavy) note(slot.second, r.level, async);  // written asynchronously: recycling the row waits for the write too
+                }
+        }
+        std::vector<uint8_t> keep(nw, 0);
+        for (uint32_t i = 0; i < n_initial; i++) keep[initial_ids[i]] = 1;
+        for (uint32_t w : opts.keep)
+            if (w < nw) keep[w] = 1;
+        p.slot_of.assign(nw, 0xFFFFFFFFu);
+        for (uint32_t i = 0; i < n_initial; i++) p.slot_of[initial_ids[i]] = p.n_slots++;
+        std::vector<std::vector<uint32_t>> release(max_level + 2);
+        for (uint32_t w = 0; w < nw; w++)
+            if (p.producer[w] != 0xFFFFFFFFu && !keep[w]) release[std::min<uint32_t>(std::max(last_any[w], wdef[w]) + 1, max_level + 1)].push_back(w);
+        std::vector<uint32_t> fifo, prev_owner;
+        size_t head = 0;
+        for (uint32_t L = 1; L <= max_level; L++) {
+            for (uint32_t w : release[L]) {
+                const uint32_t row = p.slot_of[w];
+                if (row == 0xFFFFFFFFu) continue;
+                if (prev_owner.size() <= row) prev_owner.resize(p.n_slots, 0xFFFFFFFFu);
+                prev_owner[row] = w;
+                fifo.push_back(row);
+            }
+            for (uint32_t w : def_main[L]) {
+                if (p.slot_of[w] != 0xFFFFFFFFu) continue;
+                if (head < fifo.size()) {
+                    const uint32_t row = fifo[head++], old = prev_owner[row];
+                    if (last_on[0][old]) p.level_needs_inverse[L] = std::max(p.level_needs_inverse[L], last_on[0][old]);
+                    for (int q = 0; q < N_HEAVY_LANES; q++)
+                        if (last_on[1 + q][old]) p.level_needs_heavy[q][L] = std::max(p.level_needs_heavy[q][L], last_on[1 + q][old]);
+                    p.slot_of[w] = row;
+                } else p.slot_of[w] = p.n_slots++;
+            }
+            for (uint32_t w : def_heavy[L])
+                if (p.slot_of[w] == 0xFFFFFFFFu) p.slot_of[w] = p.n_slots++;
+        }
+        // the gate programs and the inversion jobs address rows
+        auto row = [&](uint32_t w) { return w == GATE_LOCAL ? GATE_LOCAL : p.slot_of[w]; };
+        for (auto &g : gates) {
+            if (g.fused) continue;
+            std::vector<uint32_t> &w = g.words;
+            for (size_t pos = 0;;) {
+                const uint32_t w0 = w[pos], w5 = w[pos + 5];
+                const uint32_t np_mac = (w0 >> 8) & 0xff, nl_mac = (w0 >> 16) & 0xff;
+                const uint32_t np_pos = w5 & 0xff, np_neg = (w5 >> 8) & 0xff, nl_pos = (w5 >> 16) & 0xff, nl_neg = w5 >> 24;
+                if ((w0 & 0xff) != GATE_ASSERT) w[pos + 2] = row(w[pos + 2]);
+                size_t t = pos + 6;
+                for (uint32_t i = 0; i < np_mac; i++, t += 10) { w[t + 8] = row(w[t + 8]); w[t + 9] = row(w[t + 9]); }
+                for (uint32_t i = 0; i < nl_mac; i++, t += 9) w[t + 8] = row(w[t + 8]);
+                for (uint32_t i = 0; i < 2 * (np_pos + np_neg) + nl_pos + nl_neg; i++, t++) w[t] = row(w[t]);
+                if (!(w0 & GATE_TAIL_FLAG)) break;
+                pos = t;
+            }
+        }
+        for (auto &iv : inverses) iv.partner = p.slot_of[iv.partner];
+    }
     p.dyn_level_start.assign(max_level + 1, 0);
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k].assign(max_level + 1, 0);
     size_t gi = 0, ri = 0, ii = 0;
@@ -1073,8 +1200,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         for (; ri < records.size() && records[ri].level == L; ri++) {
             const PendingRecord &r = records[ri];
-            p.cls_offset[r.cls].push_back(p.prog_offset[r.opcode]);
-            p.cls_scratch[r.cls].push_back(p.prog_scratch[r.opcode]);
+            p.cls_offset[r.cls].push_back(r.cls == CLS_DIGEST ? r.opcode : p.prog_offset[r.opcode]);
+            p.cls_scratch[r.cls].push_back(r.cls == CLS_DIGEST ? 0u : p.prog_scratch[r.opcode]);
             width[L]++;
         }
     }

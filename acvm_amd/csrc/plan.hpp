@@ -39,14 +39,15 @@ static constexpr uint32_t GATE_HDR_WORDS = 5;
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
 enum ProgKind : uint32_t {
     PK_ARITH = 0, PK_RANGE = 1, PK_LOGIC = 2, PK_HASH = 3, PK_PEDERSEN = 4, PK_FIXED_BASE = 5, PK_SCHNORR = 6, PK_ZERO_OUT = 7,
-    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12, PK_ECDSA = 13, PK_PERM_SORT = 14
+    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12, PK_ECDSA = 13, PK_PERM_SORT = 14, PK_DIGEST_LEAF = 15
 };
 // kernel classes of the non-arithmetic records
 // CLS_PEDERSEN only exists in the level schedule (its own 4-waves-per-instance-group kernel); the exact path and the
 // statistics treat a Pedersen record as CLS_GRUMPKIN
 // CLS_HOSTBB: Pedersen / FixedBaseScalarMul / SchnorrVerify when the caller supplied its own BlackBoxFunctionSolver: the
 // record is executed by host callbacks between two small kernels (batch.cpp run_host_blackbox)
-enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, CLS_HOSTBB = 5, CLS_ECDSA = 6, N_CLS = 7 };
+// CLS_DIGEST: the leaves of the witness-map digest folded into the solve (PlanOpts::fold_digest): records behind the opcodes' in `prog`
+enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, CLS_HOSTBB = 5, CLS_ECDSA = 6, CLS_DIGEST = 7, N_CLS = 8 };
 
 struct Plan {
     uint32_t n_witnesses = 0;
@@ -59,11 +60,11 @@ struct Plan {
     std::vector<uint32_t> dyn_offset;           // per inversion job (denominator of a SOLVE_DYN gate), level-major
     std::vector<uint32_t> dyn_level_start;      // size n_levels + 1, indexes dyn_offset
     std::vector<uint32_t> level_needs_inverse;  // size n_levels + 1: the latest inversion level (1-based) whose results a gate of level L (1-based index) reads, 0 = none
-    // The heavy record classes run on N_HEAVY_LANES lanes of their own (heavy_lane(): Pedersen | Brillig | hashes, Grumpkin, ECDSA), each
+    // The heavy record classes run on N_HEAVY_LANES lanes of their own (heavy_lane(): Pedersen | Brillig | hashes, Grumpkin, ECDSA | digest leaves), each
     // in order. Sizes n_levels + 1, values = a 1-based level of that lane, 0 = none:
-    std::vector<uint32_t> level_needs_heavy[3];   // [lane]: the latest level of the lane whose outputs the main stream's level L reads
-    std::vector<uint32_t> inv_needs_heavy[3];     // same for the inversion batch of level L
-    std::vector<uint32_t> lane_needs_lane[3][3];  // [q][q']: the latest level of lane q' whose outputs the records of lane q at level L read
+    std::vector<uint32_t> level_needs_heavy[4];   // [lane]: the latest level of the lane whose outputs the main stream's level L reads
+    std::vector<uint32_t> inv_needs_heavy[4];     // same for the inversion batch of level L
+    std::vector<uint32_t> lane_needs_lane[4][4];  // [q][q']: the latest level of lane q' whose outputs the records of lane q at level L read
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
     // ---- projective witnesses (plan.cpp): the level kernels keep witness w as scale_w * value wherever only Arithmetic
     // gates touch it, so that a gate's most expensive coefficient becomes 1. Export and the exact path multiply by 1 / scale.
@@ -80,6 +81,10 @@ struct Plan {
     std::vector<uint32_t> cls_scratch[N_CLS];
     std::vector<uint32_t> cls_level_start[N_CLS];  // size n_levels + 1
     uint32_t n_levels = 0;
+    uint32_t n_digest_segments = 0;             // fold_digest: leaves of the digest (segments of 256 witness indices)
+    // reuse_slots: row of the witness table per witness (0xFFFFFFFF = never written by the level path), rows in total
+    std::vector<uint32_t> slot_of;
+    uint32_t n_slots = 0;
     uint32_t mem_cells = 0;                     // cells of the per-instance memory table (all blocks)
     std::vector<uint32_t> bytecode;             // Brillig programs (see plan.cpp emit_brillig)
     // ---- bookkeeping for export / failure masking
@@ -109,10 +114,21 @@ struct Plan {
 // largest dense witness table the planner accepts (witness indices 0 .. PLAN_MAX_WITNESSES - 1)
 static constexpr uint64_t PLAN_MAX_WITNESSES = 1ull << 27;
 
-static constexpr int N_HEAVY_LANES = 3;
-inline int heavy_lane(uint32_t cls) { return cls == CLS_PEDERSEN ? 1 : cls == CLS_BRILLIG ? 2 : 0; }
+static constexpr int N_HEAVY_LANES = 4;
+inline int heavy_lane(uint32_t cls) { return cls == CLS_PEDERSEN ? 1 : cls == CLS_BRILLIG ? 2 : cls == CLS_DIGEST ? 3 : 0; }
 
-// host_blackbox: the three BlackBoxFunctionSolver functions are served by caller-supplied host callbacks
-Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, bool host_blackbox = false);
+// what a batch asks of its plan beyond the circuit (acvm_batch_new_ex)
+struct PlanOpts {
+    bool host_blackbox = false;  // the three BlackBoxFunctionSolver functions are served by caller-supplied host callbacks
+    // The per-instance digest of the witness map (acvm_batch_digest) is computed DURING the solve: the leaf of every segment of 256
+    // witness indices is a record of its own class, scheduled right behind the last witness of the segment on a lane of its own.
+    bool fold_digest = false;
+    // Witness-slot liveness reuse: a witness occupies a row of the table from the level that writes it to the
+    // level of its last reader; rows are recycled. Only the initial witnesses and `keep` stay until the end.
+    bool reuse_slots = false;
+    std::vector<uint32_t> keep;
+};
+
+Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts = PlanOpts());
 
 }  // namespace acvm

@@ -134,6 +134,8 @@ typedef struct {
     uint32_t n_inverse_slots;  /* rows of the inverse table (denominators of the n_dyn_gates gates, rows reused) */
     uint32_t n_scaled_witnesses; /* witnesses the level kernels keep as scale x value (unscaled on export and for the exact path) */
     uint32_t n_arith_launches; /* launches of arith_level_kernel per solve (levels that hold gates) */
+    uint32_t n_table_rows;     /* rows of the device witness table: n_witnesses, or fewer with ACVM_BATCH_REUSE_SLOTS */
+    uint32_t n_digest_segments; /* leaves of the folded digest (ACVM_BATCH_FOLD_DIGEST), 0 if the digest is not folded */
 } acvm_stats_t;
 
 const char *acvm_last_error(void);
@@ -169,6 +171,9 @@ uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c); /* 1 + highest wit
 /* Host-only levelisation against a set of initial witness ids (no device needed): plan statistics in *out. Returns 0, or
  * ACVM_E_UNSUPPORTED (reason in acvm_last_error) if the circuit holds an opcode no kernel implements. */
 int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out);
+/* the same for a batch created with acvm_batch_new_ex's flags (n_table_rows, n_digest_segments) */
+int acvm_circuit_plan_stats_ex(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids,
+                               uint32_t n_keep, acvm_stats_t *out);
 
 /*
  * ACVM::new for n_instances instances that all assign the same initial witness ids.
@@ -176,6 +181,20 @@ int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids
  */
 acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances,
                              const uint32_t *initial_ids, uint32_t n_initial);
+/*
+ * The same with options for callers that keep only the return witnesses and a digest of every map:
+ *   ACVM_BATCH_FOLD_DIGEST  the per-instance digest (acvm_batch_digest) is computed DURING the solve, leaf by leaf as the witnesses
+ *                           of a segment complete, beside the level kernels: acvm_batch_digest then only hashes the leaves.
+ *   ACVM_BATCH_REUSE_SLOTS  witness-slot liveness reuse: a witness occupies a row of the device table from the level that writes it
+ *                           to the level of its last reader, rows are recycled (implies the folded digest: a row is hashed before
+ *                           it is reused). Afterwards only the initial witnesses and keep_ids can be read back (acvm_batch_witness
+ *                           / _extract_witnesses), plus results and digests; acvm_batch_witness_map returns ACVM_E_STATE. Instances
+ *                           that leave the generic path are re-solved from their initial witnesses in a table of their own.
+ */
+#define ACVM_BATCH_FOLD_DIGEST 1u
+#define ACVM_BATCH_REUSE_SLOTS 2u
+acvm_batch_t *acvm_batch_new_ex(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, uint32_t n_instances, const uint32_t *initial_ids,
+                                uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids, uint32_t n_keep);
 void acvm_batch_free(acvm_batch_t *b);
 /* values_be32: [n_instances][n_initial][32] canonical big-endian (reduced mod p like from_be_bytes_reduce). */
 int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32);

@@ -3,7 +3,8 @@ instances through one reused batch handle; per tile only the results, the return
 witness map are kept. An audit sample of the first tile is re-solved by the CPU oracle and compared bit-exactly (results,
 return witnesses, and the digest recomputed with hashlib over the oracle's full map).
 
-    python tools/t_config5.py [opcodes=1000000] [tile=4096] [n_tiles=2] [audit=8]
+    python tools/t_config5.py [opcodes=1000000] [tile=4096] [n_tiles=2] [audit=8] [mode=plain|fold|reuse]
+mode fold: the digest is computed during the solve (ACVM_BATCH_FOLD_DIGEST); reuse: witness-slot liveness reuse on top of it.
 """
 import json
 import os
@@ -21,6 +22,7 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 n_tiles = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 audit = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+mode = sys.argv[5] if len(sys.argv) > 5 else "plain"
 
 t0 = time.time()
 circ, ids = synth.mixed_circuit(G)
@@ -28,11 +30,11 @@ data = circ.to_bytes()
 t1 = time.time()
 gc = acvm_amd.Circuit(data)
 ret = gc.witness_set("return_values")
-batch = acvm_amd.Batch(gc, tile, ids)
+batch = acvm_amd.Batch(gc, tile, ids, fold_digest=mode in ("fold", "reuse"), reuse_slots=mode == "reuse", keep=ret)
 t2 = time.time()
 st0 = gc.plan_stats(ids)
 row = len(ids) * 32
-out = {"opcodes": G, "tile": tile, "witnesses_per_instance": st0["n_witnesses"], "levels": st0["n_levels"],
+out = {"opcodes": G, "tile": tile, "mode": mode, "witnesses_per_instance": st0["n_witnesses"], "levels": st0["n_levels"],
        "witness_table_GB": round(st0["n_witnesses"] * 32 * tile / 1e9, 1), "generate_s": round(t1 - t0, 1), "parse_plan_alloc_s": round(t2 - t1, 1),
        "plan_ms": round(st0["plan_ms"]), "scaled_witnesses": st0["n_scaled_witnesses"], "tiles": []}
 first_vals = None

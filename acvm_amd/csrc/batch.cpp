@@ -77,7 +77,7 @@ struct acvm_batch {
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr, stream_heavy = nullptr, stream_heavy2 = nullptr, stream_heavy3 = nullptr, stream_digest = nullptr;
     PlanOpts opts;                    // acvm_batch_new_ex: folded digest, slot reuse
-    uint32_t *d_leaves = nullptr;     // fold_digest: leaves [segment][8][Bp] written by the digest lane during the solve
+    uint32_t *d_leaves = nullptr;     // fold_digest: the word-wise sum of the leaves, [8][Bp], accumulated by the digest lane during the solve
     uint32_t *d_slot_of = nullptr;    // reuse_slots: witness -> row of d_W
     // reuse_slots: the exact path re-solves the flagged instances from their initial witnesses in a table of its own (row = witness
     // index, lane t = the t-th flagged instance); x_cap lanes allocated
@@ -465,7 +465,7 @@ static int batch_init(acvm_batch *b) {
     b->dp.ped_seed = nullptr;
     b->dp.fc_store = nullptr;
     b->dp.slot_of = nullptr;
-    if (p.n_digest_segments) HIPCHK(hipMalloc((void **)&b->d_leaves, (size_t)p.n_digest_segments * 8 * b->Bp * 4));
+    if (p.n_digest_segments) HIPCHK(hipMalloc((void **)&b->d_leaves, (size_t)8 * b->Bp * 4));
     if (!p.slot_of.empty()) {
         if (int rc = upload(&b->d_slot_of, p.slot_of)) return rc;
         b->dp.slot_of = b->d_slot_of;
@@ -986,6 +986,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     };
     const bool prof = tm != nullptr;
     launch_fill_u32(s, b->d_event, 0xFFFFFFFFu, b->B);
+    if (b->d_leaves) launch_fill_u32(s, b->d_leaves, 0u, 8 * b->Bp);  // the folded digest sums its leaves into this
     // Per level the constant-coefficient gates and the other record classes (stream s) and the gates that need a
     // per-instance inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of
     // either stream waits for level L of both.
@@ -1690,8 +1691,8 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
 // out32[(instance - first) * 32]
 static int digest_exact_instances(acvm_batch *b, const std::vector<uint32_t> &instances, uint32_t first, uint8_t *out32) {
     const Plan &p = b->plan;
-    const uint32_t n_seg = digest_segments(p.n_witnesses), n_slow = (uint32_t)b->slow_ids.size();
-    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)std::max(n_seg, 1u) * 32);
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256(32);
     if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + 32)) return rc;
     int32_t *d_slow_index = (int32_t *)b->d_stage;
     uint32_t *d_leaves = (uint32_t *)(b->d_stage + idx_bytes);
@@ -1724,7 +1725,7 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
         // folded into the solve: the leaves of the generic instances are there; only the root is left (and the instances of the
         // exact path, whose leaves come from their own maps below)
         if (int rc = stage_reserve(b, (size_t)n * 32)) return rc;
-        launch_digest_root(b->stream, b->d_leaves, b->Bp, first, n, p.n_digest_segments, b->d_stage);
+        launch_digest_final(b->stream, b->d_leaves, b->Bp, first, n, b->d_stage);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out32, b->d_stage, (size_t)n * 32, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
@@ -1735,10 +1736,9 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
         if (int rc = digest_exact_instances(b, flagged, first, out32)) return rc;
         return 0;
     }
-    const uint32_t n_seg = digest_segments(p.n_witnesses), n_slow = (uint32_t)b->slow_ids.size();
-    // instances in slices whose leaf scratch stays below 1 GiB
-    const uint32_t slice = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(64, (1ull << 30) / ((uint64_t)std::max(n_seg, 1u) * 32)));
-    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)std::max(n_seg, 1u) * 32 * slice);
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    const uint32_t slice = n;  // the scratch is the 32-byte sum of the leaves per instance
+    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)32 * slice);
     if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + (size_t)slice * 32)) return rc;
     int32_t *d_slow_index = (int32_t *)b->d_stage;
     uint32_t *d_leaves = (uint32_t *)(b->d_stage + idx_bytes);

@@ -118,14 +118,13 @@ void launch_hostbb_apply_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t fi
                                uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event);
 void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const ExactLanes &L, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
                                const uint32_t *outs, uint32_t n_out, const uint8_t *active, const uint8_t *rc, const uint8_t *vals);
-// per-instance digest of the witness map (kernels_hash.hip): leaves = scratch of digest_segments(n_witnesses) x 8 x n words
-uint32_t digest_segments(uint32_t n_witnesses);
+// per-instance digest of the witness map (kernels_hash.hip): acc = scratch of 8 x n words
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
-                   const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out);
+                   const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *acc, uint8_t *out);
 // the digest folded into the solve (PlanOpts::fold_digest)
 void launch_digest_fold_level(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
-                              const uint32_t *unscale_plain, uint32_t *leaves);
-void launch_digest_root(hipStream_t s, const uint32_t *leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg, uint8_t *out);
+                              const uint32_t *unscale_plain, uint32_t *acc);
+void launch_digest_final(hipStream_t s, const uint32_t *acc, uint64_t stride, uint32_t first, uint32_t n, uint8_t *out);
 // InProgress -> Solved after the last opcode
 void launch_exact_finish(hipStream_t s, const ExactLanes &L, uint32_t min_ip = 0);
 

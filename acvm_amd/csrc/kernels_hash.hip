@@ -25,130 +25,129 @@ void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram
 
 // ------------------------------------------------------------------------------------------ witness-map digest
 // SURVEY 8d (config 5): callers that do not want the full map back keep the return witnesses and a 32-byte digest per instance.
-// Definition (include/acvm_amd.h acvm_batch_digest): the assigned witnesses in ascending index, each as its 32-byte big-endian
-// canonical value, are cut into segments of DIGEST_SEG witness INDICES; leaf_k = Blake2s-256 of the assigned ones among
-// [k DIGEST_SEG, (k+1) DIGEST_SEG); digest = Blake2s-256(leaf_0 || leaf_1 || ...). Two levels so that (segments x instances)
-// lanes hash concurrently: a single Blake2s chain per instance would leave a 4 096-instance tile of a 10^6-witness circuit on 64 waves.
-static constexpr uint32_t DIGEST_SEG = 256;
-__global__ void __launch_bounds__(128) digest_leaf_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses,
-                                                          const uint32_t *__restrict__ producer, const Unscale u, const int32_t *__restrict__ slow_index,
-                                                          const uint32_t *__restrict__ assigned, uint32_t n_slow, uint32_t *__restrict__ leaves, uint32_t seg0) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, seg = seg0 + blockIdx.y;
+// Definition (include/acvm_amd.h acvm_batch_digest): witnesses 2i and 2i + 1 form pair i; mask = 1 (2i assigned) | 2 (2i + 1 assigned);
+// a pair with mask != 0 has the leaf Blake2s-256(message = the 32-byte big-endian canonical values of its assigned witnesses in ascending
+// order, personalisation = le32(i) || le32(mask)) -- ONE compression; S = the sum of all leaves taken as eight little-endian 32-bit words,
+// each word modulo 2^32; digest = Blake2s-256(S). The sum makes the leaves order-free: a leaf is hashed as soon as its two witnesses
+// exist (the folded digest of plan.cpp, which lets witness rows be recycled early), by any number of lanes, and added with atomics.
+__device__ __forceinline__ void digest_leaf_add(uint32_t (&S)[8], uint32_t pair, uint32_t mask, const Fr &ca, const Fr &cb) {
+    uint32_t h[8], w[16];
+    blake2s_init(h);
+    h[6] ^= pair;  // parameter block bytes 24..31: the personalisation
+    h[7] ^= mask;
+    const Fr &first = (mask & 1u) ? ca : cb;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        w[k] = bswap32(first.v[7 - k]);  // big-endian bytes as little-endian message words
+        w[8 + k] = mask == 3u ? bswap32(cb.v[7 - k]) : 0u;
+    }
+    blake2s_compress(h, w, mask == 3u ? 64u : 32u, true);
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k] += h[k];
+}
+static constexpr uint32_t DIGEST_CHUNK_PAIRS = 64;  // pairs one lane of the post-solve kernel hashes
+// after the solve, from the table: lane = (instance, chunk of pairs); acc = [8][n] words, zeroed by the launcher
+__global__ void __launch_bounds__(128) digest_pairs_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses,
+                                                           const uint32_t *__restrict__ producer, const Unscale u, const int32_t *__restrict__ slow_index,
+                                                           const uint32_t *__restrict__ assigned, uint32_t n_slow, uint32_t *__restrict__ acc, uint32_t chunk0) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, chunk = chunk0 + blockIdx.y;
     if (t >= n) return;
     const uint64_t j = (uint64_t)first + t;
     const bool generic = u.event[j] == 0xFFFFFFFFu;  // solved by the level kernels: the planner's assigned set, scaled columns
     const uint32_t lane = generic ? 0u : (uint32_t)slow_index[j];
-    Blake2sPieces st;
-    st.begin();
-    const uint32_t w0 = seg * DIGEST_SEG, w1 = w0 + DIGEST_SEG < n_witnesses ? w0 + DIGEST_SEG : n_witnesses;
-    for (uint32_t w = w0; w < w1; w++) {
-        const bool present = generic ? producer[w] != 0xFFFFFFFFu : ((assigned[(uint64_t)(w >> 5) * n_slow + lane] >> (w & 31)) & 1u) != 0u;
-        if (!present) continue;
-        Fr x = fr_load(W, w, Bp, j);
-        const uint32_t ui = generic && u.index ? u.index[w] : 0xFFFFFFFFu;  // wave-uniform unless the wave holds flagged instances
-        Fr one = fr_zero();
-        one.v[0] = 1;
-        x = fr_mul(x, ui != 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);  // canonical value (unscaled where the column is scaled)
-        uint32_t m[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) m[i] = bswap32(x.v[7 - i]);  // big-endian bytes as little-endian message words
-        st.put(m);
+    Fr one = fr_zero();
+    one.v[0] = 1;
+    uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t p0 = chunk * DIGEST_CHUNK_PAIRS, n_pairs = (n_witnesses + 1) / 2;
+    for (uint32_t pi = p0; pi < p0 + DIGEST_CHUNK_PAIRS && pi < n_pairs; pi++) {
+        uint32_t mask = 0;
+        Fr c[2] = {fr_zero(), fr_zero()};
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t w = 2 * pi + h;
+            if (w >= n_witnesses) continue;
+            const bool present = generic ? producer[w] != 0xFFFFFFFFu : ((assigned[(uint64_t)(w >> 5) * n_slow + lane] >> (w & 31)) & 1u) != 0u;
+            if (!present) continue;
+            mask |= 1u << h;
+            const uint32_t ui = generic && u.index ? u.index[w] : 0xFFFFFFFFu;
+            c[h] = fr_mul(fr_load(W, w, Bp, j), ui != 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);  // canonical value (unscaled where the column is scaled)
+        }
+        if (mask) digest_leaf_add(S, pi, mask, c[0], c[1]);
     }
-    uint32_t d[8];
-    st.finish(d);
 #pragma unroll
-    for (int i = 0; i < 8; i++) leaves[((uint64_t)seg * 8 + i) * n + t] = d[i];
+    for (int k = 0; k < 8; k++)
+        if (S[k]) atomicAdd(&acc[(uint64_t)k * n + t], S[k]);
 }
-__global__ void __launch_bounds__(128) digest_root_kernel(const uint32_t *__restrict__ leaves, uint32_t n, uint32_t n_seg, uint8_t *__restrict__ out) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    Blake2sPieces st;
-    st.begin();
-    for (uint32_t seg = 0; seg < n_seg; seg++) {
-        uint32_t m[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) m[i] = leaves[((uint64_t)seg * 8 + i) * n + t];
-        st.put(m);
-    }
-    uint32_t d[8];
-    st.finish(d);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(d[i] >> (8 * k));
-}
-// The same leaf DURING the solve (PlanOpts::fold_digest): one record per segment ([PK_DIGEST_LEAF, segment, n, (witness, row of unscale
-// or NONE) x n], the planner's assigned set = the generic instance), scheduled right behind the last witness of the segment. Reads the
-// table through the row map of slot reuse. Instances that leave the generic path get their leaves from the exact path's map afterwards.
+// The same leaves DURING the solve (PlanOpts::fold_digest): records [PK_DIGEST_LEAF, 0, n, (pair, witness 2i or NONE, witness 2i + 1 or NONE,
+// row of unscale or NONE x 2) x n] of the pairs whose witnesses are complete (the planner's assigned set = the generic instance), read through
+// the row map of slot reuse; acc = [8][Bp]. Instances that leave the generic path are hashed from the exact path's map afterwards.
 __global__ void __launch_bounds__(128) digest_fold_level_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ prog,
                                                                 const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ slot_of,
-                                                                const uint32_t *__restrict__ unscale_plain, uint32_t *__restrict__ leaves) {
+                                                                const uint32_t *__restrict__ unscale_plain, uint32_t *__restrict__ acc) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
     const uint32_t *__restrict__ r = prog + offsets[blockIdx.y];
-    const uint32_t seg = r[1], n = r[2];
-    Blake2sPieces st;
-    st.begin();
+    const uint32_t n = r[2];
     Fr one = fr_zero();
     one.v[0] = 1;
+    uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t w = r[3 + 2 * i], ui = r[4 + 2 * i];
-        Fr x = fr_load(W, slot_of ? slot_of[w] : w, Bp, j);
-        x = fr_mul(x, ui != 0xFFFFFFFFu ? fr_const(unscale_plain, ui) : one);  // canonical value (unscaled where the column is scaled)
-        uint32_t m[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) m[k] = bswap32(x.v[7 - k]);
-        st.put(m);
+        const uint32_t *__restrict__ e = r + 3 + 5 * i;
+        uint32_t mask = 0;
+        Fr c[2] = {fr_zero(), fr_zero()};
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t w = e[1 + h], ui = e[3 + h];
+            if (w == 0xFFFFFFFFu) continue;
+            mask |= 1u << h;
+            c[h] = fr_mul(fr_load(W, slot_of ? slot_of[w] : w, Bp, j), ui != 0xFFFFFFFFu ? fr_const(unscale_plain, ui) : one);
+        }
+        digest_leaf_add(S, e[0], mask, c[0], c[1]);
     }
-    uint32_t d[8];
-    st.finish(d);
 #pragma unroll
-    for (int k = 0; k < 8; k++) leaves[((uint64_t)seg * 8 + k) * Bp + j] = d[k];
+    for (int k = 0; k < 8; k++)
+        if (S[k]) atomicAdd(&acc[(uint64_t)k * Bp + j], S[k]);
 }
-void launch_digest_fold_level(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
-                              const uint32_t *unscale_plain, uint32_t *leaves) {
-    if (!n || !B) return;
-    for (uint32_t done = 0; done < n; done += 65535u) {
-        const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        hipLaunchKernelGGL(digest_fold_level_kernel, dim3((B + 127) / 128, m), dim3(128), 0, s, W, Bp, B, dp.prog, offsets + done, dp.slot_of, unscale_plain, leaves);
-    }
-}
-// the root over leaves laid out [seg][8][stride] (the folded digest keeps them at the batch's stride)
-void launch_digest_root(hipStream_t s, const uint32_t *leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg, uint8_t *out);
-__global__ void __launch_bounds__(128) digest_root_strided_kernel(const uint32_t *__restrict__ leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg,
-                                                                  uint8_t *__restrict__ out) {
+// digest = Blake2s-256(S); acc laid out [8][stride], instances [first, first + n)
+__global__ void __launch_bounds__(128) digest_final_kernel(const uint32_t *__restrict__ acc, uint64_t stride, uint32_t first, uint32_t n, uint8_t *__restrict__ out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    Blake2sPieces st;
-    st.begin();
-    for (uint32_t seg = 0; seg < n_seg; seg++) {
-        uint32_t m[8];
+    uint32_t h[8], w[16];
+    blake2s_init(h);
 #pragma unroll
-        for (int i = 0; i < 8; i++) m[i] = leaves[((uint64_t)seg * 8 + i) * stride + first + t];
-        st.put(m);
-    }
-    uint32_t d[8];
-    st.finish(d);
+    for (int k = 0; k < 8; k++) { w[k] = acc[(uint64_t)k * stride + first + t]; w[8 + k] = 0u; }
+    blake2s_compress(h, w, 32u, true);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(d[i] >> (8 * k));
+        for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(h[i] >> (8 * k));
 }
-void launch_digest_root(hipStream_t s, const uint32_t *leaves, uint64_t stride, uint32_t first, uint32_t n, uint32_t n_seg, uint8_t *out) {
-    if (!n) return;
-    hipLaunchKernelGGL(digest_root_strided_kernel, dim3((n + 127) / 128), dim3(128), 0, s, leaves, stride, first, n, n_seg, out);
+__global__ void zero_u32_kernel(uint32_t *p, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
 }
-uint32_t digest_segments(uint32_t n_witnesses) { return (n_witnesses + DIGEST_SEG - 1) / DIGEST_SEG; }
+// acc: scratch of 8 x n words
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
-                   const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out) {
+                   const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *acc, uint8_t *out) {
     if (!n) return;
-    const uint32_t n_seg = digest_segments(n_witnesses);
-    for (uint32_t done = 0; done < n_seg; done += 65535u) {  // gridDim.y is limited to 65535
-        const uint32_t m = n_seg - done > 65535u ? 65535u : n_seg - done;
-        hipLaunchKernelGGL(digest_leaf_kernel, dim3((n + 127) / 128, m), dim3(128), 0, s, W, Bp, first, n, n_witnesses, producer, u, slow_index, assigned, n_slow,
-                           leaves, done);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((8ull * n + 255) / 256)), dim3(256), 0, s, acc, 8ull * n);
+    const uint32_t n_chunks = ((n_witnesses + 1) / 2 + DIGEST_CHUNK_PAIRS - 1) / DIGEST_CHUNK_PAIRS;
+    for (uint32_t done = 0; done < n_chunks; done += 65535u) {  // gridDim.y is limited to 65535
+        const uint32_t m = n_chunks - done > 65535u ? 65535u : n_chunks - done;
+        hipLaunchKernelGGL(digest_pairs_kernel, dim3((n + 127) / 128, m), dim3(128), 0, s, W, Bp, first, n, n_witnesses, producer, u, slow_index, assigned, n_slow,
+                           acc, done);
     }
-    hipLaunchKernelGGL(digest_root_kernel, dim3((n + 127) / 128), dim3(128), 0, s, leaves, n, n_seg, out);
+    hipLaunchKernelGGL(digest_final_kernel, dim3((n + 127) / 128), dim3(128), 0, s, acc, (uint64_t)n, 0u, n, out);
+}
+void launch_digest_fold_level(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
+                              const uint32_t *unscale_plain, uint32_t *acc) {
+    if (!n || !B) return;
+    for (uint32_t done = 0; done < n; done += 65535u) {
+        const uint32_t m = n - done > 65535u ? 65535u : n - done;
+        hipLaunchKernelGGL(digest_fold_level_kernel, dim3((B + 127) / 128, m), dim3(128), 0, s, W, Bp, B, dp.prog, offsets + done, dp.slot_of, unscale_plain, acc);
+    }
+}
+void launch_digest_final(hipStream_t s, const uint32_t *acc, uint64_t stride, uint32_t first, uint32_t n, uint8_t *out) {
+    if (!n) return;
+    hipLaunchKernelGGL(digest_final_kernel, dim3((n + 127) / 128), dim3(128), 0, s, acc, stride, first, n, out);
 }
 
 }  // namespace acvm

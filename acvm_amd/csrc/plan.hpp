@@ -81,7 +81,7 @@ struct Plan {
     std::vector<uint32_t> cls_scratch[N_CLS];
     std::vector<uint32_t> cls_level_start[N_CLS];  // size n_levels + 1
     uint32_t n_levels = 0;
-    uint32_t n_digest_segments = 0;             // fold_digest: leaves of the digest (segments of 256 witness indices)
+    uint32_t n_digest_segments = 0;             // fold_digest: records of digest leaves (up to 128 pairs of witnesses each)
     // reuse_slots: row of the witness table per witness (0xFFFFFFFF = never written by the level path), rows in total
     std::vector<uint32_t> slot_of;
     uint32_t n_slots = 0;

@@ -321,7 +321,7 @@ def main():
 
     # ---- CPU baseline + parity on a bounded sample of tile 0 (rank 0 only)
     cpu = parity = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is an N = 1 figure (rank 0 would keep the other ranks waiting)
         from oracle import binding as ob
         cores = os.cpu_count() or 1
         threads = min(cores, 64)

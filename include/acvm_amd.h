@@ -135,7 +135,7 @@ typedef struct {
     uint32_t n_scaled_witnesses; /* witnesses the level kernels keep as scale x value (unscaled on export and for the exact path) */
     uint32_t n_arith_launches; /* launches of arith_level_kernel per solve (levels that hold gates) */
     uint32_t n_table_rows;     /* rows of the device witness table: n_witnesses, or fewer with ACVM_BATCH_REUSE_SLOTS */
-    uint32_t n_digest_segments; /* leaves of the folded digest (ACVM_BATCH_FOLD_DIGEST), 0 if the digest is not folded */
+    uint32_t n_digest_segments; /* records of leaves of the folded digest (ACVM_BATCH_FOLD_DIGEST), 0 if the digest is not folded */
 } acvm_stats_t;
 
 const char *acvm_last_error(void);
@@ -282,11 +282,13 @@ int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t i
 /*
  * Per-instance 32-byte digest of the solved witness map for instances [first, first + n), out32 = [n][32] (SURVEY 8d, config 5:
  * callers that keep only the return witnesses use it to compare whole maps without moving them -- the map of the reference is
- * what ACVM::finalize returns, acvm/src/pwg/mod.rs:176-181). Definition: take the ASSIGNED witnesses in ascending index, each as
- * its 32-byte big-endian canonical value (FieldElement::to_be_bytes, acir_field/src/generic_ark.rs:269-277); leaf_k =
- * Blake2s-256 of those with index in [256 k, 256 k + 256), in order (an empty segment hashes the empty string);
- * digest = Blake2s-256(leaf_0 || leaf_1 || ... || leaf_{ceil(n_witnesses / 256) - 1}). Works for solved, failed and waiting
- * instances alike (the map as it stands).
+ * what ACVM::finalize returns, acvm/src/pwg/mod.rs:176-181). Definition: witnesses 2i and 2i + 1 form pair i, mask = 1 (2i is
+ * assigned) | 2 (2i + 1 is assigned); a pair with mask != 0 has the leaf Blake2s-256(message = the 32-byte big-endian canonical
+ * values (FieldElement::to_be_bytes, acir_field/src/generic_ark.rs:269-277) of its assigned witnesses in ascending order,
+ * personalisation = le32(i) || le32(mask)); S = the sum of all leaves read as eight little-endian 32-bit words, each word modulo
+ * 2^32; digest = Blake2s-256(S as eight little-endian words). (hashlib: blake2s(msg, person=struct.pack("<II", i, mask)).) The
+ * leaves are order-free, so the library hashes a pair as soon as both witnesses exist (ACVM_BATCH_FOLD_DIGEST) and may recycle
+ * their rows (ACVM_BATCH_REUSE_SLOTS). Works for solved, failed and waiting instances alike (the map as it stands).
  */
 int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32);
 /*

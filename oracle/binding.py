@@ -198,10 +198,17 @@ def solve_batch(circuit: Circuit, ids, values_be: bytes, B: int, want_witness=Tr
 
 def witness_map_digest(assigned, values) -> bytes:
     """CPU restatement (Python hashlib) of the definition of acvm_batch_digest in include/acvm_amd.h, for ONE instance -- checker only:
-    assigned[w] truthy, values[w] = 32 big-endian bytes."""
+    assigned[w] truthy, values[w] = 32 big-endian bytes. Pair i = witnesses (2i, 2i + 1); leaf = Blake2s-256 of the assigned values,
+    personalised with le32(i) || le32(mask); the leaves are summed as eight little-endian u32 words; digest = Blake2s-256(sum)."""
     import hashlib
+    import struct
     nw = len(assigned)
-    leaves = []
-    for k in range(0, nw, 256):
-        leaves.append(hashlib.blake2s(b"".join(bytes(values[w]) for w in range(k, min(k + 256, nw)) if assigned[w])).digest())
-    return hashlib.blake2s(b"".join(leaves)).digest()
+    total = [0] * 8
+    for i in range((nw + 1) // 2):
+        mask = (1 if assigned[2 * i] else 0) | (2 if 2 * i + 1 < nw and assigned[2 * i + 1] else 0)
+        if not mask:
+            continue
+        msg = (bytes(values[2 * i]) if mask & 1 else b"") + (bytes(values[2 * i + 1]) if mask & 2 else b"")
+        leaf = struct.unpack("<8I", hashlib.blake2s(msg, person=struct.pack("<II", i, mask)).digest())
+        total = [(a + b) & 0xFFFFFFFF for a, b in zip(total, leaf)]
+    return hashlib.blake2s(struct.pack("<8I", *total)).digest()

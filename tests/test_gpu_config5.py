@@ -1,4 +1,4 @@
-"""BASELINE config 5 at circuit size in the driver-run suite: the 10^6-opcode mixed circuit of acvm_amd.synth
+"""BASELINE config 5 at circuit size in the driver-run suite, with and without witness-slot liveness reuse: the 10^6-opcode mixed circuit of acvm_amd.synth
 (16 memory blocks x 64 cells with per-instance dynamic indices, ToLeRadix(256, 4 limbs), every opcode class), ONE tile of 4 096
 instances through the level kernels, per-instance digests of the witness maps, and an audit sample re-solved
 by the CPU oracle: status tuples, return witnesses and digests (hashlib over the oracle's full map) bit for bit."""
@@ -43,4 +43,20 @@ def test_million_opcode_tile_against_oracle_audit(oracle):
         if ores[i].status == 0:
             got = batch.extract(ret, j, 1)[0]
             assert all(bytes(got[n]) == bytes(ovals[i][w]) for n, w in enumerate(ret)), j
+    ret_plain = batch.extract(ret, 8, tile - 8)
     batch.free()
+    # The same circuit with witness-slot liveness reuse: about half the rows, so a tile of TWICE the instances in the
+    # same memory; digests folded into the solve. Its first 4 096 instances are the plain tile's: same results, digests, return values
+    # (the edge-case instances 0..7 are re-solved from their initial witnesses in the exact path's own table).
+    big = 2 * tile
+    reuse = acvm_amd.Batch(gc, big, ids, reuse_slots=True, keep=ret)
+    st = reuse.stats()
+    assert st["n_table_rows"] < 0.6 * st["n_witnesses"]
+    reuse.set_initial_witness(synth.witness_batch(big, seed=0xAC1D0005))
+    assert reuse.solve() == n_bad
+    res2 = reuse.results()
+    assert [r.as_tuple() for r in res2[:tile]] == [r.as_tuple() for r in res]
+    assert np.array_equal(reuse.digest(0, tile), dig)
+    assert np.array_equal(reuse.extract(ret, 8, tile - 8), ret_plain)
+    assert all(res2[j].status == 0 for j in range(tile, big))
+    reuse.free()

@@ -304,8 +304,18 @@ def device_count():
     return lib().acvm_device_count()
 
 
+_current_device = 0
+
+
 def set_device(i):
+    """hipSetDevice for the calling thread (HIP's current device is per thread: helper threads call this with current_device())"""
+    global _current_device
     _check(lib().acvm_set_device(i))
+    _current_device = i
+
+
+def current_device():
+    return _current_device
 
 
 def synchronize():

@@ -75,14 +75,38 @@ def solve_tiled(circuit, initial_ids, values_be: bytes, n_instances: int, tile: 
     batch = Batch(circuit, tile, ids, solver)
     results = []
     out = np.zeros((n_instances, len(keep), 32), dtype=np.uint8)
+    host = np.frombuffer(values_be, dtype=np.uint8)
+    # H2D of tile k + 1 runs beside the solve of tile k: two device staging buffers, the upload on a helper thread (hipMemcpy
+    # releases the GIL through ctypes)
+    import threading
+    stage = [DeviceBuffer(size=max(tile * row, 1)), DeviceBuffer(size=max(tile * row, 1))]
+
+    from . import current_device, set_device
+    dev = current_device()
+
+    def upload(slot, first):
+        set_device(dev)  # HIP's current device is per thread
+        n = min(tile, n_instances - first)
+        chunk = host[first * row:(first + n) * row]
+        stage[slot].upload(chunk)
+        if n < tile:  # the last tile is padded with copies of its first instance; the padding is dropped below
+            pad = np.tile(chunk[:row], tile - n)
+            stage[slot].upload(pad, offset=n * row)
+
     try:
-        for first in range(0, n_instances, tile):
+        firsts = list(range(0, n_instances, tile))
+        if firsts:
+            upload(0, firsts[0])
+        for k, first in enumerate(firsts):
             n = min(tile, n_instances - first)
-            chunk = values_be[first * row:(first + n) * row]
-            if n < tile:  # the last tile is padded with copies of its first instance; the padding is dropped below
-                chunk = chunk + chunk[:row] * (tile - n)
-            batch.set_initial_witness(chunk)
+            nxt = None
+            if k + 1 < len(firsts):
+                nxt = threading.Thread(target=upload, args=((k + 1) & 1, firsts[k + 1]))
+                nxt.start()
+            batch.set_initial_witness_device(stage[k & 1].ptr)
             batch.solve()
+            if nxt is not None:
+                nxt.join()
             res = batch.results()[:n]
             results.extend(res)
             if digests is not None:
@@ -98,11 +122,13 @@ def solve_tiled(circuit, initial_ids, values_be: bytes, n_instances: int, tile: 
                         if res[i].status != 0:
                             i += 1
                             continue
-                        k = i
-                        while k < n and res[k].status == 0:
-                            k += 1
-                        out[first + i:first + k] = batch.extract(keep, i, k - i)
-                        i = k
+                        e = i
+                        while e < n and res[e].status == 0:
+                            e += 1
+                        out[first + i:first + e] = batch.extract(keep, i, e - i)
+                        i = e
     finally:
         batch.free()
+        for d in stage:
+            d.free()
     return results, out

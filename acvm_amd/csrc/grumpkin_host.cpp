@@ -10,6 +10,7 @@
 //   * fixed-base multiplications (G, and D[0], D[3], D[6] of the Schnorr hash ladder) use 8-bit window tables
 //     T[w][d-1] = d * 2^(8w) * P, so a 256-bit scalar costs 32 mixed additions and no doubling.
 #include "grumpkin_host.hpp"
+#include <cstdlib>
 #include "fr_host.hpp"
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -248,6 +249,8 @@ std::map<int, GrumpkinTables> g_dev;
 
 }  // namespace
 
+void launch_grumpkin_win16_table(hipStream_t s, const GrumpkinTables &T, uint4 *out);  // kernels_grumpkin.hip
+
 const GrumpkinTables *grumpkin_tables() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_host_built) {
@@ -268,6 +271,18 @@ const GrumpkinTables *grumpkin_tables() {
     t.small = (const uint4 *)(d + g_host.small_off * 16);
     t.skew = (const uint4 *)(d + g_host.skew_off * 16);
     t.ped2 = nullptr;
+    t.win16 = nullptr;
+    {   // 16-bit window tables of the fixed bases (s * G of SchnorrVerify and FixedBaseScalarMul, the three generators of the hash
+        // ladder): memory for arithmetic, like the pair table -- 16 mixed additions per 256-bit scalar instead of 32. Without the
+        // memory the 8-bit windows stay in use.
+        uint4 *w16 = nullptr;
+        const size_t entries = (size_t)GRUMPKIN_N_WINDOW_BASES * GRUMPKIN_WIN16_STRIDE;
+        if (!getenv("ACVM_NO_WIN16") && hipMalloc((void **)&w16, entries * 64) == hipSuccess) {
+            launch_grumpkin_win16_table(nullptr, t, w16);
+            if (hipDeviceSynchronize() == hipSuccess) t.win16 = w16;
+            else hipFree(w16);
+        }
+    }
     auto ins = g_dev.emplace(dev, t);
     return &ins.first->second;
 }

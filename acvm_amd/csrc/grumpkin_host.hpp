@@ -17,7 +17,9 @@ struct GrumpkinTables {
     const uint4 *small;  // [3][15]: k * D[3j+1], k = 1..15
     const uint4 *skew;   // [3]: D[3j+2]
     const uint4 *ped2;   // [30][512][512] pair table of the level Pedersen kernel (grumpkin_pair_table), else nullptr
+    const uint4 *win16;  // [4][16][65535] 16-bit windows of the same four bases: T[w][d-1] = d * 2^(16w) * P (built on the device: 268 MB)
 };
+static constexpr uint32_t GRUMPKIN_WIN16_STRIDE = 16 * 65535;  // points per base
 static constexpr uint32_t GRUMPKIN_PED2_LOG2 = 18;  // entries per generator
 
 // tables of the current device (built on first use), nullptr on failure

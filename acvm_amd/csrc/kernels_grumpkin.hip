@@ -142,6 +142,29 @@ __global__ void __launch_bounds__(64) pedersen_pair_table_kernel(GrumpkinTables 
     p[2] = make_uint4(r.y.v[0], r.y.v[1], r.y.v[2], r.y.v[3]);
     p[3] = make_uint4(r.y.v[4], r.y.v[5], r.y.v[6], r.y.v[7]);
 }
+// 16-bit window tables (GrumpkinTables::win16): entry d of window w = d * 2^(16 w) * P = the sum of the two 8-bit window entries of its
+// bytes; one lane per entry, affine by one inversion
+__global__ void __launch_bounds__(64) grumpkin_win16_table_kernel(GrumpkinTables T, uint4 *__restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (e >= (uint64_t)GRUMPKIN_N_WINDOW_BASES * GRUMPKIN_WIN16_STRIDE) return;
+    const uint32_t base = (uint32_t)(e / GRUMPKIN_WIN16_STRIDE), rem = (uint32_t)(e % GRUMPKIN_WIN16_STRIDE);
+    const uint32_t w = rem / 65535u, d = rem % 65535u + 1u, lo = d & 255u, hi = d >> 8;
+    const uint4 *tbl = T.win + (uint64_t)base * GRUMPKIN_WIN_STRIDE * 4;
+    GJac acc = gj_inf();
+    if (lo) acc = gj_add_aff(acc, gaff_load(tbl, (2u * w) * 255u + lo - 1u));
+    if (hi) acc = gj_add_aff(acc, gaff_load(tbl, (2u * w + 1u) * 255u + hi - 1u));
+    bool inf;
+    const GAff r = gj_to_aff(acc, &inf);
+    uint4 *p = out + e * 4;
+    p[0] = make_uint4(r.x.v[0], r.x.v[1], r.x.v[2], r.x.v[3]);
+    p[1] = make_uint4(r.x.v[4], r.x.v[5], r.x.v[6], r.x.v[7]);
+    p[2] = make_uint4(r.y.v[0], r.y.v[1], r.y.v[2], r.y.v[3]);
+    p[3] = make_uint4(r.y.v[4], r.y.v[5], r.y.v[6], r.y.v[7]);
+}
+void launch_grumpkin_win16_table(hipStream_t s, const GrumpkinTables &T, uint4 *out) {
+    const uint64_t n = (uint64_t)GRUMPKIN_N_WINDOW_BASES * GRUMPKIN_WIN16_STRIDE;
+    hipLaunchKernelGGL(grumpkin_win16_table_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, T, out);
+}
 void launch_pedersen_pair_table(hipStream_t s, const GrumpkinTables &T, uint4 *out) {
     hipLaunchKernelGGL(pedersen_pair_table_kernel, dim3((30u << GRUMPKIN_PED2_LOG2) / 64), dim3(64), 0, s, T, out);
 }

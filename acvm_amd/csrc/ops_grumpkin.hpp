@@ -153,9 +153,26 @@ __device__ __forceinline__ Fr reduce_mod_q(Fr k) {  // 2^256 / q < 6
     return k;
 }
 
-// k * base for a 256-bit integer k with the 8-bit window table of `base_index` (0 = G, 1..3 = D[0], D[3], D[6])
+// k * base for a 256-bit integer k with the window tables of `base_index` (0 = G, 1..3 = D[0], D[3], D[6]): 16 mixed additions
+// through the 16-bit windows (268 MB of HBM for the four bases) when they were built, else 32 through the 8-bit windows
 __device__ __forceinline__ GJac fixed_base_mul(const GrumpkinTables &T, uint32_t base_index, const Fr &k) {
     GJac acc = gj_inf();
+    if (T.win16) {
+        const uint4 *t16 = T.win16 + (uint64_t)base_index * GRUMPKIN_WIN16_STRIDE * 4;
+        // the entries are 64-byte gathers from a 67 MB table (HBM or Infinity Cache latency): the next one is in flight while the
+        // current one is added (the address depends on the scalar only)
+        auto digit = [&](uint32_t w) { return (limb_at(k, w >> 1) >> (16u * (w & 1u))) & 0xffffu; };
+        uint32_t d = digit(0);
+        GAff cur = gaff_load(t16, d ? d - 1u : 0u);
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint32_t dn = w + 1 < 16 ? digit(w + 1) : 0u;
+            const GAff nxt = gaff_load(t16, (w + 1 < 16 ? (w + 1) * 65535u : 0u) + (dn ? dn - 1u : 0u));
+            if (d) acc = gj_add_aff(acc, cur);
+            cur = nxt;
+            d = dn;
+        }
+        return acc;
+    }
     const uint4 *tbl = T.win + (uint64_t)base_index * GRUMPKIN_WIN_STRIDE * 4;
     for (uint32_t w = 0; w < 32; w++) {
         const uint32_t d = (limb_at(k, w >> 2) >> (8u * (w & 3u))) & 0xffu;
@@ -410,6 +427,8 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
     }
     const GlvSplit sp = glv_split(e);
     const Fr29 beta = fr29_from(grumpkin_beta());
+    // (requesting both rows of a window before its four doublings -- their index depends on the scalar only -- was measured slower:
+    // 2.30 -> 2.37 ms per 65 536 verifications; the rows are loaded where they are added)
     for (int w = 31; w >= 0; w--) {
         a = gj_dbl(gj_dbl(gj_dbl(gj_dbl(a))));
         for (uint32_t half = 0; half < 2; half++) {  // wave-uniform

@@ -58,9 +58,9 @@ __device__ __forceinline__ GJac gj_dbl(const GJac &p) {
     r.Z = g29_red(fr29_dbll(fr29_mul(p.Y, p.Z)));                                              // 2 * 1.03 -> < 2
     return r;
 }
-// complete mixed addition (madd-2007-bl with the exceptional cases): 7M + 4S. q is a finite affine point.
-__device__ __forceinline__ GJac gj_add_aff(const GJac &p, const GAff &q) {
-    const Fr29 x2 = fr29_from(q.x), y2 = fr29_from(q.y);                                       // < 1
+// complete mixed addition (madd-2007-bl with the exceptional cases): 7M + 4S. (x2, y2) is a finite affine point in the working form
+// (limbs < 2p); *zr, when asked for, receives Z3 / Z1 = 2H (meaningful on the ordinary path only).
+__device__ __forceinline__ GJac gj_add_aff29(const GJac &p, const Fr29 &x2, const Fr29 &y2, Fr29 *zr = nullptr) {
     if (gj_is_inf(p)) return GJac{x2, y2, g29_one()};
     const Fr29 Z1Z1 = fr29_sqr(p.Z);                                                      // < 1.03
     const Fr29 U2 = fr29_mul(x2, Z1Z1), S2 = fr29_mul(fr29_mul(y2, p.Z), Z1Z1);                // < 1.02
@@ -81,7 +81,11 @@ __device__ __forceinline__ GJac gj_add_aff(const GJac &p, const GAff &q) {
         if (fr29_is_zero_mod_p(fr29_lt2p(rr))) return gj_dbl(p);
         return gj_inf();
     }
+    if (zr) *zr = g29_red(fr29_dbll(H));                                                       // < 2
     return o;
+}
+__device__ __forceinline__ GJac gj_add_aff(const GJac &p, const GAff &q) {
+    return gj_add_aff29(p, fr29_from(q.x), fr29_from(q.y));                                    // < 1
 }
 // complete Jacobian addition (add-2007-bl): 11M + 5S
 __device__ __forceinline__ GJac gj_add(const GJac &p, const GJac &q) {
@@ -396,10 +400,16 @@ __device__ __forceinline__ uint32_t nibble128(const uint32_t (&k)[4], uint32_t w
 }
 // With a window table (15 x 27 words per lane in device scratch, word-major like every per-lane buffer): e = k1 + k2 lambda
 // (GLV, |k1|, |k2| < 2^127), then 32 joint 4-bit windows: 4 doublings + the lane's table entry |k1|_w * P + the entry
-// |k2|_w * P mapped through (X, Y, Z) -> (beta X, Y, Z); a negative half negates Y. The instruction stream is the same on every
+// |k2|_w * P mapped through (x, y) -> (beta x, y); a negative half negates y. The instruction stream is the same on every
 // lane (bit-serial double-and-add makes the whole wave pay the addition on every bit: some lane always has the bit set), and
-// the split halves the doublings: 128 doublings + 64 additions instead of 256 + 64. Without a table (Brillig's black-box op):
-// double-and-add.
+// the split halves the doublings: 128 doublings + 64 additions instead of 256 + 64.
+// The 15 multiples are brought to ONE denominator so that the 64 additions are mixed ones (11 products instead of 16) without an
+// inversion: d P = (X_d, Y_d, Z_d) is built by the chain P, 2P, 2P + P, ... whose every step reports zr_d = Z_d / Z_(d-1); backwards,
+// s_d = Z_15 / Z_d = zr_15 ... zr_(d+1) and (X_d s_d^2, Y_d s_d^3, Z_15) is the same point. (x, y) -> (x Z_15^2, y Z_15^3) maps the curve
+// onto y^2 = x^3 - 17 Z_15^6, where those pairs are AFFINE points; doubling and addition for a = 0 never read the constant, so the
+// whole ladder runs there and the result (X, Y, Z) is the point (X, Y, Z Z_15) of Grumpkin. Table row d - 1 = {x_d, y_d, beta x_d}.
+// The group has prime order q and 0 < d < 16, so the chain never meets an exceptional case; the ladder's additions keep theirs.
+// Without a table (Brillig's black-box op): double-and-add.
 __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e, uint32_t *tbl, uint64_t Bp, uint64_t j) {
     GJac a = gj_inf();
     if (!tbl) {
@@ -409,24 +419,39 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
         }
         return a;
     }
-    auto put = [&](uint32_t d, const GJac &q) {  // entry d - 1 holds d * P
+    auto put = [&](uint32_t d, uint32_t field, const Fr29 &v) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            tbl[(uint64_t)((d - 1u) * 27u + k) * Bp + j] = q.X.v[k];
-            tbl[(uint64_t)((d - 1u) * 27u + 9 + k) * Bp + j] = q.Y.v[k];
-            tbl[(uint64_t)((d - 1u) * 27u + 18 + k) * Bp + j] = q.Z.v[k];
-        }
+        for (int k = 0; k < 9; k++) tbl[(uint64_t)((d - 1u) * 27u + field * 9u + k) * Bp + j] = v.v[k];
     };
-    GJac q = gj_add_aff(gj_inf(), P);
-    put(1, q);
-    q = gj_dbl(q);
-    put(2, q);
+    auto get = [&](uint32_t d, uint32_t field) {
+        Fr29 v;
+#pragma unroll
+        for (int k = 0; k < 9; k++) v.v[k] = tbl[(uint64_t)((d - 1u) * 27u + field * 9u + k) * Bp + j];
+        return v;
+    };
+    // forward: row d - 1 = {X_d, Y_d, zr_d}
+    const Fr29 px = fr29_from(P.x), py = fr29_from(P.y);
+    GJac q = GJac{px, py, g29_one()};
+    put(1, 0, q.X); put(1, 1, q.Y); put(1, 2, q.Z);
+    q = gj_dbl(q);                          // Z_2 = 2 y Z_1 = zr_2
+    put(2, 0, q.X); put(2, 1, q.Y); put(2, 2, q.Z);
     for (uint32_t d = 3; d < 16; d++) {
-        q = gj_add_aff(q, P);
-        put(d, q);
+        Fr29 zr = g29_one();
+        q = gj_add_aff29(q, px, py, &zr);
+        put(d, 0, q.X); put(d, 1, q.Y); put(d, 2, zr);
+    }
+    const Fr29 z15 = q.Z;
+    // backward: row d - 1 = {X_d s^2, Y_d s^3, beta X_d s^2}
+    const Fr29 beta = fr29_from(grumpkin_beta());
+    Fr29 sc = g29_one();
+    for (uint32_t d = 15; d >= 1; d--) {
+        const Fr29 zr = get(d, 2);
+        const Fr29 s2 = fr29_sqr(sc);
+        const Fr29 x = fr29_mul(get(d, 0), s2), y = fr29_mul(get(d, 1), fr29_mul(s2, sc));
+        put(d, 0, x); put(d, 1, y); put(d, 2, fr29_mul(x, beta));
+        sc = fr29_mul(sc, zr);
     }
     const GlvSplit sp = glv_split(e);
-    const Fr29 beta = fr29_from(grumpkin_beta());
     // (requesting both rows of a window before its four doublings -- their index depends on the scalar only -- was measured slower:
     // 2.30 -> 2.37 ms per 65 536 verifications; the rows are loaded where they are added)
     for (int w = 31; w >= 0; w--) {
@@ -435,21 +460,16 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
             const uint32_t d = half ? nibble128(sp.k2, (uint32_t)w) : nibble128(sp.k1, (uint32_t)w);
             const bool neg = half ? sp.neg2 : sp.neg1;
             if (d) {  // per lane: its own table row
-                GJac o;
+                const Fr29 x = get(d, half ? 2u : 0u);                     // lambda * (x, y) = (beta x, y)
+                Fr29 y = get(d, 1);
+                const Fr29 ny = fr29_norm(fr29_subl(g29_zero(), y, 1));    // 2p - y: in (0, 2p) since y != 0 (mod p) on this curve
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    o.X.v[k] = tbl[(uint64_t)((d - 1u) * 27u + k) * Bp + j];
-                    o.Y.v[k] = tbl[(uint64_t)((d - 1u) * 27u + 9 + k) * Bp + j];
-                    o.Z.v[k] = tbl[(uint64_t)((d - 1u) * 27u + 18 + k) * Bp + j];
-                }
-                if (half) o.X = fr29_mul(o.X, beta);                       // lambda * (X, Y, Z) = (beta X, Y, Z); < 1.4
-                const Fr29 ny = fr29_norm(fr29_subl(g29_zero(), o.Y, 1));  // 2p - Y: in (0, 2p) since Y != 0 (mod p) on this curve
-#pragma unroll
-                for (int k = 0; k < 9; k++) o.Y.v[k] = neg ? ny.v[k] : o.Y.v[k];
-                a = gj_add(a, o);
+                for (int k = 0; k < 9; k++) y.v[k] = neg ? ny.v[k] : y.v[k];
+                a = gj_add_aff29(a, x, y);
             }
         }
     }
+    a.Z = fr29_lt2p(fr29_mul(a.Z, z15));  // back from the scaled curve; infinity stays infinity
     return a;
 }
 

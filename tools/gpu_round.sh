@@ -14,6 +14,7 @@ for wl in hash grumpkin arith_pedersen mixed; do
 done
 # the driver's command under rocprofv3 (PMC passes of bench.py itself off: one trace of one process)
 ROOT=$(pwd)
+mkdir -p gpurun_out/prof_${TAG}_bench
 ( cd /tmp && ACVM_BENCH_NO_PMC=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_${TAG}_bench/trace" -o trace -- python $ROOT/bench.py --no-cpu-baseline > "$ROOT/gpurun_out/prof_${TAG}_bench/trace.log" 2>&1 )
 find gpurun_out/prof_${TAG}_bench -name '*.db' -delete
 # keep the stats and drop the per-launch trace if it is large

@@ -42,7 +42,7 @@ struct acvm_circuit {
     std::unique_ptr<Circuit> c;
 };
 
-struct LaunchChunk { uint32_t first, count; };  // records [first, first+count) of a class's level-major list
+struct LaunchChunk { uint32_t first, count; bool coop = false; };  // records [first, first+count) of a class's level-major list (coop: CLS_HASH records flagged PLAN_HASH_COOP_FLAG)
 struct ExactSegment { uint32_t cls, begin, end; };  // opcodes [begin, end): one light span or one heavy opcode
 
 struct acvm_batch {
@@ -426,6 +426,18 @@ static int batch_init(acvm_batch *b) {
         uint64_t need = 0;
         for (size_t L = 0; L < n_levels; L++) {
             uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
+            if (k == CLS_HASH) {  // byte-message hashes first: their own kernel, no scratch (the records of a level are independent)
+                auto is_coop = [&](uint32_t r) { return (b->plan.prog[b->plan.cls_offset[k][r] + 2] & PLAN_HASH_COOP_FLAG) != 0; };
+                std::vector<std::pair<uint32_t, uint32_t>> recs;  // (offset, scratch)
+                for (int pass = 0; pass < 2; pass++)
+                    for (uint32_t r = lo; r < hi; r++)
+                        if (is_coop(r) == (pass == 0)) recs.push_back({b->plan.cls_offset[k][r], b->plan.cls_scratch[k][r]});
+                uint32_t n_coop = 0;
+                for (uint32_t r = lo; r < hi; r++) n_coop += is_coop(r);
+                for (uint32_t r = lo; r < hi; r++) { b->plan.cls_offset[k][r] = recs[r - lo].first; b->plan.cls_scratch[k][r] = recs[r - lo].second; }
+                if (n_coop) b->cls_chunks[k][L].push_back({lo, n_coop, true});
+                lo += n_coop;
+            }
             uint32_t first = lo;
             uint64_t used = 0;
             for (uint32_t r = lo; r < hi; r++) {
@@ -465,6 +477,7 @@ static int batch_init(acvm_batch *b) {
     b->dp.ped_seed = nullptr;
     b->dp.fc_store = nullptr;
     b->dp.slot_of = nullptr;
+    b->dp.hash_coop_words = b->plan.hash_coop_words;
     if (p.n_digest_segments) HIPCHK(hipMalloc((void **)&b->d_leaves, (size_t)8 * b->Bp * 4));
     if (!p.slot_of.empty()) {
         if (int rc = upload(&b->d_slot_of, p.slot_of)) return rc;
@@ -1024,6 +1037,12 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     }
     hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_lane[N_HEAVY_LANES] = {nullptr, nullptr, nullptr, nullptr};
     bool main_dirty = false;  // the main stream has launches behind last_reg
+    // A lane waits for the main stream only as far as its records read it (plan.lane_needs_main): a hash of initial witnesses and of other
+    // hashes never waits for the range checks launched beside it (config 3: the Keccak level no longer starts behind the RANGE kernel).
+    // ACVM_LANE_LEVEL_BARRIER=1 restores "lane level L starts when main level L-1 is done" (measurement aid).
+    std::vector<std::pair<uint32_t, hipEvent_t>> main_marks;  // (L, event): "main levels < L are done", in order
+    uint32_t lane_main_waited[N_HEAVY_LANES] = {0, 0, 0, 0};
+    const bool level_barrier = getenv("ACVM_LANE_LEVEL_BARRIER") && atoi(getenv("ACVM_LANE_LEVEL_BARRIER"));
     uint32_t waited_inverse_level = 0, waited_heavy[N_HEAVY_LANES] = {0, 0, 0, 0}, lane_waited[N_HEAVY_LANES][N_HEAVY_LANES] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (size_t L = 0; L < n_levels; L++) {
         uint32_t n = p.level_start[L + 1] - p.level_start[L];
@@ -1039,6 +1058,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
         if ((nd || h_work) && main_dirty) {
             HIPCHK(hipEventRecord(b->ev_sync[2 * L], s));
             last_reg = b->ev_sync[2 * L];
+            main_marks.push_back({(uint32_t)L, last_reg});
             main_dirty = false;
         }
         hipEvent_t prev_reg = last_reg;
@@ -1067,7 +1087,16 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
         if (!one_stream)
             for (int q = 0; q < N_HEAVY_LANES; q++) {
                 if (!lane_used[q]) continue;
-                if (prev_reg) HIPCHK(hipStreamWaitEvent(lane_stream[q], prev_reg, 0));
+                if (level_barrier) {
+                    if (prev_reg) HIPCHK(hipStreamWaitEvent(lane_stream[q], prev_reg, 0));
+                } else if (const uint32_t need_m = p.lane_needs_main[q][L + 1]; need_m > lane_main_waited[q]) {
+                    // the earliest mark behind main level need_m (1-based): "levels < mark" with mark >= need_m
+                    auto it = std::lower_bound(main_marks.begin(), main_marks.end(), need_m, [](const std::pair<uint32_t, hipEvent_t> &mk, uint32_t v) { return mk.first < v; });
+                    if (it != main_marks.end()) {
+                        HIPCHK(hipStreamWaitEvent(lane_stream[q], it->second, 0));
+                        lane_main_waited[q] = it->first;
+                    }
+                }
                 for (int q2 = 0; q2 < N_HEAVY_LANES; q2++) {
                     const uint32_t need_l = p.lane_needs_lane[q][q2][L + 1];
                     if (q2 != q && lane_stream[q2] != lane_stream[q] && need_l > lane_waited[q][q2]) {
@@ -1084,7 +1113,10 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + ch.first;
                 switch (k) {
                 case CLS_LIGHT: launch_light_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                case CLS_HASH: launch_hash_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
+                case CLS_HASH:
+                    if (ch.coop) launch_hash_coop_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event);
+                    else launch_hash_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]);
+                    break;
                 case CLS_GRUMPKIN: launch_grumpkin_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                 case CLS_BRILLIG: launch_brillig_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                 case CLS_PEDERSEN: launch_pedersen_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;

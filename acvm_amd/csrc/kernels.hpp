@@ -53,6 +53,7 @@ struct DeviceProgram {
     const uint32_t *ped_seed;     // per Pedersen record: hash_single(x of hash_pair(IV[domain separator], n), 0), affine, 16 x u32
     const FcStoreSlot *fc_store;  // device array, one entry per Brillig opcode with a ForeignCall (null: the circuit has none)
     const uint32_t *slot_of;      // witness -> row of the table for the level kernels (null: row = witness index; plan.cpp slot reuse)
+    uint32_t hash_coop_words;     // Plan::hash_coop_words: LDS words per instance of the cooperative hash level kernel
 };
 
 // projective witnesses (plan.cpp): device tables behind the export and the hand-over to the exact path
@@ -88,6 +89,8 @@ void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
                         uint32_t *event);
 void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                        const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
+// records flagged HASH_COOP_FLAG (ops_hash.hpp): four waves per 64 instances, the byte message in LDS
+void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event);
 void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                            const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
 // Pedersen records: 4 waves per group of 64 instances, one accumulator chain each (kernels_grumpkin.hip)

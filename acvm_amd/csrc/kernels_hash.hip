@@ -1,6 +1,7 @@
 // kernels_hash.hip -- SHA256 / Blake2s / Keccak256(+variable length) / HashToField128Security opcodes
 // (acvm/src/pwg/blackbox/hash.rs; device routines in ops_hash.hpp), level kernel + exact kernel. The same scratch-carrying
 // kernels also run Directive::PermutationSort (ops_sort.hpp), the other opcode that needs per-lane working memory.
+#include <algorithm>
 #include "ops_hash.hpp"
 #include "ops_sort.hpp"
 #include "ops_kernel.hpp"
@@ -18,6 +19,74 @@ struct HashOp {
 void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                        const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch) {
     launch_record_level<HashOp, 128>(s, W, Bp, B, dp, offsets, scratch_off, n, event, scratch);
+}
+
+// Level kernel of the records flagged HASH_COOP_FLAG (byte messages of SHA256 / Blake2s / Keccak256; batch.cpp launches the two kinds of a
+// level separately). At the batch sizes of one tile a SIMD holds ONE wave of a lane-per-instance kernel, and a byte message costs that lane
+// one table row and one reduction per BYTE before the first compression: latency-bound on those rows (VALU 29 % busy). Here a block of four
+// waves serves 64 instances of one record: wave q fetches and reduces the bytes q, q + 4, q + 8, ... of every instance (four rows in flight per
+// lane, four times the waves in flight per SIMD) into the LDS message, wave 0 hashes, and the 32 digest bytes go back through LDS so that
+// wave q stores outputs 8q .. 8q + 7 (WAVES = 4). The hash bodies are inlined here under the kernel's register budget (four waves per SIMD = 128 VGPRs).
+// WAVES = 1 is the same kernel for launches that fill the chip anyhow (many records per level): one wave per 64 instances does every
+// phase, still with the message in LDS and the lean register budget (the lane-per-instance kernel with the message in device scratch
+// and 184 VGPRs measured 6.0 ms for the hash class of the config-5 mix at 2^16 instances).
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
+hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event) {
+    extern __shared__ uint32_t lds[];  // max(hash_coop_words + 1, 8) x 64 words
+    const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    const uint64_t j = (uint64_t)blockIdx.x * 64u + lane;
+    const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
+    FastPolicy p{W, Bp, j, dp.slot_of};
+    const uint32_t func = rec[2] & 0xffu, n_in = rec[3];
+    const uint32_t *ins = rec + 6, *outs = ins + 2 * n_in;
+    const bool live = j < B;  // (rows are padded to Bp: the loads of a dead lane stay inside the table)
+    uint8_t *bytes = (uint8_t *)lds;
+    if (q == 0 && (n_in & 3u)) lds[(n_in >> 2) * 64u + lane] = 0u;  // the bytes behind the message in its last word
+    __syncthreads();
+    for (uint32_t i = q; i < n_in; i += 4u * WAVES) {  // wave-uniform bounds
+        const uint32_t i1 = i + WAVES, i2 = i + 2u * WAVES, i3 = i + 3u * WAVES;
+        const Fr a0 = p.load(ins[2 * i]);
+        const Fr a1 = i1 < n_in ? p.load(ins[2 * i1]) : a0, a2 = i2 < n_in ? p.load(ins[2 * i2]) : a0, a3 = i3 < n_in ? p.load(ins[2 * i3]) : a0;
+        bytes[4u * ((i >> 2) * 64u + lane) + (i & 3u)] = (uint8_t)fr29_redc_low(fr29_from(a0));
+        if (i1 < n_in) bytes[4u * ((i1 >> 2) * 64u + lane) + (i1 & 3u)] = (uint8_t)fr29_redc_low(fr29_from(a1));
+        if (i2 < n_in) bytes[4u * ((i2 >> 2) * 64u + lane) + (i2 & 3u)] = (uint8_t)fr29_redc_low(fr29_from(a2));
+        if (i3 < n_in) bytes[4u * ((i3 >> 2) * 64u + lane) + (i3 & 3u)] = (uint8_t)fr29_redc_low(fr29_from(a3));
+    }
+    __syncthreads();
+    Digest d;
+    if (q == 0) {
+        const LdsMsg m{lds, lane};
+        if (func == 3u) d = sha256_body(m, n_in);
+        else if (func == 4u) d = blake2s_body(m, n_in);
+        else d = keccak256_body(m, n_in);
+    }
+    __syncthreads();  // the message has been read
+    if (q == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) lds[(uint32_t)k * 64u + lane] = d.d[k];
+    }
+    __syncthreads();
+    if (!live) return;
+    bool ok = true;
+    for (uint32_t k = 0; k < 32u / WAVES; k++) {
+        const uint32_t i = (32u / WAVES) * q + k;
+        const uint32_t byte = (lds[(i >> 2) * 64u + lane] >> (8u * (i & 3u))) & 0xffu;
+        ok = p.insert(outs[2 * i], fr_from_byte(byte), outs[2 * i + 1]) && ok;  // (hash.rs:92-103 stops at the first conflict; the flagged instance re-runs exactly)
+    }
+    if (!ok) atomicMin(&event[j], rec[1]);
+}
+void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event) {
+    if (!n || !B) return;
+    const size_t lds_bytes = (size_t)std::max<uint32_t>(dp.hash_coop_words + 1u, 8u) * 64u * 4u;
+    const uint64_t groups = (uint64_t)((B + 63u) / 64u) * n;  // one per 64 instances of a record
+    const bool four = groups * 4u <= 8192u;                    // four waves each while that still fits the chip about twice (1 024 SIMDs x 4-5 waves)
+    for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
+        const uint32_t m = n - done > 65535u ? 65535u : n - done;
+        if (four) hipLaunchKernelGGL(hash_coop_level_kernel<4>, dim3((B + 63u) / 64u, m), dim3(256), lds_bytes, s, W, Bp, B, dp, offsets + done, event);
+        else hipLaunchKernelGGL(hash_coop_level_kernel<1>, dim3((B + 63u) / 64u, m), dim3(64), lds_bytes, s, W, Bp, B, dp, offsets + done, event);
+        done += m;
+    }
 }
 void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch) {
     launch_record_exact<HashOp, 64>(s, W, Bp, dp, L, opcode, scratch);

@@ -37,6 +37,21 @@ struct MsgBuf {
     }
 };
 
+// the same message held in LDS by a block that serves 64 instances (kernels_hash.hip hash_coop_level_kernel): word wi of lane l at
+// words[wi * 64 + l], byte k of it at byte address 4 * (wi * 64 + l) + k -- conflict-free for both the byte writes and the word reads
+struct LdsMsg {
+    const uint32_t *words;
+    uint32_t lane;
+    __device__ __forceinline__ uint32_t word(uint32_t wi) const { return words[wi * 64u + lane]; }
+    __device__ __forceinline__ uint32_t word_le(uint32_t wi, uint32_t len) const {
+        if (4u * wi >= len) return 0u;
+        uint32_t v = word(wi);
+        const uint32_t k = len - 4u * wi;  // valid bytes
+        if (k < 4u) v &= (1u << (8u * k)) - 1u;
+        return v;
+    }
+};
+
 struct Digest {
     uint32_t d[8];  // byte i of the digest at bits 8 * (i % 4) of d[i / 4]
     __device__ __forceinline__ uint32_t byte(uint32_t i) const {
@@ -60,7 +75,8 @@ static __constant__ uint32_t SHA256_K[64] = {
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t n) { return __builtin_rotateright32(x, n); }
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 
-static inline __device__ __noinline__ Digest sha256_msg(const MsgBuf &m, uint32_t len) {
+template <class M>
+__device__ __forceinline__ Digest sha256_body(const M &m, uint32_t len) {
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     const uint32_t n_blocks = (len + 9u + 63u) / 64u;
     for (uint32_t b = 0; b < n_blocks; b++) {
@@ -148,7 +164,8 @@ __device__ __forceinline__ void blake2s_init(uint32_t (&h)[8]) {
     for (int i = 0; i < 8; i++) h[i] = IV[i];
     h[0] ^= 0x01010020u;  // digest length 32, no key, fanout 1, depth 1
 }
-static inline __device__ __noinline__ Digest blake2s_msg(const MsgBuf &m, uint32_t len) {
+template <class M>
+__device__ __forceinline__ Digest blake2s_body(const M &m, uint32_t len) {
     uint32_t h[8];
     blake2s_init(h);
     const uint32_t n_blocks = len == 0 ? 1u : (len + 63u) / 64u;
@@ -212,32 +229,47 @@ static __constant__ uint64_t KECCAK_RC[24] = {
 
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
 
-__device__ __forceinline__ void keccak_f1600(uint64_t s[25]) {
+// Keccak-f[1600] in place: theta, then rho and pi along the one 24-cycle of the lane permutation (two temporaries), then chi row by row
+// (five temporaries): ~75 live registers instead of a second copy of the state (the first version needed 184 VGPRs and capped the class's
+// kernels at two waves per SIMD). The round loop stays rolled.
+__device__ __forceinline__ void keccak_f1600(uint64_t (&s)[25]) {
+    constexpr int PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    constexpr int ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+#pragma unroll 1
     for (int round = 0; round < 24; round++) {
-        uint64_t C[5], D[5];
+        {
+            uint64_t C[5];
 #pragma unroll
-        for (int x = 0; x < 5; x++) C[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+            for (int x = 0; x < 5; x++) C[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
 #pragma unroll
-        for (int x = 0; x < 5; x++) D[x] = C[(x + 4) % 5] ^ rotl64(C[(x + 1) % 5], 1);
+            for (int x = 0; x < 5; x++) {
+                const uint64_t D = C[(x + 4) % 5] ^ rotl64(C[(x + 1) % 5], 1);
 #pragma unroll
-        for (int i = 0; i < 25; i++) s[i] ^= D[i % 5];
-        // rho + pi
-        uint64_t B[25];
-        constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+                for (int y = 0; y < 25; y += 5) s[x + y] ^= D;
+            }
+        }
+        uint64_t t = s[1];
 #pragma unroll
-        for (int x = 0; x < 5; x++)
+        for (int i = 0; i < 24; i++) {
+            const uint64_t b = s[PILN[i]];
+            s[PILN[i]] = rotl64(t, ROTC[i]);
+            t = b;
+        }
 #pragma unroll
-            for (int y = 0; y < 5; y++) B[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(s[x + 5 * y], RHO[x + 5 * y]);
-            // chi
-#pragma unroll
-        for (int y = 0; y < 5; y++)
-#pragma unroll
-            for (int x = 0; x < 5; x++) s[x + 5 * y] = B[x + 5 * y] ^ (~B[(x + 1) % 5 + 5 * y] & B[(x + 2) % 5 + 5 * y]);
+        for (int y = 0; y < 25; y += 5) {
+            const uint64_t a0 = s[y], a1 = s[y + 1], a2 = s[y + 2], a3 = s[y + 3], a4 = s[y + 4];
+            s[y] = a0 ^ (~a1 & a2);
+            s[y + 1] = a1 ^ (~a2 & a3);
+            s[y + 2] = a2 ^ (~a3 & a4);
+            s[y + 3] = a3 ^ (~a4 & a0);
+            s[y + 4] = a4 ^ (~a0 & a1);
+        }
         s[0] ^= KECCAK_RC[round];
     }
 }
 
-static inline __device__ __noinline__ Digest keccak256_msg(const MsgBuf &m, uint32_t len) {
+template <class M>
+__device__ __forceinline__ Digest keccak256_body(const M &m, uint32_t len) {
     uint64_t s[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) s[i] = 0;
@@ -265,6 +297,11 @@ static inline __device__ __noinline__ Digest keccak256_msg(const MsgBuf &m, uint
     return out;
 }
 
+// one copy per kernel for the lane-per-instance callers (several call sites each in the exact kernels and the Brillig VM)
+static inline __device__ __noinline__ Digest sha256_msg(const MsgBuf &m, uint32_t len) { return sha256_body(m, len); }
+static inline __device__ __noinline__ Digest blake2s_msg(const MsgBuf &m, uint32_t len) { return blake2s_body(m, len); }
+static inline __device__ __noinline__ Digest keccak256_msg(const MsgBuf &m, uint32_t len) { return keccak256_body(m, len); }
+
 // digest bytes as a big-endian integer reduced mod p (from_be_bytes_reduce, generic_ark.rs:281-283), Montgomery form
 __device__ __forceinline__ Fr digest_to_field(const Digest &d) {
     Fr c;
@@ -275,10 +312,12 @@ __device__ __forceinline__ Fr digest_to_field(const Digest &d) {
 
 // ------------------------------------------------------------------------------------------------ the opcode
 // [K_HASH, opcode, func, n_in, n_out, var_w, (w, num_bits) x n_in, (out, flag) x n_out]; func = BlackBoxFuncCall tag
-// (3 SHA256, 4 Blake2s, 7 HashToField128Security, 11 Keccak256, 12 Keccak256VariableLength)
+// (3 SHA256, 4 Blake2s, 7 HashToField128Security, 11 Keccak256, 12 Keccak256VariableLength), | HASH_COOP_FLAG when every input is one
+// byte wide, the function is 3, 4 or 11, n_out == 32 and 1 <= n_in <= 1024 (plan.cpp)
+static constexpr uint32_t HASH_COOP_FLAG = 0x100u;
 template <class P>
 __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restrict__ r, uint32_t *scratch) {
-    const uint32_t func = r[2], n_in = r[3], n_out = r[4], var_w = r[5];
+    const uint32_t func = r[2] & 0xffu, n_in = r[3], n_out = r[4], var_w = r[5];  // bit 8: HASH_COOP_FLAG, a hint for the level kernel
     const uint32_t *ins = r + 6, *outs = ins + 2 * n_in;
     if (P::exact) {  // blackbox/mod.rs:55-62, get_inputs_vec order: inputs, then var_message_size
         for (uint32_t i = 0; i < n_in; i++)

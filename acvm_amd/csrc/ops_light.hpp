@@ -25,7 +25,16 @@ template <class P>
 __device__ __forceinline__ OpResult op_range(const P &p, const uint32_t *__restrict__ r) {
     OpResult pre = bb_inputs_assigned(p, r + 2, 1, 1);
     if (pre.err) return pre;
-    if (canon_num_bits(fr_to_canonical(p.load(r[2]))) > r[3]) return op_fail(DE_UNSATISFIED);
+    const Fr a = p.load(r[2]);
+    if (r[3] <= 8u) {
+        // byte-sized ranges (the bulk of a hashing circuit): only the low limb of the canonical value is formed (44 multiply-adds instead of
+        // a full reduction); the value is below 2^bits exactly when that limb is and the stored Montgomery form is the one of that small
+        // number (the representation is a bijection), which the 8 KiB byte table holds
+        const uint32_t low = fr29_redc_low(fr29_from(a));
+        if ((low >> r[3]) != 0u || !fr_eq(a, fr_from_byte(low))) return op_fail(DE_UNSATISFIED);
+        return op_ok();
+    }
+    if (canon_num_bits(fr_to_canonical(a)) > r[3]) return op_fail(DE_UNSATISFIED);
     return op_ok();
 }
 

@@ -281,13 +281,19 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     out(b.out[0]);
                     break;
                 case BB_SHA256: case BB_BLAKE2S: case BB_KECCAK256: case BB_KECCAK256_VAR: case BB_HASH_TO_FIELD_128: {
-                    // [PK_HASH, oi, func, n_in, n_out, var_w (or NONE), (w, num_bits) x n_in, (out, flag) x n_out]
+                    // [PK_HASH, oi, func (| PLAN_HASH_COOP_FLAG), n_in, n_out, var_w (or NONE), (w, num_bits) x n_in, (out, flag) x n_out]
                     p.prog_class[oi] = CLS_HASH;
                     uint64_t bytes = 0;
                     for (auto &in : b.in[0]) bytes += std::min<uint32_t>((in.num_bits + 7) / 8, 32);
                     if (bytes > (1u << 24)) { unsupported(oi, "hash input above 16 MiB"); }
                     p.prog_scratch[oi] = (uint32_t)((bytes + 3) / 4 + 1);
-                    s.insert(s.end(), {PK_HASH, oi, b.func, (uint32_t)b.in[0].size(), (uint32_t)b.out.size(),
+                    // byte messages (every input one byte wide) of the three plain hashes: the level kernel unpacks them with four
+                    // waves per 64 instances through LDS (kernels_hash.hip hash_coop_level_kernel); bit 8 of the function word says so
+                    bool coop = (b.func == BB_SHA256 || b.func == BB_BLAKE2S || b.func == BB_KECCAK256) && b.out.size() == 32 &&
+                                !b.in[0].empty() && b.in[0].size() <= PLAN_HASH_COOP_MAX_BYTES;
+                    for (auto &in : b.in[0]) coop = coop && in.num_bits >= 1 && in.num_bits <= 8;
+                    if (coop) p.hash_coop_words = std::max<uint32_t>(p.hash_coop_words, (uint32_t)(b.in[0].size() + 3) / 4);
+                    s.insert(s.end(), {PK_HASH, oi, b.func | (coop ? PLAN_HASH_COOP_FLAG : 0u), (uint32_t)b.in[0].size(), (uint32_t)b.out.size(),
                                        b.func == BB_KECCAK256_VAR ? b.in[1][0].witness : 0xFFFFFFFFu});
                     for (auto &in : b.in[0]) { s.push_back(in.witness); s.push_back(in.num_bits); }
                     for (uint32_t w : b.out) out(w);
@@ -1091,6 +1097,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         p.level_needs_heavy[q].assign(max_level + 1, 0);
         p.inv_needs_heavy[q].assign(max_level + 1, 0);
         for (int q2 = 0; q2 < N_HEAVY_LANES; q2++) p.lane_needs_lane[q][q2].assign(max_level + 1, 0);
+        p.lane_needs_main[q].assign(max_level + 1, 0);
     }
     auto needs = [&](std::vector<uint32_t> (&tab)[N_HEAVY_LANES], uint32_t at, uint32_t w) {
         if (wlane[w]) tab[wlane[w] - 1][at] = std::max(tab[wlane[w] - 1][at], heavy_level[w]);
@@ -1101,10 +1108,17 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     }
     for (auto &hr : heavy_reads) needs(p.level_needs_heavy, hr.first, hr.second);
     for (auto &iv : inverses) needs(p.inv_needs_heavy, iv.level, iv.partner);
-    for (auto &r : records)
-        if (is_heavy(r.cls))
-            for (uint32_t w : r.reads)
-                if (wlane[w] && wlane[w] - 1 != heavy_lane(r.cls)) needs(p.lane_needs_lane[heavy_lane(r.cls)], r.level, w);
+    for (auto &r : records) {
+        if (!is_heavy(r.cls)) continue;
+        for (uint32_t w : r.reads) {
+            if (wlane[w]) {
+                    if (wlane[w] - 1 != heavy_lane(r.cls)) needs(p.lane_needs_lane[heavy_lane(r.cls)], r.level, w);
+                } else if (p.producer[w] != 0xFFFFFFFFu) {  // written by a gate or a light record (an initial witness is there before the solve)
+                    uint32_t &m = p.lane_needs_main[heavy_lane(r.cls)][r.level];
+                    m = std::max(m, wdef[w]);
+                }
+        }
+    }
     // =========================================================================== witness-slot liveness reuse
     // A witness occupies a row of the table from the level that writes it to the level of its last reader; the rows of dead
     // witnesses go to a FIFO and are handed to the witnesses the MAIN stream defines later (gates, light records). The main stream

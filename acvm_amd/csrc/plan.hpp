@@ -36,6 +36,8 @@ enum GateKind : uint32_t { GATE_ASSERT = 0, GATE_SOLVE = 1, GATE_SOLVE_DYN = 2 }
 // Inversion job (inverse_batch_kernel): [denominator witness, opcode index, inverse slot]
 static constexpr uint32_t GATE_HDR_WORDS = 5;
 
+static constexpr uint32_t PLAN_HASH_COOP_FLAG = 0x100u;      // PK_HASH function word: byte message, unpacked through LDS by the level kernel
+static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 16 KiB of LDS per 64 instances
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
 enum ProgKind : uint32_t {
     PK_ARITH = 0, PK_RANGE = 1, PK_LOGIC = 2, PK_HASH = 3, PK_PEDERSEN = 4, PK_FIXED_BASE = 5, PK_SCHNORR = 6, PK_ZERO_OUT = 7,
@@ -65,6 +67,7 @@ struct Plan {
     std::vector<uint32_t> level_needs_heavy[4];   // [lane]: the latest level of the lane whose outputs the main stream's level L reads
     std::vector<uint32_t> inv_needs_heavy[4];     // same for the inversion batch of level L
     std::vector<uint32_t> lane_needs_lane[4][4];  // [q][q']: the latest level of lane q' whose outputs the records of lane q at level L read
+    std::vector<uint32_t> lane_needs_main[4];     // [q]: the latest level of the MAIN stream (gates, light records) whose outputs they read
     std::vector<FrH> constants;                 // Montgomery-form circuit constants
     // ---- projective witnesses (plan.cpp): the level kernels keep witness w as scale_w * value wherever only Arithmetic
     // gates touch it, so that a gate's most expensive coefficient becomes 1. Export and the exact path multiply by 1 / scale.
@@ -102,6 +105,7 @@ struct Plan {
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;
+    uint32_t hash_coop_words = 0;  // 32-bit message words per instance of the longest hash record flagged PLAN_HASH_COOP_FLAG
     std::vector<std::pair<uint32_t, uint32_t>> pedersen_seeds;  // per Pedersen record: (number of inputs, domain separator)
     // Brillig foreign calls: function name per (opcode << 32 | bytecode index), buffer sizes of the wait / resolve round trip
     bool has_foreign_calls = false;

@@ -69,6 +69,26 @@ def test_range_and_logic(oracle):
     assert ores[3].status == 2 and ores[3].opcode_index == 0 and ores[4].opcode_index == 1 and ores[5].status == 0
 
 
+def test_small_range_edges(oracle):
+    """RANGE with 0..8 bits takes the low-limb check (ops_light.hpp op_range): values whose low bits are in range but whose upper bits are not,
+    the multiples of 2^29 and 2^32 around the limb boundaries, p - 1, and the exact boundary 2^bits - 1 / 2^bits for every width."""
+    ops = [BB("RANGE", {"input": FI(1 + b, b)}) for b in range(9)]
+    circ = Circuit(9, ops)
+    ids = list(range(1, 10))
+    rows = []
+    for b in range(9):                       # boundary of width b at witness 1 + b; the other witnesses zero
+        for v in ((1 << b) - 1, 1 << b):
+            row = [0] * 9
+            row[b] = v
+            rows.append(row)
+    for hi in (1 << 29, 1 << 32, 1 << 58, 1 << 64, 1 << 253, P - 1, P - 256, (1 << 29) + 5, (1 << 200) + 255):
+        rows.append([0] * 8 + [hi])                  # low bits of RANGE(8)'s input in range, the value is not
+        rows.append([hi & 0] * 8 + [hi & 0xff])      # and the byte alone: passes
+    ores, _ = both_paths(oracle, circ, ids, rows)
+    for b in range(9):
+        assert ores[2 * b].status == 0 and ores[2 * b + 1].status == 2 and ores[2 * b + 1].opcode_index == b
+
+
 def test_logic_bit_mismatch_panics(oracle):
     circ = Circuit(3, [BB("AND", {"lhs": FI(1, 8), "rhs": FI(2, 16), "output": 3})])
     ores, _ = both_paths(oracle, circ, [1, 2], [[1, 2]] * 3)

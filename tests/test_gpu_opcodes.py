@@ -200,6 +200,54 @@ def test_hash_opcodes(oracle, name, n):
             assert bytes(vals[j, n + 1:n + 33, 31]) == h(bytes(rows[j])).digest()
 
 
+def test_hash_byte_messages_four_wave_kernel(oracle):
+    """The level kernel of byte messages (kernels_hash.hip hash_coop_level_kernel): widths 1..8 bits with arbitrary field values behind them
+    (fetch_nearest_bytes keeps the low byte whatever num_bits says), lengths around the word and block boundaries, an output that is also an
+    input (insert_value compares), three hashes in one level, a batch that is not a multiple of 64."""
+    r = rnd(77)
+    n = 71
+    ids = list(range(1, n + 1))
+    widths = [1 + (k % 8) for k in range(n)]
+    o = n + 1
+    ops = [BB("SHA256", {"inputs": [FI(w, b) for w, b in zip(ids, widths)], "outputs": list(range(o, o + 32))}),
+           BB("Keccak256", {"inputs": [FI(w, b) for w, b in zip(ids[:67], widths)], "outputs": list(range(o + 32, o + 64))}),
+           BB("Blake2s", {"inputs": [FI(w, b) for w, b in zip(ids[:65], widths)], "outputs": [ids[70]] + list(range(o + 64, o + 95))}),
+           BB("Keccak256", {"inputs": [FI(w, 8) for w in range(o, o + 64)], "outputs": list(range(o + 95, o + 127))})]  # second level
+    circ = Circuit(o + 127, ops)
+    rows = [[r.randrange(P) if r.random() < 0.5 else r.randrange(256) for _ in range(n)] for _ in range(131)]
+    import hashlib as hl
+    for j in (4, 9, 130):  # make the compared output right for some instances: Blake2s digest byte 0 == witness 71
+        rows[j][70] = hl.blake2s(bytes(v & 0xff for v in rows[j][:65])).digest()[0]
+    ores, stats = both_paths(oracle, circ, ids, rows)
+    assert ores[4].status == 0 and ores[9].status == 0 and ores[130].status == 0
+    assert sum(1 for x in ores if x.status == 2) >= 100  # the others fail at the Blake2s opcode (index 2) unless the byte happens to match
+    assert all(x.opcode_index == 2 for x in ores if x.status == 2)
+
+
+@pytest.mark.parametrize("n", [1023, 1024, 1025])
+def test_hash_byte_message_length_limit(oracle, n):
+    """1024 bytes is the longest message the four-wave kernel takes (16 KiB of LDS per 64 instances); 1025 goes lane-per-instance."""
+    r = rnd(n)
+    ids = list(range(1, n + 1))
+    circ = Circuit(n + 32, [BB("Keccak256", {"inputs": [FI(w, 8) for w in ids], "outputs": list(range(n + 1, n + 33))})])
+    both_paths(oracle, circ, ids, _hash_rows(r, 67, n))
+
+
+def test_hash_many_records_one_wave_instantiation(oracle):
+    """more than 2 048 (record, 64 instances) groups in one launch: the one-wave instantiation of the same kernel"""
+    r = rnd(5)
+    n, n_rec = 24, 40
+    ids = list(range(1, n + 1))
+    ops = []
+    for k in range(n_rec):
+        name = ("SHA256", "Keccak256", "Blake2s")[k % 3]
+        ops.append(BB(name, {"inputs": [FI(ids[(i + k) % n], 8) for i in range(5 + k % 19)], "outputs": list(range(n + 1 + 32 * k, n + 33 + 32 * k))}))
+    circ = Circuit(n + 32 * n_rec, ops)
+    B = 64 * 52 + 3  # 53 groups x 40 records = 2 120 groups
+    ores, _ = run_both(oracle, circ, ids, _hash_rows(r, B, n))
+    assert all(x.status == 0 for x in ores)
+
+
 def test_hash_mixed_widths_and_field_inputs(oracle):
     """fetch_nearest_bytes with num_bits != 8: multi-byte little-endian packing, truncation of wide values."""
     r = rnd(7)

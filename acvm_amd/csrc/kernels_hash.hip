@@ -33,7 +33,7 @@ void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const D
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
 hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event) {
-    extern __shared__ uint32_t lds[];  // max(hash_coop_words + 1, 8) x 64 words
+    extern __shared__ uint32_t lds[];  // max(hash_coop_words, 8) x 64 words
     const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
     const uint64_t j = (uint64_t)blockIdx.x * 64u + lane;
     const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
@@ -78,7 +78,7 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, cons
 }
 void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event) {
     if (!n || !B) return;
-    const size_t lds_bytes = (size_t)std::max<uint32_t>(dp.hash_coop_words + 1u, 8u) * 64u * 4u;
+    const size_t lds_bytes = (size_t)std::max<uint32_t>(dp.hash_coop_words, 8u) * 64u * 4u;
     const uint64_t groups = (uint64_t)((B + 63u) / 64u) * n;  // one per 64 instances of a record
     const bool four = groups * 4u <= 8192u;                    // four waves each while that still fits the chip about twice (1 024 SIMDs x 4-5 waves)
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535

@@ -20,7 +20,8 @@ static constexpr uint32_t K_NONE = 0xFFFFFFFFu;
 // record kinds of the in-order program (w0 of each record; w1 = unused for ARITH, see plan.cpp)
 enum RecKind : uint32_t {
     K_ARITH = 0, K_RANGE = 1, K_LOGIC = 2, K_HASH = 3, K_PEDERSEN = 4, K_FIXED_BASE = 5, K_SCHNORR = 6, K_ZERO_OUT = 7,
-    K_QUOTIENT = 8, K_TO_LE_RADIX = 9, K_MEM_INIT = 10, K_MEM_OP = 11, K_BRILLIG = 12, K_ECDSA = 13, K_PERM_SORT = 14
+    K_QUOTIENT = 8, K_TO_LE_RADIX = 9, K_MEM_INIT = 10, K_MEM_OP = 11, K_BRILLIG = 12, K_ECDSA = 13, K_PERM_SORT = 14,
+    K_DIGEST_LEAF = 15, K_RANGE_MULTI = 16  // level-schedule records without an opcode of their own (plan.cpp)
 };
 
 // error codes = ACVM_ERR_* of include/acvm_amd.h

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t 
     uint32_t *sc = scratch ? scratch + (uint64_t)scratch_off[blockIdx.y] * Bp : nullptr;
     FastPolicy p{W, Bp, j, dp.slot_of};
     const OpResult r = Op::run(p, rec, dp, sc, (SlowResult *)nullptr, (const ExactLanes *)nullptr, 0u);
-    if (r.err) atomicMin(&event[j], rec[1]);
+    if (r.err) atomicMin(&event[j], rec[0] == K_RANGE_MULTI ? r.aux0 : rec[1]);  // (a merged record names the failing opcode itself)
 }
 
 template <class Op, int BLOCK>

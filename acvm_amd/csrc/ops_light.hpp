@@ -38,6 +38,34 @@ __device__ __forceinline__ OpResult op_range(const P &p, const uint32_t *__restr
     return op_ok();
 }
 
+// [K_RANGE_MULTI, first opcode, n, (opcode, witness, num_bits) x n]: up to 8 RANGE opcodes of one level in one lane (level schedule only:
+// plan.cpp merges them so that a wave pays its launch and its dependent record / row latencies once per eight checks, with four rows in
+// flight). Fails with aux0 = the first (lowest) failing opcode, which record_level_kernel turns into the instance's event.
+template <class P>
+__device__ __forceinline__ OpResult op_range_multi(const P &p, const uint32_t *__restrict__ r) {
+    const uint32_t n = r[2];
+    const uint32_t *it = r + 3;
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n; i += 4u) {
+        Fr a[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) a[k] = p.load(it[3u * (i + k < n ? i + k : i) + 1u]);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            if (i + k >= n) continue;
+            const uint32_t bits = it[3u * (i + k) + 2u];
+            bool ok;
+            if (bits <= 8u) {
+                const uint32_t low = fr29_redc_low(fr29_from(a[k]));
+                ok = (low >> bits) == 0u && fr_eq(a[k], fr_from_byte(low));
+            } else ok = canon_num_bits(fr_to_canonical(a[k])) <= bits;
+            if (!ok) bad = min(bad, it[3u * (i + k)]);
+        }
+    }
+    if (bad != 0xFFFFFFFFu) return op_fail(DE_UNSATISFIED, bad);
+    return op_ok();
+}
+
 // mask_vector_le (generic_ark.rs:446-473) on a canonical integer: keep the low num_bits bits
 __device__ __forceinline__ Fr canon_mask(const Fr &c, uint32_t num_bits) {
     Fr r;
@@ -400,6 +428,7 @@ __device__ __forceinline__ OpResult dispatch_light(const P &p, const uint32_t *_
     switch (r[0]) {
     case K_ARITH: return op_arith(p, r, consts);
     case K_RANGE: return op_range(p, r);
+    case K_RANGE_MULTI: return op_range_multi(p, r);
     case K_LOGIC: return op_logic(p, r);
     case K_ZERO_OUT: return op_zero_out(p, r);
     case K_QUOTIENT: return op_quotient(p, r, consts);

@@ -102,6 +102,7 @@ static void for_each_operand_word(std::vector<uint32_t> &w, F fn) {
 struct PendingRecord {
     uint32_t level, cls, opcode;
     std::vector<uint32_t> reads;  // witnesses it reads (compared outputs included)
+    bool synthetic = false;       // a level-schedule record without an opcode of its own (digest leaves, merged RANGE checks): `opcode` is its offset in prog
 };
 // inversion of a SOLVE_DYN gate's denominator: runs beside level `level`, its result is read by gate `gate` at `use_level`
 struct PendingInverse {
@@ -1055,6 +1056,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             for (size_t at = 0; at < kv.second.size(); at += PAIRS_PER_RECORD) {
                 PendingRecord r;
                 r.cls = CLS_DIGEST;
+                r.synthetic = true;
                 r.opcode = (uint32_t)p.prog.size();  // offset of the record: digest records have no opcode
                 r.level = kv.first;
                 const size_t n = std::min<size_t>(PAIRS_PER_RECORD, kv.second.size() - at);
@@ -1073,6 +1075,48 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 records.push_back(std::move(r));
                 p.n_digest_segments++;
             }
+    }
+    // =========================================================================== RANGE opcodes of a level, eight to a record
+    // A RANGE check is one row and a few dozen instructions: launched one lane per (opcode, instance) the kernel is bound by the chain of
+    // dependent latencies every wave pays before its only load (config 3: 96 checks per instance). Merged records
+    // [PK_RANGE_MULTI, first opcode, n, (opcode, witness, num_bits) x n] keep four rows in flight per lane. The exact path keeps the
+    // opcode's own record.
+    if (!getenv("ACVM_NO_RANGE_MERGE")) {
+        std::map<uint32_t, std::vector<size_t>> by_level;
+        for (size_t i = 0; i < records.size(); i++)
+            if (!records[i].synthetic && records[i].cls == CLS_LIGHT && p.prog[p.prog_offset[records[i].opcode]] == PK_RANGE) by_level[records[i].level].push_back(i);
+        std::vector<uint8_t> drop(records.size(), 0);
+        std::vector<PendingRecord> merged;
+        constexpr size_t RANGES_PER_RECORD = 8;
+        for (auto &kv : by_level) {
+            if (kv.second.size() < 2) continue;
+            for (size_t at = 0; at < kv.second.size(); at += RANGES_PER_RECORD) {
+                const size_t n = std::min(RANGES_PER_RECORD, kv.second.size() - at);
+                PendingRecord m;
+                m.level = kv.first;
+                m.cls = CLS_LIGHT;
+                m.synthetic = true;
+                m.opcode = (uint32_t)p.prog.size();
+                p.prog.insert(p.prog.end(), {PK_RANGE_MULTI, records[kv.second[at]].opcode, (uint32_t)n});
+                for (size_t k = 0; k < n; k++) {
+                    const PendingRecord &r = records[kv.second[at + k]];
+                    const uint32_t *rec = &p.prog[p.prog_offset[r.opcode]];  // [PK_RANGE, opcode, witness, num_bits]
+                    const uint32_t w = rec[2], bits = rec[3];
+                    p.prog.insert(p.prog.end(), {r.opcode, w, bits});
+                    m.reads.insert(m.reads.end(), r.reads.begin(), r.reads.end());
+                    drop[kv.second[at + k]] = 1;
+                }
+                merged.push_back(std::move(m));
+            }
+        }
+        if (!merged.empty()) {
+            std::vector<PendingRecord> kept;
+            kept.reserve(records.size());
+            for (size_t i = 0; i < records.size(); i++)
+                if (!drop[i]) kept.push_back(std::move(records[i]));
+            for (auto &m : merged) kept.push_back(std::move(m));
+            records.swap(kept);
+        }
     }
     // =========================================================================== order by (level, program order), lay out
     // within a level the longest wave programs (hosts with tails, many terms) go first: blocks are dispatched in grid order,
@@ -1151,7 +1195,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             const int async = heavy ? 1 + heavy_lane(r.cls) : -1;
             if (!(r.cls == CLS_DIGEST && getenv("ACVM_REUSE_IGNORE_DIGEST")))  // (measurement only: rows as if no digest were kept)
                 for (uint32_t w : r.reads) note(w, r.level, async);
-            if (r.cls == CLS_DIGEST) continue;
+            if (r.synthetic) continue;
             for (auto &slot : out_slots[r.opcode])
                 if (p.producer[slot.second] == r.opcode) {
                     (heavy ? def_heavy : def_main)[r.level].push_back(slot.second);
@@ -1230,8 +1274,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         for (; ri < records.size() && records[ri].level == L; ri++) {
             const PendingRecord &r = records[ri];
-            p.cls_offset[r.cls].push_back(r.cls == CLS_DIGEST ? r.opcode : p.prog_offset[r.opcode]);
-            p.cls_scratch[r.cls].push_back(r.cls == CLS_DIGEST ? 0u : p.prog_scratch[r.opcode]);
+            p.cls_offset[r.cls].push_back(r.synthetic ? r.opcode : p.prog_offset[r.opcode]);
+            p.cls_scratch[r.cls].push_back(r.synthetic ? 0u : p.prog_scratch[r.opcode]);
             width[L]++;
         }
     }

@@ -41,7 +41,7 @@ static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 16 KiB of LDS pe
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
 enum ProgKind : uint32_t {
     PK_ARITH = 0, PK_RANGE = 1, PK_LOGIC = 2, PK_HASH = 3, PK_PEDERSEN = 4, PK_FIXED_BASE = 5, PK_SCHNORR = 6, PK_ZERO_OUT = 7,
-    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12, PK_ECDSA = 13, PK_PERM_SORT = 14, PK_DIGEST_LEAF = 15
+    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12, PK_ECDSA = 13, PK_PERM_SORT = 14, PK_DIGEST_LEAF = 15, PK_RANGE_MULTI = 16
 };
 // kernel classes of the non-arithmetic records
 // CLS_PEDERSEN only exists in the level schedule (its own 4-waves-per-instance-group kernel); the exact path and the

@@ -103,6 +103,7 @@ struct PendingRecord {
     uint32_t level, cls, opcode;
     std::vector<uint32_t> reads;  // witnesses it reads (compared outputs included)
     bool synthetic = false;       // a level-schedule record without an opcode of its own (digest leaves, merged RANGE checks): `opcode` is its offset in prog
+    uint32_t prog_at = 0xFFFFFFFFu;  // the level schedule runs this copy of the opcode's record instead (a hash record extended by fused RANGE checks)
 };
 // inversion of a SOLVE_DYN gate's denominator: runs beside level `level`, its result is read by gate `gate` at `use_level`
 struct PendingInverse {
@@ -1076,6 +1077,61 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 p.n_digest_segments++;
             }
     }
+    // =========================================================================== byte RANGE checks fused into the hash that reads the byte
+    // RANGE(w, <= 8 bits) on an input of a byte-message hash (the usual shape: every message byte is range-checked) reads the row the hash
+    // kernel reads anyway and needs the low limb it forms anyway: the level schedule runs a copy of the hash record extended by
+    // (RANGE opcode, bits) per input (function word | PLAN_HASH_RANGE_FLAG) and drops the RANGE record; a failing check flags the instance
+    // with the RANGE opcode's index, exactly as its own record would. A check may move to a later level this way (nothing reads a RANGE).
+    if (!getenv("ACVM_NO_RANGE_FUSE")) {
+        std::unordered_map<uint32_t, std::vector<size_t>> range_of;  // witness -> RANGE records (bits <= 8) not yet fused
+        for (size_t i = 0; i < records.size(); i++) {
+            const PendingRecord &r = records[i];
+            if (r.synthetic || r.cls != CLS_LIGHT) continue;
+            const uint32_t *rec = &p.prog[p.prog_offset[r.opcode]];
+            if (rec[0] == PK_RANGE && rec[3] <= 8u) range_of[rec[2]].push_back(i);
+        }
+        std::vector<size_t> hashes;
+        for (size_t i = 0; i < records.size(); i++)
+            if (!records[i].synthetic && records[i].cls == CLS_HASH && (p.prog[p.prog_offset[records[i].opcode] + 2] & PLAN_HASH_COOP_FLAG)) hashes.push_back(i);
+        std::sort(hashes.begin(), hashes.end(), [&](size_t a, size_t b) { return records[a].level != records[b].level ? records[a].level < records[b].level : a < b; });
+        std::vector<uint8_t> drop(records.size(), 0);
+        bool any_drop = false;
+        for (size_t hi : hashes) {
+            PendingRecord &h = records[hi];
+            const size_t at = p.prog_offset[h.opcode];
+            const uint32_t n_in = p.prog[at + 3], n_out = p.prog[at + 4];
+            std::vector<uint32_t> ext(2 * (size_t)n_in, 0xFFFFFFFFu);
+            bool any = false;
+            for (uint32_t i = 0; i < n_in; i++) {
+                auto it = range_of.find(p.prog[at + 6 + 2 * i]);
+                if (it == range_of.end()) continue;
+                for (size_t &ri : it->second) {
+                    if (ri == (size_t)-1 || records[ri].level > h.level) continue;  // (a check waits for its witness like the hash does)
+                    const uint32_t *rr = &p.prog[p.prog_offset[records[ri].opcode]];
+                    ext[2 * i] = rr[1];
+                    ext[2 * i + 1] = rr[3];
+                    drop[ri] = 1;
+                    ri = (size_t)-1;
+                    any = any_drop = true;
+                    break;  // one check per input slot; a second RANGE on the same witness keeps its own record (or the next slot that reads it)
+                }
+            }
+            if (!any) continue;
+            const size_t len = 6 + 2 * (size_t)n_in + 2 * (size_t)n_out;
+            h.prog_at = (uint32_t)p.prog.size();
+            std::vector<uint32_t> copy(p.prog.begin() + at, p.prog.begin() + at + len);
+            copy[2] |= PLAN_HASH_RANGE_FLAG;
+            p.prog.insert(p.prog.end(), copy.begin(), copy.end());
+            p.prog.insert(p.prog.end(), ext.begin(), ext.end());
+        }
+        if (any_drop) {
+            std::vector<PendingRecord> kept;
+            kept.reserve(records.size());
+            for (size_t i = 0; i < records.size(); i++)
+                if (!drop[i]) kept.push_back(std::move(records[i]));
+            records.swap(kept);
+        }
+    }
     // =========================================================================== RANGE opcodes of a level, eight to a record
     // A RANGE check is one row and a few dozen instructions: launched one lane per (opcode, instance) the kernel is bound by the chain of
     // dependent latencies every wave pays before its only load (config 3: 96 checks per instance). Merged records
@@ -1274,7 +1330,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         for (; ri < records.size() && records[ri].level == L; ri++) {
             const PendingRecord &r = records[ri];
-            p.cls_offset[r.cls].push_back(r.synthetic ? r.opcode : p.prog_offset[r.opcode]);
+            p.cls_offset[r.cls].push_back(r.prog_at != 0xFFFFFFFFu ? r.prog_at : r.synthetic ? r.opcode : p.prog_offset[r.opcode]);
             p.cls_scratch[r.cls].push_back(r.synthetic ? 0u : p.prog_scratch[r.opcode]);
             width[L]++;
         }

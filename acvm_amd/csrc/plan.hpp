@@ -37,6 +37,7 @@ enum GateKind : uint32_t { GATE_ASSERT = 0, GATE_SOLVE = 1, GATE_SOLVE_DYN = 2 }
 static constexpr uint32_t GATE_HDR_WORDS = 5;
 
 static constexpr uint32_t PLAN_HASH_COOP_FLAG = 0x100u;      // PK_HASH function word: byte message, unpacked through LDS by the level kernel
+static constexpr uint32_t PLAN_HASH_RANGE_FLAG = 0x200u;     // ... and (RANGE opcode or NONE, bits) per input follow the outputs: byte RANGE checks fused into the hash
 static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 16 KiB of LDS per 64 instances
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
 enum ProgKind : uint32_t {

@@ -248,6 +248,45 @@ def test_hash_many_records_one_wave_instantiation(oracle):
     assert all(x.status == 0 for x in ores)
 
 
+def test_range_checks_fused_into_hash_records(oracle):
+    """Byte RANGE checks on the inputs of a byte-message hash run inside the hash's level kernel (plan.cpp): widths 0..8 (fused), 9 and 64
+    (their own records), two checks on one witness, one witness in two input slots, checks on the outputs of the first hash that the second
+    one reads, and values that break each of them -- the failing opcode must be the RANGE opcode, the lowest one when several fail."""
+    r = rnd(31)
+    n = 40
+    ids = list(range(1, n + 1))
+    o = n + 1
+    ops = [BB("RANGE", {"input": FI(ids[k], k % 9)}) for k in range(18)]            # opcodes 0..17: widths 0..8 twice
+    ops += [BB("RANGE", {"input": FI(ids[20], 9)}), BB("RANGE", {"input": FI(ids[21], 64)})]      # 18, 19: not byte-sized
+    ops += [BB("RANGE", {"input": FI(ids[5], 3)})]                                  # 20: a second, narrower check on witness 6
+    ops += [BB("SHA256", {"inputs": [FI(w, 8) for w in ids[:32]] + [FI(ids[3], 8)], "outputs": list(range(o, o + 32))})]          # 21
+    ops += [BB("RANGE", {"input": FI(o + k, 8)}) for k in range(4)]                 # 22..25: on SHA outputs (always pass)
+    ops += [BB("RANGE", {"input": FI(o + 4, 7)})]                                   # 26: fails for half of the instances
+    ops += [BB("Keccak256", {"inputs": [FI(w, 8) for w in range(o, o + 32)] + [FI(w, 8) for w in ids[32:]], "outputs": list(range(o + 32, o + 64))})]  # 27
+    ops += [BB("RANGE", {"input": FI(ids[k], 8)}) for k in range(32, 40)]           # 28..35: after the hash that reads them, in program order
+    circ = Circuit(o + 64, ops)
+    rows = []
+    for j in range(150):
+        row = [r.randrange(1 << (k % 9)) if k < 18 else r.randrange(256) for k in range(n)]
+        row[5] = r.randrange(8)       # witness 6 also has the width-3 check of opcode 20
+        rows.append(row)
+    rows[1][0] = 1                      # RANGE(w1, 0) fails
+    rows[2][8] = 256                    # RANGE(w9, 8): low byte in range, the value is not
+    rows[3][8] = P - 1
+    rows[4][13] = 16                    # width 4
+    rows[5][5] = 31                     # passes width 5 (opcode 5), fails the second check of width 3 (opcode 20)
+    rows[6][20] = 512                   # width 9, own record
+    rows[7][35] = 1 << 29               # opcode 31, low limb zero
+    rows[8][3] = 8; rows[8][12] = 8     # two failures: opcode 3 (width 3) before opcode 12
+    rows[9][39] = 300                   # opcode 35
+    ores, _ = both_paths(oracle, circ, ids, rows)
+    want = {1: 0, 2: 8, 3: 8, 4: 13, 5: 20, 6: 18, 8: 3}
+    for j, op in want.items():
+        assert ores[j].status == 2 and ores[j].opcode_index == op, (j, ores[j].as_tuple())
+    assert ores[7].status == 2 and ores[7].opcode_index in (26, 31) and ores[9].opcode_index in (26, 35)
+    assert any(x.status == 0 for x in ores) and any(x.status == 2 and x.opcode_index == 26 for x in ores)
+
+
 def test_hash_mixed_widths_and_field_inputs(oracle):
     """fetch_nearest_bytes with num_bits != 8: multi-byte little-endian packing, truncation of wide values."""
     r = rnd(7)

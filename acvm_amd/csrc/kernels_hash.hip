@@ -27,11 +27,11 @@ void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const D
 // waves serves 64 instances of one record: wave q fetches and reduces the bytes q, q + 4, q + 8, ... of every instance (four rows in flight per
 // lane, four times the waves in flight per SIMD) into the LDS message, wave 0 hashes, and the 32 digest bytes go back through LDS so that
 // wave q stores outputs 8q .. 8q + 7 (WAVES = 4). The hash bodies are inlined here under the kernel's register budget (four waves per SIMD = 128 VGPRs).
-// the RANGE opcode fused on input i of the record fails: its opcode index, else 0xFFFFFFFF (a = the stored form, low = its canonical low limb)
-__device__ __forceinline__ uint32_t range_check(const uint32_t *__restrict__ ranges, uint32_t i, const Fr &a, uint32_t low) {
+// the RANGE opcode fused on input i of the record fails: its opcode index, else 0xFFFFFFFF (is_byte: the value is the byte `low`)
+__device__ __forceinline__ uint32_t range_check(const uint32_t *__restrict__ ranges, uint32_t i, bool is_byte, uint32_t low) {
     const uint32_t op = ranges[2u * i], bits = ranges[2u * i + 1u];
     if (op == 0xFFFFFFFFu) return op;
-    return (low >> bits) == 0u && fr_eq(a, fr_from_byte(low)) ? 0xFFFFFFFFu : op;
+    return is_byte && (low >> bits) == 0u ? 0xFFFFFFFFu : op;
 }
 // WAVES = 1 is the same kernel for launches that fill the chip anyhow (many records per level): one wave per 64 instances does every
 // phase, still with the message in LDS and the lean register budget (the lane-per-instance kernel with the message in device scratch
@@ -56,16 +56,17 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, cons
         const uint32_t i1 = i + WAVES, i2 = i + 2u * WAVES, i3 = i + 3u * WAVES;
         const Fr a0 = p.load(ins[2 * i]);
         const Fr a1 = i1 < n_in ? p.load(ins[2 * i1]) : a0, a2 = i2 < n_in ? p.load(ins[2 * i2]) : a0, a3 = i3 < n_in ? p.load(ins[2 * i3]) : a0;
-        const uint32_t l0 = fr29_redc_low(fr29_from(a0)), l1 = fr29_redc_low(fr29_from(a1)), l2 = fr29_redc_low(fr29_from(a2)), l3 = fr29_redc_low(fr29_from(a3));
+        bool b0, b1, b2, b3;  // the value is a byte (then l is that byte)
+        const uint32_t l0 = fr_low_limb(a0, b0), l1 = fr_low_limb(a1, b1), l2 = fr_low_limb(a2, b2), l3 = fr_low_limb(a3, b3);
         bytes[4u * ((i >> 2) * 64u + lane) + (i & 3u)] = (uint8_t)l0;
         if (i1 < n_in) bytes[4u * ((i1 >> 2) * 64u + lane) + (i1 & 3u)] = (uint8_t)l1;
         if (i2 < n_in) bytes[4u * ((i2 >> 2) * 64u + lane) + (i2 & 3u)] = (uint8_t)l2;
         if (i3 < n_in) bytes[4u * ((i3 >> 2) * 64u + lane) + (i3 & 3u)] = (uint8_t)l3;
         if (ranges) {  // the RANGE opcodes fused into this record (plan.cpp): same test as op_range on the limb that is here already
-            range_bad = min(range_bad, range_check(ranges, i, a0, l0));
-            if (i1 < n_in) range_bad = min(range_bad, range_check(ranges, i1, a1, l1));
-            if (i2 < n_in) range_bad = min(range_bad, range_check(ranges, i2, a2, l2));
-            if (i3 < n_in) range_bad = min(range_bad, range_check(ranges, i3, a3, l3));
+            range_bad = min(range_bad, range_check(ranges, i, b0, l0));
+            if (i1 < n_in) range_bad = min(range_bad, range_check(ranges, i1, b1, l1));
+            if (i2 < n_in) range_bad = min(range_bad, range_check(ranges, i2, b2, l2));
+            if (i3 < n_in) range_bad = min(range_bad, range_check(ranges, i3, b3, l3));
         }
     }
     if (range_bad != 0xFFFFFFFFu && live) atomicMin(&event[j], range_bad);

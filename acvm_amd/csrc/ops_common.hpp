@@ -223,6 +223,24 @@ __device__ __forceinline__ Fr fr_from_byte(uint32_t d) {
     const uint4 lo = p[0], hi = p[1];
     return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
 }
+// The inverse direction (tools/gen_byte_table.py --key): the low 10 bits of the 256 forms are pairwise distinct, so they name the only
+// byte a stored value can be; the value IS that byte exactly when the stored form equals that byte's table entry (the representation
+// is a bijection). Byte-sized witnesses -- hash inputs, byte RANGE checks -- are recognised by two small gathers and a compare instead
+// of the low limb of a Montgomery reduction (44 quarter-rate multiply-adds); anything else takes the reduction.
+static __constant__ uint8_t BYTE_KEY[1024] = {
+#include "byte_key_table.inc"
+};
+__device__ __forceinline__ bool fr_is_byte(const Fr &a, uint32_t &d) {
+    d = BYTE_KEY[a.v[0] & 1023u];
+    return fr_eq(a, fr_from_byte(d));
+}
+// low 29 bits of the canonical value of a reduced stored form (exact for every input: bytes by the tables, the rest by fr29_redc_low)
+__device__ __forceinline__ uint32_t fr_low_limb(const Fr &a, bool &is_byte) {
+    uint32_t d;
+    is_byte = fr_is_byte(a, d);
+    if (!is_byte) d = fr29_redc_low(fr29_from(a));
+    return d;
+}
 // num_bits of a canonical integer (generic_ark.rs:214-221)
 __device__ __forceinline__ uint32_t canon_num_bits(const Fr &c) {
     uint32_t n = 0;

@@ -335,8 +335,8 @@ __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restri
         // holds at these batch sizes; only the low limb of each canonical value is formed (fr29_redc_low)
         if (nb == 1u && i + 4u <= n_in && (ins[2 * i + 3] + 7u) / 8u == 1u && (ins[2 * i + 5] + 7u) / 8u == 1u && (ins[2 * i + 7] + 7u) / 8u == 1u) {
             const Fr a0 = p.load(ins[2 * i]), a1 = p.load(ins[2 * i + 2]), a2 = p.load(ins[2 * i + 4]), a3 = p.load(ins[2 * i + 6]);
-            const uint32_t l0 = fr29_redc_low(fr29_from(a0)), l1 = fr29_redc_low(fr29_from(a1)), l2 = fr29_redc_low(fr29_from(a2)),
-                           l3 = fr29_redc_low(fr29_from(a3));
+            bool b0, b1, b2, b3;
+            const uint32_t l0 = fr_low_limb(a0, b0), l1 = fr_low_limb(a1, b1), l2 = fr_low_limb(a2, b2), l3 = fr_low_limb(a3, b3);
             m.put(l0);
             m.put(l1);
             m.put(l2);

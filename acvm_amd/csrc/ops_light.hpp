@@ -27,11 +27,10 @@ __device__ __forceinline__ OpResult op_range(const P &p, const uint32_t *__restr
     if (pre.err) return pre;
     const Fr a = p.load(r[2]);
     if (r[3] <= 8u) {
-        // byte-sized ranges (the bulk of a hashing circuit): only the low limb of the canonical value is formed (44 multiply-adds instead of
-        // a full reduction); the value is below 2^bits exactly when that limb is and the stored Montgomery form is the one of that small
-        // number (the representation is a bijection), which the 8 KiB byte table holds
-        const uint32_t low = fr29_redc_low(fr29_from(a));
-        if ((low >> r[3]) != 0u || !fr_eq(a, fr_from_byte(low))) return op_fail(DE_UNSATISFIED);
+        // byte-sized ranges (the bulk of a hashing circuit): the value is below 2^bits <= 256 exactly when its stored Montgomery form is the
+        // one of a byte below 2^bits (the representation is a bijection) -- two table gathers and a compare (ops_common.hpp fr_is_byte)
+        uint32_t d;
+        if (!fr_is_byte(a, d) || (d >> r[3]) != 0u) return op_fail(DE_UNSATISFIED);
         return op_ok();
     }
     if (canon_num_bits(fr_to_canonical(a)) > r[3]) return op_fail(DE_UNSATISFIED);
@@ -56,8 +55,8 @@ __device__ __forceinline__ OpResult op_range_multi(const P &p, const uint32_t *_
             const uint32_t bits = it[3u * (i + k) + 2u];
             bool ok;
             if (bits <= 8u) {
-                const uint32_t low = fr29_redc_low(fr29_from(a[k]));
-                ok = (low >> bits) == 0u && fr_eq(a[k], fr_from_byte(low));
+                uint32_t d;
+                ok = fr_is_byte(a[k], d) && (d >> bits) == 0u;
             } else ok = canon_num_bits(fr_to_canonical(a[k])) <= bits;
             if (!ok) bad = min(bad, it[3u * (i + k)]);
         }

@@ -177,6 +177,35 @@ def test_random_circuit_shapes(oracle):
         _assert_parity(o, g, B)
 
 
+def test_unknown_in_mul_and_linear_term(oracle):
+    """The unknown both in a mul term (known partner) and in a linear term. `ArithmeticSolver::evaluate` (arithmetic.rs:212-239) turns the mul
+    term into a second LINEAR term on the same witness, `solve_fan_in_term` counts terms, not witnesses, so the reference answers
+    ExpressionHasTooManyUnknowns (the `w1 == w2` arm of `solve`, :43-62, is unreachable behind `evaluate`) -- unless the partner makes the
+    folded coefficient zero, in which case the term is dropped and the linear term alone solves the witness. The planner stops the level
+    schedule at such an opcode (every generic instance fails there); the exact kernels must give the reference's answer per instance."""
+    from acvm_amd.acir import Circuit, Expression as E, P
+    import acvm_amd
+    ops = [
+        E([(5, 1, 2)], [(P - 1, 4)], 11),                          # w4 = 5 w1 w2 + 11
+        E([(7, 4, 5)], [(3, 5), (2, 3), (9, 1)], 13),              # w5 (7 w4) + 3 w5 + 2 w3 + 9 w1 + 13 = 0
+        E([(1, 5, 5)], [(P - 1, 6)], 3),                           # w6 = w5^2 + 3
+    ]
+    circ = Circuit(6, ops)
+    ids = [1, 2, 3]
+    B = 40
+    rng = np.random.default_rng(11)
+    rows = [[int.from_bytes(rng.bytes(31), "big") for _ in range(3)] for _ in range(B)]
+    rows[2] = [1, ((-11) * pow(5, -1, P)) % P, 7]                   # w4 == 0: the mul term vanishes, 3 w5 + ... solves w5
+    rows[3] = [0, 5, 0]                                            # w4 == 11
+    values = b"".join(b"".join(v.to_bytes(32, "big") for v in r) for r in rows)
+    for force_slow in (False, True):
+        o, g, stats = _run_both(oracle, circ, ids, values, B, force_slow=force_slow)
+        _assert_parity(o, g, B)
+        assert g[0][2].status == acvm_amd.STATUS_SOLVED
+        for j in (0, 1, 3, 4, B - 1):
+            assert g[0][j].as_tuple()[:3] == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_TOO_MANY_UNKNOWNS, 1), g[0][j].as_tuple()
+
+
 def test_projective_witnesses_hand_over(oracle):
     """plan.cpp keeps arithmetic-only witnesses as scale x value. Checked here where the scaled columns meet everything else:
     a constraint on scaled witnesses that fails for some instances in mid-circuit (those columns are unscaled for the exact

@@ -1297,7 +1297,7 @@ int acvm_batch_solve(acvm_batch_t *b) try {
             if (lanes > b->x_cap) {
                 // a table of all witnesses per flagged instance: refuse when that is more than the level table itself
                 const size_t need = (size_t)p.n_witnesses * 2 * lanes * sizeof(uint4), level_table = (size_t)p.n_slots * 2 * b->Bp * sizeof(uint4);
-                if (need > level_table)
+                if (need > level_table && need > (8ull << 30))  // (a small batch pads to 64 lanes either way: below 8 GiB the table is simply allocated)
                     return set_err(ACVM_E_UNSUPPORTED, "slot reuse: " + std::to_string(n_slow) + " instances left the generic path; their own table would exceed "
                                                        "the level table -- solve this tile without ACVM_BATCH_REUSE_SLOTS");
                 for (void *q : {(void *)b->d_Wx, (void *)b->d_Memx, (void *)b->d_ids_x})

@@ -189,7 +189,9 @@ acvm_batch_t *acvm_batch_new(const acvm_circuit_t *c, const acvm_bb_solver_t *so
  *                           to the level of its last reader, rows are recycled (implies the folded digest: a row is hashed before
  *                           it is reused). Afterwards only the initial witnesses and keep_ids can be read back (acvm_batch_witness
  *                           / _extract_witnesses), plus results and digests; acvm_batch_witness_map returns ACVM_E_STATE. Instances
- *                           that leave the generic path are re-solved from their initial witnesses in a table of their own.
+ *                           that leave the generic path are re-solved from their initial witnesses in a table of their own
+ *                           (all witnesses x flagged instances, padded to 64; acvm_batch_solve returns ACVM_E_UNSUPPORTED when
+ *                           that table would be larger than both the level table and 8 GiB: solve such a tile without the flag).
  */
 #define ACVM_BATCH_FOLD_DIGEST 1u
 #define ACVM_BATCH_REUSE_SLOTS 2u

@@ -15,9 +15,74 @@ from acvm_amd import synth  # noqa: E402
 from oracle import binding as ob  # noqa: E402
 
 
+def wild_circuit(n_ops, seed):
+    """Black-box opcodes with operands and widths drawn without regard for what the values are: hash inputs of any width fed with field-sized
+    values, byte RANGE checks on them (passing and failing), outputs that are already assigned (insert_value compares), several hashes and
+    checks per level. Most instances fail somewhere; what counts is WHERE and with what, bit for bit."""
+    import random
+    from acvm_amd.acir import BlackBoxFuncCall as BB, Circuit, Expression as E, FunctionInput as FI, P, ToLeRadix, QuotientDirective
+    r = random.Random(seed)
+    n_in = 12
+    ids = list(range(1, n_in + 1))
+    nw = n_in
+    ops = []
+    bytes_w = []
+    w32 = []
+
+    def fresh(k=1):
+        nonlocal nw
+        out = list(range(nw + 1, nw + 1 + k))
+        nw += k
+        return out
+
+    def pick():
+        return r.randrange(1, nw + 1)
+
+    for _ in range(n_ops):
+        k = r.randrange(100)
+        if k < 25:
+            if bytes_w and r.random() < 0.9:
+                ops.append(BB("RANGE", {"input": FI(r.choice(bytes_w), r.choice([8, 8, 8, 8, 9, 16, 64, 254, 7]))}))
+            else:
+                ops.append(BB("RANGE", {"input": FI(pick(), r.choice([0, 1, 3, 8, 254, 254, 254]))}))
+        elif k < 40:
+            bits = r.choice([1, 8, 8, 13, 32, 64, 254])
+            out = fresh()[0] if r.random() < 0.97 else pick()
+            ops.append(BB(r.choice(["AND", "XOR"]), {"lhs": FI(pick(), bits), "rhs": FI(pick(), bits), "output": out}))
+            if bits == 8:
+                bytes_w.append(out)
+            if bits == 32:
+                w32.append(out)
+        elif k < 65:
+            name = r.choice(["SHA256", "Keccak256", "Blake2s"])
+            n = r.choice([1, 2, 3, 4, 5, 17, 33, 64])
+            src = bytes_w if len(bytes_w) >= 4 and r.random() < 0.7 else None
+            ins = [FI(r.choice(src) if src else pick(), r.choice([8, 8, 8, 1, 4, 7]) if r.random() < 0.85 else r.choice([9, 32, 254])) for _ in range(n)]
+            outs = fresh(32)
+            if r.random() < 0.03:
+                outs[r.randrange(32)] = pick()  # an output that is already assigned
+            ops.append(BB(name, {"inputs": ins, "outputs": outs}))
+            bytes_w += [w for w in outs if w > n_in]
+        elif k < 72:
+            d = fresh(4)
+            ops.append(ToLeRadix(E.from_witness(r.choice(w32) if w32 and r.random() < 0.95 else pick()), d, 256))
+            bytes_w += d
+        elif k < 80:
+            q, rem = fresh(2)
+            ops.append(QuotientDirective(E.from_witness(pick()), E.from_witness(pick()), q, rem))
+        elif k < 86:
+            ops.append(BB("HashToField128Security", {"inputs": [FI(pick(), r.choice([8, 16, 254])) for _ in range(r.randrange(1, 6))], "output": fresh()[0]}))
+        else:
+            a, b = pick(), pick()
+            out, = fresh()
+            ops.append(E([(r.randrange(1, P), a, b)], [(P - 1, out), (r.randrange(P), pick())], r.randrange(P)))
+    return Circuit(nw, ops), ids
+
+
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     n_ops = int(sys.argv[2]) if len(sys.argv) > 2 else 700
+    wild = len(sys.argv) > 3 and sys.argv[3] == "wild"
     t0 = time.time()
     bad = 0
     for k in range(n_seeds):
@@ -25,9 +90,19 @@ def main():
         heavy = k % 5 != 4
         blocks, cells = [(16, 64), (4, 16), (1, 256), (2, 2)][k % 4]
         n = n_ops + 37 * (k % 7)
-        circ, ids = synth.mixed_circuit(n, seed=seed, heavy=heavy, blocks=blocks, cells=cells)
         B = [70, 1, 64, 129, 200][k % 5]
-        values = synth.witness_batch(B, seed=seed, edge_cases=(k % 2 == 0))
+        if wild:
+            circ, ids = wild_circuit(n, seed)
+            values = bytearray(synth.witness_batch(B, n_in=len(ids), seed=seed, edge_cases=(k % 2 == 0)))
+            for j in range(B):  # most inputs byte-sized, so that checks pass often enough for later opcodes to run
+                for i in range(len(ids)):
+                    if (j * 31 + i * 7 + k) % 5:
+                        o = (j * len(ids) + i) * 32
+                        values[o:o + 31] = bytes(31)
+            values = bytes(values)
+        else:
+            circ, ids = synth.mixed_circuit(n, seed=seed, heavy=heavy, blocks=blocks, cells=cells)
+            values = synth.witness_batch(B, seed=seed, edge_cases=(k % 2 == 0))
         data = circ.to_bytes()
         ores, oasg, ovals = ob.solve_batch(ob.Circuit(data), ids, values, B)
         odig = [ob.witness_map_digest(oasg[j], ovals[j]) for j in range(B)]
@@ -41,7 +116,7 @@ def main():
                 kw.update(fold_digest=True)
             try:
                 batch = acvm_amd.Batch(gc, B, ids, **kw)
-            except acvm_amd.AcvmError as e:  # slot reuse refuses circuits it cannot cover (foreign calls, truncated plans)
+            except (acvm_amd.AcvmError, ValueError) as e:  # slot reuse refuses circuits it cannot cover (foreign calls, truncated plans)
                 line.append(f"{mode}: refused ({str(e)[:40]})")
                 continue
             if mode == "exact":

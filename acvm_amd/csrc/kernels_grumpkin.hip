@@ -32,17 +32,17 @@ void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DevicePro
 // FastPolicy only (level schedule); flagged instances take the one-lane exact kernel on the small tables (same group
 // elements, so the affine results are identical).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
-                                                                  uint32_t *__restrict__ event) {
+                                                                  uint32_t *__restrict__ event, const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
     __shared__ uint32_t lds_acc[4][27][64];  // [wave][limb of X, Y, Z (9 x 29-bit each)][lane]
     __shared__ uint32_t lds_r[16][64];       // affine result of the step (Montgomery limbs of x, y)
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;  // a scalar: loop bounds and record words indexed by it stay scalar
     const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
     const bool active = j < B;
-    const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
+    const uint32_t *__restrict__ rec = prog + offsets[blockIdx.y];  // (noalias arguments: scalar loads, see ops_kernel.hpp)
     const uint32_t n = rec[3];
     const uint32_t *ws = rec + 8;
     const GrumpkinTables &T = dp.grumpkin;
-    FastPolicy p{W, Bp, j, dp.slot_of};
+    FastPolicy p{W, Bp, j, slot_of};
     if (n == 0) {  // the point at infinity is reported as (0, 0)
         if (wave == 0 && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) atomicMin(&event[j], rec[1]);
         return;
@@ -174,7 +174,7 @@ void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
     if (!n || !B) return;
     for (uint32_t done = 0; done < n;) {
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        hipLaunchKernelGGL(pedersen_quad_level_kernel, dim3((B + 63) / 64, m), dim3(256), 0, s, W, Bp, B, dp, offsets + done, event);
+        hipLaunchKernelGGL(pedersen_quad_level_kernel, dim3((B + 63) / 64, m), dim3(256), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
         done += m;
     }
 }

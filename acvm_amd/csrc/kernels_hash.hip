@@ -38,12 +38,17 @@ __device__ __forceinline__ uint32_t range_check(const uint32_t *__restrict__ ran
 // and 184 VGPRs measured 6.0 ms for the hash class of the config-5 mix at 2^16 instances).
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
-hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event) {
+hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
+                       const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
     extern __shared__ uint32_t lds[];  // max(hash_coop_words, 8) x 64 words
-    const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    // (the wave index as a scalar: everything indexed by it -- record words, witness ids, rows of slot_of -- is then a scalar load; as a
+    // vector value each of those was a memory round trip of its own in front of every row)
+    const uint32_t lane = threadIdx.x & 63u, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t j = (uint64_t)blockIdx.x * 64u + lane;
-    const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
-    FastPolicy p{W, Bp, j, dp.slot_of};
+    // (prog and slot_of arrive as kernel arguments of their own, not inside dp: only a noalias argument lets the compiler read the record
+    // with scalar loads; through the struct every record word was a vector load that also waited for the stores before it)
+    const uint32_t *__restrict__ rec = prog + offsets[blockIdx.y];
+    FastPolicy p{W, Bp, j, slot_of};
     const uint32_t func = rec[2] & 0xffu, n_in = rec[3];
     const uint32_t *ins = rec + 6, *outs = ins + 2 * n_in;
     const bool live = j < B;  // (rows are padded to Bp: the loads of a dead lane stay inside the table)
@@ -100,8 +105,8 @@ void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, co
     const bool four = groups * 4u <= 8192u;                    // four waves each while that still fits the chip about twice (1 024 SIMDs x 4-5 waves)
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        if (four) hipLaunchKernelGGL(hash_coop_level_kernel<4>, dim3((B + 63u) / 64u, m), dim3(256), lds_bytes, s, W, Bp, B, dp, offsets + done, event);
-        else hipLaunchKernelGGL(hash_coop_level_kernel<1>, dim3((B + 63u) / 64u, m), dim3(64), lds_bytes, s, W, Bp, B, dp, offsets + done, event);
+        if (four) hipLaunchKernelGGL(hash_coop_level_kernel<4>, dim3((B + 63u) / 64u, m), dim3(256), lds_bytes, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
+        else hipLaunchKernelGGL(hash_coop_level_kernel<1>, dim3((B + 63u) / 64u, m), dim3(64), lds_bytes, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
         done += m;
     }
 }

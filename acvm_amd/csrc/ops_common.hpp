@@ -230,9 +230,29 @@ __device__ __forceinline__ Fr fr_from_byte(uint32_t d) {
 static __constant__ uint8_t BYTE_KEY[1024] = {
 #include "byte_key_table.inc"
 };
+// The same Montgomery form by arithmetic: d * r - k * p with r = 2^261 mod p and k = floor(d r / p) = (2333 d) >> 13 for d < 256 (checked
+// over all 256 values by tools/gen_byte_table.py --check). A wave-wide gather from the 8 KiB table touches up to 64 cache lines and is
+// served by the CU's one vector L1 at about a line per cycle; with sixteen waves of a hash launch per CU doing nothing else that rate,
+// not the ALUs and not HBM, bounded the launch (cycle counters around the phases of hash_coop_level_kernel: 82 k cycles to fetch and
+// recognise 16 bytes per wave, 46 k to convert and store 8 outputs, 26 k for the hash itself). ~64 instructions, no memory.
+__device__ __forceinline__ Fr fr_mont_of_byte(uint32_t d) {
+    constexpr uint32_t R261[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u};
+    constexpr uint32_t PP[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    d &= 0xffu;
+    const uint32_t k = (d * 2333u) >> 13;
+    Fr out;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int64_t acc = carry + (int64_t)((uint64_t)d * R261[i]) - (int64_t)((uint64_t)k * PP[i]);
+        out.v[i] = (uint32_t)acc;
+        carry = acc >> 32;
+    }
+    return out;
+}
 __device__ __forceinline__ bool fr_is_byte(const Fr &a, uint32_t &d) {
     d = BYTE_KEY[a.v[0] & 1023u];
-    return fr_eq(a, fr_from_byte(d));
+    return fr_eq(a, fr_mont_of_byte(d));
 }
 // low 29 bits of the canonical value of a reduced stored form (exact for every input: bytes by the tables, the rest by fr29_redc_low)
 __device__ __forceinline__ uint32_t fr_low_limb(const Fr &a, bool &is_byte) {

@@ -22,12 +22,18 @@ __device__ __forceinline__ void exact_fail(const ExactLanes &L, uint32_t t, uint
     o.x1 = r.x1;
 }
 
+// prog / consts / slot_of also arrive as kernel arguments of their own: only a noalias ARGUMENT lets the compiler read the record, the constants
+// and the row map with scalar loads; through the by-value struct every record word is a vector load that waits behind the stores before it.
 template <class Op, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ scratch_off, uint32_t *__restrict__ event,
-                                                             uint32_t *scratch) {
+                                                             uint32_t *scratch, const uint32_t *__restrict__ prog, const uint32_t *__restrict__ consts,
+                                                             const uint32_t *__restrict__ slot_of) {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= B) return;
+    dp.prog = prog;
+    dp.consts = consts;
+    dp.slot_of = slot_of;
     const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
     uint32_t *sc = scratch ? scratch + (uint64_t)scratch_off[blockIdx.y] * Bp : nullptr;
     FastPolicy p{W, Bp, j, dp.slot_of};
@@ -58,7 +64,7 @@ static void launch_record_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
         hipLaunchKernelGGL((record_level_kernel<Op, BLOCK>), dim3((B + BLOCK - 1) / BLOCK, m), dim3(BLOCK), 0, s, W, Bp, B, dp, offsets + done,
-                           scratch_off ? scratch_off + done : nullptr, event, scratch);
+                           scratch_off ? scratch_off + done : nullptr, event, scratch, dp.prog, dp.consts, dp.slot_of);
         done += m;
     }
 }

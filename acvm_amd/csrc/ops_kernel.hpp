@@ -28,12 +28,13 @@ template <class Op, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ scratch_off, uint32_t *__restrict__ event,
                                                              uint32_t *scratch, const uint32_t *__restrict__ prog, const uint32_t *__restrict__ consts,
-                                                             const uint32_t *__restrict__ slot_of) {
+                                                             const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ bytecode) {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= B) return;
     dp.prog = prog;
     dp.consts = consts;
     dp.slot_of = slot_of;
+    dp.bytecode = bytecode;
     const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
     uint32_t *sc = scratch ? scratch + (uint64_t)scratch_off[blockIdx.y] * Bp : nullptr;
     FastPolicy p{W, Bp, j, dp.slot_of};
@@ -64,7 +65,7 @@ static void launch_record_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
         hipLaunchKernelGGL((record_level_kernel<Op, BLOCK>), dim3((B + BLOCK - 1) / BLOCK, m), dim3(BLOCK), 0, s, W, Bp, B, dp, offsets + done,
-                           scratch_off ? scratch_off + done : nullptr, event, scratch, dp.prog, dp.consts, dp.slot_of);
+                           scratch_off ? scratch_off + done : nullptr, event, scratch, dp.prog, dp.consts, dp.slot_of, dp.bytecode);
         done += m;
     }
 }

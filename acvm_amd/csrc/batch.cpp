@@ -62,6 +62,7 @@ struct acvm_batch {
     std::vector<ExactSegment> segments;
     DeviceProgram dp{};
     uint32_t *d_event = nullptr;
+    uint32_t *h_flag_count = nullptr;  // pinned, device-mapped
     std::vector<uint32_t> h_event;
     bool events_clean = false;  // h_event is all 0xFFFFFFFF, slow_ids empty, slow_index all -1 (kept across solves that flag nothing)
     // exact in-order path
@@ -140,6 +141,7 @@ struct acvm_batch {
                         (void *)d_prog_offset, (void *)d_bytecode, (void *)d_init_ids, (void *)d_producer, (void *)d_dyn_offset,
                         (void *)d_slow_start, (void *)d_event, (void *)d_slow_ids, (void *)d_assigned, (void *)d_slow_res})
             if (p) hipFree(p);
+        if (h_flag_count) hipHostFree(h_flag_count);
         for (int k = 0; k < (int)N_CLS; k++)
             for (void *p : {(void *)d_cls_offset[k], (void *)d_cls_scratch_off[k], (void *)d_cls_scratch[k]})
                 if (p) hipFree(p);
@@ -518,7 +520,8 @@ static int batch_init(acvm_batch *b) {
         size_t bytes = (size_t)p.n_inverse_slots * 2 * b->Bp * sizeof(uint4);
         HIPCHK(hipMalloc((void **)&b->d_inv, bytes ? bytes : 16));
     }
-    HIPCHK(hipMalloc((void **)&b->d_event, ((size_t)b->B + 1) * 4));  // + the count of flagged instances (kernels.hip event_count_kernel)
+    HIPCHK(hipMalloc((void **)&b->d_event, ((size_t)b->B + 2) * 4));  // + the count of flagged instances and a ticket (kernels.hip event_count_kernel)
+    HIPCHK(hipHostMalloc((void **)&b->h_flag_count, 64, hipHostMallocMapped));  // the same count where the host can read it after a synchronisation
     b->unscale = Unscale{b->d_unscale_index, b->d_unscale_consts, b->d_unscale_plain, b->d_scaled_ids, (uint32_t)p.scaled_ids.size(), b->d_event};
     b->h_event.assign(b->B, 0xFFFFFFFFu);
     b->slow_index.assign(b->B, -1);
@@ -1258,9 +1261,10 @@ int acvm_batch_solve(acvm_batch_t *b) try {
     // none: only their count comes back (4 bytes instead of the B event words and a scan of them -- 30 us of a 0.25 ms solve of config 3)
     uint32_t n_flagged = b->B;
     if (!b->force_slow && b->B) {
-        launch_event_count(s, b->d_event, b->B);
-        HIPCHK(hipMemcpyAsync(&n_flagged, b->d_event + b->B, 4, hipMemcpyDeviceToHost, s));
+        *b->h_flag_count = b->B;  // (stays "everything" if the kernel did not run)
+        launch_event_count(s, b->d_event, b->B, b->h_flag_count);
         HIPCHK(hipStreamSynchronize(s));
+        n_flagged = *(volatile uint32_t *)b->h_flag_count;
     }
     if (n_flagged || !b->events_clean) {
         if (n_flagged) {

@@ -317,22 +317,33 @@ void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mism
     hipLaunchKernelGGL(fr_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, n, mismatches);
 }
 // event words of a batch: [0, B) = per instance the first opcode that left the generic path (0xFFFFFFFF: none), word B = how many did
+// (word B + 1 = a ticket: the block that takes the last one publishes the total)
 __global__ void __launch_bounds__(256) event_reset_kernel(uint32_t *__restrict__ event, uint32_t B) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < B) event[i] = 0xFFFFFFFFu;
-    else if (i == B) event[i] = 0u;
+    else if (i <= B + 1) event[i] = 0u;
 }
-__global__ void __launch_bounds__(256) event_count_kernel(uint32_t *__restrict__ event, uint32_t B) {
+// host_count: pinned host memory mapped into the device: the last block to finish stores the total there, so the host reads it after the
+// stream synchronisation it needs anyway -- no copy launch behind the last kernel of a solve
+__global__ void __launch_bounds__(256) event_count_kernel(uint32_t *__restrict__ event, uint32_t B, uint32_t *__restrict__ host_count) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool flagged = i < B && event[i] != 0xFFFFFFFFu;
     const uint32_t n = (uint32_t)__popcll(__ballot(flagged));
     if (n && (threadIdx.x & 63u) == 0) atomicAdd(&event[B], n);
+    __syncthreads();  // this block's additions are issued
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&event[B + 1], 1u) == gridDim.x - 1) {
+            __threadfence();
+            *host_count = atomicAdd(&event[B], 0u);
+        }
+    }
 }
 void launch_event_reset(hipStream_t s, uint32_t *event, uint32_t B) {
-    hipLaunchKernelGGL(event_reset_kernel, dim3(B / 256 + 1), dim3(256), 0, s, event, B);
+    hipLaunchKernelGGL(event_reset_kernel, dim3((B + 2) / 256 + 1), dim3(256), 0, s, event, B);
 }
-void launch_event_count(hipStream_t s, uint32_t *event, uint32_t B) {
-    if (B) hipLaunchKernelGGL(event_count_kernel, dim3((B + 255) / 256), dim3(256), 0, s, event, B);
+void launch_event_count(hipStream_t s, uint32_t *event, uint32_t B, uint32_t *host_count) {
+    if (B) hipLaunchKernelGGL(event_count_kernel, dim3((B + 255) / 256), dim3(256), 0, s, event, B, host_count);
 }
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n) {
     if (!n) return;

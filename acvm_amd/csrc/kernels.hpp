@@ -79,9 +79,9 @@ void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp
 void launch_modmul_rate(hipStream_t s, uint32_t *out, uint32_t blocks, uint32_t iters);
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
-// event words [0, B) <- 0xFFFFFFFF and the flagged count (word B) <- 0; the count of words != 0xFFFFFFFF into word B
+// event words [0, B) <- 0xFFFFFFFF, the flagged count (word B) and the ticket (word B + 1) <- 0; the count of words != 0xFFFFFFFF into word B and *host_count
 void launch_event_reset(hipStream_t s, uint32_t *event, uint32_t B);
-void launch_event_count(hipStream_t s, uint32_t *event, uint32_t B);
+void launch_event_count(hipStream_t s, uint32_t *event, uint32_t B, uint32_t *host_count);  // host_count: pinned, device-mapped
 void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, uint32_t n_witnesses,
                           const uint32_t *producer, const uint32_t *start_opcode);

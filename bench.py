@@ -295,11 +295,24 @@ def main():
         ret = gc.witness_set("return_values")
         host = np.frombuffer(values, dtype=np.uint8)
         ph = [0.0, 0.0, 0.0]
+        import threading
+        dev = acvm_amd.current_device()
+
+        def upload(k):  # pageable host memory -> the tile's slice of the resident buffer (hipMemcpy releases the GIL through ctypes)
+            acvm_amd.set_device(dev)  # HIP's current device is per thread
+            first = sh.starts[k]
+            sh.buf.upload(host[first * row:(first + tile) * row], offset=first * row)
+
         barrier()
         e0 = time.perf_counter()
+        a = time.perf_counter()
+        upload(0)
+        ph[0] += time.perf_counter() - a
         for k, start in enumerate(sh.starts):
-            a = time.perf_counter()
-            sh.buf.upload(host[start * row:(start + tile) * row], offset=start * row)  # pageable host memory -> HBM
+            nxt = None
+            if k + 1 < len(sh.starts):  # the upload of tile k + 1 runs beside the solve of tile k (acvm_amd/tiling.py solve_tiled does the same)
+                nxt = threading.Thread(target=upload, args=(k + 1,))
+                nxt.start()
             b_ = time.perf_counter()
             sh.load_tile(k)
             n_bad = batch.solve()
@@ -311,13 +324,16 @@ def main():
                 else:
                     batch.witness(ret[-1])
             d = time.perf_counter()
-            ph[0] += b_ - a
+            if nxt is not None:
+                nxt.join()
+            ph[0] += time.perf_counter() - d  # what of the next upload the solve did not cover
             ph[1] += c - b_
             ph[2] += d - c
         e2e_s = shard.max_over_ranks(time.perf_counter() - e0, dist)
-        e2e = {"value": total / e2e_s, "unit": "witnesses/s", "total_ms": e2e_s * 1e3, "h2d_ms_rank0": ph[0] * 1e3, "solve_ms_rank0": ph[1] * 1e3,
+        e2e = {"value": total / e2e_s, "unit": "witnesses/s", "total_ms": e2e_s * 1e3, "h2d_exposed_ms_rank0": ph[0] * 1e3, "solve_ms_rank0": ph[1] * 1e3,
                "d2h_return_ms_rank0": ph[2] * 1e3, "input_bytes_per_witness": row, "return_witnesses": len(ret),
-               "note": "pageable host buffers over PCIe, one tile at a time, nothing overlapped; `value` of the line keeps inputs resident"}
+               "note": "pageable host buffers over PCIe, tile by tile; the upload of tile k + 1 runs beside the solve of tile k (first upload and "
+                       "every D2H exposed); `value` of the line keeps inputs resident"}
 
     # ---- CPU baseline + parity on a bounded sample of tile 0 (rank 0 only)
     cpu = parity = None

@@ -624,6 +624,15 @@ FR_HD __forceinline__ void fr_store(uint4 *W, uint32_t slot, uint64_t B, uint64_
     W[(uint64_t)slot * 2 * B + j] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
     W[((uint64_t)slot * 2 + 1) * B + j] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
+// the same store marked nontemporal (global_store ... nt): a row that no wave will read again before it has left the caches anyway
+// (outputs of the hash kernels: config 3 0.447 -> 0.505 of the HBM roofline) does not displace lines that are still to be read
+__device__ __forceinline__ void fr_store_nt(uint4 *W, uint32_t slot, uint64_t B, uint64_t j, const Fr &a) {
+    uint4 *lo = W + (uint64_t)slot * 2 * B + j, *hi = lo + B;
+    __builtin_nontemporal_store(a.v[0], &lo->x); __builtin_nontemporal_store(a.v[1], &lo->y);
+    __builtin_nontemporal_store(a.v[2], &lo->z); __builtin_nontemporal_store(a.v[3], &lo->w);
+    __builtin_nontemporal_store(a.v[4], &hi->x); __builtin_nontemporal_store(a.v[5], &hi->y);
+    __builtin_nontemporal_store(a.v[6], &hi->z); __builtin_nontemporal_store(a.v[7], &hi->w);
+}
 // circuit constant (wave-uniform): 8 consecutive u32 in the constants table
 FR_HD __forceinline__ Fr fr_const(const uint32_t *__restrict__ consts, uint32_t idx) {
     Fr r;

@@ -633,6 +633,13 @@ __device__ __forceinline__ void fr_store_nt(uint4 *W, uint32_t slot, uint64_t B,
     __builtin_nontemporal_store(a.v[4], &hi->x); __builtin_nontemporal_store(a.v[5], &hi->y);
     __builtin_nontemporal_store(a.v[6], &hi->z); __builtin_nontemporal_store(a.v[7], &hi->w);
 }
+__device__ __forceinline__ Fr fr_load_nt(const uint4 *W, uint32_t slot, uint64_t B, uint64_t j) {
+    const uint4 *lo = W + (uint64_t)slot * 2 * B + j, *hi = lo + B;
+    Fr r;
+    r.v[0] = __builtin_nontemporal_load(&lo->x); r.v[1] = __builtin_nontemporal_load(&lo->y); r.v[2] = __builtin_nontemporal_load(&lo->z); r.v[3] = __builtin_nontemporal_load(&lo->w);
+    r.v[4] = __builtin_nontemporal_load(&hi->x); r.v[5] = __builtin_nontemporal_load(&hi->y); r.v[6] = __builtin_nontemporal_load(&hi->z); r.v[7] = __builtin_nontemporal_load(&hi->w);
+    return r;
+}
 // circuit constant (wave-uniform): 8 consecutive u32 in the constants table
 FR_HD __forceinline__ Fr fr_const(const uint32_t *__restrict__ consts, uint32_t idx) {
     Fr r;

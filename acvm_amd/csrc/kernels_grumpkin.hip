@@ -180,7 +180,7 @@ void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 }
 
 // ---- component probes for the parity tests (acvm_debug_grumpkin): in / out are canonical 8 x u32 little-endian
-static __device__ uint32_t g_probe_window_table[15 * 27];
+static __device__ uint32_t g_probe_window_table[16 * 27];
 __global__ void grumpkin_probe_kernel(GrumpkinTables T, uint32_t what, uint32_t param, const uint32_t *in, uint32_t n_in, uint32_t *out) {
     if (threadIdx.x || blockIdx.x) return;
     auto ld = [&](uint32_t i) { Fr c; for (int k = 0; k < 8; k++) c.v[k] = in[8 * i + k]; return c; };

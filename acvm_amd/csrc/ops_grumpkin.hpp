@@ -391,6 +391,36 @@ __device__ __forceinline__ GlvSplit glv_split(const Fr &k) {
     }
     return r;
 }
+static constexpr uint32_t VARBASE_TABLE_ENTRIES = 16;  // d P for d = 1..16 (signed 5-bit windows), 27 words each in the lane's scratch
+// Signed 5-bit windows of a magnitude below 2^127: k = sum d_i 32^i with d_i in [-15, 16], i < 26 (a window above 16 borrows 32 from the
+// next one). Digit i sits in word i / 5 at bit 6 (i % 5): bits 0..4 the magnitude, bit 5 the sign. 26 windows instead of the 32 unsigned
+// 4-bit ones: 52 additions + 130 doublings instead of 64 + 128 for one more table entry.
+struct SignedDigits { uint32_t w[6]; };
+__device__ __forceinline__ SignedDigits signed_windows5(const uint32_t (&k)[4]) {
+    SignedDigits r;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.w[i] = 0;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 26; i++) {
+        const int pos = 5 * i, limb = pos >> 5, sh = pos & 31;
+        uint64_t two = k[limb];
+        if (limb + 1 < 4) two |= (uint64_t)k[limb + 1] << 32;
+        const uint32_t bits = ((uint32_t)(two >> sh) & 31u) + carry;  // 0..32
+        const bool neg = bits > 16u;
+        const uint32_t mag = neg ? 32u - bits : bits;                // 0..16
+        carry = neg ? 1u : 0u;
+        r.w[i / 5] |= (mag | (neg ? 32u : 0u)) << (6 * (i % 5));
+    }
+    return r;  // (k < 2^127: the last window is at most 3 + 1, no carry leaves it)
+}
+__device__ __forceinline__ uint32_t signed_digit(const SignedDigits &d, uint32_t i) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        if ((uint32_t)q == i / 5u) word = d.w[q];
+    return (word >> (6u * (i % 5u))) & 63u;
+}
 __device__ __forceinline__ uint32_t nibble128(const uint32_t (&k)[4], uint32_t w) {  // 4-bit window w of a 128-bit integer
     uint32_t limb = 0;
 #pragma unroll
@@ -398,17 +428,17 @@ __device__ __forceinline__ uint32_t nibble128(const uint32_t (&k)[4], uint32_t w
         if ((uint32_t)i == (w >> 3)) limb = k[i];
     return (limb >> (4u * (w & 7u))) & 15u;
 }
-// With a window table (15 x 27 words per lane in device scratch, word-major like every per-lane buffer): e = k1 + k2 lambda
-// (GLV, |k1|, |k2| < 2^127), then 32 joint 4-bit windows: 4 doublings + the lane's table entry |k1|_w * P + the entry
-// |k2|_w * P mapped through (x, y) -> (beta x, y); a negative half negates y. The instruction stream is the same on every
+// With a window table (16 x 27 words per lane in device scratch, word-major like every per-lane buffer): e = k1 + k2 lambda
+// (GLV, |k1|, |k2| < 2^127), then 26 joint SIGNED 5-bit windows: 5 doublings + the lane's table entry |d1_w| * P + the entry
+// |d2_w| * P mapped through (x, y) -> (beta x, y); a negative half or a negative digit negates y. The instruction stream is the same on every
 // lane (bit-serial double-and-add makes the whole wave pay the addition on every bit: some lane always has the bit set), and
-// the split halves the doublings: 128 doublings + 64 additions instead of 256 + 64.
-// The 15 multiples are brought to ONE denominator so that the 64 additions are mixed ones (11 products instead of 16) without an
+// the split halves the doublings: 130 doublings + 52 additions instead of 256 + 64.
+// The 16 multiples are brought to ONE denominator so that the 52 additions are mixed ones (11 products instead of 16) without an
 // inversion: d P = (X_d, Y_d, Z_d) is built by the chain P, 2P, 2P + P, ... whose every step reports zr_d = Z_d / Z_(d-1); backwards,
-// s_d = Z_15 / Z_d = zr_15 ... zr_(d+1) and (X_d s_d^2, Y_d s_d^3, Z_15) is the same point. (x, y) -> (x Z_15^2, y Z_15^3) maps the curve
-// onto y^2 = x^3 - 17 Z_15^6, where those pairs are AFFINE points; doubling and addition for a = 0 never read the constant, so the
-// whole ladder runs there and the result (X, Y, Z) is the point (X, Y, Z Z_15) of Grumpkin. Table row d - 1 = {x_d, y_d, beta x_d}.
-// The group has prime order q and 0 < d < 16, so the chain never meets an exceptional case; the ladder's additions keep theirs.
+// s_d = Z_16 / Z_d = zr_16 ... zr_(d+1) and (X_d s_d^2, Y_d s_d^3, Z_16) is the same point. (x, y) -> (x Z_16^2, y Z_16^3) maps the curve
+// onto y^2 = x^3 - 17 Z_16^6, where those pairs are AFFINE points; doubling and addition for a = 0 never read the constant, so the
+// whole ladder runs there and the result (X, Y, Z) is the point (X, Y, Z Z_16) of Grumpkin. Table row d - 1 = {x_d, y_d, beta x_d}.
+// The group has prime order q and 0 < d <= 16, so the chain never meets an exceptional case; the ladder's additions keep theirs.
 // Without a table (Brillig's black-box op): double-and-add.
 __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e, uint32_t *tbl, uint64_t Bp, uint64_t j) {
     GJac a = gj_inf();
@@ -435,16 +465,16 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
     put(1, 0, q.X); put(1, 1, q.Y); put(1, 2, q.Z);
     q = gj_dbl(q);                          // Z_2 = 2 y Z_1 = zr_2
     put(2, 0, q.X); put(2, 1, q.Y); put(2, 2, q.Z);
-    for (uint32_t d = 3; d < 16; d++) {
+    for (uint32_t d = 3; d <= VARBASE_TABLE_ENTRIES; d++) {
         Fr29 zr = g29_one();
         q = gj_add_aff29(q, px, py, &zr);
         put(d, 0, q.X); put(d, 1, q.Y); put(d, 2, zr);
     }
-    const Fr29 z15 = q.Z;
+    const Fr29 z15 = q.Z;  // (the common denominator: Z of the last entry)
     // backward: row d - 1 = {X_d s^2, Y_d s^3, beta X_d s^2}
     const Fr29 beta = fr29_from(grumpkin_beta());
     Fr29 sc = g29_one();
-    for (uint32_t d = 15; d >= 1; d--) {
+    for (uint32_t d = VARBASE_TABLE_ENTRIES; d >= 1; d--) {
         const Fr29 zr = get(d, 2);
         const Fr29 s2 = fr29_sqr(sc);
         const Fr29 x = fr29_mul(get(d, 0), s2), y = fr29_mul(get(d, 1), fr29_mul(s2, sc));
@@ -454,11 +484,13 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
     const GlvSplit sp = glv_split(e);
     // (requesting both rows of a window before its four doublings -- their index depends on the scalar only -- was measured slower:
     // 2.30 -> 2.37 ms per 65 536 verifications; the rows are loaded where they are added)
-    for (int w = 31; w >= 0; w--) {
-        a = gj_dbl(gj_dbl(gj_dbl(gj_dbl(a))));
+    const SignedDigits d1 = signed_windows5(sp.k1), d2 = signed_windows5(sp.k2);
+    for (int w = 25; w >= 0; w--) {
+        a = gj_dbl(gj_dbl(gj_dbl(gj_dbl(gj_dbl(a)))));
         for (uint32_t half = 0; half < 2; half++) {  // wave-uniform
-            const uint32_t d = half ? nibble128(sp.k2, (uint32_t)w) : nibble128(sp.k1, (uint32_t)w);
-            const bool neg = half ? sp.neg2 : sp.neg1;
+            const uint32_t sd = half ? signed_digit(d2, (uint32_t)w) : signed_digit(d1, (uint32_t)w);
+            const uint32_t d = sd & 31u;
+            const bool neg = (half ? sp.neg2 : sp.neg1) != ((sd & 32u) != 0u);
             if (d) {  // per lane: its own table row
                 const Fr29 x = get(d, half ? 2u : 0u);                     // lambda * (x, y) = (beta x, y)
                 Fr29 y = get(d, 1);

@@ -324,7 +324,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     p.prog_class[oi] = host_blackbox ? CLS_HOSTBB : CLS_GRUMPKIN;
                     p.needs_grumpkin |= !host_blackbox;
                     // challenge preimage (32 + message bytes) + the per-lane window table of e * pk (15 Jacobian points x 27 words)
-                    p.prog_scratch[oi] = (uint32_t)((32 + b.in[3].size() + 3) / 4 + 1) + 15u * 27u;
+                    p.prog_scratch[oi] = (uint32_t)((32 + b.in[3].size() + 3) / 4 + 1) + 16u * 27u;  // message + the 16-entry window table of e * pk (ops_grumpkin.hpp)
                     s.insert(s.end(), {PK_SCHNORR, oi, b.in[0][0].witness, b.in[1][0].witness, (uint32_t)b.in[2].size(),
                                        (uint32_t)b.in[3].size()});
                     out(b.out[0]);

@@ -1020,13 +1020,14 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     // (plan.lane_needs_lane); a level of the main stream (or an inversion batch) waits for a lane only up to the level whose outputs
     // it reads (plan.level_needs_heavy[lane]): a level that reads a hash output does not wait for the Pedersen launch beside it.
     auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA || k == CLS_DIGEST; };
-    // (measured, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms; a circuit of heavy records
-    // only gains nothing from a second queue -- config 4 4.3 -> 4.6 ms -- and keeps everything on one stream)
+    // (measured in round 1, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms)
     bool any_heavy = false, any_main = !p.gate_offset.empty() || !p.cls_offset[CLS_LIGHT].empty();
     bool lane_any[N_HEAVY_LANES] = {false, false, false, false};  // a lane without records never joins the schedule (nor a capture)
     for (int k = 0; k < (int)N_CLS; k++)
         if (heavy_cls(k) && !p.cls_offset[k].empty()) { any_heavy = true; lane_any[heavy_lane(k)] = true; }
-    const bool one_stream = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || !any_main;
+    // (a circuit of heavy records only keeps everything on one stream: with the lanes side by side config 4 measured 2.62 ... 3.03 ms per solve
+    // from run to run against a steady 2.84-2.89 on one stream, and config 3 0.18 instead of 0.15 ms; ACVM_HEAVY_ONLY_SPLIT=1 splits anyway)
+    const bool one_stream = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || (!any_main && !getenv("ACVM_HEAVY_ONLY_SPLIT"));
     const bool split_heavy = !one_stream && !getenv("ACVM_NO_HEAVY_SPLIT");
     hipStream_t lane_stream[N_HEAVY_LANES] = {one_stream ? s : b->stream_heavy, one_stream ? s : (split_heavy ? b->stream_heavy2 : b->stream_heavy),
                                               one_stream ? s : (split_heavy ? b->stream_heavy3 : b->stream_heavy),

@@ -145,15 +145,16 @@ __device__ __forceinline__ EJac ej_identity(const ModCtx &f) { return EJac{mc_li
 // a = 0 (secp256k1) or a = -3 (secp256r1): M = 3 X^2 + a Z^4
 static inline __device__ __noinline__ EJac ej_dbl(const EJac &p, const ModCtx &f, bool a_minus3) {
     if (fr_is_zero(p.Z) || fr_is_zero(p.Y)) return ej_identity(f);
-    const Fr xx = mm_mul(p.X, p.X, f), yy = mm_mul(p.Y, p.Y, f), yyyy = mm_mul(yy, yy, f);
+    const Fr yy = mm_mul(p.Y, p.Y, f), yyyy = mm_mul(yy, yy, f);
     Fr s = mm_mul(p.X, yy, f);
     s = mm_add(s, s, f);
     s = mm_add(s, s, f);
-    Fr m = mm_add(mm_add(xx, xx, f), xx, f);
-    if (a_minus3) {
-        const Fr zz = mm_mul(p.Z, p.Z, f), z4 = mm_mul(zz, zz, f);
-        m = mm_sub(m, mm_add(mm_add(z4, z4, f), z4, f), f);
-    }
+    Fr m;
+    if (a_minus3) {  // 3 X^2 - 3 Z^4 = 3 (X - Z^2)(X + Z^2): one squaring and one product instead of three squarings
+        const Fr zz = mm_mul(p.Z, p.Z, f);
+        m = mm_mul(mm_sub(p.X, zz, f), mm_add(p.X, zz, f), f);
+    } else m = mm_mul(p.X, p.X, f);
+    m = mm_add(mm_add(m, m, f), m, f);
     EJac r;
     r.X = mm_sub(mm_sub(mm_mul(m, m, f), s, f), s, f);
     Fr y8 = mm_add(yyyy, yyyy, f);

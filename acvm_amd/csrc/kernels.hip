@@ -203,6 +203,19 @@ __global__ void __launch_bounds__(256) fr_selftest_kernel(uint64_t seed, uint32_
     }
     if (!fr_eq(fr_sub(fr_add(a, b), b), a)) bad |= 8;
     if (!fr_is_zero(fr_add(a, fr_neg(a)))) bad |= 16;
+    // byte-sized values (ops_common.hpp): the table, its arithmetic twin and the recognition of a stored form agree for every byte, and a
+    // value that is not a byte is told apart and still yields its canonical low limb
+    {
+        const uint32_t d = i & 0xffu;
+        uint32_t got = 0xffffffffu;
+        const Fr md = fr_from_byte(d);
+        bool isb;
+        if (!fr_eq(md, fr_mont_of_byte(d)) || !fr_eq(md, fr_from_u32(d)) || !fr_is_byte(md, got) || got != d || fr_low_limb(md, isb) != d || !isb) bad |= 128;
+        const uint32_t low = fr_low_limb(a, isb);  // a: a random reduced value (or 0, p - 1)
+        const Fr ca = fr_to_canonical(a);
+        const bool small = (ca.v[0] < 256u) && !(ca.v[1] | ca.v[2] | ca.v[3] | ca.v[4] | ca.v[5] | ca.v[6] | ca.v[7]);
+        if (isb != small || low != (small ? ca.v[0] : (ca.v[0] & 0x1fffffffu))) bad |= 256;
+    }
     if (bad) atomicAdd(mismatches, 1u);
 }
 

@@ -132,7 +132,7 @@ __device__ __forceinline__ void digest_leaf_add(uint32_t (&S)[8], uint32_t pair,
         w[k] = bswap32(first.v[7 - k]);  // big-endian bytes as little-endian message words
         w[8 + k] = mask == 3u ? bswap32(cb.v[7 - k]) : 0u;
     }
-    blake2s_compress(h, w, mask == 3u ? 64u : 32u, true);
+    blake2s_compress_body(h, w, mask == 3u ? 64u : 32u, true);
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k] += h[k];
 }

@@ -127,7 +127,9 @@ __device__ __forceinline__ Digest sha256_body(const M &m, uint32_t len) {
     c = c + d; b = rotr32(b ^ c, 7);
 
 // one compression: h <- F(h, 16 little-endian message words, byte counter t, final-block flag)
-static inline __device__ __noinline__ void blake2s_compress(uint32_t (&h)[8], const uint32_t (&w)[16], uint32_t t, bool last) {
+// (body; the shared out-of-line copy is blake2s_compress below, the digest kernels inline it: their h and w then stay in registers instead
+// of travelling through the stack of a call)
+__device__ __forceinline__ void blake2s_compress_body(uint32_t (&h)[8], const uint32_t (&w)[16], uint32_t t, bool last) {
     const uint32_t IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     uint32_t v[16];
 #pragma unroll
@@ -158,6 +160,7 @@ static inline __device__ __noinline__ void blake2s_compress(uint32_t (&h)[8], co
 #pragma unroll
     for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
 }
+static inline __device__ __noinline__ void blake2s_compress(uint32_t (&h)[8], const uint32_t (&w)[16], uint32_t t, bool last) { blake2s_compress_body(h, w, t, last); }
 __device__ __forceinline__ void blake2s_init(uint32_t (&h)[8]) {
     const uint32_t IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
 #pragma unroll

@@ -143,7 +143,7 @@ __device__ __forceinline__ Fr mm_inv(const Fr &a, const ModCtx &f) {  // prime m
 struct EJac { Fr X, Y, Z; };  // Montgomery coordinates mod p, Z == 0 <=> identity
 __device__ __forceinline__ EJac ej_identity(const ModCtx &f) { return EJac{mc_limbs(f.one), mc_limbs(f.one), fr_zero()}; }
 // a = 0 (secp256k1) or a = -3 (secp256r1): M = 3 X^2 + a Z^4
-static inline __device__ __noinline__ EJac ej_dbl(const EJac &p, const ModCtx &f, bool a_minus3) {
+__device__ __forceinline__ EJac ej_dbl(const EJac &p, const ModCtx &f, bool a_minus3) {
     if (fr_is_zero(p.Z) || fr_is_zero(p.Y)) return ej_identity(f);
     const Fr yy = mm_mul(p.Y, p.Y, f), yyyy = mm_mul(yy, yy, f);
     Fr s = mm_mul(p.X, yy, f);
@@ -167,7 +167,7 @@ static inline __device__ __noinline__ EJac ej_dbl(const EJac &p, const ModCtx &f
 }
 // complete mixed addition: q = (x, y) a finite affine point (Montgomery coordinates); 8M + 3S
 struct EAff { Fr x, y; };
-static inline __device__ __noinline__ EJac ej_add_aff(const EJac &p, const EAff &q, const ModCtx &f, bool a_minus3) {
+__device__ __forceinline__ EJac ej_add_aff(const EJac &p, const EAff &q, const ModCtx &f, bool a_minus3) {
     if (fr_is_zero(p.Z)) return EJac{q.x, q.y, mc_limbs(f.one)};
     const Fr z1z1 = mm_mul(p.Z, p.Z, f);
     const Fr u2 = mm_mul(q.x, z1z1, f), s2 = mm_mul(mm_mul(q.y, p.Z, f), z1z1, f);

@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "acvm_get_pending_foreign_call", "acvm_pending_foreign_call_inputs", "acvm_resolve_pending_foreign_call",
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
+    "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
 ]
 
 
@@ -197,7 +198,7 @@ class Stats(C.Structure):
                 ("class_algorithmic_bytes_per_instance", C.c_uint64 * 4), ("class_kernel_ms", C.c_double * 4),
                 ("n_gate_pairs", C.c_uint32), ("n_inverse_slots", C.c_uint32),
                 ("n_scaled_witnesses", C.c_uint32), ("n_arith_launches", C.c_uint32),
-                ("n_table_rows", C.c_uint32), ("n_digest_segments", C.c_uint32)]
+                ("n_table_rows", C.c_uint32), ("n_digest_segments", C.c_uint32), ("n_brillig_inlined", C.c_uint32), ("n_brillig_retries", C.c_uint32)]
 
     def as_dict(self):
         return {f: (list(getattr(self, f)) if f.startswith("class_") else getattr(self, f)) for f, _ in self._fields_}
@@ -256,6 +257,10 @@ def lib():
     L.acvm_witness_map_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_debug_modmul_rate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.acvm_tuning_set.argtypes = [C.c_char_p, C.c_longlong]
+    L.acvm_tuning_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
+    L.acvm_tuning_key.restype = C.c_char_p
+    L.acvm_tuning_key.argtypes = [C.c_uint]
     L.acvm_device_malloc.restype = C.c_void_p
     L.acvm_device_malloc.argtypes = [C.c_size_t]
     L.acvm_device_free.argtypes = [C.c_void_p]
@@ -324,6 +329,45 @@ def synchronize():
 
 def selftest(n=1 << 16, seed=1):
     return _check(lib().acvm_selftest(n, seed))
+
+
+def tuning_keys():
+    """every planner / scheduler mode and device limit of the library (csrc/tuning.hpp)"""
+    out, i = [], 0
+    while True:
+        k = lib().acvm_tuning_key(i)
+        if not k:
+            return out
+        out.append(k.decode())
+        i += 1
+
+
+def tuning_get(key):
+    v = C.c_longlong()
+    _check(lib().acvm_tuning_get(key.encode(), C.byref(v)))
+    return v.value
+
+
+def tuning_set(key, value):
+    _check(lib().acvm_tuning_set(key.encode(), int(value)))
+
+
+class tuning:
+    """with acvm_amd.tuning(scale=0, pairs=0): ... -- the modes hold for batches CREATED inside the block"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: tuning_get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning_set(k, v)
+        return False
 
 
 def modmul_rate(iters=400, waves_per_simd=8):

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacvm_amd.so")
-SOURCES = ["circuit.cpp", "plan.cpp", "batch.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_grumpkin.hip", "grumpkin_host.cpp", "kernels_brillig.hip", "kernels_ecdsa.hip", "shim.cpp"]
+SOURCES = ["circuit.cpp", "tuning.cpp", "plan.cpp", "batch.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_grumpkin.hip", "grumpkin_host.cpp", "kernels_brillig.hip", "kernels_ecdsa.hip", "shim.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
          "-ffp-contract=off"] + os.environ.get("ACVM_EXTRA_FLAGS", "").split()
@@ -26,19 +26,33 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(depfile):
+    """prerequisites recorded by the compiler (-MD) at the object's last build, or None"""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    body = text.split(":", 1)[1] if ":" in text else ""
+    return [t for t in body.replace("\\\n", " ").split() if t]
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     objs = []
     jobs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".inc")))
-    hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "acvm_amd.h")))
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(HERE, "build", s + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        dep = obj + ".d"
+        stale = force or not os.path.exists(obj)
+        if not stale:  # rebuilt when the source or any header the last build of this object read is newer (no depfile: rebuild)
+            deps = _deps(dep)
+            t = os.path.getmtime(obj)
+            stale = deps is None or any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps + [src])
+        if stale:
+            jobs.append([HIPCC] + FLAGS + ["-MD", "-MF", dep, "-c", src, "-o", obj])
         objs.append(obj)
     if jobs:  # translation units are independent: compile them concurrently
         from concurrent.futures import ThreadPoolExecutor

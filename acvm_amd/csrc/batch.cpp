@@ -42,7 +42,7 @@ struct acvm_circuit {
     std::unique_ptr<Circuit> c;
 };
 
-struct LaunchChunk { uint32_t first, count; bool coop = false; };  // records [first, first+count) of a class's level-major list (coop: CLS_HASH records flagged PLAN_HASH_COOP_FLAG)
+struct LaunchChunk { uint32_t first, count; bool coop = false; uint32_t lds_words = 0; };  // records [first, first+count) of a class's level-major list (coop: CLS_HASH records flagged PLAN_HASH_COOP_FLAG)
 struct ExactSegment { uint32_t cls, begin, end; };  // opcodes [begin, end): one light span or one heavy opcode
 
 struct acvm_batch {
@@ -96,8 +96,6 @@ struct acvm_batch {
         if (reuse()) { d.Mem = d_Memx; d.slot_of = nullptr; }
         return d;
     }
-    hipGraphExec_t graph_exec = nullptr;  // the level schedule as one graph (solve_graph)
-    uint32_t graph_launches = 0;
     std::vector<hipEvent_t> ev_heavy;  // per level 4 events: [4L + q] the records of heavy lane q at the level have run (q < 3)
     std::vector<hipEvent_t> ev_sync;
     uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_unscale_plain = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
@@ -134,6 +132,13 @@ struct acvm_batch {
     size_t stage_cap = 0;
     // acvm_batch_solve_opcode: every instance is an exact lane, slow_start[t] is its instruction pointer
     bool stepping = false;
+    // Brillig retry passes of the exact path (retry_device_limits): the compact VM scratch of the lanes being retried and their columns
+    uint32_t *d_br_scratch = nullptr, *d_br_lane = nullptr;
+    size_t br_scratch_bytes = 0;
+    uint32_t br_lane_cap = 0;
+    bool br_retry_active = false;
+    uint32_t br_max_regs = 1;  // most registers any Brillig opcode of the circuit uses
+    uint32_t n_brillig_retries = 0;  // retry passes of the last solve
 
     ~acvm_batch() {
         hipSetDevice(device);
@@ -148,7 +153,6 @@ struct acvm_batch {
         for (auto e : ev_pool) hipEventDestroy(e);
         for (auto e : ev_sync) hipEventDestroy(e);
         for (auto e : ev_heavy) hipEventDestroy(e);
-        if (graph_exec) hipGraphExecDestroy(graph_exec);
         if (stream_heavy) hipStreamDestroy(stream_heavy);
         if (stream_heavy2) hipStreamDestroy(stream_heavy2);
         if (stream_heavy3) hipStreamDestroy(stream_heavy3);
@@ -162,6 +166,8 @@ struct acvm_batch {
             if (p) hipFree(p);
         if (d_ped_seed) hipFree(d_ped_seed);
         if (d_stage) hipFree(d_stage);
+        if (d_br_scratch) hipFree(d_br_scratch);
+        if (d_br_lane) hipFree(d_br_lane);
         for (void *p : {(void *)d_fc_store, (void *)d_fc_pend_desc, (void *)d_fc_pend_vals})
             if (p) hipFree(p);
         for (auto &sl : fc_slots)
@@ -241,6 +247,18 @@ int acvm_device_upload(void *dst_device, const void *src_host, size_t bytes) {
     if (bytes) HIPCHK(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
     return 0;
 }
+
+int acvm_tuning_set(const char *key, long long value) {
+    if (!tuning_set(key, (int64_t)value)) return set_err(ACVM_E_INVALID, std::string("unknown tuning key ") + (key ? key : "(null)"));
+    return 0;
+}
+int acvm_tuning_get(const char *key, long long *value) {
+    int64_t v = 0;
+    if (!value || !tuning_get(key, &v)) return set_err(ACVM_E_INVALID, std::string("unknown tuning key ") + (key ? key : "(null)"));
+    *value = (long long)v;
+    return 0;
+}
+const char *acvm_tuning_key(unsigned index) { return tuning_key(index); }
 
 int acvm_selftest(uint32_t n, uint64_t seed) {
     uint32_t *d = nullptr, h = 0;
@@ -347,6 +365,7 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_scaled_witnesses = (uint32_t)p.scaled_ids.size();
     out->n_table_rows = p.slot_of.empty() ? p.n_witnesses : p.n_slots;
     out->n_digest_segments = p.n_digest_segments;
+    out->n_brillig_inlined = p.n_brillig_inlined;
     for (uint32_t L = 0; L + 1 < p.level_start.size(); L++) out->n_arith_launches += (p.level_start[L + 1] - p.level_start[L] + 65534) / 65535;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
@@ -431,15 +450,39 @@ static int batch_init(acvm_batch *b) {
             uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
             if (k == CLS_HASH) {  // byte-message hashes first: their own kernel, no scratch (the records of a level are independent)
                 auto is_coop = [&](uint32_t r) { return (b->plan.prog[b->plan.cls_offset[k][r] + 2] & PLAN_HASH_COOP_FLAG) != 0; };
+                // The LDS message of a launch is sized by its longest record (a 1 024-byte message takes the whole 64 KiB a workgroup may have):
+                // short messages (<= 256 bytes: 16 KiB per 64 instances) and long ones get launches of their own, so that one long message
+                // somewhere in the circuit does not cost every 64-byte SHA record its occupancy.
+                auto words_of = [&](uint32_t r) { return (b->plan.prog[b->plan.cls_offset[k][r] + 3] + 3u) / 4u; };
                 std::vector<std::pair<uint32_t, uint32_t>> recs;  // (offset, scratch)
+                uint32_t n_pass[3] = {0, 0, 0}, words_pass[2] = {0, 0};
+                for (int pass = 0; pass < 3; pass++)
+                    for (uint32_t r = lo; r < hi; r++) {
+                        const int cls = !is_coop(r) ? 2 : (words_of(r) <= 64u ? 0 : 1);
+                        if (cls != pass) continue;
+                        recs.push_back({b->plan.cls_offset[k][r], b->plan.cls_scratch[k][r]});
+                        n_pass[pass]++;
+                        if (pass < 2) words_pass[pass] = std::max(words_pass[pass], words_of(r));
+                    }
+                for (uint32_t r = lo; r < hi; r++) { b->plan.cls_offset[k][r] = recs[r - lo].first; b->plan.cls_scratch[k][r] = recs[r - lo].second; }
+                for (int pass = 0; pass < 2; pass++) {
+                    if (n_pass[pass]) b->cls_chunks[k][L].push_back({lo, n_pass[pass], true, words_pass[pass]});
+                    lo += n_pass[pass];
+                }
+            }
+            if (k == CLS_LIGHT) {  // straight-line Brillig records last: they have a kernel of their own (kernels_ops.hip LightSlOp)
+                auto is_sl = [&](uint32_t r) { return b->plan.prog[b->plan.cls_offset[k][r]] == PK_BRILLIG_SL; };
+                std::vector<uint32_t> offs;
+                uint32_t n_sl = 0;
                 for (int pass = 0; pass < 2; pass++)
                     for (uint32_t r = lo; r < hi; r++)
-                        if (is_coop(r) == (pass == 0)) recs.push_back({b->plan.cls_offset[k][r], b->plan.cls_scratch[k][r]});
-                uint32_t n_coop = 0;
-                for (uint32_t r = lo; r < hi; r++) n_coop += is_coop(r);
-                for (uint32_t r = lo; r < hi; r++) { b->plan.cls_offset[k][r] = recs[r - lo].first; b->plan.cls_scratch[k][r] = recs[r - lo].second; }
-                if (n_coop) b->cls_chunks[k][L].push_back({lo, n_coop, true});
-                lo += n_coop;
+                        if (is_sl(r) == (pass == 1)) { offs.push_back(b->plan.cls_offset[k][r]); n_sl += pass; }
+                for (uint32_t r = lo; r < hi; r++) b->plan.cls_offset[k][r] = offs[r - lo];
+                if (n_sl) {
+                    if (hi - n_sl > lo) b->cls_chunks[k][L].push_back({lo, hi - n_sl - lo});
+                    b->cls_chunks[k][L].push_back({hi - n_sl, n_sl, true});
+                    continue;
+                }
             }
             uint32_t first = lo;
             uint64_t used = 0;
@@ -480,7 +523,15 @@ static int batch_init(acvm_batch *b) {
     b->dp.ped_seed = nullptr;
     b->dp.fc_store = nullptr;
     b->dp.slot_of = nullptr;
-    b->dp.hash_coop_words = b->plan.hash_coop_words;
+    {   // limits of the Brillig VM for the level kernels and the first pass of the exact kernels (tuning.hpp)
+        const Tuning &tn = p.tune;
+        b->dp.brillig.steps = 1u << (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_steps_log2, 0), 31);
+        b->dp.brillig.call_depth = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_call_depth, 1), 1 << 20);
+        b->dp.brillig.mem_cap = 0;
+        b->dp.brillig.stride = 0;
+        for (uint32_t oi = 0; oi < p.n_opcodes; oi++)
+            if (p.prog[p.prog_offset[oi]] == PK_BRILLIG) b->br_max_regs = std::max(b->br_max_regs, p.prog[p.prog_offset[oi] + 7]);
+    }
     if (p.n_digest_segments) HIPCHK(hipMalloc((void **)&b->d_leaves, (size_t)8 * b->Bp * 4));
     if (!p.slot_of.empty()) {
         if (int rc = upload(&b->d_slot_of, p.slot_of)) return rc;
@@ -622,7 +673,7 @@ static int ensure_slow_capacity(acvm_batch *b, uint32_t n) {
 
 static ExactLanes exact_lanes(acvm_batch *b, uint32_t n_slow) {
     FcLanes fc{b->d_fc_pend_desc, b->fc_pend_desc_words, b->d_fc_pend_vals, b->fc_pend_vals_cap};
-    return ExactLanes{b->xids(), n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res, fc};
+    return ExactLanes{b->xids(), n_slow, b->d_assigned, b->d_slow_start, b->d_slow_res, fc, b->br_retry_active ? b->d_br_lane : nullptr};
 }
 
 // Foreign-call round trip, device side: the buffers a pending call's inputs are written to (per exact lane, FcLanes::pend_*) and
@@ -841,7 +892,7 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
             break;
         case CLS_HASH: launch_exact_hash(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
         case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
-        case CLS_BRILLIG: launch_exact_brillig(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_BRILLIG]); break;
+        case CLS_BRILLIG: launch_exact_brillig(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->br_retry_active ? b->d_br_scratch : b->d_cls_scratch[CLS_BRILLIG]); break;
         case CLS_ECDSA: launch_exact_ecdsa(s, b->xW(), b->xBp(), xdp, L, seg.begin); break;
         case CLS_HOSTBB:
             if (int rc = run_host_blackbox(b, seg.begin, true, n_slow)) return rc;
@@ -854,6 +905,112 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
     HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
     b->pend_host_valid = false;
     return 0;
+}
+
+// The Brillig VM of the reference has no limits: memory grows on write (brillig_vm/src/memory.rs:27-39), a program may run any number
+// of steps and nest calls to any depth (lib.rs:154-307). The kernels run with a memory capacity, a step limit and a call-stack depth
+// (BrilligLimits); a lane that reaches one ends its pass with DE_PANIC and one of the three device-limit codes. Such lanes are
+// RETRIED here: their opcode runs again (a failed VM run has no side effects: outputs are inserted after it finishes) with the
+// limit that was hit raised -- memory to twice the cell the write wanted, steps and depth sixteen-fold -- in a scratch that holds
+// only the retried lanes, until nothing hits a limit or a stated maximum of the library is reached (tuning.hpp: 2^26 steps, 2^16
+// frames, 2^22 cells by default). Past a maximum the SOLVE fails with ACVM_E_UNSUPPORTED: an instance never reports a failure the
+// reference would not report. Called with the lanes' results on the host (stream synchronised).
+static bool is_device_limit(const SlowResult &r) {
+    return r.status == ACVM_STATUS_FAILURE && r.err == ACVM_ERR_PANIC && (r.msg == 17u || r.msg == 18u || r.msg == 28u);
+}
+static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint32_t end_opcode) {
+    const Plan &p = b->plan;
+    const Tuning &tn = p.tune;
+    hipStream_t s = b->stream;
+    const BrilligLimits base = b->dp.brillig;
+    const uint64_t max_steps = 1ull << (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_steps_max_log2, 0), 31);
+    const uint64_t max_depth = (uint64_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_call_depth_max, 1), 1 << 24);
+    const uint64_t max_cells = 1ull << (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_mem_max_log2, 0), 30);
+    BrilligLimits lim = base;
+    int rc = 0;
+    for (;;) {
+        std::vector<uint32_t> lanes;
+        bool hit_steps = false, hit_depth = false, hit_mem = false;
+        uint64_t want_cells = 0, record_cells = 0;
+        uint32_t first_lane = 0;
+        for (uint32_t t = 0; t < n_slow; t++) {
+            const SlowResult &r = b->slow_res[t];
+            if (!is_device_limit(r)) continue;
+            if (lanes.empty()) first_lane = t;
+            lanes.push_back(t);
+            hit_steps |= r.msg == 18u;
+            hit_depth |= r.msg == 28u;
+            if (r.msg == 17u) { hit_mem = true; want_cells = std::max<uint64_t>(want_cells, (uint64_t)r.x0 + 1); }
+            if (r.opcode_index < p.n_opcodes && p.prog[p.prog_offset[r.opcode_index]] == PK_BRILLIG)
+                record_cells = std::max<uint64_t>(record_cells, p.prog[p.prog_offset[r.opcode_index] + 8]);
+        }
+        if (lanes.empty()) break;
+        auto refuse = [&](const std::string &what) {
+            b->solved = false;  // no results: the caller sets the inputs again (or resets) before the next solve
+            b->stepping = false;
+            const SlowResult &r = b->slow_res[first_lane];
+            return set_err(ACVM_E_UNSUPPORTED, "Brillig opcode " + std::to_string(r.opcode_index) + " of instance " + std::to_string(b->slow_ids[first_lane]) + " " + what +
+                                               "; the reference's VM has no such limit, this library does (tuning.hpp) -- solve this instance with the reference");
+        };
+        if (hit_steps) {
+            if (lim.steps >= max_steps) { rc = refuse("runs more than 2^" + std::to_string(tn.brillig_steps_max_log2) + " VM steps"); break; }
+            lim.steps = (uint32_t)std::min<uint64_t>((uint64_t)lim.steps * 16, max_steps);
+        }
+        if (hit_depth) {
+            if (lim.call_depth >= max_depth) { rc = refuse("nests more than " + std::to_string(max_depth) + " calls"); break; }
+            lim.call_depth = (uint32_t)std::min<uint64_t>((uint64_t)lim.call_depth * 16, max_depth);
+        }
+        const uint64_t cur_cells = lim.mem_cap ? lim.mem_cap : record_cells;
+        uint64_t cells = std::max<uint64_t>(cur_cells, 64);
+        if (hit_mem) {
+            if (want_cells > max_cells || cur_cells >= max_cells) { rc = refuse("writes VM memory cell " + std::to_string(want_cells - 1) + ", beyond 2^" + std::to_string(tn.brillig_mem_max_log2) + " cells"); break; }
+            cells = std::min<uint64_t>(std::max<uint64_t>(2 * want_cells, 4 * cells), max_cells);
+        }
+        lim.mem_cap = (uint32_t)cells;
+        lim.stride = ((uint64_t)lanes.size() + 63) / 64 * 64;
+        const uint64_t words = ((uint64_t)b->br_max_regs + cells) * 8 + lim.call_depth + cells / 4 + 16;
+        const size_t bytes = (size_t)words * lim.stride * 4;
+        if (bytes > b->br_scratch_bytes) {
+            if (b->d_br_scratch) hipFree(b->d_br_scratch);
+            b->d_br_scratch = nullptr;
+            b->br_scratch_bytes = 0;
+            if (hipMalloc((void **)&b->d_br_scratch, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                rc = refuse("needs " + std::to_string(bytes >> 20) + " MiB of VM scratch for " + std::to_string(lanes.size()) + " instances, which the device cannot provide");
+                break;
+            }
+            b->br_scratch_bytes = bytes;
+        }
+        if (n_slow > b->br_lane_cap) {
+            if (b->d_br_lane) hipFree(b->d_br_lane);
+            b->d_br_lane = nullptr;
+            HIPCHK(hipMalloc((void **)&b->d_br_lane, (size_t)n_slow * 4));
+            b->br_lane_cap = n_slow;
+        }
+        std::vector<uint32_t> col(n_slow, 0xFFFFFFFFu);
+        uint32_t min_start = 0xFFFFFFFFu;
+        for (size_t i = 0; i < lanes.size(); i++) {
+            const uint32_t t = lanes[i];
+            col[t] = (uint32_t)i;
+            const uint32_t at = b->slow_res[t].opcode_index;
+            b->slow_start[t] = at;  // the opcode runs again
+            min_start = std::min(min_start, at);
+            memset(&b->slow_res[t], 0, sizeof(SlowResult));
+            b->slow_res[t].status = ACVM_STATUS_IN_PROGRESS;
+        }
+        HIPCHK(hipMemcpyAsync(b->d_br_lane, col.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b->d_slow_res, b->slow_res.data(), (size_t)n_slow * sizeof(SlowResult), hipMemcpyHostToDevice, s));
+        b->dp.brillig = lim;
+        b->br_retry_active = true;
+        rc = run_exact_segments(b, n_slow, min_start, replay, end_opcode);
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_err(ACVM_E_DEVICE, "hipStreamSynchronize failed in a Brillig retry pass");
+        b->dp.brillig = base;
+        b->br_retry_active = false;
+        b->n_brillig_retries++;
+        if (rc) break;
+    }
+    return rc;
 }
 
 static int count_not_solved(acvm_batch *b) {
@@ -883,6 +1040,8 @@ static int solve_resume(acvm_batch *b) {
     HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_slow_res, b->slow_res.data(), (size_t)n_slow * sizeof(SlowResult), hipMemcpyHostToDevice, s));
     if (int rc = run_exact_segments(b, n_slow, min_start)) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    if (int rc = retry_device_limits(b, n_slow, true, 0xFFFFFFFFu)) return rc;
     HIPCHK(hipEventRecord(b->ev_end, s));
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0;
@@ -948,6 +1107,7 @@ static int solve_stepping(acvm_batch *b, bool one) {
         b->slow_res.resize(n_slow);
         HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (int rc = retry_device_limits(b, n_slow, false, end)) return rc;  // (a retried lane stands on `ip` again and re-runs only that opcode)
         for (uint32_t t = 0; t < n_slow; t++)
             if (b->slow_res[t].status == ACVM_STATUS_IN_PROGRESS && b->slow_start[t] <= ip) b->slow_start[t] = end;
         HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
@@ -955,6 +1115,8 @@ static int solve_stepping(acvm_batch *b, bool one) {
         HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
     } else {
         if (int rc = run_exact_segments(b, n_slow, ip, false)) return rc;  // ends with the Solved test of the lanes still running
+        HIPCHK(hipStreamSynchronize(s));
+        if (int rc = retry_device_limits(b, n_slow, false, 0xFFFFFFFFu)) return rc;
         for (uint32_t t = 0; t < n_slow; t++)
             if (b->slow_start[t] < p.n_opcodes) b->slow_start[t] = p.n_opcodes;
         // (run_exact_segments finishes only lanes whose pointer is at the end: publish the pointers first)
@@ -988,12 +1150,13 @@ struct LaunchTimers {
 };
 
 // The level schedule of one solve, enqueued on the batch's streams: the gate levels and the light records on the main stream,
-// the inversion batches on a second one, the heavy record classes on the heavy stream(s). Called directly, or under stream
-// capture (solve_graph: the launches and their cross-stream dependencies become ONE hipGraph that later solves replay).
+// the inversion batches on a second one, the heavy record classes on the heavy lanes. (One hipGraph of the whole schedule was
+// measured in round 2 at -2 % on the 250 k-opcode circuit and ROCm 7.2's hipStreamEndCapture recursed without bound on the
+// five-stream schedule of larger ones: removed.)
 static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     const Plan &p = b->plan;
     hipStream_t s = b->stream;
-    hipStream_t s2 = getenv("ACVM_NO_OVERLAP") ? b->stream : b->stream_dyn;  // measurement aid: serialise the two level kernels
+    hipStream_t s2 = p.tune.overlap ? b->stream_dyn : b->stream;  // (overlap = 0, a measurement aid, serialises the two level kernels)
     auto next_event = [&]() -> hipEvent_t {
         if (tm->ev_used == b->ev_pool.size()) {
             hipEvent_t e;
@@ -1026,11 +1189,9 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     for (int k = 0; k < (int)N_CLS; k++)
         if (heavy_cls(k) && !p.cls_offset[k].empty()) { any_heavy = true; lane_any[heavy_lane(k)] = true; }
     // (a circuit of heavy records only keeps everything on one stream: with the lanes side by side config 4 measured 2.62 ... 3.03 ms per solve
-    // from run to run against a steady 2.84-2.89 on one stream, and config 3 0.18 instead of 0.15 ms; ACVM_HEAVY_ONLY_SPLIT=1 splits anyway)
-    const bool one_stream = getenv("ACVM_NO_OVERLAP") || getenv("ACVM_NO_HEAVY_STREAM") || (!any_main && !getenv("ACVM_HEAVY_ONLY_SPLIT"));
-    const bool split_heavy = !one_stream && !getenv("ACVM_NO_HEAVY_SPLIT");
-    hipStream_t lane_stream[N_HEAVY_LANES] = {one_stream ? s : b->stream_heavy, one_stream ? s : (split_heavy ? b->stream_heavy2 : b->stream_heavy),
-                                              one_stream ? s : (split_heavy ? b->stream_heavy3 : b->stream_heavy),
+    // from run to run against a steady 2.84-2.89 on one stream, and config 3 0.18 instead of 0.15 ms)
+    const bool one_stream = !p.tune.overlap || !p.tune.heavy_streams || !any_main;
+    hipStream_t lane_stream[N_HEAVY_LANES] = {one_stream ? s : b->stream_heavy, one_stream ? s : b->stream_heavy2, one_stream ? s : b->stream_heavy3,
                                               one_stream ? s : b->stream_digest};
     bool any_dyn = !p.dyn_offset.empty();
     const bool any_async = any_dyn || any_heavy;
@@ -1045,10 +1206,8 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     bool main_dirty = false;  // the main stream has launches behind last_reg
     // A lane waits for the main stream only as far as its records read it (plan.lane_needs_main): a hash of initial witnesses and of other
     // hashes never waits for the range checks launched beside it (config 3: the Keccak level no longer starts behind the RANGE kernel).
-    // ACVM_LANE_LEVEL_BARRIER=1 restores "lane level L starts when main level L-1 is done" (measurement aid).
     std::vector<std::pair<uint32_t, hipEvent_t>> main_marks;  // (L, event): "main levels < L are done", in order
     uint32_t lane_main_waited[N_HEAVY_LANES] = {0, 0, 0, 0};
-    const bool level_barrier = getenv("ACVM_LANE_LEVEL_BARRIER") && atoi(getenv("ACVM_LANE_LEVEL_BARRIER"));
     uint32_t waited_inverse_level = 0, waited_heavy[N_HEAVY_LANES] = {0, 0, 0, 0}, lane_waited[N_HEAVY_LANES][N_HEAVY_LANES] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (size_t L = 0; L < n_levels; L++) {
         uint32_t n = p.level_start[L + 1] - p.level_start[L];
@@ -1093,9 +1252,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
         if (!one_stream)
             for (int q = 0; q < N_HEAVY_LANES; q++) {
                 if (!lane_used[q]) continue;
-                if (level_barrier) {
-                    if (prev_reg) HIPCHK(hipStreamWaitEvent(lane_stream[q], prev_reg, 0));
-                } else if (const uint32_t need_m = p.lane_needs_main[q][L + 1]; need_m > lane_main_waited[q]) {
+                if (const uint32_t need_m = p.lane_needs_main[q][L + 1]; need_m > lane_main_waited[q]) {
                     // the earliest mark behind main level need_m (1-based): "levels < mark" with mark >= need_m
                     auto it = std::lower_bound(main_marks.begin(), main_marks.end(), need_m, [](const std::pair<uint32_t, hipEvent_t> &mk, uint32_t v) { return mk.first < v; });
                     if (it != main_marks.end()) {
@@ -1118,9 +1275,12 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 if (prof) { e0 = next_event(); hipEventRecord(e0, sk); }
                 const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + ch.first;
                 switch (k) {
-                case CLS_LIGHT: launch_light_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
+                case CLS_LIGHT:
+                    if (ch.coop) launch_light_sl_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event);  // (coop: the level's straight-line Brillig records)
+                    else launch_light_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event);
+                    break;
                 case CLS_HASH:
-                    if (ch.coop) launch_hash_coop_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event);
+                    if (ch.coop) launch_hash_coop_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event, ch.lds_words);
                     else launch_hash_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]);
                     break;
                 case CLS_GRUMPKIN: launch_grumpkin_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
@@ -1177,40 +1337,6 @@ static int ensure_level_events(acvm_batch *b) {
     }
     return 0;
 }
-// The same schedule as ONE hipGraph (opt-in: ACVM_GRAPH=1): captured from the streams at the first solve, replayed by every later
-// solve of the batch. Measured on the config-5 mix at 250 k opcodes (tile of 4 096 instances, 748 launches, three streams): 54.0 ->
-// 52.7 ms per tile -- the circuit is bound by the work of its kernels, not by launch latency. It stays off by
-// default because ROCm 7.2's hipStreamEndCapture recurses without bound on the five-stream schedule of a circuit that size (the
-// capture of a 120 k-opcode circuit, 499 launches, ran out of stack; with an unlimited stack it took the whole box down).
-static bool graph_eligible(const acvm_batch *b) {
-    if (b->profiling || b->force_slow || !b->plan.cls_offset[CLS_HOSTBB].empty()) return false;
-    const char *e = getenv("ACVM_GRAPH");
-    return e && atoi(e) != 0;
-}
-static int solve_graph(acvm_batch *b) {
-    hipStream_t s = b->stream;
-    if (!b->graph_exec) {
-        hipGraph_t g = nullptr;
-        const bool dbg = getenv("ACVM_GRAPH_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[acvm] capture begin\n");
-        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_level_schedule(b, nullptr);
-        if (dbg) fprintf(stderr, "[acvm] enqueued rc=%d launches=%u\n", rc, b->n_launches);
-        hipError_t e = hipStreamEndCapture(s, &g);
-        if (dbg) fprintf(stderr, "[acvm] capture end: %s\n", hipGetErrorString(e));
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess) return set_err(ACVM_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        e = hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0);
-        if (dbg) fprintf(stderr, "[acvm] instantiate: %s\n", hipGetErrorString(e));
-        hipGraphDestroy(g);
-        if (e != hipSuccess) { b->graph_exec = nullptr; return set_err(ACVM_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-        b->graph_launches = b->n_launches;
-    }
-    b->n_launches = b->graph_launches;
-    HIPCHK(hipGraphLaunch(b->graph_exec, s));
-    return 0;
-}
-
 int acvm_batch_solve(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
@@ -1225,14 +1351,15 @@ int acvm_batch_solve(acvm_batch_t *b) try {
         uint32_t n_resolved = 0;
         for (uint32_t t = 0; t < b->slow_ids.size() && t < b->fc_lane.size(); t++)
             n_resolved += b->slow_res[t].status == ACVM_STATUS_REQUIRES_FOREIGN_CALL && b->fc_lane[t].resolved_new;
-        const char *e = getenv("ACVM_FC_RELEVEL");
-        const bool relevel = n_resolved && (e ? atoi(e) != 0 : (uint64_t)n_resolved * 16 >= b->B);
+        const int64_t mode = p.tune.fc_relevel;
+        const bool relevel = n_resolved && (mode >= 0 ? mode != 0 : (uint64_t)n_resolved * 16 >= b->B);
         if (!relevel) return solve_resume(b);
         b->solved = false;
     }
     hipStream_t s = b->stream;
     if (int rc = upload_fc_tables(b, 0)) return rc;  // the level kernels read the resolved results too
     b->n_launches = 0;
+    b->n_brillig_retries = 0;
     b->host_bb_msg.clear();
     b->arith_kernel_ms = 0;
     b->dyn_kernel_ms = 0;
@@ -1252,8 +1379,6 @@ int acvm_batch_solve(acvm_batch_t *b) try {
     HIPCHK(hipEventRecord(b->ev_start, s));
     if (b->force_slow) {
         launch_fill_u32(s, b->d_event, 0u, b->B);
-    } else if (graph_eligible(b)) {
-        if (int rc = solve_graph(b)) return rc;
     } else {
         if (int rc = enqueue_level_schedule(b, b->profiling ? &tm : nullptr)) return rc;
     }
@@ -1324,6 +1449,8 @@ int acvm_batch_solve(acvm_batch_t *b) try {
         if (int rc = upload_fc_tables(b, n_slow)) return rc;
         launch_exact_init(s, exact_lanes(b, n_slow));
         if (int rc = run_exact_segments(b, n_slow, min_start)) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+        if (int rc = retry_device_limits(b, n_slow, true, 0xFFFFFFFFu)) return rc;
         hipEventRecord(slow1, s);
     }
     HIPCHK(hipEventRecord(b->ev_end, s));
@@ -1563,8 +1690,10 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
         else snprintf(r.message, sizeof r.message, "%s", sr.x0 < 17 ? texts[sr.x0] : "brillig vm panic");
         break;
     }
-    case 17: snprintf(r.message, sizeof r.message, "brillig memory write at %u beyond the device capacity (set ACVM_BRILLIG_MEM_CELLS)", sr.x0); break;
+    // 17 / 18 / 28: device limits of the Brillig VM. retry_device_limits retries such lanes or fails the solve call; the texts are for debugging only
+    case 17: snprintf(r.message, sizeof r.message, "brillig memory write at %u beyond the device capacity", sr.x0); break;
     case 18: snprintf(r.message, sizeof r.message, "brillig step limit reached on the device"); break;
+    case 28: snprintf(r.message, sizeof r.message, "brillig call depth limit reached on the device"); break;
     case 19: {
         static const char *what[3] = {"Invalid public key x length", "Invalid public key y length", "Invalid signature length"};
         snprintf(r.message, sizeof r.message, "failed to solve blackbox function: %s, reason: %s", sr.x0 / 4 ? "ecdsa_secp256r1" : "ecdsa_secp256k1",
@@ -1784,8 +1913,26 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
         for (uint32_t i = 0; i < n; i++)
             if (b->slow_index[first + i] >= 0) flagged.push_back(first + i);
         if (flagged.empty()) return 0;
-        if (int rc = digest_exact_instances(b, flagged, first, out32)) return rc;
-        return 0;
+        if (flagged.size() <= 64) return digest_exact_instances(b, flagged, first, out32);
+        // many instances of the exact path (a whole batch waiting at a foreign call, a batch of failures): one launch instead of one
+        // launch + copy + synchronisation per instance
+        if (b->reuse()) {  // all lanes of the exact table at once, then scattered to their instances
+            const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+            const size_t leaf_bytes = align256((size_t)32 * n_slow);
+            if (int rc = stage_reserve(b, leaf_bytes + (size_t)n_slow * 32)) return rc;
+            uint32_t *d_acc = (uint32_t *)b->d_stage;
+            uint8_t *d_out = b->d_stage + leaf_bytes;
+            Unscale plain = b->unscale;
+            plain.event = b->d_slow_start;  // all zero: every lane of the exact table is "an instance of the exact path"
+            launch_digest(b->stream, b->d_Wx, b->x_cap, 0, n_slow, p.n_witnesses, b->d_producer, plain, (const int32_t *)b->d_ids_x, b->d_assigned, n_slow, d_acc, d_out);
+            HIPCHK(hipGetLastError());
+            std::vector<uint8_t> lanes((size_t)n_slow * 32);
+            HIPCHK(hipMemcpyAsync(lanes.data(), d_out, lanes.size(), hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            for (uint32_t j : flagged) memcpy(out32 + (size_t)(j - first) * 32, &lanes[(size_t)b->slow_index[j] * 32], 32);
+            return 0;
+        }
+        // (plain table: the table-wide kernel below serves generic and exact lanes alike through slow_index)
     }
     const uint32_t n_slow = (uint32_t)b->slow_ids.size();
     const uint32_t slice = n;  // the scratch is the 32-byte sum of the leaves per instance
@@ -1954,6 +2101,7 @@ int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     for (int k = 0; k < 4; k++) out->class_kernel_ms[k] = b->cls_kernel_ms[k];
     out->class_kernel_ms[CLS_GRUMPKIN] += b->cls_kernel_ms[CLS_PEDERSEN] + b->cls_kernel_ms[CLS_ECDSA] + b->cls_kernel_ms[CLS_HOSTBB];
     out->slow_path_ms = b->slow_path_ms;
+    out->n_brillig_retries = b->n_brillig_retries;
     return 0;
 }
 

@@ -10,6 +10,7 @@
 //   * fixed-base multiplications (G, and D[0], D[3], D[6] of the Schnorr hash ladder) use 8-bit window tables
 //     T[w][d-1] = d * 2^(8w) * P, so a 256-bit scalar costs 32 mixed additions and no doubling.
 #include "grumpkin_host.hpp"
+#include "tuning.hpp"
 #include <cstdlib>
 #include "fr_host.hpp"
 #include <hip/hip_runtime.h>
@@ -277,7 +278,7 @@ const GrumpkinTables *grumpkin_tables() {
         // memory the 8-bit windows stay in use.
         uint4 *w16 = nullptr;
         const size_t entries = (size_t)GRUMPKIN_N_WINDOW_BASES * GRUMPKIN_WIN16_STRIDE;
-        if (!getenv("ACVM_NO_WIN16") && hipMalloc((void **)&w16, entries * 64) == hipSuccess) {
+        if (tuning().win16 && hipMalloc((void **)&w16, entries * 64) == hipSuccess) {
             launch_grumpkin_win16_table(nullptr, t, w16);
             if (hipDeviceSynchronize() == hipSuccess) t.win16 = w16;
             else hipFree(w16);

@@ -32,6 +32,14 @@ struct FcLanes {
     uint32_t pend_vals_cap;
 };
 
+// limits of the Brillig VM for one launch (ops_brillig.hpp; batch.cpp retry_device_limits raises them on the exact path)
+struct BrilligLimits {
+    uint32_t steps;       // instructions one VM run may execute
+    uint32_t call_depth;  // call-stack words
+    uint32_t mem_cap;     // memory cells per lane; 0 = the record's own (planner estimate)
+    uint64_t stride;      // retry passes: lanes of the compact scratch (ExactLanes::br_lane indexes them)
+};
+
 // lanes of the exact path: flagged instances gathered through slow_ids
 struct ExactLanes {
     const uint32_t *slow_ids;
@@ -40,6 +48,7 @@ struct ExactLanes {
     const uint32_t *start_opcode;    // first opcode the lane executes (its event)
     SlowResult *results;
     FcLanes fc;
+    const uint32_t *br_lane = nullptr;  // Brillig retry pass: column of lane t in the compact VM scratch (0xFFFFFFFF: not retried); null otherwise
 };
 
 // everything a record needs besides the witness table
@@ -53,7 +62,7 @@ struct DeviceProgram {
     const uint32_t *ped_seed;     // per Pedersen record: hash_single(x of hash_pair(IV[domain separator], n), 0), affine, 16 x u32
     const FcStoreSlot *fc_store;  // device array, one entry per Brillig opcode with a ForeignCall (null: the circuit has none)
     const uint32_t *slot_of;      // witness -> row of the table for the level kernels (null: row = witness index; plan.cpp slot reuse)
-    uint32_t hash_coop_words;     // Plan::hash_coop_words: LDS words per instance of the cooperative hash level kernel
+    BrilligLimits brillig;        // limits of the Brillig VM for this launch
 };
 
 // projective witnesses (plan.cpp): device tables behind the export and the hand-over to the exact path
@@ -90,10 +99,14 @@ void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, ui
 // offsets: device array of record offsets into prog; scratch_off: per record, u32-word offset (per instance) into scratch
 void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
                         uint32_t *event);
+// the straight-line Brillig records of a level (PK_BRILLIG_SL, ops_light.hpp op_brillig_sl)
+void launch_light_sl_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
+                           uint32_t *event);
 void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                        const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
 // records flagged HASH_COOP_FLAG (ops_hash.hpp): four waves per 64 instances, the byte message in LDS
-void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event);
+// lds_words: 32-bit message words per instance of the longest record of the launch
+void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event, uint32_t lds_words);
 void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                            const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
 // Pedersen records: 4 waves per group of 64 instances, one accumulator chain each (kernels_grumpkin.hip)

@@ -40,7 +40,7 @@ template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
 hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
                        const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
-    extern __shared__ uint32_t lds[];  // max(hash_coop_words, 8) x 64 words
+    extern __shared__ uint32_t lds[];  // max(message words of the launch's longest record, 8) x 64 words
     // (the wave index as a scalar: everything indexed by it -- record words, witness ids, rows of slot_of -- is then a scalar load; as a
     // vector value each of those was a memory round trip of its own in front of every row)
     const uint32_t lane = threadIdx.x & 63u, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -98,9 +98,9 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, cons
     }
     if (!ok) atomicMin(&event[j], rec[1]);
 }
-void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event) {
+void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event, uint32_t lds_words) {
     if (!n || !B) return;
-    const size_t lds_bytes = (size_t)std::max<uint32_t>(dp.hash_coop_words, 8u) * 64u * 4u;
+    const size_t lds_bytes = (size_t)std::max<uint32_t>(lds_words, 8u) * 64u * 4u;
     const uint64_t groups = (uint64_t)((B + 63u) / 64u) * n;  // one per 64 instances of a record
     const bool four = groups * 4u <= 8192u;                    // four waves each while that still fits the chip about twice (1 024 SIMDs x 4-5 waves)
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535

@@ -13,6 +13,16 @@ struct LightOp {
         return dispatch_light(p, rec, dp.consts, dp.Mem);
     }
 };
+// The straight-line Brillig records of a level (ops_light.hpp op_brillig_sl) have a launch of their own on the main stream: their
+// executor carries the integer ALU and the field inversion (111 VGPRs against the 78 of the other light records, which keep their
+// occupancy), and its register file takes 16 KiB of LDS per block.
+struct LightSlOp {
+    template <class P>
+    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *, SlowResult *, const ExactLanes *, uint32_t) {
+        __shared__ uint32_t regs[BRILLIG_SL_REGS * 8 * LIGHT_SL_BLOCK];
+        return op_brillig_sl(p, rec, dp.consts, regs);
+    }
+};
 
 // One lane per flagged instance. Opcodes before the lane's event ran generically on exact data: their witness outputs
 // are kept (init_assigned_kernel) and only their memory side effects are re-applied here, because a later opcode of
@@ -159,6 +169,10 @@ void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const Exact
 void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
                         uint32_t *event) {
     launch_record_level<LightOp, 256>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
+}
+void launch_light_sl_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
+                           uint32_t *event) {
+    launch_record_level<LightSlOp, LIGHT_SL_BLOCK>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
 }
 void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end,
                        bool replay_memory) {

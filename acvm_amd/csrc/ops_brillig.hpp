@@ -4,9 +4,12 @@
 //   field / fixed-width integer ALU                    brillig_vm/src/arithmetic.rs:7-98 (BigUint semantics, bit_size <= 256)
 //   black box ops                                      brillig_vm/src/black_box.rs:42-165
 // Registers and memory live in per-lane device scratch laid out like the witness table ([slot][half][instance]), the call
-// stack and the hash staging bytes behind them. Control flow is per lane (SIMT divergence does the masking). The device
-// adds two limits the reference does not have, both reported loudly as failures: a memory capacity (planner estimate,
-// ACVM_BRILLIG_MEM_CELLS) and a step limit (2^22 instructions), so that a runaway program cannot hang the GPU.
+// stack and the hash staging bytes behind them. Control flow is per lane (SIMT divergence does the masking). The reference's VM has
+// no limits (memory grows on write, memory.rs:27-39; no step or call-depth bound, lib.rs:154-307); a kernel needs them: a memory
+// capacity, a step limit and a call-stack depth arrive with the launch (BrilligLimits). An instance that reaches one leaves the level
+// schedule, and the exact path RETRIES its opcode with the limits raised (batch.cpp retry_device_limits) up to the library's stated
+// maxima; past those acvm_batch_solve fails as a whole with ACVM_E_UNSUPPORTED -- an instance never reports a failure the reference
+// would not.
 #pragma once
 #include "kernels.hpp"
 #include "ops_ecdsa.hpp"
@@ -19,19 +22,13 @@ enum BrOp : uint32_t {
     BRO_BINARY_FIELD_OP = 0, BRO_BINARY_INT_OP, BRO_JUMP_IF_NOT, BRO_JUMP_IF, BRO_JUMP, BRO_CALL, BRO_CONST, BRO_RETURN,
     BRO_FOREIGN_CALL, BRO_MOV, BRO_LOAD, BRO_STORE, BRO_BLACK_BOX, BRO_TRAP, BRO_STOP
 };
-// panic codes (host: brillig_panic_text in batch.cpp)
-enum BrPanic : uint32_t {
-    BP_REG_READ = 1, BP_REG_WRITE = 2, BP_U64 = 3, BP_MEM_READ = 4, BP_BITS_256 = 6, BP_SUB_OVERFLOW = 7, BP_DIV_ZERO = 8, BP_SHIFT_BITS = 9,
-    BP_UNWRAP = 10, BP_BAD_INT_OP = 11, BP_BYTECODE_OOB = 12, BP_BAD_OPCODE = 13, BP_OUT_MEM_OOB = 15, BP_BAD_BB = 16
-};
-static constexpr uint32_t BRILLIG_STEP_LIMIT = 1u << 22;
-static constexpr uint32_t BRILLIG_CALL_STACK = 64;
 
 struct BrVm {
     uint4 *slots;     // Fr slots: registers [0, n_regs), memory [n_regs, n_regs + mem_cap)
-    uint32_t *words;  // call stack (BRILLIG_CALL_STACK words) then hash staging, word w of the lane at words[w * Bp + j]
-    uint64_t Bp, j;
-    uint32_t n_regs, mem_cap, n_mem, n_cs, pc;
+    uint32_t *words;  // call stack (cs_cap words) then hash staging, word w of the lane at words[w * Bp + j]
+    uint64_t Bp, j;   // stride and column of this lane in the VM's scratch
+    uint64_t iBp, ij; // stride and column of the INSTANCE in batch-wide tables (the foreign-call result store)
+    uint32_t n_regs, mem_cap, cs_cap, n_mem, n_cs, pc;
     uint32_t status;  // 0 running, 1 finished, 2 failure (trap / return / black box), 4 panic, 5 device limit
     uint32_t code, x0;
     Fr val;
@@ -70,144 +67,17 @@ struct BrVm {
     }
 };
 
-// ---- 256-bit helpers on canonical integers
-__device__ __forceinline__ Fr int_mask(const Fr &a, uint32_t bits) { return canon_mask(a, bits); }
-__device__ __forceinline__ int int_cmp(const Fr &a, const Fr &b) {
-    Fr d;
-    if (fr_sub256(d, a, b)) return -1;
-    return fr_is_zero(d) ? 0 : 1;
-}
-__device__ __forceinline__ Fr int_pow2(uint32_t bits) {  // 2^bits, bits < 256
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = (bits >> 5) == (uint32_t)i ? 1u << (bits & 31u) : 0u;
-    return r;
-}
-__device__ __forceinline__ Fr int_neg(const Fr &a) {
-    Fr z = fr_zero(), r;
-    fr_sub256(r, z, a);
-    return r;
-}
-__device__ __forceinline__ Fr int_mul_lo(const Fr &a, const Fr &b) {  // low 256 bits of a * b
-    uint32_t r[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) r[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int k = 0; k + i < 8; k++) {
-            c += (uint64_t)a.v[i] * b.v[k] + r[i + k];
-            r[i + k] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
-    Fr o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o.v[i] = r[i];
-    return o;
-}
-__device__ __forceinline__ uint32_t limb_or_zero(const Fr &a, int idx) {
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (k == idx) r = a.v[k];
-    return r;
-}
-__device__ __forceinline__ Fr int_shl(const Fr &a, uint32_t s) {  // s < 256
-    const int q = (int)(s >> 5);
-    const uint32_t rs = s & 31u;
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint32_t v = limb_or_zero(a, i - q) << rs;
-        if (rs) v |= limb_or_zero(a, i - q - 1) >> (32u - rs);
-        r.v[i] = v;
-    }
-    return r;
-}
-__device__ __forceinline__ Fr int_shr(const Fr &a, uint32_t s) {  // s < 256
-    const int q = (int)(s >> 5);
-    const uint32_t rs = s & 31u;
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint32_t v = limb_or_zero(a, i + q) >> rs;
-        if (rs) v |= limb_or_zero(a, i + q + 1) << (32u - rs);
-        r.v[i] = v;
-    }
-    return r;
-}
-// two's complement view of SignedDiv (arithmetic.rs:84-98): a < 2^(bits-1) -> (+, a); a < 2^bits -> (-, 2^bits - a); else (+, a - 2^bits)
-__device__ __forceinline__ bool int_to_signed(const Fr &a, uint32_t bits, Fr &mag) {
-    if (int_cmp(a, int_pow2(bits - 1u)) < 0) { mag = a; return false; }
-    if (bits == 256u) { mag = int_neg(a); return true; }
-    const Fr full = int_pow2(bits);
-    if (int_cmp(a, full) < 0) { fr_sub256(mag, full, a); return true; }
-    fr_sub256(mag, a, full);
-    return false;
-}
-
-// evaluate_binary_bigint_op (arithmetic.rs:23-81) + the conversion back to a field element (from_be_bytes_reduce)
+// evaluate_binary_bigint_op through the VM: a panic of the reference stops the lane (ops_light.hpp int_op_core)
 static inline __device__ __noinline__ Fr brillig_int_op(BrVm &vm, uint32_t op, uint32_t bits, const Fr &fa, const Fr &fb) {
-    Fr a = fr_to_canonical(fa), b = fr_to_canonical(fb), r = fr_zero();
-    if (bits > 256u) { vm.panic(BP_BITS_256); return r; }
-    switch (op) {
-    case 0: fr_add256(r, a, b); r = int_mask(r, bits); break;  // a, b < 2^254: no carry out of 256 bits
-    case 1: {  // (2^bits + a - b) % 2^bits; BigUint underflow when b > 2^bits + a
-        const bool borrow = fr_sub256(r, a, b) != 0;
-        if (borrow && bits < 256u && int_cmp(int_neg(r), int_pow2(bits)) > 0) { vm.panic(BP_SUB_OVERFLOW); return fr_zero(); }
-        r = int_mask(r, bits);
-        break;
-    }
-    case 2: r = int_mask(int_mul_lo(a, b), bits); break;
-    case 3: {  // SignedDiv
-        if (bits == 0u) { vm.panic(BP_SUB_OVERFLOW); return r; }
-        Fr ma, mb, q, rem;
-        const bool sa = int_to_signed(a, bits, ma), sb = int_to_signed(b, bits, mb);
-        if (fr_is_zero(mb)) { vm.panic(BP_DIV_ZERO); return r; }
-        canon_divrem(ma, mb, q, rem);
-        if (!((sa != sb) && !fr_is_zero(q))) r = q;
-        else if (bits == 256u) r = int_neg(q);
-        else {
-            if (int_cmp(q, int_pow2(bits)) > 0) { vm.panic(BP_SUB_OVERFLOW); return r; }
-            fr_sub256(r, int_pow2(bits), q);
-        }
-        break;
-    }
-    case 4: {  // UnsignedDiv
-        a = int_mask(a, bits);
-        b = int_mask(b, bits);
-        if (fr_is_zero(b)) { vm.panic(BP_DIV_ZERO); return r; }
-        Fr rem;
-        canon_divrem(a, b, r, rem);
-        break;
-    }
-    case 5: case 6: case 7: {
-        const int c = int_cmp(int_mask(a, bits), int_mask(b, bits));
-        r.v[0] = op == 5u ? c == 0 : (op == 6u ? c < 0 : c <= 0);
-        break;
-    }
-    case 8: case 9: case 10:
-#pragma unroll
-        for (int i = 0; i < 8; i++) r.v[i] = op == 8u ? a.v[i] & b.v[i] : (op == 9u ? a.v[i] | b.v[i] : a.v[i] ^ b.v[i]);
-        r = int_mask(r, bits);
-        break;
-    case 11: case 12: {
-        if (bits > 128u) { vm.panic(BP_SHIFT_BITS); return r; }
-        if (b.v[4] | b.v[5] | b.v[6] | b.v[7]) { vm.panic(BP_UNWRAP); return r; }  // to_u128().unwrap()
-        const bool small = !(b.v[1] | b.v[2] | b.v[3]) && b.v[0] < 256u;
-        if (small) r = int_mask(op == 11u ? int_shl(a, b.v[0]) : int_shr(a, b.v[0]), bits);
-        break;
-    }
-    default: vm.panic(BP_BAD_INT_OP); return r;
-    }
-    return fr_from_canonical(canon_reduce(r));
+    uint32_t panic = 0;
+    const Fr r = int_op_core(op, bits, fa, fb, panic);
+    if (panic) vm.panic(panic);
+    return r;
 }
 
 // black_box.rs:42-165. Operand words: see plan.cpp (HeapVector = pointer reg + size reg, HeapArray = pointer reg + literal)
 static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t bbop, const uint32_t *__restrict__ w, const GrumpkinTables &T) {
-    MsgBuf m{vm.words + (uint64_t)BRILLIG_CALL_STACK * vm.Bp, vm.Bp, vm.j, 0u, 0u};
+    MsgBuf m{vm.words + (uint64_t)vm.cs_cap * vm.Bp, vm.Bp, vm.j, 0u, 0u};
     auto heap_vector = [&](uint32_t preg, uint32_t sreg, uint64_t &ptr, uint64_t &len) {
         const Fr pv = vm.reg_get(preg), sv = vm.reg_get(sreg);
         return !vm.status && vm.to_usize(pv, ptr) && vm.to_usize(sv, len);
@@ -309,13 +179,13 @@ static inline __device__ __noinline__ void brillig_foreign_call(BrVm &vm, const 
     const uint32_t n_slow = L ? L->n_slow : 0u;
     FcStoreSlot st{nullptr, nullptr};
     if (!is_static && dp.fc_store && fc_slot != K_NONE) st = dp.fc_store[fc_slot];
-    auto desc = [&](uint32_t w) { return is_static ? sdesc[w] : st.desc[(uint64_t)w * vm.Bp + vm.j]; };
-    auto value = [&](uint32_t i) { return is_static ? fr_const(dp.consts, dp.bytecode[fc_vals_off + i]) : fr_load(st.vals, i, vm.Bp, vm.j); };
+    auto desc = [&](uint32_t w) { return is_static ? sdesc[w] : st.desc[(uint64_t)w * vm.iBp + vm.ij]; };
+    auto value = [&](uint32_t i) { return is_static ? fr_const(dp.consts, dp.bytecode[fc_vals_off + i]) : fr_load(st.vals, i, vm.iBp, vm.ij); };
     uint32_t k = fc_counter;
     bool found = is_static;
     if (!is_static) {
         k -= n_static;
-        found = st.desc && k < st.desc[vm.j];
+        found = st.desc && k < st.desc[vm.ij];
     }
     if (!found) {
         vm.status = 3;
@@ -415,13 +285,22 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
         }
         return op_ok();
     }
+    // limits and scratch addressing of this launch: the level kernels and the first pass of the exact kernels use the record's memory
+    // capacity and the lane's column of the class scratch; a retry pass of the exact path (L->br_lane) brings larger limits and a
+    // scratch that holds only the lanes being retried
+    const BrilligLimits &lim = dp.brillig;
+    const bool compact = L && L->br_lane;
+    if (compact && L->br_lane[t] == K_NONE) return op_ok();  // (not reached: a lane that is not retried is not InProgress)
     BrVm vm;
     vm.n_regs = r[7];
-    vm.mem_cap = r[8];
+    vm.mem_cap = lim.mem_cap ? lim.mem_cap : r[8];
+    vm.cs_cap = lim.call_depth;
     vm.slots = (uint4 *)scratch;
-    vm.words = scratch + (uint64_t)(vm.n_regs + vm.mem_cap) * 8u * p.Bp;
-    vm.Bp = p.Bp;
-    vm.j = p.j;
+    vm.Bp = compact ? lim.stride : p.Bp;
+    vm.j = compact ? L->br_lane[t] : p.j;
+    vm.iBp = p.Bp;
+    vm.ij = p.j;
+    vm.words = scratch + (uint64_t)(vm.n_regs + vm.mem_cap) * 8u * vm.Bp;
     vm.n_mem = vm.n_cs = vm.pc = vm.status = vm.code = vm.x0 = 0u;
     vm.val = fr_zero();
     for (uint32_t i = 0; i < vm.n_regs; i++) fr_store(vm.slots, i, vm.Bp, vm.j, fr_zero());  // unset registers read 0 (registers.rs:25-33)
@@ -445,7 +324,7 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
     if (n_bc == 0) vm.panic(BP_BYTECODE_OOB);
     uint32_t steps = 0;
     while (!vm.status) {
-        if (++steps > BRILLIG_STEP_LIMIT) { vm.status = 5; vm.code = DM_BRILLIG_STEP_LIMIT; break; }
+        if (++steps > lim.steps) { vm.status = 5; vm.code = DM_BRILLIG_STEP_LIMIT; break; }
         const uint32_t *__restrict__ ins = bc + 8u * vm.pc;
         const uint32_t op = ins[0], a = ins[1], b = ins[2], c = ins[3];
         uint32_t next = vm.pc + 1u;
@@ -478,7 +357,7 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
             else { vm.status = 2; vm.code = DM_BRILLIG_RETURN; }
             break;
         case BRO_CALL:
-            if (vm.n_cs >= BRILLIG_CALL_STACK) { vm.status = 5; vm.code = DM_BRILLIG_STEP_LIMIT; break; }
+            if (vm.n_cs >= vm.cs_cap) { vm.status = 5; vm.code = DM_BRILLIG_CALL_DEPTH; break; }
             vm.words[(uint64_t)(vm.n_cs++) * vm.Bp + vm.j] = vm.pc;
             next = ins[5];
             break;

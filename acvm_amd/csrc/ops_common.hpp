@@ -21,7 +21,7 @@ static constexpr uint32_t K_NONE = 0xFFFFFFFFu;
 enum RecKind : uint32_t {
     K_ARITH = 0, K_RANGE = 1, K_LOGIC = 2, K_HASH = 3, K_PEDERSEN = 4, K_FIXED_BASE = 5, K_SCHNORR = 6, K_ZERO_OUT = 7,
     K_QUOTIENT = 8, K_TO_LE_RADIX = 9, K_MEM_INIT = 10, K_MEM_OP = 11, K_BRILLIG = 12, K_ECDSA = 13, K_PERM_SORT = 14,
-    K_DIGEST_LEAF = 15, K_RANGE_MULTI = 16  // level-schedule records without an opcode of their own (plan.cpp)
+    K_DIGEST_LEAF = 15, K_RANGE_MULTI = 16, K_BRILLIG_SL = 17  // level-schedule records without an opcode of their own (plan.cpp)
 };
 
 // error codes = ACVM_ERR_* of include/acvm_amd.h
@@ -36,7 +36,7 @@ enum DevMsg : uint32_t {
     DM_MEM_INDEX_U64 = 6, DM_MEM_READ_EXPR = 7, DM_RADIX = 8, DM_LIMB_LOW = 9, DM_LIMB_HIGH = 10, DM_SCALAR = 11,
     DM_SCHNORR_SIG_LEN = 12, DM_SCHNORR_MSG_LEN = 13, DM_BRILLIG_TRAP = 14, DM_BRILLIG_RETURN = 15, DM_BRILLIG_PANIC = 16,
     DM_BRILLIG_MEM_CAP = 17, DM_BRILLIG_STEP_LIMIT = 18, DM_BRILLIG_BB_FAILED = 19, DM_PEDERSEN_DOMAIN = 20, DM_FC_COUNT = 21,
-    DM_FC_SIZE = 22, DM_FC_PENDING_CAP = 23, DM_HOST_MESSAGE = 24, DM_ECDSA_LEN = 25, DM_ECDSA_PANIC = 26, DM_SORT_TUPLE = 27
+    DM_FC_SIZE = 22, DM_FC_PENDING_CAP = 23, DM_HOST_MESSAGE = 24, DM_ECDSA_LEN = 25, DM_ECDSA_PANIC = 26, DM_SORT_TUPLE = 27, DM_BRILLIG_CALL_DEPTH = 28
 };
 
 // err / aux0 / aux1 are the ABI's acvm_result_t fields; msg (DevMsg) and x0, x1 let the host rebuild the message text

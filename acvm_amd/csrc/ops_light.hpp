@@ -421,6 +421,241 @@ __device__ __forceinline__ OpResult op_arith(const P &p, const uint32_t *__restr
     return op_ok();
 }
 
+// panic codes (host: brillig_panic_text in batch.cpp)
+enum BrPanic : uint32_t {
+    BP_REG_READ = 1, BP_REG_WRITE = 2, BP_U64 = 3, BP_MEM_READ = 4, BP_BITS_256 = 6, BP_SUB_OVERFLOW = 7, BP_DIV_ZERO = 8, BP_SHIFT_BITS = 9,
+    BP_UNWRAP = 10, BP_BAD_INT_OP = 11, BP_BYTECODE_OOB = 12, BP_BAD_OPCODE = 13, BP_OUT_MEM_OOB = 15, BP_BAD_BB = 16
+};
+
+// ---- 256-bit helpers on canonical integers
+__device__ __forceinline__ Fr int_mask(const Fr &a, uint32_t bits) { return canon_mask(a, bits); }
+__device__ __forceinline__ int int_cmp(const Fr &a, const Fr &b) {
+    Fr d;
+    if (fr_sub256(d, a, b)) return -1;
+    return fr_is_zero(d) ? 0 : 1;
+}
+__device__ __forceinline__ Fr int_pow2(uint32_t bits) {  // 2^bits, bits < 256
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (bits >> 5) == (uint32_t)i ? 1u << (bits & 31u) : 0u;
+    return r;
+}
+__device__ __forceinline__ Fr int_neg(const Fr &a) {
+    Fr z = fr_zero(), r;
+    fr_sub256(r, z, a);
+    return r;
+}
+__device__ __forceinline__ Fr int_mul_lo(const Fr &a, const Fr &b) {  // low 256 bits of a * b
+    uint32_t r[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k + i < 8; k++) {
+            c += (uint64_t)a.v[i] * b.v[k] + r[i + k];
+            r[i + k] = (uint32_t)c;
+            c >>= 32;
+        }
+    }
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = r[i];
+    return o;
+}
+__device__ __forceinline__ uint32_t limb_or_zero(const Fr &a, int idx) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k == idx) r = a.v[k];
+    return r;
+}
+__device__ __forceinline__ Fr int_shl(const Fr &a, uint32_t s) {  // s < 256
+    const int q = (int)(s >> 5);
+    const uint32_t rs = s & 31u;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = limb_or_zero(a, i - q) << rs;
+        if (rs) v |= limb_or_zero(a, i - q - 1) >> (32u - rs);
+        r.v[i] = v;
+    }
+    return r;
+}
+__device__ __forceinline__ Fr int_shr(const Fr &a, uint32_t s) {  // s < 256
+    const int q = (int)(s >> 5);
+    const uint32_t rs = s & 31u;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = limb_or_zero(a, i + q) >> rs;
+        if (rs) v |= limb_or_zero(a, i + q + 1) << (32u - rs);
+        r.v[i] = v;
+    }
+    return r;
+}
+// two's complement view of SignedDiv (arithmetic.rs:84-98): a < 2^(bits-1) -> (+, a); a < 2^bits -> (-, 2^bits - a); else (+, a - 2^bits)
+__device__ __forceinline__ bool int_to_signed(const Fr &a, uint32_t bits, Fr &mag) {
+    if (int_cmp(a, int_pow2(bits - 1u)) < 0) { mag = a; return false; }
+    if (bits == 256u) { mag = int_neg(a); return true; }
+    const Fr full = int_pow2(bits);
+    if (int_cmp(a, full) < 0) { fr_sub256(mag, full, a); return true; }
+    fr_sub256(mag, a, full);
+    return false;
+}
+
+// evaluate_binary_bigint_op (arithmetic.rs:23-81) + the conversion back to a field element (from_be_bytes_reduce)
+// `panic` receives a BrPanic code (and the result is meaningless) where the reference panics
+static inline __device__ Fr int_op_core(uint32_t op, uint32_t bits, const Fr &fa, const Fr &fb, uint32_t &panic) {
+    Fr a = fr_to_canonical(fa), b = fr_to_canonical(fb), r = fr_zero();
+    if (bits > 256u) { panic = BP_BITS_256; return r; }
+    switch (op) {
+    case 0: fr_add256(r, a, b); r = int_mask(r, bits); break;  // a, b < 2^254: no carry out of 256 bits
+    case 1: {  // (2^bits + a - b) % 2^bits; BigUint underflow when b > 2^bits + a
+        const bool borrow = fr_sub256(r, a, b) != 0;
+        if (borrow && bits < 256u && int_cmp(int_neg(r), int_pow2(bits)) > 0) { panic = BP_SUB_OVERFLOW; return fr_zero(); }
+        r = int_mask(r, bits);
+        break;
+    }
+    case 2: r = int_mask(int_mul_lo(a, b), bits); break;
+    case 3: {  // SignedDiv
+        if (bits == 0u) { panic = BP_SUB_OVERFLOW; return r; }
+        Fr ma, mb, q, rem;
+        const bool sa = int_to_signed(a, bits, ma), sb = int_to_signed(b, bits, mb);
+        if (fr_is_zero(mb)) { panic = BP_DIV_ZERO; return r; }
+        canon_divrem(ma, mb, q, rem);
+        if (!((sa != sb) && !fr_is_zero(q))) r = q;
+        else if (bits == 256u) r = int_neg(q);
+        else {
+            if (int_cmp(q, int_pow2(bits)) > 0) { panic = BP_SUB_OVERFLOW; return r; }
+            fr_sub256(r, int_pow2(bits), q);
+        }
+        break;
+    }
+    case 4: {  // UnsignedDiv
+        a = int_mask(a, bits);
+        b = int_mask(b, bits);
+        if (fr_is_zero(b)) { panic = BP_DIV_ZERO; return r; }
+        Fr rem;
+        canon_divrem(a, b, r, rem);
+        break;
+    }
+    case 5: case 6: case 7: {
+        const int c = int_cmp(int_mask(a, bits), int_mask(b, bits));
+        r.v[0] = op == 5u ? c == 0 : (op == 6u ? c < 0 : c <= 0);
+        break;
+    }
+    case 8: case 9: case 10:
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = op == 8u ? a.v[i] & b.v[i] : (op == 9u ? a.v[i] | b.v[i] : a.v[i] ^ b.v[i]);
+        r = int_mask(r, bits);
+        break;
+    case 11: case 12: {
+        if (bits > 128u) { panic = BP_SHIFT_BITS; return r; }
+        if (b.v[4] | b.v[5] | b.v[6] | b.v[7]) { panic = BP_UNWRAP; return r; }  // to_u128().unwrap()
+        const bool small = !(b.v[1] | b.v[2] | b.v[3]) && b.v[0] < 256u;
+        if (small) r = int_mask(op == 11u ? int_shl(a, b.v[0]) : int_shr(a, b.v[0]), bits);
+        break;
+    }
+    default: panic = BP_BAD_INT_OP; return r;
+    }
+    return fr_from_canonical(canon_reduce(r));
+}
+
+
+// ------------------------------------------------------------------------------------------------ straight-line Brillig
+// [K_BRILLIG_SL, opcode, has_pred, n_inputs, n_outputs, n_ins, E(pred)?, E(input) x n_inputs, (w, flag) x n_outputs,
+//  (kind | sub_op << 8 | dst << 16 | a << 20 | b << 24, bit_size or jump target, constant) x n_ins]
+// Level schedule only (plan.cpp "straight-line Brillig"): an Opcode::Brillig whose bytecode is BinaryFieldOp / BinaryIntOp / Const / Mov /
+// Stop / Trap and FORWARD jumps over at most BRILLIG_SL_REGS registers, with single-value inputs and outputs -- the stdlib's integer
+// fallbacks (stdlib/src/blackbox_fallbacks/uint.rs:212-260), the inversion and comparison helpers the compiler emits -- runs here without
+// the VM: same arithmetic (brillig_vm/src/arithmetic.rs:7-81), same register semantics (unset registers read 0, registers.rs:25-33;
+// input i in register i, register i into output i, pwg/brillig.rs:46-111). The wave walks the instructions once, in order; a lane
+// executes instruction i when its own program counter stands on it (a forward jump only skips ahead), so control flow stays
+// wave-uniform. The registers live in LDS (reg r, word k of lane l at regs[(8 r + k) * BLOCK + l]). Anything the reference would report
+// -- a panicking integer op, a trap, an output conflict -- only flags the instance; the exact path then runs the opcode's own
+// K_BRILLIG record in the VM, which words the failure.
+static constexpr uint32_t BRILLIG_SL_REGS = 4;
+static constexpr uint32_t LIGHT_SL_BLOCK = 128;
+enum SlKind : uint32_t { SL_FIELD = 0, SL_INT = 1, SL_CONST = 2, SL_MOV = 3, SL_JUMP = 4, SL_JUMP_IF = 5, SL_JUMP_IF_NOT = 6, SL_STOP = 7, SL_TRAP = 8 };
+__device__ __forceinline__ Fr sl_get(const uint32_t *regs, uint32_t r) {
+    Fr x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) x.v[k] = regs[(8u * r + (uint32_t)k) * LIGHT_SL_BLOCK];
+    return x;
+}
+__device__ __forceinline__ void sl_set(uint32_t *regs, uint32_t r, const Fr &x) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) regs[(8u * r + (uint32_t)k) * LIGHT_SL_BLOCK] = x.v[k];
+}
+template <class P>
+__device__ __forceinline__ OpResult op_brillig_sl(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts, uint32_t *lds) {
+    if (P::exact || !lds) return op_fail_msg(DE_PANIC, 0, DM_NONE);  // never scheduled on the exact path
+    const uint32_t has_pred = r[2], n_inputs = r[3], n_outputs = r[4], n_ins = r[5];
+    const uint32_t *q = r + 6;
+    Fr pred = fr_one();
+    if (has_pred) {
+        const OpResult e = expr_value(p, q, consts, pred);
+        if (e.err) return e;
+        q += expr_len(q);
+    }
+    uint32_t *regs = lds + threadIdx.x;
+    for (uint32_t i = 0; i < BRILLIG_SL_REGS; i++) sl_set(regs, i, fr_zero());
+    for (uint32_t i = 0; i < n_inputs; i++) {
+        Fr v;
+        const OpResult e = expr_value(p, q, consts, v);
+        if (e.err) return op_fail(DE_TOO_MANY_UNKNOWNS);
+        q += expr_len(q);
+        sl_set(regs, i, v);
+    }
+    const uint32_t *outs = q, *ins = outs + 2 * n_outputs;
+    const bool skip = fr_is_zero(pred);  // zero_out_brillig_outputs (brillig.rs:133-150)
+    uint32_t pc = skip ? 0xFFFFFFFFu : 0u;  // this lane's program counter; 0xFFFFFFFF = finished
+    bool bad = false;
+    for (uint32_t i = 0; i < n_ins; i++, ins += 3) {
+        const bool act = pc == i;
+        if (__builtin_amdgcn_ballot_w64(act) == 0) continue;  // (no lane of the wave stands here: jumped over, or all done)
+        const uint32_t w = ins[0], kind = w & 0xffu, sub = (w >> 8) & 0xffu, dst = (w >> 16) & 0xfu, ra = (w >> 20) & 0xfu, rb = (w >> 24) & 0xfu;
+        uint32_t next = i + 1u;
+        if (kind <= SL_MOV) {
+            Fr v;
+            if (kind == SL_CONST) v = fr_const(consts, ins[2]);
+            else if (kind == SL_MOV) v = sl_get(regs, ra);
+            else {
+                const Fr x = sl_get(regs, ra), y = sl_get(regs, rb);
+                if (kind == SL_FIELD) {
+                    switch (sub) {
+                    case 0: v = fr_add(x, y); break;
+                    case 1: v = fr_sub(x, y); break;
+                    case 2: v = fr_mul(x, y); break;
+                    case 3: v = fr_mul(x, fr_inv(y)); break;
+                    default: v = fr_eq(x, y) ? fr_one() : fr_zero(); break;
+                    }
+                } else {
+                    uint32_t panic = 0;
+                    v = int_op_core(sub, ins[1], x, y, panic);
+                    if (panic && act) { bad = true; next = 0xFFFFFFFFu; }
+                }
+            }
+            if (act) sl_set(regs, dst, v);
+        } else if (kind == SL_JUMP) next = ins[1];
+        else if (kind == SL_JUMP_IF || kind == SL_JUMP_IF_NOT) {
+            const bool zero = fr_is_zero(sl_get(regs, ra));
+            if (zero == (kind == SL_JUMP_IF_NOT)) next = ins[1];
+        } else {  // Stop, Trap
+            next = 0xFFFFFFFFu;
+            if (kind == SL_TRAP && act) bad = true;
+        }
+        if (act) pc = next;
+    }
+    if (bad) return op_fail(DE_PANIC);
+    bool ok = true;
+    for (uint32_t i = 0; i < n_outputs; i++)
+        ok = p.insert(outs[2 * i], skip ? fr_zero() : sl_get(regs, i), outs[2 * i + 1]) && ok;
+    return ok ? op_ok() : op_fail(DE_UNSATISFIED);
+}
+
 // every record kind of class CLS_LIGHT
 template <class P>
 __device__ __forceinline__ OpResult dispatch_light(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts, uint4 *Mem) {

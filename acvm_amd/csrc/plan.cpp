@@ -1,5 +1,6 @@
 // plan.cpp -- static replay of the reference's assigned-set bookkeeping + levelisation (see plan.hpp).
 #include "plan.hpp"
+#include "tuning.hpp"
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -109,41 +110,22 @@ struct PendingRecord {
 struct PendingInverse {
     uint32_t level, use_level, partner, opcode, gate;
 };
-// Denominators are inverted ahead of their gates, in batches: every INV_EPOCH-th level the inversion kernel takes all
-// denominators that became known since the last batch, so that one field inversion (Montgomery's trick) is shared by all of
+// Denominators are inverted ahead of their gates, in batches: every inv_epoch-th level (tuning.hpp, default 4) the inversion kernel
+// takes all denominators that became known since the last batch, so that one field inversion (Montgomery's trick) is shared by all of
 // them and its latency is off the path of the levels in between. A gate whose denominator is younger than the last batch
-// waits for the next one (at most INV_EPOCH levels).
-static uint32_t inv_epoch() {
-    static const uint32_t v = [] { const char *e = getenv("ACVM_INV_EPOCH"); const int x = e ? atoi(e) : 4; return (uint32_t)(x > 0 ? x : 4); }();
-    return v;
-}
-
+// waits for the next one (at most inv_epoch levels).
+//
 // Records of the heavy classes (hashes, Grumpkin / Pedersen, ECDSA, Brillig: bound by the integer pipe or by latency) run on their
-// own stream beside the levels of the main stream. Two scheduling knobs exist for circuits whose main stream stalls on them:
-//   * ACVM_HEAVY_EPOCH = K: heavy records are launched only every K-th level, all that became ready since the last batch together
+// own streams beside the levels of the main stream. Two scheduling modes exist for circuits whose main stream stalls on them:
+//   * heavy_epoch = K: heavy records are launched only every K-th level, all that became ready since the last batch together
 //     (like the inversion batches): fewer, fatter launches;
-//   * ACVM_HEAVY_LATENCY = D: the main stream may read the outputs of the heavy batch of level L from level L + D + 1 on, i.e. the
-//     planner prices a heavy batch at D levels of main-stream work and puts the consumers behind it instead of letting the whole
-//     level wait. Heavy records that read heavy outputs (same stream, in order) only need a later batch.
+//   * heavy_latency = D (pedersen_latency for Pedersen alone): the main stream may read the outputs of the heavy batch of level L from
+//     level L + D + 1 on, i.e. the planner prices a heavy batch at D levels of main-stream work and puts the consumers behind it
+//     instead of letting the whole level wait. Heavy records that read heavy outputs (same stream, in order) only need a later batch.
 // Measured on the config-5 mix at 250 k opcodes, tile of 4 096 instances (profiles/r02_config5_schedule.txt): when only a few records
 // read heavy outputs (round 1's generator) K = D = 4 takes a tile from 46.5 to 43.5 ms; when every tenth witness is a heavy output
 // and gates read them everywhere (the SURVEY 8d generator) the same setting stretches the DAG from 180 to 529 levels and the tile
 // from 54 to 69 ms. The default is therefore K = 1, D = 0: every record at its earliest level.
-static uint32_t heavy_epoch() {
-    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_EPOCH"); const int x = e ? atoi(e) : 1; return (uint32_t)(x > 0 ? x : 1); }();
-    return v;
-}
-static uint32_t heavy_latency() {
-    static const uint32_t v = [] { const char *e = getenv("ACVM_HEAVY_LATENCY"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 0 ? x : 0); }();
-    return v;
-}
-// The same slack for the Pedersen records alone: a commitment is a serial chain of ~45 point additions and two inversions, 0.2-0.5 ms
-// of latency for one launch however few records it holds, while its two outputs are a vanishing share of the witnesses: pricing it at
-// a few levels costs the DAG next to nothing (unlike the 32 outputs of every hash) and frees every level from waiting for it.
-static uint32_t pedersen_latency() {
-    static const uint32_t v = [] { const char *e = getenv("ACVM_PEDERSEN_LATENCY"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 0 ? x : 0); }();
-    return v;
-}
 
 // Expression record: [n_mul, n_lin, qc, (coef, l, r) x n_mul, (coef, -1/coef, w) x n_lin]
 void emit_expr(std::vector<uint32_t> &s, ConstPool &pool, const Expr &e) {
@@ -188,12 +170,79 @@ struct Reads {
 
 uint32_t clamp_reg(uint64_t r) { return r > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)r; }
 
+// =========================================================================== straight-line Brillig
+// The stdlib's integer fallbacks (stdlib/src/blackbox_fallbacks/uint.rs:212-260) and most compiler-generated helper calls (inversion and
+// comparison hints) are Brillig programs of a few instructions without loops. Running them in the VM kernel costs a launch of a 298-VGPR
+// interpreter per level (profiles/r02v_config5_1m.json: 51-58 ms per tile for 0.5 % of the opcodes). Such an opcode -- single-value inputs
+// and outputs; bytecode made of BinaryFieldOp / BinaryIntOp / Const / Mov / Stop / Trap and jumps that only go FORWARD; at most SL_REGS
+// registers -- gets a second record, [PK_BRILLIG_SL, ...] (ops_light.hpp op_brillig_sl), which the LEVEL schedule runs on the main stream
+// beside the gates. The exact path keeps the VM record, so every failure shape (panicking integer op, trap, output conflict, missing
+// input) is still reported by the VM in the reference's words.
+constexpr uint32_t SL_REGS = 4, SL_MAX_INS = 255;
+void emit_straight_line(const BrilligCall &b, uint32_t oi, ConstPool &pool, std::vector<uint32_t> &out, std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> &sl_of) {
+    const size_t n = b.bytecode.size();
+    if (n == 0 || n > SL_MAX_INS || b.inputs.size() > SL_REGS || b.outputs.size() > SL_REGS) return;
+    for (auto &in : b.inputs) if (in.is_array) return;
+    for (auto &ot : b.outputs) if (ot.is_array) return;
+    // registers: inputs and outputs keep their index; any other register moves to a free slot
+    const uint64_t fixed = std::max(b.inputs.size(), b.outputs.size());
+    std::vector<uint64_t> used;
+    auto use = [&](uint64_t r) { if (r >= fixed && std::find(used.begin(), used.end(), r) == used.end()) used.push_back(r); };
+    for (size_t k = 0; k < n; k++) {
+        const BrilligOp &op = b.bytecode[k];
+        switch (op.op) {
+        case BR_BINARY_INT_OP:
+            if (op.bit_size > 256) return;  // (the VM words that panic)
+            [[fallthrough]];
+        case BR_BINARY_FIELD_OP: use(op.a); use(op.b); use(op.c); break;
+        case BR_CONST: use(op.a); break;
+        case BR_MOV: use(op.a); use(op.b); break;
+        case BR_JUMP_IF: case BR_JUMP_IF_NOT:
+            use(op.a);
+            [[fallthrough]];
+        case BR_JUMP:
+            if (op.location <= k) return;  // a loop (or a jump onto itself): the VM runs it
+            break;
+        case BR_STOP: case BR_TRAP: break;
+        default: return;  // calls, memory, foreign calls, black boxes
+        }
+    }
+    if (fixed + used.size() > SL_REGS) return;
+    for (uint64_t r : used) if (r >= 65536) return;  // (register index past the VM's maximum: a panic of the reference)
+    auto slot = [&](uint64_t r) -> uint32_t { return r < fixed ? (uint32_t)r : (uint32_t)(fixed + (std::find(used.begin(), used.end(), r) - used.begin())); };
+    const uint32_t at = (uint32_t)out.size();
+    out.insert(out.end(), {PK_BRILLIG_SL, oi, b.has_predicate ? 1u : 0u, (uint32_t)b.inputs.size(), (uint32_t)b.outputs.size(), (uint32_t)n});
+    if (b.has_predicate) emit_expr(out, pool, b.predicate);
+    for (auto &in : b.inputs) emit_expr(out, pool, in.single);
+    const uint32_t flags_at = (uint32_t)out.size() + 1 - at;
+    for (auto &ot : b.outputs) { out.push_back(ot.w); out.push_back(0); }
+    for (size_t k = 0; k < n; k++) {
+        const BrilligOp &op = b.bytecode[k];
+        uint32_t kind = 0, sub = 0, dst = 0, ra = 0, rb = 0, x = 0, cidx = 0;
+        switch (op.op) {
+        case BR_BINARY_FIELD_OP: case BR_BINARY_INT_OP:
+            kind = op.op == BR_BINARY_INT_OP ? 1u : 0u; sub = op.sub_op; dst = slot(op.a); ra = slot(op.b); rb = slot(op.c); x = op.bit_size;
+            break;
+        case BR_CONST: kind = 2; dst = slot(op.a); cidx = pool.intern(op.value); break;
+        case BR_MOV: kind = 3; dst = slot(op.a); ra = slot(op.b); break;
+        case BR_JUMP: kind = 4; x = (uint32_t)std::min<uint64_t>(op.location, 0xFFFFFFFEull); break;
+        case BR_JUMP_IF: case BR_JUMP_IF_NOT: kind = op.op == BR_JUMP_IF ? 5u : 6u; ra = slot(op.a); x = (uint32_t)std::min<uint64_t>(op.location, 0xFFFFFFFEull); break;
+        case BR_STOP: kind = 7; break;
+        default: kind = 8; break;  // Trap
+        }
+        out.insert(out.end(), {kind | sub << 8 | dst << 16 | ra << 20 | rb << 24, x, cidx});
+    }
+    sl_of[oi] = {at, flags_at};
+}
+
 }  // namespace
 
 Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
     const bool host_blackbox = opts.host_blackbox;
+    const Tuning tune = tuning();  // one snapshot for the whole plan
     auto t0 = std::chrono::steady_clock::now();
     Plan p;
+    p.tune = tune;
     p.n_opcodes = (uint32_t)c.opcodes.size();
     // The witness table is dense (slot = witness index); the reference's BTreeMap takes any u32 index. Circuit bytes are
     // untrusted input: an index near 2^32 must neither wrap `max + 1` nor make the planner allocate per-witness vectors of
@@ -254,6 +303,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     p.prog_scratch.assign(c.opcodes.size(), 0);
     // the `flag` words (was the output already assigned for the generic instance?) are patched in the second pass
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> out_slots(c.opcodes.size());  // (position of flag word, witness)
+    // straight-line Brillig (below): the light records of the eligible opcodes, appended to `prog` behind the in-order program
+    std::vector<uint32_t> sl_prog;
+    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> sl_of;  // opcode -> (offset in sl_prog, position of its first output flag word)
     {
         std::map<uint32_t, Block> st = blocks;  // running len / readable per block in program order
         for (auto &kv : st) { kv.second.len = 0; kv.second.readable = 0; }
@@ -294,7 +346,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     bool coop = (b.func == BB_SHA256 || b.func == BB_BLAKE2S || b.func == BB_KECCAK256) && b.out.size() == 32 &&
                                 !b.in[0].empty() && b.in[0].size() <= PLAN_HASH_COOP_MAX_BYTES;
                     for (auto &in : b.in[0]) coop = coop && in.num_bits >= 1 && in.num_bits <= 8;
-                    if (coop) p.hash_coop_words = std::max<uint32_t>(p.hash_coop_words, (uint32_t)(b.in[0].size() + 3) / 4);
                     s.insert(s.end(), {PK_HASH, oi, b.func | (coop ? PLAN_HASH_COOP_FLAG : 0u), (uint32_t)b.in[0].size(), (uint32_t)b.out.size(),
                                        b.func == BB_KECCAK256_VAR ? b.in[1][0].witness : 0xFFFFFFFFu});
                     for (auto &in : b.in[0]) { s.push_back(in.witness); s.push_back(in.num_bits); }
@@ -517,11 +568,13 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 if (has_grumpkin) p.needs_grumpkin = true;
                 if (has_grumpkin && host_blackbox) unsupported(oi, "a caller-supplied BlackBoxFunctionSolver inside Brillig black-box ops");
                 uint64_t mem_cap = arr_cells + mem_hint + 64 + (max_hash_hint ? 64 : 0) + (has_foreign ? 64 : 0);
-                if (const char *e = getenv("ACVM_BRILLIG_MEM_CELLS")) mem_cap = std::max<uint64_t>(mem_cap, strtoull(e, nullptr, 10));
+                mem_cap = std::max<uint64_t>(mem_cap, (uint64_t)std::max<int64_t>(tune.brillig_mem_cells, 0));
                 mem_cap = std::min<uint64_t>(mem_cap, 1u << 20);
                 uint32_t n_regs = (uint32_t)std::max<uint64_t>(max_reg, 1);
-                // scratch: registers + memory cells (8 words each) + call stack (64 words) + byte staging for hashes
-                p.prog_scratch[oi] = (uint32_t)((n_regs + mem_cap) * 8 + 64 + (max_hash_hint ? mem_cap / 4 + 16 : 0));
+                // scratch: registers + memory cells (8 words each) + call stack + byte staging for hashes (batch.cpp brillig_scratch_words
+                // sizes the retry passes of the exact path by the same formula)
+                p.prog_scratch[oi] = (uint32_t)((n_regs + mem_cap) * 8 + (uint64_t)std::min<int64_t>(std::max<int64_t>(tune.brillig_call_depth, 1), 1 << 20) +
+                                                (max_hash_hint ? mem_cap / 4 + 16 : 0));
                 p.fc_pending_vals = std::max<uint64_t>(p.fc_pending_vals, has_foreign ? fc_pending_vals + mem_cap : 0);
                 uint32_t fc_slot = 0xFFFFFFFFu;
                 if (has_foreign) { fc_slot = (uint32_t)p.fc_slot_opcode.size(); p.fc_slot_opcode.push_back(oi); }
@@ -540,6 +593,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     if (ot.is_array) for (uint32_t w : ot.arr) out(w);
                     else out(ot.w);
                 }
+                if (tune.brillig_inline) emit_straight_line(b, oi, pool, sl_prog, sl_of);
                 break;
             }
             default:
@@ -552,6 +606,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return p;
     }
+    const uint32_t sl_base = (uint32_t)p.prog.size();  // nothing in `prog` moves from here on: later passes only append
+    p.prog.insert(p.prog.end(), sl_prog.begin(), sl_prog.end());
 
     // =========================================================================== generic-instance replay + levels
     // witnesses produced by a record of a heavy class (those run on their own stream, batch.cpp): level of the record, else 0
@@ -560,7 +616,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // hlevel[w]: the level from which the HEAVY stream may read w (level[w] is the main stream's; they differ for the outputs of
     // heavy records: the heavy stream is in order, the main stream sees them HEAVY_LATENCY levels later)
     std::vector<uint32_t> hlevel(nw, 0);
-    const uint32_t K_heavy = heavy_epoch(), D_heavy = heavy_latency();
+    const uint32_t K_heavy = (uint32_t)std::max<int64_t>(tune.heavy_epoch, 1), D_heavy = (uint32_t)std::max<int64_t>(tune.heavy_latency, 0);
+    const uint32_t D_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_latency, 0);
     auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA || cls == CLS_DIGEST; };
     std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, witness of a heavy record it reads)
     uint32_t out_latency = 0;  // levels of slack of the record whose outputs are being assigned
@@ -590,7 +647,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // operands -- all on the host, field arithmetic is exact, so the canonical value scale_w^-1 * stored is bit-identical.
     // Pinned (scale 1): initial witnesses and everything a non-Arithmetic opcode mentions. Export and the exact path unscale.
     std::vector<uint8_t> pinned(nw, 0), is_scaled(nw, 0);
-    const bool scaling_on = !getenv("ACVM_NO_SCALE");
+    const bool scaling_on = tune.scale != 0;
     {
         auto pin = [&](uint32_t w) { if (w < nw) pinned[w] = 1; };
         auto pin_expr = [&](const Expr &e) {
@@ -643,7 +700,10 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     for (uint32_t oi = 0; oi < c.opcodes.size() && p.truncated_at == 0xFFFFFFFFu; oi++) {
         const Opcode &o = c.opcodes[oi];
         if (o.kind != OP_ARITHMETIC) {
-            const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN : (uint32_t)p.prog_class[oi];
+            // a Brillig opcode with a straight-line record runs in the light class of the level schedule (the exact path keeps its VM record)
+            const auto sl_it = o.kind == OP_BRILLIG ? sl_of.find(oi) : sl_of.end();
+            const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN
+                                     : sl_it != sl_of.end() ? (uint32_t)CLS_LIGHT : (uint32_t)p.prog_class[oi];
             const bool rec_heavy = is_heavy(rec_cls);
             Reads rd(known, rec_heavy ? hlevel : level);
             uint32_t extra_level = 0;
@@ -729,7 +789,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             if (!rec_heavy)  // a main-stream record: which heavy records does it wait for
                 for (uint32_t w : rec_reads)
                     if (heavy_level[w]) heavy_reads.push_back({lvl, w});
-            out_latency = rec_cls == CLS_PEDERSEN ? std::max(D_heavy, pedersen_latency()) : D_heavy;
+            out_latency = rec_cls == CLS_PEDERSEN ? std::max(D_heavy, D_pedersen) : D_heavy;
             out_lane = (uint8_t)(1 + heavy_lane(rec_cls));
             assign_out(oi, lvl, rec_heavy);
             if (mem_access == 1) blocks[o.block_id].rlevel = std::max(blocks[o.block_id].rlevel, lvl);
@@ -739,6 +799,11 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
             p.n_other_records++;
             records.push_back({lvl, rec_cls, oi, std::move(rec_reads)});
+            if (sl_it != sl_of.end()) {  // same "already assigned" flags as the VM record's outputs, in order
+                records.back().prog_at = sl_base + sl_it->second.first;
+                for (size_t k = 0; k < out_slots[oi].size(); k++) p.prog[sl_base + sl_it->second.second + 2 * k] = p.prog[out_slots[oi][k].first];
+                p.n_brillig_inlined++;
+            }
             continue;
         }
         const Expr &e = o.expr;
@@ -792,7 +857,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             if (unk_is_folded) {
                 kind = GATE_SOLVE_DYN;
                 reads.push_back(unk_partner);
-                const uint32_t K = inv_epoch();
+                const uint32_t K = (uint32_t)std::max<int64_t>(tune.inv_epoch, 1);
                 inv_level = 1 + ((level[unk_partner] + K - 1) / K) * K;  // first batch level after the denominator is known
                 lvl = std::max(lvl, inv_level);
             } else kind = GATE_SOLVE;
@@ -916,14 +981,13 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // `local`: the host's output at first; a record may take `local` over (GATE_SETLOCAL_FLAG) when its first consumer is
     // appended directly behind it, so chains host -> tail -> tail's consumer run in one wave as well (the records that read the
     // previous owner are all in front of it by then).
-    static constexpr uint32_t GATE_MAX_TAILS = 5;
     for (uint32_t gi = 0; gi < gates.size(); gi++) {
         gates[gi].run_level = gates[gi].level;
         gates[gi].owner = gates[gi].last_gate = gi;
     }
-    if (!getenv("ACVM_NO_PAIRS")) {
-        const uint32_t max_tails = getenv("ACVM_MAX_TAILS") ? (uint32_t)atoi(getenv("ACVM_MAX_TAILS")) : GATE_MAX_TAILS;
-        const bool chains = !getenv("ACVM_NO_CHAINS");
+    if (tune.pairs) {
+        const uint32_t max_tails = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune.max_tails, 0), 64);
+        const bool chains = tune.chains != 0;
         std::vector<uint32_t> producer_gate(nw, 0xFFFFFFFFu), root_of(gates.size(), 0xFFFFFFFFu);
         for (uint32_t gi = 0; gi < gates.size(); gi++)
             if ((gates[gi].words[0] & 0xff) == GATE_SOLVE) producer_gate[gates[gi].words[2]] = gi;
@@ -977,56 +1041,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             iv.gate = slot;  // from here on: the slot
         }
     }
-    // =========================================================================== heavy records: fewer, fatter launches within their slack
-    // A heavy record launched at its earliest level usually shares the launch with one or two others, and at small tiles such a
-    // launch costs the latency of the record's serial chain however few records it holds (a Pedersen commitment: 75 us for one
-    // record of a 4 096-instance tile, 6 ns per instance when a launch is full). Its outputs are rarely needed at once: every
-    // reader has a level of its own, and the record may run anywhere before the earliest of them without delaying anything. The
-    // records are therefore moved, inside [earliest level, earliest reader - 1 - margin], onto as few launch levels as possible:
-    // processed by descending earliest level (readers before producers, so a moved record hands its slack on to the records it
-    // reads), a record joins a launch level already opened inside its window, else it opens one at its earliest level -- the
-    // mirror image of the classic interval-stabbing greedy, which is optimal in the number of points. Readers keep their levels.
-    // (opt-in, ACVM_HEAVY_SLACK=1: on the config-5 mix no heavy record has slack -- 748 -> 747 launches -- because every heavy output
-    // has a reader within a level or two)
-    if (getenv("ACVM_HEAVY_SLACK") && atoi(getenv("ACVM_HEAVY_SLACK")) && !records.empty()) {
-        const uint32_t margin = getenv("ACVM_HEAVY_MARGIN") ? (uint32_t)atoi(getenv("ACVM_HEAVY_MARGIN")) : 2u;
-        uint32_t last_level = 0;
-        for (auto &g : gates) last_level = std::max(last_level, g.level);
-        for (auto &r : records) last_level = std::max(last_level, r.level);
-        for (auto &iv : inverses) last_level = std::max(last_level, iv.level);
-        std::vector<uint32_t> deadline(nw, 0xFFFFFFFFu);  // the latest level whose records may still produce w
-        auto reader = [&](uint32_t w, uint32_t lvl) { if (lvl && lvl - 1 < deadline[w]) deadline[w] = lvl - 1; };
-        for (auto &g : gates)
-            for (uint32_t w : g.reads) reader(w, g.run_level);  // a tail reads in its host's wave
-        for (auto &iv : inverses) reader(iv.partner, iv.level);
-        std::vector<uint32_t> order;
-        for (uint32_t ri = 0; ri < records.size(); ri++) {
-            if (is_heavy(records[ri].cls)) order.push_back(ri);
-            else for (uint32_t w : records[ri].reads) reader(w, records[ri].level);
-        }
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return records[a].level > records[b].level; });
-        std::vector<uint8_t> is_launch(last_level + 2, 0);
-        uint32_t moved = 0;
-        for (uint32_t ri : order) {
-            PendingRecord &r = records[ri];
-            uint32_t hi = last_level;
-            for (auto &slot : out_slots[r.opcode])
-                if (p.producer[slot.second] == r.opcode) hi = std::min(hi, deadline[slot.second]);
-            hi = hi > r.level + margin ? hi - margin : r.level;  // leave the launch a few levels to finish before it is read
-            uint32_t at = r.level;
-            for (uint32_t L = r.level; L <= hi; L++)
-                if (is_launch[L]) { at = L; break; }
-            is_launch[at] = 1;
-            if (at != r.level) {
-                moved++;
-                r.level = at;
-                for (auto &slot : out_slots[r.opcode])
-                    if (p.producer[slot.second] == r.opcode) { heavy_level[slot.second] = at; hlevel[slot.second] = at; }
-            }
-            for (uint32_t w : r.reads) reader(w, r.level);
-        }
-        (void)moved;
-    }
     // =========================================================================== digest leaves folded into the solve
     // wdef[w]: the level whose launches write w (a fused gate writes in its host's wave; 0 = initial witness)
     std::vector<uint32_t> wdef(nw, 0);
@@ -1041,7 +1055,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         // whose assigned witnesses are complete, for the generic instance. Launched in epochs (every DIGEST_EPOCH-th level all pairs
         // completed since the last one, in records of at most 128 pairs): the leaves are order-free, so nothing waits for anything but
         // its own two witnesses, and a row can be recycled as soon as the epoch of its pair has run.
-        const uint32_t K_dig = getenv("ACVM_DIGEST_EPOCH") ? std::max(1, atoi(getenv("ACVM_DIGEST_EPOCH"))) : 8u;
+        const uint32_t K_dig = (uint32_t)std::max<int64_t>(tune.digest_epoch, 1);
         const uint32_t PAIRS_PER_RECORD = 128;
         std::map<uint32_t, std::vector<uint32_t>> by_level;  // epoch level -> pairs
         for (uint32_t i = 0; i < (nw + 1) / 2; i++) {
@@ -1082,7 +1096,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // kernel reads anyway and needs the low limb it forms anyway: the level schedule runs a copy of the hash record extended by
     // (RANGE opcode, bits) per input (function word | PLAN_HASH_RANGE_FLAG) and drops the RANGE record; a failing check flags the instance
     // with the RANGE opcode's index, exactly as its own record would. A check may move to a later level this way (nothing reads a RANGE).
-    if (!getenv("ACVM_NO_RANGE_FUSE")) {
+    if (tune.range_fuse) {
         std::unordered_map<uint32_t, std::vector<size_t>> range_of;  // witness -> RANGE records (bits <= 8) not yet fused
         for (size_t i = 0; i < records.size(); i++) {
             const PendingRecord &r = records[i];
@@ -1137,7 +1151,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // dependent latencies every wave pays before its only load (config 3: 96 checks per instance). Merged records
     // [PK_RANGE_MULTI, first opcode, n, (opcode, witness, num_bits) x n] keep four rows in flight per lane. The exact path keeps the
     // opcode's own record.
-    if (!getenv("ACVM_NO_RANGE_MERGE")) {
+    if (tune.range_merge) {
         std::map<uint32_t, std::vector<size_t>> by_level;
         for (size_t i = 0; i < records.size(); i++)
             if (!records[i].synthetic && records[i].cls == CLS_LIGHT && p.prog[p.prog_offset[records[i].opcode]] == PK_RANGE) by_level[records[i].level].push_back(i);
@@ -1249,8 +1263,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         for (auto &r : records) {
             const bool heavy = is_heavy(r.cls);
             const int async = heavy ? 1 + heavy_lane(r.cls) : -1;
-            if (!(r.cls == CLS_DIGEST && getenv("ACVM_REUSE_IGNORE_DIGEST")))  // (measurement only: rows as if no digest were kept)
-                for (uint32_t w : r.reads) note(w, r.level, async);
+            for (uint32_t w : r.reads) note(w, r.level, async);
             if (r.synthetic) continue;
             for (auto &slot : out_slots[r.opcode])
                 if (p.producer[slot.second] == r.opcode) {

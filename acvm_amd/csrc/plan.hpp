@@ -15,6 +15,7 @@
 //   * the folded gate stream of the Arithmetic opcodes for arith_level_kernel / arith_dyn_level_kernel.
 #pragma once
 #include "circuit.hpp"
+#include "tuning.hpp"
 #include <map>
 #include <string>
 #include <utility>
@@ -38,11 +39,11 @@ static constexpr uint32_t GATE_HDR_WORDS = 5;
 
 static constexpr uint32_t PLAN_HASH_COOP_FLAG = 0x100u;      // PK_HASH function word: byte message, unpacked through LDS by the level kernel
 static constexpr uint32_t PLAN_HASH_RANGE_FLAG = 0x200u;     // ... and (RANGE opcode or NONE, bits) per input follow the outputs: byte RANGE checks fused into the hash
-static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 16 KiB of LDS per 64 instances
+static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 256 message words x 64 instances = 64 KiB of LDS, the most a workgroup may ask for (batch.cpp sizes each launch by its own longest record)
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
 enum ProgKind : uint32_t {
     PK_ARITH = 0, PK_RANGE = 1, PK_LOGIC = 2, PK_HASH = 3, PK_PEDERSEN = 4, PK_FIXED_BASE = 5, PK_SCHNORR = 6, PK_ZERO_OUT = 7,
-    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12, PK_ECDSA = 13, PK_PERM_SORT = 14, PK_DIGEST_LEAF = 15, PK_RANGE_MULTI = 16
+    PK_QUOTIENT = 8, PK_TO_LE_RADIX = 9, PK_MEM_INIT = 10, PK_MEM_OP = 11, PK_BRILLIG = 12, PK_ECDSA = 13, PK_PERM_SORT = 14, PK_DIGEST_LEAF = 15, PK_RANGE_MULTI = 16, PK_BRILLIG_SL = 17
 };
 // kernel classes of the non-arithmetic records
 // CLS_PEDERSEN only exists in the level schedule (its own 4-waves-per-instance-group kernel); the exact path and the
@@ -53,6 +54,7 @@ enum ProgKind : uint32_t {
 enum OpClass : uint32_t { CLS_LIGHT = 0, CLS_HASH = 1, CLS_GRUMPKIN = 2, CLS_BRILLIG = 3, CLS_PEDERSEN = 4, CLS_HOSTBB = 5, CLS_ECDSA = 6, CLS_DIGEST = 7, N_CLS = 8 };
 
 struct Plan {
+    Tuning tune;                                // the modes this plan was built with (the batch driver reads its own from here too)
     uint32_t n_witnesses = 0;
     uint32_t n_opcodes = 0;
     std::vector<uint32_t> initial_ids;
@@ -100,13 +102,13 @@ struct Plan {
     // statistics
     uint32_t n_fast_gates = 0, n_dyn_gates = 0, max_level_width = 0, n_other_records = 0;
     uint32_t n_gate_pairs = 0;                  // gates fused behind their producer (plan.cpp "gate pairs")
+    uint32_t n_brillig_inlined = 0;             // Brillig opcodes the level schedule runs as straight-line light records (plan.cpp)
     uint32_t n_inverse_slots = 0;               // rows of the inverse table (slots are reused once their gate ran)
     uint64_t algorithmic_bytes = 0, arith_algorithmic_bytes = 0, dyn_algorithmic_bytes = 0;
     uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;
-    uint32_t hash_coop_words = 0;  // 32-bit message words per instance of the longest hash record flagged PLAN_HASH_COOP_FLAG
     std::vector<std::pair<uint32_t, uint32_t>> pedersen_seeds;  // per Pedersen record: (number of inputs, domain separator)
     // Brillig foreign calls: function name per (opcode << 32 | bytecode index), buffer sizes of the wait / resolve round trip
     bool has_foreign_calls = false;

@@ -137,13 +137,15 @@ int acvm_solve_opcode(acvm_t *a) {
 int acvm_get_status(acvm_t *a, acvm_result_t *out) {
     if (!a || !out) return ACVM_E_INVALID;
     // ACVM::new leaves the status InProgress (Solved for an empty circuit, mod.rs:147) before the first solve call
-    if (acvm_batch_results(a->b, out) == ACVM_E_STATE) {
+    const int rc = acvm_batch_results(a->b, out);
+    if (rc == ACVM_E_STATE) {
         memset(out, 0, sizeof *out);
         acvm_stats_t st;
-        if (int rc = acvm_batch_stats(a->b, &st)) return rc;
+        if (int rc2 = acvm_batch_stats(a->b, &st)) return rc2;
         out->status = st.n_opcodes == 0 ? ACVM_STATUS_SOLVED : ACVM_STATUS_IN_PROGRESS;
+        return 0;
     }
-    return 0;
+    return rc;  // any other failure (device, memory) leaves *out unwritten and is the caller's error
 }
 uint32_t acvm_instruction_pointer(acvm_t *a) {
     acvm_result_t r;
@@ -203,6 +205,7 @@ acvm_multi_t *acvm_multi_new(const acvm_circuit_t *c, const acvm_bb_solver_t *so
         if (offsets[i + 1] < offsets[i]) return nullptr;
         std::vector<uint32_t> key(ids + offsets[i], ids + offsets[i + 1]);
         std::sort(key.begin(), key.end());
+        key.erase(std::unique(key.begin(), key.end()), key.end());  // a map has every id once: a repeated id keeps its last value (scatter below)
         auto it = key_to_group.find(key);
         if (it == key_to_group.end()) {
             it = key_to_group.emplace(key, (uint32_t)keys.size()).first;

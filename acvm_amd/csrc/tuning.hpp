@@ -1,0 +1,48 @@
+// tuning.hpp -- every planner / scheduler mode of the library in ONE place (process-wide defaults; a plan keeps the snapshot it was
+// built with). The defaults are the measured optimum of DESIGN.md section 9; the other values exist so that the A/B measurements of
+// that section stay reproducible and so that the parity tests can sweep the planner's modes (tests/test_gpu_planner_modes.py). Set
+// through the ABI (acvm_tuning_set, include/acvm_amd.h) or, for command-line tools, once at first use from the environment variable
+// ACVM_TUNING="key=value,key=value". No mode changes any result: every one of them is compared bit for bit against the oracle.
+#pragma once
+#include <stdint.h>
+
+namespace acvm {
+
+struct Tuning {
+    // ---- planner (plan.cpp)
+    int64_t scale = 1;             // projective witnesses (a gate's most expensive coefficient becomes 1)
+    int64_t pairs = 1;             // wave programs: a gate runs behind its producer in the same wave
+    int64_t chains = 1;            // ... and behind a tail of that wave
+    int64_t max_tails = 5;         // records behind the host of a wave program
+    int64_t inv_epoch = 4;         // levels per batch of denominator inversions
+    int64_t heavy_epoch = 1;       // heavy records launched every K-th level only
+    int64_t heavy_latency = 0;     // levels the main stream waits before it reads a heavy output
+    int64_t pedersen_latency = 0;  // the same for Pedersen outputs alone
+    int64_t digest_epoch = 8;      // levels per batch of folded digest leaves
+    int64_t range_fuse = 1;        // byte RANGE checks run inside the hash that reads the byte
+    int64_t range_merge = 1;       // RANGE opcodes of a level, eight to a record
+    int64_t brillig_inline = 1;    // straight-line Brillig programs compiled into light records of the level schedule
+    int64_t hash_merge = 1;        // byte-message hashes of several levels in one launch where their inputs allow it
+    int64_t brillig_mem_cells = 0; // lower bound of the per-lane Brillig memory of the level kernels (0: the planner's estimate)
+    // ---- driver (batch.cpp)
+    int64_t overlap = 1;           // inversion batches and heavy lanes on streams of their own
+    int64_t heavy_streams = 1;     // heavy lanes beside the main stream (0: everything on the main stream)
+    int64_t fc_relevel = -1;       // answered foreign calls re-enter the level schedule: 1 always, 0 never, -1 when >= 1/16 of the batch was answered
+    int64_t exact_async = 1;       // the exact path of tile k runs beside the level schedule of tile k + 1 (acvm_node_*)
+    // Brillig VM limits of the device (the reference has none: brillig_vm/src/{memory.rs:27-39, lib.rs:154-307}). The level kernels run
+    // with the first value; an instance that reaches it continues on the exact path, which retries with the limit raised step by
+    // step up to the second value; beyond that acvm_batch_solve returns ACVM_E_UNSUPPORTED (never a per-instance failure the
+    // reference would not report).
+    int64_t brillig_steps_log2 = 22, brillig_steps_max_log2 = 28;
+    int64_t brillig_call_depth = 64, brillig_call_depth_max = 1 << 16;
+    int64_t brillig_mem_max_log2 = 22;  // cells of one lane's memory on the exact path at most (32 B each)
+    // ---- tables (grumpkin_host.cpp)
+    int64_t win16 = 1;             // 16-bit window tables of the four fixed bases
+};
+
+Tuning &tuning();                                   // the process-wide defaults
+bool tuning_set(const char *key, int64_t value);    // false: unknown key
+bool tuning_get(const char *key, int64_t *value);
+const char *tuning_key(unsigned index);             // enumeration for documentation / tests, nullptr past the end
+
+}  // namespace acvm

@@ -34,14 +34,16 @@
 extern "C" {
 #endif
 
-#define ACVM_AMD_ABI_VERSION 2
+#define ACVM_AMD_ABI_VERSION 3
 
 /* library-level error codes */
 enum {
     ACVM_OK = 0,
     ACVM_E_INVALID = -1,     /* bad argument / handle */
     ACVM_E_MALFORMED = -2,   /* circuit bytes do not decode (the reference would panic in bincode::deserialize) */
-    ACVM_E_UNSUPPORTED = -3, /* opcode outside the accelerated set -- refused at batch creation */
+    ACVM_E_UNSUPPORTED = -3, /* opcode outside the accelerated set -- refused at batch creation; or, from a solve call, an instance whose
+                                Brillig program exceeds the device's stated VM limits (steps / call depth / memory, see acvm_tuning_set): the
+                                reference has no such limit, so the SOLVE fails, never the instance */
     ACVM_E_DEVICE = -4,      /* no gfx950 device / HIP runtime error */
     ACVM_E_STATE = -5,       /* call not valid in the current state (reference: panic) */
     ACVM_E_NOMEM = -6        /* host allocation failed (nothing unwinds through this ABI) */
@@ -136,6 +138,8 @@ typedef struct {
     uint32_t n_arith_launches; /* launches of arith_level_kernel per solve (levels that hold gates) */
     uint32_t n_table_rows;     /* rows of the device witness table: n_witnesses, or fewer with ACVM_BATCH_REUSE_SLOTS */
     uint32_t n_digest_segments; /* records of leaves of the folded digest (ACVM_BATCH_FOLD_DIGEST), 0 if the digest is not folded */
+    uint32_t n_brillig_inlined; /* Brillig opcodes whose straight-line program the level schedule runs as a light record (no VM) */
+    uint32_t n_brillig_retries; /* passes of the last solve that re-ran Brillig opcodes of the exact path with raised VM limits */
 } acvm_stats_t;
 
 const char *acvm_last_error(void);
@@ -145,6 +149,19 @@ int acvm_set_device(int device);
 int acvm_device_synchronize(void);
 /* name of the current device's gcnArch ("gfx950...") into out */
 int acvm_device_arch(char *out, size_t out_len);
+
+/*
+ * Planner / scheduler modes and the device's Brillig VM limits, process-wide (csrc/tuning.hpp lists every key with its default;
+ * acvm_tuning_key(i) enumerates them, NULL past the end). A batch keeps the values it was created with. No mode changes a result --
+ * the parity tests sweep them against the oracle; the defaults are the measured optimum. The limits: the reference's Brillig VM has
+ * none (brillig_vm/src/memory.rs:27-39 grows memory on write, lib.rs:154-307 runs any number of steps at any call depth); the device
+ * runs with brillig_steps_log2 / brillig_call_depth / the planner's memory estimate, retries an instance that reaches one with the
+ * limit raised, and past brillig_steps_max_log2 / brillig_call_depth_max / brillig_mem_max_log2 the solve call returns
+ * ACVM_E_UNSUPPORTED. Command-line tools may preset values through the environment: ACVM_TUNING="key=value,key=value".
+ */
+int acvm_tuning_set(const char *key, long long value);
+int acvm_tuning_get(const char *key, long long *value);
+const char *acvm_tuning_key(unsigned index);
 
 /* Device self test of the field library: n pseudo-random operand pairs; returns the number of lanes whose
  * hand-scheduled routines disagree with the portable ones (0 = pass), or a negative error. */

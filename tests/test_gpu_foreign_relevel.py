@@ -57,13 +57,10 @@ def test_relevel_equals_exact_resume_and_oracle(oracle, mode):
     B = 96
     rows = [[3 + j, 1000 + 7 * j] for j in range(B)]
     rows[5][0] = 0  # invert(0) = 0: w4 = 0, still solvable
-    os.environ["ACVM_FC_RELEVEL"] = "1" if mode == "relevel" else "0"
-    try:
+    with acvm_amd.tuning(fc_relevel=1 if mode == "relevel" else 0):
         batch = acvm_amd.Batch(acvm_amd.Circuit(data), B, ids)
         batch.set_initial_witness(values_from_rows(rows))
         rounds, res = drive(batch, B)
-    finally:
-        os.environ.pop("ACVM_FC_RELEVEL", None)
     assert rounds == 2
     st = batch.stats()
     if mode == "relevel":

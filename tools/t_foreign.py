@@ -33,7 +33,7 @@ data = circ.to_bytes()
 values = synth.witness_batch(B, seed=0xAC1D0002, edge_cases=False)
 out = {"gates": G, "instances": B}
 for mode in ("relevel", "exact"):
-    os.environ["ACVM_FC_RELEVEL"] = "1" if mode == "relevel" else "0"
+    acvm_amd.tuning_set("fc_relevel", 1 if mode == "relevel" else 0)
     batch = acvm_amd.Batch(acvm_amd.Circuit(data), B, ids)
     batch.set_initial_witness(values)
     t0 = time.perf_counter()

@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
+    "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
 ]
 
 
@@ -257,6 +258,17 @@ def lib():
     L.acvm_witness_map_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_debug_modmul_rate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.acvm_node_new.restype = C.c_void_p
+    L.acvm_node_new.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.acvm_node_free.restype = None
+    L.acvm_node_free.argtypes = [C.c_void_p]
+    L.acvm_node_tile_instances.argtypes = [C.c_void_p]
+    L.acvm_node_tile_instances.restype = C.c_uint32
+    L.acvm_node_num_devices.argtypes = [C.c_void_p]
+    L.acvm_node_num_devices.restype = C.c_uint32
+    L.acvm_node_solve.restype = C.c_longlong
+    L.acvm_node_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.acvm_node_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.acvm_tuning_set.argtypes = [C.c_char_p, C.c_longlong]
     L.acvm_tuning_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
     L.acvm_tuning_key.restype = C.c_char_p
@@ -457,6 +469,71 @@ class Circuit:
         s = Stats()
         _check(lib().acvm_circuit_plan_stats_ex(self._h, arr, len(ids), (1 if fold_digest else 0) | (2 if reuse_slots else 0), karr, len(keep), C.byref(s)))
         return s.as_dict()
+
+
+class NodeOpts(C.Structure):
+    _fields_ = [("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int)), ("tile_instances", C.c_uint32), ("batch_flags", C.c_uint32)]
+
+
+class NodeStats(C.Structure):
+    _fields_ = [("n_devices", C.c_uint32), ("tile_instances", C.c_uint32), ("n_instances", C.c_uint64), ("total_ms", C.c_double),
+                ("device", C.c_int * 16), ("async_exact", C.c_uint32 * 16), ("tiles", C.c_uint32 * 16), ("exact_instances", C.c_uint32 * 16),
+                ("lane_ms", C.c_double * 16), ("solve_device_ms", C.c_double * 16), ("h2d_wait_ms", C.c_double * 16), ("export_ms", C.c_double * 16)]
+
+
+class Node:
+    """acvm_node_*: one call solves a global batch on every listed device (one handle + one host thread per device, tiles inside a
+    device, pinned double-buffered uploads, the exact path of a tile beside the next one). The caller loop it replaces:
+    acvm_js/src/execute.rs:60-119 once per instance."""
+
+    def __init__(self, circuit: "Circuit", initial_ids, keep=(), devices=None, tile=0, fold_digest=False, reuse_slots=False, solver: "BbSolver" = None):
+        self.ids, self.keep = list(initial_ids), list(keep)
+        self._solver = solver
+        arr = (C.c_uint32 * max(len(self.ids), 1))(*self.ids)
+        karr = (C.c_uint32 * max(len(self.keep), 1))(*self.keep)
+        opts = NodeOpts()
+        if devices is not None:
+            self._dev = (C.c_int * len(devices))(*devices)
+            opts.n_devices, opts.devices = len(devices), self._dev
+        opts.tile_instances = tile
+        opts.batch_flags = (Batch.FOLD_DIGEST if fold_digest else 0) | (Batch.REUSE_SLOTS if reuse_slots else 0)
+        self._h = lib().acvm_node_new(circuit._h, C.byref(solver) if solver is not None else None, arr, len(self.ids), karr, len(self.keep), C.byref(opts))
+        if not self._h:
+            raise AcvmError(lib().acvm_last_error().decode())
+        self.tile = lib().acvm_node_tile_instances(self._h)
+        self.n_devices = lib().acvm_node_num_devices(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.acvm_node_free(self._h)
+            self._h = None
+
+    def free(self):
+        self.__del__()
+
+    def solve(self, values_be, n_instances: int, results=True, kept=True, digests=True):
+        """values_be: n_instances * len(ids) * 32 bytes (bytes or a uint8 array). Returns (not_solved, results or None, kept uint8
+        [n][len(keep)][32] or None, kept_assigned uint8 [n][len(keep)] or None, digests uint8 [n][32] or None)."""
+        import numpy as np
+        buf = np.frombuffer(values_be, dtype=np.uint8) if not isinstance(values_be, np.ndarray) else values_be
+        if buf.size != n_instances * len(self.ids) * 32:
+            raise ValueError("values_be has the wrong size")
+        res = (Result * max(n_instances, 1))() if results else None
+        nk = len(self.keep)
+        kv = np.zeros((n_instances, nk, 32), dtype=np.uint8) if kept and nk else None
+        ka = np.zeros((n_instances, nk), dtype=np.uint8) if kept and nk else None
+        dg = np.zeros((n_instances, 32), dtype=np.uint8) if digests else None
+        rc = lib().acvm_node_solve(self._h, n_instances, buf.ctypes.data if buf.size else None, C.cast(res, C.c_void_p) if res is not None else None,
+                                   kv.ctypes.data if kv is not None else None, ka.ctypes.data if ka is not None else None, dg.ctypes.data if dg is not None else None)
+        _check(rc)
+        return rc, res, kv, ka, dg
+
+    def stats(self):
+        st = NodeStats()
+        _check(lib().acvm_node_stats(self._h, C.byref(st)))
+        n = st.n_devices
+        return {"n_devices": n, "tile_instances": st.tile_instances, "n_instances": st.n_instances, "total_ms": st.total_ms,
+                **{f: list(getattr(st, f))[:n] for f in ("device", "async_exact", "tiles", "exact_instances", "lane_ms", "solve_device_ms", "h2d_wait_ms", "export_ms")}}
 
 
 class Batch:

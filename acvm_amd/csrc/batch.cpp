@@ -1,9 +1,6 @@
 // batch.cpp -- the C ABI (include/acvm_amd.h) and the batch driver: one handle = one circuit plan, one
 // device-resident witness table W[slot][half][instance], one HIP stream. Mirrors the call shape of
 // acvm::pwg::ACVM (acvm/src/pwg/mod.rs:145-304) for B instances at once.
-#include "../../include/acvm_amd.h"
-#include "kernels.hpp"
-#include "plan.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -15,170 +12,16 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
-
-using namespace acvm;
+#include "batch.hpp"
 
 static thread_local std::string g_last_error;
-static int set_err(int code, const std::string &msg) {
+int set_err(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
-#define HIPCHK(expr)                                                                                      \
-    do {                                                                                                  \
-        hipError_t _e = (expr);                                                                           \
-        if (_e != hipSuccess)                                                                             \
-            return set_err(ACVM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
-    } while (0)
 
-// Nothing unwinds through the extern "C" boundary: entry points that allocate by input-dependent sizes are function-try-blocks
-#define ABI_CATCH                                                                                          \
-    catch (const std::bad_alloc &) { return set_err(ACVM_E_NOMEM, "out of host memory"); }                 \
-    catch (const std::exception &e) { return set_err(ACVM_E_INVALID, std::string("internal error: ") + e.what()); }
-#define ABI_CATCH_PTR                                                                                      \
-    catch (const std::bad_alloc &) { set_err(ACVM_E_NOMEM, "out of host memory"); return nullptr; }        \
-    catch (const std::exception &e) { set_err(ACVM_E_INVALID, std::string("internal error: ") + e.what()); return nullptr; }
-
-struct acvm_circuit {
-    std::unique_ptr<Circuit> c;
-};
-
-struct LaunchChunk { uint32_t first, count; bool coop = false; uint32_t lds_words = 0; };  // records [first, first+count) of a class's level-major list (coop: CLS_HASH records flagged PLAN_HASH_COOP_FLAG)
-struct ExactSegment { uint32_t cls, begin, end; };  // opcodes [begin, end): one light span or one heavy opcode
-
-struct acvm_batch {
-    Plan plan;
-    uint32_t B = 0;
-    uint64_t Bp = 0;  // instance stride, multiple of 64
-    int device = 0;
-    hipStream_t stream = nullptr;
-    uint4 *d_W = nullptr, *d_Mem = nullptr;
-    uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
-    uint32_t *d_prog = nullptr, *d_prog_offset = nullptr, *d_bytecode = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
-    uint32_t *d_dyn_offset = nullptr, *d_slow_start = nullptr;
-    uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::vector<std::vector<LaunchChunk>> cls_chunks[N_CLS];  // per level
-    std::vector<ExactSegment> segments;
-    DeviceProgram dp{};
-    uint32_t *d_event = nullptr;
-    uint32_t *h_flag_count = nullptr;  // pinned, device-mapped
-    std::vector<uint32_t> h_event;
-    bool events_clean = false;  // h_event is all 0xFFFFFFFF, slow_ids empty, slow_index all -1 (kept across solves that flag nothing)
-    // exact in-order path
-    std::vector<uint32_t> slow_ids, slow_start;
-    std::vector<int32_t> slow_index;  // per instance: index into slow_ids or -1
-    std::vector<SlowResult> slow_res;
-    uint32_t *d_slow_ids = nullptr, *d_assigned = nullptr;
-    SlowResult *d_slow_res = nullptr;
-    uint32_t slow_cap = 0, n_words = 0;
-    bool inputs_set = false, solved = false, force_slow = false, profiling = false;
-    hipEvent_t ev_start = nullptr, ev_end = nullptr;
-    std::vector<hipEvent_t> ev_pool;
-    double solve_device_ms = 0, arith_kernel_ms = 0, dyn_kernel_ms = 0, slow_path_ms = 0;
-    double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
-    hipStream_t stream_dyn = nullptr, stream_heavy = nullptr, stream_heavy2 = nullptr, stream_heavy3 = nullptr, stream_digest = nullptr;
-    PlanOpts opts;                    // acvm_batch_new_ex: folded digest, slot reuse
-    uint32_t *d_leaves = nullptr;     // fold_digest: the word-wise sum of the leaves, [8][Bp], accumulated by the digest lane during the solve
-    uint32_t *d_slot_of = nullptr;    // reuse_slots: witness -> row of d_W
-    // reuse_slots: the exact path re-solves the flagged instances from their initial witnesses in a table of its own (row = witness
-    // index, lane t = the t-th flagged instance); x_cap lanes allocated
-    uint4 *d_Wx = nullptr, *d_Memx = nullptr;
-    uint32_t *d_init_rows = nullptr, *d_ids_x = nullptr;
-    uint64_t x_cap = 0;
-    bool reuse() const { return opts.reuse_slots; }
-    // the table the exact kernels work on
-    uint4 *xW() const { return reuse() ? d_Wx : d_W; }
-    uint64_t xBp() const { return reuse() ? x_cap : Bp; }
-    uint32_t *xids() const { return reuse() ? d_ids_x : d_slow_ids; }
-    DeviceProgram xdp() const {
-        DeviceProgram d = dp;
-        if (reuse()) { d.Mem = d_Memx; d.slot_of = nullptr; }
-        return d;
-    }
-    std::vector<hipEvent_t> ev_heavy;  // per level 4 events: [4L + q] the records of heavy lane q at the level have run (q < 3)
-    std::vector<hipEvent_t> ev_sync;
-    uint32_t *d_unscale_index = nullptr, *d_unscale_consts = nullptr, *d_unscale_plain = nullptr, *d_scaled_ids = nullptr;  // projective witnesses (plan.cpp)
-    Unscale unscale{};
-    uint32_t *d_ped_seed = nullptr;  // seed table of the level Pedersen kernel (one row per Pedersen record)
-    uint4 *d_inv = nullptr;  // inverse table: [plan.n_inverse_slots][2 halves][Bp] x 16 B
-    uint32_t n_launches = 0;
-    // caller-supplied BlackBoxFunctionSolver
-    bool has_solver = false;
-    acvm_bb_solver_t solver{};
-    std::map<uint32_t, std::string> host_bb_msg;  // per instance: error text of a failing callback
-    // Brillig foreign-call round trip (exact lanes only)
-    struct FcValue { bool is_array; std::vector<FrH> vals; };
-    struct FcLaneState { bool resolved_new = false; };
-    std::vector<FcLaneState> fc_lane;  // per exact lane: the host answered its pending call since the last solve
-    // results the host resolved, per Brillig opcode with a ForeignCall (plan.fc_slot_opcode) and per INSTANCE: they accumulate like
-    // Brillig::foreign_call_results (pwg/mod.rs:220-224) and serve the level kernels and the exact kernels alike
-    struct FcSlot {
-        std::map<uint32_t, std::vector<std::vector<FcValue>>> inst;  // instance -> results so far
-        uint32_t desc_words = 0, vals_cap = 0;
-        uint32_t *d_desc = nullptr;
-        uint4 *d_vals = nullptr;
-        bool dirty = false;
-    };
-    std::vector<FcSlot> fc_slots;
-    FcStoreSlot *d_fc_store = nullptr;
-    uint32_t *d_fc_pend_desc = nullptr;
-    uint4 *d_fc_pend_vals = nullptr;
-    uint32_t fc_pend_desc_words = 0, fc_pend_vals_cap = 0, fc_lanes_cap = 0;
-    std::vector<uint32_t> h_pend_desc, h_pend_vals;
-    bool pend_host_valid = false;
-    // grow-only device staging arena of the entry points that move data in or out (no hipMalloc / hipFree per call)
-    uint8_t *d_stage = nullptr;
-    size_t stage_cap = 0;
-    // acvm_batch_solve_opcode: every instance is an exact lane, slow_start[t] is its instruction pointer
-    bool stepping = false;
-    // Brillig retry passes of the exact path (retry_device_limits): the compact VM scratch of the lanes being retried and their columns
-    uint32_t *d_br_scratch = nullptr, *d_br_lane = nullptr;
-    size_t br_scratch_bytes = 0;
-    uint32_t br_lane_cap = 0;
-    bool br_retry_active = false;
-    uint32_t br_max_regs = 1;  // most registers any Brillig opcode of the circuit uses
-    uint32_t n_brillig_retries = 0;  // retry passes of the last solve
-
-    ~acvm_batch() {
-        hipSetDevice(device);
-        for (void *p : {(void *)d_W, (void *)d_Mem, (void *)d_gate_stream, (void *)d_gate_offset, (void *)d_consts, (void *)d_prog,
-                        (void *)d_prog_offset, (void *)d_bytecode, (void *)d_init_ids, (void *)d_producer, (void *)d_dyn_offset,
-                        (void *)d_slow_start, (void *)d_event, (void *)d_slow_ids, (void *)d_assigned, (void *)d_slow_res})
-            if (p) hipFree(p);
-        if (h_flag_count) hipHostFree(h_flag_count);
-        for (int k = 0; k < (int)N_CLS; k++)
-            for (void *p : {(void *)d_cls_offset[k], (void *)d_cls_scratch_off[k], (void *)d_cls_scratch[k]})
-                if (p) hipFree(p);
-        for (auto e : ev_pool) hipEventDestroy(e);
-        for (auto e : ev_sync) hipEventDestroy(e);
-        for (auto e : ev_heavy) hipEventDestroy(e);
-        if (stream_heavy) hipStreamDestroy(stream_heavy);
-        if (stream_heavy2) hipStreamDestroy(stream_heavy2);
-        if (stream_heavy3) hipStreamDestroy(stream_heavy3);
-        if (stream_digest) hipStreamDestroy(stream_digest);
-        if (d_leaves) hipFree(d_leaves);
-        if (d_slot_of) hipFree(d_slot_of);
-        for (void *p : {(void *)d_Wx, (void *)d_Memx, (void *)d_init_rows, (void *)d_ids_x})
-            if (p) hipFree(p);
-        if (d_inv) hipFree(d_inv);
-        for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_unscale_plain, (void *)d_scaled_ids})
-            if (p) hipFree(p);
-        if (d_ped_seed) hipFree(d_ped_seed);
-        if (d_stage) hipFree(d_stage);
-        if (d_br_scratch) hipFree(d_br_scratch);
-        if (d_br_lane) hipFree(d_br_lane);
-        for (void *p : {(void *)d_fc_store, (void *)d_fc_pend_desc, (void *)d_fc_pend_vals})
-            if (p) hipFree(p);
-        for (auto &sl : fc_slots)
-            for (void *p : {(void *)sl.d_desc, (void *)sl.d_vals})
-                if (p) hipFree(p);
-        if (stream_dyn) hipStreamDestroy(stream_dyn);
-        if (ev_start) hipEventDestroy(ev_start);
-        if (ev_end) hipEventDestroy(ev_end);
-        if (stream) hipStreamDestroy(stream);
-    }
-};
+static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm_result_t &r);
+static void fill_result(acvm_batch *b, uint32_t j, acvm_result_t &r);
 
 template <class T>
 static int upload(T **dst, const std::vector<T> &src) {
@@ -501,7 +344,10 @@ static int batch_init(acvm_batch *b) {
         }
         // the exact kernels use slot 0 of the same buffer: it must hold the largest single record
         for (uint32_t oi = 0; oi < p.n_opcodes; oi++)
-            if (p.prog_class[oi] == (uint32_t)k) need = std::max<uint64_t>(need, p.prog_scratch[oi]);
+            if (p.prog_class[oi] == (uint32_t)k) {
+                need = std::max<uint64_t>(need, p.prog_scratch[oi]);
+                b->cls_exact_words[k] = std::max<uint64_t>(b->cls_exact_words[k], p.prog_scratch[oi]);
+            }
         if (int rc = upload(&b->d_cls_offset[k], p.cls_offset[k])) return rc;
         if (int rc = upload(&b->d_cls_scratch_off[k], scratch_off)) return rc;
         if (need) HIPCHK(hipMalloc((void **)&b->d_cls_scratch[k], (size_t)need * b->Bp * 4));
@@ -877,7 +723,7 @@ static int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_
 // (stepping: the lanes executed every earlier opcode themselves, nothing is replayed; only opcodes [min_start, end_opcode) run)
 static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start, bool replay = true, uint32_t end_opcode = 0xFFFFFFFFu) {
     const Plan &p = b->plan;
-    hipStream_t s = b->stream;
+    hipStream_t s = b->xstream();  // the batch's stream, or the side stream of an asynchronous job
     const ExactLanes L = exact_lanes(b, n_slow);
     const DeviceProgram xdp = b->xdp();
     // memory side effects of the opcodes before the earliest event are replayed by the span kernel, so start at the
@@ -890,9 +736,9 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
         case CLS_LIGHT:
             launch_exact_span(s, b->xW(), b->xBp(), xdp, L, replay ? seg.begin : std::max(seg.begin, min_start), std::min(seg.end, end_opcode), has_mem);
             break;
-        case CLS_HASH: launch_exact_hash(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_HASH]); break;
-        case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->d_cls_scratch[CLS_GRUMPKIN]); break;
-        case CLS_BRILLIG: launch_exact_brillig(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->br_retry_active ? b->d_br_scratch : b->d_cls_scratch[CLS_BRILLIG]); break;
+        case CLS_HASH: launch_exact_hash(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->xscratch(CLS_HASH)); break;
+        case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->xscratch(CLS_GRUMPKIN)); break;
+        case CLS_BRILLIG: launch_exact_brillig(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->br_retry_active ? b->d_br_scratch : b->xscratch(CLS_BRILLIG)); break;
         case CLS_ECDSA: launch_exact_ecdsa(s, b->xW(), b->xBp(), xdp, L, seg.begin); break;
         case CLS_HOSTBB:
             if (int rc = run_host_blackbox(b, seg.begin, true, n_slow)) return rc;
@@ -921,7 +767,7 @@ static bool is_device_limit(const SlowResult &r) {
 static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint32_t end_opcode) {
     const Plan &p = b->plan;
     const Tuning &tn = p.tune;
-    hipStream_t s = b->stream;
+    hipStream_t s = b->xstream();
     const BrilligLimits base = b->dp.brillig;
     const uint64_t max_steps = 1ull << (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_steps_max_log2, 0), 31);
     const uint64_t max_depth = (uint64_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_call_depth_max, 1), 1 << 24);
@@ -932,7 +778,7 @@ static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint
         std::vector<uint32_t> lanes;
         bool hit_steps = false, hit_depth = false, hit_mem = false;
         uint64_t want_cells = 0, record_cells = 0;
-        uint32_t first_lane = 0;
+        uint32_t first_lane = 0, mem_lane = 0;
         for (uint32_t t = 0; t < n_slow; t++) {
             const SlowResult &r = b->slow_res[t];
             if (!is_device_limit(r)) continue;
@@ -940,30 +786,33 @@ static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint
             lanes.push_back(t);
             hit_steps |= r.msg == 18u;
             hit_depth |= r.msg == 28u;
-            if (r.msg == 17u) { hit_mem = true; want_cells = std::max<uint64_t>(want_cells, (uint64_t)r.x0 + 1); }
+            if (r.msg == 17u) {
+                hit_mem = true;
+                if ((uint64_t)r.x0 + 1 > want_cells) { want_cells = (uint64_t)r.x0 + 1; mem_lane = t; }
+            }
             if (r.opcode_index < p.n_opcodes && p.prog[p.prog_offset[r.opcode_index]] == PK_BRILLIG)
                 record_cells = std::max<uint64_t>(record_cells, p.prog[p.prog_offset[r.opcode_index] + 8]);
         }
         if (lanes.empty()) break;
-        auto refuse = [&](const std::string &what) {
+        auto refuse = [&](const std::string &what, uint32_t lane) {
             b->solved = false;  // no results: the caller sets the inputs again (or resets) before the next solve
             b->stepping = false;
-            const SlowResult &r = b->slow_res[first_lane];
-            return set_err(ACVM_E_UNSUPPORTED, "Brillig opcode " + std::to_string(r.opcode_index) + " of instance " + std::to_string(b->slow_ids[first_lane]) + " " + what +
+            const SlowResult &r = b->slow_res[lane];
+            return set_err(ACVM_E_UNSUPPORTED, "Brillig opcode " + std::to_string(r.opcode_index) + " of instance " + std::to_string(b->slow_ids[lane]) + " " + what +
                                                "; the reference's VM has no such limit, this library does (tuning.hpp) -- solve this instance with the reference");
         };
         if (hit_steps) {
-            if (lim.steps >= max_steps) { rc = refuse("runs more than 2^" + std::to_string(tn.brillig_steps_max_log2) + " VM steps"); break; }
+            if (lim.steps >= max_steps) { rc = refuse("runs more than 2^" + std::to_string(tn.brillig_steps_max_log2) + " VM steps", first_lane); break; }
             lim.steps = (uint32_t)std::min<uint64_t>((uint64_t)lim.steps * 16, max_steps);
         }
         if (hit_depth) {
-            if (lim.call_depth >= max_depth) { rc = refuse("nests more than " + std::to_string(max_depth) + " calls"); break; }
+            if (lim.call_depth >= max_depth) { rc = refuse("nests more than " + std::to_string(max_depth) + " calls", first_lane); break; }
             lim.call_depth = (uint32_t)std::min<uint64_t>((uint64_t)lim.call_depth * 16, max_depth);
         }
         const uint64_t cur_cells = lim.mem_cap ? lim.mem_cap : record_cells;
         uint64_t cells = std::max<uint64_t>(cur_cells, 64);
         if (hit_mem) {
-            if (want_cells > max_cells || cur_cells >= max_cells) { rc = refuse("writes VM memory cell " + std::to_string(want_cells - 1) + ", beyond 2^" + std::to_string(tn.brillig_mem_max_log2) + " cells"); break; }
+            if (want_cells > max_cells || cur_cells >= max_cells) { rc = refuse("writes VM memory cell " + std::to_string(want_cells - 1) + ", beyond 2^" + std::to_string(tn.brillig_mem_max_log2) + " cells", mem_lane); break; }
             cells = std::min<uint64_t>(std::max<uint64_t>(2 * want_cells, 4 * cells), max_cells);
         }
         lim.mem_cap = (uint32_t)cells;
@@ -976,7 +825,7 @@ static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint
             b->br_scratch_bytes = 0;
             if (hipMalloc((void **)&b->d_br_scratch, bytes) != hipSuccess) {
                 (void)hipGetLastError();
-                rc = refuse("needs " + std::to_string(bytes >> 20) + " MiB of VM scratch for " + std::to_string(lanes.size()) + " instances, which the device cannot provide");
+                rc = refuse("needs " + std::to_string(bytes >> 20) + " MiB of VM scratch for " + std::to_string(lanes.size()) + " instances, which the device cannot provide", first_lane);
                 break;
             }
             b->br_scratch_bytes = bytes;
@@ -1383,6 +1232,9 @@ int acvm_batch_solve(acvm_batch_t *b) try {
         if (int rc = enqueue_level_schedule(b, b->profiling ? &tm : nullptr)) return rc;
     }
     HIPCHK(hipGetLastError());
+    // the exact job of the PREVIOUS solve (asynchronous mode) is collected here, while the device works on this solve's levels
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     // instances that left the generic path (or hit a failing opcode): exact in-order re-solve from their event on. Usually there is
     // none: only their count comes back (4 bytes instead of the B event words and a scan of them -- 30 us of a 0.25 ms solve of config 3)
     uint32_t n_flagged = b->B;
@@ -1408,25 +1260,29 @@ int acvm_batch_solve(acvm_batch_t *b) try {
     }
     uint32_t n_slow = (uint32_t)b->slow_ids.size();
     hipEvent_t slow0 = nullptr, slow1 = nullptr;
+    // asynchronous exact path (node.cpp): a bounded number of flagged instances is re-solved in the side table on stream_x while the
+    // caller goes on to the next tile; a batch full of them (a failing circuit, a truncated plan) keeps the synchronous path
+    const bool go_async = b->async_exact && n_slow && !b->force_slow && (uint64_t)n_slow * 8 <= std::max<uint64_t>(b->B, 512);
+    b->side_job = go_async;
     if (n_slow) {
         if (int rc = ensure_slow_capacity(b, n_slow)) return rc;
         HIPCHK(hipMemcpyAsync(b->d_slow_ids, b->slow_ids.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         b->slow_start.resize(n_slow);
         uint32_t min_start = 0xFFFFFFFFu;
         for (uint32_t t = 0; t < n_slow; t++) {
-            // slot reuse: the level table no longer holds what ran before the event: the lane starts over from its initial witnesses
-            b->slow_start[t] = b->reuse() ? 0u : b->h_event[b->slow_ids[t]];
+            // side table (slot reuse, asynchronous job): it does not hold what ran before the event: the lane starts over from its initial witnesses
+            b->slow_start[t] = b->side() ? 0u : b->h_event[b->slow_ids[t]];
             min_start = std::min(min_start, b->slow_start[t]);
         }
         HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         slow0 = next_event();
         slow1 = next_event();
         hipEventRecord(slow0, s);
-        if (b->reuse()) {
+        if (b->side()) {
             const uint64_t lanes = ((uint64_t)n_slow + 63) / 64 * 64;
             if (lanes > b->x_cap) {
                 // a table of all witnesses per flagged instance: refuse when that is more than the level table itself
-                const size_t need = (size_t)p.n_witnesses * 2 * lanes * sizeof(uint4), level_table = (size_t)p.n_slots * 2 * b->Bp * sizeof(uint4);
+                const size_t need = (size_t)p.n_witnesses * 2 * lanes * sizeof(uint4), level_table = (size_t)(b->reuse() ? p.n_slots : p.n_witnesses) * 2 * b->Bp * sizeof(uint4);
                 if (need > level_table && need > (8ull << 30))  // (a small batch pads to 64 lanes either way: below 8 GiB the table is simply allocated)
                     return set_err(ACVM_E_UNSUPPORTED, "slot reuse: " + std::to_string(n_slow) + " instances left the generic path; their own table would exceed "
                                                        "the level table -- solve this tile without ACVM_BATCH_REUSE_SLOTS");
@@ -1441,16 +1297,33 @@ int acvm_batch_solve(acvm_batch_t *b) try {
                 for (uint32_t t = 0; t < lanes; t++) ident[t] = t;
                 if (int rc = upload(&b->d_ids_x, ident)) return rc;
             }
-            launch_gather_initial(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, b->d_init_ids, b->d_init_rows, (uint32_t)p.initial_ids.size(), b->d_slow_ids, n_slow);
+            if (go_async && b->x_cap > b->x_scratch_lanes) {  // the job's own scratch: the level kernels of the next tile use the class buffers meanwhile
+                for (int k = 0; k < (int)N_CLS; k++) {
+                    if (b->d_x_scratch[k]) hipFree(b->d_x_scratch[k]);
+                    b->d_x_scratch[k] = nullptr;
+                    if (b->cls_exact_words[k]) HIPCHK(hipMalloc((void **)&b->d_x_scratch[k], (size_t)b->cls_exact_words[k] * b->x_cap * 4));
+                }
+                b->x_scratch_lanes = b->x_cap;
+            }
+            // (on the batch's stream: the rows of the initial witnesses are read before the next tile's import overwrites them)
+            launch_gather_initial(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, b->d_init_ids, b->reuse() ? b->d_init_rows : b->d_init_ids, (uint32_t)p.initial_ids.size(), b->d_slow_ids, n_slow);
         } else
         launch_unscale_slow(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->unscale);  // the exact kernels work on plain values
-        launch_init_assigned(s, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
+        if (go_async) {  // everything below runs on the side stream, behind the gather
+            HIPCHK(hipEventRecord(b->ev_x_ready, s));
+            HIPCHK(hipStreamWaitEvent(b->stream_x, b->ev_x_ready, 0));
+            b->pending = true;
+        }
+        hipStream_t xs = b->xstream();
+        launch_init_assigned(xs, b->d_assigned, n_slow, b->n_words, p.n_witnesses, b->d_producer, b->d_slow_start);
         b->fc_lane.assign(n_slow, acvm_batch::FcLaneState());
         if (int rc = upload_fc_tables(b, n_slow)) return rc;
-        launch_exact_init(s, exact_lanes(b, n_slow));
+        launch_exact_init(xs, exact_lanes(b, n_slow));
         if (int rc = run_exact_segments(b, n_slow, min_start)) return rc;
-        HIPCHK(hipStreamSynchronize(s));
-        if (int rc = retry_device_limits(b, n_slow, true, 0xFFFFFFFFu)) return rc;
+        if (!go_async) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (int rc = retry_device_limits(b, n_slow, true, 0xFFFFFFFFu)) return rc;
+        }
         hipEventRecord(slow1, s);
     }
     HIPCHK(hipEventRecord(b->ev_end, s));
@@ -1477,8 +1350,159 @@ int acvm_batch_solve(acvm_batch_t *b) try {
     }
     b->solved = true;
     if (!n_slow) b->slow_res.clear();
+    if (b->pending) return (int)n_slow;  // their outcome is not known yet
     return count_not_solved(b);
 } ABI_CATCH
+
+// ---- asynchronous exact path (batch.hpp)
+int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_keep, bool digests) {
+    const Plan &p = b->plan;
+    if (b->has_solver || p.has_foreign_calls || p.truncated_at != 0xFFFFFFFFu || !p.tune.exact_async) return 0;
+    if (!b->stream_x) HIPCHK(hipStreamCreateWithFlags(&b->stream_x, hipStreamNonBlocking));
+    if (!b->ev_x_ready) HIPCHK(hipEventCreateWithFlags(&b->ev_x_ready, hipEventDisableTiming));
+    b->async_exact = true;
+    b->async_keep.assign(keep, keep + n_keep);
+    b->async_digest = digests;
+    return 1;
+}
+
+// results, kept witnesses and digests of the lanes of the side table (all of them at once)
+static int side_table_outcome(acvm_batch *b, ExactOutcome *out) {
+    const Plan &p = b->plan;
+    hipStream_t s = b->xstream();
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size(), n_keep = (uint32_t)b->async_keep.size();
+    out->instance = b->slow_ids;
+    out->results.resize(n_slow);
+    for (uint32_t t = 0; t < n_slow; t++) {
+        acvm_result_t &r = out->results[t];
+        memset(&r, 0, sizeof r);
+        const SlowResult &sr = b->slow_res[t];
+        r.status = sr.status; r.err = sr.err; r.opcode_index = sr.opcode_index; r.aux0 = sr.aux0; r.aux1 = sr.aux1;
+        r.n_call_stack = sr.n_call_stack > 16 ? 16 : sr.n_call_stack;
+        for (uint32_t k = 0; k < r.n_call_stack; k++) r.call_stack[k] = sr.call_stack[k];
+    }
+    const size_t sel_bytes = align256((size_t)std::max<uint32_t>(n_keep, 1) * 4), val_bytes = align256((size_t)n_slow * std::max<uint32_t>(n_keep, 1) * 32);
+    const size_t acc_bytes = align256((size_t)32 * n_slow);
+    if (int rc = stage_reserve(b, sel_bytes + val_bytes + acc_bytes + (size_t)n_slow * 32)) return rc;
+    Unscale plain = b->unscale;
+    plain.event = b->d_slow_start;  // all zero: nothing in the side table is scaled
+    if (n_keep) {
+        uint32_t *d_sel = (uint32_t *)b->d_stage;
+        uint8_t *d_val = b->d_stage + sel_bytes;
+        HIPCHK(hipMemcpyAsync(d_sel, b->async_keep.data(), (size_t)n_keep * 4, hipMemcpyHostToDevice, s));
+        launch_export(s, b->d_Wx, b->x_cap, 0, n_slow, d_sel, n_keep, d_val, plain);
+        out->kept_values.resize((size_t)n_slow * n_keep * 32);
+        HIPCHK(hipMemcpyAsync(out->kept_values.data(), d_val, out->kept_values.size(), hipMemcpyDeviceToHost, s));
+        std::vector<uint32_t> bitmap((size_t)n_slow * b->n_words);
+        HIPCHK(hipMemcpyAsync(bitmap.data(), b->d_assigned, bitmap.size() * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        out->kept_assigned.resize((size_t)n_slow * n_keep);
+        for (uint32_t t = 0; t < n_slow; t++)
+            for (uint32_t k = 0; k < n_keep; k++) {
+                const uint32_t w = b->async_keep[k];
+                const bool a = w < p.n_witnesses && ((bitmap[(size_t)(w >> 5) * n_slow + t] >> (w & 31)) & 1u);
+                out->kept_assigned[(size_t)t * n_keep + k] = a;
+                if (!a) memset(&out->kept_values[((size_t)t * n_keep + k) * 32], 0, 32);
+            }
+    }
+    if (b->async_digest) {
+        uint32_t *d_acc = (uint32_t *)(b->d_stage + sel_bytes + val_bytes);
+        uint8_t *d_out = b->d_stage + sel_bytes + val_bytes + acc_bytes;
+        launch_digest(s, b->d_Wx, b->x_cap, 0, n_slow, p.n_witnesses, b->d_producer, plain, (const int32_t *)b->d_ids_x, b->d_assigned, n_slow, d_acc, d_out);
+        HIPCHK(hipGetLastError());
+        out->digests.resize((size_t)n_slow * 32);
+        HIPCHK(hipMemcpyAsync(out->digests.data(), d_out, out->digests.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int batch_finish_pending(acvm_batch *b, ExactOutcome *out) {
+    if (out) out->clear();
+    if (!b->pending) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    HIPCHK(hipStreamSynchronize(b->stream_x));  // (run_exact_segments ended with the copy of the lanes' results into slow_res)
+    int rc = retry_device_limits(b, n_slow, true, 0xFFFFFFFFu);
+    if (!rc && out) {
+        rc = side_table_outcome(b, out);
+        for (uint32_t t = 0; t < n_slow && !rc; t++)  // message texts
+            if (b->slow_res[t].status == ACVM_STATUS_FAILURE && b->slow_res[t].msg) format_message(b, b->slow_ids[t], b->slow_res[t], out->results[t]);
+    }
+    b->pending = false;
+    return rc;
+}
+
+int batch_export_tile(acvm_batch *b, uint32_t n, const uint32_t *keep, uint32_t n_keep, acvm_result_t *results, uint8_t *kept_values, uint8_t *kept_assigned,
+                      uint8_t *digests) {
+    const Plan &p = b->plan;
+    if (!b->solved || n > b->B) return set_err(ACVM_E_STATE, "batch not solved");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = b->stream;
+    const bool defer = b->pending;  // the instances of the exact path arrive with the job's outcome
+    if (results)
+        for (uint32_t j = 0; j < n; j++)
+            if (!(defer && b->slow_index[j] >= 0)) fill_result(b, j, results[j]);
+    if (n_keep && kept_values) {
+        const size_t sel_bytes = align256((size_t)n_keep * 4);
+        if (int rc = stage_reserve(b, sel_bytes + (size_t)n * n_keep * 32)) return rc;
+        uint32_t *d_sel = (uint32_t *)b->d_stage;
+        uint8_t *d_out = b->d_stage + sel_bytes;
+        HIPCHK(hipMemcpyAsync(d_sel, keep, (size_t)n_keep * 4, hipMemcpyHostToDevice, s));
+        launch_export(s, b->d_W, b->Bp, 0, n, d_sel, n_keep, d_out, b->unscale, b->d_slot_of);
+        HIPCHK(hipMemcpyAsync(kept_values, d_out, (size_t)n * n_keep * 32, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (uint32_t k = 0; k < n_keep; k++) {
+            const bool produced = keep[k] < p.n_witnesses && p.producer[keep[k]] != 0xFFFFFFFFu;
+            for (uint32_t j = 0; j < n; j++)
+                if (b->slow_index[j] < 0) {
+                    if (kept_assigned) kept_assigned[(size_t)j * n_keep + k] = produced;
+                    if (!produced) memset(kept_values + ((size_t)j * n_keep + k) * 32, 0, 32);
+                }
+        }
+    }
+    if (digests) {
+        if (defer || b->slow_ids.empty()) {
+            // (the table-wide kernels: flagged columns hold leftovers and are overwritten by the outcome)
+            if (p.n_digest_segments && b->d_leaves) {
+                if (int rc = stage_reserve(b, (size_t)n * 32)) return rc;
+                launch_digest_final(s, b->d_leaves, b->Bp, 0, n, b->d_stage);
+                HIPCHK(hipMemcpyAsync(digests, b->d_stage, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            } else {
+                const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)32 * n);
+                if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + (size_t)n * 32)) return rc;
+                int32_t *d_slow_index = (int32_t *)b->d_stage;
+                uint32_t *d_acc = (uint32_t *)(b->d_stage + idx_bytes);
+                uint8_t *d_out = b->d_stage + idx_bytes + leaf_bytes;
+                // every lane is read as a generic instance here: an event word that is set would send the kernel to the assigned bitmap of a
+                // job that is still running
+                Unscale u = b->unscale;
+                u.event = nullptr;
+                HIPCHK(hipMemsetAsync(d_slow_index, 0xff, (size_t)b->B * 4, s));
+                launch_digest(s, b->d_W, b->Bp, 0, n, p.n_witnesses, b->d_producer, u, d_slow_index, b->d_assigned, 0, d_acc, d_out);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(digests, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
+        } else if (int rc = acvm_batch_digest(b, 0, n, digests)) return rc;
+    }
+    if (!defer && !b->slow_ids.empty() && n_keep && kept_values) {  // synchronous exact lanes: their values from where they live
+        std::vector<uint8_t> one((size_t)b->B * 32), asg(b->B);
+        for (uint32_t k = 0; k < n_keep; k++) {
+            bool any = false;
+            for (uint32_t j = 0; j < n; j++) any |= b->slow_index[j] >= 0;
+            if (!any) break;
+            if (int rc = acvm_batch_witness(b, keep[k], one.data(), asg.data())) return rc;
+            for (uint32_t j = 0; j < n; j++)
+                if (b->slow_index[j] >= 0) {
+                    memcpy(kept_values + ((size_t)j * n_keep + k) * 32, &one[(size_t)j * 32], 32);
+                    if (kept_assigned) kept_assigned[(size_t)j * n_keep + k] = asg[j];
+                }
+        }
+    }
+    return 0;
+}
 
 // ---- ACVM::get_pending_foreign_call / resolve_pending_foreign_call (pwg/mod.rs:203-228) per instance
 static int fetch_pending(acvm_batch *b) {
@@ -1584,7 +1608,7 @@ static int reuse_check_kept(const acvm_batch *b, const uint32_t *ws, uint32_t n)
 // the instances of the exact path have their values in the table of their own: overwrite their rows of an export
 // (values_be32 [n][n_sel][32] of instances [first, first + n), d_sel = the witness list already on the device)
 static int reuse_patch_exact(acvm_batch *b, const uint32_t *d_sel, uint32_t n_sel, uint32_t first, uint32_t n, uint8_t *values_be32, uint8_t *d_tmp) {
-    if (!b->reuse()) return 0;
+    if (!b->side()) return 0;
     Unscale plain = b->unscale;
     plain.event = b->d_slow_start;  // all zero in this mode: "not the generic instance", nothing is scaled in the exact table
     for (uint32_t i = 0; i < n; i++) {
@@ -1604,7 +1628,7 @@ static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
     uint8_t *d_out = b->d_stage + 256;
     if (hipMemcpyAsync(d_sel, &w, 4, hipMemcpyHostToDevice, b->stream) != hipSuccess) return false;
     if (hipStreamSynchronize(b->stream) != hipSuccess) return false;  // &w is a stack address
-    if (b->reuse() && b->slow_index[j] >= 0) {
+    if (b->side() && b->slow_index[j] >= 0) {
         Unscale plain = b->unscale;
         plain.event = b->d_slow_start;
         launch_export(b->stream, b->d_Wx, b->x_cap, (uint32_t)b->slow_index[j], 1, d_sel, 1, d_out, plain);
@@ -1731,6 +1755,7 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
 static void fill_result(acvm_batch *b, uint32_t j, acvm_result_t &r) {
     memset(&r, 0, sizeof r);
     if (b->plan.n_opcodes == 0 || b->slow_index[j] < 0) { r.status = ACVM_STATUS_SOLVED; return; }
+    if (b->pending) { r.status = ACVM_STATUS_IN_PROGRESS; return; }  // its exact job is still running (batch_finish_pending)
     const SlowResult &sr = b->slow_res[b->slow_index[j]];
     r.status = sr.status; r.err = sr.err; r.opcode_index = sr.opcode_index; r.aux0 = sr.aux0; r.aux1 = sr.aux1;
     r.n_call_stack = sr.n_call_stack > 16 ? 16 : sr.n_call_stack;
@@ -1740,6 +1765,8 @@ static void fill_result(acvm_batch *b, uint32_t j, acvm_result_t &r) {
 
 int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out) try {
     if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     HIPCHK(hipSetDevice(b->device));
     for (uint32_t j = 0; j < b->B; j++) fill_result(b, j, out[j]);
@@ -1779,6 +1806,8 @@ int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, 
 
 int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap) try {
     if (!b || !out || !cap) return set_err(ACVM_E_INVALID, "null argument");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if (instance >= b->B) return set_err(ACVM_E_INVALID, "instance out of range");
     HIPCHK(hipSetDevice(b->device));
@@ -1839,9 +1868,11 @@ static int fetch_assigned(acvm_batch *b, uint32_t first, uint32_t n, uint8_t *as
 
 int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *assigned, uint8_t *values_be32) try {
     if (!b || !assigned || !values_be32) return set_err(ACVM_E_INVALID, "null argument");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
-    if (b->reuse()) return set_err(ACVM_E_STATE, "the batch recycles witness rows (ACVM_BATCH_REUSE_SLOTS): full maps are not kept; read the kept witnesses and the digest");
+    if (b->side()) return set_err(ACVM_E_STATE, "the batch recycles witness rows (ACVM_BATCH_REUSE_SLOTS) or solved its exact lanes in the side table: full maps are not kept; read the kept witnesses and the digest");
     HIPCHK(hipSetDevice(b->device));
     uint32_t nw = b->plan.n_witnesses;
     if (!n || !nw) return 0;
@@ -1881,7 +1912,7 @@ static int digest_exact_instances(acvm_batch *b, const std::vector<uint32_t> &in
     Unscale plain = b->unscale;
     plain.event = b->d_slow_start;  // slot reuse: all zero = "instance of the exact path" for every lane of the exact table
     for (uint32_t j : instances) {
-        if (b->reuse())  // lane t of the exact table, whose lanes index themselves
+        if (b->side())  // lane t of the exact table, whose lanes index themselves
             launch_digest(b->stream, b->d_Wx, b->x_cap, (uint32_t)b->slow_index[j], 1, p.n_witnesses, b->d_producer, plain, (const int32_t *)b->d_ids_x, b->d_assigned,
                           n_slow, d_leaves, d_out);
         else
@@ -1896,6 +1927,8 @@ static int digest_exact_instances(acvm_batch *b, const std::vector<uint32_t> &in
 // per-instance digest of the solved witness map (definition: kernels_hash.hip, include/acvm_amd.h)
 int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32) try {
     if (!b || (n && !out32)) return set_err(ACVM_E_INVALID, "null argument");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
     if (!n) return 0;
@@ -1916,7 +1949,7 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
         if (flagged.size() <= 64) return digest_exact_instances(b, flagged, first, out32);
         // many instances of the exact path (a whole batch waiting at a foreign call, a batch of failures): one launch instead of one
         // launch + copy + synchronisation per instance
-        if (b->reuse()) {  // all lanes of the exact table at once, then scattered to their instances
+        if (b->side()) {  // all lanes of the exact table at once, then scattered to their instances
             const uint32_t n_slow = (uint32_t)b->slow_ids.size();
             const size_t leaf_bytes = align256((size_t)32 * n_slow);
             if (int rc = stage_reserve(b, leaf_bytes + (size_t)n_slow * 32)) return rc;
@@ -1955,6 +1988,8 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
 int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,
                                  uint8_t *values_be32) try {
     if (!b || (n_witnesses && (!witnesses || !values_be32))) return set_err(ACVM_E_INVALID, "null argument");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
     if (!n || !n_witnesses) return 0;
@@ -2062,6 +2097,8 @@ long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8
 
 int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uint8_t *assigned) try {
     if (!b || !out_be32 || !assigned) return set_err(ACVM_E_INVALID, "null argument");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if (witness >= b->plan.n_witnesses) { memset(assigned, 0, b->B); memset(out_be32, 0, (size_t)b->B * 32); return 0; }
     HIPCHK(hipSetDevice(b->device));

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(128) digest_pairs_kernel(const uint4 *__restri
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, chunk = chunk0 + blockIdx.y;
     if (t >= n) return;
     const uint64_t j = (uint64_t)first + t;
-    const bool generic = u.event[j] == 0xFFFFFFFFu;  // solved by the level kernels: the planner's assigned set, scaled columns
+    const bool generic = !u.event || u.event[j] == 0xFFFFFFFFu;  // solved by the level kernels: the planner's assigned set, scaled columns (no event words: every lane)
     const uint32_t lane = generic ? 0u : (uint32_t)slow_index[j];
     Fr one = fr_zero();
     one.v[0] = 1;

@@ -1,0 +1,308 @@
+// node.cpp -- the node-level driver behind the C ABI (include/acvm_amd.h acvm_node_*): ONE call solves a global batch of witness
+// instances of one circuit on every GPU of the node. It replaces the loop a caller of the reference runs once per instance
+// (acvm_js/src/execute.rs:60-119: ACVM::new, solve, finalize / error string, witness extraction) and does what SURVEY 8e describes:
+//   * the global batch is split contiguously over the devices (device d owns instances [d * per, (d + 1) * per)), no exchange step;
+//   * per device one host thread drives one batch handle (one levelised plan, one witness table) through its shard in tiles;
+//   * the inputs of tile k + 1 travel host -> pinned staging -> device beside the solve of tile k (a second thread per device fills
+//     the two staging buffers and issues hipMemcpyAsync on a copy stream);
+//   * instances that leave the generic path are re-solved by the exact kernels in a side table on a stream of their own, beside the
+//     level schedule of the NEXT tile (batch.cpp, asynchronous exact path): a few diverging inputs per tile do not stall the tile;
+//   * per instance the caller gets the result record, the kept witnesses (normally the circuit's return values) and the 32-byte
+//     digest of the whole witness map, in global instance order.
+#include "batch.hpp"
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct DeviceLane {
+    int device = 0;
+    acvm_batch_t *batch = nullptr;
+    bool async = false;
+    uint8_t *pinned[2] = {nullptr, nullptr};
+    uint8_t *d_in[2] = {nullptr, nullptr};
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+    // statistics of the last solve
+    double device_ms = 0, h2d_wait_ms = 0, export_ms = 0, total_ms = 0;
+    uint32_t tiles = 0, exact_instances = 0;
+    uint64_t not_solved = 0;
+    std::string error;
+    int rc = 0;
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+struct acvm_node {
+    std::vector<DeviceLane> lanes;
+    std::vector<uint32_t> ids, keep;
+    uint32_t tile = 0, flags = 0;
+    uint64_t last_n = 0;
+    double last_total_ms = 0;
+    ~acvm_node() {
+        for (DeviceLane &l : lanes) {
+            hipSetDevice(l.device);
+            if (l.batch) acvm_batch_free(l.batch);
+            for (int k = 0; k < 2; k++) {
+                if (l.pinned[k]) hipHostFree(l.pinned[k]);
+                if (l.d_in[k]) hipFree(l.d_in[k]);
+                if (l.ev_h2d[k]) hipEventDestroy(l.ev_h2d[k]);
+            }
+            if (l.copy) hipStreamDestroy(l.copy);
+        }
+    }
+};
+
+namespace {
+
+// instances per handle when the caller leaves the choice to the library: the largest power of two (at most 2^17, the measured optimum of
+// the 10k-gate circuit) whose tables fit 70 % of the device's free memory
+uint32_t auto_tile(const acvm_circuit_t *c, const std::vector<uint32_t> &ids, const std::vector<uint32_t> &keep, uint32_t flags, int device) {
+    acvm_stats_t st;
+    if (acvm_circuit_plan_stats_ex(c, ids.data(), (uint32_t)ids.size(), flags, keep.data(), (uint32_t)keep.size(), &st) != 0) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    // witness rows + inverse rows, 32 B each, + 15 % for memory blocks, class scratch and staging
+    const double per_instance = 32.0 * ((double)st.n_table_rows + st.n_inverse_slots) * 1.15 + 4096.0;
+    uint32_t t = 1u << 17;
+    while (t > 64 && (double)t * per_instance > 0.7 * (double)free_b) t >>= 1;
+    return t;
+}
+
+// rows [first, first + n) of the caller's inputs into a pinned buffer of `tile` rows; the tail of a partial tile repeats its first row
+void fill_staging(uint8_t *dst, const uint8_t *values, size_t row, uint64_t first, uint32_t n, uint32_t tile) {
+    if (row == 0) return;
+    memcpy(dst, values + first * row, (size_t)n * row);
+    for (uint32_t i = n; i < tile; i++) memcpy(dst + (size_t)i * row, dst, row);
+}
+
+// an outcome of the exact path of the tile that started at global instance `base` (n_valid instances of it are the caller's)
+uint64_t patch_outcome(const ExactOutcome &o, uint64_t base, uint32_t n_valid, uint32_t n_keep, acvm_result_t *results, uint8_t *kept, uint8_t *kept_assigned,
+                       uint8_t *digests) {
+    uint64_t not_solved = 0;
+    for (size_t t = 0; t < o.instance.size(); t++) {
+        const uint32_t j = o.instance[t];
+        if (j >= n_valid) continue;
+        const uint64_t g = base + j;
+        not_solved += o.results[t].status != ACVM_STATUS_SOLVED;
+        if (results) results[g] = o.results[t];
+        if (kept && n_keep && !o.kept_values.empty()) memcpy(kept + g * n_keep * 32, &o.kept_values[t * (size_t)n_keep * 32], (size_t)n_keep * 32);
+        if (kept_assigned && n_keep && !o.kept_assigned.empty()) memcpy(kept_assigned + g * n_keep, &o.kept_assigned[t * (size_t)n_keep], n_keep);
+        if (digests && !o.digests.empty()) memcpy(digests + g * 32, &o.digests[t * 32], 32);
+    }
+    return not_solved;
+}
+
+void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, const uint8_t *values, acvm_result_t *results, uint8_t *kept, uint8_t *kept_assigned,
+              uint8_t *digests) {
+    const double t_begin = now_ms();
+    L.rc = 0;
+    L.error.clear();
+    L.device_ms = L.h2d_wait_ms = L.export_ms = 0;
+    L.tiles = L.exact_instances = 0;
+    L.not_solved = 0;
+    auto fail = [&](int rc, const std::string &what) { if (!L.rc) { L.rc = rc; L.error = what + ": " + acvm_last_error(); } };
+    if (hipSetDevice(L.device) != hipSuccess) { fail(ACVM_E_DEVICE, "hipSetDevice"); return; }
+    const uint32_t tile = node->tile, n_keep = (uint32_t)node->keep.size();
+    const size_t row = node->ids.size() * 32;
+    const uint64_t n = last - first;
+    const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+    if (!n_tiles) return;
+    // ---- producer: host rows -> pinned staging -> device, one tile ahead of the solver
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t staged = 0, consumed = 0;  // tiles whose H2D was issued / whose staging slot is free again
+    bool abort = false;
+    std::thread producer([&] {
+        if (hipSetDevice(L.device) != hipSuccess) return;  // HIP's current device is per thread
+        for (uint32_t k = 0; k < n_tiles; k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return abort || k < consumed + 2; });
+                if (abort) return;
+            }
+            const uint64_t base = first + (uint64_t)k * tile;
+            const uint32_t m = (uint32_t)std::min<uint64_t>(tile, last - base);
+            const int slot = (int)(k & 1);
+            fill_staging(L.pinned[slot], values, row, base, m, tile);
+            if (row) hipMemcpyAsync(L.d_in[slot], L.pinned[slot], (size_t)tile * row, hipMemcpyHostToDevice, L.copy);
+            hipEventRecord(L.ev_h2d[slot], L.copy);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                staged = k + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    auto stop_producer = [&] {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            abort = true;
+        }
+        cv.notify_all();
+        producer.join();
+    };
+    // ---- solver
+    uint64_t prev_base = 0;
+    uint32_t prev_valid = 0;
+    for (uint32_t k = 0; k < n_tiles && !L.rc; k++) {
+        const uint64_t base = first + (uint64_t)k * tile;
+        const uint32_t m = (uint32_t)std::min<uint64_t>(tile, last - base);
+        const int slot = (int)(k & 1);
+        const double t0 = now_ms();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return staged > k; });
+        }
+        if (hipEventSynchronize(L.ev_h2d[slot]) != hipSuccess) { fail(ACVM_E_DEVICE, "hipEventSynchronize"); break; }
+        L.h2d_wait_ms += now_ms() - t0;
+        if (int rc = acvm_batch_set_initial_witness_device(L.batch, L.d_in[slot])) { fail(rc, "set_initial_witness"); break; }
+        {   // the import has read the slot: the producer may refill it
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = k + 1;
+        }
+        cv.notify_all();
+        const int rc = acvm_batch_solve(L.batch);  // asynchronous handles: collects the exact job of tile k - 1 on the way
+        if (rc < 0) { fail(rc, "solve"); break; }
+        acvm_stats_t st;
+        acvm_batch_stats(L.batch, &st);
+        L.device_ms += st.solve_device_ms;
+        L.exact_instances += st.n_slow_instances;
+        L.tiles++;
+        const double t1 = now_ms();
+        if (k > 0 && !L.batch->last_outcome.instance.empty()) {
+            L.not_solved += patch_outcome(L.batch->last_outcome, prev_base, prev_valid, n_keep, results, kept, kept_assigned, digests);
+            L.batch->last_outcome.clear();
+        }
+        if (!L.batch->pending)  // a synchronous exact path: its lanes are final
+            for (size_t t = 0; t < L.batch->slow_ids.size(); t++)
+                L.not_solved += L.batch->slow_ids[t] < m && L.batch->slow_res[t].status != ACVM_STATUS_SOLVED;
+        if (int rc2 = batch_export_tile(L.batch, m, node->keep.data(), n_keep, results ? results + base : nullptr, kept ? kept + base * n_keep * 32 : nullptr,
+                                        kept_assigned ? kept_assigned + base * n_keep : nullptr, digests ? digests + base * 32 : nullptr)) {
+            fail(rc2, "export");
+            break;
+        }
+        L.export_ms += now_ms() - t1;
+        prev_base = base;
+        prev_valid = m;
+    }
+    if (!L.rc) {  // the exact job of the last tile
+        ExactOutcome o;
+        if (int rc = batch_finish_pending(L.batch, &o)) fail(rc, "exact path");
+        else L.not_solved += patch_outcome(o, prev_base, prev_valid, n_keep, results, kept, kept_assigned, digests);
+    }
+    stop_producer();
+    hipStreamSynchronize(L.copy);
+    if (L.rc) {  // leave the handle reusable
+        ExactOutcome o;
+        batch_finish_pending(L.batch, &o);
+    }
+    L.total_ms = now_ms() - t_begin;
+}
+
+}  // namespace
+
+extern "C" {
+
+acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, const uint32_t *initial_ids, uint32_t n_initial, const uint32_t *keep_ids,
+                           uint32_t n_keep, const acvm_node_opts_t *opts) try {
+    if (!c || (n_initial && !initial_ids) || (n_keep && !keep_ids)) { set_err(ACVM_E_INVALID, "null argument"); return nullptr; }
+    const int visible = acvm_device_count();
+    if (visible < 1) { set_err(ACVM_E_DEVICE, "no HIP device visible; the library has no CPU fallback"); return nullptr; }
+    auto node = std::make_unique<acvm_node>();
+    node->ids.assign(initial_ids, initial_ids + n_initial);
+    node->keep.assign(keep_ids, keep_ids + n_keep);
+    node->flags = opts ? opts->batch_flags : 0;
+    std::vector<int> devices;
+    const uint32_t n_dev = opts && opts->n_devices ? opts->n_devices : (uint32_t)visible;
+    for (uint32_t i = 0; i < n_dev; i++) {
+        const int d = opts && opts->devices ? opts->devices[i] : (int)i;
+        if (d < 0 || d >= visible) { set_err(ACVM_E_INVALID, "device index " + std::to_string(d) + " out of range (" + std::to_string(visible) + " visible)"); return nullptr; }
+        devices.push_back(d);
+    }
+    node->tile = opts && opts->tile_instances ? opts->tile_instances : auto_tile(c, node->ids, node->keep, node->flags, devices[0]);
+    if (!node->tile) return nullptr;  // (the planner's refusal is the error text)
+    node->lanes.resize(devices.size());
+    const size_t row = (size_t)n_initial * 32;
+    // one handle per device, created side by side (each allocates tens of GB and levelises the circuit)
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < devices.size(); i++) {
+        node->lanes[i].device = devices[i];
+        th.emplace_back([&, i] {
+            DeviceLane &L = node->lanes[i];
+            auto fail = [&](int rc, const std::string &what) { L.rc = rc; L.error = what + ": " + acvm_last_error(); };
+            if (hipSetDevice(L.device) != hipSuccess) { L.rc = ACVM_E_DEVICE; L.error = "hipSetDevice failed"; return; }
+            L.batch = acvm_batch_new_ex(c, solver, node->tile, node->ids.data(), n_initial, node->flags, node->keep.data(), n_keep);
+            if (!L.batch) { fail(ACVM_E_DEVICE, "acvm_batch_new_ex"); return; }
+            const int a = batch_enable_async_exact(L.batch, node->keep.data(), n_keep, true);
+            if (a < 0) { fail(a, "async exact path"); return; }
+            L.async = a == 1;
+            const size_t bytes = std::max<size_t>((size_t)node->tile * row, 16);
+            bool ok = hipStreamCreateWithFlags(&L.copy, hipStreamNonBlocking) == hipSuccess;
+            for (int k = 0; k < 2 && ok; k++)
+                ok = hipHostMalloc((void **)&L.pinned[k], bytes, hipHostMallocDefault) == hipSuccess && hipMalloc((void **)&L.d_in[k], bytes) == hipSuccess &&
+                     hipEventCreateWithFlags(&L.ev_h2d[k], hipEventDisableTiming) == hipSuccess;
+            if (!ok) { L.rc = ACVM_E_DEVICE; L.error = "staging buffers: allocation failed"; }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (DeviceLane &L : node->lanes)
+        if (L.rc) { set_err(L.rc, "device " + std::to_string(L.device) + ": " + L.error); return nullptr; }
+    return node.release();
+} ABI_CATCH_PTR
+
+void acvm_node_free(acvm_node_t *n) { delete n; }
+
+uint32_t acvm_node_tile_instances(const acvm_node_t *n) { return n ? n->tile : 0; }
+uint32_t acvm_node_num_devices(const acvm_node_t *n) { return n ? (uint32_t)n->lanes.size() : 0; }
+
+long long acvm_node_solve(acvm_node_t *n, uint64_t n_instances, const uint8_t *values_be32, acvm_result_t *results, uint8_t *kept_be32, uint8_t *kept_assigned,
+                          uint8_t *digests32) try {
+    if (!n || (n_instances && !n->ids.empty() && !values_be32)) return set_err(ACVM_E_INVALID, "null argument");
+    const double t0 = now_ms();
+    const size_t D = n->lanes.size();
+    // contiguous split, multiples of 64 instances per device except the last
+    std::vector<uint64_t> bound(D + 1, 0);
+    const uint64_t per = ((n_instances + D - 1) / D + 63) / 64 * 64;
+    for (size_t d = 0; d <= D; d++) bound[d] = std::min<uint64_t>(n_instances, per * d);
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < D; d++)
+        th.emplace_back(run_lane, n, std::ref(n->lanes[d]), bound[d], bound[d + 1], values_be32, results, kept_be32, kept_assigned, digests32);
+    for (auto &t : th) t.join();
+    n->last_n = n_instances;
+    n->last_total_ms = now_ms() - t0;
+    for (DeviceLane &L : n->lanes)
+        if (L.rc) return set_err(L.rc, "device " + std::to_string(L.device) + ": " + L.error);
+    long long not_solved = 0;
+    for (DeviceLane &L : n->lanes) not_solved += (long long)L.not_solved;
+    return not_solved;
+} ABI_CATCH
+
+int acvm_node_stats(acvm_node_t *n, acvm_node_stats_t *out) {
+    if (!n || !out) return set_err(ACVM_E_INVALID, "null argument");
+    memset(out, 0, sizeof *out);
+    out->n_devices = (uint32_t)n->lanes.size();
+    out->tile_instances = n->tile;
+    out->n_instances = n->last_n;
+    out->total_ms = n->last_total_ms;
+    for (size_t d = 0; d < n->lanes.size() && d < 16; d++) {
+        const DeviceLane &L = n->lanes[d];
+        out->device[d] = L.device;
+        out->async_exact[d] = L.async;
+        out->tiles[d] = L.tiles;
+        out->exact_instances[d] = L.exact_instances;
+        out->lane_ms[d] = L.total_ms;
+        out->solve_device_ms[d] = L.device_ms;
+        out->h2d_wait_ms[d] = L.h2d_wait_ms;
+        out->export_ms[d] = L.export_ms;
+    }
+    return 0;
+}
+
+}  // extern "C"

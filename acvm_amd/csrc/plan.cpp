@@ -801,7 +801,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             records.push_back({lvl, rec_cls, oi, std::move(rec_reads)});
             if (sl_it != sl_of.end()) {  // same "already assigned" flags as the VM record's outputs, in order
                 records.back().prog_at = sl_base + sl_it->second.first;
-                for (size_t k = 0; k < out_slots[oi].size(); k++) p.prog[sl_base + sl_it->second.second + 2 * k] = p.prog[out_slots[oi][k].first];
+                for (size_t k = 0; k < out_slots[oi].size(); k++) p.prog[sl_base + sl_it->second.first + sl_it->second.second + 2 * k] = p.prog[out_slots[oi][k].first];
                 p.n_brillig_inlined++;
             }
             continue;

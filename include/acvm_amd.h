@@ -20,7 +20,8 @@
  *   trait BlackBoxFunctionSolver  blackbox_solver/src/lib.rs:27-45   acvm_bb_solver_t (vtable)
  *
  * Threading (reference: `&mut self`, backend not Sync): one batch handle = one host thread + one HIP
- * device + one stream. Handles are independent; there is no global mutable state.
+ * device + one stream set. Handles are independent, also on one device; the only process-wide state is read-mostly
+ * (the tuning table, the per-device lookup tables, built once under a lock). acvm_node_* drives one handle per device.
  * Errors: functions return 0 on success or a negative ACVM_E_* code; acvm_last_error() gives text.
  * The library requires a gfx950 device for every compute entry point and fails loudly without one;
  * there is no CPU fallback.
@@ -377,6 +378,49 @@ uint32_t acvm_multi_num_witnesses(const acvm_multi_t *m);
 int acvm_multi_witness_map(acvm_multi_t *m, uint32_t instance, uint8_t *assigned, uint8_t *values_be32);
 /* the batch handle and the index inside it that serve `instance` (foreign calls, digests, ... go through the batch API) */
 acvm_batch_t *acvm_multi_locate(acvm_multi_t *m, uint32_t instance, uint32_t *index_in_batch);
+
+
+/*
+ * The node-level driver: ONE call solves a global batch of instances of one circuit on every GPU of the node. It stands
+ * for the loop a caller of the reference runs once per instance -- ACVM::new, solve, finalize or the error string, the return
+ * witnesses (acvm_js/src/execute.rs:60-119, public_witness.rs:10-21) -- and owns what that loop needs on this hardware: the split of the
+ * batch over the devices (contiguous, no exchange step), tiles inside a device (a 10k-gate circuit at 2^20 instances is 335 GB of
+ * witness table), pinned staging with the upload of tile k + 1 beside the solve of tile k, the exact re-solve of diverging instances
+ * beside the next tile, one host thread + one handle + one stream set per device.
+ *   acvm_node_new    one batch handle of tile_instances instances per listed device (a device may be listed twice: two handles driven by
+ *                    two host threads). keep_ids: the witnesses returned per instance (normally ACVM_SET_RETURN_VALUES).
+ *   acvm_node_solve  values_be32 [n_instances][n_initial][32] in host memory (pageable is fine); any of the outputs may be NULL:
+ *                    results [n_instances], kept_be32 [n_instances][n_keep][32] (zeros where unassigned), kept_assigned [n_instances][n_keep],
+ *                    digests32 [n_instances][32] (acvm_batch_digest's definition). Returns the number of instances not Solved, or a
+ *                    negative error. The handle is reusable: call it again with the next global batch.
+ */
+typedef struct acvm_node acvm_node_t;
+typedef struct {
+    uint32_t n_devices;       /* 0 = every visible device */
+    const int *devices;       /* n_devices indices, NULL = 0 .. n_devices - 1 */
+    uint32_t tile_instances;  /* instances per handle; 0 = the largest power of two <= 2^17 whose tables fit the device */
+    uint32_t batch_flags;     /* ACVM_BATCH_* of the handles */
+} acvm_node_opts_t;
+typedef struct {
+    uint32_t n_devices, tile_instances;
+    uint64_t n_instances;
+    double total_ms;            /* wall clock of the last acvm_node_solve */
+    int device[16];
+    uint32_t async_exact[16];   /* 1: the handle re-solves diverging instances beside the next tile */
+    uint32_t tiles[16], exact_instances[16];
+    double lane_ms[16];         /* wall clock of the device's thread */
+    double solve_device_ms[16]; /* HIP-event time of its solves */
+    double h2d_wait_ms[16];     /* what of the uploads the solves did not cover */
+    double export_ms[16];       /* results, kept witnesses and digests leaving the device */
+} acvm_node_stats_t;
+acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, const uint32_t *initial_ids, uint32_t n_initial,
+                           const uint32_t *keep_ids, uint32_t n_keep, const acvm_node_opts_t *opts);
+void acvm_node_free(acvm_node_t *n);
+uint32_t acvm_node_tile_instances(const acvm_node_t *n);
+uint32_t acvm_node_num_devices(const acvm_node_t *n);
+long long acvm_node_solve(acvm_node_t *n, uint64_t n_instances, const uint8_t *values_be32, acvm_result_t *results, uint8_t *kept_be32,
+                          uint8_t *kept_assigned, uint8_t *digests32);
+int acvm_node_stats(acvm_node_t *n, acvm_node_stats_t *out);
 
 #ifdef __cplusplus
 }

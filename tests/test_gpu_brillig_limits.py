@@ -75,7 +75,7 @@ def test_step_limit_past_the_maximum_fails_the_solve_call(oracle):
             batch.solve()
 
 
-def recursion(depth_reg=0):
+def recursion(out=2):
     # f(n): if n == 0 return; n -= 1; acc += 1; call f   -- call depth = n + 1
     bc = [("Const", 1, 0), ("Const", 2, 1), ("Const", 3, 0),   # zero, one, acc
           ("Call", 6), ("Mov", 0, 3), ("Stop",),               # 3, 4, 5
@@ -83,7 +83,7 @@ def recursion(depth_reg=0):
           ("BinaryFieldOp", 0, "Sub", 0, 2), ("BinaryFieldOp", 3, "Add", 3, 2),  # 8, 9
           ("Call", 6),                                         # 10
           ("Return",)]                                         # 11
-    return Brillig(inputs=[W(1)], outputs=[2], bytecode=bc)
+    return Brillig(inputs=[W(1)], outputs=[out], bytecode=bc)
 
 
 def test_call_depth_beyond_64(oracle):
@@ -114,8 +114,8 @@ def test_a_failing_program_still_fails_after_a_retry(oracle):
 def test_limits_while_stepping(oracle):
     """acvm_batch_solve_opcode (ACVM::solve_opcode, pwg/mod.rs:243-303): the retry happens inside the step that executes the opcode"""
     import acvm_amd
-    circ = Circuit(5, [store_far(), recursion(), E([], [(1, 3), (1, 2), (-1, 5)], 0)])
-    # recursion reads w1 as n; store_far reads (w1, w2)
+    circ = Circuit(5, [store_far(), recursion(out=4), E([], [(1, 3), (1, 4), (-1, 5)], 0)])
+    # recursion reads w1 as n and writes w4; store_far reads (w1, w2) and writes w3
     rows = [[70, 5], [3000, 6], [2, 7]]
     data = circ.to_bytes()
     batch = acvm_amd.Batch(acvm_amd.Circuit(data), len(rows), [1, 2])

@@ -1,0 +1,100 @@
+"""The node-level driver (acvm_node_*, node.cpp): one call = split over devices + tiles + pinned double-buffered uploads + the exact path
+beside the next tile. The test box has ONE GPU: "two devices" is device 0 listed twice -- two handles driven by two host threads on one
+device, which is also the header's threading contract (include/acvm_amd.h). Everything is compared with one plain batch of the same
+instances and, through results / kept witnesses / digests, with the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def plain_batch(data, ids, values, B, keep):
+    import acvm_amd
+    batch = acvm_amd.Batch(acvm_amd.Circuit(data), B, ids)
+    batch.set_initial_witness(values)
+    batch.solve()
+    res = [r.as_tuple() for r in batch.results()]
+    dig = batch.digest()
+    kept = np.zeros((B, len(keep), 32), dtype=np.uint8)
+    asg = np.zeros((B, len(keep)), dtype=np.uint8)
+    for k, w in enumerate(keep):
+        v, a = batch.witness(w)
+        kept[:, k] = v
+        asg[:, k] = a
+    batch.free()
+    return res, kept, asg, dig
+
+
+@pytest.mark.parametrize("devices,tile,B", [([0], 256, 1000), ([0, 0], 192, 1000), ([0, 0], 64, 130), ([0, 0, 0], 512, 700)])
+def test_node_equals_one_batch_and_oracle(oracle, devices, tile, B):
+    """mixed circuit with edge-case instances: the flagged instances of every tile take the asynchronous exact path; partial last tiles"""
+    import acvm_amd
+    from acvm_amd import synth
+    circ, ids = synth.mixed_circuit(500, seed=0x40DE0001)
+    values = synth.witness_batch(B, seed=0x40DE0001, edge_cases=True)
+    data = circ.to_bytes()
+    gc = acvm_amd.Circuit(data)
+    keep = gc.witness_set("return_values") + [ids[0], 7]
+    want = plain_batch(data, ids, values, B, keep)
+    node = acvm_amd.Node(gc, ids, keep=keep, devices=devices, tile=tile)
+    for _ in range(2):  # the handle is reusable
+        not_solved, res, kept, asg, dig = node.solve(values, B)
+        assert [r.as_tuple() for r in res] == want[0]
+        assert not_solved == sum(1 for r in want[0] if r[0] != 0)
+        assert np.array_equal(asg, want[2]) and np.array_equal(kept, want[1])
+        assert np.array_equal(dig, want[3])
+    st = node.stats()
+    assert st["n_devices"] == len(devices) and sum(st["tiles"]) >= (B + tile - 1) // tile
+    assert sum(st["exact_instances"]) > 0 and all(st["async_exact"])
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, values, B)
+    for j in range(0, B, 7):
+        assert res[j].as_tuple() == ores[j].as_tuple()
+        assert bytes(dig[j]) == oracle.witness_map_digest(oasg[j], ovals[j])
+        if res[j].message or ores[j].message:
+            assert res[j].message == ores[j].message
+    node.free()
+
+
+def test_node_with_slot_reuse_and_null_outputs(oracle):
+    import acvm_amd
+    from acvm_amd import synth
+    circ, ids = synth.mixed_circuit(400, seed=0x40DE0002)
+    B = 300
+    values = synth.witness_batch(B, seed=0x40DE0002, edge_cases=True)
+    data = circ.to_bytes()
+    gc = acvm_amd.Circuit(data)
+    keep = gc.witness_set("return_values")
+    want = plain_batch(data, ids, values, B, keep)
+    node = acvm_amd.Node(gc, ids, keep=keep, devices=[0, 0], tile=128, reuse_slots=True)
+    not_solved, res, kept, asg, dig = node.solve(values, B)
+    assert [r.as_tuple() for r in res] == want[0] and np.array_equal(dig, want[3]) and np.array_equal(kept, want[1]) and np.array_equal(asg, want[2])
+    n2, r2, k2, a2, d2 = node.solve(values, B, results=False, kept=False, digests=False)  # only the count
+    assert n2 == not_solved and r2 is None and k2 is None and d2 is None
+    node.free()
+
+
+def test_node_foreign_calls_stay_synchronous(oracle):
+    """a circuit with a pending foreign call cannot defer its exact lanes (the caller must answer): the handle stays synchronous and the
+    instances report RequiresForeignCall"""
+    import acvm_amd
+    from acvm_amd.acir import Brillig, Circuit, Expression as E
+    from acvm_amd.synth import values_from_rows
+    circ = Circuit(3, [Brillig(inputs=[E.from_witness(1)], outputs=[2], bytecode=[("ForeignCall", "f", [("Register", 0)], [("Register", 0)]), ("Stop",)])])
+    node = acvm_amd.Node(acvm_amd.Circuit(circ.to_bytes()), [1], keep=[2], devices=[0], tile=64)
+    not_solved, res, kept, asg, dig = node.solve(values_from_rows([[5], [6], [7]]), 3)
+    assert not_solved == 3 and all(r.status == acvm_amd.STATUS_REQUIRES_FOREIGN_CALL for r in res) and not any(node.stats()["async_exact"])
+    node.free()
+
+
+def test_node_auto_tile_and_empty_batch():
+    import acvm_amd
+    from acvm_amd import synth
+    circ, ids = synth.arithmetic_circuit(300, seed=3)
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    node = acvm_amd.Node(gc, ids, keep=gc.witness_set("return_values"))
+    assert node.tile == 1 << 17 and node.n_devices == acvm_amd.device_count()
+    assert node.solve(b"", 0)[0] == 0
+    values = synth.witness_batch(100, seed=3, edge_cases=False)
+    not_solved, res, kept, asg, dig = node.solve(values, 100)
+    assert not_solved == 0 and asg.all()
+    node.free()

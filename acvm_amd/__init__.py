@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
-    "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
+    "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
 ]
 
 
@@ -269,6 +269,7 @@ def lib():
     L.acvm_node_solve.restype = C.c_longlong
     L.acvm_node_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.acvm_node_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.acvm_debug_stream_rate.argtypes = [C.c_size_t, C.POINTER(C.c_double)]
     L.acvm_tuning_set.argtypes = [C.c_char_p, C.c_longlong]
     L.acvm_tuning_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
     L.acvm_tuning_key.restype = C.c_char_p
@@ -380,6 +381,13 @@ class tuning:
         for k, v in self.old.items():
             tuning_set(k, v)
         return False
+
+
+def stream_rate(nbytes=4 << 30):
+    """GB/s (read + written) of a nontemporal copy of nbytes: the measured streaming ceiling beside the spec peak of the HBM roofline"""
+    r = C.c_double()
+    _check(lib().acvm_debug_stream_rate(nbytes, C.byref(r)))
+    return r.value
 
 
 def modmul_rate(iters=400, waves_per_simd=8):

@@ -148,6 +148,40 @@ int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modm
     return 0;
 }
 
+// The measured streaming ceiling beside the spec peak of the HBM roofline: a nontemporal copy of `bytes` (read + written), best of three.
+int acvm_debug_stream_rate(size_t bytes, double *read_plus_write_gb_per_s) {
+    if (!read_plus_write_gb_per_s || bytes < (1u << 20)) return set_err(ACVM_E_INVALID, "bad argument");
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    const uint64_t n = bytes / 16;
+    uint4 *src = nullptr, *dst = nullptr;
+    HIPCHK(hipMalloc((void **)&src, n * 16));
+    if (hipMalloc((void **)&dst, n * 16) != hipSuccess) { hipFree(src); return set_err(ACVM_E_DEVICE, "hipMalloc failed"); }
+    HIPCHK(hipMemset(src, 1, n * 16));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 4; r++) {
+        hipEventRecord(e0, nullptr);
+        launch_stream_rate(nullptr, src, dst, n, (uint32_t)prop.multiProcessorCount * 16);
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r && ms < best) best = ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(src);
+    hipFree(dst);
+    HIPCHK(hipGetLastError());
+    *read_plus_write_gb_per_s = 2.0 * (double)(n * 16) / (best * 1e-3) / 1e9;
+    return 0;
+}
+
 // Component probes of the Grumpkin kernels for the parity tests: what = 0 host table point (param = table << 24 | index),
 // 1 device hash_single(in[0], parity = param), 2 device hash-ladder compress(in[0..n_in)), 3 device fixed_base_mul(table
 // base param, integer in[0]), 4 device table point. in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian.

@@ -86,6 +86,7 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
                           const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event);
 void launch_modmul_rate(hipStream_t s, uint32_t *out, uint32_t blocks, uint32_t iters);
+void launch_stream_rate(hipStream_t s, const uint4 *src, uint4 *dst, uint64_t n, uint32_t blocks);
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 // event words [0, B) <- 0xFFFFFFFF, the flagged count (word B) and the ticket (word B + 1) <- 0; the count of words != 0xFFFFFFFF into word B and *host_count

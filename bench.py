@@ -12,6 +12,10 @@ Other workloads (parity-test configs, measured for DESIGN.md; 2^16 instances per
     --workload grumpkin        config 4: Pedersen + FixedBaseScalarMul + SchnorrVerify circuit
     --workload arith_pedersen  the north-star shape: 10k arithmetic gates + 8 Pedersen commitments
     --workload mixed           the config-5 opcode mix at --gates opcodes (every kernel class in one circuit)
+    --workload config5         config 5 at circuit size: the 10^6-opcode mixed circuit (--gates), tiles of --tile-log2 (default 2^12) instances,
+                               --total-log2 (default 2^14) per GPU; a step = solve + per-instance map digest of every tile (what config 5 keeps)
+The default run (N = 1) also appends `other_workloads`: three-step legs of arith_pedersen (the north-star target shape), hash and grumpkin,
+each parity-checked against the oracle and carrying its own roofline / alu_roofline (--no-legs skips them).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without a launcher: spawns the N ranks itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -38,8 +42,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLASS_KERNEL = ["light_level_kernel", "hash_level_kernel", "grumpkin_level_kernel", "brillig_level_kernel"]
 # substring of the kernel's symbol in the rocprofv3 output
-KERNEL_SYMBOL = {"light_level_kernel": "record_level_kernel<acvm::LightOp", "hash_level_kernel": "record_level_kernel<acvm::HashOp",
-                 "grumpkin_level_kernel": "record_level_kernel<acvm::GrumpkinOp", "brillig_level_kernel": "record_level_kernel<acvm::BrilligOp"}
+# substrings of the symbols of the kernels a class's launches run (a class may have several: the byte-message hashes have a kernel of their own)
+KERNEL_SYMBOL = {"arith_level_kernel": ["arith_level_kernel"], "inverse_batch_kernel": ["inverse_batch_kernel"],
+                 "light_level_kernel": ["record_level_kernel<acvm::LightOp", "record_level_kernel<acvm::LightSlOp"],
+                 "hash_level_kernel": ["hash_coop_level_kernel", "record_level_kernel<acvm::HashOp"],
+                 "grumpkin_level_kernel": ["record_level_kernel<acvm::GrumpkinOp", "pedersen_quad_level_kernel", "record_level_kernel<acvm::EcdsaOp"],
+                 "brillig_level_kernel": ["record_level_kernel<acvm::BrilligOp"]}
 # FETCH_SIZE reports half the bytes of a 16 B/lane coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section); both factors
 # were re-derived on this part from a 4 GiB copy (profiles/traffic.json: x1.99998 / x1.00000)
 PMC_READ_CORRECTION, PMC_WRITE_CORRECTION = 2.0, 1.0
@@ -68,10 +76,12 @@ def make_workload(args, first, n):
         circ, ids = synth.arith_pedersen_circuit(args.gates, args.pedersen)
         values = synth.witness_batch(n, seed=0xAC1D0006, first_instance=first)
         name = f"{args.gates}-gate arithmetic + {args.pedersen} Pedersen ACIR"
-    elif args.workload == "mixed":
+    elif args.workload in ("mixed", "config5"):
         circ, ids = synth.mixed_circuit(args.gates)
         values = synth.witness_batch(n, seed=0xAC1D0005, first_instance=first)
         name = f"{args.gates}-opcode mixed ACIR (config-5 mix: arithmetic, range/logic, directives, memory, Brillig, hashes, Pedersen)"
+        if args.workload == "config5":
+            name += "; a step = solve + per-instance map digest of every tile"
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     return circ, ids, values, name
@@ -143,7 +153,7 @@ def measure_traffic(args, kernel_substr):
     WRITE_SIZE separately, kernel-trace only) over a one-tile run of this script. None if rocprofv3 is missing or fails."""
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        tot, n = pick(pmc_pass(args, counter), [kernel_substr])
+        tot, n = pick(pmc_pass(args, counter), kernel_substr)
         if not n:
             return None
         out[counter] = (tot / n, n)
@@ -155,8 +165,8 @@ def measure_traffic(args, kernel_substr):
 
 
 # kernels of the integer-bound record classes (judged against an ALU roofline, not HBM)
-ALU_KERNELS = {"grumpkin_level_kernel": ["record_level_kernel<acvm::GrumpkinOp", "pedersen_quad_level_kernel", "record_level_kernel<acvm::EcdsaOp"],
-               "hash_level_kernel": ["record_level_kernel<acvm::HashOp"], "brillig_level_kernel": ["record_level_kernel<acvm::BrilligOp"]}
+ALU_KERNELS = {"grumpkin_level_kernel": KERNEL_SYMBOL["grumpkin_level_kernel"], "hash_level_kernel": KERNEL_SYMBOL["hash_level_kernel"],
+               "brillig_level_kernel": KERNEL_SYMBOL["brillig_level_kernel"]}
 
 
 def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
@@ -179,22 +189,229 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
                           "(acvm_debug_modmul_rate: 8 interleaved chains per SIMD); peak = that probe's measured modmul/s in this run"}
 
 
+class ClockSampler:
+    """shader clock (MHz) while the timed region runs: rocm-smi polled from a thread; median of the samples, or None"""
+
+    def __init__(self, device):
+        import shutil
+        import threading
+        self.samples, self.stop, self.device = [], False, device
+        self.th = threading.Thread(target=self._run, daemon=True) if shutil.which("rocm-smi") and not os.environ.get("ACVM_BENCH_NO_PMC") else None
+
+    def _run(self):
+        import re
+        while not self.stop:
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+                if m:
+                    self.samples.append(int(m.group(1)))
+            except (OSError, subprocess.SubprocessError):
+                return
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.th:
+            self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        if self.th:
+            self.th.join(timeout=15)
+        return False
+
+    def median(self):
+        s = sorted(self.samples)
+        return s[len(s) // 2] if s else None
+
+
+def cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_digests):
+    """The CPU oracle (a port of the reference's in-order solver, oracle/) on a bounded sample of tile 0: the parity check of the run
+    (results, assigned sets, every witness, digests) and the cpu_baseline of the line -- median of three timed runs per variant."""
+    import numpy as np
+    from oracle import binding as ob
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    per = {"arith": 96, "hash": 1024, "grumpkin": 256, "arith_pedersen": 48, "mixed": 32, "config5": 1}[args.workload]  # about a second of all host cores
+    sample = args.cpu_sample or min(tile, max(threads if args.workload == "config5" else 64, per * threads))
+    sh.load_tile(0)
+    batch.solve()
+    results0 = batch.results()
+    oc = ob.Circuit(data)
+    sample_vals = values[: sample * row]
+    runs = []
+    for rep in range(3 if args.workload != "config5" else 1):
+        c0 = time.perf_counter()
+        ores, oasg, ovals = ob.solve_batch(oc, ids, sample_vals, sample, want_witness=True, n_threads=threads, mode=ob.MODE_CACHE_INV)
+        runs.append(time.perf_counter() - c0)
+    cpu_s = sorted(runs)[len(runs) // 2]
+    if args.workload == "config5":  # full maps of a 10^6-opcode circuit: compare through the digests and the return witnesses
+        dig = batch.digest(0, sample)
+        ok = all(results0[j].as_tuple() == ores[j].as_tuple() for j in range(sample))
+        ok = ok and all(bytes(dig[j]) == ob.witness_map_digest(oasg[j], ovals[j]) for j in range(min(sample, 4)))
+        n_dig = min(sample, 4)
+    else:
+        gasg, gvals = batch.witness_map(0, sample)
+        ok = all(results0[j].as_tuple() == ores[j].as_tuple() for j in range(sample))
+        ok = ok and bool(np.array_equal(gasg, oasg[:, : gasg.shape[1]])) and bool(np.array_equal(gvals, ovals[:, : gvals.shape[1]]))
+        n_dig = min(sample, 16) if inst_digests is not None else 0
+        if n_dig:  # the digests that feed the digest of digests, against hashlib over the oracle's maps
+            ok = ok and all(bytes(inst_digests[j]) == ob.witness_map_digest(oasg[j], ovals[j]) for j in range(n_dig))
+    parity = {"checked_instances": sample, "bit_exact": bool(ok), "digests_checked": n_dig}
+    cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "kind": "port", "variant": "cpu_ref_dense_mt",
+           "runs_s": [round(x, 3) for x in runs],
+           "sample": f"{sample} instances of the same circuit, oracle/ (gcc -O3 -march=native; dense witness vector, constant divisors inverted once), "
+                     f"{threads} threads, median of {len(runs)} runs: {cpu_s:.2f} s"}
+    if args.workload != "config5":  # BASELINE.md section 2: the two single-core variants, about a second each, median of three
+        one = max(1, min(sample, int(round(1.0 * sample / (cpu_s * threads)))))
+        t1 = []
+        for rep in range(3):
+            c1 = time.perf_counter()
+            ob.solve_batch(oc, ids, values[: one * row], one, want_witness=False, n_threads=1, mode=ob.MODE_CACHE_INV)
+            t1.append(time.perf_counter() - c1)
+        one_s = sorted(t1)[1]
+        cpu["cpu_ref_dense"] = {"value": one / one_s, "unit": "witnesses/s", "cores": 1, "sample": f"{one} instances, median of 3 runs: {one_s:.2f} s"}
+        few = max(1, one // 6)
+        t2 = []
+        for rep in range(3):
+            c2 = time.perf_counter()
+            ob.solve_batch(oc, ids, values[: few * row], few, want_witness=False, n_threads=1, mode=ob.MODE_SPARSE_MAP)
+            t2.append(time.perf_counter() - c2)
+        few_s = sorted(t2)[1]
+        cpu["cpu_ref_faithful"] = {"value": few / few_s, "unit": "witnesses/s", "cores": 1,
+                                   "sample": f"{few} instances, median of 3 runs: {few_s:.2f} s; BTreeMap-shaped witness map, one field inversion per solved witness (the reference's data structures)"}
+    return cpu, parity
+
+
+def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
+    """`roofline` (+ `alu_roofline`) of the dominant kernel of the last profiled tile: algorithmic bytes of its launches / their HIP-event
+    durations against the HBM peak; HBM traffic, VALU issue fraction and the ALU roofline from in-run PMC passes (N = 1 only)."""
+    import acvm_amd
+    arith_ms, dyn_ms, cls_ms = st["arith_kernel_ms"], st["dyn_kernel_ms"], list(st["class_kernel_ms"])
+    cand = {"arith_level_kernel": (arith_ms, st["arith_algorithmic_bytes_per_instance"], st["n_arith_launches"]),
+            "inverse_batch_kernel": (dyn_ms, st["dyn_algorithmic_bytes_per_instance"], 0)}
+    for k in range(4):
+        cand[CLASS_KERNEL[k]] = (cls_ms[k], st["class_algorithmic_bytes_per_instance"][k], 0)
+    dominant = "arith_level_kernel" if args.workload in ("arith", "config5") else max(cand, key=lambda k: cand[k][0])
+    k_ms, k_bytes, k_launches = cand[dominant]
+    if dominant in ALU_KERNELS and st["solve_device_ms"] > 0 and k_ms > st["solve_device_ms"]:
+        # the lanes of the class (Pedersen | FixedBase, Schnorr, ECDSA) ran side by side: their HIP-event durations overlap and add up to more
+        # than the solve; the class was busy for the solve's device time
+        k_ms = st["solve_device_ms"]
+    achieved = k_bytes * tile / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": dominant, "kernel_ms_per_tile": k_ms, "algorithmic_bytes_per_tile": k_bytes * tile,
+            "kernel_timing": "HIP events around every launch of the last tile of the last timed step (on the launching stream)",
+            "launches_per_tile_all_kernels": st["n_kernel_launches"],
+            "other_kernels_ms_per_tile": {k: v[0] for k, v in cand.items() if k != dominant and v[0] > 0}}
+    if k_launches:
+        roof["kernel_launches_per_tile"] = k_launches
+        roof["kernel_avg_launch_ms"] = k_ms / k_launches
+        roof["algorithmic_bytes_per_launch"] = k_bytes * tile / k_launches
+    alu = None
+    if world == 1 and pmc:
+        tr = measure_traffic(args, KERNEL_SYMBOL.get(dominant, [dominant]))
+        if tr:
+            roof["traffic"] = tr["bytes_per_launch"]
+            roof["traffic_detail"] = tr
+        if dominant == "arith_level_kernel" and k_launches:
+            # share of the VALU issue slots the gate kernel fills: its VALU wave instructions (PMC, own pass) x 4 cycles (a wave64 instruction
+            # on a 16-lane SIMD) / (SIMDs x launch time x the shader clock sampled while the kernel ran)
+            v, n = pick(pmc_pass(args, "SQ_INSTS_VALU"), KERNEL_SYMBOL[dominant]) if sclk_mhz else (0, 0)
+            if n and sclk_mhz:
+                n_simd = 4 * acvm_amd.modmul_probe_cus()
+                roof["valu_issue_frac"] = (v / n) * 4.0 / (n_simd * (k_ms / k_launches / 1e3) * sclk_mhz * 1e6)
+                roof["valu_issue_detail"] = {"valu_wave_insts_per_launch": v / n, "sclk_mhz_under_load": sclk_mhz, "simds": n_simd,
+                                             "definition": "SQ_INSTS_VALU per launch x 4 cycles / (SIMDs x launch seconds x sclk)"}
+        if dominant in ALU_KERNELS:
+            peak, probe_n = acvm_amd.modmul_rate(400, 8)
+            alu = measure_alu(args, dominant, k_ms, peak, 8 * 100 * 2 * 256 * acvm_amd.modmul_probe_cus()) or {"bound": "valu", "unit": "modmul/s", "peak": peak, "achieved": None, "frac": None}
+            roof["note"] = "integer-ALU bound class: the HBM fraction is for information, see alu_roofline"
+    return roof, alu
+
+
+def run_leg(name, steps=3, warmup=2, pmc=True):
+    """one of the other workloads as a short leg of the default run (N = 1): 2^16 instances, one tile, parity-checked"""
+    import acvm_amd
+    from acvm_amd import tiling
+    a = argparse.Namespace(workload=name, gates=10000, pedersen=8, cpu_sample={"hash": 4096, "grumpkin": 512, "arith_pedersen": 256}.get(name, 0), eff_tile_log2=16)
+    n = 1 << 16
+    circ, ids, values, wname = make_workload(a, 0, n)
+    data = circ.to_bytes()
+    gc = acvm_amd.Circuit(data)
+    sh = tiling.ResidentShard(gc, ids, values, n, n)
+    batch = sh.batch
+    batch.set_profiling(True)
+    sh.load_tile(0)
+    for _ in range(warmup):
+        batch.reset()
+        batch.solve()
+    batch.set_profiling(False)
+    acvm_amd.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i == steps - 1:
+            batch.set_profiling(True)
+        batch.reset()
+        batch.solve()
+    acvm_amd.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = batch.stats()
+    batch.set_profiling(False)
+    roof, alu = roofline_block(a, st, n, 1, None, pmc=pmc)
+    cpu, parity = cpu_baseline_and_parity(a, data, ids, values, batch, sh, n, len(ids) * 32, None)
+    sh.free()
+    out = {"workload": wname, "value": n * steps / elapsed, "unit": "witnesses/s", "instances": n, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "device_ms_last_step": st["solve_device_ms"], "levels": st["n_levels"], "launches": st["n_kernel_launches"], "roofline": roof, "alu_roofline": alu,
+           "cpu_baseline": {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}, "parity": parity}
+    return out
+
+
+def end_to_end_node(gc, ids, values, total, tile, n_dev_rank):
+    """PCIe-inclusive rate through the node-level driver (acvm_node_solve: host buffers in, results + return witnesses + digests out):
+    pinned double-buffered uploads beside the solves, the exact path of a tile beside the next one"""
+    import acvm_amd
+    ret = gc.witness_set("return_values")
+    node = acvm_amd.Node(gc, ids, keep=ret, devices=[acvm_amd.current_device()], tile=tile)
+    node.solve(values[: tile * len(ids) * 32], tile, results=False)  # warm-up: staging buffers touched, tables built
+    best = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        not_solved, _, kept, asg, dig = node.solve(values, total, results=False)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, node.stats(), not_solved)
+    node.free()
+    dt, st, not_solved = best
+    return {"value": total / dt, "unit": "witnesses/s", "total_ms": dt * 1e3, "solve_device_ms": st["solve_device_ms"], "h2d_exposed_ms": st["h2d_wait_ms"],
+            "export_ms": st["export_ms"], "exact_path_instances": st["exact_instances"], "not_solved": not_solved, "input_bytes_per_witness": len(ids) * 32,
+            "returned_per_witness": f"{len(ret)} return witness(es) x 32 B + 32 B digest",
+            "note": "acvm_node_solve on pageable host buffers over PCIe (the library's own pinned staging, uploads of tile k + 1 beside the solve of tile k, "
+                    "diverging instances re-solved beside the next tile); `value` of the line keeps inputs resident"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)  # the device reaches its clocks after about two solves (profiles/README.md)
-    ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen", "mixed"])
-    ap.add_argument("--gates", type=int, default=10000)
+    ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen", "mixed", "config5"])
+    ap.add_argument("--gates", type=int, default=None, help="opcodes of the synthetic circuit (default 10000; 1000000 for config5)")
     ap.add_argument("--pedersen", type=int, default=8)
-    ap.add_argument("--total-log2", type=int, default=None, help="global batch = 2^this (default: 20 for arith = the metric; 16 per GPU otherwise)")
-    ap.add_argument("--tile-log2", type=int, default=17, help="instances per batch handle = 2^this (10k gates x 2^17 = 42 GB of witness table; measured 2^16 / 2^17 / 2^18: 5.22 / 5.41 / 5.30 M witnesses/s)")
+    ap.add_argument("--total-log2", type=int, default=None, help="global batch = 2^this (default: 20 for arith = the metric; 14 per GPU for config5; 16 per GPU otherwise)")
+    ap.add_argument("--tile-log2", type=int, default=None, help="instances per batch handle = 2^this (default 17: 10k gates x 2^17 = 42 GB of witness table, measured 2^16 / 2^17 / 2^18: 5.22 / 5.41 / 5.30 M witnesses/s; 12 for config5)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-digest", action="store_true", help="skip the digest-of-digests pass")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other_workloads legs of the default run")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the one-tile run the PMC passes profile
     args = ap.parse_args()
+    if args.gates is None:
+        args.gates = 1000000 if args.workload == "config5" else 10000
+    if args.tile_log2 is None:
+        args.tile_log2 = 12 if args.workload == "config5" else 17
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inner:
         spawn_ranks(args.gpus)
 
@@ -213,9 +430,13 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks but {n_dev} HIP device(s) visible (set ACVM_BENCH_SHARE_GPU=1 to let ranks share a GPU in tests)")
     acvm_amd.set_device(local_rank % n_dev)
 
-    strong = args.workload == "arith" or args.total_log2 is not None
-    total = 1 << (args.total_log2 if args.total_log2 is not None else (20 if args.workload == "arith" else 16)) if strong else (1 << 16) * world
-    if total % world or (total // world) % shard.DIGEST_CHUNK:
+    config5 = args.workload == "config5"
+    strong = args.workload == "arith" or (args.total_log2 is not None and not config5)
+    if strong:
+        total = 1 << (args.total_log2 if args.total_log2 is not None else 20)
+    else:
+        total = (1 << (args.total_log2 if args.total_log2 is not None else (14 if config5 else 16))) * world
+    if total % world or ((total // world) % shard.DIGEST_CHUNK and not args.inner):
         raise SystemExit(f"bench.py: the global batch {total} must split into {world} shards that are multiples of {shard.DIGEST_CHUNK}")
     n_rank = total // world
     first = rank * n_rank
@@ -244,31 +465,34 @@ def main():
     if n_tiles == 1:
         sh.load_tile(0)
     barrier()
-    t0 = time.perf_counter()
-    arith_ms = dyn_ms = dev_ms = 0.0
-    cls_ms = [0.0] * 4
+    dev_ms = 0.0
     n_failed = 0
-    for i in range(args.steps):
-        for k in range(n_tiles):
-            # per-launch HIP events (two per launch) cost 3 % of a solve: they bracket the launches of the LAST tile of the LAST step only
-            last = i == args.steps - 1 and k == n_tiles - 1
-            if last:
-                batch.set_profiling(True)
-            if n_tiles > 1:
-                sh.load_tile(k)  # ACVM::new of the tile: import of its resident inputs into the reused table
-            else:
-                batch.reset()    # one tile holds the whole shard: its initial witnesses are in the table already
-            n_failed += batch.solve()
-            if i == args.steps - 1:
-                dev_ms += batch.stats()["solve_device_ms"]
-    acvm_amd.synchronize()
-    my_elapsed = time.perf_counter() - t0
+    digest_ms = 0.0
+    with ClockSampler(acvm_amd.current_device()) as clock:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            for k in range(n_tiles):
+                # per-launch HIP events (two per launch) cost 3 % of a solve: they bracket the launches of the LAST tile of the LAST step only
+                last = i == args.steps - 1 and k == n_tiles - 1
+                if last:
+                    batch.set_profiling(True)
+                if n_tiles > 1:
+                    sh.load_tile(k)  # ACVM::new of the tile: import of its resident inputs into the reused table
+                else:
+                    batch.reset()    # one tile holds the whole shard: its initial witnesses are in the table already
+                n_failed += batch.solve()
+                if i == args.steps - 1:
+                    dev_ms += batch.stats()["solve_device_ms"]
+                if config5:  # what config 5 keeps of a tile: the per-instance digest of the map (the return witness rides along)
+                    d0 = time.perf_counter()
+                    batch.digest(0, tile)
+                    digest_ms += (time.perf_counter() - d0) * 1e3
+        acvm_amd.synchronize()
+        my_elapsed = time.perf_counter() - t0
     barrier()
     elapsed = shard.max_over_ranks(my_elapsed, dist)
     st = batch.stats()
-    arith_ms, dyn_ms, cls_ms = st["arith_kernel_ms"], st["dyn_kernel_ms"], list(st["class_kernel_ms"])
     batch.set_profiling(False)
-    results = batch.results()  # of the last tile
     rank_rates = shard.gather_floats(n_rank * args.steps / my_elapsed, dist)
 
     if args.inner:  # the profiled one-tile run: nothing to report; the modmul probe runs so that the PMC passes see it
@@ -278,6 +502,7 @@ def main():
 
     # ---- digest of digests: every rank hashes the witness maps of its shard (one more pass, untimed), rank 0 combines
     dod = None
+    inst_digests = None
     if not args.no_digest:
         d0 = time.perf_counter()
         inst_digests = sh.digests()
@@ -289,127 +514,45 @@ def main():
                "definition": "Blake2s-256 over the chunk digests in global instance order; chunk digest = Blake2s-256 over the acvm_batch_digest "
                              "values of its instances: the same value for every number of ranks and every tile size"}
 
-    # ---- end to end: H2D of the inputs + import + solve + D2H of the return witnesses, tile by tile from host memory (per rank)
+    # ---- end to end through the node-level driver, per rank on its own device (host buffers in, results out)
     e2e = None
     if not args.no_end_to_end:
-        ret = gc.witness_set("return_values")
-        host = np.frombuffer(values, dtype=np.uint8)
-        ph = [0.0, 0.0, 0.0]
-        import threading
-        dev = acvm_amd.current_device()
-
-        def upload(k):  # pageable host memory -> the tile's slice of the resident buffer (hipMemcpy releases the GIL through ctypes)
-            acvm_amd.set_device(dev)  # HIP's current device is per thread
-            first = sh.starts[k]
-            sh.buf.upload(host[first * row:(first + tile) * row], offset=first * row)
-
+        sh.free()  # the node driver allocates its own handle: give the table back first
+        sh = None
         barrier()
-        e0 = time.perf_counter()
-        a = time.perf_counter()
-        upload(0)
-        ph[0] += time.perf_counter() - a
-        for k, start in enumerate(sh.starts):
-            nxt = None
-            if k + 1 < len(sh.starts):  # the upload of tile k + 1 runs beside the solve of tile k (acvm_amd/tiling.py solve_tiled does the same)
-                nxt = threading.Thread(target=upload, args=(k + 1,))
-                nxt.start()
-            b_ = time.perf_counter()
-            sh.load_tile(k)
-            n_bad = batch.solve()
-            c = time.perf_counter()
-            if ret:
-                # extract_indices refuses unsolved instances: the edge-case instances of the synthetic batch fail by design
-                if n_bad == 0:
-                    batch.extract(ret, 0, tile)
-                else:
-                    batch.witness(ret[-1])
-            d = time.perf_counter()
-            if nxt is not None:
-                nxt.join()
-            ph[0] += time.perf_counter() - d  # what of the next upload the solve did not cover
-            ph[1] += c - b_
-            ph[2] += d - c
-        e2e_s = shard.max_over_ranks(time.perf_counter() - e0, dist)
-        e2e = {"value": total / e2e_s, "unit": "witnesses/s", "total_ms": e2e_s * 1e3, "h2d_exposed_ms_rank0": ph[0] * 1e3, "solve_ms_rank0": ph[1] * 1e3,
-               "d2h_return_ms_rank0": ph[2] * 1e3, "input_bytes_per_witness": row, "return_witnesses": len(ret),
-               "note": "pageable host buffers over PCIe, tile by tile; the upload of tile k + 1 runs beside the solve of tile k (first upload and "
-                       "every D2H exposed); `value` of the line keeps inputs resident"}
+        mine = end_to_end_node(gc, ids, values, n_rank, tile, n_dev)
+        e2e_s = shard.max_over_ranks(mine["total_ms"] / 1e3, dist)
+        e2e = dict(mine, value=total / e2e_s, total_ms=e2e_s * 1e3)
+        sh = tiling.ResidentShard(gc, ids, values, n_rank, tile)
+        batch = sh.batch
 
     # ---- CPU baseline + parity on a bounded sample of tile 0 (rank 0 only)
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is an N = 1 figure (rank 0 would keep the other ranks waiting)
-        from oracle import binding as ob
-        cores = os.cpu_count() or 1
-        threads = min(cores, 64)
-        per = {"arith": 96, "hash": 1024, "grumpkin": 256, "arith_pedersen": 48, "mixed": 32}[args.workload]  # a few seconds of all host cores
-        sample = args.cpu_sample or min(tile, max(64, per * threads))
-        sh.load_tile(0)
-        batch.solve()
-        results0 = batch.results()
-        oc = ob.Circuit(data)
-        sample_vals = values[: sample * row]
-        c0 = time.perf_counter()
-        ores, oasg, ovals = ob.solve_batch(oc, ids, sample_vals, sample, want_witness=True, n_threads=threads, mode=ob.MODE_CACHE_INV)
-        cpu_s = time.perf_counter() - c0
-        gasg, gvals = batch.witness_map(0, sample)
-        ok = all(results0[j].as_tuple() == ores[j].as_tuple() for j in range(sample))
-        ok = ok and bool(np.array_equal(gasg, oasg[:, : gasg.shape[1]])) and bool(np.array_equal(gvals, ovals[:, : gvals.shape[1]]))
-        n_dig = min(sample, 16)
-        if not args.no_digest:  # the digests that feed the digest of digests, against hashlib over the oracle's maps
-            ok = ok and all(bytes(inst_digests[j]) == ob.witness_map_digest(oasg[j], ovals[j]) for j in range(n_dig))
-        parity = {"checked_instances": sample, "bit_exact": ok, "digests_checked": 0 if args.no_digest else n_dig}
-        cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "kind": "port", "variant": "cpu_ref_dense_mt",
-               "sample": f"{sample} instances of the same circuit, oracle/liboracle.so (dense witness vector, constant divisors inverted once), "
-                         f"{threads} threads, {cpu_s:.2f} s"}
-        # the two single-core variants, a few seconds each
-        one = max(1, min(sample, int(round(3.0 * sample / (cpu_s * threads)))))
-        c1 = time.perf_counter()
-        ob.solve_batch(oc, ids, values[: one * row], one, want_witness=False, n_threads=1, mode=ob.MODE_CACHE_INV)
-        one_s = time.perf_counter() - c1
-        cpu["cpu_ref_dense"] = {"value": one / one_s, "unit": "witnesses/s", "cores": 1, "sample": f"{one} instances, {one_s:.2f} s"}
-        few = max(1, one // 6)
-        c2 = time.perf_counter()
-        ob.solve_batch(oc, ids, values[: few * row], few, want_witness=False, n_threads=1, mode=ob.MODE_SPARSE_MAP)
-        few_s = time.perf_counter() - c2
-        cpu["cpu_ref_faithful"] = {"value": few / few_s, "unit": "witnesses/s", "cores": 1,
-                                   "sample": f"{few} instances, {few_s:.2f} s; BTreeMap-shaped witness map, one field inversion per solved witness (the reference's data structures)"}
-        if not ok:
+        cpu, parity = cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_digests)
+        if not parity["bit_exact"]:
             print(json.dumps({"error": "parity check failed; the measurement is void", "parity": parity}), flush=True)
             raise SystemExit(2)
+    sh.free()
 
     if rank == 0:
         value = total * args.steps / elapsed
-        # dominant kernel of the workload: the arithmetic level kernel, or the record class that took the most time
-        cand = {"arith_level_kernel": (arith_ms, st["arith_algorithmic_bytes_per_instance"], st["n_arith_launches"]),
-                "inverse_batch_kernel": (dyn_ms, st["dyn_algorithmic_bytes_per_instance"], 0)}
-        for k in range(4):
-            cand[CLASS_KERNEL[k]] = (cls_ms[k], st["class_algorithmic_bytes_per_instance"][k], 0)
-        dominant = "arith_level_kernel" if args.workload == "arith" else max(cand, key=lambda k: cand[k][0])
-        k_ms, k_bytes, k_launches = cand[dominant]
-        if dominant in ALU_KERNELS and st["solve_device_ms"] > 0 and k_ms > st["solve_device_ms"]:
-            # the lanes of the class (Pedersen | FixedBase, Schnorr, ECDSA) ran side by side: their HIP-event durations overlap and add up to more
-            # than the solve; the class was busy for the solve's device time
-            k_ms = st["solve_device_ms"]
-        achieved = k_bytes * tile / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": dominant, "kernel_ms_per_tile": k_ms, "algorithmic_bytes_per_tile": k_bytes * tile,
-                "kernel_timing": f"HIP events around every launch of the last tile of timed step {args.steps} of {args.steps} (on the launching stream)",
-                "launches_per_tile_all_kernels": st["n_kernel_launches"],
-                "other_kernels_ms_per_tile": {k: v[0] for k, v in cand.items() if k != dominant and v[0] > 0}}
-        if k_launches:
-            roof["kernel_launches_per_tile"] = k_launches
-            roof["kernel_avg_launch_ms"] = k_ms / k_launches
-            roof["algorithmic_bytes_per_launch"] = k_bytes * tile / k_launches
-        if world == 1:
-            tr = measure_traffic(args, KERNEL_SYMBOL.get(dominant, dominant))
-            if tr:
-                roof["traffic"] = tr["bytes_per_launch"]
-                roof["traffic_detail"] = tr
-        alu = None
-        if world == 1 and dominant in ALU_KERNELS:
-            peak, probe_n = acvm_amd.modmul_rate(400, 8)
-            alu = measure_alu(args, dominant, k_ms, peak, 8 * 100 * 2 * 256 * acvm_amd.modmul_probe_cus()) or {"bound": "valu", "unit": "modmul/s", "peak": peak, "achieved": None, "frac": None}
-            roof["note"] = "integer-ALU bound class: the HBM fraction is for information, see alu_roofline"
+        roof, alu = roofline_block(args, st, tile, world, clock.median())
+        if world == 1 and not os.environ.get("ACVM_BENCH_NO_PMC"):
+            try:
+                roof["peak_measured_copy"] = acvm_amd.stream_rate(4 << 30)
+                roof["peak_measured_copy_note"] = "GB/s read + written of a nontemporal 16-B-per-lane copy of 4 GiB on this device in this run: what streaming code reaches of the 8 TB/s spec peak"
+                roof["frac_of_measured_copy"] = roof["achieved"] / roof["peak_measured_copy"]
+            except acvm_amd.AcvmError:
+                pass
+        legs = None
+        if world == 1 and args.workload == "arith" and not args.no_legs and not args.no_cpu_baseline:
+            legs = {}
+            for name in ("arith_pedersen", "hash", "grumpkin"):
+                try:
+                    legs[name] = run_leg(name)
+                except (acvm_amd.AcvmError, OSError, ValueError) as e:  # a leg must not void the metric's line
+                    legs[name] = {"error": str(e)[:300]}
         line = {
             "metric": "witnesses solved/sec (whole node)",
             "value": value,
@@ -426,7 +569,7 @@ def main():
             "config": {"workload": f"{workload_name}, batch 2^{total.bit_length() - 1} witnesses over {world} GPU(s)", "opcodes": st["n_opcodes"],
                        "global_batch": total, "instances_per_gpu": n_rank, "tile_instances": tile, "tiles_per_gpu_per_step": n_tiles, "levels": st["n_levels"],
                        "not_solved_rank0_all_steps": n_failed, "slow_path_instances_last_tile": st["n_slow_instances"],
-                       "algorithmic_bytes_per_witness": st["algorithmic_bytes_per_instance"],
+                       "algorithmic_bytes_per_witness": st["algorithmic_bytes_per_instance"], "brillig_opcodes_inlined": st["n_brillig_inlined"],
                        "device_ms_per_step_rank0": dev_ms, "inputs_resident_setup_s_rank0": round(h2d_resident_s, 3),
                        "parallelism": f"instances sharded x{world}, no collectives"},
             "per_rank_witnesses_per_s": rank_rates,
@@ -437,8 +580,11 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
         }
+        if config5:
+            line["config"]["digest_ms_per_step_rank0"] = digest_ms / args.steps
+        if legs is not None:
+            line["other_workloads"] = legs
         print(json.dumps(line), flush=True)
-    sh.free()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -180,6 +180,9 @@ int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, u
  * kernel uses) on every SIMD, waves_per_simd dependent chains of 2 * iters products interleaved per SIMD; the best of three timed
  * launches as modmul/s, and the number of products one launch executes. */
 int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modmul_per_s, uint64_t *n_modmul);
+/* The measured streaming ceiling of the device for the witness table's access shape (reported beside the 8 TB/s spec peak of the HBM
+ * roofline): a nontemporal 16-byte-per-lane copy of `bytes` bytes, read + written bytes per second of the best of three launches. */
+int acvm_debug_stream_rate(size_t bytes, double *read_plus_write_gb_per_s);
 
 /* Circuit::read: gzip(bincode) or raw bincode bytes. */
 acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);

@@ -1,4 +1,4 @@
-"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+"""ctypes binding of the CPU oracle (oracle/liboracle-<cpu tag>.so) -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
 package (acvm_amd) never does.
@@ -8,7 +8,21 @@ import os
 import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_DIR, "liboracle.so")
+
+
+def _cpu_tag():
+    """the library is built -march=native (oracle/Makefile): one file per kind of host CPU"""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((line for line in f if line.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return hashlib.sha1(" ".join(sorted(flags.split(":")[-1].split())).encode()).hexdigest()[:10]
+
+
+_LIB_NAME = f"liboracle-{_cpu_tag()}.so"
+_LIB_PATH = os.path.join(_DIR, _LIB_NAME)
 
 ST_SOLVED, ST_IN_PROGRESS, ST_FAILURE, ST_REQUIRES_FOREIGN_CALL = 0, 1, 2, 3
 (E_NONE, E_MISSING_ASSIGNMENT, E_TOO_MANY_UNKNOWNS, E_UNSUPPORTED_BLACKBOX, E_UNSATISFIED, E_INDEX_OOB,
@@ -28,7 +42,7 @@ class Result(C.Structure):
 def build(force=False):
     srcs = [os.path.join(_DIR, f) for f in os.listdir(_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
     if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-C", _DIR, "-s", "liboracle.so"])
+        subprocess.check_call(["make", "-C", _DIR, "-s", f"OUT={_LIB_NAME}", _LIB_NAME])
     return _LIB_PATH
 
 

@@ -384,7 +384,8 @@ class tuning:
 
 
 def stream_rate(nbytes=4 << 30):
-    """GB/s (read + written) of a nontemporal copy of nbytes: the measured streaming ceiling beside the spec peak of the HBM roofline"""
+    """GB/s moved by a two-rows-in, one-row-out stream of nbytes per row (the gate kernel's access shape): the measured streaming ceiling
+    beside the spec peak of the HBM roofline"""
     r = C.c_double()
     _check(lib().acvm_debug_stream_rate(nbytes, C.byref(r)))
     return r.value

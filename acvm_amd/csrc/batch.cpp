@@ -148,25 +148,25 @@ int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modm
     return 0;
 }
 
-// The measured streaming ceiling beside the spec peak of the HBM roofline: a nontemporal copy of `bytes` (read + written), best of three.
-int acvm_debug_stream_rate(size_t bytes, double *read_plus_write_gb_per_s) {
-    if (!read_plus_write_gb_per_s || bytes < (1u << 20)) return set_err(ACVM_E_INVALID, "bad argument");
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, dev));
-    const uint64_t n = bytes / 16;
-    uint4 *src = nullptr, *dst = nullptr;
-    HIPCHK(hipMalloc((void **)&src, n * 16));
-    if (hipMalloc((void **)&dst, n * 16) != hipSuccess) { hipFree(src); return set_err(ACVM_E_DEVICE, "hipMalloc failed"); }
-    HIPCHK(hipMemset(src, 1, n * 16));
+// The measured streaming ceiling beside the spec peak of the HBM roofline: two rows of `bytes` read and one written by a kernel with the
+// gate kernel's access shape (kernels.hip stream_rate_kernel), best of four; bytes moved = 3 x bytes.
+int acvm_debug_stream_rate(size_t bytes, double *gb_per_s) {
+    if (!gb_per_s || bytes < (1u << 20)) return set_err(ACVM_E_INVALID, "bad argument");
+    const uint64_t n = bytes / 16 / 256 * 256;
+    uint4 *buf[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; k++)
+        if (hipMalloc((void **)&buf[k], n * 16) != hipSuccess) {
+            for (int q = 0; q < k; q++) hipFree(buf[q]);
+            return set_err(ACVM_E_DEVICE, "hipMalloc failed");
+        }
+    for (int k = 0; k < 3; k++) HIPCHK(hipMemset(buf[k], k + 1, n * 16));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     float best = 1e30f;
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 5; r++) {
         hipEventRecord(e0, nullptr);
-        launch_stream_rate(nullptr, src, dst, n, (uint32_t)prop.multiProcessorCount * 16);
+        launch_stream_rate(nullptr, buf[0], buf[1], buf[2], n);
         hipEventRecord(e1, nullptr);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -175,10 +175,9 @@ int acvm_debug_stream_rate(size_t bytes, double *read_plus_write_gb_per_s) {
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
-    hipFree(src);
-    hipFree(dst);
+    for (int k = 0; k < 3; k++) hipFree(buf[k]);
     HIPCHK(hipGetLastError());
-    *read_plus_write_gb_per_s = 2.0 * (double)(n * 16) / (best * 1e-3) / 1e9;
+    *gb_per_s = 3.0 * (double)(n * 16) / (best * 1e-3) / 1e9;
     return 0;
 }
 
@@ -266,6 +265,41 @@ int acvm_circuit_plan_stats_ex(const acvm_circuit_t *c, const uint32_t *initial_
     if (!p.unsupported.empty()) return set_err(ACVM_E_UNSUPPORTED, p.unsupported);
     return 0;
 } ABI_CATCH
+
+// The two fixed field elements of the witness-map digest (include/acvm_amd.h acvm_batch_digest): Blake2s-256 of the ASCII strings
+// "acvm_amd witness map digest: g" / "... h", read as big-endian integers and reduced modulo p.
+static const uint8_t DIGEST_G[32] = {0x23, 0x35, 0x53, 0x18, 0xdb, 0xff, 0xab, 0x2f, 0xb7, 0x72, 0x11, 0x7c, 0x57, 0x5c, 0x61, 0xb1,
+                                     0x79, 0xf8, 0xc9, 0x83, 0x3c, 0x83, 0xba, 0x65, 0x59, 0x7e, 0x17, 0x3c, 0x35, 0xc4, 0xbb, 0xe3};
+static const uint8_t DIGEST_H[32] = {0x28, 0x25, 0x78, 0x33, 0xe7, 0x23, 0x7f, 0xbd, 0x29, 0x7c, 0x55, 0x74, 0x6b, 0xe0, 0xa3, 0xa9,
+                                     0x8a, 0x2a, 0x89, 0x8d, 0x8a, 0xb1, 0x0b, 0xe0, 0x05, 0xaa, 0x2f, 0xdf, 0x9c, 0x60, 0x11, 0xa4};
+// device tables of the digest: g^(w+1), g^(w+1) / scale_w for the scaled witnesses, h^(w+1), and the h-sum of the planner's assigned set
+static int ensure_digest_tables(acvm_batch *b) {
+    if (b->d_fp_g) return 0;
+    const Plan &p = b->plan;
+    const uint32_t nw = p.n_witnesses;
+    const FrH g = frh::from_be_bytes32_reduce(DIGEST_G, 32), h = frh::from_be_bytes32_reduce(DIGEST_H, 32);
+    std::vector<uint32_t> tg((size_t)std::max<uint32_t>(nw, 1) * 8), th((size_t)std::max<uint32_t>(nw, 1) * 8), tgs(std::max<size_t>(p.unscale.size(), 1) * 8), hgen(8);
+    FrH gp = g, hp = h, hsum = frh::zero();
+    auto put = [](std::vector<uint32_t> &v, size_t i, const FrH &x) {
+        const FrH d = frh::to_device_form(x);
+        memcpy(&v[8 * i], d.l, 32);
+    };
+    for (uint32_t w = 0; w < nw; w++) {
+        put(tg, w, gp);
+        put(th, w, hp);
+        if (p.unscale_index[w] != 0xFFFFFFFFu) put(tgs, p.unscale_index[w], frh::mul(gp, p.unscale[p.unscale_index[w]]));
+        if (p.producer[w] != 0xFFFFFFFFu) hsum = frh::add(hsum, hp);
+        gp = frh::mul(gp, g);
+        hp = frh::mul(hp, h);
+    }
+    put(hgen, 0, hsum);
+    if (int rc = upload(&b->d_fp_g, tg)) return rc;
+    if (int rc = upload(&b->d_fp_h, th)) return rc;
+    if (int rc = upload(&b->d_fp_gs, tgs)) return rc;
+    if (int rc = upload(&b->d_fp_hgen, hgen)) return rc;
+    b->fp = DigestTables{b->d_fp_g, b->d_fp_gs, b->d_fp_h, b->d_fp_hgen};
+    return 0;
+}
 
 static int batch_init(acvm_batch *b) {
     HIPCHK(hipGetDevice(&b->device));
@@ -412,7 +446,10 @@ static int batch_init(acvm_batch *b) {
         for (uint32_t oi = 0; oi < p.n_opcodes; oi++)
             if (p.prog[p.prog_offset[oi]] == PK_BRILLIG) b->br_max_regs = std::max(b->br_max_regs, p.prog[p.prog_offset[oi] + 7]);
     }
-    if (p.n_digest_segments) HIPCHK(hipMalloc((void **)&b->d_leaves, (size_t)8 * b->Bp * 4));
+    if (p.n_digest_segments) {
+        HIPCHK(hipMalloc((void **)&b->d_leaves, (size_t)p.n_digest_segments * 2 * b->Bp * sizeof(uint4)));
+        if (int rc = ensure_digest_tables(b)) return rc;
+    }
     if (!p.slot_of.empty()) {
         if (int rc = upload(&b->d_slot_of, p.slot_of)) return rc;
         b->dp.slot_of = b->d_slot_of;
@@ -1050,7 +1087,6 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     };
     const bool prof = tm != nullptr;
     launch_event_reset(s, b->d_event, b->B);
-    if (b->d_leaves) launch_fill_u32(s, b->d_leaves, 0u, 8 * b->Bp);  // the folded digest sums its leaves into this
     // Per level the constant-coefficient gates and the other record classes (stream s) and the gates that need a
     // per-instance inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of
     // either stream waits for level L of both.
@@ -1170,7 +1206,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 case CLS_BRILLIG: launch_brillig_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
                 case CLS_PEDERSEN: launch_pedersen_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
                 case CLS_ECDSA: launch_ecdsa_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                case CLS_DIGEST: launch_digest_fold_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_unscale_plain, b->d_leaves); break;
+                case CLS_DIGEST: launch_digest_fold_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->fp, b->d_leaves); break;
                 case CLS_HOSTBB:  // host callbacks: everything launched so far on any stream must have finished
                     if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
                     for (int q = 0; q < N_HEAVY_LANES; q++)
@@ -1400,6 +1436,31 @@ int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_kee
     return 1;
 }
 
+// digests of lanes [first, first + n) of a witness table into host memory out32 ([n][32]), staged through the arena on stream s:
+// arena = (slow_index) | partial sums | digests. The per-instance lane of `assigned` comes from a device array (d_slow_index) or from the
+// batch's host vector (use_host_index: uploaded here); neither is needed when u.event is null (every lane read as an instance of the
+// level kernels).
+static int digest_range(acvm_batch *b, hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const Unscale &u, const int32_t *d_slow_index,
+                        bool use_host_index, uint32_t n_slow, uint8_t *out32) {
+    const Plan &p = b->plan;
+    if (!n) return 0;
+    if (int rc = ensure_digest_tables(b)) return rc;
+    const size_t idx_bytes = use_host_index ? align256((size_t)b->B * 4) : 0;
+    const size_t part_bytes = align256((size_t)digest_chunks(p.n_witnesses) * n * 32);
+    if (int rc = stage_reserve(b, idx_bytes + part_bytes + (size_t)n * 32)) return rc;
+    if (use_host_index) {
+        HIPCHK(hipMemcpyAsync(b->d_stage, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice, s));
+        d_slow_index = (const int32_t *)b->d_stage;
+    }
+    uint4 *d_part = (uint4 *)(b->d_stage + idx_bytes);
+    uint8_t *d_out = b->d_stage + idx_bytes + part_bytes;
+    launch_digest(s, W, Bp, first, n, p.n_witnesses, b->d_producer, u, b->fp, d_slow_index, b->d_assigned, n_slow, d_part, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out32, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
 // results, kept witnesses and digests of the lanes of the side table (all of them at once)
 static int side_table_outcome(acvm_batch *b, ExactOutcome *out) {
     const Plan &p = b->plan;
@@ -1416,8 +1477,7 @@ static int side_table_outcome(acvm_batch *b, ExactOutcome *out) {
         for (uint32_t k = 0; k < r.n_call_stack; k++) r.call_stack[k] = sr.call_stack[k];
     }
     const size_t sel_bytes = align256((size_t)std::max<uint32_t>(n_keep, 1) * 4), val_bytes = align256((size_t)n_slow * std::max<uint32_t>(n_keep, 1) * 32);
-    const size_t acc_bytes = align256((size_t)32 * n_slow);
-    if (int rc = stage_reserve(b, sel_bytes + val_bytes + acc_bytes + (size_t)n_slow * 32)) return rc;
+    if (int rc = stage_reserve(b, sel_bytes + val_bytes)) return rc;
     Unscale plain = b->unscale;
     plain.event = b->d_slow_start;  // all zero: nothing in the side table is scaled
     if (n_keep) {
@@ -1440,13 +1500,8 @@ static int side_table_outcome(acvm_batch *b, ExactOutcome *out) {
             }
     }
     if (b->async_digest) {
-        uint32_t *d_acc = (uint32_t *)(b->d_stage + sel_bytes + val_bytes);
-        uint8_t *d_out = b->d_stage + sel_bytes + val_bytes + acc_bytes;
-        launch_digest(s, b->d_Wx, b->x_cap, 0, n_slow, p.n_witnesses, b->d_producer, plain, (const int32_t *)b->d_ids_x, b->d_assigned, n_slow, d_acc, d_out);
-        HIPCHK(hipGetLastError());
         out->digests.resize((size_t)n_slow * 32);
-        HIPCHK(hipMemcpyAsync(out->digests.data(), d_out, out->digests.size(), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (int rc = digest_range(b, s, b->d_Wx, b->x_cap, 0, n_slow, plain, (const int32_t *)b->d_ids_x, false, n_slow, out->digests.data())) return rc;
     }
     return 0;
 }
@@ -1500,24 +1555,15 @@ int batch_export_tile(acvm_batch *b, uint32_t n, const uint32_t *keep, uint32_t 
             // (the table-wide kernels: flagged columns hold leftovers and are overwritten by the outcome)
             if (p.n_digest_segments && b->d_leaves) {
                 if (int rc = stage_reserve(b, (size_t)n * 32)) return rc;
-                launch_digest_final(s, b->d_leaves, b->Bp, 0, n, b->d_stage);
+                launch_digest_final(s, b->d_leaves, p.n_digest_segments, b->Bp, 0, n, nullptr, b->fp, b->d_stage);
                 HIPCHK(hipMemcpyAsync(digests, b->d_stage, (size_t)n * 32, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
             } else {
-                const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)32 * n);
-                if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + (size_t)n * 32)) return rc;
-                int32_t *d_slow_index = (int32_t *)b->d_stage;
-                uint32_t *d_acc = (uint32_t *)(b->d_stage + idx_bytes);
-                uint8_t *d_out = b->d_stage + idx_bytes + leaf_bytes;
                 // every lane is read as a generic instance here: an event word that is set would send the kernel to the assigned bitmap of a
                 // job that is still running
                 Unscale u = b->unscale;
                 u.event = nullptr;
-                HIPCHK(hipMemsetAsync(d_slow_index, 0xff, (size_t)b->B * 4, s));
-                launch_digest(s, b->d_W, b->Bp, 0, n, p.n_witnesses, b->d_producer, u, d_slow_index, b->d_assigned, 0, d_acc, d_out);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(digests, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
+                if (int rc = digest_range(b, s, b->d_W, b->Bp, 0, n, u, nullptr, false, 0, digests)) return rc;
             }
         } else if (int rc = acvm_batch_digest(b, 0, n, digests)) return rc;
     }
@@ -1932,29 +1978,21 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     return 0;
 } ABI_CATCH
 
-// digests of the listed instances of the exact path from their own witness maps, one at a time (few by construction), into
+// digests of the instances of the exact path listed in `flagged` (instance indices >= first), from their own witness maps, into
 // out32[(instance - first) * 32]
-static int digest_exact_instances(acvm_batch *b, const std::vector<uint32_t> &instances, uint32_t first, uint8_t *out32) {
-    const Plan &p = b->plan;
+static int digest_exact_instances(acvm_batch *b, const std::vector<uint32_t> &flagged, uint32_t first, uint8_t *out32) {
     const uint32_t n_slow = (uint32_t)b->slow_ids.size();
-    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256(32);
-    if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + 32)) return rc;
-    int32_t *d_slow_index = (int32_t *)b->d_stage;
-    uint32_t *d_leaves = (uint32_t *)(b->d_stage + idx_bytes);
-    uint8_t *d_out = b->d_stage + idx_bytes + leaf_bytes;
-    HIPCHK(hipMemcpyAsync(d_slow_index, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice, b->stream));
-    Unscale plain = b->unscale;
-    plain.event = b->d_slow_start;  // slot reuse: all zero = "instance of the exact path" for every lane of the exact table
-    for (uint32_t j : instances) {
-        if (b->side())  // lane t of the exact table, whose lanes index themselves
-            launch_digest(b->stream, b->d_Wx, b->x_cap, (uint32_t)b->slow_index[j], 1, p.n_witnesses, b->d_producer, plain, (const int32_t *)b->d_ids_x, b->d_assigned,
-                          n_slow, d_leaves, d_out);
-        else
-        launch_digest(b->stream, b->d_W, b->Bp, j, 1, p.n_witnesses, b->d_producer, b->unscale, d_slow_index, b->d_assigned, n_slow, d_leaves, d_out);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(out32 + (size_t)(j - first) * 32, d_out, 32, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->side()) {  // all lanes of the side table at once (lane t = the t-th flagged instance), then scattered to their instances
+        Unscale plain = b->unscale;
+        plain.event = b->d_slow_start;  // all zero: every lane of the side table is "an instance of the exact path"
+        std::vector<uint8_t> lanes((size_t)n_slow * 32);
+        if (int rc = digest_range(b, b->stream, b->d_Wx, b->x_cap, 0, n_slow, plain, (const int32_t *)b->d_ids_x, false, n_slow, lanes.data())) return rc;
+        for (uint32_t j : flagged) memcpy(out32 + (size_t)(j - first) * 32, &lanes[(size_t)b->slow_index[j] * 32], 32);
+        return 0;
     }
+    // plain table: the instance's own column, one launch each (few by construction: acvm_batch_digest takes the table-wide kernel otherwise)
+    for (uint32_t j : flagged)
+        if (int rc = digest_range(b, b->stream, b->d_W, b->Bp, j, 1, b->unscale, nullptr, true, n_slow, out32 + (size_t)(j - first) * 32)) return rc;
     return 0;
 }
 
@@ -1968,55 +2006,30 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
     if (!n) return 0;
     HIPCHK(hipSetDevice(b->device));
     const Plan &p = b->plan;
+    if (int rc = ensure_digest_tables(b)) return rc;
+    std::vector<uint32_t> flagged;
+    for (uint32_t i = 0; i < n; i++)
+        if (b->slow_index[first + i] >= 0) flagged.push_back(first + i);
     if (p.n_digest_segments && b->d_leaves && !b->force_slow && !b->stepping) {
-        // folded into the solve: the leaves of the generic instances are there; only the root is left (and the instances of the
-        // exact path, whose leaves come from their own maps below)
+        // folded into the solve: the partial sums of the generic instances are there; only their total is left (and the instances of the
+        // exact path, whose sums come from their own maps below)
         if (int rc = stage_reserve(b, (size_t)n * 32)) return rc;
-        launch_digest_final(b->stream, b->d_leaves, b->Bp, first, n, b->d_stage);
+        launch_digest_final(b->stream, b->d_leaves, p.n_digest_segments, b->Bp, first, n, b->d_event, b->fp, b->d_stage);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out32, b->d_stage, (size_t)n * 32, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
-        std::vector<uint32_t> flagged;
-        for (uint32_t i = 0; i < n; i++)
-            if (b->slow_index[first + i] >= 0) flagged.push_back(first + i);
         if (flagged.empty()) return 0;
-        if (flagged.size() <= 64) return digest_exact_instances(b, flagged, first, out32);
-        // many instances of the exact path (a whole batch waiting at a foreign call, a batch of failures): one launch instead of one
-        // launch + copy + synchronisation per instance
-        if (b->side()) {  // all lanes of the exact table at once, then scattered to their instances
-            const uint32_t n_slow = (uint32_t)b->slow_ids.size();
-            const size_t leaf_bytes = align256((size_t)32 * n_slow);
-            if (int rc = stage_reserve(b, leaf_bytes + (size_t)n_slow * 32)) return rc;
-            uint32_t *d_acc = (uint32_t *)b->d_stage;
-            uint8_t *d_out = b->d_stage + leaf_bytes;
-            Unscale plain = b->unscale;
-            plain.event = b->d_slow_start;  // all zero: every lane of the exact table is "an instance of the exact path"
-            launch_digest(b->stream, b->d_Wx, b->x_cap, 0, n_slow, p.n_witnesses, b->d_producer, plain, (const int32_t *)b->d_ids_x, b->d_assigned, n_slow, d_acc, d_out);
-            HIPCHK(hipGetLastError());
-            std::vector<uint8_t> lanes((size_t)n_slow * 32);
-            HIPCHK(hipMemcpyAsync(lanes.data(), d_out, lanes.size(), hipMemcpyDeviceToHost, b->stream));
-            HIPCHK(hipStreamSynchronize(b->stream));
-            for (uint32_t j : flagged) memcpy(out32 + (size_t)(j - first) * 32, &lanes[(size_t)b->slow_index[j] * 32], 32);
-            return 0;
-        }
-        // (plain table: the table-wide kernel below serves generic and exact lanes alike through slow_index)
+        if (b->side() || flagged.size() <= 64) return digest_exact_instances(b, flagged, first, out32);
+        // (plain table with many instances of the exact path -- a whole batch waiting at a foreign call, a batch of failures: the
+        // table-wide kernel below serves generic and exact lanes alike through slow_index)
     }
-    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
-    const uint32_t slice = n;  // the scratch is the 32-byte sum of the leaves per instance
-    const size_t idx_bytes = align256((size_t)b->B * 4), leaf_bytes = align256((size_t)32 * slice);
-    if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + (size_t)slice * 32)) return rc;
-    int32_t *d_slow_index = (int32_t *)b->d_stage;
-    uint32_t *d_leaves = (uint32_t *)(b->d_stage + idx_bytes);
-    uint8_t *d_out = b->d_stage + idx_bytes + leaf_bytes;
-    HIPCHK(hipMemcpyAsync(d_slow_index, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice, b->stream));
-    for (uint32_t done = 0; done < n; done += slice) {
-        const uint32_t m = std::min(slice, n - done);
-        launch_digest(b->stream, b->d_W, b->Bp, first + done, m, p.n_witnesses, b->d_producer, b->unscale, d_slow_index, b->d_assigned, n_slow, d_leaves, d_out);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(out32 + (size_t)done * 32, d_out, (size_t)m * 32, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->side()) {  // the level table does not hold the maps of the exact path's instances
+        Unscale u = b->unscale;
+        u.event = nullptr;  // (their columns are read as leftovers and overwritten below)
+        if (int rc = digest_range(b, b->stream, b->d_W, b->Bp, first, n, u, nullptr, false, 0, out32)) return rc;
+        return flagged.empty() ? 0 : digest_exact_instances(b, flagged, first, out32);
     }
-    return 0;
+    return digest_range(b, b->stream, b->d_W, b->Bp, first, n, b->unscale, nullptr, true, (uint32_t)b->slow_ids.size(), out32);
 } ABI_CATCH
 
 int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,

@@ -78,7 +78,9 @@ struct acvm_batch {
     double cls_kernel_ms[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     hipStream_t stream_dyn = nullptr, stream_heavy = nullptr, stream_heavy2 = nullptr, stream_heavy3 = nullptr, stream_digest = nullptr;
     PlanOpts opts;                    // acvm_batch_new_ex: folded digest, slot reuse
-    uint32_t *d_leaves = nullptr;     // fold_digest: the word-wise sum of the leaves, [8][Bp], accumulated by the digest lane during the solve
+    uint4 *d_leaves = nullptr;        // fold_digest: the partial sums of the digest, [records][2][Bp] x 16 B, written by the digest lane during the solve
+    uint32_t *d_fp_g = nullptr, *d_fp_gs = nullptr, *d_fp_h = nullptr, *d_fp_hgen = nullptr;  // tables of the digest (kernels.hpp DigestTables), built at the first use
+    DigestTables fp{};
     uint32_t *d_slot_of = nullptr;    // reuse_slots: witness -> row of d_W
     // reuse_slots: the exact path re-solves the flagged instances from their initial witnesses in a table of its own (row = witness
     // index, lane t = the t-th flagged instance); x_cap lanes allocated
@@ -174,6 +176,8 @@ struct acvm_batch {
         if (stream_heavy3) hipStreamDestroy(stream_heavy3);
         if (stream_digest) hipStreamDestroy(stream_digest);
         if (d_leaves) hipFree(d_leaves);
+        for (void *p : {(void *)d_fp_g, (void *)d_fp_gs, (void *)d_fp_h, (void *)d_fp_hgen})
+            if (p) hipFree(p);
         if (d_slot_of) hipFree(d_slot_of);
         for (void *p : {(void *)d_Wx, (void *)d_Memx, (void *)d_init_rows, (void *)d_ids_x})
             if (p) hipFree(p);

@@ -243,20 +243,16 @@ __global__ void __launch_bounds__(256) modmul_rate_kernel(uint32_t *__restrict__
     for (int i = 0; i < 9; i++) s += a.v[i] ^ b.v[i];
     out[(uint64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-// The streaming ceiling of the part for the witness table's access shape (a wave = 64 consecutive instances = 1 KiB per access, nontemporal):
-// a copy of n 16-byte units, every lane one unit per step of the grid. bench.py reports it beside the 8 TB/s spec peak of the roofline.
-__global__ void __launch_bounds__(256) stream_rate_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint4 v;
-        v.x = __builtin_nontemporal_load(&src[i].x); v.y = __builtin_nontemporal_load(&src[i].y);
-        v.z = __builtin_nontemporal_load(&src[i].z); v.w = __builtin_nontemporal_load(&src[i].w);
-        __builtin_nontemporal_store(v.x, &dst[i].x); __builtin_nontemporal_store(v.y, &dst[i].y);
-        __builtin_nontemporal_store(v.z, &dst[i].z); __builtin_nontemporal_store(v.w, &dst[i].w);
-    }
+// The streaming ceiling of the part for the gate kernel's access shape (tools/copybench.hip "2 reads + 1 write, one tile per block": a wave =
+// 64 consecutive instances = 1 KiB per access, two operand rows read and one output row written per lane, the grid covers the data
+// exactly like a level launch): n 16-byte units per row. bench.py reports it beside the 8 TB/s spec peak of the roofline.
+__global__ void __launch_bounds__(256) stream_rate_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, uint4 *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint4 x = a[i], y = b[i];
+    out[i] = make_uint4(x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w);
 }
-void launch_stream_rate(hipStream_t s, const uint4 *src, uint4 *dst, uint64_t n, uint32_t blocks) {
-    hipLaunchKernelGGL(stream_rate_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+void launch_stream_rate(hipStream_t s, const uint4 *a, const uint4 *b, uint4 *out, uint64_t n) {
+    hipLaunchKernelGGL(stream_rate_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, s, a, b, out);
 }
 void launch_modmul_rate(hipStream_t s, uint32_t *out, uint32_t blocks, uint32_t iters) {
     hipLaunchKernelGGL(modmul_rate_kernel, dim3(blocks), dim3(256), 0, s, out, 1u, iters);

@@ -86,7 +86,7 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
                           const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event);
 void launch_modmul_rate(hipStream_t s, uint32_t *out, uint32_t blocks, uint32_t iters);
-void launch_stream_rate(hipStream_t s, const uint4 *src, uint4 *dst, uint64_t n, uint32_t blocks);
+void launch_stream_rate(hipStream_t s, const uint4 *a, const uint4 *b, uint4 *out, uint64_t n);  // n: multiple of 256
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 // event words [0, B) <- 0xFFFFFFFF, the flagged count (word B) and the ticket (word B + 1) <- 0; the count of words != 0xFFFFFFFF into word B and *host_count
@@ -138,13 +138,22 @@ void launch_hostbb_apply_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t fi
                                uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event);
 void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const ExactLanes &L, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
                                const uint32_t *outs, uint32_t n_out, const uint8_t *active, const uint8_t *rc, const uint8_t *vals);
-// per-instance digest of the witness map (kernels_hash.hip): acc = scratch of 8 x n words
+// per-instance digest of the witness map (kernels_hash.hip; definition: include/acvm_amd.h acvm_batch_digest). Device tables of the
+// polynomial fingerprint, 8 x u32 per entry in the device's Montgomery form:
+struct DigestTables {
+    const uint32_t *g_pow;     // [n_witnesses]: g^(w+1)
+    const uint32_t *g_scaled;  // [scaled witnesses, rows of Unscale]: g^(w+1) / scale_w
+    const uint32_t *h_pow;     // [n_witnesses]: h^(w+1)
+    const uint32_t *h_generic; // [1]: the sum of h^(w+1) over the witnesses the planner saw assigned
+};
+uint32_t digest_chunks(uint32_t n_witnesses);  // rows of the partial-sum scratch of launch_digest: digest_chunks x n x 32 bytes
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
-                   const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *acc, uint8_t *out);
-// the digest folded into the solve (PlanOpts::fold_digest)
+                   const DigestTables &T, const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint4 *partial, uint8_t *out);
+// the digest folded into the solve (PlanOpts::fold_digest): partial = [records][2][Bp] x 16 B
 void launch_digest_fold_level(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
-                              const uint32_t *unscale_plain, uint32_t *acc);
-void launch_digest_final(hipStream_t s, const uint32_t *acc, uint64_t stride, uint32_t first, uint32_t n, uint8_t *out);
+                              const DigestTables &T, uint4 *partial);
+void launch_digest_final(hipStream_t s, const uint4 *partial, uint32_t n_rows, uint64_t stride, uint32_t first, uint32_t n, const uint32_t *event, const DigestTables &T,
+                         uint8_t *out);
 // InProgress -> Solved after the last opcode
 void launch_exact_finish(hipStream_t s, const ExactLanes &L, uint32_t min_ip = 0);
 

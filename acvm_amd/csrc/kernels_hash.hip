@@ -116,129 +116,161 @@ void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram
 
 // ------------------------------------------------------------------------------------------ witness-map digest
 // SURVEY 8d (config 5): callers that do not want the full map back keep the return witnesses and a 32-byte digest per instance.
-// Definition (include/acvm_amd.h acvm_batch_digest): witnesses 2i and 2i + 1 form pair i; mask = 1 (2i assigned) | 2 (2i + 1 assigned);
-// a pair with mask != 0 has the leaf Blake2s-256(message = the 32-byte big-endian canonical values of its assigned witnesses in ascending
-// order, personalisation = le32(i) || le32(mask)) -- ONE compression; S = the sum of all leaves taken as eight little-endian 32-bit words,
-// each word modulo 2^32; digest = Blake2s-256(S). The sum makes the leaves order-free: a leaf is hashed as soon as its two witnesses
-// exist (the folded digest of plan.cpp, which lets witness rows be recycled early), by any number of lanes, and added with atomics.
-__device__ __forceinline__ void digest_leaf_add(uint32_t (&S)[8], uint32_t pair, uint32_t mask, const Fr &ca, const Fr &cb) {
-    uint32_t h[8], w[16];
-    blake2s_init(h);
-    h[6] ^= pair;  // parameter block bytes 24..31: the personalisation
-    h[7] ^= mask;
-    const Fr &first = (mask & 1u) ? ca : cb;
+// Definition (include/acvm_amd.h acvm_batch_digest): D = sum over the ASSIGNED witnesses w of (value_w * g^(w+1) + h^(w+1)) in BN254-Fr, with
+// two fixed field elements g and h; digest = Blake2s-256(D as 32 big-endian bytes). A polynomial fingerprint: one field product per
+// witness, order-free, and linear -- so that (1) a witness the level kernels keep scaled needs no product of its own to leave the scaled
+// form: its stored value scale_w * value_w is multiplied by g^(w+1) / scale_w, a circuit constant; (2) two products share one Montgomery
+// reduction (fr29_dot<2>); (3) the h-sum of an instance the level kernels solved is a constant of the plan (its assigned set is the
+// planner's), added once at the end. Round 2's digest (one Blake2s compression per pair of witnesses plus a product to leave the scaled
+// form) cost 100 ms per 4 096 x 10^6 tile, two thirds of a solve; this one is bound by reading the table once.
+// Partial sums: a lane covers DIGEST_CHUNK witnesses of one instance and stores their sum (Montgomery form, reduced) at partial[chunk][lane];
+// digest_final_kernel adds the rows up. No atomics.
+static constexpr uint32_t DIGEST_CHUNK = 1024;
+struct FpAcc {
+    Fr29 h;
+    uint32_t hw;
+};
+__device__ __forceinline__ void fp_init(FpAcc &a) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        w[k] = bswap32(first.v[7 - k]);  // big-endian bytes as little-endian message words
-        w[8 + k] = mask == 3u ? bswap32(cb.v[7 - k]) : 0u;
-    }
-    blake2s_compress_body(h, w, mask == 3u ? 64u : 32u, true);
-#pragma unroll
-    for (int k = 0; k < 8; k++) S[k] += h[k];
+    for (int i = 0; i < 9; i++) a.h.v[i] = 0;
+    a.hw = 0;
 }
-static constexpr uint32_t DIGEST_CHUNK_PAIRS = 64;  // pairs one lane of the post-solve kernel hashes
-// after the solve, from the table: lane = (instance, chunk of pairs); acc = [8][n] words, zeroed by the launcher
-__global__ void __launch_bounds__(128) digest_pairs_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses,
-                                                           const uint32_t *__restrict__ producer, const Unscale u, const int32_t *__restrict__ slow_index,
-                                                           const uint32_t *__restrict__ assigned, uint32_t n_slow, uint32_t *__restrict__ acc, uint32_t chunk0) {
+__device__ __forceinline__ void fp_add(FpAcc &a, const Fr29 &x, uint32_t weight) {
+    gate_h_room(a.h, a.hw, weight);
+    a.h = fr29_addl(a.h, x);
+}
+__device__ __forceinline__ Fr fp_value(const FpAcc &a) {
+    GateSum s;
+    s.v = fr29_norm(a.h);
+    s.bound = a.hw;
+    return fr29_pack(gate_sum_canon(s));
+}
+// sum of stored_w * coef_w over the listed witnesses for a wave whose lanes are all instances of the level kernels (wave-uniform
+// coefficients, two products per reduction). ws / cs: `n` (witness row, coefficient address) pairs produced by `next`.
+template <class Next>
+__device__ __forceinline__ Fr fp_sum_generic(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, Next next) {
+    FpAcc acc;
+    fp_init(acc);
+    uint32_t row0 = 0, row1 = 0;
+    const uint32_t *c0 = nullptr, *c1 = nullptr;
+    for (;;) {
+        if (!next(row0, c0)) break;
+        const Fr29 x0 = fr29_from(fr_load_nt(W, row0, Bp, j)), k0 = fr29_from(fr_const(c0, 0));
+        if (!next(row1, c1)) {
+            fp_add(acc, fr29_mul(x0, k0), 17);
+            break;
+        }
+        const Fr29 x1 = fr29_from(fr_load_nt(W, row1, Bp, j)), k1 = fr29_from(fr_const(c1, 0));
+        const Fr29 l[2] = {x0, x1}, m[2] = {k0, k1};
+        fp_add(acc, fr29_dot<2>(l, m), 17);
+    }
+    return fp_value(acc);
+}
+// after the solve, from the table: lane = instance first + t (or ids[t]), blockIdx.y = chunk of witnesses. Instances of the exact path (event
+// word set; `assigned` bitmap, lane slow_index[j]) hold plain values and carry their own h-sum.
+__global__ void __launch_bounds__(256) digest_chunk_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses,
+                                                           const uint32_t *__restrict__ producer, const Unscale u, const DigestTables T,
+                                                           const int32_t *__restrict__ slow_index, const uint32_t *__restrict__ assigned, uint32_t n_slow,
+                                                           uint4 *__restrict__ partial, uint32_t chunk0) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, chunk = chunk0 + blockIdx.y;
-    if (t >= n) return;
-    const uint64_t j = (uint64_t)first + t;
-    const bool generic = !u.event || u.event[j] == 0xFFFFFFFFu;  // solved by the level kernels: the planner's assigned set, scaled columns (no event words: every lane)
-    const uint32_t lane = generic ? 0u : (uint32_t)slow_index[j];
-    Fr one = fr_zero();
-    one.v[0] = 1;
-    uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const uint32_t p0 = chunk * DIGEST_CHUNK_PAIRS, n_pairs = (n_witnesses + 1) / 2;
-    for (uint32_t pi = p0; pi < p0 + DIGEST_CHUNK_PAIRS && pi < n_pairs; pi++) {
-        uint32_t mask = 0;
-        Fr c[2] = {fr_zero(), fr_zero()};
-        for (uint32_t h = 0; h < 2; h++) {
-            const uint32_t w = 2 * pi + h;
-            if (w >= n_witnesses) continue;
+    const bool live = t < n;
+    const uint64_t j = (uint64_t)first + (live ? t : 0u);
+    const bool generic = !u.event || u.event[j] == 0xFFFFFFFFu;  // solved by the level kernels: the planner's assigned set, scaled columns
+    const uint32_t w_begin = chunk * DIGEST_CHUNK, w_end = min(n_witnesses, w_begin + DIGEST_CHUNK);
+    Fr sum;
+    if (__builtin_amdgcn_ballot_w64(live && !generic) == 0) {
+        uint32_t w = w_begin;
+        sum = fp_sum_generic(W, Bp, j, [&](uint32_t &row, const uint32_t *&coef) {
+            while (w < w_end && producer[w] == 0xFFFFFFFFu) w++;
+            if (w >= w_end) return false;
+            const uint32_t ui = u.index ? u.index[w] : 0xFFFFFFFFu;
+            row = w;
+            coef = ui != 0xFFFFFFFFu ? T.g_scaled + 8 * (uint64_t)ui : T.g_pow + 8 * (uint64_t)w;
+            w++;
+            return true;
+        });
+    } else {  // a wave that holds an instance of the exact path: per-lane coefficients and masks
+        const uint32_t lane = generic ? 0u : (uint32_t)slow_index[j];
+        sum = fr_zero();
+        for (uint32_t w = w_begin; w < w_end; w++) {
             const bool present = generic ? producer[w] != 0xFFFFFFFFu : ((assigned[(uint64_t)(w >> 5) * n_slow + lane] >> (w & 31)) & 1u) != 0u;
             if (!present) continue;
-            mask |= 1u << h;
             const uint32_t ui = generic && u.index ? u.index[w] : 0xFFFFFFFFu;
-            c[h] = fr_mul(fr_load(W, w, Bp, j), ui != 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);  // canonical value (unscaled where the column is scaled)
+            const Fr k = ui != 0xFFFFFFFFu ? fr_const(T.g_scaled, ui) : fr_const(T.g_pow, w);
+            sum = fr_add(sum, fr_mul(fr_load(W, w, Bp, j), k));
+            if (!generic) sum = fr_add(sum, fr_const(T.h_pow, w));
         }
-        if (mask) digest_leaf_add(S, pi, mask, c[0], c[1]);
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (S[k]) atomicAdd(&acc[(uint64_t)k * n + t], S[k]);
+    if (live) fr_store(partial, chunk, n, t, sum);
 }
-// The same leaves DURING the solve (PlanOpts::fold_digest): records [PK_DIGEST_LEAF, 0, n, (pair, witness 2i or NONE, witness 2i + 1 or NONE,
-// row of unscale or NONE x 2) x n] of the pairs whose witnesses are complete (the planner's assigned set = the generic instance), read through
-// the row map of slot reuse; acc = [8][Bp]. Instances that leave the generic path are hashed from the exact path's map afterwards.
-__global__ void __launch_bounds__(128) digest_fold_level_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ prog,
+// The same sums DURING the solve (PlanOpts::fold_digest): records [PK_DIGEST_LEAF, row of `partial`, n, (witness, row of g_scaled or NONE) x n] of the
+// witnesses that are complete (the planner's assigned set = the generic instance), read through the row map of slot reuse. Instances
+// that leave the generic path are summed from the exact path's map afterwards.
+__global__ void __launch_bounds__(256) digest_fold_level_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ prog,
                                                                 const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ slot_of,
-                                                                const uint32_t *__restrict__ unscale_plain, uint32_t *__restrict__ acc) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B) return;
+                                                                const DigestTables T, uint4 *__restrict__ partial) {
+    const uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j0 < B;
+    const uint64_t j = live ? j0 : 0u;
     const uint32_t *__restrict__ r = prog + offsets[blockIdx.y];
     const uint32_t n = r[2];
-    Fr one = fr_zero();
-    one.v[0] = 1;
-    uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t *__restrict__ e = r + 3 + 5 * i;
-        uint32_t mask = 0;
-        Fr c[2] = {fr_zero(), fr_zero()};
-        for (uint32_t h = 0; h < 2; h++) {
-            const uint32_t w = e[1 + h], ui = e[3 + h];
-            if (w == 0xFFFFFFFFu) continue;
-            mask |= 1u << h;
-            c[h] = fr_mul(fr_load(W, slot_of ? slot_of[w] : w, Bp, j), ui != 0xFFFFFFFFu ? fr_const(unscale_plain, ui) : one);
-        }
-        digest_leaf_add(S, e[0], mask, c[0], c[1]);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (S[k]) atomicAdd(&acc[(uint64_t)k * Bp + j], S[k]);
+    uint32_t i = 0;
+    const Fr sum = fp_sum_generic(W, Bp, j, [&](uint32_t &row, const uint32_t *&coef) {
+        if (i >= n) return false;
+        const uint32_t w = r[3 + 2 * i], ui = r[4 + 2 * i];
+        row = slot_of ? slot_of[w] : w;
+        coef = ui != 0xFFFFFFFFu ? T.g_scaled + 8 * (uint64_t)ui : T.g_pow + 8 * (uint64_t)w;
+        i++;
+        return true;
+    });
+    if (live) fr_store(partial, r[1], Bp, j, sum);
 }
-// digest = Blake2s-256(S); acc laid out [8][stride], instances [first, first + n)
-__global__ void __launch_bounds__(128) digest_final_kernel(const uint32_t *__restrict__ acc, uint64_t stride, uint32_t first, uint32_t n, uint8_t *__restrict__ out) {
+// digest = Blake2s-256(D): D = the rows of `partial` added up (+ the plan's h-sum for an instance of the level kernels), as 32 big-endian
+// bytes. partial laid out [row][2 halves][stride]; instances [first, first + n) of it.
+__global__ void __launch_bounds__(128) digest_final_kernel(const uint4 *__restrict__ partial, uint32_t n_rows, uint64_t stride, uint32_t first, uint32_t n,
+                                                           const uint32_t *__restrict__ event, uint32_t event_first, const DigestTables T, uint8_t *__restrict__ out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    Fr s = fr_zero();
+    for (uint32_t r = 0; r < n_rows; r++) s = fr_add(s, fr_load(partial, r, stride, (uint64_t)first + t));
+    const bool generic = !event || event[(uint64_t)event_first + t] == 0xFFFFFFFFu;
+    if (generic) s = fr_add(s, fr_const(T.h_generic, 0));
+    const Fr c = fr_to_canonical(s);
     uint32_t h[8], w[16];
     blake2s_init(h);
 #pragma unroll
-    for (int k = 0; k < 8; k++) { w[k] = acc[(uint64_t)k * stride + first + t]; w[8 + k] = 0u; }
+    for (int k = 0; k < 8; k++) { w[k] = bswap32(c.v[7 - k]); w[8 + k] = 0u; }  // big-endian bytes as little-endian message words
     blake2s_compress(h, w, 32u, true);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(h[i] >> (8 * k));
 }
-__global__ void zero_u32_kernel(uint32_t *p, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
-}
-// acc: scratch of 8 x n words
+uint32_t digest_chunks(uint32_t n_witnesses) { return (n_witnesses + DIGEST_CHUNK - 1) / DIGEST_CHUNK; }
+// partial: scratch of digest_chunks(n_witnesses) x n x 32 bytes
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
-                   const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *acc, uint8_t *out) {
+                   const DigestTables &T, const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint4 *partial, uint8_t *out) {
     if (!n) return;
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((8ull * n + 255) / 256)), dim3(256), 0, s, acc, 8ull * n);
-    const uint32_t n_chunks = ((n_witnesses + 1) / 2 + DIGEST_CHUNK_PAIRS - 1) / DIGEST_CHUNK_PAIRS;
+    const uint32_t n_chunks = digest_chunks(n_witnesses);
     for (uint32_t done = 0; done < n_chunks; done += 65535u) {  // gridDim.y is limited to 65535
         const uint32_t m = n_chunks - done > 65535u ? 65535u : n_chunks - done;
-        hipLaunchKernelGGL(digest_pairs_kernel, dim3((n + 127) / 128, m), dim3(128), 0, s, W, Bp, first, n, n_witnesses, producer, u, slow_index, assigned, n_slow,
-                           acc, done);
+        hipLaunchKernelGGL(digest_chunk_kernel, dim3((n + 255) / 256, m), dim3(256), 0, s, W, Bp, first, n, n_witnesses, producer, u, T, slow_index, assigned, n_slow,
+                           partial, done);
     }
-    hipLaunchKernelGGL(digest_final_kernel, dim3((n + 127) / 128), dim3(128), 0, s, acc, (uint64_t)n, 0u, n, out);
+    hipLaunchKernelGGL(digest_final_kernel, dim3((n + 127) / 128), dim3(128), 0, s, partial, n_chunks, (uint64_t)n, 0u, n, u.event, first, T, out);
 }
 void launch_digest_fold_level(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
-                              const uint32_t *unscale_plain, uint32_t *acc) {
+                              const DigestTables &T, uint4 *partial) {
     if (!n || !B) return;
     for (uint32_t done = 0; done < n; done += 65535u) {
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        hipLaunchKernelGGL(digest_fold_level_kernel, dim3((B + 127) / 128, m), dim3(128), 0, s, W, Bp, B, dp.prog, offsets + done, dp.slot_of, unscale_plain, acc);
+        hipLaunchKernelGGL(digest_fold_level_kernel, dim3((B + 255) / 256, m), dim3(256), 0, s, W, Bp, B, dp.prog, offsets + done, dp.slot_of, T, partial);
     }
 }
-void launch_digest_final(hipStream_t s, const uint32_t *acc, uint64_t stride, uint32_t first, uint32_t n, uint8_t *out) {
+void launch_digest_final(hipStream_t s, const uint4 *partial, uint32_t n_rows, uint64_t stride, uint32_t first, uint32_t n, const uint32_t *event, const DigestTables &T,
+                         uint8_t *out) {
     if (!n) return;
-    hipLaunchKernelGGL(digest_final_kernel, dim3((n + 127) / 128), dim3(128), 0, s, acc, stride, first, n, out);
+    hipLaunchKernelGGL(digest_final_kernel, dim3((n + 127) / 128), dim3(128), 0, s, partial, n_rows, stride, first, n, event, first, T, out);
 }
 
 }  // namespace acvm

@@ -1050,42 +1050,32 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         for (auto &slot : out_slots[r.opcode])
             if (p.producer[slot.second] == r.opcode) wdef[slot.second] = r.level;
     if (opts.fold_digest && p.truncated_at == 0xFFFFFFFFu) {
-        // record: [PK_DIGEST_LEAF, 0, n, (pair, witness 2i or NONE, witness 2i + 1 or NONE, row of `unscale` or NONE x 2) x n]: the leaves
-        // (include/acvm_amd.h acvm_batch_digest: one Blake2s compression per pair of witness indices, summed word-wise) of the pairs
-        // whose assigned witnesses are complete, for the generic instance. Launched in epochs (every DIGEST_EPOCH-th level all pairs
-        // completed since the last one, in records of at most 128 pairs): the leaves are order-free, so nothing waits for anything but
-        // its own two witnesses, and a row can be recycled as soon as the epoch of its pair has run.
+        // record: [PK_DIGEST_LEAF, row of the partial-sum table, n, (witness, row of `unscale` or NONE) x n]: the terms value_w * g^(w+1) of the digest
+        // (include/acvm_amd.h acvm_batch_digest: a polynomial fingerprint, one product per witness, order-free) of the witnesses that are
+        // complete, for the generic instance. Launched in epochs (every digest_epoch-th level all witnesses completed since the last one, in
+        // records of at most 256): nothing waits for anything but its own witness, and a row can be recycled as soon as the epoch of its
+        // witness has run.
         const uint32_t K_dig = (uint32_t)std::max<int64_t>(tune.digest_epoch, 1);
-        const uint32_t PAIRS_PER_RECORD = 128;
-        std::map<uint32_t, std::vector<uint32_t>> by_level;  // epoch level -> pairs
-        for (uint32_t i = 0; i < (nw + 1) / 2; i++) {
-            uint32_t lvl = 0;
-            bool any = false;
-            for (uint32_t w = 2 * i; w < std::min(nw, 2 * i + 2); w++)
-                if (p.producer[w] != 0xFFFFFFFFu) { any = true; lvl = std::max(lvl, wdef[w] + 1); }
-            if (!any) continue;
-            lvl = std::max(lvl, 1u);
-            by_level[(lvl + K_dig - 1) / K_dig * K_dig].push_back(i);
+        const uint32_t PER_RECORD = 256;
+        std::map<uint32_t, std::vector<uint32_t>> by_level;  // epoch level -> witnesses
+        for (uint32_t w = 0; w < nw; w++) {
+            if (p.producer[w] == 0xFFFFFFFFu) continue;
+            const uint32_t lvl = std::max(wdef[w] + 1, 1u);
+            by_level[(lvl + K_dig - 1) / K_dig * K_dig].push_back(w);
         }
         for (auto &kv : by_level)
-            for (size_t at = 0; at < kv.second.size(); at += PAIRS_PER_RECORD) {
+            for (size_t at = 0; at < kv.second.size(); at += PER_RECORD) {
                 PendingRecord r;
                 r.cls = CLS_DIGEST;
                 r.synthetic = true;
                 r.opcode = (uint32_t)p.prog.size();  // offset of the record: digest records have no opcode
                 r.level = kv.first;
-                const size_t n = std::min<size_t>(PAIRS_PER_RECORD, kv.second.size() - at);
-                p.prog.insert(p.prog.end(), {PK_DIGEST_LEAF, 0u, (uint32_t)n});
+                const size_t n = std::min<size_t>(PER_RECORD, kv.second.size() - at);
+                p.prog.insert(p.prog.end(), {PK_DIGEST_LEAF, p.n_digest_segments, (uint32_t)n});
                 for (size_t k = 0; k < n; k++) {
-                    const uint32_t i = kv.second[at + k];
-                    uint32_t w[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, u[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-                    for (uint32_t h = 0; h < 2; h++)
-                        if (2 * i + h < nw && p.producer[2 * i + h] != 0xFFFFFFFFu) {
-                            w[h] = 2 * i + h;
-                            u[h] = p.unscale_index[w[h]];
-                            r.reads.push_back(w[h]);
-                        }
-                    p.prog.insert(p.prog.end(), {i, w[0], w[1], u[0], u[1]});
+                    const uint32_t w = kv.second[at + k];
+                    p.prog.insert(p.prog.end(), {w, p.unscale_index[w]});
+                    r.reads.push_back(w);
                 }
                 records.push_back(std::move(r));
                 p.n_digest_segments++;

@@ -180,9 +180,10 @@ int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, u
  * kernel uses) on every SIMD, waves_per_simd dependent chains of 2 * iters products interleaved per SIMD; the best of three timed
  * launches as modmul/s, and the number of products one launch executes. */
 int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modmul_per_s, uint64_t *n_modmul);
-/* The measured streaming ceiling of the device for the witness table's access shape (reported beside the 8 TB/s spec peak of the HBM
- * roofline): a nontemporal 16-byte-per-lane copy of `bytes` bytes, read + written bytes per second of the best of three launches. */
-int acvm_debug_stream_rate(size_t bytes, double *read_plus_write_gb_per_s);
+/* The measured streaming ceiling of the device for the gate kernel's access shape (reported beside the 8 TB/s spec peak of the HBM
+ * roofline): two rows of `bytes` bytes read and one written, 16 bytes per lane, the grid covering the data like a level launch;
+ * bytes moved (3 x bytes) per second of the best of four launches, in GB/s. */
+int acvm_debug_stream_rate(size_t bytes, double *gb_per_s);
 
 /* Circuit::read: gzip(bincode) or raw bincode bytes. */
 acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);
@@ -305,13 +306,17 @@ int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t i
 /*
  * Per-instance 32-byte digest of the solved witness map for instances [first, first + n), out32 = [n][32] (SURVEY 8d, config 5:
  * callers that keep only the return witnesses use it to compare whole maps without moving them -- the map of the reference is
- * what ACVM::finalize returns, acvm/src/pwg/mod.rs:176-181). Definition: witnesses 2i and 2i + 1 form pair i, mask = 1 (2i is
- * assigned) | 2 (2i + 1 is assigned); a pair with mask != 0 has the leaf Blake2s-256(message = the 32-byte big-endian canonical
- * values (FieldElement::to_be_bytes, acir_field/src/generic_ark.rs:269-277) of its assigned witnesses in ascending order,
- * personalisation = le32(i) || le32(mask)); S = the sum of all leaves read as eight little-endian 32-bit words, each word modulo
- * 2^32; digest = Blake2s-256(S as eight little-endian words). (hashlib: blake2s(msg, person=struct.pack("<II", i, mask)).) The
- * leaves are order-free, so the library hashes a pair as soon as both witnesses exist (ACVM_BATCH_FOLD_DIGEST) and may recycle
- * their rows (ACVM_BATCH_REUSE_SLOTS). Works for solved, failed and waiting instances alike (the map as it stands).
+ * what ACVM::finalize returns, acvm/src/pwg/mod.rs:176-181). Definition: with the two fixed elements of BN254-Fr
+ *     g = Blake2s-256("acvm_amd witness map digest: g"),  h = Blake2s-256("acvm_amd witness map digest: h")
+ * (the 32 digest bytes read as a big-endian integer, reduced modulo p),
+ *     D = sum over the ASSIGNED witnesses w of ( value_w * g^(w+1) + h^(w+1) )  in BN254-Fr,
+ *     digest = Blake2s-256( D as 32 big-endian bytes )          (value_w: FieldElement, acir_field/src/generic_ark.rs:156-406).
+ * A polynomial fingerprint of the map (two maps differ in D unless g is a root of their difference: probability < 2^-230 for maps
+ * that do not depend on g; it is an integrity check, not a commitment against an adversary who knows g). The h-term tells an
+ * unassigned witness from one assigned zero. Linear and order-free on purpose: one field product per witness -- a witness the level
+ * kernels keep scaled (DESIGN.md "projective witnesses") is folded into its coefficient -- summed in any order, so the library adds
+ * a witness as soon as it exists (ACVM_BATCH_FOLD_DIGEST) and may recycle its row (ACVM_BATCH_REUSE_SLOTS). Works for solved,
+ * failed and waiting instances alike (the map as it stands). oracle/binding.py witness_map_digest restates it with Python integers.
  */
 int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32);
 /*

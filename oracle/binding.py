@@ -210,19 +210,37 @@ def solve_batch(circuit: Circuit, ids, values_be: bytes, B: int, want_witness=Tr
     return res, assigned, vals
 
 
-def witness_map_digest(assigned, values) -> bytes:
-    """CPU restatement (Python hashlib) of the definition of acvm_batch_digest in include/acvm_amd.h, for ONE instance -- checker only:
-    assigned[w] truthy, values[w] = 32 big-endian bytes. Pair i = witnesses (2i, 2i + 1); leaf = Blake2s-256 of the assigned values,
-    personalised with le32(i) || le32(mask); the leaves are summed as eight little-endian u32 words; digest = Blake2s-256(sum)."""
+P_BN254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_DIGEST_POWERS = {}
+
+
+def _digest_powers(nw):
+    """[g^(w+1)], [h^(w+1)] for w < nw; g, h = Blake2s-256("acvm_amd witness map digest: g" / "... h") as big-endian integers mod p"""
     import hashlib
-    import struct
+    got = _DIGEST_POWERS.get("t")
+    if got is None or len(got[0]) < nw:
+        g = int.from_bytes(hashlib.blake2s(b"acvm_amd witness map digest: g").digest(), "big") % P_BN254
+        h = int.from_bytes(hashlib.blake2s(b"acvm_amd witness map digest: h").digest(), "big") % P_BN254
+        gp, hp, gs, hs = g, h, [], []
+        for _ in range(nw):
+            gs.append(gp)
+            hs.append(hp)
+            gp = gp * g % P_BN254
+            hp = hp * h % P_BN254
+        got = _DIGEST_POWERS["t"] = (gs, hs)
+    return got
+
+
+def witness_map_digest(assigned, values) -> bytes:
+    """CPU restatement (Python big integers + hashlib) of the definition of acvm_batch_digest in include/acvm_amd.h, for ONE instance --
+    checker only: assigned[w] truthy, values[w] = 32 big-endian bytes. D = sum over the assigned witnesses of value_w * g^(w+1) + h^(w+1)
+    modulo p; digest = Blake2s-256(D as 32 big-endian bytes)."""
+    import hashlib
     nw = len(assigned)
-    total = [0] * 8
-    for i in range((nw + 1) // 2):
-        mask = (1 if assigned[2 * i] else 0) | (2 if 2 * i + 1 < nw and assigned[2 * i + 1] else 0)
-        if not mask:
-            continue
-        msg = (bytes(values[2 * i]) if mask & 1 else b"") + (bytes(values[2 * i + 1]) if mask & 2 else b"")
-        leaf = struct.unpack("<8I", hashlib.blake2s(msg, person=struct.pack("<II", i, mask)).digest())
-        total = [(a + b) & 0xFFFFFFFF for a, b in zip(total, leaf)]
-    return hashlib.blake2s(struct.pack("<8I", *total)).digest()
+    gs, hs = _digest_powers(nw)
+    raw = bytes(values) if isinstance(values, (bytes, bytearray)) else values.tobytes() if hasattr(values, "tobytes") else b"".join(bytes(v) for v in values)
+    acc = 0
+    for w in range(nw):
+        if assigned[w]:
+            acc += int.from_bytes(raw[32 * w:32 * w + 32], "big") * gs[w] + hs[w]
+    return hashlib.blake2s((acc % P_BN254).to_bytes(32, "big")).digest()

@@ -102,7 +102,7 @@ def test_mutated_circuits_never_trip_the_sanitizers(driver, tmp_path):
             f.write(struct.pack("<I", len(b)))
             f.write(b)
     env = dict(os.environ, ASAN_OPTIONS="abort_on_error=0:detect_leaks=1:allocator_may_return_null=1:max_allocation_size_mb=4096", UBSAN_OPTIONS="print_stacktrace=1")
-    out = subprocess.run([driver, str(path)], capture_output=True, text=True, env=env, timeout=900)
+    out = subprocess.run([driver, str(path)], capture_output=True, text=True, env=env, timeout=max(900, N_MUTANTS // 10))
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-6000:])
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-6000:]
     words = out.stdout.split()

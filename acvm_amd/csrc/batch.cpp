@@ -483,6 +483,7 @@ static int batch_init(acvm_batch *b) {
     }
     b->n_words = (p.n_witnesses + 31) / 32;
     if (int rc = upload(&b->d_producer, p.producer)) return rc;
+    if (int rc = upload(&b->d_prog_class, p.prog_class)) return rc;
     if (int rc = upload(&b->d_dyn_offset, p.dyn_offset)) return rc;
     {
         size_t bytes = (size_t)p.n_inverse_slots * 2 * b->Bp * sizeof(uint4);
@@ -797,24 +798,23 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
     hipStream_t s = b->xstream();  // the batch's stream, or the side stream of an asynchronous job
     const ExactLanes L = exact_lanes(b, n_slow);
     const DeviceProgram xdp = b->xdp();
-    // memory side effects of the opcodes before the earliest event are replayed by the span kernel, so start at the
-    // first segment that holds a memory opcode or the earliest event, whichever comes first
-    bool has_mem = replay && p.mem_cells != 0;
-    for (const ExactSegment &seg : b->segments) {
-        if (seg.end <= min_start && !(has_mem && seg.cls == CLS_LIGHT)) continue;
-        if (seg.begin >= end_opcode) break;
-        switch (seg.cls) {
-        case CLS_LIGHT:
-            launch_exact_span(s, b->xW(), b->xBp(), xdp, L, replay ? seg.begin : std::max(seg.begin, min_start), std::min(seg.end, end_opcode), has_mem);
-            break;
-        case CLS_HASH: launch_exact_hash(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->xscratch(CLS_HASH)); break;
-        case CLS_GRUMPKIN: launch_exact_grumpkin(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->xscratch(CLS_GRUMPKIN)); break;
-        case CLS_BRILLIG: launch_exact_brillig(s, b->xW(), b->xBp(), xdp, L, seg.begin, b->br_retry_active ? b->d_br_scratch : b->xscratch(CLS_BRILLIG)); break;
-        case CLS_ECDSA: launch_exact_ecdsa(s, b->xW(), b->xBp(), xdp, L, seg.begin); break;
-        case CLS_HOSTBB:
-            if (int rc = run_host_blackbox(b, seg.begin, true, n_slow)) return rc;
-            break;
+    // Memory side effects of the opcodes before the earliest event are replayed by the kernel, so the run starts at the first opcode
+    // when the circuit has memory blocks, else at the earliest event. One launch covers every class (kernels_brillig.hip
+    // exact_run_kernel); only the opcodes of a caller-supplied BlackBoxFunctionSolver split it (host callbacks in between).
+    const bool has_mem = replay && p.mem_cells != 0;
+    const ExactScratch sc{b->xscratch(CLS_HASH), b->xscratch(CLS_GRUMPKIN), b->br_retry_active ? b->d_br_scratch : b->xscratch(CLS_BRILLIG)};
+    const uint32_t end = std::min(end_opcode, p.n_opcodes);
+    uint32_t at = has_mem ? 0u : std::min(min_start, end);
+    while (at < end) {
+        uint32_t stop = at;
+        while (stop < end && p.prog_class[stop] != CLS_HOSTBB) stop++;
+        launch_exact_run(s, b->xW(), b->xBp(), xdp, L, at, stop, has_mem, b->d_prog_class, sc);
+        if (stop < end) {
+            if (stop >= min_start)  // (no lane stands before an opcode in front of the earliest start)
+                if (int rc = run_host_blackbox(b, stop, true, n_slow)) return rc;
+            stop++;
         }
+        at = stop;
     }
     launch_exact_finish(s, L, b->stepping ? p.n_opcodes : 0u);
     HIPCHK(hipGetLastError());

@@ -54,6 +54,7 @@ struct acvm_batch {
     uint32_t *d_gate_stream = nullptr, *d_gate_offset = nullptr, *d_consts = nullptr;
     uint32_t *d_prog = nullptr, *d_prog_offset = nullptr, *d_bytecode = nullptr, *d_init_ids = nullptr, *d_producer = nullptr;
     uint32_t *d_dyn_offset = nullptr, *d_slow_start = nullptr;
+    uint8_t *d_prog_class = nullptr;  // OpClass per opcode, for the one-launch exact path
     uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -175,6 +176,7 @@ struct acvm_batch {
         if (stream_heavy2) hipStreamDestroy(stream_heavy2);
         if (stream_heavy3) hipStreamDestroy(stream_heavy3);
         if (stream_digest) hipStreamDestroy(stream_digest);
+        if (d_prog_class) hipFree(d_prog_class);
         if (d_leaves) hipFree(d_leaves);
         for (void *p : {(void *)d_fp_g, (void *)d_fp_gs, (void *)d_fp_h, (void *)d_fp_hgen})
             if (p) hipFree(p);

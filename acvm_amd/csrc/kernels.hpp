@@ -122,6 +122,11 @@ void launch_exact_init(hipStream_t s, const ExactLanes &L);
 // opcodes [op_begin, op_end) of class CLS_LIGHT in program order
 void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end,
                        bool replay_memory);
+// opcodes [op_begin, op_end) of EVERY class but CLS_HOSTBB in one launch (kernels_brillig.hip exact_run_kernel); prog_class: device
+// array, OpClass per opcode; the class scratch buffers as the per-opcode kernels take them
+struct ExactScratch { uint32_t *hash, *grumpkin, *brillig; };
+void launch_exact_run(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end, bool replay_memory,
+                      const uint8_t *prog_class, const ExactScratch &sc);
 // one opcode of a heavy class
 void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
 void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);

@@ -19,7 +19,7 @@ MODES = [
 def test_mode_is_bit_exact(oracle, mode):
     import acvm_amd
     from acvm_amd import synth
-    seed = 0x300D0000 + (hash(tuple(sorted(mode.items()))) & 0xFFF)
+    seed = 0x300D0000 + MODES.index(mode)
     circ, ids = synth.mixed_circuit(900, seed=seed, heavy=True, blocks=4, cells=16)
     B = 130
     values = synth.witness_batch(B, seed=seed, edge_cases=True)
@@ -34,7 +34,11 @@ def test_mode_is_bit_exact(oracle, mode):
                 kw.update(reuse_slots=True, keep=gc.witness_set("return_values"))
             if variant == "fold":
                 kw.update(fold_digest=True)
-            batch = acvm_amd.Batch(gc, B, ids, **kw)
+            try:
+                batch = acvm_amd.Batch(gc, B, ids, **kw)
+            except acvm_amd.AcvmError:  # slot reuse refuses a circuit whose plan is truncated (an opcode no generic instance can execute)
+                assert variant == "reuse"
+                continue
             if variant == "exact":
                 batch.set_force_slow_path(True)
             batch.set_initial_witness(values)

@@ -12,18 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacvm_amd.so")
-SOURCES = ["circuit.cpp", "tuning.cpp", "plan.cpp", "batch.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_grumpkin.hip", "grumpkin_host.cpp", "kernels_brillig.hip", "kernels_ecdsa.hip", "shim.cpp", "node.cpp"]
+SOURCES = ["circuit.cpp", "tuning.cpp", "display.cpp", "plan.cpp", "batch.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_grumpkin.hip", "grumpkin_host.cpp", "kernels_brillig.hip", "kernels_ecdsa.hip", "shim.cpp", "node.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
          "-ffp-contract=off"] + os.environ.get("ACVM_EXTRA_FLAGS", "").split()
-
-
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "acvm_amd.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def _deps(depfile):
@@ -37,8 +29,6 @@ def _deps(depfile):
 
 
 def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
     objs = []
     jobs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
@@ -63,6 +53,8 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 6)) as ex:
             list(ex.map(run, jobs))
+    if not jobs and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
+        return LIB  # nothing was recompiled and the library is newer than every object
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd))

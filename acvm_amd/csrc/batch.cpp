@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include "batch.hpp"
+#include "display.hpp"
 
 static thread_local std::string g_last_error;
 int set_err(int code, const std::string &msg) {
@@ -419,14 +420,6 @@ static int batch_init(acvm_batch *b) {
         if (int rc = upload(&b->d_cls_offset[k], p.cls_offset[k])) return rc;
         if (int rc = upload(&b->d_cls_scratch_off[k], scratch_off)) return rc;
         if (need) HIPCHK(hipMalloc((void **)&b->d_cls_scratch[k], (size_t)need * b->Bp * 4));
-    }
-    // exact path: consecutive light opcodes form one span, every heavy opcode is its own launch
-    for (uint32_t oi = 0; oi < p.n_opcodes;) {
-        uint32_t cls = p.prog_class[oi], end = oi + 1;
-        if (cls == CLS_LIGHT)
-            while (end < p.n_opcodes && p.prog_class[end] == CLS_LIGHT) end++;
-        b->segments.push_back({cls, oi, end});
-        oi = end;
     }
     b->dp.prog = b->d_prog;
     b->dp.prog_offset = b->d_prog_offset;
@@ -1884,6 +1877,55 @@ int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, 
     return (int)v.size();
 } ABI_CATCH
 
+// The expression ExpressionHasTooManyUnknowns quotes for `instance`, as its Display text: witnesses the instance has assigned are read
+// back one by one (rare path: one failing instance).
+static std::string too_many_unknowns_expression(acvm_batch *b, const Circuit &circ, uint32_t instance, uint32_t opcode_index) {
+    if (opcode_index >= circ.opcodes.size()) return "";
+    const int32_t lane = b->slow_index[instance];
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    auto known = [&](uint32_t w) -> bool {
+        if (w >= b->plan.n_witnesses) return false;
+        if (lane < 0) return b->plan.producer[w] != 0xFFFFFFFFu;
+        uint32_t bitsw = 0;
+        if (hipMemcpy(&bitsw, b->d_assigned + (size_t)(w >> 5) * n_slow + lane, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        return (bitsw >> (w & 31)) & 1u;
+    };
+    auto value = [&](uint32_t w) {
+        uint8_t be[32] = {0};
+        fetch_one(b, instance, w, be);
+        return frh::from_be_bytes32_reduce(be, 32);
+    };
+    // ArithmeticSolver::evaluate (arithmetic.rs:212-239)
+    auto evaluate = [&](const Expr &e) {
+        Expr r;
+        for (const MulTerm &t : e.mul) {
+            const bool kl = known(t.l), kr = known(t.r);
+            if (kl && kr) r.qc = frh::add(r.qc, frh::mul(frh::mul(t.c, value(t.l)), value(t.r)));
+            else if (!kl && !kr) { if (!t.c.is_zero()) r.mul.push_back(t); }
+            else {
+                const FrH v = frh::mul(t.c, value(kl ? t.l : t.r));
+                if (!v.is_zero()) r.lin.push_back({v, kl ? t.r : t.l});
+            }
+        }
+        for (const LinTerm &t : e.lin) {
+            if (known(t.w)) r.qc = frh::add(r.qc, frh::mul(t.c, value(t.w)));
+            else if (!t.c.is_zero()) r.lin.push_back(t);
+        }
+        r.qc = frh::add(r.qc, e.qc);
+        return r;
+    };
+    const Opcode &o = circ.opcodes[opcode_index];
+    if (o.kind == OP_ARITHMETIC) return expression_display(evaluate(o.expr));
+    if (o.kind == OP_BRILLIG) {  // the first input, in order, that does not reduce to a constant (get_value, pwg/mod.rs:321-332)
+        auto stuck = [&](const Expr &e) { const Expr r = evaluate(e); return !r.mul.empty() || !r.lin.empty(); };
+        for (const BrilligInput &in : o.brillig->inputs) {
+            if (!in.is_array) { if (stuck(in.single)) return expression_display(in.single); }
+            else for (const Expr &e : in.arr) if (stuck(e)) return expression_display(e);
+        }
+    }
+    return "";
+}
+
 int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap) try {
     if (!b || !out || !cap) return set_err(ACVM_E_INVALID, "null argument");
     if (b->pending)
@@ -1910,7 +1952,13 @@ int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t i
     if (have >= 0) return snprintf(out, cap, "Assertion failed: %s", msg);
     switch (r.err) {
     case ACVM_ERR_MISSING_ASSIGNMENT: return snprintf(out, cap, "Cannot solve opcode: missing assignment for witness index %u", r.aux0);
-    case ACVM_ERR_TOO_MANY_UNKNOWNS: return snprintf(out, cap, "Cannot solve opcode: expression has too many unknowns");
+    case ACVM_ERR_TOO_MANY_UNKNOWNS: {
+        // OpcodeNotSolvable::ExpressionHasTooManyUnknowns(Expression) (pwg/mod.rs:72-78): the text carries the expression -- the opcode
+        // partially evaluated on the instance's map for Opcode::Arithmetic (arithmetic.rs:31,38-42), the input expression as written for
+        // Opcode::Brillig (brillig.rs:46-74)
+        const std::string e = c ? too_many_unknowns_expression(b, *c->c, instance, r.opcode_index) : std::string();
+        return snprintf(out, cap, "Cannot solve opcode: expression has too many unknowns %s", e.c_str());
+    }
     case ACVM_ERR_UNSUPPORTED_BLACKBOX:
         return snprintf(out, cap, "Backend does not currently support the %s opcode. ACVM does not currently have a fallback for this opcode.", func);
     case ACVM_ERR_UNSATISFIED: return snprintf(out, cap, "Cannot satisfy constraint");

@@ -42,7 +42,6 @@ struct acvm_circuit {
 };
 
 struct LaunchChunk { uint32_t first, count; bool coop = false; uint32_t lds_words = 0; };  // records [first, first+count) of a class's level-major list (coop: CLS_HASH records flagged PLAN_HASH_COOP_FLAG)
-struct ExactSegment { uint32_t cls, begin, end; };  // opcodes [begin, end): one light span or one heavy opcode
 
 struct acvm_batch {
     Plan plan;
@@ -59,7 +58,6 @@ struct acvm_batch {
     uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<std::vector<LaunchChunk>> cls_chunks[N_CLS];  // per level
-    std::vector<ExactSegment> segments;
     DeviceProgram dp{};
     uint32_t *d_event = nullptr;
     uint32_t *h_flag_count = nullptr;  // pinned, device-mapped

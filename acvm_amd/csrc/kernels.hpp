@@ -119,22 +119,14 @@ void launch_brillig_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, cons
 
 // ---- exact in-order kernels (ExactPolicy): one lane per flagged instance
 void launch_exact_init(hipStream_t s, const ExactLanes &L);
-// opcodes [op_begin, op_end) of class CLS_LIGHT in program order
-void launch_exact_span(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end,
-                       bool replay_memory);
 // opcodes [op_begin, op_end) of EVERY class but CLS_HOSTBB in one launch (kernels_brillig.hip exact_run_kernel); prog_class: device
 // array, OpClass per opcode; the class scratch buffers as the per-opcode kernels take them
 struct ExactScratch { uint32_t *hash, *grumpkin, *brillig; };
 void launch_exact_run(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t op_begin, uint32_t op_end, bool replay_memory,
                       const uint8_t *prog_class, const ExactScratch &sc);
-// one opcode of a heavy class
-void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
-void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
-void launch_exact_brillig(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch);
 void launch_grumpkin_probe(hipStream_t s, const GrumpkinTables &T, uint32_t what, uint32_t param, const uint32_t *in, uint32_t n_in, uint32_t *out);
 // ECDSA (kernels_ecdsa.hip)
 void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event);
-void launch_exact_ecdsa(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode);
 // caller-supplied BlackBoxFunctionSolver (kernels_ops.hip)
 void launch_hostbb_precheck(hipStream_t s, const ExactLanes &L, uint32_t opcode, const uint32_t *sel, uint32_t n_sel, uint8_t *active);
 void launch_hostbb_gather(hipStream_t s, const uint4 *W, uint64_t Bp, const uint32_t *ids, uint32_t first, uint32_t n_lanes, const uint32_t *sel,

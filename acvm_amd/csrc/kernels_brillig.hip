@@ -16,9 +16,6 @@ void launch_brillig_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, cons
                           const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch) {
     launch_record_level<BrilligOp, 64>(s, W, Bp, B, dp, offsets, scratch_off, n, event, scratch);
 }
-void launch_exact_brillig(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch) {
-    launch_record_exact<BrilligOp, 64>(s, W, Bp, dp, L, opcode, scratch);
-}
 
 // ---------------------------------------------------------------------------------------------- the exact path in one launch
 // Opcodes [op_begin, op_end) in program order for the lanes of the exact path (acvm/src/pwg/mod.rs:236-303 for the instances that left
@@ -26,7 +23,8 @@ void launch_exact_brillig(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProg
 // opcode's class. Round 2 launched one kernel per heavy opcode and one per span of light opcodes: on the 10^6-opcode circuit that is
 // ~20 000 launches of one wave each, 3 us apiece -- five diverging instances cost a tile +64 ms. Occupancy is irrelevant here (a handful
 // of lanes), so the kernel may be as fat as its fattest class. Opcodes before a lane's start only replay their memory side effects
-// (see exact_span_kernel). A caller-supplied BlackBoxFunctionSolver still splits the run at its opcodes (batch.cpp).
+// (a later opcode of the level schedule may already have overwritten the cell; their witness outputs are kept: init_assigned_kernel).
+// A caller-supplied BlackBoxFunctionSolver still splits the run at its opcodes (batch.cpp).
 __global__ void __launch_bounds__(64) exact_run_kernel(uint4 *W, uint64_t Bp, DeviceProgram dp, ExactLanes L, uint32_t op_begin, uint32_t op_end, uint32_t replay_memory,
                                                        const uint8_t *__restrict__ prog_class, ExactScratch sc) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;

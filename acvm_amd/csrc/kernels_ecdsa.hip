@@ -14,8 +14,5 @@ struct EcdsaOp {
 void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event) {
     launch_record_level<EcdsaOp, 64>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
 }
-void launch_exact_ecdsa(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode) {
-    launch_record_exact<EcdsaOp, 64>(s, W, Bp, dp, L, opcode, nullptr);
-}
 
 }  // namespace acvm

@@ -17,9 +17,6 @@ void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
                            const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch) {
     launch_record_level<GrumpkinOp, 64>(s, W, Bp, B, dp, offsets, scratch_off, n, event, scratch);
 }
-void launch_exact_grumpkin(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch) {
-    launch_record_exact<GrumpkinOp, 64>(s, W, Bp, dp, L, opcode, scratch);
-}
 
 // ---------------------------------------------------------------------------------------------- Pedersen, 4 waves per instance group
 // One Pedersen record is a chain of (n + 1) hash_pairs, each 2 x 29 dependent table additions plus a normalisation: a single

@@ -110,9 +110,6 @@ void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, co
         done += m;
     }
 }
-void launch_exact_hash(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode, uint32_t *scratch) {
-    launch_record_exact<HashOp, 64>(s, W, Bp, dp, L, opcode, scratch);
-}
 
 // ------------------------------------------------------------------------------------------ witness-map digest
 // SURVEY 8d (config 5): callers that do not want the full map back keep the return witnesses and a 32-byte digest per instance.

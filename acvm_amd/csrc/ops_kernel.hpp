@@ -1,9 +1,9 @@
-// ops_kernel.hpp -- the two kernel skeletons every non-arithmetic record class is instantiated in:
+// ops_kernel.hpp -- the kernel skeleton every non-arithmetic record class is instantiated in:
 //   record_level_kernel<Op>  FastPolicy: grid = (instances / block, records of one dependency level); errors only flag
 //                            the instance (event word = min failing opcode index) for the exact path
-//   record_exact_kernel<Op>  ExactPolicy: one opcode, one lane per flagged instance that is still InProgress and whose
-//                            event is not after this opcode; errors become the instance's final result
-// Op::run(policy, record, program, per-record scratch) is the templated device routine of the class.
+// Op::run(policy, record, program, per-record scratch) is the templated device routine of the class. The exact path
+// (ExactPolicy: per-instance assigned set, errors become the instance's final result) runs every class in ONE kernel,
+// kernels_brillig.hip exact_run_kernel.
 #pragma once
 #include "kernels.hpp"
 #include "ops_common.hpp"
@@ -43,22 +43,6 @@ __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t 
 }
 
 template <class Op, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) record_exact_kernel(uint4 *W, uint64_t Bp, DeviceProgram dp, ExactLanes L, uint32_t opcode,
-                                                             uint32_t *scratch) {
-    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= L.n_slow) return;
-    if (L.results[t].status != 1u || L.start_opcode[t] > opcode) return;
-    const uint32_t *__restrict__ rec = dp.prog + dp.prog_offset[opcode];
-    ExactPolicy p{W, Bp, L.slow_ids[t], L.assigned, L.n_slow, t};
-    const OpResult r = Op::run(p, rec, dp, scratch, &L.results[t], &L, t);
-    if (r.err == DE_WAIT_FOREIGN_CALL) {  // ACVMStatus::RequiresForeignCall: the instruction pointer stays on this opcode
-        L.results[t].status = 3u;
-        L.results[t].opcode_index = opcode;
-        L.results[t].x0 = r.x0;
-    } else if (r.err) exact_fail(L, t, opcode, r);
-}
-
-template <class Op, int BLOCK>
 static void launch_record_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                                 const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch) {
     if (!n || !B) return;
@@ -69,11 +53,4 @@ static void launch_record_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B
         done += m;
     }
 }
-template <class Op, int BLOCK>
-static void launch_record_exact(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram &dp, const ExactLanes &L, uint32_t opcode,
-                                uint32_t *scratch) {
-    if (!L.n_slow) return;
-    hipLaunchKernelGGL((record_exact_kernel<Op, BLOCK>), dim3((L.n_slow + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, W, Bp, dp, L, opcode, scratch);
-}
-
 }  // namespace acvm

@@ -300,7 +300,9 @@ int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, 
  * the failing location -- the opcode of UnsatisfiedConstrain / IndexOutOfBounds, the last call-stack entry of
  * BrilligFunctionFailed -- has an assert message in `c`, else the Display text of the OpcodeResolutionError
  * (acvm/src/pwg/mod.rs:100-114). Returns the full length; 0 and an empty string for an instance that did not fail.
- * (ExpressionHasTooManyUnknowns is reported without the expression text.)
+ * ExpressionHasTooManyUnknowns carries its expression like the reference's Display: the opcode partially evaluated on the instance's map
+ * for Opcode::Arithmetic (acvm/src/pwg/arithmetic.rs:31,38-42), the offending input expression for Opcode::Brillig (brillig.rs:46-74), in the
+ * formats of acir_field/src/generic_ark.rs:13-74 and acir/src/circuit/opcodes.rs:88-102 (needs `c`; without it the text ends after "unknowns ").
  */
 int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap);
 /*

@@ -127,3 +127,63 @@ def test_witness_map_digest_with_black_box_outputs(oracle):
     batch.free()
     for j in range(B):
         assert bytes(got[j]) == oracle.witness_map_digest(oasg[j], ovals[j]), f"instance {j} (status {ores[j].status})"
+
+
+# ---- OpcodeNotSolvable::ExpressionHasTooManyUnknowns(Expression): the Display text carries the expression (pwg/mod.rs:72-78)
+_SUP = "⁰¹²³⁴⁵⁶⁷⁸⁹"
+
+
+def field_display(v):
+    """impl Display for FieldElement, acir_field/src/generic_ark.rs:13-74, restated with Python integers"""
+    v %= P
+    if v == 0:
+        return "0"
+    minus = (P - v) % P
+    neg = len(str(minus)) < len(str(v))
+    s = minus if neg else v
+    out = "-" if neg else ""
+    if bin(s).count("1") == 1:
+        bit = s.bit_length() - 1
+        return out + (str(1 << bit) if bit < 4 else "2" + "".join(_SUP[int(d)] for d in str(bit)))
+    for power in (64, 32, 16, 8, 4):
+        if s % (1 << power) == 0:
+            return out + "2" + "".join(_SUP[int(d)] for d in str(power)) + "×" + str(s >> power)
+    return out + str(s)
+
+
+def expr_display(mul, lin, qc):
+    """impl Display for Expression (expression/mod.rs:40-48) over Opcode::Arithmetic's Debug text (circuit/opcodes.rs:88-102)"""
+    if not mul and len(lin) == 1 and lin[0][0] % P == 1 and qc % P == 0:
+        return f"x{lin[0][1]}"
+    return "%EXPR [ " + "".join(f"({field_display(c)}, _{a}, _{b}) " for c, a, b in mul) + "".join(f"({field_display(c)}, _{w}) " for c, w in lin) + field_display(qc) + " ]%"
+
+
+def test_field_display_shapes():
+    assert [field_display(v) for v in (0, 1, 2, 8, 16, 1 << 64, P - 1, P - 16, 3 << 64, 5 << 32, 48, 7, 1 << 100)] == \
+        ["0", "1", "2", "8", "2⁴", "2⁶⁴", "-1", "-2⁴", "2⁶⁴×3", "2³²×5", "2⁴×3", "7", "2¹⁰⁰"]
+
+
+def test_too_many_unknowns_quotes_the_evaluated_expression():
+    from acvm_amd.acir import Brillig
+    # opcode 0: 3*w1*w2 + 5*w1*w8 + 0*w9*w9 + 7*w3 + 2*w8 + 11*w9 - (2^64)*w2 + 100 = 0 with w8, w9 unknown: evaluate() folds the known parts into the
+    # constant, turns 5*w1*w8 into a linear term on w8 (dropped where w1 == 0), keeps the unknown linear terms in order
+    e0 = E([(3, 1, 2), (5, 1, 8), (0, 9, 9)], [(7, 3), (2, 8), (11, 9), (P - (1 << 64), 2)], 100)
+    circ = Circuit(9, [e0])
+    rows = [[4, 6, 9], [0, 1, 2], [P - 1, 1 << 70, 5]]
+    c, b = solve(circ, [1, 2, 3], rows)
+    for j, (w1, w2, w3) in enumerate(rows):
+        lin = ([((5 * w1) % P, 8)] if (5 * w1) % P else []) + [(2, 8), (11, 9)]
+        qc = (3 * w1 * w2 + 7 * w3 - (1 << 64) * w2 + 100) % P
+        assert b.error_string(j) == "Cannot solve opcode: expression has too many unknowns " + expr_display([], lin, qc), j
+    # two unknown multiplicands stay a mul term; a bare unknown witness prints as x{w}
+    circ = Circuit(9, [E([(P - 2, 8, 9)], [(1, 1)], 0)])
+    c, b = solve(circ, [1], [[5]])
+    assert b.error_string(0) == "Cannot solve opcode: expression has too many unknowns " + expr_display([(P - 2, 8, 9)], [], 5)
+    # Brillig: the input expression as written (brillig.rs:46-74), the first one that does not reduce to a constant
+    br = Brillig(inputs=[E.from_witness(1), [E([], [(1, 1), (3, 9)], 4), E.from_witness(8)], E.from_witness(8)], outputs=[7], bytecode=[("Stop",)])
+    circ = Circuit(9, [br])
+    c, b = solve(circ, [1], [[5]])
+    assert b.error_string(0) == "Cannot solve opcode: expression has too many unknowns " + expr_display([], [(1, 1), (3, 9)], 4)
+    br = Brillig(inputs=[E.from_witness(8)], outputs=[7], bytecode=[("Stop",)])
+    c, b = solve(Circuit(9, [br]), [1], [[5]])
+    assert b.error_string(0) == "Cannot solve opcode: expression has too many unknowns x8"

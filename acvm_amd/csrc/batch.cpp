@@ -812,7 +812,9 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
     launch_exact_finish(s, L, b->stepping ? p.n_opcodes : 0u);
     HIPCHK(hipGetLastError());
     b->slow_res.resize(n_slow);
-    HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
+    // (a copy into pageable host memory blocks the caller until the stream has drained: an asynchronous job fetches its lanes' results
+    // when it is collected, batch_finish_pending)
+    if (!b->pending) HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s));
     b->pend_host_valid = false;
     return 0;
 }
@@ -1333,8 +1335,8 @@ int acvm_batch_solve(acvm_batch_t *b) try {
         b->slow_start.resize(n_slow);
         uint32_t min_start = 0xFFFFFFFFu;
         for (uint32_t t = 0; t < n_slow; t++) {
-            // side table (slot reuse, asynchronous job): it does not hold what ran before the event: the lane starts over from its initial witnesses
-            b->slow_start[t] = b->side() ? 0u : b->h_event[b->slow_ids[t]];
+            // slot reuse: the level table no longer holds what ran before the event: the lane starts over from its initial witnesses
+            b->slow_start[t] = b->reuse() ? 0u : b->h_event[b->slow_ids[t]];
             min_start = std::min(min_start, b->slow_start[t]);
         }
         HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
@@ -1368,8 +1370,12 @@ int acvm_batch_solve(acvm_batch_t *b) try {
                 }
                 b->x_scratch_lanes = b->x_cap;
             }
-            // (on the batch's stream: the rows of the initial witnesses are read before the next tile's import overwrites them)
-            launch_gather_initial(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, b->d_init_ids, b->reuse() ? b->d_init_rows : b->d_init_ids, (uint32_t)p.initial_ids.size(), b->d_slow_ids, n_slow);
+            // (on the batch's stream: the level table is read before the next tile's import overwrites it)
+            if (b->reuse()) launch_gather_initial(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, b->d_init_ids, b->d_init_rows, (uint32_t)p.initial_ids.size(), b->d_slow_ids, n_slow);
+            else {  // the whole column of every flagged instance, plain values: the job resumes at the instance's event like the in-place path
+                launch_gather_columns(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, p.n_witnesses, b->d_slow_ids, n_slow, b->d_unscale_index, b->d_unscale_consts);
+                launch_gather_columns(s, b->d_Memx, b->x_cap, b->d_Mem, b->Bp, p.mem_cells, b->d_slow_ids, n_slow, nullptr, nullptr);
+            }
         } else
         launch_unscale_slow(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->unscale);  // the exact kernels work on plain values
         if (go_async) {  // everything below runs on the side stream, behind the gather
@@ -1504,7 +1510,9 @@ int batch_finish_pending(acvm_batch *b, ExactOutcome *out) {
     if (!b->pending) return 0;
     HIPCHK(hipSetDevice(b->device));
     const uint32_t n_slow = (uint32_t)b->slow_ids.size();
-    HIPCHK(hipStreamSynchronize(b->stream_x));  // (run_exact_segments ended with the copy of the lanes' results into slow_res)
+    b->slow_res.resize(n_slow);
+    HIPCHK(hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, b->stream_x));
+    HIPCHK(hipStreamSynchronize(b->stream_x));
     int rc = retry_device_limits(b, n_slow, true, 0xFFFFFFFFu);
     if (!rc && out) {
         rc = side_table_outcome(b, out);

@@ -267,6 +267,26 @@ __global__ void gather_initial_kernel(uint4 *__restrict__ Wx, uint64_t Bpx, cons
     const uint32_t k = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
     fr_store(Wx, init_ids[k], Bpx, t, fr_load(W, init_rows[k], Bp, slow_ids[t]));
 }
+// asynchronous exact path without slot reuse (batch.cpp): the WHOLE column of every flagged instance moves into the side table (lane t =
+// the t-th flagged instance), scaled witnesses back to plain values on the way, so that the exact kernels can resume at the instance's
+// event exactly as they would in place while the level table is handed to the next tile. rows = witnesses (or memory cells: u.index null)
+__global__ void __launch_bounds__(256) gather_columns_kernel(uint4 *__restrict__ Wx, uint64_t Bpx, const uint4 *__restrict__ W, uint64_t Bp, uint32_t n_rows,
+                                                             const uint32_t *__restrict__ slow_ids, uint32_t n_slow, const uint32_t *__restrict__ unscale_index,
+                                                             const uint32_t *__restrict__ unscale_consts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n_rows * n_slow) return;
+    const uint32_t w = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
+    Fr x = fr_load(W, w, Bp, slow_ids[t]);
+    const uint32_t ui = unscale_index ? unscale_index[w] : 0xFFFFFFFFu;
+    if (ui != 0xFFFFFFFFu) x = fr_mul(x, fr_const(unscale_consts, ui));
+    fr_store(Wx, w, Bpx, t, x);
+}
+void launch_gather_columns(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, uint32_t n_rows, const uint32_t *slow_ids, uint32_t n_slow,
+                           const uint32_t *unscale_index, const uint32_t *unscale_consts) {
+    const uint64_t n = (uint64_t)n_rows * n_slow;
+    if (!n) return;
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wx, Bpx, W, Bp, n_rows, slow_ids, n_slow, unscale_index, unscale_consts);
+}
 void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,
                            const uint32_t *slow_ids, uint32_t n_slow) {
     const uint64_t n = (uint64_t)n_init * n_slow;

@@ -68,9 +68,9 @@ struct BrVm {
 };
 
 // evaluate_binary_bigint_op through the VM: a panic of the reference stops the lane (ops_light.hpp int_op_core)
-static inline __device__ __noinline__ Fr brillig_int_op(BrVm &vm, uint32_t op, uint32_t bits, const Fr &fa, const Fr &fb) {
+static inline __device__ __noinline__ Fr brillig_int_op(BrVm &vm, uint32_t op, uint32_t bits, const Fr &fa, const Fr &fb, const Fr &pow2) {
     uint32_t panic = 0;
-    const Fr r = int_op_core(op, bits, fa, fb, panic);
+    const Fr r = int_op_core(op, bits, fa, fb, panic, &pow2);
     if (panic) vm.panic(panic);
     return r;
 }
@@ -345,7 +345,9 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
         case BRO_BINARY_INT_OP: {
             const Fr x = vm.reg_get(b), y = vm.reg_get(c);
             if (vm.status) break;
-            const Fr v = brillig_int_op(vm, ins[4] & 0xffu, ins[4] >> 8, x, y);
+            // (word 6: the constant 2^bit_size mod p of a Sub wider than 256 bits, else unused)
+            const uint32_t bits = ins[4] >> 8;
+            const Fr v = brillig_int_op(vm, ins[4] & 0xffu, bits, x, y, bits > 256u && (ins[4] & 0xffu) == 1u ? fr_const(dp.consts, ins[6]) : fr_zero());
             if (!vm.status) vm.reg_set(a, v);
             break;
         }

@@ -464,6 +464,26 @@ __device__ __forceinline__ Fr int_mul_lo(const Fr &a, const Fr &b) {  // low 256
     for (int i = 0; i < 8; i++) o.v[i] = r[i];
     return o;
 }
+__device__ __forceinline__ Fr int_mul_full(const Fr &a, const Fr &b, Fr &hi) {  // a * b = hi 2^256 + (returned low half)
+    uint32_t r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            c += (uint64_t)a.v[i] * b.v[k] + r[i + k];
+            r[i + k] = (uint32_t)c;
+            c >>= 32;
+        }
+        r[i + 8] = (uint32_t)c;
+    }
+    Fr lo;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { lo.v[i] = r[i]; hi.v[i] = r[8 + i]; }
+    return lo;
+}
 __device__ __forceinline__ uint32_t limb_or_zero(const Fr &a, int idx) {
     uint32_t r = 0;
 #pragma unroll
@@ -507,22 +527,37 @@ __device__ __forceinline__ bool int_to_signed(const Fr &a, uint32_t bits, Fr &ma
 
 // evaluate_binary_bigint_op (arithmetic.rs:23-81) + the conversion back to a field element (from_be_bytes_reduce)
 // `panic` receives a BrPanic code (and the result is meaningless) where the reference panics
-static inline __device__ Fr int_op_core(uint32_t op, uint32_t bits, const Fr &fa, const Fr &fb, uint32_t &panic) {
+// bit_size > 256 (the reference's BigUint takes any size; operands are field elements < p < 2^254): the masks are no-ops on 256-bit values,
+// so only two ops still see the modulus 2^bits: Mul, whose 512-bit product is masked before it is reduced mod p, and Sub with a < b,
+// whose result 2^bits + a - b survives only as its residue (2^bits mod p) + a - b -- `pow2` = the Montgomery form of 2^bits mod p, a
+// constant the planner computes per instruction. SignedDiv sees two non-negative numbers. Shifts panic above 128 bits either way.
+static inline __device__ Fr int_op_core(uint32_t op, uint32_t bits, const Fr &fa, const Fr &fb, uint32_t &panic, const Fr *pow2 = nullptr) {
     Fr a = fr_to_canonical(fa), b = fr_to_canonical(fb), r = fr_zero();
-    if (bits > 256u) { panic = BP_BITS_256; return r; }
     switch (op) {
     case 0: fr_add256(r, a, b); r = int_mask(r, bits); break;  // a, b < 2^254: no carry out of 256 bits
     case 1: {  // (2^bits + a - b) % 2^bits; BigUint underflow when b > 2^bits + a
         const bool borrow = fr_sub256(r, a, b) != 0;
+        if (borrow && bits > 256u) return pow2 ? fr_add(*pow2, fr_sub(fa, fb)) : (panic = BP_BITS_256, fr_zero());
         if (borrow && bits < 256u && int_cmp(int_neg(r), int_pow2(bits)) > 0) { panic = BP_SUB_OVERFLOW; return fr_zero(); }
         r = int_mask(r, bits);
         break;
     }
-    case 2: r = int_mask(int_mul_lo(a, b), bits); break;
+    case 2:
+        if (bits > 256u) {  // (a b mod 2^bits) mod p = lo + hi 2^256 with the high half masked at bits - 256
+            Fr hi;
+            r = int_mul_full(a, b, hi);
+            hi = int_mask(hi, bits - 256u);
+            const Fr c256 = {{0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u}};  // 2^256 mod p
+            return fr_add(fr_from_canonical(canon_reduce(r)), fr_mul(fr_from_canonical(canon_reduce(hi)), fr_from_canonical(c256)));
+        }
+        r = int_mask(int_mul_lo(a, b), bits);
+        break;
     case 3: {  // SignedDiv
         if (bits == 0u) { panic = BP_SUB_OVERFLOW; return r; }
         Fr ma, mb, q, rem;
-        const bool sa = int_to_signed(a, bits, ma), sb = int_to_signed(b, bits, mb);
+        bool sa = false, sb = false;
+        if (bits > 256u) { ma = a; mb = b; }  // a, b < 2^254 <= 2^(bits - 1): both non-negative
+        else { sa = int_to_signed(a, bits, ma); sb = int_to_signed(b, bits, mb); }
         if (fr_is_zero(mb)) { panic = BP_DIV_ZERO; return r; }
         canon_divrem(ma, mb, q, rem);
         if (!((sa != sb) && !fr_is_zero(q))) r = q;
@@ -634,7 +669,8 @@ __device__ __forceinline__ OpResult op_brillig_sl(const P &p, const uint32_t *__
                     }
                 } else {
                     uint32_t panic = 0;
-                    v = int_op_core(sub, ins[1], x, y, panic);
+                    const Fr pow2 = ins[1] > 256u && sub == 1u ? fr_const(consts, ins[2]) : fr_zero();  // 2^bit_size mod p of a wide Sub (plan.cpp)
+                    v = int_op_core(sub, ins[1], x, y, panic, &pow2);
                     if (panic && act) { bad = true; next = 0xFFFFFFFFu; }
                 }
             }

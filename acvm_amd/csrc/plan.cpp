@@ -169,6 +169,15 @@ struct Reads {
 };
 
 uint32_t clamp_reg(uint64_t r) { return r > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)r; }
+// 2^bits mod p (Brillig's BinaryIntOp::Sub at a bit size beyond 256: brillig_vm/src/arithmetic.rs:34, ops_light.hpp int_op_core)
+FrH pow2_mod_p(uint32_t bits) {
+    FrH base = frh::from_u64(2), acc = frh::one();
+    for (uint32_t e = bits; e; e >>= 1) {
+        if (e & 1) acc = frh::mul(acc, base);
+        base = frh::mul(base, base);
+    }
+    return acc;
+}
 
 // =========================================================================== straight-line Brillig
 // The stdlib's integer fallbacks (stdlib/src/blackbox_fallbacks/uint.rs:212-260) and most compiler-generated helper calls (inversion and
@@ -191,10 +200,7 @@ void emit_straight_line(const BrilligCall &b, uint32_t oi, ConstPool &pool, std:
     for (size_t k = 0; k < n; k++) {
         const BrilligOp &op = b.bytecode[k];
         switch (op.op) {
-        case BR_BINARY_INT_OP:
-            if (op.bit_size > 256) return;  // (the VM words that panic)
-            [[fallthrough]];
-        case BR_BINARY_FIELD_OP: use(op.a); use(op.b); use(op.c); break;
+        case BR_BINARY_INT_OP: case BR_BINARY_FIELD_OP: use(op.a); use(op.b); use(op.c); break;
         case BR_CONST: use(op.a); break;
         case BR_MOV: use(op.a); use(op.b); break;
         case BR_JUMP_IF: case BR_JUMP_IF_NOT:
@@ -222,6 +228,7 @@ void emit_straight_line(const BrilligCall &b, uint32_t oi, ConstPool &pool, std:
         switch (op.op) {
         case BR_BINARY_FIELD_OP: case BR_BINARY_INT_OP:
             kind = op.op == BR_BINARY_INT_OP ? 1u : 0u; sub = op.sub_op; dst = slot(op.a); ra = slot(op.b); rb = slot(op.c); x = op.bit_size;
+            if (kind == 1 && sub == 1 && op.bit_size > 256) cidx = pool.intern(pow2_mod_p(op.bit_size));  // a wide Sub: 2^bits mod p
             break;
         case BR_CONST: kind = 2; dst = slot(op.a); cidx = pool.intern(op.value); break;
         case BR_MOV: kind = 3; dst = slot(op.a); ra = slot(op.b); break;
@@ -483,7 +490,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     switch (op.op) {
                     case BR_BINARY_FIELD_OP: case BR_BINARY_INT_OP:
                         w[1] = reg(op.a); w[2] = reg(op.b); w[3] = reg(op.c);
+                        // (bit sizes of 512 and more all behave alike -- no operation can reach the modulus 2^bits -- but for the constant below)
                         w[4] = op.sub_op | (op.op == BR_BINARY_INT_OP ? std::min<uint32_t>(op.bit_size, 0xFFFFFFu) << 8 : 0u);
+                        if (op.op == BR_BINARY_INT_OP && op.sub_op == 1 && op.bit_size > 256) w[6] = pool.intern(pow2_mod_p(op.bit_size));  // Sub: 2^bits mod p
                         break;
                     case BR_JUMP_IF_NOT: case BR_JUMP_IF:
                         w[1] = reg(op.a); w[5] = (uint32_t)std::min<uint64_t>(op.location, 0xFFFFFFFFull);

@@ -8,7 +8,8 @@
  *   /root/reference/brillig_vm/src/memory.rs:4-45       reads out of range panic, writes grow with 0
  *   /root/reference/brillig_vm/src/black_box.rs:42-165  black box ops
  *   /root/reference/acvm/src/pwg/brillig.rs:20-150      BrilligSolver::solve, zero_out_brillig_outputs
- * Integer ops support bit_size <= 256 (the reference's BigUint is unbounded; larger sizes report E_PANIC here).
+ * Integer ops take any bit_size like the reference's BigUint arithmetic (operands are field elements < p < 2^254, so past 256 bits only
+ * Sub and Mul can still see the modulus 2^bit_size; see int_op).
  * Pinned by tests/test_oracle_brillig.py against brillig_vm/src/arithmetic.rs:149-234 known answers,
  * acvm/tests/solver.rs:308-608 and acvm_js/test/shared/{foreign_call,complex_foreign_call}.ts.
  */
@@ -130,6 +131,18 @@ static int to_signed(const uint64_t a[4], uint32_t bits, uint64_t mag[4]) {
     return lt;
 }
 
+/* 2^bits mod p for any u32 bits (square and multiply) */
+static void fr_pow2_bits(fr_t *out, uint32_t bits) {
+    fr_t base, acc;
+    fr_from_u64(&base, 2);
+    fr_from_u64(&acc, 1);
+    for (uint32_t e = bits; e; e >>= 1) {
+        if (e & 1) fr_mul(&acc, &acc, &base);
+        fr_mul(&base, &base, &base);
+    }
+    *out = acc;
+}
+
 static void vm_panic(vm_t *vm, const char *m) { vm->status = 4; snprintf(vm->msg, sizeof vm->msg, "%s", m); }
 
 /* arithmetic.rs:23-81 evaluate_binary_bigint_op */
@@ -138,7 +151,9 @@ static void int_op(vm_t *vm, uint32_t op, uint32_t bits, const fr_t *fa, const f
     fr_to_canonical(fa, a);
     fr_to_canonical(fb, b);
     memset(r8, 0, sizeof r8);
-    if (bits > 256) { vm_panic(vm, "bit_size > 256 is not supported"); return; }
+    /* bit_size > 256 (the reference's BigUint takes any size; operands are < p < 2^254): Add cannot wrap; the masks of the other ops
+     * are no-ops on 256-bit values; Mul masks its 512-bit product; Sub with a < b is 2^bits + a - b, a number of `bits` bits that only its
+     * residue mod p survives (from_be_bytes_reduce): (2^bits mod p) + a - b in the field; SignedDiv sees two non-negative numbers. */
     switch (op) {
     case BI_ADD: {
         u128 c = 0;
@@ -148,6 +163,15 @@ static void int_op(vm_t *vm, uint32_t op, uint32_t bits, const fr_t *fa, const f
         break;
     }
     case BI_SUB: { /* (2^bits + a - b) % 2^bits ; BigUint underflow panics when b > 2^bits + a */
+        if (bits > 256) {
+            fr_t d;
+            fr_sub(&d, fa, fb);
+            if (cmp4(a, b) >= 0) { *out = d; return; }
+            fr_t p2;
+            fr_pow2_bits(&p2, bits);
+            fr_add(out, &p2, &d);
+            return;
+        }
         uint64_t t[5] = {a[0], a[1], a[2], a[3], 0}, bb[5] = {b[0], b[1], b[2], b[3], 0};
         u128 c = (u128)t[bits / 64] + (1ULL << (bits % 64));
         t[bits / 64] = (uint64_t)c;
@@ -182,7 +206,9 @@ static void int_op(vm_t *vm, uint32_t op, uint32_t bits, const fr_t *fa, const f
     case BI_SIGNED_DIV: {
         if (bits == 0) { vm_panic(vm, "attempt to subtract with overflow"); return; }
         uint64_t ma[4], mb[4], q[4], r[4];
-        int sa = to_signed(a, bits, ma), sb = to_signed(b, bits, mb);
+        int sa = 0, sb = 0;
+        if (bits > 256) { memcpy(ma, a, 32); memcpy(mb, b, 32); } /* a, b < 2^254 <= 2^(bits-1): both non-negative */
+        else { sa = to_signed(a, bits, ma); sb = to_signed(b, bits, mb); }
         if (is_zero4(mb)) { vm_panic(vm, "attempt to divide by zero"); return; }
         divrem4(ma, mb, q, r); /* BigInt division truncates toward zero */
         int neg = (sa ^ sb) && !is_zero4(q);

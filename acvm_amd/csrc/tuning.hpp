@@ -33,7 +33,7 @@ struct Tuning {
     // with the first value; an instance that reaches it continues on the exact path, which retries with the limit raised step by
     // step up to the second value; beyond that acvm_batch_solve returns ACVM_E_UNSUPPORTED (never a per-instance failure the
     // reference would not report).
-    int64_t brillig_steps_log2 = 22, brillig_steps_max_log2 = 28;
+    int64_t brillig_steps_log2 = 22, brillig_steps_max_log2 = 26;
     int64_t brillig_call_depth = 64, brillig_call_depth_max = 1 << 16;
     int64_t brillig_mem_max_log2 = 22;  // cells of one lane's memory on the exact path at most (32 B each)
     // ---- tables (grumpkin_host.cpp)

@@ -13,7 +13,7 @@ Coefficients: 50 % from {1, -1}, 50 % uniform Fr, never 0. Terms are sorted like
 """
 import numpy as np
 
-from .acir import Circuit, Expression, P
+from .acir import BlackBoxFuncCall, Circuit, Expression, FunctionInput, P
 
 MASK = (1 << 64) - 1
 
@@ -257,6 +257,46 @@ def grumpkin_rows(B, signed=None, n_pedersen_inputs=2, seed=0xAC1D0004, first_in
 
 def rows_to_bytes_fast(rows) -> bytes:
     return values_from_rows(rows)
+
+
+# the two ECDSA vectors of the reference's own tests (blackbox_solver/src/lib.rs:216-284): hashed message, public key, signature
+ECDSA_VECTORS = {
+    "EcdsaSecp256k1": dict(z="3a73f4123a5cd2121f21cd7e8d358835476949d035d9c2da6806b4633ac8c1e2", x="a0434d9e47f3c86235477c7b1ae6ae5d3442d49b1943c2b752a68e2a47e247c7",
+                           y="893aba425419bc27a3b6c7e693a24c696f794c2ed877a1593cbee53b037368d7",
+                           sig="e5081c80ab427dc370346f4a0e31aa2bad8d9798c38061db9ae55a4e8df454fd28119894344e71b78770cc931d61f480ecbb0b89d6eb69690161e49a715fcd55"),
+    "EcdsaSecp256r1": dict(z="54705ba3baafdbdfba8c5f9a70f7a89bee98d906b53e31074da7baecdc0da9ad", x="550f471003f3df97c3df506ac797f6721fb1a1fb7b8f6f83d224498a65c88e24",
+                           y="136093d7012e509a73715cbd0b00a3cc0ff4b5c01b3ffa196ab1fb327036b8e6",
+                           sig="2c70a8d084b62bfc5ce03641caf9f72ad4da8c81bfe6ec9487bb5e1bef62a13218ad9ee29eaf351fdc50f1520c425e9b908a07278b43b0ec7b872778c14e0784"),
+}
+
+
+def ecdsa_circuit():
+    """one EcdsaSecp256k1 and one EcdsaSecp256r1 opcode (blackbox/signature/ecdsa.rs): 2 x 160 byte-wide inputs, one output each"""
+    ops, ids = [], []
+    w = 1
+    for name in ("EcdsaSecp256k1", "EcdsaSecp256r1"):
+        x, y, sig, msg = [list(range(w + a, w + b)) for a, b in ((0, 32), (32, 64), (64, 128), (128, 160))]
+        ids += list(range(w, w + 160))
+        w += 160
+        ops.append((name, x, y, sig, msg))
+    out0 = w
+    circ = Circuit(out0 + 1, [BlackBoxFuncCall(name, {"public_key_x": [FunctionInput(v, 8) for v in x], "public_key_y": [FunctionInput(v, 8) for v in y],
+                                                    "signature": [FunctionInput(v, 8) for v in sig], "hashed_message": [FunctionInput(v, 8) for v in msg],
+                                                    "output": out0 + k}) for k, (name, x, y, sig, msg) in enumerate(ops)],
+                   private_parameters=ids, return_values=[out0, out0 + 1])
+    return circ, ids
+
+
+def ecdsa_batch(B, first_instance=0):
+    """the reference's two vectors in every instance; every 7th instance (of the global batch) has one message bit flipped: its signatures do not verify"""
+    import numpy as np
+    good = np.frombuffer(b"".join(bytes.fromhex(ECDSA_VECTORS[n][k]) for n in ("EcdsaSecp256k1", "EcdsaSecp256r1") for k in ("x", "y", "sig", "z")), dtype=np.uint8)
+    vals = np.zeros((B, 320, 32), dtype=np.uint8)
+    vals[:, :, 31] = good[None, :]
+    bad = (np.arange(first_instance, first_instance + B) % 7) == 0
+    vals[bad, 140, 31] ^= 1
+    vals[bad, 300, 31] ^= 1
+    return vals.tobytes()
 
 
 def arith_pedersen_circuit(n_gates=10000, n_pedersen=8, n_in=16, seed=0xAC1D0006):

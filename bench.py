@@ -10,6 +10,7 @@ instance of the global batch (per tile: import of the resident inputs, then the 
 Other workloads (parity-test configs, measured for DESIGN.md; 2^16 instances per GPU unless --total-log2 is given):
     --workload hash            config 3: SHA256 + Keccak256 + RANGE circuit
     --workload grumpkin        config 4: Pedersen + FixedBaseScalarMul + SchnorrVerify circuit
+    --workload ecdsa           EcdsaSecp256k1 + EcdsaSecp256r1
     --workload arith_pedersen  the north-star shape: 10k arithmetic gates + 8 Pedersen commitments
     --workload mixed           the config-5 opcode mix at --gates opcodes (every kernel class in one circuit)
     --workload config5         config 5 at circuit size: the 10^6-opcode mixed circuit (--gates), tiles of --tile-log2 (default 2^12) instances,
@@ -72,6 +73,10 @@ def make_workload(args, first, n):
         arr = np.frombuffer(synth.values_from_rows(base), dtype=np.uint8).reshape(len(base), -1)
         values = arr[(first + np.arange(n)) % len(base)].tobytes()
         name = "Pedersen + FixedBaseScalarMul + SchnorrVerify ACIR"
+    elif args.workload == "ecdsa":
+        circ, ids = synth.ecdsa_circuit()
+        values = synth.ecdsa_batch(n, first_instance=first)
+        name = "EcdsaSecp256k1 + EcdsaSecp256r1 ACIR (the reference's two vectors, every 7th instance tampered)"
     elif args.workload == "arith_pedersen":
         circ, ids = synth.arith_pedersen_circuit(args.gates, args.pedersen)
         values = synth.witness_batch(n, seed=0xAC1D0006, first_instance=first)
@@ -233,7 +238,7 @@ def cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_
     from oracle import binding as ob
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
-    per = {"arith": 96, "hash": 1024, "grumpkin": 256, "arith_pedersen": 48, "mixed": 32, "config5": 1}[args.workload]  # about a second of all host cores
+    per = {"arith": 96, "hash": 1024, "grumpkin": 256, "ecdsa": 64, "arith_pedersen": 48, "mixed": 32, "config5": 1}[args.workload]  # about a second of all host cores
     sample = args.cpu_sample or min(tile, max(threads if args.workload == "config5" else 64, per * threads))
     sh.load_tile(0)
     batch.solve()
@@ -335,7 +340,7 @@ def run_leg(name, steps=3, warmup=2, pmc=True):
     """one of the other workloads as a short leg of the default run (N = 1): 2^16 instances, one tile, parity-checked"""
     import acvm_amd
     from acvm_amd import tiling
-    a = argparse.Namespace(workload=name, gates=10000, pedersen=8, cpu_sample={"hash": 4096, "grumpkin": 512, "arith_pedersen": 256}.get(name, 0), eff_tile_log2=16)
+    a = argparse.Namespace(workload=name, gates=10000, pedersen=8, cpu_sample={"hash": 4096, "grumpkin": 512, "ecdsa": 512, "arith_pedersen": 256}.get(name, 0), eff_tile_log2=16)
     n = 1 << 16
     circ, ids, values, wname = make_workload(a, 0, n)
     data = circ.to_bytes()
@@ -396,7 +401,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)  # the device reaches its clocks after about two solves (profiles/README.md)
-    ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "arith_pedersen", "mixed", "config5"])
+    ap.add_argument("--workload", default="arith", choices=["arith", "hash", "grumpkin", "ecdsa", "arith_pedersen", "mixed", "config5"])
     ap.add_argument("--gates", type=int, default=None, help="opcodes of the synthetic circuit (default 10000; 1000000 for config5)")
     ap.add_argument("--pedersen", type=int, default=8)
     ap.add_argument("--total-log2", type=int, default=None, help="global batch = 2^this (default: 20 for arith = the metric; 14 per GPU for config5; 16 per GPU otherwise)")
@@ -549,7 +554,7 @@ def main():
         legs = None
         if world == 1 and args.workload == "arith" and not args.no_legs and not args.no_cpu_baseline:
             legs = {}
-            for name in ("arith_pedersen", "hash", "grumpkin"):
+            for name in ("arith_pedersen", "hash", "grumpkin", "ecdsa"):
                 try:
                     legs[name] = run_leg(name)
                 except (acvm_amd.AcvmError, OSError, ValueError) as e:  # a leg must not void the metric's line

@@ -496,13 +496,20 @@ FR_HD __forceinline__ int64_t fr_mad_i64(int32_t a, int32_t b, int64_t c) {
     return (int64_t)a * b + c;
 #endif
 }
-FR_HD __forceinline__ int32_t fr_p30(int i) {
-    constexpr int32_t P30[9] = {0x30000001, 0x0f87d64f, 0x1b970914, 0x0cfa121e, 0x01585d28, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x3064};
-    return P30[i];
-}
-FR_HD inline __noinline__ Fr fr_inv(const Fr &a) {
+// The modulus of a safegcd inversion: its 9 x 30-bit limbs and its inverse modulo 2^30. BN254-Fr here; ops_ecdsa.hpp instantiates the same
+// routine for the four moduli of secp256k1 / secp256r1 (any odd modulus below 2^256 works: 600 divsteps cover 256-bit inputs).
+struct FrMod30 {
+    static FR_HD __forceinline__ int32_t p30(int i) {
+        constexpr int32_t P30[9] = {0x30000001, 0x0f87d64f, 0x1b970914, 0x0cfa121e, 0x01585d28, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x3064};
+        return P30[i];
+    }
+    static constexpr uint32_t PINV30 = 0x10000001u;  // p^-1 mod 2^30
+};
+// x^-1 mod M for the integer x < M held in a (0 for x = 0), as an integer < M
+template <class M>
+FR_HD __forceinline__ Fr fr_safegcd_inv(const Fr &a) {
     constexpr int32_t M30 = 0x3fffffff;
-    constexpr uint32_t PINV30 = 0x10000001u;  // p^-1 mod 2^30
+    constexpr uint32_t PINV30 = M::PINV30;
     FrS30 d, e, f, g;
     // 8 x 32 -> 9 x 30
 #pragma unroll
@@ -511,7 +518,7 @@ FR_HD inline __noinline__ Fr fr_inv(const Fr &a) {
         uint64_t two = a.v[w];
         if (w + 1 < 8) two |= (uint64_t)a.v[w + 1] << 32;
         g.v[i] = (int32_t)((uint32_t)(two >> sh) & (uint32_t)M30);
-        f.v[i] = fr_p30(i);
+        f.v[i] = M::p30(i);
         d.v[i] = 0;
         e.v[i] = i == 0 ? 1 : 0;
     }
@@ -545,15 +552,15 @@ FR_HD inline __noinline__ Fr fr_inv(const Fr &a) {
             int64_t ce = fr_mad_i64(tq, d.v[0], fr_mad_i64(tr, e.v[0], 0));
             md -= (int32_t)((PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
             me -= (int32_t)((PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
-            cd = fr_mad_i64(fr_p30(0), md, cd);
-            ce = fr_mad_i64(fr_p30(0), me, ce);
+            cd = fr_mad_i64(M::p30(0), md, cd);
+            ce = fr_mad_i64(M::p30(0), me, ce);
             cd >>= 30;
             ce >>= 30;
 #pragma unroll
             for (int i = 1; i < 9; i++) {
                 const int32_t di = d.v[i], ei = e.v[i];
-                cd = fr_mad_i64(tu, di, fr_mad_i64(tv, ei, fr_mad_i64(fr_p30(i), md, cd)));
-                ce = fr_mad_i64(tq, di, fr_mad_i64(tr, ei, fr_mad_i64(fr_p30(i), me, ce)));
+                cd = fr_mad_i64(tu, di, fr_mad_i64(tv, ei, fr_mad_i64(M::p30(i), md, cd)));
+                ce = fr_mad_i64(tq, di, fr_mad_i64(tr, ei, fr_mad_i64(M::p30(i), me, ce)));
                 d.v[i - 1] = (int32_t)cd & M30;
                 e.v[i - 1] = (int32_t)ce & M30;
                 cd >>= 30;
@@ -588,18 +595,18 @@ FR_HD inline __noinline__ Fr fr_inv(const Fr &a) {
         const int32_t cond_neg = f.v[8] >> 31;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            d.v[i] += fr_p30(i) & cond_add;
+            d.v[i] += M::p30(i) & cond_add;
             d.v[i] = (d.v[i] ^ cond_neg) - cond_neg;
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) { d.v[i + 1] += d.v[i] >> 30; d.v[i] &= M30; }
         cond_add = d.v[8] >> 31;
 #pragma unroll
-        for (int i = 0; i < 9; i++) d.v[i] += fr_p30(i) & cond_add;
+        for (int i = 0; i < 9; i++) d.v[i] += M::p30(i) & cond_add;
 #pragma unroll
         for (int i = 0; i < 8; i++) { d.v[i + 1] += d.v[i] >> 30; d.v[i] &= M30; }
     }
-    // 9 x 30 -> 8 x 32: x^-1 = a^-1 R^-1 as an integer < p; one Montgomery product with R^3 returns a^-1 R
+    // 9 x 30 -> 8 x 32
     Fr c;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -609,8 +616,10 @@ FR_HD inline __noinline__ Fr fr_inv(const Fr &a) {
         if (l + 2 < 9) acc |= (uint64_t)(uint32_t)d.v[l + 2] << (60 - sh);
         c.v[i] = (uint32_t)acc;
     }
-    return fr_mul(c, fr_r3());
+    return c;
 }
+// x^-1 = a^-1 R^-1 as an integer < p for the Montgomery representative x = a R; one Montgomery product with R^3 returns a^-1 R
+FR_HD inline __noinline__ Fr fr_inv(const Fr &a) { return fr_mul(fr_safegcd_inv<FrMod30>(a), fr_r3()); }
 
 // ---- witness table access: W[slot][half][instance] of 16-byte units (limbs 0..3 / 4..7), so that a
 // wavefront's 64 lanes read 1 KiB contiguous per instruction.

@@ -197,11 +197,11 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
 class ClockSampler:
     """shader clock (MHz) while the timed region runs: rocm-smi polled from a thread; median of the samples, or None"""
 
-    def __init__(self, device):
+    def __init__(self, device, enabled=True):
         import shutil
         import threading
         self.samples, self.stop, self.device = [], False, device
-        self.th = threading.Thread(target=self._run, daemon=True) if shutil.which("rocm-smi") and not os.environ.get("ACVM_BENCH_NO_PMC") else None
+        self.th = threading.Thread(target=self._run, daemon=True) if enabled and shutil.which("rocm-smi") and not os.environ.get("ACVM_BENCH_NO_PMC") else None
 
     def _run(self):
         import re
@@ -473,7 +473,9 @@ def main():
     dev_ms = 0.0
     n_failed = 0
     digest_ms = 0.0
-    with ClockSampler(acvm_amd.current_device()) as clock:
+    # (the sampler forks rocm-smi every 50 ms: harmless beside the 190 ms steps of the gate kernel, whose VALU issue fraction needs the clock,
+    # but it would disturb the sub-millisecond steps of the hash / Grumpkin workloads: those run without it)
+    with ClockSampler(acvm_amd.current_device(), enabled=args.workload in ("arith", "config5")) as clock:
         t0 = time.perf_counter()
         for i in range(args.steps):
             for k in range(n_tiles):

@@ -98,3 +98,34 @@ def test_node_auto_tile_and_empty_batch():
     not_solved, res, kept, asg, dig = node.solve(values, 100)
     assert not_solved == 0 and asg.all()
     node.free()
+
+
+def test_two_batch_handles_from_two_host_threads(oracle):
+    """the threading contract of include/acvm_amd.h through the plain batch API: independent handles on one device, each driven by its own host
+    thread at the same time (ctypes releases the GIL inside the calls), give what they give one after the other"""
+    import threading
+    import acvm_amd
+    from acvm_amd import synth
+    circ, ids = synth.mixed_circuit(700, seed=0x40DE0007)
+    data = circ.to_bytes()
+    B = 500
+    vals = [synth.witness_batch(B, seed=0x40DE0007 + k, edge_cases=True) for k in range(2)]
+    want = [plain_batch(data, ids, vals[k], B, [ids[0]]) for k in range(2)]
+    got = [None, None]
+
+    def run(k):
+        acvm_amd.set_device(0)
+        for _ in range(3):
+            b = acvm_amd.Batch(acvm_amd.Circuit(data), B, ids, fold_digest=bool(k))
+            b.set_initial_witness(vals[k])
+            b.solve()
+            got[k] = ([r.as_tuple() for r in b.results()], b.digest())
+            b.free()
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert got[k][0] == want[k][0] and np.array_equal(got[k][1], want[k][3])

@@ -27,6 +27,10 @@ struct DeviceLane {
     uint8_t *d_in[2] = {nullptr, nullptr};
     hipStream_t copy = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+    // kept witnesses leave the device beside the NEXT tile's solve: export kernel + D2H into pinned memory are enqueued behind a solve and
+    // harvested after the following one
+    uint32_t *d_keep = nullptr;
+    uint8_t *d_exp[2] = {nullptr, nullptr}, *h_exp[2] = {nullptr, nullptr};
     // statistics of the last solve
     double device_ms = 0, h2d_wait_ms = 0, export_ms = 0, total_ms = 0;
     uint32_t tiles = 0, exact_instances = 0;
@@ -53,7 +57,10 @@ struct acvm_node {
                 if (l.pinned[k]) hipHostFree(l.pinned[k]);
                 if (l.d_in[k]) hipFree(l.d_in[k]);
                 if (l.ev_h2d[k]) hipEventDestroy(l.ev_h2d[k]);
+                if (l.d_exp[k]) hipFree(l.d_exp[k]);
+                if (l.h_exp[k]) hipHostFree(l.h_exp[k]);
             }
+            if (l.d_keep) hipFree(l.d_keep);
             if (l.copy) hipStreamDestroy(l.copy);
         }
     }
@@ -163,6 +170,29 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
     // ---- solver
     uint64_t prev_base = 0;
     uint32_t prev_valid = 0;
+    bool in_flight = false;  // kept witnesses of a tile on their way to pinned memory
+    int fl_slot = 0;
+    uint64_t fl_base = 0;
+    uint32_t fl_n = 0;
+    std::vector<uint32_t> fl_flagged;
+    const Plan &plan = L.batch->plan;
+    auto harvest = [&] {
+        if (!in_flight) return;
+        in_flight = false;
+        memcpy(kept + fl_base * n_keep * 32, L.h_exp[fl_slot], (size_t)fl_n * n_keep * 32);
+        std::vector<uint8_t> flagged(fl_n, 0);
+        for (uint32_t j : fl_flagged)
+            if (j < fl_n) flagged[j] = 1;
+        for (uint32_t k2 = 0; k2 < n_keep; k2++) {  // the level kernels' assigned set is the planner's
+            const uint32_t w = node->keep[k2];
+            const bool produced = w < plan.n_witnesses && plan.producer[w] != 0xFFFFFFFFu;
+            for (uint32_t j = 0; j < fl_n; j++) {
+                if (flagged[j]) continue;
+                if (kept_assigned) kept_assigned[(fl_base + j) * n_keep + k2] = produced;
+                if (!produced) memset(kept + ((fl_base + j) * n_keep + k2) * 32, 0, 32);
+            }
+        }
+    };
     for (uint32_t k = 0; k < n_tiles && !L.rc; k++) {
         const uint64_t base = first + (uint64_t)k * tile;
         const uint32_t m = (uint32_t)std::min<uint64_t>(tile, last - base);
@@ -188,6 +218,8 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         L.exact_instances += st.n_slow_instances;
         L.tiles++;
         const double t1 = now_ms();
+        // the kept witnesses of the PREVIOUS tile have arrived in pinned memory (this solve synchronised the stream behind their copy)
+        harvest();
         if (k > 0 && !L.batch->last_outcome.instance.empty()) {
             L.not_solved += patch_outcome(L.batch->last_outcome, prev_base, prev_valid, n_keep, results, kept, kept_assigned, digests);
             L.batch->last_outcome.clear();
@@ -195,14 +227,31 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         if (!L.batch->pending)  // a synchronous exact path: its lanes are final
             for (size_t t = 0; t < L.batch->slow_ids.size(); t++)
                 L.not_solved += L.batch->slow_ids[t] < m && L.batch->slow_res[t].status != ACVM_STATUS_SOLVED;
-        if (int rc2 = batch_export_tile(L.batch, m, node->keep.data(), n_keep, results ? results + base : nullptr, kept ? kept + base * n_keep * 32 : nullptr,
-                                        kept_assigned ? kept_assigned + base * n_keep : nullptr, digests ? digests + base * 32 : nullptr)) {
+        // instances of a SYNCHRONOUS exact path have their values (and assigned sets) where only the batch knows: such a tile exports in one
+        // synchronous step; every other tile enqueues its kept witnesses and goes on
+        const bool overlap = kept && n_keep && (L.batch->slow_ids.empty() || L.batch->pending);
+        if (int rc2 = batch_export_tile(L.batch, m, node->keep.data(), overlap ? 0u : n_keep, results ? results + base : nullptr,
+                                        kept && !overlap ? kept + base * n_keep * 32 : nullptr, kept_assigned && !overlap ? kept_assigned + base * n_keep : nullptr,
+                                        digests ? digests + base * 32 : nullptr)) {
             fail(rc2, "export");
             break;
+        }
+        if (overlap) {
+            launch_export(L.batch->stream, L.batch->d_W, L.batch->Bp, 0, m, L.d_keep, n_keep, L.d_exp[slot], L.batch->unscale, L.batch->d_slot_of);
+            if (hipMemcpyAsync(L.h_exp[slot], L.d_exp[slot], (size_t)m * n_keep * 32, hipMemcpyDeviceToHost, L.batch->stream) != hipSuccess) { fail(ACVM_E_DEVICE, "hipMemcpyAsync"); break; }
+            in_flight = true;
+            fl_slot = slot;
+            fl_base = base;
+            fl_n = m;
+            fl_flagged.assign(L.batch->slow_ids.begin(), L.batch->slow_ids.end());  // (arrive with the exact job's outcome)
         }
         L.export_ms += now_ms() - t1;
         prev_base = base;
         prev_valid = m;
+    }
+    if (!L.rc && in_flight) {
+        if (hipStreamSynchronize(L.batch->stream) != hipSuccess) fail(ACVM_E_DEVICE, "hipStreamSynchronize");
+        else harvest();
     }
     if (!L.rc) {  // the exact job of the last tile
         ExactOutcome o;
@@ -260,6 +309,13 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
             for (int k = 0; k < 2 && ok; k++)
                 ok = hipHostMalloc((void **)&L.pinned[k], bytes, hipHostMallocDefault) == hipSuccess && hipMalloc((void **)&L.d_in[k], bytes) == hipSuccess &&
                      hipEventCreateWithFlags(&L.ev_h2d[k], hipEventDisableTiming) == hipSuccess;
+            if (ok && n_keep) {
+                const size_t eb = (size_t)node->tile * n_keep * 32;
+                ok = hipMalloc((void **)&L.d_keep, (size_t)n_keep * 4) == hipSuccess &&
+                     hipMemcpy(L.d_keep, node->keep.data(), (size_t)n_keep * 4, hipMemcpyHostToDevice) == hipSuccess;
+                for (int k = 0; k < 2 && ok; k++)
+                    ok = hipMalloc((void **)&L.d_exp[k], eb) == hipSuccess && hipHostMalloc((void **)&L.h_exp[k], eb, hipHostMallocDefault) == hipSuccess;
+            }
             if (!ok) { L.rc = ACVM_E_DEVICE; L.error = "staging buffers: allocation failed"; }
         });
     }

@@ -190,3 +190,26 @@ def test_batched_vtable_members_are_called_once_per_opcode(oracle):
     for j, r in enumerate(rows):
         assert res[j].status == acvm_amd.STATUS_SOLVED
         assert int.from_bytes(vals[j, n_in + 3].tobytes(), "big") == r[2] % P and int.from_bytes(vals[j, n_in + 4].tobytes(), "big") == r[3] % P
+
+
+def test_multi_repeated_id_keeps_its_last_value(oracle):
+    """a map has every id once: an instance that lists an id twice keeps the LAST value, like BTreeMap::insert (acvm_multi_new used to refuse it)"""
+    import ctypes as C
+    import numpy as np
+    ops = [E([(1, 1, 2)], [(P - 1, 3)], 0)]
+    circ = Circuit(3, ops)
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    ids = np.asarray([1, 2, 1, 1, 2], dtype=np.uint32)          # instance 0: {1: 3 -> 9, 2: 5}; instance 1: {1: 4, 2: 6}
+    offsets = np.asarray([0, 3, 5], dtype=np.uint64)
+    vals = b"".join(int(v).to_bytes(32, "big") for v in (3, 5, 9, 4, 6))
+    L = acvm_amd.lib()
+    h = L.acvm_multi_new(gc._h, None, 2, offsets.ctypes.data, ids.ctypes.data, vals)
+    assert h, L.acvm_last_error()
+    assert L.acvm_multi_num_groups(h) == 1 and L.acvm_multi_solve(h) == 0
+    nw = L.acvm_multi_num_witnesses(h)
+    for inst, want in ((0, 45), (1, 24)):
+        asg = np.zeros(nw, dtype=np.uint8)
+        v = np.zeros((nw, 32), dtype=np.uint8)
+        assert L.acvm_multi_witness_map(h, inst, asg.ctypes.data, v.ctypes.data) == 0
+        assert asg[3] and int.from_bytes(v[3].tobytes(), "big") == want
+    L.acvm_multi_free(h)

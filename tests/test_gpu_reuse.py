@@ -104,3 +104,22 @@ def test_slot_reuse_refusals():
     circ = Circuit(3, [Brillig(inputs=[E.from_witness(1)], outputs=[2], bytecode=[("ForeignCall", "f", [("Register", 0)], [("Register", 0)]), ("Stop",)])])
     with pytest.raises(acvm_amd.AcvmError, match="slot reuse"):
         acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), 4, [1], reuse_slots=True)
+
+
+def test_kept_witness_that_nothing_produces_reads_as_unassigned():
+    """slot reuse: a keep id below n_witnesses that no opcode assigns has no row of the table; reading it back must answer "unassigned, zero"
+    like the plain batch does (round 2 read terabytes past the table)"""
+    from acvm_amd.acir import P, Circuit, Expression as E
+    from acvm_amd.synth import values_from_rows
+    circ = Circuit(9, [E([(1, 1, 2)], [(P - 1, 3)], 0)])  # witnesses 4..9 exist in the numbering but nothing assigns them
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    for reuse in (False, True):
+        b = acvm_amd.Batch(gc, 70, [1, 2], reuse_slots=reuse, keep=[3, 7])
+        b.set_initial_witness(values_from_rows([[j + 1, j + 2] for j in range(70)]))
+        assert b.solve() == 0
+        vals, asg = b.witness(7)
+        assert not asg.any() and not vals.any()
+        vals, asg = b.witness(3)
+        assert asg.all() and int.from_bytes(vals[5].tobytes(), "big") == 6 * 7
+        with pytest.raises(acvm_amd.AcvmError, match="Witness not found"):
+            b.extract([3, 7])

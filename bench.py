@@ -466,6 +466,8 @@ def main():
     batch.set_profiling(True)  # warm-up with per-launch events, so that the event pool exists before the timed region
     for _ in range(args.warmup):
         sh.solve_pass()
+    if config5 and args.warmup:
+        batch.digest(0, tile)  # (the digest's coefficient tables are built at its first use: not inside the timed region)
     batch.set_profiling(False)
     if n_tiles == 1:
         sh.load_tile(0)

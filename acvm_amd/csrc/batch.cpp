@@ -428,6 +428,7 @@ static int batch_init(acvm_batch *b) {
     b->dp.Mem = b->d_Mem;
     b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr};
     b->dp.ped_seed = nullptr;
+    b->dp.ecdsa_g = nullptr;
     b->dp.fc_store = nullptr;
     b->dp.slot_of = nullptr;
     {   // limits of the Brillig VM for the level kernels and the first pass of the exact kernels (tuning.hpp)
@@ -455,6 +456,10 @@ static int batch_init(acvm_batch *b) {
         std::vector<FcStoreSlot> tab(b->fc_slots.size(), FcStoreSlot{nullptr, nullptr});
         if (int rc = upload(&b->d_fc_store, tab)) return rc;
         b->dp.fc_store = b->d_fc_store;
+    }
+    if (p.needs_ecdsa) {
+        b->dp.ecdsa_g = ecdsa_generator_tables();
+        if (!b->dp.ecdsa_g) return set_err(ACVM_E_DEVICE, "could not build the ECDSA generator tables on the device");
     }
     if (p.needs_grumpkin) {
         // the level schedule's Pedersen kernel reads the 503 MB pair table (one mixed addition per 18 bits of input)

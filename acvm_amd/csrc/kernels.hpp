@@ -59,6 +59,7 @@ struct DeviceProgram {
     const uint32_t *bytecode;     // Brillig programs
     uint4 *Mem;                   // per-instance memory blocks, laid out like W
     GrumpkinTables grumpkin;      // device lookup tables (null pointers if the circuit has no Grumpkin opcode)
+    const uint32_t *ecdsa_g;      // generator tables of secp256k1 / secp256r1 (kernels_ecdsa.hip; null: the circuit has no ECDSA call)
     const uint32_t *ped_seed;     // per Pedersen record: hash_single(x of hash_pair(IV[domain separator], n), 0), affine, 16 x u32
     const FcStoreSlot *fc_store;  // device array, one entry per Brillig opcode with a ForeignCall (null: the circuit has none)
     const uint32_t *slot_of;      // witness -> row of the table for the level kernels (null: row = witness index; plan.cpp slot reuse)
@@ -128,6 +129,8 @@ void launch_exact_run(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram 
                       const uint8_t *prog_class, const ExactScratch &sc);
 void launch_grumpkin_probe(hipStream_t s, const GrumpkinTables &T, uint32_t what, uint32_t param, const uint32_t *in, uint32_t n_in, uint32_t *out);
 // ECDSA (kernels_ecdsa.hip)
+// d * 2^(8 j) * G of both curves (secp_device.hpp), built once per device; null on a device error
+const uint32_t *ecdsa_generator_tables();
 void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event);
 // caller-supplied BlackBoxFunctionSolver (kernels_ops.hip)
 void launch_hostbb_precheck(hipStream_t s, const ExactLanes &L, uint32_t opcode, const uint32_t *sel, uint32_t n_sel, uint8_t *active);

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(64) exact_run_kernel(uint4 *W, uint64_t Bp, De
         case 1: r = rec[0] == K_PERM_SORT ? op_perm_sort(p, rec, dp.consts, sc.hash) : op_hash(p, rec, sc.hash); break;    // CLS_HASH
         case 2: r = dispatch_grumpkin(p, rec, dp.grumpkin, sc.grumpkin); break;                                            // CLS_GRUMPKIN (Pedersen included)
         case 3: r = op_brillig(p, rec, dp, sc.brillig, &L.results[t], &L, t); break;                                       // CLS_BRILLIG
-        case 6: r = op_ecdsa(p, rec); break;                                                                               // CLS_ECDSA
+        case 6: r = op_ecdsa(p, rec, dp.ecdsa_g); break;                                                                               // CLS_ECDSA
         default: r = op_fail_msg(DE_PANIC, 0, DM_NONE); break;  // (CLS_HOSTBB never reaches this kernel)
         }
         if (r.err == DE_WAIT_FOREIGN_CALL) {  // ACVMStatus::RequiresForeignCall: the instruction pointer stays on this opcode

@@ -1,18 +1,49 @@
-// kernels_ecdsa.hip -- EcdsaSecp256k1 / EcdsaSecp256r1 opcodes (device routines in ops_ecdsa.hpp), level + exact kernel.
+// kernels_ecdsa.hip -- EcdsaSecp256k1 / EcdsaSecp256r1 opcodes (device routines in ops_ecdsa.hpp / secp_device.hpp): the level kernel and
+// the tables of the two generators.
 #include "ops_ecdsa.hpp"
 #include "ops_kernel.hpp"
+#include <map>
+#include <mutex>
 
 namespace acvm {
 
 struct EcdsaOp {
     template <class P>
-    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &, uint32_t *, SlowResult *, const ExactLanes *, uint32_t) {
-        return op_ecdsa(p, rec);
+    static __device__ __forceinline__ OpResult run(const P &p, const uint32_t *__restrict__ rec, const DeviceProgram &dp, uint32_t *, SlowResult *, const ExactLanes *, uint32_t) {
+        return op_ecdsa(p, rec, dp.ecdsa_g);
     }
 };
 
 void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event) {
     launch_record_level<EcdsaOp, 64>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
+}
+
+// one thread per (curve, window j, digit d): 2 x 32 x 256 entries of 16 words, digit 0 left zero
+__global__ void ecdsa_gtable_kernel(uint32_t *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t curve = t >> 13, j = (t >> 8) & 31u, d = t & 255u;
+    if (curve > 1u) return;
+    SAff e{fr_zero(), fr_zero()};
+    if (d) e = curve == 0u ? secp_gtable_entry<0>(j, d) : secp_gtable_entry<1>(j, d);
+    uint32_t *o = out + (size_t)t * 16u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { o[k] = e.x.v[k]; o[8 + k] = e.y.v[k]; }
+}
+
+const uint32_t *ecdsa_generator_tables() {
+    static std::mutex mu;
+    static std::map<int, uint32_t *> per_device;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) return it->second;
+    uint32_t *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)2 * SECP_GTABLE_WORDS * 4) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(ecdsa_gtable_kernel, dim3(2 * 32 * 256 / 64), dim3(64), 0, nullptr, d);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(d); return nullptr; }
+    per_device.emplace(dev, d);
+    return d;
 }
 
 }  // namespace acvm

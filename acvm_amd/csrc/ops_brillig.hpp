@@ -76,7 +76,8 @@ static inline __device__ __noinline__ Fr brillig_int_op(BrVm &vm, uint32_t op, u
 }
 
 // black_box.rs:42-165. Operand words: see plan.cpp (HeapVector = pointer reg + size reg, HeapArray = pointer reg + literal)
-static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t bbop, const uint32_t *__restrict__ w, const GrumpkinTables &T) {
+static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t bbop, const uint32_t *__restrict__ w, const GrumpkinTables &T,
+                                                             const uint32_t *__restrict__ ecdsa_g) {
     MsgBuf m{vm.words + (uint64_t)vm.cs_cap * vm.Bp, vm.Bp, vm.j, 0u, 0u};
     auto heap_vector = [&](uint32_t preg, uint32_t sreg, uint64_t &ptr, uint64_t &len) {
         const Fr pv = vm.reg_get(preg), sv = vm.reg_get(sreg);
@@ -109,7 +110,7 @@ static inline __device__ __noinline__ void brillig_black_box(BrVm &vm, uint32_t 
         uint32_t panic = 0;
         const uint32_t ok = ecdsa_verify(
             bbop - 4u, [&](uint32_t i) { return mem_byte(ap[0], i); }, [&](uint32_t i) { return mem_byte(ap[1], i); },
-            [&](uint32_t i) { return mem_byte(ap[2], i); }, (uint32_t)len, [&](uint32_t i) { return mem_byte(ptr, i); }, &panic);
+            [&](uint32_t i) { return mem_byte(ap[2], i); }, (uint32_t)len, [&](uint32_t i) { return mem_byte(ptr, i); }, ecdsa_g, &panic);
         if (panic) { vm.status = 4; vm.code = 110u + panic; return; }
         vm.reg_set(w[8], ok ? fr_one() : fr_zero());
         return;
@@ -382,7 +383,7 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
         }
         case BRO_TRAP: vm.status = 2; vm.code = DM_BRILLIG_TRAP; break;
         case BRO_STOP: vm.status = 1; break;
-        case BRO_BLACK_BOX: brillig_black_box(vm, ins[4], dp.bytecode + ins[7], dp.grumpkin); break;
+        case BRO_BLACK_BOX: brillig_black_box(vm, ins[4], dp.bytecode + ins[7], dp.grumpkin, dp.ecdsa_g); break;
         case BRO_FOREIGN_CALL: brillig_foreign_call(vm, dp.bytecode + ins[7], dp, r[9], r[10], fc_counter, n_bc, r[11], L, t); break;
         default: vm.panic(BP_BAD_OPCODE); break;
         }

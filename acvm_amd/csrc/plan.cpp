@@ -406,6 +406,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 case BB_ECDSA_SECP256K1: case BB_ECDSA_SECP256R1:
                     // [PK_ECDSA, oi, curve, n_x, n_y, n_sig, n_msg, out, flag, ws: x..., y..., sig..., msg...]
                     p.prog_class[oi] = CLS_ECDSA;
+                    p.needs_ecdsa = true;
                     s.insert(s.end(), {PK_ECDSA, oi, b.func == BB_ECDSA_SECP256R1 ? 1u : 0u, (uint32_t)b.in[0].size(), (uint32_t)b.in[1].size(),
                                        (uint32_t)b.in[2].size(), (uint32_t)b.in[3].size()});
                     out(b.out[0]);
@@ -511,6 +512,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                         // operands go to an extra block behind the instruction array (patched below)
                         w[4] = op.bbop;
                         if (op.bbop >= 6) has_grumpkin = true;
+                        if (op.bbop == 4 || op.bbop == 5) p.needs_ecdsa = true;
                         max_hash_hint = 1;
                         break;
                     }

@@ -109,6 +109,7 @@ struct Plan {
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
     bool needs_grumpkin = false;
+    bool needs_ecdsa = false;  // an ECDSA opcode or Brillig black box: the batch carries the generator tables (kernels_ecdsa.hip)
     std::vector<std::pair<uint32_t, uint32_t>> pedersen_seeds;  // per Pedersen record: (number of inputs, domain separator)
     // Brillig foreign calls: function name per (opcode << 32 | bytecode index), buffer sizes of the wait / resolve round trip
     bool has_foreign_calls = false;

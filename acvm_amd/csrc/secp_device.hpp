@@ -333,6 +333,69 @@ FR_HD __forceinline__ Fr sn_mul(const Fr &a, const Fr &b) {
     return sn_mont<C>(sn_mont<C>(a, b), secp_limbs([](int i) { return Secp<C>::r2n(i); }));
 }
 
+template <int C>
+FR_HD __forceinline__ Fr sn_add(const Fr &a, const Fr &b) {
+    Fr r, d;
+    const uint32_t c = fr_add256(r, a, b);
+    const uint32_t borrow = fr_sub256(d, r, sn_modulus<C>());
+    const bool sub = c != 0u || borrow == 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = sub ? d.v[i] : r.v[i];
+    return r;
+}
+template <int C>
+FR_HD __forceinline__ Fr sn_sub(const Fr &a, const Fr &b) {
+    Fr r, q;
+    const uint32_t mask = fr_sub256(r, a, b) ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) q.v[i] = Secp<C>::n(i) & mask;
+    fr_add256(r, r, q);
+    return r;
+}
+
+// ---- secp256k1 only: the endomorphism (x, y) -> (beta x, y) = lambda (x, y). k = k1 + k2 lambda (mod n) with |k1|, |k2| < 2^128 halves the
+// doublings of a variable-base product. The split is the one of libsecp256k1 (scalar_split_lambda): with the lattice basis (a1, b1), (a2, b2)
+// of {(x, y): x + y lambda = 0 mod n}, c1 = round(k g1 / 2^384), c2 = round(k g2 / 2^384) for g1 = round(2^384 b2 / n), g2 = round(2^384 (-b1) / n),
+// k2 = c1 (-b1) + c2 (-b2), k1 = k - k2 lambda. Returned as magnitudes < 2^128 and signs. (Constants re-derived and the bound checked over
+// 200 000 scalars by the script quoted in DESIGN.md section 9; tests/test_secp_device_on_host.py checks k1 + k2 lambda = k.)
+struct SecpSplit { Fr k1, k2; bool neg1, neg2; };
+FR_HD __forceinline__ Fr secp_round_shift384(const uint32_t t[16]) {  // (t + 2^383) >> 384 of a 512-bit product
+    Fr c = fr_zero();
+    uint64_t acc = (uint64_t)t[12] + (t[11] >> 31);
+    c.v[0] = (uint32_t)acc;
+    acc >>= 32;
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        acc += t[12 + i];
+        c.v[i] = (uint32_t)acc;
+        acc >>= 32;
+    }
+    c.v[4] = (uint32_t)acc;
+    return c;
+}
+FR_HD inline __noinline__ SecpSplit secp256k1_split_lambda(const Fr &k) {
+    const Fr g1 = {{0x45dbb031u, 0xe893209au, 0x71e8ca7fu, 0x3daa8a14u, 0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u}};
+    const Fr g2 = {{0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu, 0x0abfe4c4u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u}};
+    const Fr mb1 = {{0x0abfe4c3u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u, 0u, 0u, 0u, 0u}};
+    const Fr mb2 = {{0x3db1562cu, 0xd765cda8u, 0x0774346du, 0x8a280ac5u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
+    const Fr lam = {{0x1b23bd72u, 0xdf02967cu, 0x20816678u, 0x122e22eau, 0x8812645au, 0xa5261c02u, 0xc05c30e0u, 0x5363ad4cu}};
+    uint32_t t[16];
+    secp_mul_wide(t, k, g1);
+    const Fr c1 = secp_round_shift384(t);
+    secp_mul_wide(t, k, g2);
+    const Fr c2 = secp_round_shift384(t);
+    SecpSplit r;
+    r.k2 = sn_add<0>(sn_mul<0>(c1, mb1), sn_mul<0>(c2, mb2));
+    r.k1 = sn_sub<0>(k, sn_mul<0>(r.k2, lam));
+    const Fr half = secp_limbs([](int i) { return Secp<0>::half_n(i); });
+    Fr d;
+    r.neg1 = fr_sub256(d, half, r.k1) != 0u;  // k1 > n / 2: the small representative is n - k1
+    if (r.neg1) r.k1 = sn_sub<0>(fr_zero(), r.k1);
+    r.neg2 = fr_sub256(d, half, r.k2) != 0u;
+    if (r.neg2) r.k2 = sn_sub<0>(fr_zero(), r.k2);
+    return r;
+}
+
 // ---- points: Jacobian (X / Z^2, Y / Z^3), Z == 0 <=> identity; a = 0 (secp256k1) or a = -3 (secp256r1)
 struct SJac { Fr X, Y, Z; };
 struct SAff { Fr x, y; };
@@ -438,29 +501,9 @@ FR_HD __forceinline__ uint32_t secp_limb_at(const Fr &a, uint32_t k) {  // a.v[k
     for (uint32_t i = 0; i < 8; i++) w = i == k ? a.v[i] : w;
     return w;
 }
+// acc + u1 G from the table of the generator
 template <int C>
-FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const SAff &Q, const Fr &u2, const uint32_t *__restrict__ gtab) {
-    SAff tab[8];
-    secp_window_table<C>(tab, Q);
-    // signed digits of u2: with e = u2 + 0x88..8, digit i = nibble i of e - 8 in [-8, 7] (i < 64), digit 64 = the carry
-    Fr e, eights;
-#pragma unroll
-    for (int i = 0; i < 8; i++) eights.v[i] = 0x88888888u;
-    const uint32_t top = fr_add256(e, u2, eights);
-    SJac acc = sj_identity();
-    if (top) acc = SJac{Q.x, Q.y, secp_one()};
-#pragma unroll 1
-    for (int i = 255; i >= 0; i--) {  // one doubling and one addition in the loop body: the code stays within reach of the instruction cache
-        acc = sj_dbl<C>(acc);
-        if (i & 3) continue;
-        const int32_t dg = (int32_t)((secp_limb_at(e, (uint32_t)i >> 5) >> (i & 31)) & 15u) - 8;
-        if (dg != 0) {
-            const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
-            SAff q = tab[mag - 1u];
-            if (dg < 0) q.y = sp_neg<C>(q.y);
-            acc = sj_add_aff<C>(acc, q);
-        }
-    }
+FR_HD __forceinline__ SJac secp_add_generator_multiple(SJac acc, const Fr &u1, const uint32_t *__restrict__ gtab) {
 #pragma unroll 1
     for (uint32_t j = 0; j < 32u; j++) {
         const uint32_t d = (secp_limb_at(u1, j >> 2) >> (8u * (j & 3u))) & 255u;
@@ -473,6 +516,68 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const SAff &Q, const Fr &
         }
     }
     return acc;
+}
+template <int C>
+FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const SAff &Q, const Fr &u2, const uint32_t *__restrict__ gtab) {
+    SAff tab[8];
+    secp_window_table<C>(tab, Q);
+    Fr eights;
+#pragma unroll
+    for (int i = 0; i < 8; i++) eights.v[i] = 0x88888888u;
+    SJac acc = sj_identity();
+    if constexpr (C == 0) {
+        // u2 = k1 + k2 lambda: two 128-bit ladders on one accumulator, 128 doublings; lambda (k Q) = (beta x, y) of the same table
+        const Fr beta = {{0x719501eeu, 0xc1396c28u, 0x12f58995u, 0x9cf04975u, 0xac3434e9u, 0x6e64479eu, 0x657c0710u, 0x7ae96a2bu}};
+        Fr bx[8];
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) bx[k] = sp_mul<C>(tab[k].x, beta);
+        const SecpSplit sp = secp256k1_split_lambda(u2);
+        // signed digits: e = k + 0x88..8 over 32 nibbles, digit i = nibble i of e - 8 (i < 32), digit 32 = bit 128 of e
+        Fr e1, e2, eights128 = eights;
+#pragma unroll
+        for (int i = 4; i < 8; i++) eights128.v[i] = 0u;
+        fr_add256(e1, sp.k1, eights128);
+        fr_add256(e2, sp.k2, eights128);
+#pragma unroll 1
+        for (int i = 128; i >= 0; i--) {
+            if (i != 128) acc = sj_dbl<C>(acc);
+            if (i & 3) continue;
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                Fr e;
+#pragma unroll
+                for (int k = 0; k < 8; k++) e.v[k] = h ? e2.v[k] : e1.v[k];
+                const uint32_t nib = (secp_limb_at(e, (uint32_t)i >> 5) >> (i & 31)) & 15u;
+                int32_t dg = i == 128 ? (int32_t)(nib & 1u) : (int32_t)nib - 8;
+                if (h ? sp.neg2 : sp.neg1) dg = -dg;
+                if (dg != 0) {
+                    const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
+                    SAff q = tab[mag - 1u];
+                    if (h) q.x = bx[mag - 1u];
+                    if (dg < 0) q.y = sp_neg<C>(q.y);
+                    acc = sj_add_aff<C>(acc, q);
+                }
+            }
+        }
+    } else {
+        // signed digits of u2: with e = u2 + 0x88..8, digit i = nibble i of e - 8 in [-8, 7] (i < 64), digit 64 = the carry
+        Fr e;
+        const uint32_t top = fr_add256(e, u2, eights);
+        if (top) acc = SJac{Q.x, Q.y, secp_one()};
+#pragma unroll 1
+        for (int i = 255; i >= 0; i--) {  // one doubling and one addition in the loop body: the code stays within reach of the instruction cache
+            acc = sj_dbl<C>(acc);
+            if (i & 3) continue;
+            const int32_t dg = (int32_t)((secp_limb_at(e, (uint32_t)i >> 5) >> (i & 31)) & 15u) - 8;
+            if (dg != 0) {
+                const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
+                SAff q = tab[mag - 1u];
+                if (dg < 0) q.y = sp_neg<C>(q.y);
+                acc = sj_add_aff<C>(acc, q);
+            }
+        }
+    }
+    return secp_add_generator_multiple<C>(acc, u1, gtab);
 }
 
 // panic codes (host texts in batch.cpp ecdsa_panic_text)

@@ -149,6 +149,20 @@ def test_point_formulas_and_generator_table(exe, c):
         assert tuple(int(t, 16) for t in g.split()) == w, l
 
 
+def test_secp256k1_endomorphism_split(exe):
+    """k = k1 + k2 lambda (mod n) with both parts below 2^128 in magnitude (secp_device.hpp secp256k1_split_lambda)"""
+    n = CURVES[0]["n"]
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    rng = random.Random(77)
+    ks = [0, 1, 2, n - 1, n - 2, n // 2, n // 2 + 1, lam, n - lam, 2**128, 2**128 - 1, 2**255, (2**256 - 1) % n] + [rng.randrange(n) for _ in range(3000)]
+    got = ask(exe, [f"0 split {k:x}" for k in ks])
+    for k, g in zip(ks, got):
+        k1, s1, k2, s2 = g.split()
+        k1, k2 = int(k1, 16), int(k2, 16)
+        assert k1 < 2**128 and k2 < 2**128, hex(k)
+        assert ((-k1 if s1 == "1" else k1) + (-k2 if s2 == "1" else k2) * lam) % n == k, hex(k)
+
+
 @pytest.mark.parametrize("c", [0, 1])
 def test_verification(exe, c):
     cv = CURVES[c]
@@ -186,6 +200,17 @@ def test_verification(exe, c):
     # small scalars, u2 with a top carry in the signed recoding (r / s close to n)
     cases.append((n - 1, 1, Q[0], Q[1] & 1, 32, n - 1))
     cases.append((1, 1, Q[0], Q[1] & 1, 32, 0))
+    # u2 = r / s with special shapes (secp256k1: the halves of the endomorphism split): u2 = 1, 2^128, lambda, n - 1 for s = r / u2
+    for u2 in (1, 2, 2**128, 2**128 - 1, 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72, n - 1, n - 2**128):
+        d, k = rng.randrange(1, n), rng.randrange(1, n)
+        Qd = ec_mul(cv, d, cv["g"])
+        r = ec_mul(cv, k, cv["g"])[0] % n
+        s = r * pow(u2, -1, n) % n
+        z = (s * k - r * d) % n   # k = (z + r d) / s
+        if 0 < s <= n // 2:
+            cases.append((r, s, Qd[0], Qd[1] & 1, 32, z))
+        else:
+            cases.append((r, n - s, Qd[0], Qd[1] & 1, 32, z))   # high-S counterpart: rejected or, mirrored, another valid-looking input
     lines = [f"{c} verify {r:x} {s:x} {x:x} {yo} {nm} {z:x}" for r, s, x, yo, nm, z in cases]
     got = ask(exe, lines)
     seen = set()

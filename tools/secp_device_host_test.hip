@@ -2,6 +2,7 @@
 // line from stdin, prints one answer per line; tests/test_secp_device_on_host.py compares with Python integers. Nothing is launched.
 //   <c> mul a b | sqr a | add a b | sub a b | inv a | ninv a | nmul a b | sqrt a        -> hex
 //   <c> dbl X Y Z | addaff X Y Z x y                                                  -> X Y Z (Jacobian, hex)
+//   0 split k                                                                         -> |k1| neg1 |k2| neg2 (secp256k1's endomorphism split)
 //   <c> gtab j d                                                                      -> x y
 //   <c> verify r s x y_odd n_msg z                                                    -> result panic      (table of the generator built on first use)
 #include "../acvm_amd/csrc/secp_device.hpp"
@@ -57,6 +58,9 @@ static void serve(const std::vector<std::string> &w) {
         uint32_t panic = 0;
         const uint32_t ok = secp_verify<C>(A(2), A(3), A(4), (uint32_t)atoi(w[5].c_str()), (uint32_t)atoi(w[6].c_str()), A(7), gtable<C>(), &panic);
         printf("%u %u", ok, panic);
+    } else if (op == "split") {
+        const SecpSplit sp = secp256k1_split_lambda(A(2));
+        put(sp.k1); printf(" %d ", sp.neg1 ? 1 : 0); put(sp.k2); printf(" %d", sp.neg2 ? 1 : 0);
     } else printf("?");
     printf("\n");
 }

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "acvm_new", "acvm_free", "acvm_solve", "acvm_solve_opcode", "acvm_get_status", "acvm_instruction_pointer", "acvm_witness_map", "acvm_finalize",
     "acvm_get_pending_foreign_call", "acvm_pending_foreign_call_inputs", "acvm_resolve_pending_foreign_call",
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
-    "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
+    "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_debug_secp_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
     "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
 ]
@@ -258,6 +258,7 @@ def lib():
     L.acvm_witness_map_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_debug_modmul_rate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.acvm_debug_secp_rate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.acvm_node_new.restype = C.c_void_p
     L.acvm_node_new.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.acvm_node_free.restype = None
@@ -395,6 +396,13 @@ def modmul_rate(iters=400, waves_per_simd=8):
     """(modmul/s, products per launch) of the back-to-back fr29_mul probe: the peak of the ALU roofline"""
     r, n = C.c_double(), C.c_uint64()
     _check(lib().acvm_debug_modmul_rate(iters, waves_per_simd, C.byref(r), C.byref(n)))
+    return r.value, n.value
+
+
+def secp_rate(curve, iters=400, waves_per_simd=8):
+    """(products/s, products per launch) of the back-to-back sp_mul / sp_sqr probe of secp256k1 (0) / secp256r1 (1): the peak of the ECDSA kernels' ALU roofline"""
+    r, n = C.c_double(), C.c_uint64()
+    _check(lib().acvm_debug_secp_rate(curve, iters, waves_per_simd, C.byref(r), C.byref(n)))
     return r.value, n.value
 
 

@@ -117,8 +117,9 @@ int acvm_selftest(uint32_t n, uint64_t seed) {
 }
 
 // Peak of the ALU roofline: back-to-back Montgomery products on every SIMD, `waves_per_simd` chains interleaved.
-int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modmul_per_s, uint64_t *n_modmul) {
-    if (!modmul_per_s || !iters || !waves_per_simd) return set_err(ACVM_E_INVALID, "bad argument");
+// field: 0 = BN254-Fr in the 29-bit working form (fr29_mul), 1 / 2 = the base field of secp256k1 / secp256r1 (sp_mul, sp_sqr in turn)
+static int product_rate(uint32_t field, uint32_t iters, uint32_t waves_per_simd, double *per_s, uint64_t *n_products) {
+    if (!per_s || !iters || !waves_per_simd || field > 2) return set_err(ACVM_E_INVALID, "bad argument");
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     hipDeviceProp_t prop;
@@ -132,7 +133,8 @@ int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modm
     float best = 1e30f;
     for (int r = 0; r < 4; r++) {  // the first run warms the clocks up
         hipEventRecord(e0, nullptr);
-        launch_modmul_rate(nullptr, d, blocks, iters);
+        if (field == 0) launch_modmul_rate(nullptr, d, blocks, iters);
+        else launch_secp_rate(nullptr, field - 1, d, blocks, iters);
         hipEventRecord(e1, nullptr);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -144,10 +146,17 @@ int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modm
     hipFree(d);
     HIPCHK(hipGetLastError());
     const double n = (double)blocks * 256.0 * iters * 2.0;
-    *modmul_per_s = n / (best * 1e-3);
-    if (n_modmul) *n_modmul = (uint64_t)n;
+    *per_s = n / (best * 1e-3);
+    if (n_products) *n_products = (uint64_t)n;
     return 0;
 }
+int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modmul_per_s, uint64_t *n_modmul) try {
+    return product_rate(0, iters, waves_per_simd, modmul_per_s, n_modmul);
+} catch (...) { return set_err(ACVM_E_DEVICE, "probe failed"); }
+int acvm_debug_secp_rate(uint32_t curve, uint32_t iters, uint32_t waves_per_simd, double *products_per_s, uint64_t *n_products) try {
+    if (curve > 1) return set_err(ACVM_E_INVALID, "curve: 0 = secp256k1, 1 = secp256r1");
+    return product_rate(1 + curve, iters, waves_per_simd, products_per_s, n_products);
+} catch (...) { return set_err(ACVM_E_DEVICE, "probe failed"); }
 
 // The measured streaming ceiling beside the spec peak of the HBM roofline: two rows of `bytes` read and one written by a kernel with the
 // gate kernel's access shape (kernels.hip stream_rate_kernel), best of four; bytes moved = 3 x bytes.

@@ -30,6 +30,32 @@ __global__ void ecdsa_gtable_kernel(uint32_t *out) {
     for (int k = 0; k < 8; k++) { o[k] = e.x.v[k]; o[8 + k] = e.y.v[k]; }
 }
 
+// The ALU roofline of the ECDSA kernels: every lane runs a chain of 2 * iters base-field products of one curve, a product and a square in
+// turn (a verification is 54 % products, 46 % squares: DESIGN.md section 6); several waves per SIMD interleave their chains.
+template <int C>
+__global__ void __launch_bounds__(256) secp_rate_kernel(uint32_t *__restrict__ out, uint32_t seed, uint32_t iters) {
+    Fr a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a.v[i] = (threadIdx.x + 1) * 2654435761u + seed + i;
+        b.v[i] = a.v[i] ^ 0x5bd1e995u;
+    }
+    a.v[7] >>= 1;  // < p
+    b.v[7] >>= 1;
+    for (uint32_t i = 0; i < iters; i++) {
+        a = sp_mul<C>(a, b);
+        b = sp_sqr<C>(a);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += a.v[i] ^ b.v[i];
+    out[(uint64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+void launch_secp_rate(hipStream_t s, uint32_t curve, uint32_t *out, uint32_t blocks, uint32_t iters) {
+    if (curve == 0u) hipLaunchKernelGGL(secp_rate_kernel<0>, dim3(blocks), dim3(256), 0, s, out, 1u, iters);
+    else hipLaunchKernelGGL(secp_rate_kernel<1>, dim3(blocks), dim3(256), 0, s, out, 1u, iters);
+}
+
 const uint32_t *ecdsa_generator_tables() {
     static std::mutex mu;
     static std::map<int, uint32_t *> per_device;

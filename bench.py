@@ -194,6 +194,29 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
                           "(acvm_debug_modmul_rate: 8 interleaved chains per SIMD); peak = that probe's measured modmul/s in this run"}
 
 
+# Base-field products (multiplications + squarings of secp_device.hpp) of ONE verification, counted from the routine:
+# decompression 2 + the square-root chain (253 S + 13 / 7 M) + 1; the window table {Q .. 8Q} 119 (+ 8 for the beta x of secp256k1); the ladder
+# 128 / 256 doublings x 7 / 8 and on average 61 / 60.5 mixed additions x 11; 31.9 additions of generator-table points x 11; the final x 2.
+# Not counted: three safegcd inversions and ~12 products of the scalar field per verification (about 8 % of the instructions).
+ECDSA_PRODUCTS = {0: 2 + 266 + 1 + 119 + 8 + 128 * 7 + 61 * 11 + 351 + 2, 1: 2 + 260 + 1 + 120 + 256 * 8 + 665.5 + 351 + 2}
+
+
+def ecdsa_alu_roofline(tile, kernel_ms):
+    """ALU roofline of the ECDSA kernel in base-field products: what one launch computes (both curves, one verification each per instance)
+    per second of its HIP-event time, against the back-to-back sp_mul / sp_sqr probe of each curve measured in this run"""
+    import acvm_amd
+    peaks = [acvm_amd.secp_rate(c, 400, 8)[0] for c in (0, 1)]
+    per_instance = ECDSA_PRODUCTS[0] + ECDSA_PRODUCTS[1]
+    at_peak_s = tile * (ECDSA_PRODUCTS[0] / peaks[0] + ECDSA_PRODUCTS[1] / peaks[1])
+    achieved = tile * per_instance / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+    return {"bound": "valu", "unit": "field products/s", "achieved": achieved, "peak": tile * per_instance / at_peak_s,
+            "frac": at_peak_s / (kernel_ms / 1e3) if kernel_ms > 0 else None,
+            "products_per_verification": {"secp256k1": ECDSA_PRODUCTS[0], "secp256r1": ECDSA_PRODUCTS[1]},
+            "probe_products_per_s": {"secp256k1": peaks[0], "secp256r1": peaks[1]}, "kernel_ms_per_tile": kernel_ms,
+            "definition": "products (multiplications and squarings of the curve's base field) one launch executes, counted from the routine, / its HIP-event "
+                          "time; peak = the time the same products take in the back-to-back sp_mul / sp_sqr probe (acvm_debug_secp_rate, 8 chains per SIMD)"}
+
+
 class ClockSampler:
     """shader clock (MHz) while the timed region runs: rocm-smi polled from a thread; median of the samples, or None"""
 
@@ -329,7 +352,10 @@ def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
                 roof["valu_issue_frac"] = (v / n) * 4.0 / (n_simd * (k_ms / k_launches / 1e3) * sclk_mhz * 1e6)
                 roof["valu_issue_detail"] = {"valu_wave_insts_per_launch": v / n, "sclk_mhz_under_load": sclk_mhz, "simds": n_simd,
                                              "definition": "SQ_INSTS_VALU per launch x 4 cycles / (SIMDs x launch seconds x sclk)"}
-        if dominant in ALU_KERNELS:
+        if args.workload == "ecdsa":
+            alu = ecdsa_alu_roofline(tile, k_ms)
+            roof["note"] = "integer-ALU bound class: the HBM fraction is for information, see alu_roofline"
+        elif dominant in ALU_KERNELS:
             peak, probe_n = acvm_amd.modmul_rate(400, 8)
             alu = measure_alu(args, dominant, k_ms, peak, 8 * 100 * 2 * 256 * acvm_amd.modmul_probe_cus()) or {"bound": "valu", "unit": "modmul/s", "peak": peak, "achieved": None, "frac": None}
             roof["note"] = "integer-ALU bound class: the HBM fraction is for information, see alu_roofline"

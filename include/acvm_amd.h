@@ -180,6 +180,9 @@ int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, u
  * kernel uses) on every SIMD, waves_per_simd dependent chains of 2 * iters products interleaved per SIMD; the best of three timed
  * launches as modmul/s, and the number of products one launch executes. */
 int acvm_debug_modmul_rate(uint32_t iters, uint32_t waves_per_simd, double *modmul_per_s, uint64_t *n_modmul);
+/* The same for the ECDSA kernels: back-to-back base-field products of secp256k1 (curve 0) / secp256r1 (curve 1), a product and a square in turn
+ * (acvm_amd/csrc/secp_device.hpp sp_mul / sp_sqr). */
+int acvm_debug_secp_rate(uint32_t curve, uint32_t iters, uint32_t waves_per_simd, double *products_per_s, uint64_t *n_products);
 /* The measured streaming ceiling of the device for the gate kernel's access shape (reported beside the 8 TB/s spec peak of the HBM
  * roofline): two rows of `bytes` bytes read and one written, 16 bytes per lane, the grid covering the data like a level launch;
  * bytes moved (3 x bytes) per second of the best of four launches, in GB/s. */

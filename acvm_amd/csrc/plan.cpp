@@ -7,22 +7,64 @@
 #include <cstdlib>
 #include <map>
 #include <queue>
+#include <stdexcept>
 #include <unordered_map>
 
 namespace acvm {
 namespace {
 
+// The circuit's constants (pool ids of the device table) and the memo of -1/c. One open-addressing table serves both: a 10^6-opcode circuit
+// with distinct coefficients makes ~10^7 lookups, and two node-based maps spent 40 % of the planning time in cache misses.
 struct ConstPool {
     std::vector<FrH> &pool;
-    struct KeyHash {
-        size_t operator()(const std::array<uint64_t, 4> &k) const {
-            return (size_t)((k[0] * 0x9E3779B97F4A7C15ULL) ^ (k[1] * 0xC2B2AE3D27D4EB4FULL) ^ (k[2] << 1) ^ k[3]);
-        }
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    struct Entry {
+        FrH v, ninv;
+        uint32_t id = NONE, inv_id = NONE;  // pool ids of v and of -1/v once something refers to them
+        uint8_t has_inv = 0;                // 1: ninv = -1/v; 2: queued in prefill_neg_inv
     };
-    std::unordered_map<std::array<uint64_t, 4>, uint32_t, KeyHash> index;
-    std::unordered_map<std::array<uint64_t, 4>, FrH, KeyHash> neg_inv_cache;
+    std::vector<Entry> ents;
+    std::vector<uint64_t> slots;  // tag << 32 | entry index + 1; 0 = empty
+    size_t mask = 0;
     FrH one = frh::one(), minus_one = frh::neg(frh::one());
-    explicit ConstPool(std::vector<FrH> &p) : pool(p) {}
+    explicit ConstPool(std::vector<FrH> &p) : pool(p) { rehash(1u << 12); }
+    static uint64_t hash(const FrH &c) {
+        uint64_t h = c.l[0] * 0x9E3779B97F4A7C15ULL ^ c.l[1] * 0xC2B2AE3D27D4EB4FULL ^ c.l[2] * 0x165667B19E3779F9ULL ^ c.l[3] * 0x27D4EB2F165667C5ULL;
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ULL;
+        return h ^ h >> 32;
+    }
+    void rehash(size_t n) {
+        slots.assign(n, 0);
+        mask = n - 1;
+        for (size_t e = 0; e < ents.size(); e++) {
+            const uint64_t h = hash(ents[e].v);
+            size_t i = h & mask;
+            while (slots[i]) i = (i + 1) & mask;
+            slots[i] = (h >> 32) << 32 | (uint64_t)(e + 1);
+        }
+    }
+    uint32_t entry(const FrH &c) {  // index of c's entry, created on first sight
+        const uint64_t h = hash(c), tag = h >> 32;
+        size_t i = h & mask;
+        for (; slots[i]; i = (i + 1) & mask)
+            if (slots[i] >> 32 == tag && ents[(uint32_t)slots[i] - 1].v == c) return (uint32_t)slots[i] - 1;
+        if (ents.size() >= 0xFFFFFFF0u) throw std::length_error("too many constants");
+        Entry e;
+        e.v = c;
+        e.ninv = frh::zero();
+        ents.push_back(e);
+        slots[i] = tag << 32 | (uint64_t)ents.size();
+        if (ents.size() * 2 > slots.size()) rehash(slots.size() * 2);
+        return (uint32_t)ents.size() - 1;
+    }
+    uint32_t id_of(uint32_t e) {
+        if (ents[e].id == NONE) {
+            ents[e].id = (uint32_t)pool.size();
+            pool.push_back(ents[e].v);
+        }
+        return ents[e].id;
+    }
     uint32_t coef(const FrH &c) {  // multiplicative coefficient
         if (c == one) return COEF_ONE;
         if (c == minus_one) return COEF_MINUS_ONE;
@@ -33,47 +75,56 @@ struct ConstPool {
         if (c.is_zero()) return COEF_ZERO;
         return intern(c);
     }
-    uint32_t intern(const FrH &c) {
-        std::array<uint64_t, 4> k = {c.l[0], c.l[1], c.l[2], c.l[3]};
-        auto it = index.find(k);
-        if (it != index.end()) return it->second;
-        uint32_t id = (uint32_t)pool.size();
-        pool.push_back(c);
-        index.emplace(k, id);
-        return id;
-    }
+    uint32_t intern(const FrH &c) { return id_of(entry(c)); }
     // -1/c for a whole set of coefficients with ONE field inversion (Montgomery's trick): the planner needs -1/c of every
     // coefficient of every Arithmetic opcode (gate folding, and the exact kernels' records), and a host inversion costs
     // as much as 300 products
     void prefill_neg_inv(const std::vector<FrH> &coefs) {
-        std::vector<FrH> todo, prefix;
+        std::vector<uint32_t> todo;
+        std::vector<FrH> prefix;
         for (const FrH &c : coefs) {
             if (c.is_zero() || c == one || c == minus_one) continue;
-            std::array<uint64_t, 4> k = {c.l[0], c.l[1], c.l[2], c.l[3]};
-            if (neg_inv_cache.emplace(k, frh::zero()).second) todo.push_back(c);  // placeholder until the batch is done
+            const uint32_t e = entry(c);
+            if (!ents[e].has_inv) { ents[e].has_inv = 2; todo.push_back(e); }
         }
         if (todo.empty()) return;
         prefix.resize(todo.size());
         FrH acc = frh::one();
-        for (size_t i = 0; i < todo.size(); i++) { acc = frh::mul(acc, todo[i]); prefix[i] = acc; }
+        for (size_t i = 0; i < todo.size(); i++) { acc = frh::mul(acc, ents[todo[i]].v); prefix[i] = acc; }
         FrH inv = frh::inverse(acc);
         for (size_t i = todo.size(); i-- > 0;) {
             const FrH inv_i = i ? frh::mul(inv, prefix[i - 1]) : inv;
-            inv = frh::mul(inv, todo[i]);
-            std::array<uint64_t, 4> k = {todo[i].l[0], todo[i].l[1], todo[i].l[2], todo[i].l[3]};
-            neg_inv_cache[k] = frh::neg(inv_i);
+            inv = frh::mul(inv, ents[todo[i]].v);
+            ents[todo[i]].ninv = frh::neg(inv_i);
+            ents[todo[i]].has_inv = 1;
         }
+    }
+    uint32_t entry_with_inv(const FrH &c) {
+        const uint32_t e = entry(c);
+        if (ents[e].has_inv != 1) {
+            ents[e].ninv = frh::neg(frh::inverse(c));
+            ents[e].has_inv = 1;
+        }
+        return e;
     }
     // -1/c, memoised (real circuits repeat a handful of coefficients)
     FrH neg_inv(const FrH &c) {
         if (c == one) return minus_one;
         if (c == minus_one) return one;
-        std::array<uint64_t, 4> k = {c.l[0], c.l[1], c.l[2], c.l[3]};
-        auto it = neg_inv_cache.find(k);
-        if (it != neg_inv_cache.end()) return it->second;
-        FrH r = frh::neg(frh::inverse(c));
-        neg_inv_cache.emplace(k, r);
-        return r;
+        return ents[entry_with_inv(c)].ninv;
+    }
+    // (coefficient id, id of -1/coefficient) of a linear term of an in-order record, c != 0: one lookup for both
+    void lin_ids(const FrH &c, uint32_t &cid, uint32_t &iid) {
+        if (c == one) { cid = COEF_ONE; iid = COEF_MINUS_ONE; return; }
+        if (c == minus_one) { cid = COEF_MINUS_ONE; iid = COEF_ONE; return; }
+        const uint32_t e = entry_with_inv(c);
+        cid = id_of(e);
+        if (ents[e].inv_id == NONE) {
+            const FrH ni = ents[e].ninv;  // (coef() may grow `ents`)
+            const uint32_t id = coef(ni);
+            ents[e].inv_id = id;
+        }
+        iid = ents[e].inv_id;
     }
 };
 
@@ -138,8 +189,10 @@ void emit_expr(std::vector<uint32_t> &s, ConstPool &pool, const Expr &e) {
         s.push_back(t.r);
     }
     for (auto &t : e.lin) {
-        s.push_back(pool.coef_or_zero(t.c));
-        s.push_back(t.c.is_zero() ? COEF_ZERO : pool.coef(pool.neg_inv(t.c)));
+        uint32_t cid = COEF_ZERO, iid = COEF_ZERO;
+        if (!t.c.is_zero()) pool.lin_ids(t.c, cid, iid);
+        s.push_back(cid);
+        s.push_back(iid);
         s.push_back(t.w);
     }
 }
@@ -935,7 +988,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         const FrH qc_scaled = sc(frh::mul(base, e.qc));
         for (auto &t : terms) {
             const FrH e_t = sc(t.pe);
-            const uint32_t cc = pool.coef(e_t);
+            const uint32_t cc = e_t == f_one ? COEF_ONE : e_t == f_minus_one ? COEF_MINUS_ONE : 0u;  // (a general coefficient travels inline: nothing to intern)
             if (t.prod) {
                 if (cc == COEF_ONE && pp.size() < 2 * 255) { pp.push_back(t.a); pp.push_back(t.b); }
                 else if (cc == COEF_MINUS_ONE && pn.size() < 2 * 255) { pn.push_back(t.a); pn.push_back(t.b); }

@@ -533,7 +533,7 @@ acvm_batch_t *acvm_batch_new_ex(const acvm_circuit_t *c, const acvm_bb_solver_t 
         set_err(ACVM_E_UNSUPPORTED, b->plan.unsupported);
         return nullptr;
     }
-    b->B = n_instances;
+    b->B = b->capacity = n_instances;
     b->Bp = ((uint64_t)n_instances + 63) / 64 * 64;
     if (batch_init(b.get()) != 0) return nullptr;
     return b.release();
@@ -1519,6 +1519,16 @@ static int side_table_outcome(acvm_batch *b, ExactOutcome *out) {
     return 0;
 }
 
+int batch_set_live_count(acvm_batch *b, uint32_t n) {
+    if (!b || !n || n > b->capacity) return set_err(ACVM_E_INVALID, "live count out of range");
+    if (n != b->B) {
+        b->B = n;
+        b->inputs_set = false;
+        b->solved = false;
+        b->stepping = false;
+    }
+    return 0;
+}
 int batch_finish_pending(acvm_batch *b, ExactOutcome *out) {
     if (out) out->clear();
     if (!b->pending) return 0;

@@ -45,7 +45,8 @@ struct LaunchChunk { uint32_t first, count; bool coop = false; uint32_t lds_word
 
 struct acvm_batch {
     Plan plan;
-    uint32_t B = 0;
+    uint32_t B = 0;          // live instances: what the next import / solve covers (batch_set_live_count; <= capacity)
+    uint32_t capacity = 0;   // instances the handle was created for: every table is sized by it
     uint64_t Bp = 0;  // instance stride, multiple of 64
     int device = 0;
     hipStream_t stream = nullptr;
@@ -210,6 +211,9 @@ extern "C" {
 // Turns the handle's exact path asynchronous where the circuit allows it (no caller-supplied solver, no foreign calls, a plan the level
 // kernels cover entirely); `keep` and `digests` say what an outcome carries. Returns 1 if enabled, 0 if the handle stays synchronous.
 int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_keep, bool digests);
+// The next import and solve cover instances [0, n) only, 1 <= n <= the instances the handle was created for (the last, partial tile of a
+// shard: lanes beyond n are dead instead of solving copies of some instance). A pending exact job of the previous solve is unaffected.
+int batch_set_live_count(acvm_batch *b, uint32_t n);
 // waits for the exact job in flight (if any) and moves its outcome into *out (cleared first)
 int batch_finish_pending(acvm_batch *b, ExactOutcome *out);
 // results / kept witnesses / digests of instances [0, n) of the last solve for the instances the LEVEL kernels solved; instances of the

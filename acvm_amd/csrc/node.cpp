@@ -82,9 +82,9 @@ uint32_t auto_tile(const acvm_circuit_t *c, const std::vector<uint32_t> &ids, co
     return t;
 }
 
-// rows [first, first + n) of the caller's inputs into a pinned buffer of `tile` rows; the tail of a partial tile repeats its first row
+// rows [first, first + n) of the caller's inputs into a pinned buffer (a partial tile fills and uploads its own rows only: batch_set_live_count)
 // (a tile of the 10k-gate circuit is 64 MB: one core copies that in ~10 ms, which would be exposed in front of the first tile; four do it in ~3)
-void fill_staging(uint8_t *dst, const uint8_t *values, size_t row, uint64_t first, uint32_t n, uint32_t tile) {
+void fill_staging(uint8_t *dst, const uint8_t *values, size_t row, uint64_t first, uint32_t n) {
     if (row == 0) return;
     const uint8_t *src = values + first * row;
     const size_t bytes = (size_t)n * row;
@@ -98,7 +98,6 @@ void fill_staging(uint8_t *dst, const uint8_t *values, size_t row, uint64_t firs
         memcpy(dst, src, std::min(part, bytes));
         for (auto &h : helpers) h.join();
     }
-    for (uint32_t i = n; i < tile; i++) memcpy(dst + (size_t)i * row, dst, row);
 }
 
 // an outcome of the exact path of the tile that started at global instance `base` (n_valid instances of it are the caller's)
@@ -149,8 +148,8 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
             const uint64_t base = first + (uint64_t)k * tile;
             const uint32_t m = (uint32_t)std::min<uint64_t>(tile, last - base);
             const int slot = (int)(k & 1);
-            fill_staging(L.pinned[slot], values, row, base, m, tile);
-            if (row) hipMemcpyAsync(L.d_in[slot], L.pinned[slot], (size_t)tile * row, hipMemcpyHostToDevice, L.copy);
+            fill_staging(L.pinned[slot], values, row, base, m);
+            if (row) hipMemcpyAsync(L.d_in[slot], L.pinned[slot], (size_t)m * row, hipMemcpyHostToDevice, L.copy);
             hipEventRecord(L.ev_h2d[slot], L.copy);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -204,6 +203,7 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         }
         if (hipEventSynchronize(L.ev_h2d[slot]) != hipSuccess) { fail(ACVM_E_DEVICE, "hipEventSynchronize"); break; }
         L.h2d_wait_ms += now_ms() - t0;
+        if (int rc = batch_set_live_count(L.batch, m)) { fail(rc, "live count"); break; }  // a partial last tile: the lanes behind it are dead
         if (int rc = acvm_batch_set_initial_witness_device(L.batch, L.d_in[slot])) { fail(rc, "set_initial_witness"); break; }
         {   // the import has read the slot: the producer may refill it
             std::lock_guard<std::mutex> lk(mu);

@@ -25,7 +25,7 @@ def plain_batch(data, ids, values, B, keep):
     return res, kept, asg, dig
 
 
-@pytest.mark.parametrize("devices,tile,B", [([0], 256, 1000), ([0, 0], 192, 1000), ([0, 0], 64, 130), ([0, 0, 0], 512, 700)])
+@pytest.mark.parametrize("devices,tile,B", [([0], 256, 1000), ([0, 0], 192, 1000), ([0, 0], 64, 130), ([0, 0, 0], 512, 700), ([0], 512, 3)])
 def test_node_equals_one_batch_and_oracle(oracle, devices, tile, B):
     """mixed circuit with edge-case instances: the flagged instances of every tile take the asynchronous exact path; partial last tiles"""
     import acvm_amd
@@ -45,7 +45,9 @@ def test_node_equals_one_batch_and_oracle(oracle, devices, tile, B):
         assert np.array_equal(dig, want[3])
     st = node.stats()
     assert st["n_devices"] == len(devices) and sum(st["tiles"]) >= (B + tile - 1) // tile
-    assert sum(st["exact_instances"]) > 0 and all(st["async_exact"])
+    assert all(st["async_exact"])
+    # (a partial last tile solves its own instances only: the lanes behind them are dead, not copies of an instance)
+    assert 0 < sum(st["exact_instances"]) <= B
     ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, values, B)
     for j in range(0, B, 7):
         assert res[j].as_tuple() == ores[j].as_tuple()

@@ -44,6 +44,7 @@ for seed in range(n_seeds):
             print(f"seed {seed}: ops {n_ops} B {B} tile {tile} handles {handles} {mode} rep {rep}: DIVERGES")
             sys.exit(1)
     st = node.stats()
+    assert sum(st["exact_instances"]) <= B
     print(f"seed {seed}: ops {n_ops} B {B} tile {tile} handles {handles} {mode}: ok (not solved {not_solved}, exact {sum(st['exact_instances'])}, async {st['async_exact']})", flush=True)
     node.free()
 print(f"{n_seeds} node configurations bit-exact against one batch in {time.time() - t0:.0f} s")

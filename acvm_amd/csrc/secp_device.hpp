@@ -85,49 +85,69 @@ FR_HD __forceinline__ bool secp_geq(const Fr &a, const Fr &b) {
     return fr_sub256(d, a, b) == 0;
 }
 
-// ---- wide products
+// ---- wide products, column by column: a column's 64-bit products are summed in a 96-bit accumulator (acc, top). On the device one term is
+// v_mad_u64_u32 (the 64-bit accumulate of the multiplier, carry out in vcc) + v_addc_co_u32; written in C the compiler builds the 64-bit
+// addend of every term from a zeroed register pair (132 v_mov + 49 64-bit adds beside the 64 multiplies of one product: 245 instructions;
+// this form: 164).
+FR_HD __forceinline__ void secp_mac(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "v"(b) : "vcc");
+#else
+    const uint64_t p = (uint64_t)a * b, s = acc + p;
+    top += s < p ? 1u : 0u;
+    acc = s;
+#endif
+}
 FR_HD __forceinline__ void secp_mul_wide(uint32_t t[16], const Fr &a, const Fr &b) {
+    uint64_t acc = 0;
+    uint32_t top = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0;
+    for (int k = 0; k < 15; k++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.v[j] * b.v[i] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
+        for (int i = 0; i < 8; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 7) continue;
+            secp_mac(acc, top, a.v[i], b.v[j]);
         }
-        t[i + 8] = (uint32_t)c;
+        t[k] = (uint32_t)acc;
+        acc = acc >> 32 | (uint64_t)top << 32;
+        top = 0;
     }
+    t[15] = (uint32_t)acc;
 }
 // 28 cross products, doubled, + 8 squares
 FR_HD __forceinline__ void secp_sqr_wide(uint32_t t[16], const Fr &a) {
+    uint64_t acc = 0;
+    uint32_t top = 0;
+    t[0] = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0;
+    for (int k = 1; k < 14; k++) {
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = i + 1; j < 8; j++) {
-            c += (uint64_t)a.v[i] * a.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
+        for (int i = 0; i < 8; i++) {
+            const int j = k - i;
+            if (j <= i || j > 7) continue;
+            secp_mac(acc, top, a.v[i], a.v[j]);
         }
-        t[i + 8] = (uint32_t)c;
+        t[k] = (uint32_t)acc;
+        acc = acc >> 32 | (uint64_t)top << 32;
+        top = 0;
     }
+    t[14] = (uint32_t)acc;
+    t[15] = (uint32_t)(acc >> 32);
 #pragma unroll
     for (int i = 15; i > 0; i--) t[i] = t[i] << 1 | t[i - 1] >> 31;
-    t[0] <<= 1;
-    uint64_t c = 0;
+    t[0] = 0;
+    uint32_t cin = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] * a.v[i] + t[2 * i];
-        t[2 * i] = (uint32_t)c;
-        c >>= 32;
-        c += t[2 * i + 1];
-        t[2 * i + 1] = (uint32_t)c;
-        c >>= 32;
+    for (int i = 0; i < 8; i++) {  // + a_i^2 at words 2i, 2i + 1, the carry of a pair into the next
+        uint64_t pair = (uint64_t)t[2 * i] | (uint64_t)t[2 * i + 1] << 32;
+        uint32_t over = 0;
+        secp_mac(pair, over, a.v[i], a.v[i]);
+        const uint64_t s = pair + cin;
+        over += s < pair ? 1u : 0u;
+        t[2 * i] = (uint32_t)s;
+        t[2 * i + 1] = (uint32_t)(s >> 32);
+        cin = over;
     }
 }
 

@@ -1169,10 +1169,18 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 waited_heavy[q] = need_h;
             }
         }
+        // the level's light records (not the straight-line Brillig ones: a kernel of their own) ride in the gate launch when there is one
+        const LaunchChunk *fused_light = nullptr;
+        if (n && p.tune.light_fuse)
+            for (const LaunchChunk &ch : b->cls_chunks[CLS_LIGHT][L])
+                if (!ch.coop && (uint64_t)n + ch.count <= 65535u) { fused_light = &ch; break; }
         if (n) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (prof) { e0 = next_event(); hipEventRecord(e0, s); }
-            launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event, b->d_inv);
+            if (fused_light)
+                launch_arith_light_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_inv, b->dp,
+                                         b->d_cls_offset[CLS_LIGHT] + fused_light->first, fused_light->count, b->d_event);
+            else launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event, b->d_inv);
             if (prof) { e1 = next_event(); hipEventRecord(e1, s); tm->reg_pairs.push_back({e0, e1}); }
             b->n_launches += (n + 65534) / 65535;
         }
@@ -1198,6 +1206,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
             }
         for (int k = 0; k < (int)N_CLS; k++)
             for (const LaunchChunk &ch : b->cls_chunks[k][L]) {
+                if (&ch == fused_light) continue;  // went with the gates
                 hipStream_t sk = heavy_cls(k) ? lane_stream[heavy_lane(k)] : s;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (prof) { e0 = next_event(); hipEventRecord(e0, sk); }

@@ -85,48 +85,14 @@ __global__ void __launch_bounds__(256) unscale_slow_kernel(uint4 *__restrict__ W
     fr_store(W, w, Bp, j, fr_mul(fr_load(W, w, Bp, j), fr_const(consts, k)));
 }
 
-// ------------------------------------------------------------------------------------------ level kernel
-// grid = (ceil(B/256), gates in level). Lane = instance. The gate record is wave-uniform.
-__device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream,
-                                                 const uint32_t *__restrict__ gate_offset, const uint32_t *__restrict__ consts,
-                                                 uint32_t *__restrict__ event, const uint4 *__restrict__ Inv) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B) return;
-    const uint32_t *__restrict__ g = gate_stream + gate_offset[blockIdx.y];
-    Fr29 local = fr29_from(fr_zero());
-    bool host = true;
-    for (;;) {  // the record, then the records fused behind it (they read this one's output as GATE_LOCAL)
-        const uint32_t w0 = g[0], kind = w0 & 0xff, opcode = g[1], out = g[2];
-        const GateSum sum = gate_sum_lazy(W, Bp, j, g, consts, local);
-        Fr29 acc;
-        if (kind == 2) {
-            // the unknown is multiplied by a known witness (arithmetic.rs:68-91): out = sum' / partner, and 1 / partner was put
-            // into the inverse table by an earlier inverse_batch_kernel. The lazy sum (< 8p) is a valid product operand as it is.
-            acc = fr29_cond_sub_p(fr29_mul(sum.v, fr29_from(fr_load_nt(Inv, g[4], Bp, j))));
-        } else {
-            acc = gate_sum_canon(sum);
-        }
-        if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
-            uint32_t z = 0;
-#pragma unroll
-            for (int i = 0; i < 9; i++) z |= acc.v[i];
-            if (z) atomicMin(&event[j], opcode);
-        } else {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
-            fr_store_nt(W, out, Bp, j, fr29_pack(acc));  // read again levels later, long after it left the caches: 5.38 -> 5.50 M witnesses/s
-        }
-        if (!(w0 & GATE_TAIL_FLAG)) break;
-        if (host || (w0 & GATE_SETLOCAL_FLAG)) local = acc;  // the tails read the host's output until a record takes `local` over
-        host = false;
-        g += gate_record_words(g);
-    }
-}
+// ------------------------------------------------------------------------------------------ level kernel (body: ops_common.hpp arith_level_body)
 #ifndef ARITH_BLOCK
 #define ARITH_BLOCK 256
 #endif
 __global__ void __launch_bounds__(ARITH_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
 arith_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream, const uint32_t *__restrict__ gate_offset,
                    const uint32_t *__restrict__ consts, uint32_t *__restrict__ event, const uint4 *__restrict__ Inv) {
-    arith_level_body(W, Bp, B, gate_stream, gate_offset, consts, event, Inv);
+    arith_level_body(W, Bp, B, gate_stream, gate_offset, consts, event, Inv, blockIdx.y);
 }
 
 // Denominators of the gates whose unknown is multiplied by a known witness (arithmetic.rs:68-91): 1 / partner for a batch of

@@ -145,6 +145,31 @@ void launch_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
                         uint32_t *event) {
     launch_record_level<LightOp, 256>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
 }
+// A level's gates and its light records in ONE launch (batch.cpp): both are independent work of the same level on the main stream, and as
+// launches of their own the few light records of a level (540 launches of ~20 us on the 10^6-opcode circuit) each ran alone between the drain
+// of one gate launch and the ramp of the next. The light blocks come first (blockIdx.y < n_light): they are the longer ones. Both bodies
+// fit the gate kernel's register budget (78 VGPRs each).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+arith_light_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream, const uint32_t *__restrict__ gate_offset,
+                         const uint32_t *__restrict__ consts, uint32_t *__restrict__ event, const uint4 *__restrict__ Inv, uint32_t n_light,
+                         const uint32_t *__restrict__ light_offsets, const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of, uint4 *Mem) {
+    if (blockIdx.y >= n_light) {
+        arith_level_body(W, Bp, B, gate_stream, gate_offset, consts, event, Inv, blockIdx.y - n_light);
+        return;
+    }
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= B) return;
+    const uint32_t *__restrict__ rec = prog + light_offsets[blockIdx.y];
+    FastPolicy p{W, Bp, j, slot_of};
+    const OpResult r = dispatch_light(p, rec, consts, Mem);
+    if (r.err) atomicMin(&event[j], rec[0] == K_RANGE_MULTI ? r.aux0 : rec[1]);
+}
+void launch_arith_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset, uint32_t n_gates,
+                              const uint4 *inv, const DeviceProgram &dp, const uint32_t *light_offsets, uint32_t n_light, uint32_t *event) {
+    if (!B || !(n_gates + n_light)) return;
+    hipLaunchKernelGGL(arith_light_level_kernel, dim3((B + 255) / 256, n_gates + n_light), dim3(256), 0, s, W, Bp, B, gate_stream, gate_offset, dp.consts, event, inv,
+                       n_light, light_offsets, dp.prog, dp.slot_of, dp.Mem);
+}
 void launch_light_sl_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
                            uint32_t *event) {
     launch_record_level<LightSlOp, LIGHT_SL_BLOCK>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);

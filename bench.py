@@ -44,7 +44,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLASS_KERNEL = ["light_level_kernel", "hash_level_kernel", "grumpkin_level_kernel", "brillig_level_kernel"]
 # substring of the kernel's symbol in the rocprofv3 output
 # substrings of the symbols of the kernels a class's launches run (a class may have several: the byte-message hashes have a kernel of their own)
-KERNEL_SYMBOL = {"arith_level_kernel": ["arith_level_kernel"], "inverse_batch_kernel": ["inverse_batch_kernel"],
+KERNEL_SYMBOL = {"arith_level_kernel": ["arith_level_kernel", "arith_light_level_kernel"],  # (the second: a level whose light records ride along)
+                 "inverse_batch_kernel": ["inverse_batch_kernel"],
                  "light_level_kernel": ["record_level_kernel<acvm::LightOp", "record_level_kernel<acvm::LightSlOp"],
                  "hash_level_kernel": ["hash_coop_level_kernel", "record_level_kernel<acvm::HashOp"],
                  "grumpkin_level_kernel": ["record_level_kernel<acvm::GrumpkinOp", "pedersen_quad_level_kernel", "record_level_kernel<acvm::EcdsaOp"],

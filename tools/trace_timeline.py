@@ -9,7 +9,7 @@ import os
 import sys
 from collections import defaultdict
 
-CLASSES = [("arith", "arith_level_kernel"), ("inv", "inverse_batch_kernel"), ("light", "LightOp"), ("lightsl", "LightSlOp"), ("hash", "hash_coop_level_kernel"),
+CLASSES = [("arith", "arith_l"), ("inv", "inverse_batch_kernel"), ("light", "LightOp"), ("lightsl", "LightSlOp"), ("hash", "hash_coop_level_kernel"),
            ("hash", "HashOp"), ("pedersen", "pedersen_quad"), ("grumpkin", "GrumpkinOp"), ("brillig", "BrilligOp"), ("ecdsa", "EcdsaOp"), ("digest", "digest_")]
 
 

@@ -3,6 +3,7 @@
 // spread the long-running lanes over all SIMDs.
 #include "ops_grumpkin.hpp"
 #include "ops_kernel.hpp"
+#include "tuning.hpp"
 
 namespace acvm {
 
@@ -28,10 +29,16 @@ void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 //    publishes the x coordinate that seeds the next hash_pair.
 // FastPolicy only (level schedule); flagged instances take the one-lane exact kernel on the small tables (same group
 // elements, so the affine results are identical).
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets,
-                                                                  uint32_t *__restrict__ event, const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
-    __shared__ uint32_t lds_acc[4][27][64];  // [wave][limb of X, Y, Z (9 x 29-bit each)][lane]
-    __shared__ uint32_t lds_r[16][64];       // affine result of the step (Montgomery limbs of x, y)
+// WAVES = 1: the same chain on ONE wave per 64 instances, for launches of more than 512 groups (half the SIMDs hold a wave of it): no
+// partial points to combine -- the three Jacobian additions of every step are 12 % of a commitment's products -- no LDS, no barriers.
+// Alone on the device (tools/t_pedersen_sweep.py): 8 records x 2^16 instances 3.41 -> 2.61 ms, 1 record x 2^16 0.56 -> 0.44 ms, equal at 512
+// groups, and below that the four-wave form wins on latency (64 groups: 0.22 against 0.37 ms).
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
+pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
+                           const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
+    __shared__ uint32_t lds_acc[WAVES == 4 ? 4 : 1][WAVES == 4 ? 27 : 1][64];  // [wave][limb of X, Y, Z (9 x 29-bit each)][lane]
+    __shared__ uint32_t lds_r[WAVES == 4 ? 16 : 1][64];                         // affine result of the step (Montgomery limbs of x, y)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;  // a scalar: loop bounds and record words indexed by it stay scalar
     const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
     const bool active = j < B;
@@ -49,56 +56,69 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     // point. Step 1 therefore only walks the 15 generators of the first input (4, 4, 4, 3 per wave) and adds the seed point;
     // from step 2 on, wave w takes generators [0, 8) or [8, 15) (w & 1) of the running value or of the next input (w >> 1).
     Fr r = fr_zero(), y = fr_zero();
-    for (uint32_t step = 1; step <= n; step++) {
-        const uint32_t parity = step == 1 ? 1u : wave >> 1;
-        const uint32_t i0 = step == 1 ? 4u * wave : (wave & 1u ? 8u : 0u), i1 = step == 1 ? (wave == 3 ? 15u : 4u * wave + 4u) : (wave & 1u ? 15u : 8u);
-        Fr src = r;
-        if (parity) src = active ? p.load(ws[step - 1]) : fr_one();
+    // one pair-table entry per 18 bits (even slice through the endomorphism + odd slice): generators [i0, i1) of one operand onto acc
+    auto walk = [&](GJac acc, const Fr &src, uint32_t parity, uint32_t i0, uint32_t i1) {
         const Fr v = fr_to_canonical(src);
-        // one pair-table entry per 18 bits (even slice through the endomorphism + odd slice)
-        GJac acc = gj_inf();
         const uint32_t gen0 = parity ? 15u : 0u;
         for (uint32_t i = i0; i < i1; i++) {
             const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
             acc = gj_add_aff(acc, gaff_load(T.ped2, ((gen0 + i) << GRUMPKIN_PED2_LOG2) | a << 9 | b));
         }
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            lds_acc[wave][k][lane] = acc.X.v[k];
-            lds_acc[wave][9 + k][lane] = acc.Y.v[k];
-            lds_acc[wave][18 + k][lane] = acc.Z.v[k];
-        }
-        __syncthreads();
-        // the serial tail of the step (three additions, one inversion) rotates over the four waves
-        if (wave == ((blockIdx.x + blockIdx.y + step) & 3u)) {
-            GJac s = acc;
+        return acc;
+    };
+    for (uint32_t step = 1; step <= n; step++) {
+        if constexpr (WAVES == 1) {
+            GJac s = walk(gj_inf(), active ? p.load(ws[step - 1]) : fr_one(), 1u, 0u, 15u);
             if (step == 1) s = gj_add_aff(s, GAff{fr_const(dp.ped_seed, 2 * ws[n]), fr_const(dp.ped_seed, 2 * ws[n] + 1)});
-            for (uint32_t dw = 1; dw < 4; dw++) {
-                const uint32_t w2 = (wave + dw) & 3u;
-                GJac o;
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    o.X.v[k] = lds_acc[w2][k][lane];
-                    o.Y.v[k] = lds_acc[w2][9 + k][lane];
-                    o.Z.v[k] = lds_acc[w2][18 + k][lane];
-                }
-                s = gj_add(s, o);
-            }
+            else s = walk(s, r, 0u, 0u, 15u);
             bool inf;
             const GAff a = gj_to_aff(s, &inf);
+            r = a.x;
+            y = a.y;
+        } else {
+            const uint32_t parity = step == 1 ? 1u : wave >> 1;
+            const uint32_t i0 = step == 1 ? 4u * wave : (wave & 1u ? 8u : 0u), i1 = step == 1 ? (wave == 3 ? 15u : 4u * wave + 4u) : (wave & 1u ? 15u : 8u);
+            Fr src = r;
+            if (parity) src = active ? p.load(ws[step - 1]) : fr_one();
+            const GJac acc = walk(gj_inf(), src, parity, i0, i1);
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                lds_acc[wave][k][lane] = acc.X.v[k];
+                lds_acc[wave][9 + k][lane] = acc.Y.v[k];
+                lds_acc[wave][18 + k][lane] = acc.Z.v[k];
+            }
+            __syncthreads();
+            // the serial tail of the step (three additions, one inversion) rotates over the four waves
+            if (wave == ((blockIdx.x + blockIdx.y + step) & 3u)) {
+                GJac s = acc;
+                if (step == 1) s = gj_add_aff(s, GAff{fr_const(dp.ped_seed, 2 * ws[n]), fr_const(dp.ped_seed, 2 * ws[n] + 1)});
+                for (uint32_t dw = 1; dw < 4; dw++) {
+                    const uint32_t w2 = (wave + dw) & 3u;
+                    GJac o;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        o.X.v[k] = lds_acc[w2][k][lane];
+                        o.Y.v[k] = lds_acc[w2][9 + k][lane];
+                        o.Z.v[k] = lds_acc[w2][18 + k][lane];
+                    }
+                    s = gj_add(s, o);
+                }
+                bool inf;
+                const GAff a = gj_to_aff(s, &inf);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    lds_r[k][lane] = a.x.v[k];
+                    lds_r[8 + k][lane] = a.y.v[k];
+                }
+            }
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                lds_r[k][lane] = a.x.v[k];
-                lds_r[8 + k][lane] = a.y.v[k];
+                r.v[k] = lds_r[k][lane];
+                y.v[k] = lds_r[8 + k][lane];
             }
+            __syncthreads();  // lds_r / lds_acc are rewritten by the next step
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            r.v[k] = lds_r[k][lane];
-            y.v[k] = lds_r[8 + k][lane];
-        }
-        __syncthreads();  // lds_r / lds_acc are rewritten by the next step
     }
     if (wave == 0 && active && (!p.insert(rec[4], r, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
 }
@@ -169,9 +189,13 @@ void launch_pedersen_pair_table(hipStream_t s, const GrumpkinTables &T, uint4 *o
 void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
                            uint32_t *event) {
     if (!n || !B) return;
+    const uint64_t groups = (uint64_t)((B + 63u) / 64u) * n;  // one per 64 instances of a record
+    const int64_t mode = tuning().pedersen_waves;               // 0: by the size of the launch; 1 / 4: forced (A/B measurements)
+    const bool one = mode == 1 || (mode != 4 && groups > 512u);  // (measured alone, tools/t_pedersen_sweep.py: equal at 512 groups, one wave 21-24 % faster from 1 024 on)
     for (uint32_t done = 0; done < n;) {
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        hipLaunchKernelGGL(pedersen_quad_level_kernel, dim3((B + 63) / 64, m), dim3(256), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
+        if (one) hipLaunchKernelGGL(pedersen_quad_level_kernel<1>, dim3((B + 63) / 64, m), dim3(64), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
+        else hipLaunchKernelGGL(pedersen_quad_level_kernel<4>, dim3((B + 63) / 64, m), dim3(256), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
         done += m;
     }
 }

@@ -575,6 +575,12 @@ int acvm_batch_set_profiling(acvm_batch_t *b, int on) {
     b->profiling = on != 0;
     return 0;
 }
+int acvm_batch_set_instances(acvm_batch_t *b, uint32_t n) try {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
+    return batch_set_live_count(b, n);
+} ABI_CATCH
 int acvm_batch_reset(acvm_batch_t *b) {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     b->solved = false;

@@ -246,6 +246,10 @@ int acvm_batch_solve(acvm_batch_t *b);
 int acvm_batch_solve_opcode(acvm_batch_t *b);
 /* back to the state right after set_initial_witness (same inputs, nothing solved) */
 int acvm_batch_reset(acvm_batch_t *b);
+/* The handle serves any batch size up to the n_instances it was created with (its plan and tables are kept): from the next
+ * acvm_batch_set_initial_witness on, every call covers instances [0, n), 1 <= n <= that capacity; the lanes behind n are dead. A caller whose
+ * batches vary in size creates ONE handle for the largest (planning a 10^6-opcode circuit takes seconds) instead of one per size. */
+int acvm_batch_set_instances(acvm_batch_t *b, uint32_t n);
 /* force every instance through the exact in-order kernel instead of the level-parallel one (validation) */
 int acvm_batch_set_force_slow_path(acvm_batch_t *b, int on);
 int acvm_batch_results(acvm_batch_t *b, acvm_result_t *out /*[n_instances]*/);

@@ -213,3 +213,38 @@ def test_multi_repeated_id_keeps_its_last_value(oracle):
         assert L.acvm_multi_witness_map(h, inst, asg.ctypes.data, v.ctypes.data) == 0
         assert asg[3] and int.from_bytes(v[3].tobytes(), "big") == want
     L.acvm_multi_free(h)
+
+
+@pytest.mark.parametrize("flags", [{}, {"fold_digest": True, "reuse_slots": True}])
+def test_one_handle_serves_smaller_batches(oracle, flags):
+    """acvm_batch_set_instances: a handle created for 300 instances solves batches of 300, 70, 1 and 300 again -- results, every witness and the
+    digests equal the oracle's for exactly the live instances (edge-case inputs: some take the exact path)"""
+    circ, ids = synth.mixed_circuit(400, seed=0xAC1D0B07)
+    data = circ.to_bytes()
+    gc = acvm_amd.Circuit(data)
+    keep = gc.witness_set("return_values") + [ids[0]]
+    try:
+        batch = acvm_amd.Batch(gc, 300, ids, keep=keep, **flags)
+    except acvm_amd.AcvmError as e:
+        pytest.skip(f"planner refuses this mode for the circuit: {e}")
+    oc = oracle.Circuit(data)
+    for n, seed in ((300, 1), (70, 2), (1, 3), (300, 4)):
+        values = synth.witness_batch(n, seed=0xAC1D0B07 + seed, edge_cases=True)
+        batch.set_instances(n)
+        batch.set_initial_witness(values)
+        batch.solve()
+        res = batch.results()
+        ores, oasg, ovals = oracle.solve_batch(oc, ids, values, n)
+        assert len(res) == n and [r.as_tuple() for r in res] == [r.as_tuple() for r in ores]
+        dig = batch.digest()
+        assert dig.shape[0] == n
+        for j in range(n):
+            assert bytes(dig[j]) == oracle.witness_map_digest(oasg[j], ovals[j]), (n, j)
+        for w in keep:
+            v, a = batch.witness(w)
+            assert v.shape[0] == n and np.array_equal(a.astype(bool), oasg[:, w].astype(bool)) and np.array_equal(v[a.astype(bool)], ovals[:, w][a.astype(bool)])
+    with pytest.raises(acvm_amd.AcvmError):
+        batch.set_instances(301)
+    with pytest.raises(acvm_amd.AcvmError):
+        batch.set_instances(0)
+    batch.free()

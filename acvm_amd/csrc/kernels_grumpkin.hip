@@ -36,9 +36,10 @@ void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
 pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
-                           const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
+                           const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of, uint32_t prio) {
     __shared__ uint32_t lds_acc[WAVES == 4 ? 4 : 1][WAVES == 4 ? 27 : 1][64];  // [wave][limb of X, Y, Z (9 x 29-bit each)][lane]
     __shared__ uint32_t lds_r[WAVES == 4 ? 16 : 1][64];                         // affine result of the step (Montgomery limbs of x, y)
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;  // a scalar: loop bounds and record words indexed by it stay scalar
     const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
     const bool active = j < B;
@@ -191,11 +192,12 @@ void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
     if (!n || !B) return;
     const uint64_t groups = (uint64_t)((B + 63u) / 64u) * n;  // one per 64 instances of a record
     const int64_t mode = tuning().pedersen_waves;               // 0: by the size of the launch; 1 / 4: forced (A/B measurements)
+    const uint32_t prio = (uint32_t)tuning().pedersen_prio;
     const bool one = mode == 1 || (mode != 4 && groups > 512u);  // (measured alone, tools/t_pedersen_sweep.py: equal at 512 groups, one wave 21-24 % faster from 1 024 on)
     for (uint32_t done = 0; done < n;) {
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        if (one) hipLaunchKernelGGL(pedersen_quad_level_kernel<1>, dim3((B + 63) / 64, m), dim3(64), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
-        else hipLaunchKernelGGL(pedersen_quad_level_kernel<4>, dim3((B + 63) / 64, m), dim3(256), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
+        if (one) hipLaunchKernelGGL(pedersen_quad_level_kernel<1>, dim3((B + 63) / 64, m), dim3(64), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of, prio);
+        else hipLaunchKernelGGL(pedersen_quad_level_kernel<4>, dim3((B + 63) / 64, m), dim3(256), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of, prio);
         done += m;
     }
 }

@@ -23,6 +23,7 @@ struct Tuning {
     int64_t range_merge = 1;       // RANGE opcodes of a level, eight to a record
     int64_t brillig_inline = 1;    // straight-line Brillig programs compiled into light records of the level schedule
     int64_t pedersen_waves = 0;    // waves per 64 instances of the level Pedersen kernel: 0 = four, or one when the launch fills the chip anyhow; 1 / 4 force
+    int64_t pedersen_prio = 1;     // s_setprio 3 in the level Pedersen kernel: its few long waves win the issue arbitration against the gate kernel's many
     int64_t light_fuse = 1;        // the light records of a level ride in its gate launch
     int64_t brillig_mem_cells = 0; // lower bound of the per-lane Brillig memory of the level kernels (0: the planner's estimate)
     // ---- driver (batch.cpp)

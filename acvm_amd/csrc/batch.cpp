@@ -1507,7 +1507,7 @@ static int side_table_outcome(acvm_batch *b, ExactOutcome *out) {
     const size_t sel_bytes = align256((size_t)std::max<uint32_t>(n_keep, 1) * 4), val_bytes = align256((size_t)n_slow * std::max<uint32_t>(n_keep, 1) * 32);
     if (int rc = stage_reserve(b, sel_bytes + val_bytes)) return rc;
     Unscale plain = b->unscale;
-    plain.event = b->d_slow_start;  // all zero: nothing in the side table is scaled
+    plain.event = b->d_slow_start;  // (opcode indices, never 0xFFFFFFFF = "solved by the level kernels": nothing in the side table is scaled)
     if (n_keep) {
         uint32_t *d_sel = (uint32_t *)b->d_stage;
         uint8_t *d_val = b->d_stage + sel_bytes;
@@ -1730,7 +1730,7 @@ static int reuse_check_kept(const acvm_batch *b, const uint32_t *ws, uint32_t n)
 static int reuse_patch_exact(acvm_batch *b, const uint32_t *d_sel, uint32_t n_sel, uint32_t first, uint32_t n, uint8_t *values_be32, uint8_t *d_tmp) {
     if (!b->side()) return 0;
     Unscale plain = b->unscale;
-    plain.event = b->d_slow_start;  // all zero in this mode: "not the generic instance", nothing is scaled in the exact table
+    plain.event = b->d_slow_start;  // opcode indices, never 0xFFFFFFFF: "not the generic instance", nothing is scaled in the exact table
     for (uint32_t i = 0; i < n; i++) {
         const int32_t t = b->slow_index[first + i];
         if (t < 0) continue;
@@ -2079,7 +2079,7 @@ static int digest_exact_instances(acvm_batch *b, const std::vector<uint32_t> &fl
     const uint32_t n_slow = (uint32_t)b->slow_ids.size();
     if (b->side()) {  // all lanes of the side table at once (lane t = the t-th flagged instance), then scattered to their instances
         Unscale plain = b->unscale;
-        plain.event = b->d_slow_start;  // all zero: every lane of the side table is "an instance of the exact path"
+        plain.event = b->d_slow_start;  // opcode indices, never 0xFFFFFFFF: every lane of the side table is "an instance of the exact path"
         std::vector<uint8_t> lanes((size_t)n_slow * 32);
         if (int rc = digest_range(b, b->stream, b->d_Wx, b->x_cap, 0, n_slow, plain, (const int32_t *)b->d_ids_x, false, n_slow, lanes.data())) return rc;
         for (uint32_t j : flagged) memcpy(out32 + (size_t)(j - first) * 32, &lanes[(size_t)b->slow_index[j] * 32], 32);

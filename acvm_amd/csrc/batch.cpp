@@ -252,6 +252,7 @@ static void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_table_rows = p.slot_of.empty() ? p.n_witnesses : p.n_slots;
     out->n_digest_segments = p.n_digest_segments;
     out->n_brillig_inlined = p.n_brillig_inlined;
+    out->n_hash_chained = p.n_hash_chained;
     for (uint32_t L = 0; L + 1 < p.level_start.size(); L++) out->n_arith_launches += (p.level_start[L + 1] - p.level_start[L] + 65534) / 65535;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
@@ -374,7 +375,17 @@ static int batch_init(acvm_batch *b) {
                 // The LDS message of a launch is sized by its longest record (a 1 024-byte message takes the whole 64 KiB a workgroup may have):
                 // short messages (<= 256 bytes: 16 KiB per 64 instances) and long ones get launches of their own, so that one long message
                 // somewhere in the circuit does not cost every 64-byte SHA record its occupancy.
-                auto words_of = [&](uint32_t r) { return (b->plan.prog[b->plan.cls_offset[k][r] + 3] + 3u) / 4u; };
+                auto words_of = [&](uint32_t r) {  // message words of the record, or of the longest member of the chain it heads (plan.cpp hash chains)
+                    uint32_t words = 0;
+                    for (size_t at = b->plan.cls_offset[k][r];;) {
+                        const std::vector<uint32_t> &pg = b->plan.prog;
+                        const uint32_t n_in = pg[at + 3];
+                        words = std::max(words, (n_in + 3u) / 4u);
+                        if (!(pg[at + 2] & PLAN_HASH_CHAIN_FLAG)) break;
+                        at = pg[pg[at + 6 + 2 * (size_t)n_in + 64 + ((pg[at + 2] & PLAN_HASH_RANGE_FLAG) ? 2 * (size_t)n_in : 0)]];
+                    }
+                    return words;
+                };
                 std::vector<std::pair<uint32_t, uint32_t>> recs;  // (offset, scratch)
                 uint32_t n_pass[3] = {0, 0, 0}, words_pass[2] = {0, 0};
                 for (int pass = 0; pass < 3; pass++)

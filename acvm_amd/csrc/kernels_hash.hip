@@ -36,11 +36,16 @@ __device__ __forceinline__ uint32_t range_check(const uint32_t *__restrict__ ran
 // WAVES = 1 is the same kernel for launches that fill the chip anyhow (many records per level): one wave per 64 instances does every
 // phase, still with the message in LDS and the lean register budget (the lane-per-instance kernel with the message in device scratch
 // and 184 VGPRs measured 6.0 ms for the hash class of the config-5 mix at 2^16 instances).
+// Chains (plan.cpp "hash chains"): a record whose function word carries HASH_CHAIN_FLAG is followed, in the same block, by the byte-message hash that
+// consumes its digest (a hash of a hash, a Merkle path): the word behind the record is the offset of a link [offset of the next record, source of
+// each of its inputs: index of the previous digest's byte or NONE]; the next record takes those bytes from LDS instead of reading back the rows the
+// block has just written, and the launch of its own (and the lock-step read / hash / write phases of that launch) is gone.
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
 hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
                        const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
-    extern __shared__ uint32_t lds[];  // max(message words of the launch's longest record, 8) x 64 words
+    extern __shared__ uint32_t lds[];       // max(message words of the launch's longest record, 8) x 64 words
+    __shared__ uint32_t lds_prev[8][64];    // the digest of the previous record of a chain
     // (the wave index as a scalar: everything indexed by it -- record words, witness ids, rows of slot_of -- is then a scalar load; as a
     // vector value each of those was a memory round trip of its own in front of every row)
     const uint32_t lane = threadIdx.x & 63u, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -48,55 +53,75 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, cons
     // (prog and slot_of arrive as kernel arguments of their own, not inside dp: only a noalias argument lets the compiler read the record
     // with scalar loads; through the struct every record word was a vector load that also waited for the stores before it)
     const uint32_t *__restrict__ rec = prog + offsets[blockIdx.y];
+    const uint32_t *__restrict__ src = nullptr;  // per input of a chained record: byte of the previous digest, or NONE (null: the head of a chain)
     FastPolicy p{W, Bp, j, slot_of};
-    const uint32_t func = rec[2] & 0xffu, n_in = rec[3];
-    const uint32_t *ins = rec + 6, *outs = ins + 2 * n_in;
     const bool live = j < B;  // (rows are padded to Bp: the loads of a dead lane stay inside the table)
     uint8_t *bytes = (uint8_t *)lds;
-    const uint32_t *ranges = (rec[2] & HASH_RANGE_FLAG) ? outs + 64 : nullptr;  // (opcode or NONE, bits) per input
-    uint32_t range_bad = 0xFFFFFFFFu;
-    if (q == 0 && (n_in & 3u)) lds[(n_in >> 2) * 64u + lane] = 0u;  // the bytes behind the message in its last word
-    __syncthreads();
-    for (uint32_t i = q; i < n_in; i += 4u * WAVES) {  // wave-uniform bounds
-        const uint32_t i1 = i + WAVES, i2 = i + 2u * WAVES, i3 = i + 3u * WAVES;
-        const Fr a0 = p.load(ins[2 * i]);
-        const Fr a1 = i1 < n_in ? p.load(ins[2 * i1]) : a0, a2 = i2 < n_in ? p.load(ins[2 * i2]) : a0, a3 = i3 < n_in ? p.load(ins[2 * i3]) : a0;
-        bool b0, b1, b2, b3;  // the value is a byte (then l is that byte)
-        const uint32_t l0 = fr_low_limb(a0, b0), l1 = fr_low_limb(a1, b1), l2 = fr_low_limb(a2, b2), l3 = fr_low_limb(a3, b3);
-        bytes[4u * ((i >> 2) * 64u + lane) + (i & 3u)] = (uint8_t)l0;
-        if (i1 < n_in) bytes[4u * ((i1 >> 2) * 64u + lane) + (i1 & 3u)] = (uint8_t)l1;
-        if (i2 < n_in) bytes[4u * ((i2 >> 2) * 64u + lane) + (i2 & 3u)] = (uint8_t)l2;
-        if (i3 < n_in) bytes[4u * ((i3 >> 2) * 64u + lane) + (i3 & 3u)] = (uint8_t)l3;
-        if (ranges) {  // the RANGE opcodes fused into this record (plan.cpp): same test as op_range on the limb that is here already
-            range_bad = min(range_bad, range_check(ranges, i, b0, l0));
-            if (i1 < n_in) range_bad = min(range_bad, range_check(ranges, i1, b1, l1));
-            if (i2 < n_in) range_bad = min(range_bad, range_check(ranges, i2, b2, l2));
-            if (i3 < n_in) range_bad = min(range_bad, range_check(ranges, i3, b3, l3));
+    for (;;) {
+        const uint32_t func = rec[2] & 0xffu, n_in = rec[3];
+        const uint32_t *ins = rec + 6, *outs = ins + 2 * n_in;
+        const uint32_t *ranges = (rec[2] & HASH_RANGE_FLAG) ? outs + 64 : nullptr;  // (opcode or NONE, bits) per input
+        uint32_t range_bad = 0xFFFFFFFFu;
+        if (q == 0 && (n_in & 3u)) lds[(n_in >> 2) * 64u + lane] = 0u;  // the bytes behind the message in its last word
+        __syncthreads();
+        // one input: (low limb, is a byte) from its row, or the byte of the previous digest
+        auto fetch = [&](uint32_t i, bool &is_byte) {
+            const uint32_t from = src ? src[i] : 0xFFFFFFFFu;  // (scalar: i is wave-uniform)
+            if (from != 0xFFFFFFFFu) {
+                is_byte = true;
+                return (lds_prev[from >> 2][lane] >> (8u * (from & 3u))) & 0xffu;
+            }
+            return fr_low_limb(p.load(ins[2 * i]), is_byte);
+        };
+        for (uint32_t i = q; i < n_in; i += 4u * WAVES) {  // wave-uniform bounds
+            const uint32_t i1 = i + WAVES, i2 = i + 2u * WAVES, i3 = i + 3u * WAVES;
+            bool b0, b1 = true, b2 = true, b3 = true;  // the value is a byte (then l is that byte)
+            const uint32_t l0 = fetch(i, b0), l1 = i1 < n_in ? fetch(i1, b1) : 0u, l2 = i2 < n_in ? fetch(i2, b2) : 0u, l3 = i3 < n_in ? fetch(i3, b3) : 0u;
+            bytes[4u * ((i >> 2) * 64u + lane) + (i & 3u)] = (uint8_t)l0;
+            if (i1 < n_in) bytes[4u * ((i1 >> 2) * 64u + lane) + (i1 & 3u)] = (uint8_t)l1;
+            if (i2 < n_in) bytes[4u * ((i2 >> 2) * 64u + lane) + (i2 & 3u)] = (uint8_t)l2;
+            if (i3 < n_in) bytes[4u * ((i3 >> 2) * 64u + lane) + (i3 & 3u)] = (uint8_t)l3;
+            if (ranges) {  // the RANGE opcodes fused into this record (plan.cpp): same test as op_range on the limb that is here already
+                range_bad = min(range_bad, range_check(ranges, i, b0, l0));
+                if (i1 < n_in) range_bad = min(range_bad, range_check(ranges, i1, b1, l1));
+                if (i2 < n_in) range_bad = min(range_bad, range_check(ranges, i2, b2, l2));
+                if (i3 < n_in) range_bad = min(range_bad, range_check(ranges, i3, b3, l3));
+            }
         }
-    }
-    if (range_bad != 0xFFFFFFFFu && live) atomicMin(&event[j], range_bad);
-    __syncthreads();
-    Digest d;
-    if (q == 0) {
-        const LdsMsg m{lds, lane};
-        if (func == 3u) d = sha256_body(m, n_in);
-        else if (func == 4u) d = blake2s_body(m, n_in);
-        else d = keccak256_body(m, n_in);
-    }
-    __syncthreads();  // the message has been read
-    if (q == 0) {
+        if (range_bad != 0xFFFFFFFFu && live) atomicMin(&event[j], range_bad);
+        __syncthreads();
+        Digest d;
+        if (q == 0) {
+            const LdsMsg m{lds, lane};
+            if (func == 3u) d = sha256_body(m, n_in);
+            else if (func == 4u) d = blake2s_body(m, n_in);
+            else d = keccak256_body(m, n_in);
+        }
+        __syncthreads();  // the message has been read
+        const bool more = (rec[2] & HASH_CHAIN_FLAG) != 0u;
+        if (q == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) lds[(uint32_t)k * 64u + lane] = d.d[k];
+            for (int k = 0; k < 8; k++) {
+                lds[(uint32_t)k * 64u + lane] = d.d[k];
+                if (more) lds_prev[k][lane] = d.d[k];
+            }
+        }
+        __syncthreads();
+        if (live) {
+            bool ok = true;
+            for (uint32_t k = 0; k < 32u / WAVES; k++) {
+                const uint32_t i = (32u / WAVES) * q + k;
+                const uint32_t byte = (lds[(i >> 2) * 64u + lane] >> (8u * (i & 3u))) & 0xffu;
+                ok = p.insert(outs[2 * i], fr_from_byte(byte), outs[2 * i + 1]) && ok;  // (hash.rs:92-103 stops at the first conflict; the flagged instance re-runs exactly)
+            }
+            if (!ok) atomicMin(&event[j], rec[1]);
+        }
+        if (!more) break;
+        const uint32_t *__restrict__ link = prog + (ranges ? ranges + 2 * n_in : outs + 64)[0];
+        __syncthreads();  // every wave has read its part of the digest out of `lds`, which the next message overwrites
+        rec = prog + link[0];
+        src = link + 1;
     }
-    __syncthreads();
-    if (!live) return;
-    bool ok = true;
-    for (uint32_t k = 0; k < 32u / WAVES; k++) {
-        const uint32_t i = (32u / WAVES) * q + k;
-        const uint32_t byte = (lds[(i >> 2) * 64u + lane] >> (8u * (i & 3u))) & 0xffu;
-        ok = p.insert(outs[2 * i], fr_from_byte(byte), outs[2 * i + 1]) && ok;  // (hash.rs:92-103 stops at the first conflict; the flagged instance re-runs exactly)
-    }
-    if (!ok) atomicMin(&event[j], rec[1]);
 }
 void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event, uint32_t lds_words) {
     if (!n || !B) return;

@@ -318,6 +318,7 @@ __device__ __forceinline__ Fr digest_to_field(const Digest &d) {
 // (3 SHA256, 4 Blake2s, 7 HashToField128Security, 11 Keccak256, 12 Keccak256VariableLength), | HASH_COOP_FLAG when every input is one
 // byte wide, the function is 3, 4 or 11, n_out == 32 and 1 <= n_in <= 1024 (plan.cpp)
 static constexpr uint32_t HASH_COOP_FLAG = 0x100u;
+static constexpr uint32_t HASH_CHAIN_FLAG = 0x400u;  // level-schedule copy of the record: one more word behind it, the offset of the link to the record that hashes this digest (kernels_hash.hip)
 static constexpr uint32_t HASH_RANGE_FLAG = 0x200u;  // level-schedule copy of the record: (RANGE opcode or NONE, bits) x n_in behind the outputs
 template <class P>
 __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restrict__ r, uint32_t *scratch) {

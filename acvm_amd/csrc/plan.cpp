@@ -156,6 +156,7 @@ struct PendingRecord {
     std::vector<uint32_t> reads;  // witnesses it reads (compared outputs included)
     bool synthetic = false;       // a level-schedule record without an opcode of its own (digest leaves, merged RANGE checks): `opcode` is its offset in prog
     uint32_t prog_at = 0xFFFFFFFFu;  // the level schedule runs this copy of the opcode's record instead (a hash record extended by fused RANGE checks)
+    bool chained = false;            // runs behind another hash record in that record's workgroup (hash chains): not in the level lists
 };
 // inversion of a SOLVE_DYN gate's denominator: runs beside level `level`, its result is read by gate `gate` at `use_level`
 struct PendingInverse {
@@ -1200,6 +1201,108 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             records.swap(kept);
         }
     }
+    // =========================================================================== hash chains
+    // A byte-message hash B whose inputs are the digest of another byte-message hash A plus witnesses that were already known when A was
+    // launched (a hash of a hash; the links of a Merkle path) runs behind A in A's workgroup (kernels_hash.hip): the level schedule gets a
+    // copy of A's record with PLAN_HASH_CHAIN_FLAG and one more word, the offset of a link [offset of B's record, per input of B: the byte
+    // of A's digest it is, or NONE]; B itself leaves the level lists (its outputs count as written by A's launch). B may carry a link of its
+    // own. Only the previous digest is at hand in the block, so B reads nothing of an earlier member of its chain.
+    if (tune.hash_chain) {
+        auto rec_at = [&](const PendingRecord &r) { return (size_t)(r.prog_at != 0xFFFFFFFFu ? r.prog_at : p.prog_offset[r.opcode]); };
+        auto is_coop = [&](const PendingRecord &r) { return !r.synthetic && r.cls == CLS_HASH && (p.prog[rec_at(r) + 2] & PLAN_HASH_COOP_FLAG) && p.prog[rec_at(r) + 4] == 32u; };
+        std::unordered_map<uint32_t, std::pair<size_t, uint32_t>> digest_byte;  // witness -> (record, index of the output)
+        std::vector<size_t> hashes;
+        for (size_t i = 0; i < records.size(); i++) {
+            if (!is_coop(records[i])) continue;
+            hashes.push_back(i);
+            const size_t at = rec_at(records[i]);
+            const uint32_t n_in = p.prog[at + 3];
+            for (uint32_t k = 0; k < 32u; k++) {
+                const uint32_t w = p.prog[at + 6 + 2 * n_in + 2 * k];
+                if (p.producer[w] == records[i].opcode) digest_byte.emplace(w, std::make_pair(i, k));  // (an output that only compares is no source)
+            }
+        }
+        std::sort(hashes.begin(), hashes.end(), [&](size_t a, size_t b) { return records[a].level != records[b].level ? records[a].level < records[b].level : a < b; });
+        const size_t NO = (size_t)-1;
+        std::vector<size_t> next(records.size(), NO), prev(records.size(), NO);
+        std::vector<uint32_t> launch_level(records.size(), 0);
+        for (size_t i : hashes) launch_level[i] = records[i].level;
+        for (size_t bi : hashes) {
+            const size_t at = rec_at(records[bi]);
+            const uint32_t n_in = p.prog[at + 3];
+            size_t a = NO;
+            bool ok = true;
+            for (uint32_t k = 0; k < n_in && ok; k++) {
+                auto it = digest_byte.find(p.prog[at + 6 + 2 * k]);
+                if (it == digest_byte.end() || it->second.first == bi) continue;
+                const size_t cand = it->second.first;
+                if (records[cand].level >= records[bi].level) continue;  // not a producer of this input on the schedule (then the check below refuses)
+                if (a == NO) a = cand;
+                else if (a != cand && records[cand].level > records[a].level) a = cand;  // the youngest producer is the only possible predecessor
+            }
+            if (a == NO || next[a] != NO) continue;
+            const uint32_t head_level = launch_level[a];
+            for (uint32_t k = 0; k < n_in && ok; k++) {
+                const uint32_t w = p.prog[at + 6 + 2 * k];
+                auto it = digest_byte.find(w);
+                if (it != digest_byte.end() && it->second.first == a) continue;
+                ok = level[w] + 1 <= head_level;  // known before the launch of the head: readable from the table like the head's own inputs
+            }
+            for (uint32_t w : records[bi].reads) {  // (compared outputs and whatever else the record reads)
+                auto it = digest_byte.find(w);
+                if (it != digest_byte.end() && it->second.first == a) continue;
+                if (p.producer[w] == records[bi].opcode) continue;
+                ok = ok && level[w] + 1 <= head_level;
+            }
+            if (!ok) continue;
+            next[a] = bi;
+            prev[bi] = a;
+            launch_level[bi] = head_level;
+        }
+        std::vector<uint8_t> drop(records.size(), 0);
+        bool any = false;
+        for (size_t hi : hashes) {
+            if (prev[hi] != NO || next[hi] == NO) continue;  // heads of chains only
+            std::vector<size_t> chain;
+            for (size_t m = hi; m != NO; m = next[m]) chain.push_back(m);
+            uint32_t link_at = 0xFFFFFFFFu;  // offset of the link TO the member being emitted (from the tail backwards)
+            for (size_t c = chain.size(); c-- > 0;) {
+                PendingRecord &m = records[chain[c]];
+                const size_t at = rec_at(m);
+                const uint32_t n_in = p.prog[at + 3];
+                const size_t len = 6 + 2 * (size_t)n_in + 64 + ((p.prog[at + 2] & PLAN_HASH_RANGE_FLAG) ? 2 * (size_t)n_in : 0);
+                uint32_t copy_at = (uint32_t)at;
+                if (c + 1 < chain.size()) {  // a successor follows: copy with the flag and the offset of its link
+                    std::vector<uint32_t> copy(p.prog.begin() + at, p.prog.begin() + at + len);
+                    copy[2] |= PLAN_HASH_CHAIN_FLAG;
+                    copy.push_back(link_at);
+                    copy_at = (uint32_t)p.prog.size();
+                    p.prog.insert(p.prog.end(), copy.begin(), copy.end());
+                }
+                if (c > 0) {  // the link to this member: [its record, source of each input]
+                    const size_t pa = chain[c - 1];
+                    link_at = (uint32_t)p.prog.size();
+                    p.prog.push_back(copy_at);
+                    for (uint32_t k = 0; k < n_in; k++) {
+                        auto it = digest_byte.find(p.prog[at + 6 + 2 * k]);
+                        p.prog.push_back(it != digest_byte.end() && it->second.first == pa ? it->second.second : 0xFFFFFFFFu);
+                    }
+                    drop[chain[c]] = 1;
+                    any = true;
+                    for (uint32_t k = 0; k < 32u; k++) {  // its outputs appear with the head's launch
+                        const uint32_t w = p.prog[at + 6 + 2 * n_in + 2 * k];
+                        if (p.producer[w] == m.opcode) heavy_level[w] = records[hi].level;
+                    }
+                } else m.prog_at = copy_at;
+            }
+            p.n_hash_chained += (uint32_t)chain.size() - 1;
+        }
+        if (any) {
+            // the chained records stay in `records` (their reads and outputs count in the dependency tables below) at the head's level, but not in the level lists
+            for (size_t i = 0; i < records.size(); i++)
+                if (drop[i]) { records[i].level = launch_level[i]; records[i].chained = true; }
+        }
+    }
     // =========================================================================== RANGE opcodes of a level, eight to a record
     // A RANGE check is one row and a few dozen instructions: launched one lane per (opcode, instance) the kernel is bound by the chain of
     // dependent latencies every wave pays before its only load (config 3: 96 checks per instance). Merged records
@@ -1397,6 +1500,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         for (; ri < records.size() && records[ri].level == L; ri++) {
             const PendingRecord &r = records[ri];
+            if (r.chained) continue;
             p.cls_offset[r.cls].push_back(r.prog_at != 0xFFFFFFFFu ? r.prog_at : r.synthetic ? r.opcode : p.prog_offset[r.opcode]);
             p.cls_scratch[r.cls].push_back(r.synthetic ? 0u : p.prog_scratch[r.opcode]);
             width[L]++;

@@ -38,6 +38,7 @@ enum GateKind : uint32_t { GATE_ASSERT = 0, GATE_SOLVE = 1, GATE_SOLVE_DYN = 2 }
 static constexpr uint32_t GATE_HDR_WORDS = 5;
 
 static constexpr uint32_t PLAN_HASH_COOP_FLAG = 0x100u;      // PK_HASH function word: byte message, unpacked through LDS by the level kernel
+static constexpr uint32_t PLAN_HASH_CHAIN_FLAG = 0x400u;     // ... and the offset of a chain link follows (the record that hashes this digest runs in the same block)
 static constexpr uint32_t PLAN_HASH_RANGE_FLAG = 0x200u;     // ... and (RANGE opcode or NONE, bits) per input follow the outputs: byte RANGE checks fused into the hash
 static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 256 message words x 64 instances = 64 KiB of LDS, the most a workgroup may ask for (batch.cpp sizes each launch by its own longest record)
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
@@ -108,6 +109,7 @@ struct Plan {
     uint64_t cls_algorithmic_bytes[N_CLS] = {0, 0, 0, 0, 0, 0, 0};
     double plan_ms = 0;
     std::string unsupported;  // non-empty: circuit holds an opcode no kernel implements
+    uint32_t n_hash_chained = 0;  // byte-message hashes that run behind the hash whose digest they consume (hash chains)
     bool needs_grumpkin = false;
     bool needs_ecdsa = false;  // an ECDSA opcode or Brillig black box: the batch carries the generator tables (kernels_ecdsa.hip)
     std::vector<std::pair<uint32_t, uint32_t>> pedersen_seeds;  // per Pedersen record: (number of inputs, domain separator)

@@ -21,6 +21,7 @@ struct Tuning {
     int64_t digest_epoch = 8;      // levels per batch of folded digest leaves
     int64_t range_fuse = 1;        // byte RANGE checks run inside the hash that reads the byte
     int64_t range_merge = 1;       // RANGE opcodes of a level, eight to a record
+    int64_t hash_chain = 1;        // a byte-message hash of another one's digest runs behind it in the same workgroup
     int64_t brillig_inline = 1;    // straight-line Brillig programs compiled into light records of the level schedule
     int64_t pedersen_waves = 0;    // waves per 64 instances of the level Pedersen kernel: 0 = four, or one when the launch fills the chip anyhow; 1 / 4 force
     int64_t pedersen_prio = 1;     // s_setprio 3 in the level Pedersen kernel: its few long waves win the issue arbitration against the gate kernel's many

@@ -141,6 +141,7 @@ typedef struct {
     uint32_t n_digest_segments; /* records of leaves of the folded digest (ACVM_BATCH_FOLD_DIGEST), 0 if the digest is not folded */
     uint32_t n_brillig_inlined; /* Brillig opcodes whose straight-line program the level schedule runs as a light record (no VM) */
     uint32_t n_brillig_retries; /* passes of the last solve that re-ran Brillig opcodes of the exact path with raised VM limits */
+    uint32_t n_hash_chained;   /* byte-message hashes that run in the workgroup of the hash whose digest they consume (no launch of their own) */
 } acvm_stats_t;
 
 const char *acvm_last_error(void);

@@ -287,6 +287,43 @@ def test_range_checks_fused_into_hash_records(oracle):
     assert any(x.status == 0 for x in ores) and any(x.status == 2 and x.opcode_index == 26 for x in ores)
 
 
+@pytest.mark.parametrize("failing", [False, True])
+def test_hash_chains(oracle, failing):
+    """A byte-message hash of another one's digest runs behind it in the same workgroup (plan.cpp hash chains, kernels_hash.hip): a chain of
+    three with the digest bytes interleaved with other inputs and out of order, a second consumer of the same digest (own launch), a
+    consumer that also reads a gate output of the head's level and one that reads two digests (no chain), RANGE checks on digest bytes,
+    and a chained hash whose output is already assigned (compared)."""
+    import acvm_amd
+    r = rnd(77)
+    n = 48
+    ids = list(range(1, n + 1))
+    o = n + 1
+    d1, d2, d3, d4, d5, d6 = (list(range(o + 32 * k, o + 32 * k + 32)) for k in range(6))
+    g = o + 32 * 6
+    ops = [BB("SHA256", {"inputs": [FI(w, 8) for w in ids[:20]], "outputs": d1}),                                       # 0
+           BB("Keccak256", {"inputs": [FI(w, 8) for w in d1 + ids[20:30]], "outputs": d2}),                             # 1: behind 0
+           BB("RANGE", {"input": FI(d2[3], 8)}), BB("RANGE", {"input": FI(d2[4], 5 if failing else 8)}),                  # 2, 3: on digest bytes (3 fails often)
+           BB("Blake2s", {"inputs": [FI(w, 8) for w in d2[16:] + ids[30:33] + d2[:16][::-1]], "outputs": d3}),          # 4: behind 1
+           BB("SHA256", {"inputs": [FI(w, 8) for w in d1[::-1]], "outputs": d4}),                                       # 5: second consumer of d1
+           E([], [(1, g), (P - 1, ids[40])], 0),                                                                        # 6: g = w41, level 1
+           BB("Blake2s", {"inputs": [FI(w, 8) for w in d3] + [FI(g, 8)], "outputs": d5}),                               # 7: reads g: no chain
+           BB("Keccak256", {"inputs": [FI(w, 8) for w in d4 + d3[:8]], "outputs": d6}),                                 # 8: two digests: no chain
+           BB("SHA256", {"inputs": [FI(w, 8) for w in d6[:8] + ids[42:44]], "outputs": [ids[44] if failing else g + 32] + list(range(g + 1, g + 32))})]  # 9: behind 8, first output compared
+    circ = Circuit(g + 33, ops)
+    rows = [[r.randrange(256) for _ in range(n)] for _ in range(130)]
+    rows[3][2] = P - 1          # a field-sized value where a byte is expected: its low byte goes into the message
+    rows[4][21] = 1 << 40
+    ores, stats = both_paths(oracle, circ, ids, rows)
+    assert stats["n_hash_chained"] == 3, stats["n_hash_chained"]
+    if failing:
+        assert any(x.status == 2 and x.opcode_index == 3 for x in ores) and any(x.status == 2 and x.opcode_index == 9 for x in ores)
+    else:
+        assert all(x.status == 0 for x in ores)
+    with acvm_amd.tuning(hash_chain=0):
+        _, stats0 = run_both(oracle, circ, ids, rows)
+    assert stats0["n_hash_chained"] == 0
+
+
 def test_hash_mixed_widths_and_field_inputs(oracle):
     """fetch_nearest_bytes with num_bits != 8: multi-byte little-endian packing, truncation of wide values."""
     r = rnd(7)

@@ -1471,6 +1471,8 @@ int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_kee
     if (!b->ev_x_ready) HIPCHK(hipEventCreateWithFlags(&b->ev_x_ready, hipEventDisableTiming));
     b->async_exact = true;
     b->async_keep.assign(keep, keep + n_keep);
+    for (uint32_t &w : b->async_keep)
+        if (w >= p.n_witnesses) w = 0xFFFFFFFFu;  // (no row: exports as unassigned)
     b->async_digest = digests;
     return 1;
 }

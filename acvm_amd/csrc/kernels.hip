@@ -58,9 +58,11 @@ __global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__rest
     Fr one = fr_zero();
     one.v[0] = 1;
     // row_of: the table's rows under slot reuse (plan.cpp); a witness nothing produces has no row (0xFFFFFFFF) and exports as zero
-    const uint32_t row = row_of ? row_of[sel[k]] : sel[k];
+    // (a selector 0xFFFFFFFF -- the host's stand-in for a witness index beyond the circuit -- has no row either)
+    const uint32_t w = sel[k];
+    const uint32_t row = w == 0xFFFFFFFFu ? w : row_of ? row_of[w] : w;
     Fr x = row == 0xFFFFFFFFu ? fr_zero() : fr_load(W, row, Bp, first + t);
-    const uint32_t ui = u.index ? u.index[sel[k]] : 0xFFFFFFFFu;
+    const uint32_t ui = u.index && w != 0xFFFFFFFFu ? u.index[w] : 0xFFFFFFFFu;
     // out of Montgomery form; a scaled column leaves it through the canonical integer 1 / scale instead of 1
     x = fr_mul(x, ui != 0xFFFFFFFFu && u.event[first + t] == 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);
     uint8_t *p = out + ((uint64_t)t * n_sel + k) * 32;

@@ -279,6 +279,9 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
     auto node = std::make_unique<acvm_node>();
     node->ids.assign(initial_ids, initial_ids + n_initial);
     node->keep.assign(keep_ids, keep_ids + n_keep);
+    // a kept witness beyond the circuit is simply never assigned (WitnessMap::get -> None): on the device it travels as 0xFFFFFFFF, "no row"
+    for (uint32_t &w : node->keep)
+        if (w >= acvm_circuit_num_witnesses(c)) w = 0xFFFFFFFFu;
     node->flags = opts ? opts->batch_flags : 0;
     std::vector<int> devices;
     const uint32_t n_dev = opts && opts->n_devices ? opts->n_devices : (uint32_t)visible;

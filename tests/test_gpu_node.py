@@ -131,3 +131,31 @@ def test_two_batch_handles_from_two_host_threads(oracle):
         t.join()
     for k in range(2):
         assert got[k][0] == want[k][0] and np.array_equal(got[k][1], want[k][3])
+
+
+def test_node_refuses_what_it_cannot_serve():
+    """acvm_node_new fails loudly -- a null handle and the reason in acvm_last_error -- for a device that is not there, a duplicate initial id and
+    slot reuse on a circuit the level kernels do not cover entirely; nothing is left half-built. A kept witness beyond the circuit is not an
+    error: it is simply never assigned (WitnessMap::get -> None)."""
+    import acvm_amd
+    from acvm_amd import synth
+    from acvm_amd.acir import Brillig, Circuit, Expression as E
+    circ, ids = synth.arithmetic_circuit(200, seed=5)
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    with pytest.raises(acvm_amd.AcvmError):
+        acvm_amd.Node(gc, ids, devices=[acvm_amd.device_count() + 7], tile=64)
+    with pytest.raises(acvm_amd.AcvmError):
+        acvm_amd.Node(gc, ids + [ids[0]], devices=[0], tile=64)
+    for flags in ({}, {"reuse_slots": True}):
+        node = acvm_amd.Node(gc, ids, keep=[1 << 30, ids[0], 0xFFFFFFFE], devices=[0], tile=64, **flags)
+        values = synth.witness_batch(100, seed=5, edge_cases=True)
+        not_solved, res, kept, asg, dig = node.solve(values, 100)
+        assert not asg[:, 0].any() and not asg[:, 2].any() and asg[:, 1].all() and not kept[:, 0].any() and not kept[:, 2].any()
+        assert np.array_equal(kept[:, 1], plain_batch(circ.to_bytes(), ids, values, 100, [ids[0]])[1][:, 0])
+        node.free()
+    fc = Circuit(3, [Brillig(inputs=[E.from_witness(1)], outputs=[2], bytecode=[("ForeignCall", "f", [("Register", 0)], [("Register", 0)]), ("Stop",)])])
+    with pytest.raises(acvm_amd.AcvmError):
+        acvm_amd.Node(acvm_amd.Circuit(fc.to_bytes()), [1], keep=[2], devices=[0], tile=64, reuse_slots=True)
+    node = acvm_amd.Node(gc, ids, devices=[0], tile=64)  # and the library is still usable
+    assert node.solve(synth.witness_batch(10, seed=5, edge_cases=False), 10)[0] == 0
+    node.free()

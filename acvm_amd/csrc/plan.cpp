@@ -682,7 +682,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     // heavy records: the heavy stream is in order, the main stream sees them HEAVY_LATENCY levels later)
     std::vector<uint32_t> hlevel(nw, 0);
     const uint32_t K_heavy = (uint32_t)std::max<int64_t>(tune.heavy_epoch, 1), D_heavy = (uint32_t)std::max<int64_t>(tune.heavy_latency, 0);
-    const uint32_t D_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_latency, 0);
+    const uint32_t D_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_latency, 0), K_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_epoch, 1);
     auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA || cls == CLS_DIGEST; };
     std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, witness of a heavy record it reads)
     uint32_t out_latency = 0;  // levels of slack of the record whose outputs are being assigned
@@ -848,6 +848,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             uint32_t lvl = std::max(rd.lvl, extra_level);
             lvl = out_levels(oi, lvl, rec_heavy) + 1;
             if (rec_heavy) lvl = (lvl + K_heavy - 1) / K_heavy * K_heavy;  // the next heavy batch
+            if (rec_cls == CLS_PEDERSEN && K_pedersen > 1) lvl = (lvl + K_pedersen - 1) / K_pedersen * K_pedersen;
             std::vector<uint32_t> rec_reads = rd.ws;  // compared outputs are reads too
             for (auto &slot : out_slots[oi])
                 if (known[slot.second]) rec_reads.push_back(slot.second);

@@ -17,7 +17,8 @@ struct Tuning {
     int64_t inv_epoch = 4;         // levels per batch of denominator inversions
     int64_t heavy_epoch = 1;       // heavy records launched every K-th level only
     int64_t heavy_latency = 0;     // levels the main stream waits before it reads a heavy output
-    int64_t pedersen_latency = 0;  // the same for Pedersen outputs alone
+    int64_t pedersen_latency = 1;  // the same for Pedersen outputs alone
+    int64_t pedersen_epoch = 2;    // Pedersen records launched every K-th level only (fatter launches: the one-wave kernel needs more than 512 groups)
     int64_t digest_epoch = 8;      // levels per batch of folded digest leaves
     int64_t range_fuse = 1;        // byte RANGE checks run inside the hash that reads the byte
     int64_t range_merge = 1;       // RANGE opcodes of a level, eight to a record

@@ -925,7 +925,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 reads.push_back(unk_partner);
                 const uint32_t K = (uint32_t)std::max<int64_t>(tune.inv_epoch, 1);
                 inv_level = 1 + ((level[unk_partner] + K - 1) / K) * K;  // first batch level after the denominator is known
-                lvl = std::max(lvl, inv_level);
+                lvl = std::max(lvl, inv_level + (uint32_t)std::max<int64_t>(tune.inv_latency, 0));  // (levels of slack before the gate reads the inverse)
             } else kind = GATE_SOLVE;
         }
         // zero-coefficient products / linear terms contribute exactly 0: drop them from the device program.

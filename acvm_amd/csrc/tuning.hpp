@@ -15,6 +15,7 @@ struct Tuning {
     int64_t chains = 1;            // ... and behind a tail of that wave
     int64_t max_tails = 5;         // records behind the host of a wave program
     int64_t inv_epoch = 4;         // levels per batch of denominator inversions
+    int64_t inv_latency = 1;       // levels of slack between an inversion batch and the first gate that reads it
     int64_t heavy_epoch = 1;       // heavy records launched every K-th level only
     int64_t heavy_latency = 0;     // levels the main stream waits before it reads a heavy output
     int64_t pedersen_latency = 1;  // the same for Pedersen outputs alone

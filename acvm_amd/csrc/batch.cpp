@@ -446,7 +446,7 @@ static int batch_init(acvm_batch *b) {
     b->dp.consts = b->d_consts;
     b->dp.bytecode = b->d_bytecode;
     b->dp.Mem = b->d_Mem;
-    b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr};
+    b->dp.grumpkin = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     b->dp.ped_seed = nullptr;
     b->dp.ecdsa_g = nullptr;
     b->dp.fc_store = nullptr;
@@ -484,9 +484,18 @@ static int batch_init(acvm_batch *b) {
     if (p.needs_grumpkin) {
         // the level schedule's Pedersen kernel reads the 503 MB pair table (one mixed addition per 18 bits of input)
         const bool pairs = !p.cls_offset[CLS_PEDERSEN].empty();
-        const GrumpkinTables *t = pairs ? grumpkin_pair_table() : grumpkin_tables();
+        const bool windows = pairs && p.tune.pedersen_window_bits == (int64_t)GRUMPKIN_PEDW_BITS;  // 6.4 GB of 22-bit windows instead of the 503 MB of pairs
+        bool windows_built = false;
+        const GrumpkinTables *t = nullptr;
+        if (windows) {
+            t = grumpkin_window_table();
+            windows_built = t != nullptr;
+            if (!t) (void)hipGetLastError();  // (no room for 6.4 GB beside what the process holds: the pair table serves the same kernel)
+        }
+        if (!t) t = pairs ? grumpkin_pair_table() : grumpkin_tables();
         if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
         b->dp.grumpkin = *t;
+        if (!windows_built) b->dp.grumpkin.pedw = nullptr;  // (another batch of the process may have built it: this one was planned for the pair table)
         if (!p.pedersen_seeds.empty()) {  // the instance-independent head of every Pedersen chain (kernels_grumpkin.hip)
             std::vector<uint32_t> keys;
             for (auto &k : p.pedersen_seeds) { keys.push_back(k.first); keys.push_back(k.second); }

@@ -273,6 +273,7 @@ const GrumpkinTables *grumpkin_tables() {
     t.skew = (const uint4 *)(d + g_host.skew_off * 16);
     t.ped2 = nullptr;
     t.win16 = nullptr;
+    t.pedw = nullptr;
     {   // 16-bit window tables of the fixed bases (s * G of SchnorrVerify and FixedBaseScalarMul, the three generators of the hash
         // ladder): memory for arithmetic, like the pair table -- 16 mixed additions per 256-bit scalar instead of 32. Without the
         // memory the 8-bit windows stay in use.
@@ -304,6 +305,29 @@ const GrumpkinTables *grumpkin_pair_table() {
     launch_pedersen_pair_table(nullptr, t, d);
     if (hipDeviceSynchronize() != hipSuccess) { hipFree(d); return nullptr; }
     t.ped2 = d;
+    return &t;
+}
+
+void launch_pedersen_window_table(hipStream_t s, const GrumpkinTables &T, uint4 *out, uint32_t *n_infinite);  // kernels_grumpkin.hip
+
+const GrumpkinTables *grumpkin_window_table() {
+    const GrumpkinTables *base = grumpkin_tables();
+    if (!base) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    GrumpkinTables &t = g_dev.find(dev)->second;
+    if (t.pedw) return &t;
+    uint4 *d = nullptr;
+    uint32_t *d_bad = nullptr, bad = 1;
+    const size_t entries = (size_t)2 * GRUMPKIN_PEDW_WINDOWS << GRUMPKIN_PEDW_BITS;
+    if (hipMalloc((void **)&d, entries * 64) != hipSuccess) return nullptr;
+    if (hipMalloc((void **)&d_bad, 4) != hipSuccess || hipMemset(d_bad, 0, 4) != hipSuccess) { hipFree(d); hipFree(d_bad); return nullptr; }
+    launch_pedersen_window_table(nullptr, t, d, d_bad);
+    const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;  // (no entry may be the identity)
+    hipFree(d_bad);
+    if (!ok) { hipFree(d); return nullptr; }
+    t.pedw = d;
     return &t;
 }
 

@@ -18,6 +18,7 @@ struct GrumpkinTables {
     const uint4 *skew;   // [3]: D[3j+2]
     const uint4 *ped2;   // [30][512][512] pair table of the level Pedersen kernel (grumpkin_pair_table), else nullptr
     const uint4 *win16;  // [4][16][65535] 16-bit windows of the same four bases: T[w][d-1] = d * 2^(16w) * P (built on the device: 268 MB)
+    const uint4 *pedw;   // [2][12][2^22] window table of the level Pedersen kernel (grumpkin_window_table), else nullptr
 };
 static constexpr uint32_t GRUMPKIN_WIN16_STRIDE = 16 * 65535;  // points per base
 static constexpr uint32_t GRUMPKIN_PED2_LOG2 = 18;  // entries per generator
@@ -29,6 +30,12 @@ const GrumpkinTables *grumpkin_tables();
 // hash_single (the even slice goes through the endomorphism), so that the level kernel pays one mixed addition per 18 bits
 // instead of two. For the last generator of a value (g % 15 == 14, one slice only) the entry is beta((a + 1) D[g]).
 const GrumpkinTables *grumpkin_pair_table();
+// ... and with pedw built (6.4 GB, generated on the device on first use). The slices of hash_single are linear in the bits of the scalar -- a slice
+// a of generator D contributes (a + 1) D = a_hi 2^k D + a_lo D + D -- so the 29 slices (261 bits) of a value can be cut at ANY bit: entry [parity][j][v]
+// is the joint contribution of bits [22 j, 22 j + 22) of the scalar (the pieces of the two to four slices the window touches, the even slices through
+// the endomorphism, plus the `+ 1` of every slice that starts inside the window): 12 mixed additions per hash_single instead of the pair table's 15.
+static constexpr uint32_t GRUMPKIN_PEDW_BITS = 22, GRUMPKIN_PEDW_WINDOWS = 12;
+const GrumpkinTables *grumpkin_window_table();
 bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]);
 
 }  // namespace acvm

@@ -58,8 +58,16 @@ pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, 
     // from step 2 on, wave w takes generators [0, 8) or [8, 15) (w & 1) of the running value or of the next input (w >> 1).
     Fr r = fr_zero(), y = fr_zero();
     // one pair-table entry per 18 bits (even slice through the endomorphism + odd slice): generators [i0, i1) of one operand onto acc
+    // (with the window table the same routine walks windows [i0, i1) of the value's 12: GRUMPKIN_PEDW_BITS bits of the scalar per addition)
+    const bool win = T.pedw != nullptr;
+    const uint32_t n_units = win ? GRUMPKIN_PEDW_WINDOWS : 15u;  // table additions per operand
     auto walk = [&](GJac acc, const Fr &src, uint32_t parity, uint32_t i0, uint32_t i1) {
         const Fr v = fr_to_canonical(src);
+        if (win) {
+            for (uint32_t jw = i0; jw < i1; jw++)
+                acc = gj_add_aff(acc, gaff_load(T.pedw, ((parity * GRUMPKIN_PEDW_WINDOWS + jw) << GRUMPKIN_PEDW_BITS) | bits_at(v, GRUMPKIN_PEDW_BITS * jw, GRUMPKIN_PEDW_BITS)));
+            return acc;
+        }
         const uint32_t gen0 = parity ? 15u : 0u;
         for (uint32_t i = i0; i < i1; i++) {
             const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
@@ -69,16 +77,17 @@ pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, 
     };
     for (uint32_t step = 1; step <= n; step++) {
         if constexpr (WAVES == 1) {
-            GJac s = walk(gj_inf(), active ? p.load(ws[step - 1]) : fr_one(), 1u, 0u, 15u);
+            GJac s = walk(gj_inf(), active ? p.load(ws[step - 1]) : fr_one(), 1u, 0u, n_units);
             if (step == 1) s = gj_add_aff(s, GAff{fr_const(dp.ped_seed, 2 * ws[n]), fr_const(dp.ped_seed, 2 * ws[n] + 1)});
-            else s = walk(s, r, 0u, 0u, 15u);
+            else s = walk(s, r, 0u, 0u, n_units);
             bool inf;
             const GAff a = gj_to_aff(s, &inf);
             r = a.x;
             y = a.y;
         } else {
             const uint32_t parity = step == 1 ? 1u : wave >> 1;
-            const uint32_t i0 = step == 1 ? 4u * wave : (wave & 1u ? 8u : 0u), i1 = step == 1 ? (wave == 3 ? 15u : 4u * wave + 4u) : (wave & 1u ? 15u : 8u);
+            const uint32_t q4 = (n_units + 3u) / 4u, h2 = (n_units + 1u) / 2u;  // 15 generators: 4, 4, 4, 3 and 8, 7; 12 windows: 3 each and 6, 6
+            const uint32_t i0 = step == 1 ? q4 * wave : (wave & 1u ? h2 : 0u), i1 = step == 1 ? (wave == 3 ? n_units : q4 * wave + q4) : (wave & 1u ? n_units : h2);
             Fr src = r;
             if (parity) src = active ? p.load(ws[step - 1]) : fr_one();
             const GJac acc = walk(gj_inf(), src, parity, i0, i1);
@@ -182,6 +191,34 @@ __global__ void __launch_bounds__(64) grumpkin_win16_table_kernel(GrumpkinTables
 void launch_grumpkin_win16_table(hipStream_t s, const GrumpkinTables &T, uint4 *out) {
     const uint64_t n = (uint64_t)GRUMPKIN_N_WINDOW_BASES * GRUMPKIN_WIN16_STRIDE;
     hipLaunchKernelGGL(grumpkin_win16_table_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, T, out);
+}
+// window table of the level Pedersen kernel (grumpkin_host.hpp GrumpkinTables::pedw): one lane per entry [parity][window j][v]
+__global__ void __launch_bounds__(64) pedersen_window_table_kernel(GrumpkinTables T, uint4 *__restrict__ out, uint32_t *__restrict__ n_infinite) {
+    const uint64_t e = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint32_t v = (uint32_t)e & ((1u << GRUMPKIN_PEDW_BITS) - 1u), pj = (uint32_t)(e >> GRUMPKIN_PEDW_BITS), parity = pj / GRUMPKIN_PEDW_WINDOWS, j = pj % GRUMPKIN_PEDW_WINDOWS;
+    const uint32_t w_lo = GRUMPKIN_PEDW_BITS * j, w_hi = w_lo + GRUMPKIN_PEDW_BITS;
+    GJac acc = gj_inf();
+    for (uint32_t s = w_lo / 9u; s < 29u && 9u * s < w_hi; s++) {  // the slices (9 bits each: a_0, b_0, a_1, ..., a_14) the window touches
+        const uint32_t lo = max(9u * s, w_lo), hi = min(9u * s + 9u, w_hi);
+        const uint32_t piece = ((v >> (lo - w_lo)) & ((1u << (hi - lo)) - 1u)) << (lo - 9u * s);  // its bits at their place in the slice
+        const bool starts_here = lo == 9u * s;                                                     // then the slice's `+ 1` rides in this window
+        if (!starts_here && piece == 0u) continue;
+        GAff pt = gaff_load(T.ped, (15u * parity + s / 2u) * GRUMPKIN_PED_ENTRIES + (starts_here ? piece : piece - 1u));  // (k + 1) D at index k
+        if ((s & 1u) == 0u) pt.x = fr_mul(pt.x, grumpkin_beta());  // the even slices go through the endomorphism (x, y) -> (beta x, y)
+        acc = gj_add_aff(acc, pt);
+    }
+    bool inf;
+    const GAff r = gj_to_aff(acc, &inf);
+    if (inf) atomicAdd(n_infinite, 1u);
+    uint4 *p = out + e * 4;
+    p[0] = make_uint4(r.x.v[0], r.x.v[1], r.x.v[2], r.x.v[3]);
+    p[1] = make_uint4(r.x.v[4], r.x.v[5], r.x.v[6], r.x.v[7]);
+    p[2] = make_uint4(r.y.v[0], r.y.v[1], r.y.v[2], r.y.v[3]);
+    p[3] = make_uint4(r.y.v[4], r.y.v[5], r.y.v[6], r.y.v[7]);
+}
+void launch_pedersen_window_table(hipStream_t s, const GrumpkinTables &T, uint4 *out, uint32_t *n_infinite) {
+    const uint64_t n = (uint64_t)2 * GRUMPKIN_PEDW_WINDOWS << GRUMPKIN_PEDW_BITS;
+    hipLaunchKernelGGL(pedersen_window_table_kernel, dim3((unsigned)(n / 64)), dim3(64), 0, s, T, out, n_infinite);
 }
 void launch_pedersen_pair_table(hipStream_t s, const GrumpkinTables &T, uint4 *out) {
     hipLaunchKernelGGL(pedersen_pair_table_kernel, dim3((30u << GRUMPKIN_PED2_LOG2) / 64), dim3(64), 0, s, T, out);

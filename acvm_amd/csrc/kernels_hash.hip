@@ -192,11 +192,7 @@ __device__ __forceinline__ Fr fp_sum_generic(const uint4 *__restrict__ W, uint64
             fp_add(acc, fr29_dot<FP_DOT>(x, k), 17);
             continue;
         }
-        if (n >= 4) {  // (only with FP_DOT = 6, measured no faster than 4 at 132 VGPRs: a tail of four or five)
-            const Fr29 l[4] = {x[0], x[1], x[2], x[3]}, m[4] = {k[0], k[1], k[2], k[3]};
-            fp_add(acc, fr29_dot<4>(l, m), 17);
-            if (n == 5) fp_add(acc, fr29_mul(x[4], k[4]), 17);
-        } else if (n == 3) {
+        if (n == 3) {  // (six to a reduction measured no faster than four, at 132 VGPRs)
             const Fr29 l[3] = {x[0], x[1], x[2]}, m[3] = {k[0], k[1], k[2]};
             fp_add(acc, fr29_dot<3>(l, m), 17);
         } else if (n == 2) {

@@ -18,10 +18,10 @@ void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
     launch_record_level<EcdsaOp, 64>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
 }
 
-// one thread per (curve, window j, digit d): 2 x 32 x 256 entries of 16 words, digit 0 left zero
+// one thread per (curve, window j, digit d): 2 x SECP_GWINDOWS x 2^SECP_GWIN entries of 16 words, digit 0 left zero
 __global__ void ecdsa_gtable_kernel(uint32_t *out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t curve = t >> 13, j = (t >> 8) & 31u, d = t & 255u;
+    const uint32_t per_curve = SECP_GWINDOWS << SECP_GWIN, curve = t / per_curve, j = (t % per_curve) >> SECP_GWIN, d = t & ((1u << SECP_GWIN) - 1u);
     if (curve > 1u) return;
     SAff e{fr_zero(), fr_zero()};
     if (d) e = curve == 0u ? secp_gtable_entry<0>(j, d) : secp_gtable_entry<1>(j, d);
@@ -66,7 +66,7 @@ const uint32_t *ecdsa_generator_tables() {
     if (it != per_device.end()) return it->second;
     uint32_t *d = nullptr;
     if (hipMalloc((void **)&d, (size_t)2 * SECP_GTABLE_WORDS * 4) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(ecdsa_gtable_kernel, dim3(2 * 32 * 256 / 64), dim3(64), 0, nullptr, d);
+    hipLaunchKernelGGL(ecdsa_gtable_kernel, dim3(2u * (SECP_GWINDOWS << SECP_GWIN) / 64u), dim3(64), 0, nullptr, d);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(d); return nullptr; }
     per_device.emplace(dev, d);
     return d;

@@ -10,8 +10,8 @@
 //   * inversions: safegcd (fr_device.hpp fr_safegcd_inv) with the modulus as a template parameter.
 //   * square root for the decompression of the public key (both p = 3 mod 4): addition chains for (p + 1) / 4 (253 squarings + 13 / 7 products).
 //   * u1 G + u2 Q: u2 Q on signed 4-bit windows over a per-lane table {Q .. 8Q} normalised to affine with ONE inversion (256 doublings +
-//     65 mixed additions, every lane adds at the same steps); u1 G as 32 mixed additions from a precomputed table d * 2^(8j) * G
-//     (32 x 255 affine points per curve, 512 KiB, built once per device by secp_gtable_entry) onto the same accumulator.
+//     65 mixed additions, every lane adds at the same steps); u1 G as 16 mixed additions from a precomputed table d * 2^(16 j) * G
+//     (16 x 65 535 affine points per curve, 64 MiB, built once per device by secp_gtable_entry) onto the same accumulator.
 #pragma once
 #include "fr_device.hpp"
 
@@ -473,16 +473,22 @@ FR_HD __forceinline__ SAff secp_generator() {
     return SAff{secp_limbs([](int i) { return Secp<C>::gx(i); }), secp_limbs([](int i) { return Secp<C>::gy(i); })};
 }
 
-// ---- the table of the generator: entry (j, d) = d * 2^(8 j) * G, j < 32, 1 <= d < 256, 16 words (x, y) at ((j * 256 + d) * 16)
-constexpr uint32_t SECP_GTABLE_WORDS = 32u * 256u * 16u;  // per curve
+// ---- the table of the generator: entry (j, d) = d * 2^(W j) * G, j < 256 / W, 1 <= d < 2^W, 16 words (x, y) at (((j << W) + d) * 16).
+// W = SECP_GWIN_BITS: 16 on the device (16 additions for u1 G, 64 MiB per curve); the host-run test builds its table with -DSECP_GWIN_BITS=8.
+#ifndef SECP_GWIN_BITS
+#define SECP_GWIN_BITS 16
+#endif
+constexpr uint32_t SECP_GWIN = SECP_GWIN_BITS, SECP_GWINDOWS = 256u / SECP_GWIN;
+static_assert(SECP_GWIN == 8u || SECP_GWIN == 16u, "window of the generator table");
+constexpr uint32_t SECP_GTABLE_WORDS = (SECP_GWINDOWS << SECP_GWIN) * 16u;  // per curve
 template <int C>
 FR_HD inline SAff secp_gtable_entry(uint32_t j, uint32_t d) {
     const SAff G = secp_generator<C>();
     SJac base{G.x, G.y, secp_one()};
-    for (uint32_t i = 0; i < 8u * j; i++) base = sj_dbl<C>(base);
+    for (uint32_t i = 0; i < SECP_GWIN * j; i++) base = sj_dbl<C>(base);
     const SAff B = sj_to_affine<C>(base);
     SJac acc = sj_identity();
-    for (int i = 7; i >= 0; i--) {
+    for (int i = (int)SECP_GWIN - 1; i >= 0; i--) {
         acc = sj_dbl<C>(acc);
         if ((d >> i) & 1u) acc = sj_add_aff<C>(acc, B);
     }
@@ -525,10 +531,10 @@ FR_HD __forceinline__ uint32_t secp_limb_at(const Fr &a, uint32_t k) {  // a.v[k
 template <int C>
 FR_HD __forceinline__ SJac secp_add_generator_multiple(SJac acc, const Fr &u1, const uint32_t *__restrict__ gtab) {
 #pragma unroll 1
-    for (uint32_t j = 0; j < 32u; j++) {
-        const uint32_t d = (secp_limb_at(u1, j >> 2) >> (8u * (j & 3u))) & 255u;
+    for (uint32_t j = 0; j < SECP_GWINDOWS; j++) {
+        const uint32_t d = (secp_limb_at(u1, (SECP_GWIN * j) >> 5) >> ((SECP_GWIN * j) & 31u)) & ((1u << SECP_GWIN) - 1u);
         if (d != 0u) {
-            const uint32_t *g = gtab + (size_t)(j * 256u + d) * 16u;
+            const uint32_t *g = gtab + (size_t)((j << SECP_GWIN) + d) * 16u;
             SAff q;
 #pragma unroll
             for (int k = 0; k < 8; k++) { q.x.v[k] = g[k]; q.y.v[k] = g[8 + k]; }

@@ -197,9 +197,9 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
 
 # Base-field products (multiplications + squarings of secp_device.hpp) of ONE verification, counted from the routine:
 # decompression 2 + the square-root chain (253 S + 13 / 7 M) + 1; the window table {Q .. 8Q} 119 (+ 8 for the beta x of secp256k1); the ladder
-# 128 / 256 doublings x 7 / 8 and on average 61 / 60.5 mixed additions x 11; 31.9 additions of generator-table points x 11; the final x 2.
+# 128 / 256 doublings x 7 / 8 and on average 61 / 60.5 mixed additions x 11; 16 additions of generator-table points (16-bit windows) x 11; the final x 2.
 # Not counted: three safegcd inversions and ~12 products of the scalar field per verification (about 8 % of the instructions).
-ECDSA_PRODUCTS = {0: 2 + 266 + 1 + 119 + 8 + 128 * 7 + 61 * 11 + 351 + 2, 1: 2 + 260 + 1 + 120 + 256 * 8 + 665.5 + 351 + 2}
+ECDSA_PRODUCTS = {0: 2 + 266 + 1 + 119 + 8 + 128 * 7 + 61 * 11 + 176 + 2, 1: 2 + 260 + 1 + 120 + 256 * 8 + 665.5 + 176 + 2}
 
 
 def ecdsa_alu_roofline(tile, kernel_ms):

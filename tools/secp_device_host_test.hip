@@ -4,7 +4,8 @@
 //   <c> dbl X Y Z | addaff X Y Z x y                                                  -> X Y Z (Jacobian, hex)
 //   0 split k                                                                         -> |k1| neg1 |k2| neg2 (secp256k1's endomorphism split)
 //   <c> gtab j d                                                                      -> x y
-//   <c> verify r s x y_odd n_msg z                                                    -> result panic      (table of the generator built on first use)
+//   <c> verify r s x y_odd n_msg z                                                    -> result panic      (table of the generator built on first use;
+//                                                                                        build with -DSECP_GWIN_BITS=8: the device's 16-bit table takes minutes on the host)
 #include "../acvm_amd/csrc/secp_device.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -31,10 +32,10 @@ static const uint32_t *gtable() {
     static std::vector<uint32_t> t;
     if (t.empty()) {
         t.assign(SECP_GTABLE_WORDS, 0u);
-        for (uint32_t j = 0; j < 32; j++)
-            for (uint32_t d = 1; d < 256; d++) {
+        for (uint32_t j = 0; j < SECP_GWINDOWS; j++)
+            for (uint32_t d = 1; d < (1u << SECP_GWIN); d++) {
                 const SAff e = secp_gtable_entry<C>(j, d);
-                for (int k = 0; k < 8; k++) { t[(j * 256 + d) * 16 + k] = e.x.v[k]; t[(j * 256 + d) * 16 + 8 + k] = e.y.v[k]; }
+                for (int k = 0; k < 8; k++) { t[((j << SECP_GWIN) + d) * 16 + k] = e.x.v[k]; t[((j << SECP_GWIN) + d) * 16 + 8 + k] = e.y.v[k]; }
             }
     }
     return t.data();

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_debug_secp_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
-    "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
+    "acvm_device_release_tables", "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
 ]
 
 
@@ -261,6 +261,8 @@ def lib():
     L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_debug_modmul_rate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.acvm_debug_secp_rate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.acvm_device_release_tables.restype = C.c_longlong
+    L.acvm_device_release_tables.argtypes = [C.c_int]
     L.acvm_node_new.restype = C.c_void_p
     L.acvm_node_new.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.acvm_node_free.restype = None
@@ -384,6 +386,14 @@ class tuning:
         for k, v in self.old.items():
             tuning_set(k, v)
         return False
+
+
+def release_tables(device=0):
+    """acvm_device_release_tables: frees the lookup tables of `device` (bytes given back); AcvmError while a handle of the device still uses them"""
+    r = lib().acvm_device_release_tables(device)
+    if r < 0:
+        raise AcvmError(lib().acvm_last_error().decode())
+    return r
 
 
 def stream_rate(nbytes=4 << 30):

@@ -92,6 +92,15 @@ int acvm_device_upload(void *dst_device, const void *src_host, size_t bytes) {
     return 0;
 }
 
+long long acvm_device_release_tables(int device) {
+    if (device < 0 || device >= acvm_device_count()) return set_err(ACVM_E_INVALID, "device index out of range");
+    size_t freed = 0;
+    const int rc = device_tables_free(device, &freed);
+    if (rc == 1) return set_err(ACVM_E_STATE, "batch handles of device " + std::to_string(device) + " still use its lookup tables: free them first");
+    if (rc < 0) return set_err(ACVM_E_DEVICE, "could not select device " + std::to_string(device));
+    return (long long)freed;
+}
+
 int acvm_tuning_set(const char *key, long long value) {
     if (!tuning_set(key, (int64_t)value)) return set_err(ACVM_E_INVALID, std::string("unknown tuning key ") + (key ? key : "(null)"));
     return 0;
@@ -197,8 +206,16 @@ int acvm_debug_stream_rate(size_t bytes, double *gb_per_s) {
 int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64) try {
     if (!out_be64) return set_err(ACVM_E_INVALID, "null argument");
     if (what == 0) return grumpkin_host_point(param >> 24, param & 0xffffffu, out_be64) ? 0 : set_err(ACVM_E_INVALID, "bad table index");
-    const GrumpkinTables *t = grumpkin_tables();
-    if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+    GrumpkinTables tabs;
+    if (!grumpkin_tables(&tabs)) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+    const GrumpkinTables *t = &tabs;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    struct Hold {  // the probe holds the device's tables while it runs (acvm_device_release_tables refuses meanwhile)
+        int d;
+        explicit Hold(int dev_) : d(dev_) { device_tables_retain(d); }
+        ~Hold() { device_tables_unref(d); }
+    } hold(dev);
     std::vector<uint32_t> in(8 * (n_in ? n_in : 1), 0), out(16, 0);
     for (uint32_t i = 0; i < n_in; i++)
         for (int k = 0; k < 32; k++) in[8 * i + k / 4] |= (uint32_t)in_be32[32 * i + 31 - k] << (8 * (k % 4));
@@ -477,6 +494,10 @@ static int batch_init(acvm_batch *b) {
         if (int rc = upload(&b->d_fc_store, tab)) return rc;
         b->dp.fc_store = b->d_fc_store;
     }
+    if (p.needs_ecdsa || p.needs_grumpkin) {  // the handle holds the device's table set until it is destroyed
+        device_tables_retain(b->device);
+        b->holds_tables = true;
+    }
     if (p.needs_ecdsa) {
         b->dp.ecdsa_g = ecdsa_generator_tables();
         if (!b->dp.ecdsa_g) return set_err(ACVM_E_DEVICE, "could not build the ECDSA generator tables on the device");
@@ -485,15 +506,15 @@ static int batch_init(acvm_batch *b) {
         // the level schedule's Pedersen kernel reads the 503 MB pair table (one mixed addition per 18 bits of input)
         const bool pairs = !p.cls_offset[CLS_PEDERSEN].empty();
         const bool windows = pairs && p.tune.pedersen_window_bits == (int64_t)GRUMPKIN_PEDW_BITS;  // 6.4 GB of 22-bit windows instead of the 503 MB of pairs
-        bool windows_built = false;
-        const GrumpkinTables *t = nullptr;
+        bool windows_built = false, have = false;
+        GrumpkinTables tabs;
+        const GrumpkinTables *t = &tabs;
         if (windows) {
-            t = grumpkin_window_table();
-            windows_built = t != nullptr;
-            if (!t) (void)hipGetLastError();  // (no room for 6.4 GB beside what the process holds: the pair table serves the same kernel)
+            have = windows_built = grumpkin_window_table(&tabs);
+            if (!have) (void)hipGetLastError();  // (no room for 6.4 GB beside what the process holds: the pair table serves the same kernel)
         }
-        if (!t) t = pairs ? grumpkin_pair_table() : grumpkin_tables();
-        if (!t) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+        if (!have) have = pairs ? grumpkin_pair_table(&tabs) : grumpkin_tables(&tabs);
+        if (!have) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
         b->dp.grumpkin = *t;
         if (!windows_built) b->dp.grumpkin.pedw = nullptr;  // (another batch of the process may have built it: this one was planned for the pair table)
         if (!p.pedersen_seeds.empty()) {  // the instance-independent head of every Pedersen chain (kernels_grumpkin.hip)
@@ -560,17 +581,22 @@ acvm_batch_t *acvm_batch_new_ex(const acvm_circuit_t *c, const acvm_bb_solver_t 
 } ABI_CATCH_PTR
 void acvm_batch_free(acvm_batch_t *b) { delete b; }
 
-int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32) try {
-    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+int batch_import_async(acvm_batch *b, const void *d_values_be32, hipEvent_t imported) {
     HIPCHK(hipSetDevice(b->device));
     launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->reuse() ? b->d_init_rows : b->d_init_ids,
                   (uint32_t)b->plan.initial_ids.size());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(b->stream));
+    if (imported) HIPCHK(hipEventRecord(imported, b->stream));
     b->inputs_set = true;
     b->solved = false;
     b->stepping = false;
     clear_fc_store(b);
+    return 0;
+}
+int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_be32) try {
+    if (!b) return set_err(ACVM_E_INVALID, "null batch");
+    if (int rc = batch_import_async(b, d_values_be32, nullptr)) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));  // the caller may reuse its buffer as soon as the call returns
     return 0;
 } ABI_CATCH
 
@@ -1300,6 +1326,42 @@ static int ensure_level_events(acvm_batch *b) {
     }
     return 0;
 }
+// The side table of the exact path (slot reuse, and the asynchronous jobs of the node driver): all witnesses x `n_lanes` flagged instances,
+// padded to 64 lanes, the memory blocks beside it and -- for a job that runs beside the next tile's level kernels, which use the class
+// buffers meanwhile -- per-class scratch of its own. Grow-only. 0 = ready, negative = an error (ACVM_E_DEVICE: no room).
+static int ensure_side_table(acvm_batch *b, uint32_t n_lanes, bool own_scratch) {
+    const Plan &p = b->plan;
+    const uint64_t lanes = ((uint64_t)std::max<uint32_t>(n_lanes, 1) + 63) / 64 * 64;
+    if (lanes > b->x_cap) {
+        // a table of all witnesses per flagged instance: refuse when that is more than the level table itself
+        const size_t need = (size_t)p.n_witnesses * 2 * lanes * sizeof(uint4), level_table = (size_t)(b->reuse() ? p.n_slots : p.n_witnesses) * 2 * b->Bp * sizeof(uint4);
+        if (need > level_table && need > (8ull << 30))  // (a small batch pads to 64 lanes either way: below 8 GiB the table is simply allocated)
+            return set_err(ACVM_E_UNSUPPORTED, "slot reuse: " + std::to_string(n_lanes) + " instances left the generic path; their own table would exceed "
+                                               "the level table -- solve this tile without ACVM_BATCH_REUSE_SLOTS");
+        for (void *q : {(void *)b->d_Wx, (void *)b->d_Memx, (void *)b->d_ids_x})
+            if (q) hipFree(q);
+        b->d_Wx = b->d_Memx = nullptr;
+        b->d_ids_x = nullptr;
+        b->x_cap = 0;
+        HIPCHK(hipMalloc((void **)&b->d_Wx, std::max<size_t>(need, 16)));
+        HIPCHK(hipMalloc((void **)&b->d_Memx, std::max<size_t>(16, (size_t)p.mem_cells * 2 * lanes * sizeof(uint4))));
+        std::vector<uint32_t> ident(lanes);
+        for (uint32_t t = 0; t < lanes; t++) ident[t] = t;
+        if (int rc = upload(&b->d_ids_x, ident)) return rc;
+        b->x_cap = lanes;
+    }
+    if (own_scratch && b->x_cap > b->x_scratch_lanes) {
+        b->x_scratch_lanes = 0;
+        for (int k = 0; k < (int)N_CLS; k++) {
+            if (b->d_x_scratch[k]) hipFree(b->d_x_scratch[k]);
+            b->d_x_scratch[k] = nullptr;
+            if (b->cls_exact_words[k]) HIPCHK(hipMalloc((void **)&b->d_x_scratch[k], (size_t)b->cls_exact_words[k] * b->x_cap * 4));
+        }
+        b->x_scratch_lanes = b->x_cap;
+    }
+    return 0;
+}
+
 int acvm_batch_solve(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
@@ -1376,7 +1438,7 @@ int acvm_batch_solve(acvm_batch_t *b) try {
     hipEvent_t slow0 = nullptr, slow1 = nullptr;
     // asynchronous exact path (node.cpp): a bounded number of flagged instances is re-solved in the side table on stream_x while the
     // caller goes on to the next tile; a batch full of them (a failing circuit, a truncated plan) keeps the synchronous path
-    const bool go_async = b->async_exact && n_slow && !b->force_slow && (uint64_t)n_slow * 8 <= std::max<uint64_t>(b->B, 512);
+    bool go_async = b->async_exact && n_slow && !b->force_slow && (uint64_t)n_slow * 8 <= std::max<uint64_t>(b->B, 512);
     b->side_job = go_async;
     if (n_slow) {
         if (int rc = ensure_slow_capacity(b, n_slow)) return rc;
@@ -1393,32 +1455,17 @@ int acvm_batch_solve(acvm_batch_t *b) try {
         slow1 = next_event();
         hipEventRecord(slow0, s);
         if (b->side()) {
-            const uint64_t lanes = ((uint64_t)n_slow + 63) / 64 * 64;
-            if (lanes > b->x_cap) {
-                // a table of all witnesses per flagged instance: refuse when that is more than the level table itself
-                const size_t need = (size_t)p.n_witnesses * 2 * lanes * sizeof(uint4), level_table = (size_t)(b->reuse() ? p.n_slots : p.n_witnesses) * 2 * b->Bp * sizeof(uint4);
-                if (need > level_table && need > (8ull << 30))  // (a small batch pads to 64 lanes either way: below 8 GiB the table is simply allocated)
-                    return set_err(ACVM_E_UNSUPPORTED, "slot reuse: " + std::to_string(n_slow) + " instances left the generic path; their own table would exceed "
-                                                       "the level table -- solve this tile without ACVM_BATCH_REUSE_SLOTS");
-                for (void *q : {(void *)b->d_Wx, (void *)b->d_Memx, (void *)b->d_ids_x})
-                    if (q) hipFree(q);
-                b->d_Wx = b->d_Memx = nullptr;
-                b->d_ids_x = nullptr;
-                b->x_cap = lanes;
-                HIPCHK(hipMalloc((void **)&b->d_Wx, need));
-                HIPCHK(hipMalloc((void **)&b->d_Memx, std::max<size_t>(16, (size_t)p.mem_cells * 2 * lanes * sizeof(uint4))));
-                std::vector<uint32_t> ident(lanes);
-                for (uint32_t t = 0; t < lanes; t++) ident[t] = t;
-                if (int rc = upload(&b->d_ids_x, ident)) return rc;
+            const int grown = ensure_side_table(b, n_slow, go_async);
+            if (grown < 0) {
+                // no room for the side table of this many lanes. A handle that does not recycle rows still has every column in the level table:
+                // the job runs there, in place, before the caller's next import (the synchronous path); slot reuse has no such fallback
+                if (b->reuse()) return grown;
+                (void)hipGetLastError();
+                go_async = false;
+                b->side_job = false;
             }
-            if (go_async && b->x_cap > b->x_scratch_lanes) {  // the job's own scratch: the level kernels of the next tile use the class buffers meanwhile
-                for (int k = 0; k < (int)N_CLS; k++) {
-                    if (b->d_x_scratch[k]) hipFree(b->d_x_scratch[k]);
-                    b->d_x_scratch[k] = nullptr;
-                    if (b->cls_exact_words[k]) HIPCHK(hipMalloc((void **)&b->d_x_scratch[k], (size_t)b->cls_exact_words[k] * b->x_cap * 4));
-                }
-                b->x_scratch_lanes = b->x_cap;
-            }
+        }
+        if (b->side()) {
             // (on the batch's stream: the level table is read before the next tile's import overwrites it)
             if (b->reuse()) launch_gather_initial(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, b->d_init_ids, b->d_init_rows, (uint32_t)p.initial_ids.size(), b->d_slow_ids, n_slow);
             else {  // the whole column of every flagged instance, plain values: the job resumes at the instance's event like the in-place path
@@ -1473,6 +1520,12 @@ int acvm_batch_solve(acvm_batch_t *b) try {
 } ABI_CATCH
 
 // ---- asynchronous exact path (batch.hpp)
+// exact lanes whose side table a handle allocates up front: what a tile of a few diverging inputs needs, bounded by 1 GiB
+static uint32_t async_exact_first_lanes(const Plan &p, uint32_t capacity) {
+    const uint64_t by_bytes = (1ull << 30) / std::max<uint64_t>(64, (uint64_t)(p.n_witnesses + p.mem_cells) * 32);
+    const uint64_t lanes = std::min<uint64_t>(std::min<uint64_t>(1024, std::max<uint64_t>(capacity / 8, 64)), std::max<uint64_t>(by_bytes, 64));
+    return (uint32_t)(lanes / 64 * 64);
+}
 int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_keep, bool digests) {
     const Plan &p = b->plan;
     if (b->has_solver || p.has_foreign_calls || p.truncated_at != 0xFFFFFFFFu || !p.tune.exact_async) return 0;
@@ -1483,7 +1536,54 @@ int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_kee
     for (uint32_t &w : b->async_keep)
         if (w >= p.n_witnesses) w = 0xFFFFFFFFu;  // (no row: exports as unassigned)
     b->async_digest = digests;
+    // the side table of the first lanes now: a device without room for it says so at creation, not in the middle of a run (a job with more
+    // lanes grows it, and falls back to the in-place path when it cannot)
+    if (int rc = ensure_side_table(b, async_exact_first_lanes(p, b->capacity), true)) return rc;
     return 1;
+}
+size_t batch_device_bytes(const Plan &p, const PlanOpts &opts, uint64_t instances, bool async_exact) {
+    const uint64_t Bp = (std::max<uint64_t>(instances, 1) + 63) / 64 * 64;
+    const uint64_t rows = (opts.reuse_slots ? p.n_slots : p.n_witnesses) + (uint64_t)p.mem_cells + p.n_inverse_slots + p.n_digest_segments;
+    size_t bytes = (size_t)rows * 2 * Bp * sizeof(uint4) + (size_t)Bp * 8;
+    const uint64_t scratch_cap_words = std::max<uint64_t>(1, (1ull << 30) / (Bp * 4));
+    for (int k = 0; k < (int)N_CLS; k++) {  // class scratch: the fattest level of the class (batch_init chunks a level at scratch_cap_words), or its fattest record
+        uint64_t need = 0;
+        for (size_t L = 0; L + 1 < p.cls_level_start[k].size(); L++) {
+            uint64_t used = 0;
+            for (uint32_t r = p.cls_level_start[k][L]; r < p.cls_level_start[k][L + 1]; r++) used += p.cls_scratch[k][r];
+            need = std::max(need, std::min(used, std::max<uint64_t>(scratch_cap_words, 1)));
+        }
+        for (uint32_t oi = 0; oi < p.n_opcodes; oi++)
+            if (p.prog_class[oi] == (uint32_t)k) need = std::max<uint64_t>(need, p.prog_scratch[oi]);
+        bytes += (size_t)need * Bp * 4;
+    }
+    if (async_exact) bytes += (size_t)async_exact_first_lanes(p, (uint32_t)std::min<uint64_t>(instances, 0xFFFFFFFFu)) * (p.n_witnesses + (uint64_t)p.mem_cells) * 32;
+    return bytes;
+}
+
+void batch_take_outcome(acvm_batch *b, ExactOutcome *out) {
+    *out = std::move(b->last_outcome);
+    b->last_outcome.clear();
+}
+const std::vector<uint32_t> *batch_exact_instances(const acvm_batch *b) { return &b->slow_ids; }
+bool batch_exact_pending(const acvm_batch *b) { return b->pending; }
+uint32_t batch_exact_unsolved(const acvm_batch *b, uint32_t n) {
+    if (b->pending) return 0;  // (their outcome is not known yet)
+    uint32_t bad = 0;
+    for (size_t t = 0; t < b->slow_ids.size() && t < b->slow_res.size(); t++) bad += b->slow_ids[t] < n && b->slow_res[t].status != ACVM_STATUS_SOLVED;
+    return bad;
+}
+bool batch_generic_assigned(const acvm_batch *b, uint32_t w) { return w < b->plan.n_witnesses && b->plan.producer[w] != 0xFFFFFFFFu; }
+int batch_enqueue_kept(acvm_batch *b, uint32_t n, const uint32_t *d_keep, uint32_t n_keep, uint8_t *d_out, uint8_t *h_out, hipStream_t copy_stream,
+                       hipEvent_t exported, hipEvent_t arrived) {
+    HIPCHK(hipSetDevice(b->device));
+    launch_export(b->stream, b->d_W, b->Bp, 0, n, d_keep, n_keep, d_out, b->unscale, b->d_slot_of);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(exported, b->stream));
+    HIPCHK(hipStreamWaitEvent(copy_stream, exported, 0));
+    HIPCHK(hipMemcpyAsync(h_out, d_out, (size_t)n * n_keep * 32, hipMemcpyDeviceToHost, copy_stream));
+    HIPCHK(hipEventRecord(arrived, copy_stream));
+    return 0;
 }
 
 // digests of lanes [first, first + n) of a witness table into host memory out32 ([n][32]), staged through the arena on stream s:
@@ -1765,18 +1865,23 @@ static int reuse_patch_exact(acvm_batch *b, const uint32_t *d_sel, uint32_t n_se
 
 // one witness of one instance as 32 canonical big-endian bytes (message texts only; rare)
 static bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
-    if (stage_reserve(b, 512) != 0) return false;
-    uint32_t *d_sel = (uint32_t *)b->d_stage;
-    uint8_t *d_out = b->d_stage + 256;
-    if (hipMemcpyAsync(d_sel, &w, 4, hipMemcpyHostToDevice, b->stream) != hipSuccess) return false;
-    if (hipStreamSynchronize(b->stream) != hipSuccess) return false;  // &w is a stack address
-    if (b->side() && b->slow_index[j] >= 0) {
+    // While an exact job is pending its lanes live in the side table and the caller's NEXT tile may already be enqueued on the handle's
+    // stream: the fetch goes through the job's stream (and a staging slot of its own), so that a failing instance's message does not wait
+    // for a whole level schedule.
+    const bool side_lane = b->side() && b->slow_index[j] >= 0;
+    hipStream_t s = b->pending && side_lane ? b->stream_x : b->stream;
+    if (!b->d_fetch && hipMalloc((void **)&b->d_fetch, 512) != hipSuccess) return false;
+    uint32_t *d_sel = (uint32_t *)b->d_fetch;
+    uint8_t *d_out = b->d_fetch + 256;
+    if (hipMemcpyAsync(d_sel, &w, 4, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+    if (hipStreamSynchronize(s) != hipSuccess) return false;  // &w is a stack address
+    if (side_lane) {
         Unscale plain = b->unscale;
         plain.event = b->d_slow_start;
-        launch_export(b->stream, b->d_Wx, b->x_cap, (uint32_t)b->slow_index[j], 1, d_sel, 1, d_out, plain);
+        launch_export(s, b->d_Wx, b->x_cap, (uint32_t)b->slow_index[j], 1, d_sel, 1, d_out, plain);
     } else
-    launch_export(b->stream, b->d_W, b->Bp, j, 1, d_sel, 1, d_out, b->unscale, b->d_slot_of);
-    return hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, b->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
+    launch_export(s, b->d_W, b->Bp, j, 1, d_sel, 1, d_out, b->unscale, b->d_slot_of);
+    return hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
 }
 
 // message text of a failure, rebuilt from the device's DevMsg code (ops_common.hpp) + payload

@@ -121,6 +121,7 @@ struct acvm_batch {
     uint32_t *d_ped_seed = nullptr;  // seed table of the level Pedersen kernel (one row per Pedersen record)
     uint4 *d_inv = nullptr;  // inverse table: [plan.n_inverse_slots][2 halves][Bp] x 16 B
     uint32_t n_launches = 0;
+    bool holds_tables = false;  // a reference on the device's lookup-table set (grumpkin_host.hpp device_tables_retain)
     // caller-supplied BlackBoxFunctionSolver
     bool has_solver = false;
     acvm_bb_solver_t solver{};
@@ -148,6 +149,7 @@ struct acvm_batch {
     // grow-only device staging arena of the entry points that move data in or out (no hipMalloc / hipFree per call)
     uint8_t *d_stage = nullptr;
     size_t stage_cap = 0;
+    uint8_t *d_fetch = nullptr;  // 512 bytes for single-value fetches (message texts): usable while d_stage serves another stream
     // acvm_batch_solve_opcode: every instance is an exact lane, slow_start[t] is its instruction pointer
     bool stepping = false;
     // Brillig retry passes of the exact path (retry_device_limits): the compact VM scratch of the lanes being retried and their columns
@@ -187,6 +189,7 @@ struct acvm_batch {
             if (p) hipFree(p);
         if (d_ped_seed) hipFree(d_ped_seed);
         if (d_stage) hipFree(d_stage);
+        if (d_fetch) hipFree(d_fetch);
         if (stream_x) { hipStreamSynchronize(stream_x); hipStreamDestroy(stream_x); }
         if (ev_x_ready) hipEventDestroy(ev_x_ready);
         for (int k = 0; k < (int)N_CLS; k++)
@@ -202,23 +205,44 @@ struct acvm_batch {
         if (ev_start) hipEventDestroy(ev_start);
         if (ev_end) hipEventDestroy(ev_end);
         if (stream) hipStreamDestroy(stream);
+        if (holds_tables) device_tables_unref(device);
     }
 };
 
-// ---- internal entry points of batch.cpp for the node-level driver (node.cpp); C linkage only because batch.cpp defines them inside its
-// extern "C" block (they are not part of the ABI and not exported through the header)
+// ---- internal interface of the batch handle for the node-level driver (node.cpp): what the driver needs beyond the public ABI, as calls --
+// node.cpp does not reach into the struct. C linkage only because batch.cpp defines them inside its extern "C" block (they are not part
+// of the ABI and not declared in the public header).
 extern "C" {
 // Turns the handle's exact path asynchronous where the circuit allows it (no caller-supplied solver, no foreign calls, a plan the level
-// kernels cover entirely); `keep` and `digests` say what an outcome carries. Returns 1 if enabled, 0 if the handle stays synchronous.
+// kernels cover entirely); `keep` and `digests` say what an outcome carries. The side table of the first lanes is allocated here, so that
+// a device without room for it says so at creation. Returns 1 if enabled, 0 if the handle stays synchronous.
 int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_keep, bool digests);
 // The next import and solve cover instances [0, n) only, 1 <= n <= the instances the handle was created for (the last, partial tile of a
 // shard: lanes beyond n are dead instead of solving copies of some instance). A pending exact job of the previous solve is unaffected.
 int batch_set_live_count(acvm_batch *b, uint32_t n);
+// acvm_batch_set_initial_witness_device without the wait: the import is enqueued on the handle's stream and `imported` recorded behind it;
+// the caller keeps d_values_be32 untouched until that event has fired.
+int batch_import_async(acvm_batch *b, const void *d_values_be32, hipEvent_t imported);
 // waits for the exact job in flight (if any) and moves its outcome into *out (cleared first)
 int batch_finish_pending(acvm_batch *b, ExactOutcome *out);
+// the outcome of the previous solve's exact job, which the last acvm_batch_solve collected on its way (moved into *out; empty if none)
+void batch_take_outcome(acvm_batch *b, ExactOutcome *out);
+// the instances of the last solve that left the generic path; pending: their exact job still runs (the outcome arrives one solve later)
+const std::vector<uint32_t> *batch_exact_instances(const acvm_batch *b);
+bool batch_exact_pending(const acvm_batch *b);
+// of the first n instances: those whose (synchronous, final) exact lane did not reach Solved
+uint32_t batch_exact_unsolved(const acvm_batch *b, uint32_t n);
+// witness w is assigned in the generic instance (the planner's assigned set = what every instance of the level kernels has)
+bool batch_generic_assigned(const acvm_batch *b, uint32_t w);
 // results / kept witnesses / digests of instances [0, n) of the last solve for the instances the LEVEL kernels solved; instances of the
 // exact path are left untouched when an exact job is pending (they arrive with its outcome) and filled in otherwise.
 // results [n] or null, kept_values [n][n_keep][32] or null, kept_assigned [n][n_keep] or null, digests [n][32] or null
 int batch_export_tile(acvm_batch *b, uint32_t n, const uint32_t *keep, uint32_t n_keep, acvm_result_t *results, uint8_t *kept_values, uint8_t *kept_assigned,
                       uint8_t *digests);
+// the kept witnesses of instances [0, n) leave the device without being waited for: the export kernel runs on the handle's stream (behind
+// the solve, in front of the next import), the copy into h_out on `copy_stream` behind it; `arrived` is recorded behind the copy.
+int batch_enqueue_kept(acvm_batch *b, uint32_t n, const uint32_t *d_keep, uint32_t n_keep, uint8_t *d_out, uint8_t *h_out, hipStream_t copy_stream,
+                       hipEvent_t exported, hipEvent_t arrived);
+// device bytes a handle of `instances` instances of this plan allocates (tables, class scratch, inverse rows, the first side table)
+size_t batch_device_bytes(const acvm::Plan &p, const acvm::PlanOpts &opts, uint64_t instances, bool async_exact);
 }  // extern "C"

@@ -16,10 +16,12 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
 namespace acvm {
+void launch_grumpkin_win16_table(hipStream_t s, const GrumpkinTables &T, uint4 *out);  // kernels_grumpkin.hip
 namespace {
 
 // ---- Keccak-256 (Keccak-f[1600], rate 136, pad 0x01 .. 0x80), host
@@ -243,34 +245,60 @@ HostTables build_host_tables() {
     return T;
 }
 
-std::mutex g_mu;
+// ---- the per-device table sets. One set per HIP device, built on first use and kept until the caller releases it
+// (acvm_device_release_tables, or the last handle of the device with tuning tables_keep = 0). Builds take the SET's lock only -- the handles
+// acvm_node_new creates side by side on eight devices build their tables in parallel -- and run on the set's own stream, which is
+// synchronised instead of the device: a handle already solving on the device is not stalled by a second handle's first use of a table.
+std::once_flag g_host_once;
 HostTables g_host;
-bool g_host_built = false;
-std::map<int, GrumpkinTables> g_dev;
+const HostTables &host_tables() {
+    std::call_once(g_host_once, [] { g_host = build_host_tables(); });
+    return g_host;
+}
 
-}  // namespace
+struct DeviceTableSet {
+    std::mutex mu;
+    hipStream_t build = nullptr;
+    bool base_built = false;
+    uint32_t *base_alloc = nullptr;   // ped | win | small | skew, one allocation
+    GrumpkinTables t{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *ecdsa = nullptr;        // generator tables of the two ECDSA curves (kernels_ecdsa.hip)
+    uint32_t users = 0;               // live batch handles (and probes in flight) that hold pointers into the set
+};
+std::mutex g_sets_mu;  // guards the map only
+std::map<int, std::unique_ptr<DeviceTableSet>> g_sets;
 
-void launch_grumpkin_win16_table(hipStream_t s, const GrumpkinTables &T, uint4 *out);  // kernels_grumpkin.hip
-
-const GrumpkinTables *grumpkin_tables() {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_host_built) {
-        g_host = build_host_tables();
-        g_host_built = true;
-    }
-    if (!g_host.ok) return nullptr;
+DeviceTableSet *table_set(int dev) {
+    std::lock_guard<std::mutex> lk(g_sets_mu);
+    auto &p = g_sets[dev];
+    if (!p) p = std::make_unique<DeviceTableSet>();
+    return p.get();
+}
+DeviceTableSet *current_set(int *dev_out = nullptr) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    auto it = g_dev.find(dev);
-    if (it != g_dev.end()) return &it->second;
+    if (dev_out) *dev_out = dev;
+    return table_set(dev);
+}
+bool ensure_stream(DeviceTableSet &S) { return S.build || hipStreamCreateWithFlags(&S.build, hipStreamNonBlocking) == hipSuccess; }
+
+// (S.mu held) the four host-built tables and, with tuning win16, the 16-bit window tables
+bool ensure_base(DeviceTableSet &S) {
+    if (S.base_built) return true;
+    const HostTables &H = host_tables();
+    if (!H.ok || !ensure_stream(S)) return false;
     uint32_t *d = nullptr;
-    if (hipMalloc((void **)&d, g_host.words.size() * 4) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, g_host.words.data(), g_host.words.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
-    GrumpkinTables t;
-    t.ped = (const uint4 *)(d + g_host.ped_off * 16);
-    t.win = (const uint4 *)(d + g_host.win_off * 16);
-    t.small = (const uint4 *)(d + g_host.small_off * 16);
-    t.skew = (const uint4 *)(d + g_host.skew_off * 16);
+    if (hipMalloc((void **)&d, H.words.size() * 4) != hipSuccess) return false;
+    if (hipMemcpyAsync(d, H.words.data(), H.words.size() * 4, hipMemcpyHostToDevice, S.build) != hipSuccess || hipStreamSynchronize(S.build) != hipSuccess) {
+        hipFree(d);
+        return false;
+    }
+    S.base_alloc = d;
+    GrumpkinTables &t = S.t;
+    t.ped = (const uint4 *)(d + H.ped_off * 16);
+    t.win = (const uint4 *)(d + H.win_off * 16);
+    t.small = (const uint4 *)(d + H.small_off * 16);
+    t.skew = (const uint4 *)(d + H.skew_off * 16);
     t.ped2 = nullptr;
     t.win16 = nullptr;
     t.pedw = nullptr;
@@ -280,68 +308,149 @@ const GrumpkinTables *grumpkin_tables() {
         uint4 *w16 = nullptr;
         const size_t entries = (size_t)GRUMPKIN_N_WINDOW_BASES * GRUMPKIN_WIN16_STRIDE;
         if (tuning().win16 && hipMalloc((void **)&w16, entries * 64) == hipSuccess) {
-            launch_grumpkin_win16_table(nullptr, t, w16);
-            if (hipDeviceSynchronize() == hipSuccess) t.win16 = w16;
+            launch_grumpkin_win16_table(S.build, t, w16);
+            if (hipGetLastError() == hipSuccess && hipStreamSynchronize(S.build) == hipSuccess) t.win16 = w16;
             else hipFree(w16);
         }
     }
-    auto ins = g_dev.emplace(dev, t);
-    return &ins.first->second;
+    S.base_built = true;
+    return true;
 }
+
+void free_set(DeviceTableSet &S) {  // (S.mu held, no users)
+    for (const void *p : {(const void *)S.base_alloc, (const void *)S.t.ped2, (const void *)S.t.win16, (const void *)S.t.pedw, (const void *)S.ecdsa})
+        if (p) hipFree(const_cast<void *>(p));
+    if (S.build) hipStreamDestroy(S.build);
+    S.build = nullptr;
+    S.base_alloc = nullptr;
+    S.ecdsa = nullptr;
+    S.base_built = false;
+    S.t = GrumpkinTables{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+}
+
+}  // namespace
 
 void launch_pedersen_pair_table(hipStream_t s, const GrumpkinTables &T, uint4 *out);  // kernels_grumpkin.hip
-
-const GrumpkinTables *grumpkin_pair_table() {
-    const GrumpkinTables *base = grumpkin_tables();
-    if (!base) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    GrumpkinTables &t = g_dev.find(dev)->second;
-    if (t.ped2) return &t;
-    uint4 *d = nullptr;
-    const size_t entries = (size_t)30 << GRUMPKIN_PED2_LOG2;
-    if (hipMalloc((void **)&d, entries * 64) != hipSuccess) return nullptr;
-    launch_pedersen_pair_table(nullptr, t, d);
-    if (hipDeviceSynchronize() != hipSuccess) { hipFree(d); return nullptr; }
-    t.ped2 = d;
-    return &t;
-}
-
 void launch_pedersen_window_table(hipStream_t s, const GrumpkinTables &T, uint4 *out, uint32_t *n_infinite);  // kernels_grumpkin.hip
+void launch_ecdsa_gtable(hipStream_t s, uint32_t *out);  // kernels_ecdsa.hip
+size_t ecdsa_gtable_bytes();
 
-const GrumpkinTables *grumpkin_window_table() {
-    const GrumpkinTables *base = grumpkin_tables();
-    if (!base) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    GrumpkinTables &t = g_dev.find(dev)->second;
-    if (t.pedw) return &t;
-    uint4 *d = nullptr;
-    uint32_t *d_bad = nullptr, bad = 1;
-    const size_t entries = (size_t)2 * GRUMPKIN_PEDW_WINDOWS << GRUMPKIN_PEDW_BITS;
-    if (hipMalloc((void **)&d, entries * 64) != hipSuccess) return nullptr;
-    if (hipMalloc((void **)&d_bad, 4) != hipSuccess || hipMemset(d_bad, 0, 4) != hipSuccess) { hipFree(d); hipFree(d_bad); return nullptr; }
-    launch_pedersen_window_table(nullptr, t, d, d_bad);
-    const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;  // (no entry may be the identity)
-    hipFree(d_bad);
-    if (!ok) { hipFree(d); return nullptr; }
-    t.pedw = d;
-    return &t;
+bool grumpkin_tables(GrumpkinTables *out) {
+    DeviceTableSet *S = current_set();
+    if (!S) return false;
+    std::lock_guard<std::mutex> lk(S->mu);
+    if (!ensure_base(*S)) return false;
+    *out = S->t;
+    return true;
 }
 
-const void *grumpkin_tables_device() { return grumpkin_tables(); }
+bool grumpkin_pair_table(GrumpkinTables *out) {
+    DeviceTableSet *S = current_set();
+    if (!S) return false;
+    std::lock_guard<std::mutex> lk(S->mu);
+    if (!ensure_base(*S)) return false;
+    GrumpkinTables &t = S->t;
+    if (!t.ped2) {
+        uint4 *d = nullptr;
+        const size_t entries = (size_t)30 << GRUMPKIN_PED2_LOG2;
+        if (hipMalloc((void **)&d, entries * 64) != hipSuccess) return false;
+        launch_pedersen_pair_table(S->build, t, d);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(S->build) != hipSuccess) { hipFree(d); return false; }
+        t.ped2 = d;
+    }
+    *out = t;
+    return true;
+}
+
+bool grumpkin_window_table(GrumpkinTables *out) {
+    DeviceTableSet *S = current_set();
+    if (!S) return false;
+    std::lock_guard<std::mutex> lk(S->mu);
+    if (!ensure_base(*S)) return false;
+    GrumpkinTables &t = S->t;
+    if (!t.pedw) {
+        uint4 *d = nullptr;
+        uint32_t *d_bad = nullptr, bad = 1;
+        const size_t entries = (size_t)2 * GRUMPKIN_PEDW_WINDOWS << GRUMPKIN_PEDW_BITS;
+        if (hipMalloc((void **)&d, entries * 64) != hipSuccess) return false;
+        if (hipMalloc((void **)&d_bad, 4) != hipSuccess || hipMemsetAsync(d_bad, 0, 4, S->build) != hipSuccess) { hipFree(d); hipFree(d_bad); return false; }
+        launch_pedersen_window_table(S->build, t, d, d_bad);
+        const bool ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, S->build) == hipSuccess &&
+                        hipStreamSynchronize(S->build) == hipSuccess && bad == 0;  // (no entry may be the identity)
+        hipFree(d_bad);
+        if (!ok) { hipFree(d); return false; }
+        t.pedw = d;
+    }
+    *out = t;
+    return true;
+}
+
+const uint32_t *ecdsa_generator_tables() {
+    DeviceTableSet *S = current_set();
+    if (!S) return nullptr;
+    std::lock_guard<std::mutex> lk(S->mu);
+    if (S->ecdsa) return S->ecdsa;
+    if (!ensure_stream(*S)) return nullptr;
+    uint32_t *d = nullptr;
+    if (hipMalloc((void **)&d, ecdsa_gtable_bytes()) != hipSuccess) return nullptr;
+    launch_ecdsa_gtable(S->build, d);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(S->build) != hipSuccess) { hipFree(d); return nullptr; }
+    S->ecdsa = d;
+    return d;
+}
+
+void device_tables_retain(int device) {
+    DeviceTableSet *S = table_set(device);
+    std::lock_guard<std::mutex> lk(S->mu);
+    S->users++;
+}
+void device_tables_unref(int device) {
+    DeviceTableSet *S = table_set(device);
+    std::lock_guard<std::mutex> lk(S->mu);
+    if (S->users) S->users--;
+    if (!S->users && !tuning().tables_keep) {
+        int prev = 0;
+        const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+        if (hipSetDevice(device) == hipSuccess) free_set(*S);
+        if (have_prev) hipSetDevice(prev);
+    }
+}
+// 0 = freed (or nothing to free), 1 = handles of the device still hold the tables, -1 = the device could not be selected
+int device_tables_free(int device, size_t *bytes_freed) {
+    DeviceTableSet *S = table_set(device);
+    std::lock_guard<std::mutex> lk(S->mu);
+    if (bytes_freed) *bytes_freed = 0;
+    if (S->users) return 1;
+    if (!S->base_built && !S->ecdsa) return 0;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    size_t before = 0, after = 0, total = 0;
+    hipMemGetInfo(&before, &total);
+    free_set(*S);
+    hipMemGetInfo(&after, &total);
+    if (bytes_freed) *bytes_freed = after > before ? after - before : 0;
+    if (have_prev) hipSetDevice(prev);
+    return 0;
+}
+// bytes the fixed tables of a Grumpkin / ECDSA circuit would ADD to the current device (what is not built yet), for memory sizing
+size_t device_tables_missing_bytes(bool grumpkin, bool pedersen_level, bool window_table, bool ecdsa) {
+    DeviceTableSet *S = current_set();
+    if (!S) return 0;
+    std::lock_guard<std::mutex> lk(S->mu);
+    size_t need = 0;
+    if (grumpkin && !S->base_built) need += host_tables().words.size() * 4 + (tuning().win16 ? (size_t)GRUMPKIN_N_WINDOW_BASES * GRUMPKIN_WIN16_STRIDE * 64 : 0);
+    if (grumpkin && pedersen_level) {
+        if (window_table && !S->t.pedw) need += ((size_t)2 * GRUMPKIN_PEDW_WINDOWS << GRUMPKIN_PEDW_BITS) * 64;
+        else if (!window_table && !S->t.ped2) need += ((size_t)30 << GRUMPKIN_PED2_LOG2) * 64;
+    }
+    if (ecdsa && !S->ecdsa) need += ecdsa_gtable_bytes();
+    return need;
+}
 
 // host copy of a table point (tests / self check): which = 0 ped, 1 win, 2 small, 3 skew
 bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]) {
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_host_built) {
-            g_host = build_host_tables();
-            g_host_built = true;
-        }
-    }
+    const HostTables &g_host = host_tables();
     if (!g_host.ok) return false;
     size_t off = which == 0 ? g_host.ped_off : which == 1 ? g_host.win_off : which == 2 ? g_host.small_off : g_host.skew_off;
     size_t idx = off + index;

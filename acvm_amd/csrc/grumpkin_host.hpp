@@ -23,19 +23,30 @@ struct GrumpkinTables {
 static constexpr uint32_t GRUMPKIN_WIN16_STRIDE = 16 * 65535;  // points per base
 static constexpr uint32_t GRUMPKIN_PED2_LOG2 = 18;  // entries per generator
 
-// tables of the current device (built on first use), nullptr on failure
-const GrumpkinTables *grumpkin_tables();
+// Tables of the CURRENT device, built on first use and kept in a per-device set (grumpkin_host.cpp): a copy of the set's pointers into
+// *out, false on failure. Builds take the device's own lock and synchronise the set's build stream (never the device).
+bool grumpkin_tables(GrumpkinTables *out);
 // the same tables with ped2 built (503 MB of HBM, generated on the device on first use): entry [g][a][b] is
 // beta((a + 1) D[g]) + (b + 1) D[g], i.e. the contribution of two consecutive 9-bit slices of a plookup Pedersen
 // hash_single (the even slice goes through the endomorphism), so that the level kernel pays one mixed addition per 18 bits
 // instead of two. For the last generator of a value (g % 15 == 14, one slice only) the entry is beta((a + 1) D[g]).
-const GrumpkinTables *grumpkin_pair_table();
+bool grumpkin_pair_table(GrumpkinTables *out);
 // ... and with pedw built (6.4 GB, generated on the device on first use). The slices of hash_single are linear in the bits of the scalar -- a slice
 // a of generator D contributes (a + 1) D = a_hi 2^k D + a_lo D + D -- so the 29 slices (261 bits) of a value can be cut at ANY bit: entry [parity][j][v]
 // is the joint contribution of bits [22 j, 22 j + 22) of the scalar (the pieces of the two to four slices the window touches, the even slices through
 // the endomorphism, plus the `+ 1` of every slice that starts inside the window): 12 mixed additions per hash_single instead of the pair table's 15.
 static constexpr uint32_t GRUMPKIN_PEDW_BITS = 22, GRUMPKIN_PEDW_WINDOWS = 12;
-const GrumpkinTables *grumpkin_window_table();
+bool grumpkin_window_table(GrumpkinTables *out);
 bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]);
+// generator tables of the two ECDSA curves on the current device (kernels_ecdsa.hip builds them), nullptr on failure
+const uint32_t *ecdsa_generator_tables();
+// Lifetime of a device's set: every batch handle whose circuit reads a table holds a reference from its creation to its destruction
+// (device_tables_retain / _unref); device_tables_free releases the device memory of a set nobody holds (acvm_device_release_tables:
+// 0 freed, 1 still in use, -1 device error); with tuning tables_keep = 0 the last handle's destruction frees it.
+void device_tables_retain(int device);
+void device_tables_unref(int device);
+int device_tables_free(int device, size_t *bytes_freed);
+// device memory the fixed tables of a circuit would still add to the current device (memory sizing of acvm_node_new)
+size_t device_tables_missing_bytes(bool grumpkin, bool pedersen_level, bool window_table, bool ecdsa);
 
 }  // namespace acvm

@@ -2,8 +2,6 @@
 // the tables of the two generators.
 #include "ops_ecdsa.hpp"
 #include "ops_kernel.hpp"
-#include <map>
-#include <mutex>
 
 namespace acvm {
 
@@ -56,20 +54,10 @@ void launch_secp_rate(hipStream_t s, uint32_t curve, uint32_t *out, uint32_t blo
     else hipLaunchKernelGGL(secp_rate_kernel<1>, dim3(blocks), dim3(256), 0, s, out, 1u, iters);
 }
 
-const uint32_t *ecdsa_generator_tables() {
-    static std::mutex mu;
-    static std::map<int, uint32_t *> per_device;
-    std::lock_guard<std::mutex> lk(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    auto it = per_device.find(dev);
-    if (it != per_device.end()) return it->second;
-    uint32_t *d = nullptr;
-    if (hipMalloc((void **)&d, (size_t)2 * SECP_GTABLE_WORDS * 4) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(ecdsa_gtable_kernel, dim3(2u * (SECP_GWINDOWS << SECP_GWIN) / 64u), dim3(64), 0, nullptr, d);
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(d); return nullptr; }
-    per_device.emplace(dev, d);
-    return d;
+// the tables of both curves (grumpkin_host.cpp keeps them in the device's table set and builds them on the set's stream)
+size_t ecdsa_gtable_bytes() { return (size_t)2 * SECP_GTABLE_WORDS * 4; }
+void launch_ecdsa_gtable(hipStream_t s, uint32_t *out) {
+    hipLaunchKernelGGL(ecdsa_gtable_kernel, dim3(2u * (SECP_GWINDOWS << SECP_GWIN) / 64u), dim3(64), 0, s, out);
 }
 
 }  // namespace acvm

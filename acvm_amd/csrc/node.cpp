@@ -10,6 +10,7 @@
 //   * per instance the caller gets the result record, the kept witnesses (normally the circuit's return values) and the 32-byte
 //     digest of the whole witness map, in global instance order.
 #include "batch.hpp"
+#include "circuit.hpp"
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -25,8 +26,10 @@ struct DeviceLane {
     bool async = false;
     uint8_t *pinned[2] = {nullptr, nullptr};
     uint8_t *d_in[2] = {nullptr, nullptr};
-    hipStream_t copy = nullptr;
+    hipStream_t copy = nullptr, out = nullptr;  // uploads of the producer thread; downloads of the kept witnesses
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+    hipEvent_t ev_imported[2] = {nullptr, nullptr};  // the import kernel has read staging slot k: the next upload into it may start
+    hipEvent_t ev_exported[2] = {nullptr, nullptr}, ev_arrived[2] = {nullptr, nullptr};  // kept witnesses: export kernel done / copy in pinned memory
     // kept witnesses leave the device beside the NEXT tile's solve: export kernel + D2H into pinned memory are enqueued behind a solve and
     // harvested after the following one
     uint32_t *d_keep = nullptr;
@@ -56,12 +59,14 @@ struct acvm_node {
             for (int k = 0; k < 2; k++) {
                 if (l.pinned[k]) hipHostFree(l.pinned[k]);
                 if (l.d_in[k]) hipFree(l.d_in[k]);
-                if (l.ev_h2d[k]) hipEventDestroy(l.ev_h2d[k]);
+                for (hipEvent_t e : {l.ev_h2d[k], l.ev_imported[k], l.ev_exported[k], l.ev_arrived[k]})
+                    if (e) hipEventDestroy(e);
                 if (l.d_exp[k]) hipFree(l.d_exp[k]);
                 if (l.h_exp[k]) hipHostFree(l.h_exp[k]);
             }
             if (l.d_keep) hipFree(l.d_keep);
             if (l.copy) hipStreamDestroy(l.copy);
+            if (l.out) hipStreamDestroy(l.out);
         }
     }
 };
@@ -69,16 +74,31 @@ struct acvm_node {
 namespace {
 
 // instances per handle when the caller leaves the choice to the library: the largest power of two (at most 2^17, the measured optimum of
-// the 10k-gate circuit) whose tables fit 70 % of the device's free memory
-uint32_t auto_tile(const acvm_circuit_t *c, const std::vector<uint32_t> &ids, const std::vector<uint32_t> &keep, uint32_t flags, int device) {
-    acvm_stats_t st;
-    if (acvm_circuit_plan_stats_ex(c, ids.data(), (uint32_t)ids.size(), flags, keep.data(), (uint32_t)keep.size(), &st) != 0) return 0;
-    size_t free_b = 0, total_b = 0;
-    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
-    // witness rows + inverse rows, 32 B each, + 15 % for memory blocks, class scratch and staging
-    const double per_instance = 32.0 * ((double)st.n_table_rows + st.n_inverse_slots) * 1.15 + 4096.0;
+// the 10k-gate circuit) that every listed device has room for. Per device: 90 % of its free memory, less the lookup
+// tables the circuit would still build there, divided by the number of handles the device is listed for; a handle needs its tables, class
+// scratch and first side table (batch_device_bytes) plus this driver's staging and export buffers.
+uint32_t auto_tile(const acvm_circuit_t *c, const std::vector<uint32_t> &ids, const std::vector<uint32_t> &keep, uint32_t flags, const std::vector<int> &devices) {
+    PlanOpts opts;
+    opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;
+    opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
+    opts.keep = keep;
+    const Plan p = build_plan(*c->c, ids.data(), (uint32_t)ids.size(), opts);
+    if (!p.unsupported.empty()) { set_err(ACVM_E_UNSUPPORTED, p.unsupported); return 0; }
+    const bool pedersen_level = !p.cls_offset[CLS_PEDERSEN].empty();
+    const bool window_table = pedersen_level && p.tune.pedersen_window_bits == (int64_t)GRUMPKIN_PEDW_BITS;
+    double budget = 1e30;
+    for (int d : devices) {
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(d) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { set_err(ACVM_E_DEVICE, "hipMemGetInfo failed"); return 0; }
+        const double tables = (double)device_tables_missing_bytes(p.needs_grumpkin, pedersen_level, window_table, p.needs_ecdsa);
+        const double copies = (double)std::count(devices.begin(), devices.end(), d);
+        budget = std::min(budget, (0.9 * (double)free_b - tables) / copies);
+    }
+    const double io_per_instance = 2.0 * 32.0 * (double)ids.size() * 2.0 /* pinned + device staging are separate pools; count the device one twice for slack */ +
+                                   2.0 * 32.0 * (double)keep.size();
     uint32_t t = 1u << 17;
-    while (t > 64 && (double)t * per_instance > 0.7 * (double)free_b) t >>= 1;
+    while (t > 64 && (double)batch_device_bytes(p, opts, t, true) + io_per_instance * t > budget) t >>= 1;
+    if ((double)batch_device_bytes(p, opts, t, true) + io_per_instance * t > budget) { set_err(ACVM_E_DEVICE, "not enough free device memory for a tile of 64 instances of this circuit"); return 0; }
     return t;
 }
 
@@ -132,13 +152,24 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
     const uint64_t n = last - first;
     const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
     if (!n_tiles) return;
-    // ---- producer: host rows -> pinned staging -> device, one tile ahead of the solver
+    // ---- producer: host rows -> pinned staging -> device, one tile ahead of the solver. Every failure of it reaches the solver (producer_rc):
+    // a solver that waited for a tile that never comes would hang, one that went on after a failed copy would solve stale inputs.
     std::mutex mu;
     std::condition_variable cv;
-    uint32_t staged = 0, consumed = 0;  // tiles whose H2D was issued / whose staging slot is free again
+    uint32_t staged = 0, consumed = 0;  // tiles whose H2D was issued / whose import was enqueued (the staging slot is handed back through ev_imported)
     bool abort = false;
+    int producer_rc = 0;
+    std::string producer_err;
     std::thread producer([&] {
-        if (hipSetDevice(L.device) != hipSuccess) return;  // HIP's current device is per thread
+        auto give_up = [&](const char *what, hipError_t e) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                producer_rc = ACVM_E_DEVICE;
+                producer_err = std::string(what) + ": " + hipGetErrorString(e);
+            }
+            cv.notify_all();
+        };
+        if (hipError_t e = hipSetDevice(L.device); e != hipSuccess) { give_up("hipSetDevice (upload thread)", e); return; }  // HIP's current device is per thread
         for (uint32_t k = 0; k < n_tiles; k++) {
             {
                 std::unique_lock<std::mutex> lk(mu);
@@ -148,9 +179,14 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
             const uint64_t base = first + (uint64_t)k * tile;
             const uint32_t m = (uint32_t)std::min<uint64_t>(tile, last - base);
             const int slot = (int)(k & 1);
+            // the pinned half of the slot is free once its previous upload has been read by the copy engine (ev_h2d, waited for by the solver
+            // before it enqueued that tile's import), the device half once that import kernel has run (ev_imported)
+            if (k >= 2)
+                if (hipError_t e = hipStreamWaitEvent(L.copy, L.ev_imported[slot], 0); e != hipSuccess) { give_up("hipStreamWaitEvent", e); return; }
             fill_staging(L.pinned[slot], values, row, base, m);
-            if (row) hipMemcpyAsync(L.d_in[slot], L.pinned[slot], (size_t)m * row, hipMemcpyHostToDevice, L.copy);
-            hipEventRecord(L.ev_h2d[slot], L.copy);
+            if (row)
+                if (hipError_t e = hipMemcpyAsync(L.d_in[slot], L.pinned[slot], (size_t)m * row, hipMemcpyHostToDevice, L.copy); e != hipSuccess) { give_up("hipMemcpyAsync (upload)", e); return; }
+            if (hipError_t e = hipEventRecord(L.ev_h2d[slot], L.copy); e != hipSuccess) { give_up("hipEventRecord", e); return; }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 staged = k + 1;
@@ -174,23 +210,23 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
     uint64_t fl_base = 0;
     uint32_t fl_n = 0;
     std::vector<uint32_t> fl_flagged;
-    const Plan &plan = L.batch->plan;
-    auto harvest = [&] {
-        if (!in_flight) return;
+    auto harvest = [&]() -> bool {  // the kept witnesses of the tile in flight: wait for their copy (it ran beside the solve that followed), scatter
+        if (!in_flight) return true;
         in_flight = false;
+        if (hipEventSynchronize(L.ev_arrived[fl_slot]) != hipSuccess) { fail(ACVM_E_DEVICE, "hipEventSynchronize (kept witnesses)"); return false; }
         memcpy(kept + fl_base * n_keep * 32, L.h_exp[fl_slot], (size_t)fl_n * n_keep * 32);
         std::vector<uint8_t> flagged(fl_n, 0);
         for (uint32_t j : fl_flagged)
             if (j < fl_n) flagged[j] = 1;
         for (uint32_t k2 = 0; k2 < n_keep; k2++) {  // the level kernels' assigned set is the planner's
-            const uint32_t w = node->keep[k2];
-            const bool produced = w < plan.n_witnesses && plan.producer[w] != 0xFFFFFFFFu;
+            const bool produced = batch_generic_assigned(L.batch, node->keep[k2]);
             for (uint32_t j = 0; j < fl_n; j++) {
                 if (flagged[j]) continue;
                 if (kept_assigned) kept_assigned[(fl_base + j) * n_keep + k2] = produced;
                 if (!produced) memset(kept + ((fl_base + j) * n_keep + k2) * 32, 0, 32);
             }
         }
+        return true;
     };
     for (uint32_t k = 0; k < n_tiles && !L.rc; k++) {
         const uint64_t base = first + (uint64_t)k * tile;
@@ -199,13 +235,15 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         const double t0 = now_ms();
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return staged > k; });
+            cv.wait(lk, [&] { return staged > k || producer_rc != 0; });
+            if (producer_rc) { L.rc = producer_rc; L.error = "upload of tile " + std::to_string(k) + ": " + producer_err; break; }
         }
         if (hipEventSynchronize(L.ev_h2d[slot]) != hipSuccess) { fail(ACVM_E_DEVICE, "hipEventSynchronize"); break; }
         L.h2d_wait_ms += now_ms() - t0;
         if (int rc = batch_set_live_count(L.batch, m)) { fail(rc, "live count"); break; }  // a partial last tile: the lanes behind it are dead
-        if (int rc = acvm_batch_set_initial_witness_device(L.batch, L.d_in[slot])) { fail(rc, "set_initial_witness"); break; }
-        {   // the import has read the slot: the producer may refill it
+        // the import is enqueued, not waited for: it runs behind the export kernel of the previous tile and in front of this tile's levels
+        if (int rc = batch_import_async(L.batch, L.d_in[slot], L.ev_imported[slot])) { fail(rc, "set_initial_witness"); break; }
+        {   // the producer may prepare the tile after next (its upload waits for ev_imported on the copy stream)
             std::lock_guard<std::mutex> lk(mu);
             consumed = k + 1;
         }
@@ -218,18 +256,19 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         L.exact_instances += st.n_slow_instances;
         L.tiles++;
         const double t1 = now_ms();
-        // the kept witnesses of the PREVIOUS tile have arrived in pinned memory (this solve synchronised the stream behind their copy)
-        harvest();
-        if (k > 0 && !L.batch->last_outcome.instance.empty()) {
-            L.not_solved += patch_outcome(L.batch->last_outcome, prev_base, prev_valid, n_keep, results, kept, kept_assigned, digests);
-            L.batch->last_outcome.clear();
+        // the kept witnesses of the PREVIOUS tile: their copy ran on the download stream beside this solve
+        if (!harvest()) break;
+        if (k > 0) {
+            ExactOutcome o;
+            batch_take_outcome(L.batch, &o);
+            if (!o.instance.empty()) L.not_solved += patch_outcome(o, prev_base, prev_valid, n_keep, results, kept, kept_assigned, digests);
         }
-        if (!L.batch->pending)  // a synchronous exact path: its lanes are final
-            for (size_t t = 0; t < L.batch->slow_ids.size(); t++)
-                L.not_solved += L.batch->slow_ids[t] < m && L.batch->slow_res[t].status != ACVM_STATUS_SOLVED;
+        const bool pending = batch_exact_pending(L.batch);
+        const std::vector<uint32_t> &exact_ids = *batch_exact_instances(L.batch);
+        L.not_solved += batch_exact_unsolved(L.batch, m);  // (a synchronous exact path: its lanes are final)
         // instances of a SYNCHRONOUS exact path have their values (and assigned sets) where only the batch knows: such a tile exports in one
         // synchronous step; every other tile enqueues its kept witnesses and goes on
-        const bool overlap = kept && n_keep && (L.batch->slow_ids.empty() || L.batch->pending);
+        const bool overlap = kept && n_keep && (exact_ids.empty() || pending);
         if (int rc2 = batch_export_tile(L.batch, m, node->keep.data(), overlap ? 0u : n_keep, results ? results + base : nullptr,
                                         kept && !overlap ? kept + base * n_keep * 32 : nullptr, kept_assigned && !overlap ? kept_assigned + base * n_keep : nullptr,
                                         digests ? digests + base * 32 : nullptr)) {
@@ -237,22 +276,18 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
             break;
         }
         if (overlap) {
-            launch_export(L.batch->stream, L.batch->d_W, L.batch->Bp, 0, m, L.d_keep, n_keep, L.d_exp[slot], L.batch->unscale, L.batch->d_slot_of);
-            if (hipMemcpyAsync(L.h_exp[slot], L.d_exp[slot], (size_t)m * n_keep * 32, hipMemcpyDeviceToHost, L.batch->stream) != hipSuccess) { fail(ACVM_E_DEVICE, "hipMemcpyAsync"); break; }
+            if (int rc3 = batch_enqueue_kept(L.batch, m, L.d_keep, n_keep, L.d_exp[slot], L.h_exp[slot], L.out, L.ev_exported[slot], L.ev_arrived[slot])) { fail(rc3, "export of the kept witnesses"); break; }
             in_flight = true;
             fl_slot = slot;
             fl_base = base;
             fl_n = m;
-            fl_flagged.assign(L.batch->slow_ids.begin(), L.batch->slow_ids.end());  // (arrive with the exact job's outcome)
+            fl_flagged.assign(exact_ids.begin(), exact_ids.end());  // (arrive with the exact job's outcome)
         }
         L.export_ms += now_ms() - t1;
         prev_base = base;
         prev_valid = m;
     }
-    if (!L.rc && in_flight) {
-        if (hipStreamSynchronize(L.batch->stream) != hipSuccess) fail(ACVM_E_DEVICE, "hipStreamSynchronize");
-        else harvest();
-    }
+    if (!L.rc) harvest();
     if (!L.rc) {  // the exact job of the last tile
         ExactOutcome o;
         if (int rc = batch_finish_pending(L.batch, &o)) fail(rc, "exact path");
@@ -260,9 +295,11 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
     }
     stop_producer();
     hipStreamSynchronize(L.copy);
+    hipStreamSynchronize(L.out);
     if (L.rc) {  // leave the handle reusable
         ExactOutcome o;
         batch_finish_pending(L.batch, &o);
+        acvm_device_synchronize();  // (an import enqueued for a tile that was never solved)
     }
     L.total_ms = now_ms() - t_begin;
 }
@@ -284,13 +321,16 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
         if (w >= acvm_circuit_num_witnesses(c)) w = 0xFFFFFFFFu;
     node->flags = opts ? opts->batch_flags : 0;
     std::vector<int> devices;
+    // n_devices == 0 selects every visible device and `devices` is not read (it holds n_devices entries: none)
+    const bool listed = opts && opts->n_devices && opts->devices;
     const uint32_t n_dev = opts && opts->n_devices ? opts->n_devices : (uint32_t)visible;
+    if (n_dev > 16) { set_err(ACVM_E_INVALID, "at most 16 handles per node (acvm_node_stats_t)"); return nullptr; }
     for (uint32_t i = 0; i < n_dev; i++) {
-        const int d = opts && opts->devices ? opts->devices[i] : (int)i;
+        const int d = listed ? opts->devices[i] : (int)i;
         if (d < 0 || d >= visible) { set_err(ACVM_E_INVALID, "device index " + std::to_string(d) + " out of range (" + std::to_string(visible) + " visible)"); return nullptr; }
         devices.push_back(d);
     }
-    node->tile = opts && opts->tile_instances ? opts->tile_instances : auto_tile(c, node->ids, node->keep, node->flags, devices[0]);
+    node->tile = opts && opts->tile_instances ? opts->tile_instances : auto_tile(c, node->ids, node->keep, node->flags, devices);
     if (!node->tile) return nullptr;  // (the planner's refusal is the error text)
     node->lanes.resize(devices.size());
     const size_t row = (size_t)n_initial * 32;
@@ -308,10 +348,11 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
             if (a < 0) { fail(a, "async exact path"); return; }
             L.async = a == 1;
             const size_t bytes = std::max<size_t>((size_t)node->tile * row, 16);
-            bool ok = hipStreamCreateWithFlags(&L.copy, hipStreamNonBlocking) == hipSuccess;
+            bool ok = hipStreamCreateWithFlags(&L.copy, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&L.out, hipStreamNonBlocking) == hipSuccess;
             for (int k = 0; k < 2 && ok; k++)
                 ok = hipHostMalloc((void **)&L.pinned[k], bytes, hipHostMallocDefault) == hipSuccess && hipMalloc((void **)&L.d_in[k], bytes) == hipSuccess &&
-                     hipEventCreateWithFlags(&L.ev_h2d[k], hipEventDisableTiming) == hipSuccess;
+                     hipEventCreateWithFlags(&L.ev_h2d[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_imported[k], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&L.ev_exported[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_arrived[k], hipEventDisableTiming) == hipSuccess;
             if (ok && n_keep) {
                 const size_t eb = (size_t)node->tile * n_keep * 32;
                 ok = hipMalloc((void **)&L.d_keep, (size_t)n_keep * 4) == hipSuccess &&

@@ -18,7 +18,7 @@ const Key KEYS[] = {
     {"fc_relevel", &Tuning::fc_relevel}, {"exact_async", &Tuning::exact_async}, {"brillig_steps_log2", &Tuning::brillig_steps_log2},
     {"brillig_steps_max_log2", &Tuning::brillig_steps_max_log2}, {"brillig_call_depth", &Tuning::brillig_call_depth},
     {"brillig_call_depth_max", &Tuning::brillig_call_depth_max}, {"brillig_mem_max_log2", &Tuning::brillig_mem_max_log2},
-    {"pedersen_window_bits", &Tuning::pedersen_window_bits}, {"win16", &Tuning::win16},
+    {"pedersen_window_bits", &Tuning::pedersen_window_bits}, {"win16", &Tuning::win16}, {"tables_keep", &Tuning::tables_keep},
 };
 constexpr unsigned N_KEYS = sizeof KEYS / sizeof KEYS[0];
 

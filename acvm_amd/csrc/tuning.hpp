@@ -44,6 +44,7 @@ struct Tuning {
     // ---- tables (grumpkin_host.cpp)
     int64_t pedersen_window_bits = 22; // 22 (0: off): the level Pedersen kernel reads 22-bit windows (6.4 GB of tables, 12 additions per hash_single) instead of slice pairs (503 MB, 15)
     int64_t win16 = 1;             // 16-bit window tables of the four fixed bases
+    int64_t tables_keep = 1;       // 1: a device's lookup tables stay until acvm_device_release_tables; 0: the last handle of the device frees them
 };
 
 Tuning &tuning();                                   // the process-wide defaults

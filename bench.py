@@ -6,7 +6,8 @@ Default workload = BASELINE.json's metric: 10k-gate arithmetic-only ACIR, batch 
 scaling: 2^20 / N instances per GPU, no data-path collective); a rank solves its shard in tiles of 2^--tile-log2 instances (default 2^17)
 through one reused batch handle (the 335 GB witness table of 2^20 instances does not fit one GPU's 288 GB: SURVEY 8e). The
 inputs of the whole shard are resident in HBM before the timed region starts; a "step" = ACVM::new + ACVM::solve of every
-instance of the global batch (per tile: import of the resident inputs, then the level kernels), witness maps left in HBM.
+instance of the global batch (per tile: import of the resident inputs, then the level kernels -- the same for every N and every tile
+count), witness maps left in HBM.
 Other workloads (parity-test configs, measured for DESIGN.md; 2^16 instances per GPU unless --total-log2 is given):
     --workload hash            config 3: SHA256 + Keccak256 + RANGE circuit
     --workload grumpkin        config 4: Pedersen + FixedBaseScalarMul + SchnorrVerify circuit
@@ -15,8 +16,9 @@ Other workloads (parity-test configs, measured for DESIGN.md; 2^16 instances per
     --workload mixed           the config-5 opcode mix at --gates opcodes (every kernel class in one circuit)
     --workload config5         config 5 at circuit size: the 10^6-opcode mixed circuit (--gates), tiles of --tile-log2 (default 2^12) instances,
                                --total-log2 (default 2^14) per GPU; a step = solve + per-instance map digest of every tile (what config 5 keeps)
-The default run (N = 1) also appends `other_workloads`: three-step legs of arith_pedersen (the north-star target shape), hash and grumpkin,
-each parity-checked against the oracle and carrying its own roofline / alu_roofline (--no-legs skips them).
+The default run (N = 1) also appends `other_workloads`: legs of arith_pedersen (the north-star target shape, at the metric's batch: 2^20 in
+tiles), hash, grumpkin and ecdsa, each parity-checked against the oracle and carrying its own roofline / alu_roofline (--no-legs skips
+them), then the same legs once more as the compact `legs`, and `summary` as the last key of the line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without a launcher: spawns the N ranks itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -24,9 +26,10 @@ each parity-checked against the oracle and carrying its own roofline / alu_roofl
 One process per GPU. Rank 0 prints ONE JSON line: whole-job witnesses/s (max-over-ranks time), per-rank rates, the digest of
 digests over the per-instance witness-map digests of ALL ranks (identical for every N and tile size: the ranks provably solved
 disjoint shards of one batch), `roofline` of the dominant kernel (algorithmic bytes of its launches / their HIP-event durations,
-events on the batch's own streams), `end_to_end` (H2D of the inputs + solve + D2H of the return witnesses), and `cpu_baseline`
-(the CPU oracle -- a port of the reference's in-order solver -- timed on a bounded sample of the same workload, which is also the
-bit-exact parity check of the run; variants of BASELINE.md section 2).
+events on the batch's own streams; HBM traffic from in-run rocprofv3 PMC passes on rank 0's device), `end_to_end` (H2D of the inputs +
+solve + D2H of the return witnesses), and `cpu_baseline` (the CPU oracle -- a port of the reference's in-order solver -- timed on every
+host core on a bounded sample of the same workload, which is also the bit-exact parity check of the run; variants of BASELINE.md
+section 2). Rank 0 computes `cpu_baseline`, `parity` and `roofline.traffic` for EVERY world size, after the timed region and the last barrier.
 """
 import argparse
 import json
@@ -255,13 +258,32 @@ class ClockSampler:
         return s[len(s) // 2] if s else None
 
 
+def timed_one_core(ob, oc, ids, values, row, n0, n_max, mode, target_s=1.2):
+    """median of three one-core runs of at least about a second each (the sample grows until one run takes target_s): (instances, seconds)"""
+    n = max(1, min(n0, n_max))
+    while True:
+        c = time.perf_counter()
+        ob.solve_batch(oc, ids, values[: n * row], n, want_witness=False, n_threads=1, mode=mode)
+        dt = time.perf_counter() - c
+        if dt >= 0.8 * target_s or n >= n_max:
+            break
+        n = min(n_max, max(n + 1, int(n * target_s / max(dt, 1e-4)) + 1))
+    runs = [dt]
+    for rep in range(2):
+        c = time.perf_counter()
+        ob.solve_batch(oc, ids, values[: n * row], n, want_witness=False, n_threads=1, mode=mode)
+        runs.append(time.perf_counter() - c)
+    return n, sorted(runs)[1]
+
+
 def cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_digests):
     """The CPU oracle (a port of the reference's in-order solver, oracle/) on a bounded sample of tile 0: the parity check of the run
-    (results, assigned sets, every witness, digests) and the cpu_baseline of the line -- median of three timed runs per variant."""
+    (results, assigned sets, every witness, digests) and the cpu_baseline of the line -- median of three timed runs per variant.
+    Rank 0 runs it for every world size (after the timed region and the last barrier: the other ranks are done), on ALL host cores."""
     import numpy as np
     from oracle import binding as ob
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = cores
     per = {"arith": 96, "hash": 1024, "grumpkin": 256, "ecdsa": 64, "arith_pedersen": 48, "mixed": 32, "config5": 1}[args.workload]  # about a second of all host cores
     sample = args.cpu_sample or min(tile, max(threads if args.workload == "config5" else 64, per * threads))
     sh.load_tile(0)
@@ -288,26 +310,15 @@ def cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_
         if n_dig:  # the digests that feed the digest of digests, against hashlib over the oracle's maps
             ok = ok and all(bytes(inst_digests[j]) == ob.witness_map_digest(oasg[j], ovals[j]) for j in range(n_dig))
     parity = {"checked_instances": sample, "bit_exact": bool(ok), "digests_checked": n_dig}
-    cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "kind": "port", "variant": "cpu_ref_dense_mt",
+    cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "host_cores": cores, "kind": "port", "variant": "cpu_ref_dense_mt",
            "runs_s": [round(x, 3) for x in runs],
            "sample": f"{sample} instances of the same circuit, oracle/ (gcc -O3 -march=native; dense witness vector, constant divisors inverted once), "
-                     f"{threads} threads, median of {len(runs)} runs: {cpu_s:.2f} s"}
-    if args.workload != "config5":  # the two single-core variants, about a second each, median of three
-        one = max(1, min(sample, int(round(1.0 * sample / (cpu_s * threads)))))
-        t1 = []
-        for rep in range(3):
-            c1 = time.perf_counter()
-            ob.solve_batch(oc, ids, values[: one * row], one, want_witness=False, n_threads=1, mode=ob.MODE_CACHE_INV)
-            t1.append(time.perf_counter() - c1)
-        one_s = sorted(t1)[1]
+                     f"{threads} threads = every host core (os.cpu_count() = {cores}), median of {len(runs)} runs: {cpu_s:.2f} s"}
+    if args.workload != "config5":  # the two single-core variants, at least about a second per run, median of three
+        n_max = min(tile, len(values) // row)
+        one, one_s = timed_one_core(ob, oc, ids, values, row, int(round(1.2 * sample / (cpu_s * threads))), n_max, ob.MODE_CACHE_INV)
         cpu["cpu_ref_dense"] = {"value": one / one_s, "unit": "witnesses/s", "cores": 1, "sample": f"{one} instances, median of 3 runs: {one_s:.2f} s"}
-        few = max(1, one // 6)
-        t2 = []
-        for rep in range(3):
-            c2 = time.perf_counter()
-            ob.solve_batch(oc, ids, values[: few * row], few, want_witness=False, n_threads=1, mode=ob.MODE_SPARSE_MAP)
-            t2.append(time.perf_counter() - c2)
-        few_s = sorted(t2)[1]
+        few, few_s = timed_one_core(ob, oc, ids, values, row, max(1, one // 6), n_max, ob.MODE_SPARSE_MAP)
         cpu["cpu_ref_faithful"] = {"value": few / few_s, "unit": "witnesses/s", "cores": 1,
                                    "sample": f"{few} instances, median of 3 runs: {few_s:.2f} s; BTreeMap-shaped witness map, one field inversion per solved witness (the reference's data structures)"}
     return cpu, parity
@@ -315,7 +326,8 @@ def cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_
 
 def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
     """`roofline` (+ `alu_roofline`) of the dominant kernel of the last profiled tile: algorithmic bytes of its launches / their HIP-event
-    durations against the HBM peak; HBM traffic, VALU issue fraction and the ALU roofline from in-run PMC passes (N = 1 only)."""
+    durations against the HBM peak; HBM traffic, VALU issue fraction and the ALU roofline from in-run PMC passes (rank 0 on its own device,
+    for every world size: the passes profile a one-tile run of the size this rank's tiles have)."""
     import acvm_amd
     arith_ms, dyn_ms, cls_ms = st["arith_kernel_ms"], st["dyn_kernel_ms"], list(st["class_kernel_ms"])
     cand = {"arith_level_kernel": (arith_ms, st["arith_algorithmic_bytes_per_instance"], st["n_arith_launches"]),
@@ -339,7 +351,7 @@ def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
         roof["kernel_avg_launch_ms"] = k_ms / k_launches
         roof["algorithmic_bytes_per_launch"] = k_bytes * tile / k_launches
     alu = None
-    if world == 1 and pmc:
+    if pmc:
         tr = measure_traffic(args, KERNEL_SYMBOL.get(dominant, [dominant]))
         if tr:
             roof["traffic"] = tr["bytes_per_launch"]
@@ -363,41 +375,57 @@ def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
     return roof, alu
 
 
-def run_leg(name, steps=3, warmup=2, pmc=True):
-    """one of the other workloads as a short leg of the default run (N = 1): 2^16 instances, one tile, parity-checked"""
+def run_leg(name, total_log2=16, tile_log2=16, steps=3, warmup=2, pmc=True):
+    """one of the other workloads as a short leg of the default run (N = 1), parity-checked. A step is what it is for the metric's workload:
+    per tile, import of the resident inputs + solve (arith_pedersen, the north-star target shape, runs at the metric's batch: 2^20 in tiles)"""
     import acvm_amd
     from acvm_amd import tiling
-    a = argparse.Namespace(workload=name, gates=10000, pedersen=8, cpu_sample={"hash": 4096, "grumpkin": 512, "ecdsa": 512, "arith_pedersen": 256}.get(name, 0), eff_tile_log2=16)
-    n = 1 << 16
+    a = argparse.Namespace(workload=name, gates=10000, pedersen=8, cpu_sample={"hash": 4096, "grumpkin": 512, "ecdsa": 512, "arith_pedersen": 256}.get(name, 0),
+                           eff_tile_log2=tile_log2)
+    n, tile = 1 << total_log2, 1 << tile_log2
     circ, ids, values, wname = make_workload(a, 0, n)
     data = circ.to_bytes()
     gc = acvm_amd.Circuit(data)
-    sh = tiling.ResidentShard(gc, ids, values, n, n)
+    sh = tiling.ResidentShard(gc, ids, values, n, tile)
     batch = sh.batch
+    n_tiles = len(sh.starts)
     batch.set_profiling(True)
-    sh.load_tile(0)
     for _ in range(warmup):
-        batch.reset()
-        batch.solve()
+        sh.solve_pass()
     batch.set_profiling(False)
     acvm_amd.synchronize()
+    solve_ms = 0.0
     t0 = time.perf_counter()
     for i in range(steps):
-        if i == steps - 1:
-            batch.set_profiling(True)
-        batch.reset()
-        batch.solve()
+        for k in range(n_tiles):
+            if i == steps - 1 and k == n_tiles - 1:
+                batch.set_profiling(True)
+            sh.load_tile(k)
+            batch.solve()
+            if i == steps - 1:
+                solve_ms += batch.stats()["solve_device_ms"]
     acvm_amd.synchronize()
     elapsed = time.perf_counter() - t0
     st = batch.stats()
     batch.set_profiling(False)
-    roof, alu = roofline_block(a, st, n, 1, None, pmc=pmc)
-    cpu, parity = cpu_baseline_and_parity(a, data, ids, values, batch, sh, n, len(ids) * 32, None)
+    roof, alu = roofline_block(a, st, tile, 1, None, pmc=pmc)
+    cpu, parity = cpu_baseline_and_parity(a, data, ids, values, batch, sh, tile, len(ids) * 32, None)
     sh.free()
-    out = {"workload": wname, "value": n * steps / elapsed, "unit": "witnesses/s", "instances": n, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
-           "device_ms_last_step": st["solve_device_ms"], "levels": st["n_levels"], "launches": st["n_kernel_launches"], "roofline": roof, "alu_roofline": alu,
-           "cpu_baseline": {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}, "parity": parity}
+    out = {"workload": wname, "value": n * steps / elapsed, "unit": "witnesses/s", "instances": n, "tile_instances": tile, "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "step": "per tile: import of the resident inputs + solve",
+           "solve_device_ms_last_step": solve_ms, "value_solve_only": n / (solve_ms / 1e3) if solve_ms > 0 else None,
+           "levels": st["n_levels"], "launches": st["n_kernel_launches"], "roofline": roof, "alu_roofline": alu,
+           "cpu_baseline": {k: cpu[k] for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}, "parity": parity}
     return out
+
+
+def leg_summary(leg):
+    """[witnesses/s, ms per step, HBM fraction of the dominant kernel, ALU fraction or None, parity ok] of a leg, for the tail of the line"""
+    if not leg or "error" in leg:
+        return None
+    r, a = leg.get("roofline") or {}, leg.get("alu_roofline") or {}
+    rnd = lambda x, k: None if x is None else round(x, k)
+    return [round(leg["value"]), round(leg["ms_per_step"], 3), rnd(r.get("frac"), 4), rnd(a.get("frac"), 4), bool((leg.get("parity") or {}).get("bit_exact"))]
 
 
 def end_to_end_node(gc, ids, values, total, tile, n_dev_rank):
@@ -496,15 +524,14 @@ def main():
     if config5 and args.warmup:
         batch.digest(0, tile)  # (the digest's coefficient tables are built at its first use: not inside the timed region)
     batch.set_profiling(False)
-    if n_tiles == 1:
-        sh.load_tile(0)
     barrier()
     dev_ms = 0.0
     n_failed = 0
     digest_ms = 0.0
     # (the sampler forks rocm-smi every 50 ms: harmless beside the 190 ms steps of the gate kernel, whose VALU issue fraction needs the clock,
-    # but it would disturb the sub-millisecond steps of the hash / Grumpkin workloads: those run without it)
-    with ClockSampler(acvm_amd.current_device(), enabled=args.workload in ("arith", "config5")) as clock:
+    # but it would disturb the sub-millisecond steps of the hash / Grumpkin workloads, and N ranks of it would disturb each other: it runs
+    # where its value is used -- rank 0 of a one-rank run of the gate workloads)
+    with ClockSampler(acvm_amd.current_device(), enabled=rank == 0 and world == 1 and args.workload in ("arith", "config5")) as clock:
         t0 = time.perf_counter()
         for i in range(args.steps):
             for k in range(n_tiles):
@@ -512,10 +539,9 @@ def main():
                 last = i == args.steps - 1 and k == n_tiles - 1
                 if last:
                     batch.set_profiling(True)
-                if n_tiles > 1:
-                    sh.load_tile(k)  # ACVM::new of the tile: import of its resident inputs into the reused table
-                else:
-                    batch.reset()    # one tile holds the whole shard: its initial witnesses are in the table already
+                # the same step for every N and every tile count: ACVM::new of the tile (import of its resident inputs into the reused table),
+                # then ACVM::solve
+                sh.load_tile(k)
                 n_failed += batch.solve()
                 if i == args.steps - 1:
                     dev_ms += batch.stats()["solve_device_ms"]
@@ -559,69 +585,89 @@ def main():
         mine = end_to_end_node(gc, ids, values, n_rank, tile, n_dev)
         e2e_s = shard.max_over_ranks(mine["total_ms"] / 1e3, dist)
         e2e = dict(mine, value=total / e2e_s, total_ms=e2e_s * 1e3)
-        sh = tiling.ResidentShard(gc, ids, values, n_rank, tile)
-        batch = sh.batch
 
-    # ---- CPU baseline + parity on a bounded sample of tile 0 (rank 0 only)
+    # ---- everything below is rank 0's: the other ranks have delivered what the line needs from them (times, rates, chunk digests, their
+    # end-to-end time) and leave; rank 0 computes the CPU baseline + parity and the PMC passes for EVERY world size, on its own device
+    barrier()
+    if rank != 0:
+        if sh is not None:
+            sh.free()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     cpu = parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is an N = 1 figure (rank 0 would keep the other ranks waiting)
+    if not args.no_cpu_baseline:
+        if sh is None:
+            sh = tiling.ResidentShard(gc, ids, values, n_rank, tile)
+            batch = sh.batch
         cpu, parity = cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_digests)
         if not parity["bit_exact"]:
             print(json.dumps({"error": "parity check failed; the measurement is void", "parity": parity}), flush=True)
             raise SystemExit(2)
-    sh.free()
+    if sh is not None:
+        sh.free()
 
-    if rank == 0:
-        value = total * args.steps / elapsed
-        roof, alu = roofline_block(args, st, tile, world, clock.median())
-        if world == 1 and not os.environ.get("ACVM_BENCH_NO_PMC"):
+    value = total * args.steps / elapsed
+    roof, alu = roofline_block(args, st, tile, world, clock.median())
+    if not os.environ.get("ACVM_BENCH_NO_PMC"):
+        try:
+            roof["peak_measured_copy"] = acvm_amd.stream_rate(4 << 30)
+            roof["peak_measured_copy_note"] = "GB/s moved by a two-rows-in, one-row-out stream (the gate kernel's access shape, 4 GiB per row) on this device in this run: what streaming code reaches of the 8 TB/s spec peak; `achieved` counts ALGORITHMIC bytes, the kernel's real traffic is `traffic`"
+            if roof.get("traffic") and roof.get("kernel_avg_launch_ms"):
+                roof["traffic_frac_of_measured_copy"] = roof["traffic"] / (roof["kernel_avg_launch_ms"] / 1e3) / 1e9 / roof["peak_measured_copy"]
+        except acvm_amd.AcvmError:
+            pass
+    legs = None
+    if world == 1 and args.workload == "arith" and not args.no_legs and not args.no_cpu_baseline:
+        legs = {}
+        # arith_pedersen is north_star's target shape: it runs at the metric's batch (2^20 in tiles of 2^16: its Pedersen launches are sized for that tile)
+        for name, kw in (("arith_pedersen", dict(total_log2=20, tile_log2=16, steps=5, warmup=1)), ("hash", {}), ("grumpkin", {}), ("ecdsa", {})):
             try:
-                roof["peak_measured_copy"] = acvm_amd.stream_rate(4 << 30)
-                roof["peak_measured_copy_note"] = "GB/s moved by a two-rows-in, one-row-out stream (the gate kernel's access shape, 4 GiB per row) on this device in this run: what streaming code reaches of the 8 TB/s spec peak; `achieved` counts ALGORITHMIC bytes, the kernel's real traffic is `traffic`"
-                if roof.get("traffic") and roof.get("kernel_avg_launch_ms"):
-                    roof["traffic_frac_of_measured_copy"] = roof["traffic"] / (roof["kernel_avg_launch_ms"] / 1e3) / 1e9 / roof["peak_measured_copy"]
-            except acvm_amd.AcvmError:
-                pass
-        legs = None
-        if world == 1 and args.workload == "arith" and not args.no_legs and not args.no_cpu_baseline:
-            legs = {}
-            for name in ("arith_pedersen", "hash", "grumpkin", "ecdsa"):
-                try:
-                    legs[name] = run_leg(name)
-                except (acvm_amd.AcvmError, OSError, ValueError) as e:  # a leg must not void the metric's line
-                    legs[name] = {"error": str(e)[:300]}
-        line = {
-            "metric": "witnesses solved/sec (whole node)",
-            "value": value,
-            "unit": "witnesses/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
-            "vs_baseline": None,
-            "dtype": "u256 (8x u32 limbs, BN254-Fr Montgomery)",
-            "data": "synthetic",
-            "config": {"workload": f"{workload_name}, batch 2^{total.bit_length() - 1} witnesses over {world} GPU(s)", "opcodes": st["n_opcodes"],
-                       "global_batch": total, "instances_per_gpu": n_rank, "tile_instances": tile, "tiles_per_gpu_per_step": n_tiles, "levels": st["n_levels"],
-                       "not_solved_rank0_all_steps": n_failed, "slow_path_instances_last_tile": st["n_slow_instances"],
-                       "algorithmic_bytes_per_witness": st["algorithmic_bytes_per_instance"], "brillig_opcodes_inlined": st["n_brillig_inlined"],
-                       "device_ms_per_step_rank0": dev_ms, "inputs_resident_setup_s_rank0": round(h2d_resident_s, 3),
-                       "parallelism": f"instances sharded x{world}, no collectives"},
-            "per_rank_witnesses_per_s": rank_rates,
-            "digest_of_digests": dod,
-            "roofline": roof,
-            "alu_roofline": alu,
-            "end_to_end": e2e,
-            "cpu_baseline": cpu,
-            "parity": parity,
-        }
-        if config5:
-            line["config"]["digest_ms_per_step_rank0"] = digest_ms / args.steps
-        if legs is not None:
-            line["other_workloads"] = legs
-        print(json.dumps(line), flush=True)
+                legs[name] = run_leg(name, **kw)
+            except (acvm_amd.AcvmError, OSError, ValueError) as e:  # a leg must not void the metric's line
+                legs[name] = {"error": str(e)[:300]}
+    line = {
+        "metric": "witnesses solved/sec (whole node)",
+        "value": value,
+        "unit": "witnesses/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        "dtype": "u256 (8x u32 limbs, BN254-Fr Montgomery)",
+        "data": "synthetic",
+        "config": {"workload": f"{workload_name}, batch 2^{total.bit_length() - 1} witnesses over {world} GPU(s)", "opcodes": st["n_opcodes"],
+                   "global_batch": total, "instances_per_gpu": n_rank, "tile_instances": tile, "tiles_per_gpu_per_step": n_tiles, "levels": st["n_levels"],
+                   "step": "per tile: import of the resident inputs (ACVM::new) + solve, the same for every N",
+                   "not_solved_rank0_all_steps": n_failed, "slow_path_instances_last_tile": st["n_slow_instances"],
+                   "algorithmic_bytes_per_witness": st["algorithmic_bytes_per_instance"], "brillig_opcodes_inlined": st["n_brillig_inlined"],
+                   "device_ms_per_step_rank0": dev_ms, "inputs_resident_setup_s_rank0": round(h2d_resident_s, 3), "host_cores": os.cpu_count(),
+                   "parallelism": f"instances sharded x{world}, no collectives"},
+        "per_rank_witnesses_per_s": rank_rates,
+        "digest_of_digests": dod,
+        "roofline": roof,
+        "alu_roofline": alu,
+        "end_to_end": e2e,
+        "cpu_baseline": cpu,
+        "parity": parity,
+    }
+    if config5:
+        line["config"]["digest_ms_per_step_rank0"] = digest_ms / args.steps
+    if legs is not None:
+        line["other_workloads"] = legs
+        # the same legs once more, compact, at the END of the line (a reader that keeps only the tail still sees them):
+        # [witnesses/s, ms per step, HBM fraction of the dominant kernel, ALU fraction, parity ok]
+        line["legs"] = {k: leg_summary(v) for k, v in legs.items()}
+    rnd = lambda x, k: None if x is None else round(x, k)
+    line["summary"] = {"value": round(value), "n_gpus": world, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "roofline_frac": rnd(roof.get("frac"), 4),
+                       "kernel_avg_launch_ms": rnd(roof.get("kernel_avg_launch_ms"), 5), "traffic_bytes_per_launch": roof.get("traffic"),
+                       "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"), "valu_issue_frac": rnd(roof.get("valu_issue_frac"), 4),
+                       "end_to_end": None if not e2e else round(e2e["value"]), "cpu_baseline": None if not cpu else [round(cpu["value"], 1), cpu["cores"]],
+                       "parity_ok": None if not parity else parity["bit_exact"], "digest_of_digests": None if not dod else dod["value"][:16]}
+    print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

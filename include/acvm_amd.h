@@ -21,7 +21,8 @@
  *
  * Threading (reference: `&mut self`, backend not Sync): one batch handle = one host thread + one HIP
  * device + one stream set. Handles are independent, also on one device; the only process-wide state is read-mostly
- * (the tuning table, the per-device lookup tables, built once under a lock). acvm_node_* drives one handle per device.
+ * (the tuning table; the per-device lookup tables, built once under a per-device lock and reference-counted by the handles).
+ * acvm_node_* drives one handle per device.
  * Errors: functions return 0 on success or a negative ACVM_E_* code; acvm_last_error() gives text.
  * The library requires a gfx950 device for every compute entry point and fails loudly without one;
  * there is no CPU fallback.
@@ -151,6 +152,17 @@ int acvm_set_device(int device);
 int acvm_device_synchronize(void);
 /* name of the current device's gcnArch ("gfx950...") into out */
 int acvm_device_arch(char *out, size_t out_len);
+/*
+ * The per-device lookup tables (Grumpkin: 3 MB of fixed-base and Pedersen slice tables, 268 MB of 16-bit windows, the 503 MB pair table
+ * or the 6.4 GB window table of the level Pedersen kernel; ECDSA: 2 x 64 MiB of generator windows) are built on the device at the first
+ * handle whose circuit needs them -- under a lock of that device only, on a stream of their own -- and shared by every later handle of the
+ * device. They stay until this call: frees the tables of `device` and returns the bytes given back, or ACVM_E_STATE while a handle of
+ * that device still uses them (free the handles first). The next handle that needs a table rebuilds it (0.3 s for the largest).
+ * acvm_tuning_set("tables_keep", 0) makes the destruction of a device's last handle release them without this call.
+ * The reference keeps its counterpart -- the wasm instance with barretenberg's tables -- for the lifetime of the solver object
+ * (barretenberg_blackbox_solver/src/wasm/mod.rs:59-82).
+ */
+long long acvm_device_release_tables(int device);
 
 /*
  * Planner / scheduler modes and the device's Brillig VM limits, process-wide (csrc/tuning.hpp lists every key with its default;

@@ -25,7 +25,8 @@ def plain_batch(data, ids, values, B, keep):
     return res, kept, asg, dig
 
 
-@pytest.mark.parametrize("devices,tile,B", [([0], 256, 1000), ([0, 0], 192, 1000), ([0, 0], 64, 130), ([0, 0, 0], 512, 700), ([0], 512, 3)])
+@pytest.mark.parametrize("devices,tile,B", [([0], 256, 1000), ([0, 0], 192, 1000), ([0, 0], 64, 130), ([0, 0, 0], 512, 700), ([0], 512, 3),
+                                            ([0] * 8, 128, 2500)])  # (eight lanes: the shape acvm_node_new has on an 8-GPU node, rehearsed on one device)
 def test_node_equals_one_batch_and_oracle(oracle, devices, tile, B):
     """mixed circuit with edge-case instances: the flagged instances of every tile take the asynchronous exact path; partial last tiles"""
     import acvm_amd
@@ -86,6 +87,38 @@ def test_node_foreign_calls_stay_synchronous(oracle):
     not_solved, res, kept, asg, dig = node.solve(values_from_rows([[5], [6], [7]]), 3)
     assert not_solved == 3 and all(r.status == acvm_amd.STATUS_REQUIRES_FOREIGN_CALL for r in res) and not any(node.stats()["async_exact"])
     node.free()
+
+
+def test_node_lookup_tables_are_shared_refcounted_and_releasable():
+    """eight handles of a circuit with Pedersen opcodes on one device build the device's lookup tables once (under the device's lock, on a build
+    stream), hold them while they live, and acvm_device_release_tables gives the memory back afterwards -- and only afterwards"""
+    import gc
+    import acvm_amd
+    from acvm_amd import synth
+    gc.collect()  # (handles of earlier tests that are only waiting for the collector hold the tables too)
+    circ, ids = synth.mixed_circuit(300, seed=0x40DE0011)
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    values = synth.witness_batch(600, seed=0x40DE0011, edge_cases=True)
+    node = acvm_amd.Node(gc, ids, keep=gc.witness_set("return_values"), devices=[0] * 8, tile=64)
+    first = node.solve(values, 600)
+    with pytest.raises(acvm_amd.AcvmError):
+        acvm_amd.release_tables(0)  # in use
+    node.free()
+    freed = acvm_amd.release_tables(0)
+    assert freed > (1 << 28)  # the 16-bit windows alone are 268 MB
+    assert acvm_amd.release_tables(0) == 0  # nothing left
+    node = acvm_amd.Node(gc, ids, keep=gc.witness_set("return_values"), devices=[0, 0], tile=128)  # rebuilt on demand, same results
+    again = node.solve(values, 600)
+    assert [r.as_tuple() for r in again[1]] == [r.as_tuple() for r in first[1]] and np.array_equal(again[4], first[4])
+    node.free()
+    acvm_amd.tuning_set("tables_keep", 0)  # the last handle of the device frees the tables itself
+    try:
+        node = acvm_amd.Node(gc, ids, keep=gc.witness_set("return_values"), devices=[0], tile=128)
+        node.solve(values, 600)
+        node.free()
+        assert acvm_amd.release_tables(0) == 0
+    finally:
+        acvm_amd.tuning_set("tables_keep", 1)
 
 
 def test_node_auto_tile_and_empty_batch():

@@ -17,4 +17,4 @@ for line in sys.stdin:
           round(r["kernel_ms_per_tile"], 2), "ms/tile", {k: round(v, 2) for k, v in r["other_kernels_ms_per_tile"].items()},
           "| traffic", None if r.get("traffic") is None else round(r["traffic"] / 1e9, 3), "GB | alu", None if not a.get("frac") else round(a["frac"], 3),
           "| e2e", None if not e else round(e["value"]), "| cpu", None if not c else round(c["value"], 1),
-          "| dod", (d.get("digest_of_digests") or {}).get("value", "")[:12])
+          "| dod", (d.get("digest_of_digests") or {}).get("value", "")[:12], "| legs", d.get("legs"))

@@ -22,116 +22,221 @@ void launch_hash_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const D
 }
 
 // Level kernel of the records flagged HASH_COOP_FLAG (byte messages of SHA256 / Blake2s / Keccak256; batch.cpp launches the two kinds of a
-// level separately). At the batch sizes of one tile a SIMD holds ONE wave of a lane-per-instance kernel, and a byte message costs that lane
-// one table row and one reduction per BYTE before the first compression: latency-bound on those rows (VALU 29 % busy). Here a block of four
-// waves serves 64 instances of one record: wave q fetches and reduces the bytes q, q + 4, q + 8, ... of every instance (four rows in flight per
-// lane, four times the waves in flight per SIMD) into the LDS message, wave 0 hashes, and the 32 digest bytes go back through LDS so that
-// wave q stores outputs 8q .. 8q + 7 (WAVES = 4). The hash bodies are inlined here under the kernel's register budget (four waves per SIMD = 128 VGPRs).
+// level separately). A block of WAVES waves serves 64 instances of one record -- and of the records chained behind it (plan.cpp "hash
+// chains": the hash of another hash's digest runs in its predecessor's block and takes the digest bytes from LDS).
+//
+// What bounds the launch (round 4, tools/t_hash_sweep.py): at 2^16 instances config 3 is 1 024 blocks for 1 024 SIMD slots, all resident at
+// once, so the whole chip moves through read / hash / write in lock-step -- HBM idles while every block hashes, the ALUs idle while every
+// block waits for its rows: 87 us = 59 us of traffic at the streaming rate + 19 us of dependent hash chain + the ramp. A launch that holds
+// more items than slots overlaps by itself; this one has to overlap INSIDE the block:
+//   * wave 0 hashes; while it does, waves 1..3 (a) store the outputs of the PREVIOUS record of the chain from its digest in LDS and (b)
+//     fetch the inputs of the NEXT record that are not digest bytes (the planner admits a record to a chain only if those were known when
+//     the head was launched) into the second message buffer. Config 3: the 32 extra rows of the Keccak travel under the SHA-256, the 32
+//     output rows of the SHA-256 under the Keccak; only the head's 64 input rows and the tail's 32 output rows are moved by all four waves
+//     with nothing to hide behind.
+//   * the byte <-> Montgomery-form tables (8 KiB + 1 KiB) live in LDS: a fetched row is recognised as a byte by one table byte and a 32-byte
+//     compare (28 instructions per row instead of the 80 of the arithmetic form, which round 2 had taken because a wave-wide gather from
+//     the 8 KiB table in memory is served by the CU's one vector L1 at a line per cycle), an output byte is converted by a 32-byte LDS read.
+//   * the hash bodies name gfx950's three-input bit operation and funnel shift (hash_device.hpp): SHA-256 24 instead of 29 instructions per
+//     round, Keccak-f 180 instead of 288.
 // the RANGE opcode fused on input i of the record fails: its opcode index, else 0xFFFFFFFF (is_byte: the value is the byte `low`)
 __device__ __forceinline__ uint32_t range_check(const uint32_t *__restrict__ ranges, uint32_t i, bool is_byte, uint32_t low) {
     const uint32_t op = ranges[2u * i], bits = ranges[2u * i + 1u];
     if (op == 0xFFFFFFFFu) return op;
     return is_byte && (low >> bits) == 0u ? 0xFFFFFFFFu : op;
 }
-// WAVES = 1 is the same kernel for launches that fill the chip anyhow (many records per level): one wave per 64 instances does every
-// phase, still with the message in LDS and the lean register budget (the lane-per-instance kernel with the message in device scratch
-// and 184 VGPRs measured 6.0 ms for the hash class of the config-5 mix at 2^16 instances).
-// Chains (plan.cpp "hash chains"): a record whose function word carries HASH_CHAIN_FLAG is followed, in the same block, by the byte-message hash that
-// consumes its digest (a hash of a hash, a Merkle path): the word behind the record is the offset of a link [offset of the next record, source of
-// each of its inputs: index of the previous digest's byte or NONE]; the next record takes those bytes from LDS instead of reading back the rows the
-// block has just written, and the launch of its own (and the lock-step read / hash / write phases of that launch) is gone.
+// the byte tables of ops_common.hpp in LDS: mont[2 d], mont[2 d + 1] = the stored form of byte d; key = BYTE_KEY as words
+struct CoopTables {
+    const uint4 *mont;
+    const uint32_t *key;
+};
+__device__ __forceinline__ uint32_t coop_low_limb(const Fr &a, const CoopTables &T, bool &is_byte) {
+    const uint32_t k = a.v[0] & 1023u;
+    uint32_t d = (T.key[k >> 2] >> (8u * (k & 3u))) & 0xffu;  // the only byte this value can be (ops_common.hpp fr_is_byte)
+    const uint4 lo = T.mont[2u * d], hi = T.mont[2u * d + 1u];
+    const uint32_t diff = ((a.v[0] ^ lo.x) | (a.v[1] ^ lo.y) | (a.v[2] ^ lo.z) | (a.v[3] ^ lo.w)) | ((a.v[4] ^ hi.x) | (a.v[5] ^ hi.y) | (a.v[6] ^ hi.z) | (a.v[7] ^ hi.w));
+    is_byte = diff == 0u;
+    if (!is_byte) d = fr29_redc_low(fr29_from(a));
+    return d;
+}
+__device__ __forceinline__ Fr coop_from_byte(uint32_t d, const CoopTables &T) {
+    const uint4 lo = T.mont[2u * d], hi = T.mont[2u * d + 1u];
+    return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+}
+// Rows of a record into its LDS message, four in flight per lane: the inputs list[k] (list == nullptr: input k itself) for k = w, w + nw, ... < count
+// (w, nw, count, the list and the record are wave-uniform). Fused RANGE checks ride along.
+__device__ __forceinline__ void coop_fetch_rows(const FastPolicy &p, const uint32_t *__restrict__ ins, const uint32_t *__restrict__ ranges,
+                                                const uint32_t *__restrict__ list, uint32_t count, uint32_t w, uint32_t nw, uint8_t *bytes, uint32_t lane,
+                                                const CoopTables &T, uint32_t &range_bad) {
+    for (uint32_t k = w; k < count; k += 4u * nw) {
+        const uint32_t k1 = k + nw, k2 = k + 2u * nw, k3 = k + 3u * nw;
+        const uint32_t i0 = list ? list[k] : k, i1 = k1 < count ? (list ? list[k1] : k1) : 0u, i2 = k2 < count ? (list ? list[k2] : k2) : 0u,
+                       i3 = k3 < count ? (list ? list[k3] : k3) : 0u;
+        Fr a0 = p.load(ins[2u * i0]), a1 = a0, a2 = a0, a3 = a0;
+        if (k1 < count) a1 = p.load(ins[2u * i1]);
+        if (k2 < count) a2 = p.load(ins[2u * i2]);
+        if (k3 < count) a3 = p.load(ins[2u * i3]);
+        bool b0, b1 = true, b2 = true, b3 = true;  // the value is a byte (then l is that byte)
+        const uint32_t l0 = coop_low_limb(a0, T, b0);
+        bytes[4u * ((i0 >> 2) * 64u + lane) + (i0 & 3u)] = (uint8_t)l0;
+        if (ranges) range_bad = min(range_bad, range_check(ranges, i0, b0, l0));
+        if (k1 < count) {
+            const uint32_t l1 = coop_low_limb(a1, T, b1);
+            bytes[4u * ((i1 >> 2) * 64u + lane) + (i1 & 3u)] = (uint8_t)l1;
+            if (ranges) range_bad = min(range_bad, range_check(ranges, i1, b1, l1));
+        }
+        if (k2 < count) {
+            const uint32_t l2 = coop_low_limb(a2, T, b2);
+            bytes[4u * ((i2 >> 2) * 64u + lane) + (i2 & 3u)] = (uint8_t)l2;
+            if (ranges) range_bad = min(range_bad, range_check(ranges, i2, b2, l2));
+        }
+        if (k3 < count) {
+            const uint32_t l3 = coop_low_limb(a3, T, b3);
+            bytes[4u * ((i3 >> 2) * 64u + lane) + (i3 & 3u)] = (uint8_t)l3;
+            if (ranges) range_bad = min(range_bad, range_check(ranges, i3, b3, l3));
+        }
+    }
+}
+// the inputs of a chained record that are bytes of its predecessor's digest (src[i] != NONE), i = w, w + nw, ...: LDS to LDS
+__device__ __forceinline__ void coop_copy_chained(const uint32_t *__restrict__ src, const uint32_t *__restrict__ ranges, uint32_t n_in, uint32_t w, uint32_t nw,
+                                                  const uint32_t (*dig)[64], uint8_t *bytes, uint32_t lane, uint32_t &range_bad) {
+    for (uint32_t i = w; i < n_in; i += nw) {
+        const uint32_t from = src[i];
+        if (from == 0xFFFFFFFFu) continue;
+        const uint32_t byte = (dig[from >> 2][lane] >> (8u * (from & 3u))) & 0xffu;
+        bytes[4u * ((i >> 2) * 64u + lane) + (i & 3u)] = (uint8_t)byte;
+        if (ranges) range_bad = min(range_bad, range_check(ranges, i, true, byte));
+    }
+}
+// outputs i = w, w + nw, ... < 32 of a record from its digest in LDS; false on a conflict with an assigned output (hash.rs:92-103 stops at
+// the first one; the flagged instance re-runs exactly)
+__device__ __forceinline__ bool coop_store_outputs(const FastPolicy &p, const uint32_t *__restrict__ outs, const uint32_t (*dig)[64], uint32_t w, uint32_t nw,
+                                                   uint32_t lane, const CoopTables &T) {
+    bool ok = true;
+    for (uint32_t i = w; i < 32u; i += nw) {
+        const uint32_t byte = (dig[i >> 2][lane] >> (8u * (i & 3u))) & 0xffu;
+        ok = p.insert(outs[2u * i], coop_from_byte(byte, T), outs[2u * i + 1u]) && ok;
+    }
+    return ok;
+}
+// WAVES = 4: one item -- 64 instances of a record and of its chain -- per block, pipelined as above. WAVES = 1, for launches that fill the
+// chip anyhow (many records per level): four independent items per block, one per wave, which share only the tables; a wave does every
+// phase in turn and talks to no other wave (a lane reads back only the bytes and words it wrote itself).
+// LDS of an item: n_buf message buffers of buf_words x 64 words (a second one where the next record's rows are fetched while this one is
+// hashed; launches whose longest message leaves no room for it take turns), then the digest of the record being hashed and, pipelined, of
+// its predecessor.
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
-hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
-                       const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of) {
-    extern __shared__ uint32_t lds[];       // max(message words of the launch's longest record, 8) x 64 words
-    __shared__ uint32_t lds_prev[8][64];    // the digest of the previous record of a chain
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
+                       const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of, uint32_t buf_words, uint32_t n_buf) {
+    extern __shared__ uint32_t lds[];
+    __shared__ uint4 lds_mont[512];
+    __shared__ uint32_t lds_key[256];
+    constexpr bool PIPE = WAVES > 1;
     // (the wave index as a scalar: everything indexed by it -- record words, witness ids, rows of slot_of -- is then a scalar load; as a
     // vector value each of those was a memory round trip of its own in front of every row)
     const uint32_t lane = threadIdx.x & 63u, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t j = (uint64_t)blockIdx.x * 64u + lane;
-    // (prog and slot_of arrive as kernel arguments of their own, not inside dp: only a noalias argument lets the compiler read the record
+    const uint32_t w = PIPE ? q : 0u;  // this wave's index among the WAVES waves of its item
+    const uint32_t msg_words = n_buf * buf_words * 64u;
+    uint32_t *item = lds + (PIPE ? 0u : q * (msg_words + 512u));
+    uint32_t (*lds_dig)[8][64] = (uint32_t (*)[8][64])(item + msg_words);
+    const uint64_t group = PIPE ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x * 4u + q;
+    const uint64_t j = group * 64u + lane;
+    for (uint32_t t = threadIdx.x; t < 512u; t += 256u) lds_mont[t] = ((const uint4 *)BYTE_MONT)[t];
+    lds_key[threadIdx.x] = ((const uint32_t *)BYTE_KEY)[threadIdx.x];
+    const CoopTables T{lds_mont, lds_key};
+    __syncthreads();  // the tables (the only block-wide barrier of the one-wave items)
+    if (!PIPE && group * 64u >= B) return;
+    auto sync = [] { if (PIPE) __syncthreads(); };
+    // (prog and slot_of arrive as kernel arguments of their own, not inside a struct: only a noalias argument lets the compiler read the record
     // with scalar loads; through the struct every record word was a vector load that also waited for the stores before it)
     const uint32_t *__restrict__ rec = prog + offsets[blockIdx.y];
-    const uint32_t *__restrict__ src = nullptr;  // per input of a chained record: byte of the previous digest, or NONE (null: the head of a chain)
     FastPolicy p{W, Bp, j, slot_of};
     const bool live = j < B;  // (rows are padded to Bp: the loads of a dead lane stay inside the table)
-    uint8_t *bytes = (uint8_t *)lds;
+    const bool two = PIPE && n_buf == 2u;
+    uint32_t cur = 0, dcur = 0;  // message buffer / digest buffer of `rec`
+    uint32_t range_bad = 0xFFFFFFFFu, conflict = 0xFFFFFFFFu;
+    const uint32_t *__restrict__ pend_outs = nullptr;  // outputs of the predecessor, still to be stored (pipelined items)
+    uint32_t pend_opcode = 0;
+    {   // the head's inputs: every wave of the item fetches
+        const uint32_t n_in = rec[3];
+        const uint32_t *ins = rec + 6, *ranges = (rec[2] & HASH_RANGE_FLAG) ? ins + 2u * n_in + 64u : nullptr;
+        if (w == 0 && (n_in & 3u)) item[(n_in >> 2) * 64u + lane] = 0u;  // the bytes behind the message in its last word
+        sync();
+        coop_fetch_rows(p, ins, ranges, nullptr, n_in, w, WAVES, (uint8_t *)item, lane, T, range_bad);
+    }
+    sync();
     for (;;) {
         const uint32_t func = rec[2] & 0xffu, n_in = rec[3];
-        const uint32_t *ins = rec + 6, *outs = ins + 2 * n_in;
-        const uint32_t *ranges = (rec[2] & HASH_RANGE_FLAG) ? outs + 64 : nullptr;  // (opcode or NONE, bits) per input
-        uint32_t range_bad = 0xFFFFFFFFu;
-        if (q == 0 && (n_in & 3u)) lds[(n_in >> 2) * 64u + lane] = 0u;  // the bytes behind the message in its last word
-        __syncthreads();
-        // one input: (low limb, is a byte) from its row, or the byte of the previous digest
-        auto fetch = [&](uint32_t i, bool &is_byte) {
-            const uint32_t from = src ? src[i] : 0xFFFFFFFFu;  // (scalar: i is wave-uniform)
-            if (from != 0xFFFFFFFFu) {
-                is_byte = true;
-                return (lds_prev[from >> 2][lane] >> (8u * (from & 3u))) & 0xffu;
-            }
-            return fr_low_limb(p.load(ins[2 * i]), is_byte);
-        };
-        for (uint32_t i = q; i < n_in; i += 4u * WAVES) {  // wave-uniform bounds
-            const uint32_t i1 = i + WAVES, i2 = i + 2u * WAVES, i3 = i + 3u * WAVES;
-            bool b0, b1 = true, b2 = true, b3 = true;  // the value is a byte (then l is that byte)
-            const uint32_t l0 = fetch(i, b0), l1 = i1 < n_in ? fetch(i1, b1) : 0u, l2 = i2 < n_in ? fetch(i2, b2) : 0u, l3 = i3 < n_in ? fetch(i3, b3) : 0u;
-            bytes[4u * ((i >> 2) * 64u + lane) + (i & 3u)] = (uint8_t)l0;
-            if (i1 < n_in) bytes[4u * ((i1 >> 2) * 64u + lane) + (i1 & 3u)] = (uint8_t)l1;
-            if (i2 < n_in) bytes[4u * ((i2 >> 2) * 64u + lane) + (i2 & 3u)] = (uint8_t)l2;
-            if (i3 < n_in) bytes[4u * ((i3 >> 2) * 64u + lane) + (i3 & 3u)] = (uint8_t)l3;
-            if (ranges) {  // the RANGE opcodes fused into this record (plan.cpp): same test as op_range on the limb that is here already
-                range_bad = min(range_bad, range_check(ranges, i, b0, l0));
-                if (i1 < n_in) range_bad = min(range_bad, range_check(ranges, i1, b1, l1));
-                if (i2 < n_in) range_bad = min(range_bad, range_check(ranges, i2, b2, l2));
-                if (i3 < n_in) range_bad = min(range_bad, range_check(ranges, i3, b3, l3));
-            }
-        }
-        if (range_bad != 0xFFFFFFFFu && live) atomicMin(&event[j], range_bad);
-        __syncthreads();
-        Digest d;
-        if (q == 0) {
-            const LdsMsg m{lds, lane};
+        const uint32_t *ins = rec + 6, *outs = ins + 2u * n_in;
+        const uint32_t *ranges = (rec[2] & HASH_RANGE_FLAG) ? outs + 64u : nullptr;  // (opcode or NONE, bits) per input
+        const bool more = (rec[2] & HASH_CHAIN_FLAG) != 0u;
+        // the link to the record that hashes this digest: [its record, source of each of its inputs (byte of this digest or NONE), the count and the
+        // indices of the NONE inputs]
+        const uint32_t *__restrict__ link = more ? prog + (ranges ? ranges + 2u * n_in : outs + 64u)[0] : nullptr;
+        const uint32_t *__restrict__ nrec = more ? prog + link[0] : nullptr;
+        const uint32_t n_next = more ? nrec[3] : 0u;
+        const uint32_t *nins = more ? nrec + 6 : nullptr, *nranges = more && (nrec[2] & HASH_RANGE_FLAG) ? nrec + 6 + 2u * n_next + 64u : nullptr;
+        uint32_t *msg = item + cur * buf_words * 64u;
+        uint32_t *nmsg = item + (two ? cur ^ 1u : 0u) * buf_words * 64u;
+        if (w == 0) {
+            Digest d;
+            const LdsMsg m{msg, lane};
             if (func == 3u) d = sha256_body(m, n_in);
             else if (func == 4u) d = blake2s_body(m, n_in);
             else d = keccak256_body(m, n_in);
-        }
-        __syncthreads();  // the message has been read
-        const bool more = (rec[2] & HASH_CHAIN_FLAG) != 0u;
-        if (q == 0) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                lds[(uint32_t)k * 64u + lane] = d.d[k];
-                if (more) lds_prev[k][lane] = d.d[k];
+            for (int k = 0; k < 8; k++) lds_dig[dcur][k][lane] = d.d[k];
+        } else if (PIPE) {  // beside the hash: the predecessor's outputs, the successor's rows
+            if (pend_outs && live && !coop_store_outputs(p, pend_outs, lds_dig[dcur ^ 1u], w - 1u, WAVES - 1, lane, T)) conflict = min(conflict, pend_opcode);
+            if (more && two) {
+                if (w == 1 && (n_next & 3u)) nmsg[(n_next >> 2) * 64u + lane] = 0u;
+                coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w - 1u, WAVES - 1, (uint8_t *)nmsg, lane, T, range_bad);
             }
         }
-        __syncthreads();
-        if (live) {
-            bool ok = true;
-            for (uint32_t k = 0; k < 32u / WAVES; k++) {
-                const uint32_t i = (32u / WAVES) * q + k;
-                const uint32_t byte = (lds[(i >> 2) * 64u + lane] >> (8u * (i & 3u))) & 0xffu;
-                ok = p.insert(outs[2 * i], fr_from_byte(byte), outs[2 * i + 1]) && ok;  // (hash.rs:92-103 stops at the first conflict; the flagged instance re-runs exactly)
-            }
-            if (!ok) atomicMin(&event[j], rec[1]);
-        }
+        sync();  // the digest is in LDS (and the message has been read)
         if (!more) break;
-        const uint32_t *__restrict__ link = prog + (ranges ? ranges + 2 * n_in : outs + 64)[0];
-        __syncthreads();  // every wave has read its part of the digest out of `lds`, which the next message overwrites
-        rec = prog + link[0];
-        src = link + 1;
+        if (!PIPE) {  // one wave: its outputs now
+            if (live && !coop_store_outputs(p, outs, lds_dig[dcur], 0u, 1u, lane, T)) conflict = min(conflict, rec[1]);
+        } else {
+            pend_outs = outs;
+            pend_opcode = rec[1];
+        }
+        // the successor's message: its rows (unless they came in beside the hash), then the digest bytes it reads
+        if (!two) {
+            if (w == 0 && (n_next & 3u)) nmsg[(n_next >> 2) * 64u + lane] = 0u;
+            sync();
+            coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w, WAVES, (uint8_t *)nmsg, lane, T, range_bad);
+        }
+        coop_copy_chained(link + 1u, nranges, n_next, w, WAVES, lds_dig[dcur], (uint8_t *)nmsg, lane, range_bad);
+        rec = nrec;
+        cur = two ? cur ^ 1u : 0u;
+        if (PIPE) dcur ^= 1u;
+        sync();
+    }
+    // the tail's outputs (in a pipelined item the predecessor's went out beside the tail's hash): every wave of the item stores
+    if (live) {
+        const uint32_t *outs = rec + 6 + 2u * rec[3];
+        if (!coop_store_outputs(p, outs, lds_dig[dcur], w, WAVES, lane, T)) conflict = min(conflict, rec[1]);
+        const uint32_t bad = min(range_bad, conflict);
+        if (bad != 0xFFFFFFFFu) atomicMin(&event[j], bad);
     }
 }
 void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event, uint32_t lds_words) {
     if (!n || !B) return;
-    const size_t lds_bytes = (size_t)std::max<uint32_t>(lds_words, 8u) * 64u * 4u;
-    const uint64_t groups = (uint64_t)((B + 63u) / 64u) * n;  // one per 64 instances of a record
-    const bool four = groups * 4u <= 8192u;                    // four waves each while that still fits the chip about twice (1 024 SIMDs x 4-5 waves)
+    const uint32_t buf_words = std::max<uint32_t>(lds_words, 8u);
+    const uint32_t groups_b = (B + 63u) / 64u;
+    const uint64_t groups = (uint64_t)groups_b * n;  // items: one per 64 instances of a record
+    // four waves per item while that still fits the chip about twice (1 024 SIMDs x 4-5 waves); a single item with a long message has the block's
+    // LDS to itself either way
+    const bool four = groups * 4u <= 8192u || buf_words > 32u;
+    // pipelined items take a second message buffer while the block stays under 48 KiB of dynamic LDS (9 KiB are static: the tables)
+    const uint32_t n_buf = four && (size_t)2 * buf_words * 256u <= (44u << 10) ? 2u : 1u;
+    const size_t item_bytes = ((size_t)n_buf * buf_words * 64u + (four ? 1024u : 512u)) * 4u;
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        if (four) hipLaunchKernelGGL(hash_coop_level_kernel<4>, dim3((B + 63u) / 64u, m), dim3(256), lds_bytes, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
-        else hipLaunchKernelGGL(hash_coop_level_kernel<1>, dim3((B + 63u) / 64u, m), dim3(64), lds_bytes, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of);
+        if (four) hipLaunchKernelGGL(hash_coop_level_kernel<4>, dim3(groups_b, m), dim3(256), item_bytes, s, W, Bp, B, offsets + done, event, dp.prog, dp.slot_of, buf_words, n_buf);
+        else hipLaunchKernelGGL(hash_coop_level_kernel<1>, dim3((groups_b + 3u) / 4u, m), dim3(256), 4u * item_bytes, s, W, Bp, B, offsets + done, event, dp.prog, dp.slot_of, buf_words, n_buf);
         done += m;
     }
 }

@@ -1284,10 +1284,15 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     const size_t pa = chain[c - 1];
                     link_at = (uint32_t)p.prog.size();
                     p.prog.push_back(copy_at);
+                    std::vector<uint32_t> from_rows;  // the inputs that are NOT bytes of the predecessor's digest: readable while the predecessor is hashed
                     for (uint32_t k = 0; k < n_in; k++) {
                         auto it = digest_byte.find(p.prog[at + 6 + 2 * k]);
-                        p.prog.push_back(it != digest_byte.end() && it->second.first == pa ? it->second.second : 0xFFFFFFFFu);
+                        const bool chained_in = it != digest_byte.end() && it->second.first == pa;
+                        p.prog.push_back(chained_in ? it->second.second : 0xFFFFFFFFu);
+                        if (!chained_in) from_rows.push_back(k);
                     }
+                    p.prog.push_back((uint32_t)from_rows.size());
+                    p.prog.insert(p.prog.end(), from_rows.begin(), from_rows.end());
                     drop[chain[c]] = 1;
                     any = true;
                     for (uint32_t k = 0; k < 32u; k++) {  // its outputs appear with the head's launch

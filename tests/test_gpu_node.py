@@ -96,7 +96,7 @@ def test_node_lookup_tables_are_shared_refcounted_and_releasable():
     import acvm_amd
     from acvm_amd import synth
     gc.collect()  # (handles of earlier tests that are only waiting for the collector hold the tables too)
-    circ, ids = synth.mixed_circuit(300, seed=0x40DE0011)
+    circ, ids = synth.arith_pedersen_circuit(200, 3)
     gc = acvm_amd.Circuit(circ.to_bytes())
     values = synth.witness_batch(600, seed=0x40DE0011, edge_cases=True)
     node = acvm_amd.Node(gc, ids, keep=gc.witness_set("return_values"), devices=[0] * 8, tile=64)

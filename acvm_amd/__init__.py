@@ -12,11 +12,13 @@ import os
 from . import acir  # noqa: F401  (data model + wire format)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libacvm_amd.so")
+# (ACVM_AMD_LIB: another build of the same ABI, for A/B measurements of two library versions on one box: tools/gpu_ab_lib.sh)
+LIB_PATH = os.environ.get("ACVM_AMD_LIB") or os.path.join(_HERE, "libacvm_amd.so")
 
 STATUS_SOLVED, STATUS_IN_PROGRESS, STATUS_FAILURE, STATUS_REQUIRES_FOREIGN_CALL = 0, 1, 2, 3
 (ERR_NONE, ERR_MISSING_ASSIGNMENT, ERR_TOO_MANY_UNKNOWNS, ERR_UNSUPPORTED_BLACKBOX, ERR_UNSATISFIED, ERR_INDEX_OOB,
- ERR_BLACKBOX_FAILED, ERR_BRILLIG_FAILED, ERR_PANIC) = range(9)
+ ERR_BLACKBOX_FAILED, ERR_BRILLIG_FAILED, ERR_PANIC, ERR_DEVICE_LIMIT) = range(10)
+LIMIT_BRILLIG_STEPS, LIMIT_BRILLIG_CALL_DEPTH, LIMIT_BRILLIG_MEMORY, LIMIT_DEVICE_MEMORY = 1, 2, 3, 4
 
 # every symbol include/acvm_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -34,12 +36,16 @@ ABI_SYMBOLS = [
     "acvm_multi_new", "acvm_multi_free", "acvm_multi_num_groups", "acvm_multi_solve", "acvm_multi_results", "acvm_multi_num_witnesses",
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_debug_secp_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
-    "acvm_device_release_tables", "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
+    "acvm_device_release_tables", "acvm_circuit_opcode_kinds", "acvm_batch_error_expression", "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
 ]
 
 
 class AcvmError(RuntimeError):
     pass
+
+
+class ExpressionHead(C.Structure):
+    _fields_ = [("n_mul", C.c_uint32), ("n_lin", C.c_uint32), ("opcode_index", C.c_uint32), ("q_c", C.c_uint8 * 32)]
 
 
 class Result(C.Structure):
@@ -261,6 +267,8 @@ def lib():
     L.acvm_batch_witness_map_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acvm_debug_modmul_rate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.acvm_debug_secp_rate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.acvm_circuit_opcode_kinds.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.acvm_batch_error_expression.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ExpressionHead), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
     L.acvm_device_release_tables.restype = C.c_longlong
     L.acvm_device_release_tables.argtypes = [C.c_int]
     L.acvm_node_new.restype = C.c_void_p
@@ -476,6 +484,14 @@ class Circuit:
     LOCATION_ACIR = 0xFFFFFFFF
     SETS = {"private_parameters": 0, "public_parameters": 1, "return_values": 2, "public_inputs": 3, "circuit_arguments": 4}
 
+    def opcode_kinds(self):
+        """ACVM::opcodes seen through the ABI: [(Opcode variant, sub-kind)] per opcode (acvm_circuit_opcode_kinds)"""
+        import numpy as np
+        n = lib().acvm_circuit_num_opcodes(self._h)
+        k = np.zeros((max(n, 1), 2), dtype=np.uint32)
+        _check(lib().acvm_circuit_opcode_kinds(self._h, 0, n, k.ctypes.data))
+        return [(int(a), int(b)) for a, b in k[:n]]
+
     def get_assert_message(self, acir_index: int, brillig_index: int = None):
         """Circuit::get_assert_message (circuit/mod.rs:43-51) for OpcodeLocation::Acir / ::Brillig; None if there is none."""
         buf = C.create_string_buffer(4096)
@@ -652,6 +668,27 @@ class Batch:
         buf = C.create_string_buffer(1024)
         _check(lib().acvm_batch_error_string(self._h, self.circuit._h, instance, buf, 1024))
         return buf.value.decode()
+
+    def error_expression(self, instance: int):
+        """ExpressionHasTooManyUnknowns(Expression) of a failed instance as data (acvm_batch_error_expression): None if the instance did not fail
+        that way, else {"opcode_index", "mul": [(coef, wl, wr)], "lin": [(coef, w)], "q_c"} with coefficients as integers"""
+        import numpy as np
+        head = ExpressionHead()
+        cap = 64
+        while True:
+            mc, mw = np.zeros((cap, 32), dtype=np.uint8), np.zeros((cap, 2), dtype=np.uint32)
+            lc, lw = np.zeros((cap, 32), dtype=np.uint8), np.zeros(cap, dtype=np.uint32)
+            rc = _check(lib().acvm_batch_error_expression(self._h, self.circuit._h, instance, C.byref(head), mc.ctypes.data, mw.ctypes.data, cap,
+                                                          lc.ctypes.data, lw.ctypes.data, cap))
+            if rc == 0:
+                return None
+            if max(head.n_mul, head.n_lin) <= cap:
+                break
+            cap = max(head.n_mul, head.n_lin)
+        be = lambda a: int.from_bytes(bytes(a), "big")
+        return {"opcode_index": head.opcode_index, "q_c": be(head.q_c),
+                "mul": [(be(mc[i]), int(mw[i, 0]), int(mw[i, 1])) for i in range(head.n_mul)],
+                "lin": [(be(lc[i]), int(lw[i])) for i in range(head.n_lin)]}
 
     def extract(self, witnesses, first=0, n=None):
         """extract_indices (public_witness.rs:10-21) for instances [first, first + n): uint8 array [n][len(witnesses)][32];

@@ -248,6 +248,18 @@ acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len) try {
 void acvm_circuit_free(acvm_circuit_t *c) { delete c; }
 uint32_t acvm_circuit_num_opcodes(const acvm_circuit_t *c) { return c ? (uint32_t)c->c->opcodes.size() : 0; }
 uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c) { return c ? c->c->max_witness + 1 : 0; }
+int acvm_circuit_opcode_kinds(const acvm_circuit_t *c, uint32_t first, uint32_t n, uint32_t *kinds) {
+    if (!c || (n && !kinds)) return set_err(ACVM_E_INVALID, "null argument");
+    const std::vector<Opcode> &ops = c->c->opcodes;
+    if ((uint64_t)first + n > ops.size()) return set_err(ACVM_E_INVALID, "opcode range out of bounds");
+    for (uint32_t i = 0; i < n; i++) {
+        const Opcode &o = ops[first + i];
+        kinds[2 * i] = o.kind;
+        kinds[2 * i + 1] = o.kind == OP_BLACKBOX ? o.bb->func : o.kind == OP_DIRECTIVE ? o.dir->kind : o.kind == OP_BRILLIG ? (uint32_t)o.brillig->bytecode.size()
+                           : o.kind == OP_MEMORY_OP || o.kind == OP_MEMORY_INIT ? o.block_id : 0u;
+    }
+    return 0;
+}
 
 static void plan_stats(const Plan &p, acvm_stats_t *out) {
     memset(out, 0, sizeof *out);
@@ -891,10 +903,24 @@ static int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start
 // RETRIED here: their opcode runs again (a failed VM run has no side effects: outputs are inserted after it finishes) with the
 // limit that was hit raised -- memory to twice the cell the write wanted, steps and depth sixteen-fold -- in a scratch that holds
 // only the retried lanes, until nothing hits a limit or a stated maximum of the library is reached (tuning.hpp: 2^26 steps, 2^16
-// frames, 2^22 cells by default). Past a maximum the SOLVE fails with ACVM_E_UNSUPPORTED: an instance never reports a failure the
-// reference would not report. Called with the lanes' results on the host (stream synchronised).
+// frames, 2^22 cells by default). Past a maximum THAT INSTANCE ends with status Failure / ACVM_ERR_DEVICE_LIMIT -- an outcome the
+// reference does not have and the header says so: "this library could not finish the instance, run it with the reference" -- and every
+// other instance of the batch keeps its result (round 3 failed the whole solve call and lost them: the reference's caller loop,
+// acvm_js/src/execute.rs:60-119, loses one instance at most). Called with the lanes' results on the host (stream synchronised).
 static bool is_device_limit(const SlowResult &r) {
     return r.status == ACVM_STATUS_FAILURE && r.err == ACVM_ERR_PANIC && (r.msg == 17u || r.msg == 18u || r.msg == 28u);
+}
+// the lane's final word: Failure / ACVM_ERR_DEVICE_LIMIT at its Brillig opcode, aux0 = the limit that was reached, aux1 = its value
+static void give_up_lane(SlowResult &r, uint32_t kind, uint64_t limit, uint64_t wanted) {
+    const uint32_t opcode = r.opcode_index;
+    memset(&r, 0, sizeof r);
+    r.status = ACVM_STATUS_FAILURE;
+    r.err = ACVM_ERR_DEVICE_LIMIT;
+    r.opcode_index = opcode;
+    r.aux0 = kind;
+    r.aux1 = (uint32_t)std::min<uint64_t>(limit, 0xFFFFFFFFu);
+    r.msg = 29u;  // DM_DEVICE_LIMIT (ops_common.hpp): format_message words it
+    r.x0 = (uint32_t)std::min<uint64_t>(wanted, 0xFFFFFFFFu);
 }
 static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint32_t end_opcode) {
     const Plan &p = b->plan;
@@ -907,46 +933,37 @@ static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint
     BrilligLimits lim = base;
     int rc = 0;
     for (;;) {
-        std::vector<uint32_t> lanes;
-        bool hit_steps = false, hit_depth = false, hit_mem = false;
-        uint64_t want_cells = 0, record_cells = 0;
-        uint32_t first_lane = 0, mem_lane = 0;
+        // the memory a retried lane runs with so far (0 = the planner's estimate of its record)
+        uint64_t record_cells = 0;
         for (uint32_t t = 0; t < n_slow; t++) {
             const SlowResult &r = b->slow_res[t];
+            if (is_device_limit(r) && r.opcode_index < p.n_opcodes && p.prog[p.prog_offset[r.opcode_index]] == PK_BRILLIG)
+                record_cells = std::max<uint64_t>(record_cells, p.prog[p.prog_offset[r.opcode_index] + 8]);
+        }
+        const uint64_t cur_cells = lim.mem_cap ? lim.mem_cap : record_cells;
+        // lanes past a stated maximum are final; the rest is retried with the limits they reached raised
+        std::vector<uint32_t> lanes;
+        bool hit_steps = false, hit_depth = false, hit_mem = false;
+        uint64_t want_cells = 0;
+        for (uint32_t t = 0; t < n_slow; t++) {
+            SlowResult &r = b->slow_res[t];
             if (!is_device_limit(r)) continue;
-            if (lanes.empty()) first_lane = t;
+            if (r.msg == 18u && lim.steps >= max_steps) { give_up_lane(r, ACVM_LIMIT_BRILLIG_STEPS, max_steps, 0); continue; }
+            if (r.msg == 28u && lim.call_depth >= max_depth) { give_up_lane(r, ACVM_LIMIT_BRILLIG_CALL_DEPTH, max_depth, 0); continue; }
+            if (r.msg == 17u && ((uint64_t)r.x0 + 1 > max_cells || cur_cells >= max_cells)) { give_up_lane(r, ACVM_LIMIT_BRILLIG_MEMORY, max_cells, r.x0); continue; }
             lanes.push_back(t);
             hit_steps |= r.msg == 18u;
             hit_depth |= r.msg == 28u;
             if (r.msg == 17u) {
                 hit_mem = true;
-                if ((uint64_t)r.x0 + 1 > want_cells) { want_cells = (uint64_t)r.x0 + 1; mem_lane = t; }
+                want_cells = std::max<uint64_t>(want_cells, (uint64_t)r.x0 + 1);
             }
-            if (r.opcode_index < p.n_opcodes && p.prog[p.prog_offset[r.opcode_index]] == PK_BRILLIG)
-                record_cells = std::max<uint64_t>(record_cells, p.prog[p.prog_offset[r.opcode_index] + 8]);
         }
         if (lanes.empty()) break;
-        auto refuse = [&](const std::string &what, uint32_t lane) {
-            b->solved = false;  // no results: the caller sets the inputs again (or resets) before the next solve
-            b->stepping = false;
-            const SlowResult &r = b->slow_res[lane];
-            return set_err(ACVM_E_UNSUPPORTED, "Brillig opcode " + std::to_string(r.opcode_index) + " of instance " + std::to_string(b->slow_ids[lane]) + " " + what +
-                                               "; the reference's VM has no such limit, this library does (tuning.hpp) -- solve this instance with the reference");
-        };
-        if (hit_steps) {
-            if (lim.steps >= max_steps) { rc = refuse("runs more than 2^" + std::to_string(tn.brillig_steps_max_log2) + " VM steps", first_lane); break; }
-            lim.steps = (uint32_t)std::min<uint64_t>((uint64_t)lim.steps * 16, max_steps);
-        }
-        if (hit_depth) {
-            if (lim.call_depth >= max_depth) { rc = refuse("nests more than " + std::to_string(max_depth) + " calls", first_lane); break; }
-            lim.call_depth = (uint32_t)std::min<uint64_t>((uint64_t)lim.call_depth * 16, max_depth);
-        }
-        const uint64_t cur_cells = lim.mem_cap ? lim.mem_cap : record_cells;
+        if (hit_steps) lim.steps = (uint32_t)std::min<uint64_t>((uint64_t)lim.steps * 16, max_steps);
+        if (hit_depth) lim.call_depth = (uint32_t)std::min<uint64_t>((uint64_t)lim.call_depth * 16, max_depth);
         uint64_t cells = std::max<uint64_t>(cur_cells, 64);
-        if (hit_mem) {
-            if (want_cells > max_cells || cur_cells >= max_cells) { rc = refuse("writes VM memory cell " + std::to_string(want_cells - 1) + ", beyond 2^" + std::to_string(tn.brillig_mem_max_log2) + " cells", mem_lane); break; }
-            cells = std::min<uint64_t>(std::max<uint64_t>(2 * want_cells, 4 * cells), max_cells);
-        }
+        if (hit_mem) cells = std::min<uint64_t>(std::max<uint64_t>(2 * want_cells, 4 * cells), max_cells);
         lim.mem_cap = (uint32_t)cells;
         lim.stride = ((uint64_t)lanes.size() + 63) / 64 * 64;
         const uint64_t words = ((uint64_t)b->br_max_regs + cells) * 8 + lim.call_depth + cells / 4 + 16;
@@ -956,8 +973,8 @@ static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint
             b->d_br_scratch = nullptr;
             b->br_scratch_bytes = 0;
             if (hipMalloc((void **)&b->d_br_scratch, bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                rc = refuse("needs " + std::to_string(bytes >> 20) + " MiB of VM scratch for " + std::to_string(lanes.size()) + " instances, which the device cannot provide", first_lane);
+                (void)hipGetLastError();  // the device cannot hold the VM scratch of these lanes: they are final too
+                for (uint32_t t : lanes) give_up_lane(b->slow_res[t], ACVM_LIMIT_DEVICE_MEMORY, bytes >> 20, 0);
                 break;
             }
             b->br_scratch_bytes = bytes;
@@ -982,10 +999,19 @@ static int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint
         HIPCHK(hipMemcpyAsync(b->d_br_lane, col.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(b->d_slow_start, b->slow_start.data(), (size_t)n_slow * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(b->d_slow_res, b->slow_res.data(), (size_t)n_slow * sizeof(SlowResult), hipMemcpyHostToDevice, s));
+        // (the lanes that were given up stay Failure on the host and on the device: the exact kernels skip a lane that is not InProgress;
+        // run_exact_segments fetches the device's records back, which is why the host copy of those lanes is restored below)
+        std::vector<std::pair<uint32_t, SlowResult>> final_lanes;
+        for (uint32_t t = 0; t < n_slow; t++)
+            if (b->slow_res[t].err == ACVM_ERR_DEVICE_LIMIT) final_lanes.push_back({t, b->slow_res[t]});
         b->dp.brillig = lim;
         b->br_retry_active = true;
         rc = run_exact_segments(b, n_slow, min_start, replay, end_opcode);
+        if (!rc && b->pending) {  // (an asynchronous job leaves its results on the device: fetch them for the next look at the limits)
+            if (hipMemcpyAsync(b->slow_res.data(), b->d_slow_res, (size_t)n_slow * sizeof(SlowResult), hipMemcpyDeviceToHost, s) != hipSuccess) rc = set_err(ACVM_E_DEVICE, "hipMemcpyAsync failed in a Brillig retry pass");
+        }
         if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_err(ACVM_E_DEVICE, "hipStreamSynchronize failed in a Brillig retry pass");
+        for (auto &fl : final_lanes) b->slow_res[fl.first] = fl.second;
         b->dp.brillig = base;
         b->br_retry_active = false;
         b->n_brillig_retries++;
@@ -1961,7 +1987,7 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
         else snprintf(r.message, sizeof r.message, "%s", sr.x0 < 17 ? texts[sr.x0] : "brillig vm panic");
         break;
     }
-    // 17 / 18 / 28: device limits of the Brillig VM. retry_device_limits retries such lanes or fails the solve call; the texts are for debugging only
+    // 17 / 18 / 28: device limits of the Brillig VM. retry_device_limits retries such lanes or ends them with ACVM_ERR_DEVICE_LIMIT (29); the texts are for debugging only
     case 17: snprintf(r.message, sizeof r.message, "brillig memory write at %u beyond the device capacity", sr.x0); break;
     case 18: snprintf(r.message, sizeof r.message, "brillig step limit reached on the device"); break;
     case 28: snprintf(r.message, sizeof r.message, "brillig call depth limit reached on the device"); break;
@@ -1990,6 +2016,17 @@ static void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm
         break;
     }
     case 27: snprintf(r.message, sizeof r.message, "index out of bounds: the len is %u but the index is %u", sr.x0, sr.x1); break;
+    case 29: {  // ACVM_ERR_DEVICE_LIMIT: not a reference outcome (include/acvm_amd.h)
+        static const char *what[5] = {"", "VM steps", "nested calls", "cells of VM memory", "MiB of VM scratch on the device"};
+        const uint32_t k = sr.aux0 < 5 ? sr.aux0 : 0;
+        if (k == ACVM_LIMIT_BRILLIG_MEMORY)
+            snprintf(r.message, sizeof r.message, "device limit: the Brillig program writes VM memory cell %u, beyond the %u cells this library runs it with; "
+                                                  "the reference has no such limit: solve this instance with it", sr.x0, sr.aux1);
+        else
+            snprintf(r.message, sizeof r.message, "device limit: the Brillig program needs more than %u %s; the reference has no such limit: solve this "
+                                                  "instance with it", sr.aux1, what[k]);
+        break;
+    }
     case 24: {
         auto it = b->host_bb_msg.find(j);
         snprintf(r.message, sizeof r.message, "%s", it == b->host_bb_msg.end() ? "" : it->second.c_str());
@@ -2051,10 +2088,12 @@ int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, 
     return (int)v.size();
 } ABI_CATCH
 
-// The expression ExpressionHasTooManyUnknowns quotes for `instance`, as its Display text: witnesses the instance has assigned are read
-// back one by one (rare path: one failing instance).
-static std::string too_many_unknowns_expression(acvm_batch *b, const Circuit &circ, uint32_t instance, uint32_t opcode_index) {
-    if (opcode_index >= circ.opcodes.size()) return "";
+// The expression OpcodeNotSolvable::ExpressionHasTooManyUnknowns carries for `instance` (pwg/mod.rs:72-78): the opcode partially evaluated
+// on the instance's map for Opcode::Arithmetic (arithmetic.rs:31,38-42), the first input expression that does not reduce to a constant, as
+// written, for Opcode::Brillig (brillig.rs:46-74, get_value pwg/mod.rs:321-332). Witnesses the instance has assigned are read back one by
+// one (rare path: one failing instance). false: the opcode carries no such expression.
+static bool too_many_unknowns_expr(acvm_batch *b, const Circuit &circ, uint32_t instance, uint32_t opcode_index, Expr &out) {
+    if (opcode_index >= circ.opcodes.size()) return false;
     const int32_t lane = b->slow_index[instance];
     const uint32_t n_slow = (uint32_t)b->slow_ids.size();
     auto known = [&](uint32_t w) -> bool {
@@ -2089,16 +2128,54 @@ static std::string too_many_unknowns_expression(acvm_batch *b, const Circuit &ci
         return r;
     };
     const Opcode &o = circ.opcodes[opcode_index];
-    if (o.kind == OP_ARITHMETIC) return expression_display(evaluate(o.expr));
+    if (o.kind == OP_ARITHMETIC) { out = evaluate(o.expr); return true; }
     if (o.kind == OP_BRILLIG) {  // the first input, in order, that does not reduce to a constant (get_value, pwg/mod.rs:321-332)
         auto stuck = [&](const Expr &e) { const Expr r = evaluate(e); return !r.mul.empty() || !r.lin.empty(); };
         for (const BrilligInput &in : o.brillig->inputs) {
-            if (!in.is_array) { if (stuck(in.single)) return expression_display(in.single); }
-            else for (const Expr &e : in.arr) if (stuck(e)) return expression_display(e);
+            if (!in.is_array) { if (stuck(in.single)) { out = in.single; return true; } }
+            else for (const Expr &e : in.arr) if (stuck(e)) { out = e; return true; }
         }
     }
-    return "";
+    return false;
 }
+static std::string too_many_unknowns_expression(acvm_batch *b, const Circuit &circ, uint32_t instance, uint32_t opcode_index) {
+    Expr e;
+    return too_many_unknowns_expr(b, circ, instance, opcode_index, e) ? expression_display(e) : std::string();
+}
+
+int acvm_batch_error_expression(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, acvm_expression_t *head, uint8_t *mul_coef_be32,
+                                uint32_t *mul_witnesses, uint32_t cap_mul, uint8_t *lin_coef_be32, uint32_t *lin_witnesses, uint32_t cap_lin) try {
+    if (!b || !c || !head) return set_err(ACVM_E_INVALID, "null argument");
+    memset(head, 0, sizeof *head);
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if (instance >= b->B) return set_err(ACVM_E_INVALID, "instance out of range");
+    HIPCHK(hipSetDevice(b->device));
+    acvm_result_t r;
+    fill_result(b, instance, r);
+    if (r.status != ACVM_STATUS_FAILURE || r.err != ACVM_ERR_TOO_MANY_UNKNOWNS) return 0;
+    Expr e;
+    if (!too_many_unknowns_expr(b, *c->c, instance, r.opcode_index, e)) return 0;
+    auto put_be = [](uint8_t *dst, const FrH &x) {
+        uint64_t can[4];
+        frh::to_canonical(x, can);
+        for (int k = 0; k < 32; k++) dst[31 - k] = (uint8_t)(can[k / 8] >> (8 * (k % 8)));
+    };
+    head->n_mul = (uint32_t)e.mul.size();
+    head->n_lin = (uint32_t)e.lin.size();
+    head->opcode_index = r.opcode_index;
+    put_be(head->q_c, e.qc);
+    for (uint32_t i = 0; i < head->n_mul && i < cap_mul; i++) {
+        if (mul_coef_be32) put_be(mul_coef_be32 + 32 * (size_t)i, e.mul[i].c);
+        if (mul_witnesses) { mul_witnesses[2 * i] = e.mul[i].l; mul_witnesses[2 * i + 1] = e.mul[i].r; }
+    }
+    for (uint32_t i = 0; i < head->n_lin && i < cap_lin; i++) {
+        if (lin_coef_be32) put_be(lin_coef_be32 + 32 * (size_t)i, e.lin[i].c);
+        if (lin_witnesses) lin_witnesses[i] = e.lin[i].w;
+    }
+    return 1;
+} ABI_CATCH
 
 int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap) try {
     if (!b || !out || !cap) return set_err(ACVM_E_INVALID, "null argument");
@@ -2140,6 +2217,7 @@ int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t i
     case ACVM_ERR_BLACKBOX_FAILED: return snprintf(out, cap, "Failed to solve blackbox function: %s, reason: %s", func, r.message);
     case ACVM_ERR_BRILLIG_FAILED: return snprintf(out, cap, "Failed to solve brillig function, reason: %s", r.message);
     case ACVM_ERR_PANIC: return snprintf(out, cap, "panicked: %s", r.message);
+    case ACVM_ERR_DEVICE_LIMIT: return snprintf(out, cap, "Not solved by this library (%s)", r.message);
     default: return snprintf(out, cap, "unknown error %u", r.err);
     }
 } ABI_CATCH

@@ -16,33 +16,66 @@
 namespace acvm {
 
 // ------------------------------------------------------------------------------------------ import
-// in: [B][n_in][32] big-endian. One lane per (instance, input).
+// in: [B][n_in][32] big-endian. A block converts 64 instances x 4 consecutive inputs: the four inputs of an instance are 128 contiguous
+// bytes of `in` (one line per four lanes, where one lane per (instance, input) had every lane fetch its own 32 bytes from a line of its own),
+// and the values reach the table through LDS, 64 lanes to a row (1 KiB contiguous per half). ALIGNED: `in` is 16-byte aligned (every
+// buffer of the library is; a caller's device pointer may not be) and the bytes travel as two 16-byte loads.
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
                                                              const uint8_t *__restrict__ in, const uint32_t *__restrict__ ids,
                                                              uint32_t n_in) {
-    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t k = blockIdx.y;
-    if (j >= B) return;
-    const uint8_t *p = in + ((uint64_t)j * n_in + k) * 32;
-    Fr x;
+    __shared__ uint4 tile[4][2][65];
+    const uint32_t t = threadIdx.x;
+    const uint64_t j0 = (uint64_t)blockIdx.x * 64u;
+    const uint32_t k0 = blockIdx.y * 4u;
+    {
+        const uint32_t ji = t >> 2, kk = t & 3u;
+        const uint64_t j = j0 + ji;
+        const uint32_t k = k0 + kk;
+        if (j < B && k < n_in) {
+            const uint8_t *p = in + (j * n_in + k) * 32u;
+            Fr x;
+            if (ALIGNED) {
+                const uint4 *q = (const uint4 *)p;  // read once (nontemporal): bytes [0, 16) are the most significant
+                x.v[7] = __builtin_bswap32(__builtin_nontemporal_load(&q[0].x)); x.v[6] = __builtin_bswap32(__builtin_nontemporal_load(&q[0].y));
+                x.v[5] = __builtin_bswap32(__builtin_nontemporal_load(&q[0].z)); x.v[4] = __builtin_bswap32(__builtin_nontemporal_load(&q[0].w));
+                x.v[3] = __builtin_bswap32(__builtin_nontemporal_load(&q[1].x)); x.v[2] = __builtin_bswap32(__builtin_nontemporal_load(&q[1].y));
+                x.v[1] = __builtin_bswap32(__builtin_nontemporal_load(&q[1].z)); x.v[0] = __builtin_bswap32(__builtin_nontemporal_load(&q[1].w));
+            } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint8_t *q = p + 28 - 4 * i;  // limb i = bytes [28-4i, 32-4i) big-endian
-        x.v[i] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3];
-    }
-    // reduce: 2^256 / p < 6, so at most 5 subtractions
-    for (int it = 0; it < 5; it++) {
-        Fr d;
-        uint64_t br = 0;
+                for (int i = 0; i < 8; i++) {
+                    const uint8_t *q = p + 28 - 4 * i;  // limb i = bytes [28-4i, 32-4i) big-endian
+                    x.v[i] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3];
+                }
+            }
+            // reduce: 2^256 / p < 6, so at most 5 subtractions
+            for (int it = 0; it < 5; it++) {
+                Fr d;
+                uint64_t br = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t t = (uint64_t)x.v[i] - fr_p(i) - br;
-            d.v[i] = (uint32_t)t;
-            br = (t >> 32) & 1;
+                for (int i = 0; i < 8; i++) {
+                    uint64_t tt = (uint64_t)x.v[i] - fr_p(i) - br;
+                    d.v[i] = (uint32_t)tt;
+                    br = (tt >> 32) & 1;
+                }
+                if (!br) x = d;
+            }
+            const Fr m = fr_mul(x, fr_r2());
+            tile[kk][0][ji] = make_uint4(m.v[0], m.v[1], m.v[2], m.v[3]);
+            tile[kk][1][ji] = make_uint4(m.v[4], m.v[5], m.v[6], m.v[7]);
         }
-        if (!br) x = d;
     }
-    fr_store(W, ids[k], Bp, j, fr_mul(x, fr_r2()));
+    __syncthreads();
+    {
+        const uint32_t kk = t >> 6, ji = t & 63u;
+        const uint64_t j = j0 + ji;
+        const uint32_t k = k0 + kk;
+        if (j < B && k < n_in) {
+            uint4 *row = W + (uint64_t)ids[k] * 2u * Bp + j;
+            row[0] = tile[kk][0][ji];
+            row[Bp] = tile[kk][1][ji];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ export
@@ -294,7 +327,9 @@ __global__ void init_assigned_kernel(uint32_t *assigned, uint32_t n_slow, uint32
 // ------------------------------------------------------------------------------------------ launchers
 void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in) {
     if (!B || !n_in) return;
-    hipLaunchKernelGGL(import_witness_kernel, dim3((B + 255) / 256, n_in), dim3(256), 0, s, W, Bp, B, in, ids, n_in);
+    const dim3 grid((B + 63u) / 64u, (n_in + 3u) / 4u);
+    if (((uintptr_t)in & 15u) == 0) hipLaunchKernelGGL(import_witness_kernel<true>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in);
+    else hipLaunchKernelGGL(import_witness_kernel<false>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in);
 }
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out,
                    const Unscale &u, const uint32_t *row_of) {

@@ -36,7 +36,8 @@ enum DevMsg : uint32_t {
     DM_MEM_INDEX_U64 = 6, DM_MEM_READ_EXPR = 7, DM_RADIX = 8, DM_LIMB_LOW = 9, DM_LIMB_HIGH = 10, DM_SCALAR = 11,
     DM_SCHNORR_SIG_LEN = 12, DM_SCHNORR_MSG_LEN = 13, DM_BRILLIG_TRAP = 14, DM_BRILLIG_RETURN = 15, DM_BRILLIG_PANIC = 16,
     DM_BRILLIG_MEM_CAP = 17, DM_BRILLIG_STEP_LIMIT = 18, DM_BRILLIG_BB_FAILED = 19, DM_PEDERSEN_DOMAIN = 20, DM_FC_COUNT = 21,
-    DM_FC_SIZE = 22, DM_FC_PENDING_CAP = 23, DM_HOST_MESSAGE = 24, DM_ECDSA_LEN = 25, DM_ECDSA_PANIC = 26, DM_SORT_TUPLE = 27, DM_BRILLIG_CALL_DEPTH = 28
+    DM_FC_SIZE = 22, DM_FC_PENDING_CAP = 23, DM_HOST_MESSAGE = 24, DM_ECDSA_LEN = 25, DM_ECDSA_PANIC = 26, DM_SORT_TUPLE = 27, DM_BRILLIG_CALL_DEPTH = 28,
+    DM_DEVICE_LIMIT = 29  // host only: an instance the exact path gave up on (batch.cpp retry_device_limits)
 };
 
 // err / aux0 / aux1 are the ABI's acvm_result_t fields; msg (DevMsg) and x0, x1 let the host rebuild the message text
@@ -300,6 +301,41 @@ __device__ __forceinline__ uint32_t fr_low_limb(const Fr &a, bool &is_byte) {
     is_byte = fr_is_byte(a, d);
     if (!is_byte) d = fr29_redc_low(fr29_from(a));
     return d;
+}
+// to_u8_vec (acvm/src/pwg/blackbox/signature/mod.rs:5-18: the last big-endian byte of each witness) of 32 witnesses, read as ONE big-endian
+// 256-bit integer (limbs little-endian): a signature half, a public-key coordinate, a hashed message. Four rows are in flight per lane and
+// the byte comes from the table path (fr_low_limb), where one row at a time with a Montgomery reduction apiece (160 per ECDSA opcode, 74 per
+// SchnorrVerify) left the one wave a SIMD holds waiting for every row in turn -- 0.55 / 0.86 ms of a 2^16-instance launch whose rows the
+// import had just pushed out of the memory-side cache (tools/t_step_gap.py, round 4).
+template <class P>
+static __device__ __noinline__ Fr load_be32_bytes(const P &p, const uint32_t *__restrict__ ws) {
+    Fr r = fr_zero();
+    for (uint32_t g = 0; g < 8u; g++) {
+        const Fr a0 = p.load(ws[4u * g]), a1 = p.load(ws[4u * g + 1u]), a2 = p.load(ws[4u * g + 2u]), a3 = p.load(ws[4u * g + 3u]);
+        bool b;
+        const uint32_t limb = (fr_low_limb(a0, b) & 0xffu) << 24 | (fr_low_limb(a1, b) & 0xffu) << 16 | (fr_low_limb(a2, b) & 0xffu) << 8 | (fr_low_limb(a3, b) & 0xffu);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((uint32_t)k == 7u - g) r.v[k] = limb;
+    }
+    return r;
+}
+// the same for a byte string of any length, four rows at a time: put(i, byte)
+template <class P, class Put>
+__device__ __forceinline__ void load_bytes(const P &p, const uint32_t *__restrict__ ws, uint32_t n, Put put) {
+    uint32_t i = 0;
+    for (; i + 4u <= n; i += 4u) {
+        const Fr a0 = p.load(ws[i]), a1 = p.load(ws[i + 1u]), a2 = p.load(ws[i + 2u]), a3 = p.load(ws[i + 3u]);
+        bool b;
+        put(i, fr_low_limb(a0, b) & 0xffu);
+        put(i + 1u, fr_low_limb(a1, b) & 0xffu);
+        put(i + 2u, fr_low_limb(a2, b) & 0xffu);
+        put(i + 3u, fr_low_limb(a3, b) & 0xffu);
+    }
+    for (; i < n; i++) {
+        bool b;
+        put(i, fr_low_limb(p.load(ws[i]), b) & 0xffu);
+    }
 }
 // num_bits of a canonical integer (generic_ark.rs:214-221)
 __device__ __forceinline__ uint32_t canon_num_bits(const Fr &c) {

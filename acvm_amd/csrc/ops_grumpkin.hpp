@@ -505,17 +505,11 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
     return a;
 }
 
-template <class SigByte, class MsgByte>
-__device__ __forceinline__ bool grumpkin_schnorr_verify(const GrumpkinTables &T, const Fr &pkx, const Fr &pky, SigByte sig_byte, uint32_t n_msg,
-                                                        MsgByte msg_byte, MsgBuf &m, uint32_t *window_table = nullptr) {
-    Fr s = fr_zero(), e = fr_zero();
-    for (uint32_t i = 0; i < 32; i++) {  // big-endian 32-byte integers
-        const uint32_t sb = sig_byte(i) & 0xffu, eb = sig_byte(32u + i) & 0xffu;
-        const uint32_t limb = 7u - (i >> 2), sh = 24u - 8u * (i & 3u);
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if ((uint32_t)k == limb) { s.v[k] |= sb << sh; e.v[k] |= eb << sh; }
-    }
+// s, e: the two halves of the signature as 256-bit integers (big-endian bytes 0..31 and 32..63); the message bytes are staged in `m` behind the
+// 32 bytes of the compressed point by `fill_msg(put)`, put(i, byte) storing message byte i
+template <class FillMsg>
+__device__ __forceinline__ bool grumpkin_schnorr_verify_values(const GrumpkinTables &T, const Fr &pkx, const Fr &pky, Fr s, Fr e, uint32_t n_msg, FillMsg fill_msg, MsgBuf &m,
+                                                               uint32_t *window_table = nullptr) {
     const Fr e_raw = e;
     s = reduce_mod_q(s);
     e = reduce_mod_q(e);
@@ -538,7 +532,7 @@ __device__ __forceinline__ bool grumpkin_schnorr_verify(const GrumpkinTables &T,
     const Fr c = fr_to_canonical(gj_to_aff(acc, &inf).x);
     m.begin();
     for (uint32_t i = 0; i < 32; i++) m.put(limb_at(c, 7u - (i >> 2)) >> (24u - 8u * (i & 3u)));
-    for (uint32_t i = 0; i < n_msg; i++) m.put(msg_byte(i));
+    fill_msg([&](uint32_t, uint32_t byte) { m.put(byte); });  // (in order)
     m.end();
     const Digest d = blake2s_msg(m, 32u + n_msg);
     // digest byte i == signature byte 32 + i, i.e. the big-endian bytes of e as given
@@ -546,6 +540,21 @@ __device__ __forceinline__ bool grumpkin_schnorr_verify(const GrumpkinTables &T,
 #pragma unroll
     for (int i = 0; i < 8; i++) diff |= bswap32(d.d[i]) ^ e_raw.v[7 - i];
     return diff == 0;
+}
+
+// the same with the signature and message bytes behind accessors (the Brillig VM's black-box op reads them from its memory)
+template <class SigByte, class MsgByte>
+__device__ __forceinline__ bool grumpkin_schnorr_verify(const GrumpkinTables &T, const Fr &pkx, const Fr &pky, SigByte sig_byte, uint32_t n_msg,
+                                                        MsgByte msg_byte, MsgBuf &m, uint32_t *window_table = nullptr) {
+    Fr s = fr_zero(), e = fr_zero();
+    for (uint32_t i = 0; i < 32; i++) {  // big-endian 32-byte integers
+        const uint32_t sb = sig_byte(i) & 0xffu, eb = sig_byte(32u + i) & 0xffu;
+        const uint32_t limb = 7u - (i >> 2), sh = 24u - 8u * (i & 3u);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((uint32_t)k == limb) { s.v[k] |= sb << sh; e.v[k] |= eb << sh; }
+    }
+    return grumpkin_schnorr_verify_values(T, pkx, pky, s, e, n_msg, [&](auto put) { for (uint32_t i = 0; i < n_msg; i++) put(i, msg_byte(i)); }, m, window_table);
 }
 
 // [K_SCHNORR, opcode, pkx, pky, n_sig, n_msg, out, flag, sig ws..., msg ws...]
@@ -562,10 +571,10 @@ __device__ __forceinline__ OpResult op_schnorr(const P &p, const uint32_t *__res
     if (n_sig < 64u) return op_fail_msg(DE_PANIC, 5u, DM_SCHNORR_SIG_LEN, n_sig);        // lib.rs:50-52 slice panics
     if (128u + n_msg >= 1024u) return op_fail_msg(DE_PANIC, 5u, DM_SCHNORR_MSG_LEN);      // wasm/schnorr.rs:79-82
     MsgBuf m{scratch, p.Bp, p.j, 0u, 0u};
-    // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness
-    const bool ok = grumpkin_schnorr_verify(
-        T, p.load(r[2]), p.load(r[3]), [&](uint32_t i) { return fr_to_canonical(p.load(sig[i])).v[0]; }, n_msg,
-        [&](uint32_t i) { return fr_to_canonical(p.load(msg[i])).v[0]; }, m, scratch + (uint64_t)((32u + n_msg + 3u) / 4u + 1u) * p.Bp);
+    // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness, four rows in flight (ops_common.hpp)
+    const Fr s = load_be32_bytes(p, sig), e = load_be32_bytes(p, sig + 32);
+    const bool ok = grumpkin_schnorr_verify_values(
+        T, p.load(r[2]), p.load(r[3]), s, e, n_msg, [&](auto put) { load_bytes(p, msg, n_msg, put); }, m, scratch + (uint64_t)((32u + n_msg + 3u) / 4u + 1u) * p.Bp);
     if (!p.insert(r[6], ok ? fr_one() : fr_zero(), r[7])) return op_fail(DE_UNSATISFIED);
     return op_ok();
 }

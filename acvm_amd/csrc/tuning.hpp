@@ -36,8 +36,8 @@ struct Tuning {
     int64_t exact_async = 1;       // the exact path of tile k runs beside the level schedule of tile k + 1 (acvm_node_*)
     // Brillig VM limits of the device (the reference has none: brillig_vm/src/{memory.rs:27-39, lib.rs:154-307}). The level kernels run
     // with the first value; an instance that reaches it continues on the exact path, which retries with the limit raised step by
-    // step up to the second value; beyond that acvm_batch_solve returns ACVM_E_UNSUPPORTED (never a per-instance failure the
-    // reference would not report).
+    // step up to the second value; beyond that THAT instance ends with ACVM_ERR_DEVICE_LIMIT (include/acvm_amd.h: not a reference
+    // outcome, the other instances keep their results).
     int64_t brillig_steps_log2 = 22, brillig_steps_max_log2 = 26;
     int64_t brillig_call_depth = 64, brillig_call_depth_max = 1 << 16;
     int64_t brillig_mem_max_log2 = 22;  // cells of one lane's memory on the exact path at most (32 B each)

@@ -36,16 +36,15 @@
 extern "C" {
 #endif
 
-#define ACVM_AMD_ABI_VERSION 3
+#define ACVM_AMD_ABI_VERSION 4
 
 /* library-level error codes */
 enum {
     ACVM_OK = 0,
     ACVM_E_INVALID = -1,     /* bad argument / handle */
     ACVM_E_MALFORMED = -2,   /* circuit bytes do not decode (the reference would panic in bincode::deserialize) */
-    ACVM_E_UNSUPPORTED = -3, /* opcode outside the accelerated set -- refused at batch creation; or, from a solve call, an instance whose
-                                Brillig program exceeds the device's stated VM limits (steps / call depth / memory, see acvm_tuning_set): the
-                                reference has no such limit, so the SOLVE fails, never the instance */
+    ACVM_E_UNSUPPORTED = -3, /* opcode outside the accelerated set -- refused at batch creation (an instance whose Brillig program
+                                exceeds the device's VM limits is a per-instance outcome, ACVM_ERR_DEVICE_LIMIT, not a failed call) */
     ACVM_E_DEVICE = -4,      /* no gfx950 device / HIP runtime error */
     ACVM_E_STATE = -5,       /* call not valid in the current state (reference: panic) */
     ACVM_E_NOMEM = -6        /* host allocation failed (nothing unwinds through this ABI) */
@@ -64,8 +63,17 @@ enum {
     ACVM_ERR_INDEX_OOB = 5,            /* IndexOutOfBounds{index = aux0, array_size = aux1} */
     ACVM_ERR_BLACKBOX_FAILED = 6,      /* BlackBoxFunctionFailed(func = aux0, message) */
     ACVM_ERR_BRILLIG_FAILED = 7,       /* BrilligFunctionFailed{message, call_stack} */
-    ACVM_ERR_PANIC = 8                 /* the reference would panic at this opcode (message) */
+    ACVM_ERR_PANIC = 8,                /* the reference would panic at this opcode (message) */
+    /* NOT a reference outcome. The reference's Brillig VM has no resource limits (brillig_vm/src/memory.rs:27-39, lib.rs:154-307); the device
+     * runs a program with limits, raises them on the exact path, and past the stated maxima of the library (acvm_tuning_set: brillig_steps_max_log2,
+     * brillig_call_depth_max, brillig_mem_max_log2) or of the device's memory THIS INSTANCE ends here: status Failure at its Brillig opcode,
+     * aux0 = ACVM_LIMIT_* (what was reached), aux1 = the limit. It says "this library could not finish the instance", not "the circuit is
+     * unsatisfied": re-run the instance with the reference (or with raised maxima). Every other instance of the batch keeps its result, as the
+     * reference's caller loop loses one instance at most (acvm_js/src/execute.rs:60-119). */
+    ACVM_ERR_DEVICE_LIMIT = 9
 };
+enum { ACVM_LIMIT_BRILLIG_STEPS = 1, ACVM_LIMIT_BRILLIG_CALL_DEPTH = 2, ACVM_LIMIT_BRILLIG_MEMORY = 3 /* cells of 32 bytes */,
+       ACVM_LIMIT_DEVICE_MEMORY = 4 /* MiB of VM scratch the device could not provide */ };
 
 /* Per-instance outcome. Same layout and numbering as the CPU oracle's result record. */
 typedef struct {
@@ -170,8 +178,8 @@ long long acvm_device_release_tables(int device);
  * the parity tests sweep them against the oracle; the defaults are the measured optimum. The limits: the reference's Brillig VM has
  * none (brillig_vm/src/memory.rs:27-39 grows memory on write, lib.rs:154-307 runs any number of steps at any call depth); the device
  * runs with brillig_steps_log2 / brillig_call_depth / the planner's memory estimate, retries an instance that reaches one with the
- * limit raised, and past brillig_steps_max_log2 / brillig_call_depth_max / brillig_mem_max_log2 the solve call returns
- * ACVM_E_UNSUPPORTED. Command-line tools may preset values through the environment: ACVM_TUNING="key=value,key=value".
+ * limit raised, and past brillig_steps_max_log2 / brillig_call_depth_max / brillig_mem_max_log2 that instance ends with
+ * ACVM_ERR_DEVICE_LIMIT (the others keep their results). Command-line tools may preset values through the environment: ACVM_TUNING="key=value,key=value".
  */
 int acvm_tuning_set(const char *key, long long value);
 int acvm_tuning_get(const char *key, long long *value);
@@ -206,6 +214,16 @@ acvm_circuit_t *acvm_circuit_from_bytes(const uint8_t *bytes, size_t len);
 void acvm_circuit_free(acvm_circuit_t *c);
 uint32_t acvm_circuit_num_opcodes(const acvm_circuit_t *c);
 uint32_t acvm_circuit_num_witnesses(const acvm_circuit_t *c); /* 1 + highest witness index referenced */
+/*
+ * ACVM::opcodes (acvm/src/pwg/mod.rs:166-168) seen through the ABI: for opcodes [first, first + n) of the circuit, kinds[2 i] = the variant of
+ * acir::circuit::Opcode in declaration order (opcodes.rs:15-34: 0 Arithmetic, 1 BlackBoxFuncCall, 2 Directive, 3 Brillig, 4 MemoryOp,
+ * 5 MemoryInit) and kinds[2 i + 1] = what tells its instances apart at a glance: the BlackBoxFuncCall variant (black_box_function_call.rs:20-115,
+ * the tags of ACVM_ERR_UNSUPPORTED_BLACKBOX's aux0), the Directive variant (0 Quotient, 1 ToLeRadix, 2 PermutationSort), the length of a
+ * Brillig bytecode, the block id of a memory opcode, 0 for Arithmetic. With acvm_circuit_num_opcodes and acvm_result_t.opcode_index (the
+ * instruction pointer) a binding serves `opcodes()` from the Vec<Opcode> it was constructed with and can assert it is the circuit the
+ * handle runs.
+ */
+int acvm_circuit_opcode_kinds(const acvm_circuit_t *c, uint32_t first, uint32_t n, uint32_t *kinds /*[n][2]*/);
 /* Host-only levelisation against a set of initial witness ids (no device needed): plan statistics in *out. Returns 0, or
  * ACVM_E_UNSUPPORTED (reason in acvm_last_error) if the circuit holds an opcode no kernel implements. */
 int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out);
@@ -325,6 +343,23 @@ int acvm_circuit_witness_set(const acvm_circuit_t *c, int which, uint32_t *out, 
  * formats of acir_field/src/generic_ark.rs:13-74 and acir/src/circuit/opcodes.rs:88-102 (needs `c`; without it the text ends after "unknowns ").
  */
 int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, char *out, size_t cap);
+/*
+ * The same expression as DATA: OpcodeNotSolvable::ExpressionHasTooManyUnknowns(Expression) (acvm/src/pwg/mod.rs:72-78) carries the opcode
+ * partially evaluated on the instance's witness map (arithmetic.rs:31,38-42; for Opcode::Brillig the offending input expression as written,
+ * brillig.rs:46-74), and a binding rebuilds that variant from it instead of from a Default::default(). Returns 1 and fills *head and the
+ * arrays when `instance` failed with ACVM_ERR_TOO_MANY_UNKNOWNS, 0 (head zeroed) when it did not. Expression (acir/src/native_types/
+ * expression/mod.rs:17-28) = sum mul_coef[i] * w[mul_witnesses[2 i]] * w[mul_witnesses[2 i + 1]] + sum lin_coef[i] * w[lin_witnesses[i]] + q_c,
+ * terms in the order the reference's evaluate() leaves them (mul terms that stay, then mul terms that folded into linear ones, then the
+ * linear terms); coefficients canonical 32-byte big-endian. Up to cap_mul / cap_lin terms are written (any array may be NULL); head has the counts.
+ */
+typedef struct {
+    uint32_t n_mul, n_lin;
+    uint32_t opcode_index; /* the opcode that could not be solved */
+    uint8_t q_c[32];
+} acvm_expression_t;
+int acvm_batch_error_expression(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t instance, acvm_expression_t *head, uint8_t *mul_coef_be32,
+                                uint32_t *mul_witnesses /*[cap_mul][2]*/, uint32_t cap_mul, uint8_t *lin_coef_be32, uint32_t *lin_witnesses,
+                                uint32_t cap_lin);
 /*
  * Per-instance 32-byte digest of the solved witness map for instances [first, first + n), out32 = [n][32] (SURVEY 8d, config 5:
  * callers that keep only the return witnesses use it to compare whole maps without moving them -- the map of the reference is

@@ -1,9 +1,10 @@
 """The reference's Brillig VM has no resource limits: memory grows on write (brillig_vm/src/memory.rs:27-39), a program runs any number of
 steps at any call depth (brillig_vm/src/lib.rs:154-307). The device runs with limits (csrc/tuning.hpp) and must never turn a program
 the reference solves into a failing instance: a lane that reaches a limit leaves the level schedule and the exact path retries its
-opcode with the limit raised (batch.cpp retry_device_limits); only past the library's stated maxima does the SOLVE CALL fail
-(ACVM_E_UNSUPPORTED), never the instance. Checked here against the oracle (which has no such limits), through the level schedule,
-through the exact path, and one opcode at a time."""
+opcode with the limit raised (batch.cpp retry_device_limits). Past the library's stated maxima THAT instance ends with the one outcome the
+reference does not have -- Failure / ACVM_ERR_DEVICE_LIMIT, "solve it with the reference" -- and every other instance of the batch keeps its
+result (the reference's caller loop loses one instance at most, acvm_js/src/execute.rs:60-119). Checked here against the oracle (which has
+no such limits), through the level schedule, through the exact path, through the node driver, and one opcode at a time."""
 import pytest
 
 from acvm_amd.acir import Brillig, Circuit, Expression as E
@@ -31,17 +32,43 @@ def test_memory_grows_beyond_the_planner_estimate(oracle):
     assert all(r.status == 0 for r in ores)
 
 
-def test_memory_beyond_the_stated_maximum_fails_the_solve_call_not_the_instance(oracle):
+def others_survive(oracle, circ, ids, rows, over, kind, **limits):
+    """instance `over` is beyond a stated maximum: it alone ends with ACVM_ERR_DEVICE_LIMIT (aux0 = kind) at the Brillig opcode; every other
+    instance has the oracle's result and witness map -- through the level schedule and with every instance forced through the exact path"""
+    import numpy as np
     import acvm_amd
-    circ = Circuit(3, [store_far()])
-    with acvm_amd.tuning(brillig_mem_max_log2=12):
+    data, values = circ.to_bytes(), values_from_rows(rows)
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, values, len(rows))
+    assert all(r.status == 0 for r in ores)  # the reference solves all of them
+    with acvm_amd.tuning(**limits):
+        for force in (False, True):
+            batch = acvm_amd.Batch(acvm_amd.Circuit(data), len(rows), ids)
+            batch.set_initial_witness(values)
+            batch.set_force_slow_path(force)
+            assert batch.solve() == 1  # the call succeeds: one instance is not Solved
+            res = batch.results()
+            asg, vals = batch.witness_map()
+            for j in range(len(rows)):
+                if j == over:
+                    assert (res[j].status, res[j].err, res[j].opcode_index, res[j].aux0) == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_DEVICE_LIMIT, 0, kind)
+                    assert b"reference has no such limit" in res[j].message
+                    assert "Not solved by this library" in batch.error_string(j)
+                else:
+                    assert res[j].as_tuple() == ores[j].as_tuple()
+                    assert np.array_equal(asg[j], oasg[j][: asg.shape[1]]) and np.array_equal(vals[j], ovals[j][: vals.shape[1]])
+            batch.free()
+        return res[over]
+
+
+def test_memory_beyond_the_stated_maximum_fails_the_instance_not_the_call(oracle):
+    import acvm_amd
+    circ = Circuit(4, [store_far(), E([], [(1, 3), (-1, 4)], 0)])
+    r = others_survive(oracle, circ, [1, 2], [[5, 1], [3000, 2], [100000, 3], [7, 4]], over=2, kind=acvm_amd.LIMIT_BRILLIG_MEMORY, brillig_mem_max_log2=12)
+    assert r.aux1 == 1 << 12 and b"cell 100000" in r.message
+    with acvm_amd.tuning(brillig_mem_max_log2=12):  # the same handle serves the next batch
         batch = acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), 3, [1, 2])
-        batch.set_initial_witness(values_from_rows([[5, 1], [3000, 2], [100000, 3]]))  # the last one needs more than 2^12 cells
-        with pytest.raises(acvm_amd.AcvmError, match="error -3.*instance 2.*memory cell 100000"):
-            batch.solve()
-        with pytest.raises(acvm_amd.AcvmError, match="not solved"):
-            batch.results()
-        # the same handle, inputs the device can hold: solves
+        batch.set_initial_witness(values_from_rows([[5, 1], [3000, 2], [100000, 3]]))
+        assert batch.solve() == 1
         batch.set_initial_witness(values_from_rows([[5, 1], [3000, 2], [4000, 3]]))
         assert batch.solve() == 0
 
@@ -65,14 +92,12 @@ def test_step_limit_is_raised_for_long_loops(oracle):
     assert all(r.status == 0 for r in ores)
 
 
-def test_step_limit_past_the_maximum_fails_the_solve_call(oracle):
+def test_step_limit_past_the_maximum_fails_the_instance(oracle):
     import acvm_amd
-    circ = Circuit(2, [counting_loop()])
-    with acvm_amd.tuning(brillig_steps_log2=8, brillig_steps_max_log2=12):
-        batch = acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), 2, [1])
-        batch.set_initial_witness(values_from_rows([[10], [5000]]))  # 20 000 steps > 2^12
-        with pytest.raises(acvm_amd.AcvmError, match="error -3.*instance 1.*VM steps"):
-            batch.solve()
+    circ = Circuit(3, [counting_loop(), E([], [(1, 2), (-1, 3)], 0)])
+    r = others_survive(oracle, circ, [1], [[10], [5000], [300], [0]], over=1, kind=acvm_amd.LIMIT_BRILLIG_STEPS,  # 20 000 steps > 2^12
+                       brillig_steps_log2=8, brillig_steps_max_log2=12)
+    assert r.aux1 == 1 << 12
 
 
 def recursion(out=2):
@@ -93,14 +118,32 @@ def test_call_depth_beyond_64(oracle):
     assert all(r.status == 0 for r in ores)
 
 
-def test_call_depth_past_the_maximum_fails_the_solve_call(oracle):
+def test_call_depth_past_the_maximum_fails_the_instance(oracle):
     import acvm_amd
-    circ = Circuit(2, [recursion()])
-    with acvm_amd.tuning(brillig_call_depth_max=128):
-        batch = acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), 2, [1])
-        batch.set_initial_witness(values_from_rows([[100], [500]]))
-        with pytest.raises(acvm_amd.AcvmError, match="error -3.*instance 1.*calls"):
-            batch.solve()
+    circ = Circuit(3, [recursion(), E([], [(1, 2), (-1, 3)], 0)])
+    r = others_survive(oracle, circ, [1], [[100], [500], [3], [90]], over=1, kind=acvm_amd.LIMIT_BRILLIG_CALL_DEPTH, brillig_call_depth_max=128)
+    assert r.aux1 == 128
+
+
+def test_node_driver_returns_the_other_instances(oracle):
+    """acvm_node_solve over tiles with the exact path beside the next tile: the instance past a maximum comes back as ACVM_ERR_DEVICE_LIMIT in the
+    caller's arrays, the 199 others as the oracle has them"""
+    import numpy as np
+    import acvm_amd
+    circ = Circuit(4, [store_far(), E([], [(1, 3), (-1, 4)], 0)])
+    rows = [[5 + (j % 40), j + 1] for j in range(200)]
+    rows[77] = [100000, 9]
+    data, values = circ.to_bytes(), values_from_rows(rows)
+    ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), [1, 2], values, len(rows))
+    with acvm_amd.tuning(brillig_mem_max_log2=12):
+        node = acvm_amd.Node(acvm_amd.Circuit(data), [1, 2], keep=[4], devices=[0, 0], tile=64)
+        not_solved, res, kept, asg, dig = node.solve(values, len(rows))
+        node.free()
+    assert not_solved == 1 and (res[77].status, res[77].err, res[77].aux0) == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_DEVICE_LIMIT, acvm_amd.LIMIT_BRILLIG_MEMORY)
+    for j in range(len(rows)):
+        if j != 77:
+            assert res[j].as_tuple() == ores[j].as_tuple() and asg[j, 0] == 1 and bytes(kept[j, 0]) == bytes(ovals[j][4])
+            assert bytes(dig[j]) == oracle.witness_map_digest(oasg[j], ovals[j])
 
 
 def test_a_failing_program_still_fails_after_a_retry(oracle):

@@ -175,15 +175,48 @@ def test_too_many_unknowns_quotes_the_evaluated_expression():
         lin = ([((5 * w1) % P, 8)] if (5 * w1) % P else []) + [(2, 8), (11, 9)]
         qc = (3 * w1 * w2 + 7 * w3 - (1 << 64) * w2 + 100) % P
         assert b.error_string(j) == "Cannot solve opcode: expression has too many unknowns " + expr_display([], lin, qc), j
+        # ... and as data (acvm_batch_error_expression): what a binding rebuilds OpcodeNotSolvable::ExpressionHasTooManyUnknowns(Expression) from
+        assert b.error_expression(j) == {"opcode_index": 0, "mul": [], "lin": lin, "q_c": qc}, j
     # two unknown multiplicands stay a mul term; a bare unknown witness prints as x{w}
     circ = Circuit(9, [E([(P - 2, 8, 9)], [(1, 1)], 0)])
     c, b = solve(circ, [1], [[5]])
     assert b.error_string(0) == "Cannot solve opcode: expression has too many unknowns " + expr_display([(P - 2, 8, 9)], [], 5)
+    assert b.error_expression(0) == {"opcode_index": 0, "mul": [(P - 2, 8, 9)], "lin": [], "q_c": 5}
     # Brillig: the input expression as written (brillig.rs:46-74), the first one that does not reduce to a constant
     br = Brillig(inputs=[E.from_witness(1), [E([], [(1, 1), (3, 9)], 4), E.from_witness(8)], E.from_witness(8)], outputs=[7], bytecode=[("Stop",)])
     circ = Circuit(9, [br])
     c, b = solve(circ, [1], [[5]])
     assert b.error_string(0) == "Cannot solve opcode: expression has too many unknowns " + expr_display([], [(1, 1), (3, 9)], 4)
+    assert b.error_expression(0) == {"opcode_index": 0, "mul": [], "lin": [(1, 1), (3, 9)], "q_c": 4}
     br = Brillig(inputs=[E.from_witness(8)], outputs=[7], bytecode=[("Stop",)])
     c, b = solve(Circuit(9, [br]), [1], [[5]])
     assert b.error_string(0) == "Cannot solve opcode: expression has too many unknowns x8"
+    assert b.error_expression(0) == {"opcode_index": 0, "mul": [], "lin": [(1, 8)], "q_c": 0}
+    # an instance that solved (or failed otherwise) carries no such expression; ACVM::opcodes through the ABI
+    c, b = solve(Circuit(3, [E([], [(1, 1), (P - 1, 2)], 0), E([], [(1, 2)], 0)]), [1], [[0], [5]])
+    assert b.error_expression(0) is None and b.error_expression(1) is None and b.results()[1].err == acvm_amd_err("UNSATISFIED")
+
+
+def acvm_amd_err(name):
+    import acvm_amd
+    return getattr(acvm_amd, "ERR_" + name)
+
+
+def test_opcode_kinds_mirror_the_circuit():
+    """acvm_circuit_opcode_kinds: ACVM::opcodes (pwg/mod.rs:166-168) as (variant, sub-kind) per opcode, for the seven reference circuits' opcode mix"""
+    import acvm_amd
+    from acvm_amd import synth
+    circ, ids = synth.mixed_circuit(400, seed=0x0C0DE)
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    kinds = gc.opcode_kinds()
+    assert len(kinds) == len(circ.opcodes) == gc.num_opcodes
+    names = {"Expression": (0, 0), "BlackBoxFuncCall": (1, None), "QuotientDirective": (2, 0), "ToLeRadix": (2, 1), "PermutationSort": (2, 2),
+             "Brillig": (3, None), "MemoryOp": (4, None), "MemoryInit": (5, None)}
+    assert len({k for k, _ in kinds}) >= 5  # the mix holds most variants
+    for (k, sub), op in zip(kinds, circ.opcodes):
+        want_k, want_sub = names[type(op).__name__]
+        assert k == want_k and (want_sub is None or sub == want_sub), (k, sub, type(op).__name__)
+        if k == 3:
+            assert sub == len(op.bytecode)
+        if k in (4, 5):
+            assert sub == op.block_id

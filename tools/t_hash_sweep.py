@@ -9,7 +9,8 @@ section 9 asserted without ("the phases overlap once a launch holds more items t
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acvm_amd  # noqa: E402
 from acvm_amd import synth  # noqa: E402
 from acvm_amd.acir import BlackBoxFuncCall as BB, Circuit, FunctionInput as FI  # noqa: E402

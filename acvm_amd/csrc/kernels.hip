@@ -71,9 +71,10 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
         const uint64_t j = j0 + ji;
         const uint32_t k = k0 + kk;
         if (j < B && k < n_in) {
-            uint4 *row = W + (uint64_t)ids[k] * 2u * Bp + j;
-            row[0] = tile[kk][0][ji];
-            row[Bp] = tile[kk][1][ji];
+            // (nontemporal like the level kernels' stores: the rows are read by later launches, not by this one)
+            const uint4 lo = tile[kk][0][ji], hi = tile[kk][1][ji];
+            const Fr m = {{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+            fr_store_nt(W, ids[k], Bp, j, m);
         }
     }
 }

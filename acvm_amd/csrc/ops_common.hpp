@@ -305,8 +305,7 @@ __device__ __forceinline__ uint32_t fr_low_limb(const Fr &a, bool &is_byte) {
 // to_u8_vec (acvm/src/pwg/blackbox/signature/mod.rs:5-18: the last big-endian byte of each witness) of 32 witnesses, read as ONE big-endian
 // 256-bit integer (limbs little-endian): a signature half, a public-key coordinate, a hashed message. Four rows are in flight per lane and
 // the byte comes from the table path (fr_low_limb), where one row at a time with a Montgomery reduction apiece (160 per ECDSA opcode, 74 per
-// SchnorrVerify) left the one wave a SIMD holds waiting for every row in turn -- 0.55 / 0.86 ms of a 2^16-instance launch whose rows the
-// import had just pushed out of the memory-side cache (tools/t_step_gap.py, round 4).
+// SchnorrVerify) left the one wave a SIMD holds waiting for every row in turn.
 template <class P>
 static __device__ __noinline__ Fr load_be32_bytes(const P &p, const uint32_t *__restrict__ ws) {
     Fr r = fr_zero();

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "acvm_last_error", "acvm_abi_version", "acvm_device_count", "acvm_set_device", "acvm_device_synchronize",
     "acvm_device_arch", "acvm_selftest", "acvm_debug_grumpkin", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
     "acvm_circuit_num_witnesses", "acvm_circuit_plan_stats", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
-    "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_reset", "acvm_batch_set_instances", "acvm_batch_set_force_slow_path",
+    "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_solve_then_import", "acvm_batch_reset", "acvm_batch_set_instances", "acvm_batch_set_force_slow_path",
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
     "acvm_batch_set_profiling", "acvm_batch_pending_foreign_call", "acvm_batch_pending_foreign_call_inputs",
     "acvm_batch_resolve_foreign_call", "acvm_circuit_assert_message", "acvm_circuit_witness_set", "acvm_batch_error_string",
@@ -244,6 +244,7 @@ def lib():
     L.acvm_batch_set_initial_witness.argtypes = [C.c_void_p, C.c_void_p]
     L.acvm_batch_set_initial_witness_device.argtypes = [C.c_void_p, C.c_void_p]
     L.acvm_batch_solve.argtypes = [C.c_void_p]
+    L.acvm_batch_solve_then_import.argtypes = [C.c_void_p, C.c_void_p]
     L.acvm_batch_reset.argtypes = [C.c_void_p]
     L.acvm_batch_set_instances.argtypes = [C.c_void_p, C.c_uint32]
     L.acvm_batch_set_force_slow_path.argtypes = [C.c_void_p, C.c_int]
@@ -618,7 +619,11 @@ class Batch:
             raise ValueError("initial witness buffer has the wrong size")
         _check(lib().acvm_batch_set_initial_witness(self._h, buf.ctypes.data))
 
-    def solve(self) -> int:
+    def solve(self, then_import: int = 0) -> int:
+        """ACVM::solve for every instance; then_import: device pointer of the NEXT tile's inputs, imported behind the solve when no instance
+        left the generic path (acvm_batch_solve_then_import)"""
+        if then_import:
+            return _check(lib().acvm_batch_solve_then_import(self._h, then_import))
         return _check(lib().acvm_batch_solve(self._h))
 
     def solve_opcode(self) -> int:

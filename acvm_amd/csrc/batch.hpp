@@ -121,6 +121,10 @@ struct acvm_batch {
     uint32_t *d_ped_seed = nullptr;  // seed table of the level Pedersen kernel (one row per Pedersen record)
     uint4 *d_inv = nullptr;  // inverse table: [plan.n_inverse_slots][2 halves][Bp] x 16 B
     uint32_t n_launches = 0;
+    // the next tile's import behind this solve (acvm_batch_solve_then_import): the caller's device buffer, and whether the import ran
+    const void *next_inputs = nullptr;
+    bool next_imported = false;
+    hipEvent_t ev_counted = nullptr;  // behind the event count of a solve: what the host waits for instead of the whole stream
     bool holds_tables = false;  // a reference on the device's lookup-table set (grumpkin_host.hpp device_tables_retain)
     // caller-supplied BlackBoxFunctionSolver
     bool has_solver = false;
@@ -204,6 +208,7 @@ struct acvm_batch {
         if (stream_dyn) hipStreamDestroy(stream_dyn);
         if (ev_start) hipEventDestroy(ev_start);
         if (ev_end) hipEventDestroy(ev_end);
+        if (ev_counted) hipEventDestroy(ev_counted);
         if (stream) hipStreamDestroy(stream);
         if (holds_tables) device_tables_unref(device);
     }

@@ -20,11 +20,14 @@ namespace acvm {
 // bytes of `in` (one line per four lanes, where one lane per (instance, input) had every lane fetch its own 32 bytes from a line of its own),
 // and the values reach the table through LDS, 64 lanes to a row (1 KiB contiguous per half). ALIGNED: `in` is 16-byte aligned (every
 // buffer of the library is; a caller's device pointer may not be) and the bytes travel as two 16-byte loads.
+// gate: null, or a device word that must be zero for the import to happen (the count of instances that left the generic path in the solve
+// the import was enqueued behind: batch.cpp "the next tile's import behind the solve").
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
                                                              const uint8_t *__restrict__ in, const uint32_t *__restrict__ ids,
-                                                             uint32_t n_in) {
+                                                             uint32_t n_in, const uint32_t *__restrict__ gate) {
     __shared__ uint4 tile[4][2][65];
+    if (gate && *gate != 0u) return;  // (block-uniform)
     const uint32_t t = threadIdx.x;
     const uint64_t j0 = (uint64_t)blockIdx.x * 64u;
     const uint32_t k0 = blockIdx.y * 4u;
@@ -326,11 +329,11 @@ __global__ void init_assigned_kernel(uint32_t *assigned, uint32_t n_slow, uint32
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in) {
+void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate) {
     if (!B || !n_in) return;
     const dim3 grid((B + 63u) / 64u, (n_in + 3u) / 4u);
-    if (((uintptr_t)in & 15u) == 0) hipLaunchKernelGGL(import_witness_kernel<true>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in);
-    else hipLaunchKernelGGL(import_witness_kernel<false>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in);
+    if (((uintptr_t)in & 15u) == 0) hipLaunchKernelGGL(import_witness_kernel<true>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate);
+    else hipLaunchKernelGGL(import_witness_kernel<false>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate);
 }
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out,
                    const Unscale &u, const uint32_t *row_of) {

@@ -76,7 +76,7 @@ struct Unscale {
     const uint32_t *event;       // per instance: 0xFFFFFFFF = solved by the level kernels (its column is still scaled)
 };
 
-void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in);
+void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate = nullptr);
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
                    uint8_t *out, const Unscale &u, const uint32_t *row_of = nullptr);
 void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,

@@ -30,9 +30,18 @@ class ResidentShard:
         if self.starts[-1] + self.tile < n:
             self.starts.append(n - self.tile)
 
+    def tile_ptr(self, k: int) -> int:
+        return self.buf.ptr + self.starts[k % len(self.starts)] * self.row
+
     def load_tile(self, k: int):
-        """ACVM::new for tile k from the resident buffer"""
-        self.batch.set_initial_witness_device(self.buf.ptr + self.starts[k] * self.row)
+        """ACVM::new for tile k from the resident buffer (free when the previous solve_tile already brought it in)"""
+        self.batch.set_initial_witness_device(self.tile_ptr(k))
+
+    def solve_tile(self, k: int, pipelined=True) -> int:
+        """ACVM::solve of tile k (loaded before); pipelined: the import of tile k + 1 (cyclically: the next pass starts over) rides behind the solve
+        (acvm_batch_solve_then_import), so that the device does not idle across the tile boundary. Only for passes that read nothing of the
+        initial witnesses between tiles."""
+        return self.batch.solve(then_import=self.tile_ptr(k + 1) if pipelined else 0)
 
     def solve_pass(self, on_tile=None):
         """one pass over the shard; on_tile(k, first_new, first_in_tile) runs after tile k's solve, while its table is live:

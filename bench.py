@@ -410,7 +410,7 @@ def run_leg(name, total_log2=16, tile_log2=16, steps=3, warmup=2, pmc=True):
             if i == steps - 1 and k == n_tiles - 1:
                 batch.set_profiling(True)
             sh.load_tile(k)
-            batch.solve()
+            sh.solve_tile(k)
             if i == steps - 1:
                 solve_ms += batch.stats()["solve_device_ms"]
     acvm_amd.synchronize()
@@ -475,6 +475,7 @@ def main():
     ap.add_argument("--no-digest", action="store_true", help="skip the digest-of-digests pass")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the other_workloads legs of the default run")
+    ap.add_argument("--no-pipeline", action="store_true", help="plain acvm_batch_solve per tile instead of acvm_batch_solve_then_import (A/B of the tile boundary)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the one-tile run the PMC passes profile
     args = ap.parse_args()
     if args.gates is None:
@@ -551,7 +552,8 @@ def main():
                 # the same step for every N and every tile count: ACVM::new of the tile (import of its resident inputs into the reused table),
                 # then ACVM::solve
                 sh.load_tile(k)
-                n_failed += batch.solve()
+                # (the next tile's import rides behind this solve: acvm_batch_solve_then_import; config 5 reads the map's digest between tiles)
+                n_failed += sh.solve_tile(k, pipelined=not config5 and not args.no_pipeline)
                 if i == args.steps - 1:
                     dev_ms += batch.stats()["solve_device_ms"]
                 if config5:  # what config 5 keeps of a tile: the per-instance digest of the map (the return witness rides along)
@@ -652,7 +654,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{workload_name}, batch 2^{total.bit_length() - 1} witnesses over {world} GPU(s)", "opcodes": st["n_opcodes"],
                    "global_batch": total, "instances_per_gpu": n_rank, "tile_instances": tile, "tiles_per_gpu_per_step": n_tiles, "levels": st["n_levels"],
-                   "step": "per tile: import of the resident inputs (ACVM::new) + solve, the same for every N",
+                   "step": "per tile: import of the resident inputs (ACVM::new) + solve, the same for every N"
+                           + ("" if config5 or args.no_pipeline else "; the next tile's import is enqueued behind the solve (acvm_batch_solve_then_import)"),
                    "not_solved_rank0_all_steps": n_failed, "slow_path_instances_last_tile": st["n_slow_instances"],
                    "algorithmic_bytes_per_witness": st["algorithmic_bytes_per_instance"], "brillig_opcodes_inlined": st["n_brillig_inlined"],
                    "device_ms_per_step_rank0": dev_ms, "inputs_resident_setup_s_rank0": round(h2d_resident_s, 3), "host_cores": os.cpu_count(),

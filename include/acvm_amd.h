@@ -266,6 +266,18 @@ int acvm_device_upload(void *dst_device, const void *src_host, size_t bytes);
 /* ACVM::solve for every instance. Returns the number of instances not Solved, or a negative error. */
 int acvm_batch_solve(acvm_batch_t *b);
 /*
+ * The same solve for a caller that runs tile after tile through one handle (a 10k-gate circuit at 2^20 instances is eight tiles of one
+ * handle's table): d_next_values_be32 is the device buffer of the NEXT tile's initial witnesses (layout of acvm_batch_set_initial_witness_device,
+ * valid until the solve after this one returns). Its import is enqueued behind this solve and gated on the device: it runs if, and only if, no
+ * instance of this solve left the generic path (the exact path needs this tile's rows otherwise). The call returns when this solve's outcome
+ * is known, while that import may still be running; the following acvm_batch_set_initial_witness_device with the SAME pointer then costs
+ * nothing (or performs the import, had it been held back), and the next tile's kernels follow the import without a gap. Until then results,
+ * statistics and every witness that is not an initial one can be read as after acvm_batch_solve; reading an initial witness, a whole map
+ * or an unfolded digest returns ACVM_E_STATE -- those rows may already hold the next tile. Not with a caller-supplied solver, stepping or
+ * resumed foreign calls (then it is acvm_batch_solve). The reference has no counterpart: one ACVM solves one instance (pwg/mod.rs:236-241).
+ */
+int acvm_batch_solve_then_import(acvm_batch_t *b, const void *d_next_values_be32);
+/*
  * ACVM::solve_opcode (acvm/src/pwg/mod.rs:243-303) for the batch: executes ONE opcode -- the one at the smallest instruction
  * pointer among the instances that are InProgress -- for every InProgress instance standing on it, through the exact in-order
  * kernels (one lane per instance). Instances only ever differ in their instruction pointer after a foreign call: one that

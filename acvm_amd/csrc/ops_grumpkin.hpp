@@ -486,7 +486,8 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
     // 2.30 -> 2.37 ms per 65 536 verifications; the rows are loaded where they are added)
     const SignedDigits d1 = signed_windows5(sp.k1), d2 = signed_windows5(sp.k2);
     for (int w = 25; w >= 0; w--) {
-        a = gj_dbl(gj_dbl(gj_dbl(gj_dbl(gj_dbl(a)))));
+#pragma unroll 1
+        for (int k = 0; k < 5; k++) a = gj_dbl(a);  // (one copy of the doubling: with the addition below the loop stays inside the instruction cache)
         for (uint32_t half = 0; half < 2; half++) {  // wave-uniform
             const uint32_t sd = half ? signed_digit(d2, (uint32_t)w) : signed_digit(d1, (uint32_t)w);
             const uint32_t d = sd & 31u;

@@ -1201,9 +1201,13 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
     bool lane_any[N_HEAVY_LANES] = {false, false, false, false};  // a lane without records never joins the schedule (nor a capture)
     for (int k = 0; k < (int)N_CLS; k++)
         if (heavy_cls(k) && !p.cls_offset[k].empty()) { any_heavy = true; lane_any[heavy_lane(k)] = true; }
-    // (a circuit of heavy records only keeps everything on one stream: with the lanes side by side config 4 measured 2.62 ... 3.03 ms per solve
-    // from run to run against a steady 2.84-2.89 on one stream, and config 3 0.18 instead of 0.15 ms)
-    const bool one_stream = !p.tune.overlap || !p.tune.heavy_streams || !any_main;
+    // A circuit of heavy records only kept everything on one stream until round 4 (round 2 had measured config 4 at 2.62 ... 3.03 ms from run to run
+    // with the lanes side by side against a steady 2.84-2.89 on one stream, and config 3 0.18 instead of 0.15 ms). But a record kernel of the
+    // integer-bound classes that follows a large launch -- the import of its tile -- on the SAME stream runs 16-44 % longer than on a stream of its
+    // own (profiles/r04_import_effect.txt: config 4 import + solve 3.27 -> 2.15 ms, ECDSA 3.83 -> 3.32 ms per 2^16): such circuits take the lanes'
+    // streams too (tuning heavy_only_streams); a circuit of byte-message hashes alone stays on the main stream.
+    const bool integer_bound = !p.cls_offset[CLS_GRUMPKIN].empty() || !p.cls_offset[CLS_PEDERSEN].empty() || !p.cls_offset[CLS_ECDSA].empty() || !p.cls_offset[CLS_BRILLIG].empty();
+    const bool one_stream = !p.tune.overlap || !p.tune.heavy_streams || (!any_main && !(p.tune.heavy_only_streams && integer_bound));
     hipStream_t lane_stream[N_HEAVY_LANES] = {one_stream ? s : b->stream_heavy, one_stream ? s : b->stream_heavy2, one_stream ? s : b->stream_heavy3,
                                               one_stream ? s : b->stream_digest};
     bool any_dyn = !p.dyn_offset.empty();

@@ -161,8 +161,7 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__rest
     {   // the head's inputs: every wave of the item fetches
         const uint32_t n_in = rec[3];
         const uint32_t *ins = rec + 6, *ranges = (rec[2] & HASH_RANGE_FLAG) ? ins + 2u * n_in + 64u : nullptr;
-        if (w == 0 && (n_in & 3u)) item[(n_in >> 2) * 64u + lane] = 0u;  // the bytes behind the message in its last word
-        sync();
+        // (the bytes behind the message in its last word are never read: LdsMsg::word_le masks them)
         coop_fetch_rows(p, ins, ranges, nullptr, n_in, w, WAVES, (uint8_t *)item, lane, T, range_bad);
     }
     sync();
@@ -190,7 +189,6 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__rest
         } else if (PIPE) {  // beside the hash: the predecessor's outputs, the successor's rows
             if (pend_outs && live && !coop_store_outputs(p, pend_outs, lds_dig[dcur ^ 1u], w - 1u, WAVES - 1, lane, T)) conflict = min(conflict, pend_opcode);
             if (more && two) {
-                if (w == 1 && (n_next & 3u)) nmsg[(n_next >> 2) * 64u + lane] = 0u;
                 coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w - 1u, WAVES - 1, (uint8_t *)nmsg, lane, T, range_bad);
             }
         }
@@ -204,8 +202,6 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__rest
         }
         // the successor's message: its rows (unless they came in beside the hash), then the digest bytes it reads
         if (!two) {
-            if (w == 0 && (n_next & 3u)) nmsg[(n_next >> 2) * 64u + lane] = 0u;
-            sync();
             coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w, WAVES, (uint8_t *)nmsg, lane, T, range_bad);
         }
         coop_copy_chained(link + 1u, nranges, n_next, w, WAVES, lds_dig[dcur], (uint8_t *)nmsg, lane, range_bad);

@@ -32,6 +32,9 @@ struct Tuning {
     // ---- driver (batch.cpp)
     int64_t overlap = 1;           // inversion batches and heavy lanes on streams of their own
     int64_t heavy_streams = 1;     // heavy lanes beside the main stream (0: everything on the main stream)
+    int64_t heavy_only_streams = 1; // a circuit of heavy records only: its lanes on their own streams too (0: one stream). A record kernel that follows a
+                                   // large launch -- the import of its tile -- on the SAME stream runs 16-44 % longer (profiles/r04_import_effect.txt):
+                                   // config 4 import + solve 3.27 -> 2.15 ms, ECDSA 3.83 -> 3.32 ms per 2^16
     int64_t fc_relevel = -1;       // answered foreign calls re-enter the level schedule: 1 always, 0 never, -1 when >= 1/16 of the batch was answered
     int64_t exact_async = 1;       // the exact path of tile k runs beside the level schedule of tile k + 1 (acvm_node_*)
     // Brillig VM limits of the device (the reference has none: brillig_vm/src/{memory.rs:27-39, lib.rs:154-307}). The level kernels run

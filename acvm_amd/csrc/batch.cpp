@@ -395,7 +395,7 @@ static int batch_init(acvm_batch *b) {
     for (int k = 0; k < (int)N_CLS; k++) {
         const size_t n_levels = p.n_levels;
         b->cls_chunks[k].assign(n_levels, {});
-        std::vector<uint32_t> scratch_off(p.cls_offset[k].size(), 0);
+        std::vector<uint32_t> scratch_off(2 * p.cls_offset[k].size(), 0);  // per record: (offset, words) of its per-lane scratch, in u32 words
         uint64_t need = 0;
         for (size_t L = 0; L < n_levels; L++) {
             uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
@@ -431,6 +431,17 @@ static int batch_init(acvm_batch *b) {
                     lo += n_pass[pass];
                 }
             }
+            if (k == CLS_GRUMPKIN && hi - lo > 1) {
+                // the longest records first (SchnorrVerify ~1.7 ms of one wave per SIMD, FixedBaseScalarMul 0.3): workgroups are placed in grid order,
+                // and at ~240 registers a SIMD holds two of these waves -- a long wave that arrives last waits for a slot behind short ones elsewhere
+                std::vector<std::pair<uint32_t, uint32_t>> recs;
+                for (uint32_t r = lo; r < hi; r++) recs.push_back({b->plan.cls_offset[k][r], b->plan.cls_scratch[k][r]});
+                std::stable_sort(recs.begin(), recs.end(), [&](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) {
+                    auto rank = [&](uint32_t off) { const uint32_t kind = b->plan.prog[off]; return kind == PK_SCHNORR ? 0 : kind == PK_PEDERSEN ? 1 : 2; };
+                    return rank(x.first) < rank(y.first);
+                });
+                for (uint32_t r = lo; r < hi; r++) { b->plan.cls_offset[k][r] = recs[r - lo].first; b->plan.cls_scratch[k][r] = recs[r - lo].second; }
+            }
             if (k == CLS_LIGHT) {  // straight-line Brillig records last: they have a kernel of their own (kernels_ops.hip LightSlOp)
                 auto is_sl = [&](uint32_t r) { return b->plan.prog[b->plan.cls_offset[k][r]] == PK_BRILLIG_SL; };
                 std::vector<uint32_t> offs;
@@ -454,7 +465,8 @@ static int batch_init(acvm_batch *b) {
                     first = r;
                     used = 0;
                 }
-                scratch_off[r] = (uint32_t)used;
+                scratch_off[2 * r] = (uint32_t)used;
+                scratch_off[2 * r + 1] = (uint32_t)w;
                 used += w;
                 need = std::max(need, used);
             }
@@ -1299,7 +1311,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
                 hipStream_t sk = heavy_cls(k) ? lane_stream[heavy_lane(k)] : s;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (prof) { e0 = next_event(); hipEventRecord(e0, sk); }
-                const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + ch.first;
+                const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + 2 * (size_t)ch.first;
                 switch (k) {
                 case CLS_LIGHT:
                     if (ch.coop) launch_light_sl_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event);  // (coop: the level's straight-line Brillig records)

@@ -297,8 +297,8 @@ __device__ __forceinline__ OpResult op_brillig(const P &p, const uint32_t *__res
     vm.mem_cap = lim.mem_cap ? lim.mem_cap : r[8];
     vm.cs_cap = lim.call_depth;
     vm.slots = (uint4 *)scratch;
-    vm.Bp = compact ? lim.stride : p.Bp;
-    vm.j = compact ? L->br_lane[t] : p.j;
+    vm.Bp = compact ? lim.stride : p.scratch_stride();
+    vm.j = compact ? L->br_lane[t] : p.scratch_lane();
     vm.iBp = p.Bp;
     vm.ij = p.j;
     vm.words = scratch + (uint64_t)(vm.n_regs + vm.mem_cap) * 8u * vm.Bp;

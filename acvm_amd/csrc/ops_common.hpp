@@ -358,7 +358,10 @@ struct FastPolicy {
     uint4 *W;
     uint64_t Bp, j;
     const uint32_t *__restrict__ slot_of = nullptr;  // witness -> row of the table (plan.cpp slot reuse); null: the witness index
+    uint64_t sBp = 0, sj = 0;  // stride and lane of the record's per-lane scratch (ops_kernel.hpp: per wave, stride 64); 0: the table's
     static constexpr bool exact = false;
+    __device__ __forceinline__ uint64_t scratch_stride() const { return sBp ? sBp : Bp; }
+    __device__ __forceinline__ uint64_t scratch_lane() const { return sBp ? sj : j; }
     __device__ __forceinline__ uint32_t row(uint32_t w) const { return slot_of ? slot_of[w] : w; }
     __device__ __forceinline__ bool known(uint32_t) const { return true; }
     __device__ __forceinline__ Fr load(uint32_t w) const { return fr_load(W, row(w), Bp, j); }  // (nontemporal here: config-5 mix 30.4 -> 30.8 ms, not taken)
@@ -375,6 +378,8 @@ struct ExactPolicy {
     uint32_t *assigned;
     uint32_t n_slow, t;
     static constexpr bool exact = true;
+    __device__ __forceinline__ uint64_t scratch_stride() const { return Bp; }  // (the exact lanes' scratch: [word][lane])
+    __device__ __forceinline__ uint64_t scratch_lane() const { return j; }
     __device__ __forceinline__ bool known(uint32_t w) const { return (assigned[(uint64_t)(w >> 5) * n_slow + t] >> (w & 31)) & 1u; }
     __device__ __forceinline__ Fr load(uint32_t w) const { return fr_load(W, w, Bp, j); }
     __device__ __forceinline__ bool insert(uint32_t w, const Fr &v, uint32_t) const {

@@ -571,11 +571,12 @@ __device__ __forceinline__ OpResult op_schnorr(const P &p, const uint32_t *__res
     }
     if (n_sig < 64u) return op_fail_msg(DE_PANIC, 5u, DM_SCHNORR_SIG_LEN, n_sig);        // lib.rs:50-52 slice panics
     if (128u + n_msg >= 1024u) return op_fail_msg(DE_PANIC, 5u, DM_SCHNORR_MSG_LEN);      // wasm/schnorr.rs:79-82
-    MsgBuf m{scratch, p.Bp, p.j, 0u, 0u};
+    const uint32_t msg_words = (32u + n_msg + 3u) / 4u + 1u;
+    MsgBuf m{scratch, p.scratch_stride(), p.scratch_lane(), 0u, 0u};
     // to_u8_vec (signature/mod.rs:5-18): the last big-endian byte of each witness, four rows in flight (ops_common.hpp)
     const Fr s = load_be32_bytes(p, sig), e = load_be32_bytes(p, sig + 32);
     const bool ok = grumpkin_schnorr_verify_values(
-        T, p.load(r[2]), p.load(r[3]), s, e, n_msg, [&](auto put) { load_bytes(p, msg, n_msg, put); }, m, scratch + (uint64_t)((32u + n_msg + 3u) / 4u + 1u) * p.Bp);
+        T, p.load(r[2]), p.load(r[3]), s, e, n_msg, [&](auto put) { load_bytes(p, msg, n_msg, put); }, m, scratch + (uint64_t)msg_words * p.scratch_stride());
     if (!p.insert(r[6], ok ? fr_one() : fr_zero(), r[7])) return op_fail(DE_UNSATISFIED);
     return op_ok();
 }

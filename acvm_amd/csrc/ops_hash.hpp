@@ -83,7 +83,7 @@ __device__ __forceinline__ OpResult op_hash(const P &p, const uint32_t *__restri
         if (var_w != K_NONE && !p.known(var_w)) return op_fail(DE_MISSING_ASSIGNMENT, var_w);
     }
     // get_hash_input (hash.rs:51-86): fetch_nearest_bytes = low ceil(num_bits / 8) bytes, least significant first
-    MsgBuf m{scratch, p.Bp, p.j, 0u, 0u};
+    MsgBuf m{scratch, p.scratch_stride(), p.scratch_lane(), 0u, 0u};
     m.begin();
     for (uint32_t i = 0; i < n_in;) {
         const uint32_t nb = (ins[2 * i + 1] + 7u) / 8u;

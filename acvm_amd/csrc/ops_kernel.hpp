@@ -36,8 +36,17 @@ __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t 
     dp.slot_of = slot_of;
     dp.bytecode = bytecode;
     const uint32_t *__restrict__ rec = dp.prog + offsets[blockIdx.y];
-    uint32_t *sc = scratch ? scratch + (uint64_t)scratch_off[blockIdx.y] * Bp : nullptr;
+    // The record's per-lane scratch (scratch_off: offset and words per record) is laid out per WAVE inside the words x Bp region the planner reserved:
+    // [wave][word][64 lanes]. A wave's words are consecutive 256-byte lines; laid out [word][instance] they were a power of two (4 x instances
+    // bytes) apart, and the 432-word window table of SchnorrVerify kept landing on the same few channels: config 4 ran at 2.0 or at 3.3 ms per 2^16
+    // depending on where the process's buffers happened to sit (profiles/r04_import_effect.txt).
     FastPolicy p{W, Bp, j, dp.slot_of};
+    uint32_t *sc = nullptr;
+    if (scratch) {
+        sc = scratch + (uint64_t)scratch_off[2u * blockIdx.y] * Bp + (j >> 6) * 64u * (uint64_t)scratch_off[2u * blockIdx.y + 1u];
+        p.sBp = 64u;
+        p.sj = j & 63u;
+    }
     const OpResult r = Op::run(p, rec, dp, sc, (SlowResult *)nullptr, (const ExactLanes *)nullptr, 0u);
     if (r.err) atomicMin(&event[j], rec[0] == K_RANGE_MULTI ? r.aux0 : rec[1]);  // (a merged record names the failing opcode itself)
 }
@@ -49,7 +58,7 @@ static void launch_record_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
         hipLaunchKernelGGL((record_level_kernel<Op, BLOCK>), dim3((B + BLOCK - 1) / BLOCK, m), dim3(BLOCK), 0, s, W, Bp, B, dp, offsets + done,
-                           scratch_off ? scratch_off + done : nullptr, event, scratch, dp.prog, dp.consts, dp.slot_of, dp.bytecode);
+                           scratch_off ? scratch_off + 2 * (size_t)done : nullptr, event, scratch, dp.prog, dp.consts, dp.slot_of, dp.bytecode);
         done += m;
     }
 }

@@ -25,7 +25,7 @@ template <class P>
 __device__ __forceinline__ OpResult op_perm_sort(const P &p, const uint32_t *__restrict__ r, const uint32_t *__restrict__ consts, uint32_t *scratch) {
     const uint32_t n = r[2], tuple = r[3], n_sort_by = r[4], n_bits = r[5];
     const uint32_t *sort_by = r + 6, *bit_ws = sort_by + n_sort_by, *e = bit_ws + 2 * n_bits;
-    const LaneWords S{scratch, p.Bp, p.j};
+    const LaneWords S{scratch, p.scratch_stride(), p.scratch_lane()};
     // scratch map (words): values [0, 8 n tuple) | order [n] | x_values [n] | y_values [n] | bits [..] | bump region
     const uint32_t o_vals = 0, o_order = 8 * n * tuple, o_xv = o_order + n, o_yv = o_xv + n, o_base = o_yv + n;
     // ---- evaluate (mod.rs:91-101): get_value of every tuple component, in order

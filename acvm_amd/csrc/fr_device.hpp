@@ -120,12 +120,6 @@ FR_HD __forceinline__ uint32_t fr_p29(int i) {
 // 8 x 32 -> 9 x 29 (exact; limbs < 2^29, top limb < 2^24)
 FR_HD __forceinline__ Fr29 fr29_from(const Fr &a) {
     Fr29 r;
-#ifdef ACVM_FAKE_UNPACK  // measurement only (tools/): what the kernels would cost if the table held the 29-bit limbs (WRONG values)
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = a.v[i] & 0x1fffffffu;
-    r.v[8] = a.v[7] >> 29;
-    return r;
-#endif
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
@@ -138,12 +132,6 @@ FR_HD __forceinline__ Fr29 fr29_from(const Fr &a) {
 // 9 x 29 (limbs < 2^29, value < 2^256) -> 8 x 32
 FR_HD __forceinline__ Fr fr29_pack(const Fr29 &a) {
     Fr r;
-#ifdef ACVM_FAKE_UNPACK
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = a.v[i];
-    r.v[7] |= a.v[8] << 29;
-    return r;
-#endif
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int bit = 32 * i, l = bit / 29, sh = bit - 29 * l;  // limb l holds bits [29 l, 29 l + 29)

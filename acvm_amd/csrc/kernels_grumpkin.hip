@@ -77,9 +77,18 @@ pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, 
     };
     for (uint32_t step = 1; step <= n; step++) {
         if constexpr (WAVES == 1) {
-            GJac s = walk(gj_inf(), active ? p.load(ws[step - 1]) : fr_one(), 1u, 0u, n_units);
-            if (step == 1) s = gj_add_aff(s, GAff{fr_const(dp.ped_seed, 2 * ws[n]), fr_const(dp.ped_seed, 2 * ws[n] + 1)});
-            else s = walk(s, r, 0u, 0u, n_units);
+            // (ONE call site of the walk: two make the compiler keep it as a function, whose by-value points travel through the lane's scratch)
+            GJac s = gj_inf();
+#pragma unroll 1
+            for (uint32_t pass = 0; pass < 2; pass++) {
+                if (pass == 1u && step == 1u) {
+                    s = gj_add_aff(s, GAff{fr_const(dp.ped_seed, 2 * ws[n]), fr_const(dp.ped_seed, 2 * ws[n] + 1)});
+                    break;
+                }
+                Fr src = r;
+                if (pass == 0u) src = active ? p.load(ws[step - 1]) : fr_one();
+                s = walk(s, src, pass ^ 1u, 0u, n_units);
+            }
             bool inf;
             const GAff a = gj_to_aff(s, &inf);
             r = a.x;
@@ -240,7 +249,7 @@ void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 }
 
 // ---- component probes for the parity tests (acvm_debug_grumpkin): in / out are canonical 8 x u32 little-endian
-static __device__ uint32_t g_probe_window_table[16 * 27];
+static __device__ uint32_t g_probe_window_table[GRUMPKIN_VARBASE_SCRATCH_WORDS];
 __global__ void grumpkin_probe_kernel(GrumpkinTables T, uint32_t what, uint32_t param, const uint32_t *in, uint32_t n_in, uint32_t *out) {
     if (threadIdx.x || blockIdx.x) return;
     auto ld = [&](uint32_t i) { Fr c; for (int k = 0; k < 8; k++) c.v[k] = in[8 * i + k]; return c; };

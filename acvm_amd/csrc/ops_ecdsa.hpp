@@ -15,9 +15,10 @@ namespace acvm {
 // 1 valid, 0 invalid, or a panic code in *panic. Bytes come through byte accessors (32 + 32 + 64 + n_msg). gtab: the generator tables of both
 // curves (kernels_ecdsa.hip ecdsa_generator_tables), curve c at c * SECP_GTABLE_WORDS.
 // the same on assembled integers: r, s (signature halves), x (public key), the parity of y, the digest z (n_msg == 32, else it panics inside)
-__device__ __forceinline__ uint32_t ecdsa_verify_values(uint32_t curve, const Fr &r, const Fr &s, const Fr &x, uint32_t y_odd, uint32_t n_msg, const Fr &z,
+__device__ __forceinline__ uint32_t ecdsa_verify_values(uint32_t curve, const Fr &r, const Fr &s, const Fr &x, const Fr &y, uint32_t n_msg, const Fr &z,
                                                         const uint32_t *__restrict__ gtab, uint32_t *panic) {
-    return curve == 0u ? secp_verify<0>(r, s, x, y_odd, n_msg, z, gtab, panic) : secp_verify<1>(r, s, x, y_odd, n_msg, z, gtab + SECP_GTABLE_WORDS, panic);
+    const uint32_t y_odd = y.v[0] & 1u;  // (the last byte of public_key_y)
+    return curve == 0u ? secp_verify<0>(r, s, x, y_odd, n_msg, z, gtab, panic, &y) : secp_verify<1>(r, s, x, y_odd, n_msg, z, gtab + SECP_GTABLE_WORDS, panic, &y);
 }
 template <class PkX, class PkY, class Sig, class Msg>
 __device__ __forceinline__ uint32_t ecdsa_verify(uint32_t curve, PkX pkx, PkY pky, Sig sig, uint32_t n_msg, Msg msg, const uint32_t *__restrict__ gtab,
@@ -32,10 +33,9 @@ __device__ __forceinline__ uint32_t ecdsa_verify(uint32_t curve, PkX pkx, PkY pk
         }
         return r;
     };
-    const Fr r = be32(sig, 0), s = be32(sig, 32), x = be32(pkx, 0);
-    const uint32_t y_odd = pky(31) & 1u;
+    const Fr r = be32(sig, 0), s = be32(sig, 32), x = be32(pkx, 0), y = be32(pky, 0);
     const Fr z = n_msg == 32u ? be32(msg, 0) : fr_zero();
-    return ecdsa_verify_values(curve, r, s, x, y_odd, n_msg, z, gtab, panic);
+    return ecdsa_verify_values(curve, r, s, x, y, n_msg, z, gtab, panic);
 }
 
 // [K_ECDSA, opcode, curve, n_x, n_y, n_sig, n_msg, out, flag, ws: x..., y..., sig..., msg...]
@@ -51,13 +51,12 @@ __device__ __forceinline__ OpResult op_ecdsa(const P &p, const uint32_t *__restr
     if (n_x != 32u) return op_fail_msg(DE_BLACKBOX_FAILED, func, DM_ECDSA_LEN, 0u, n_x);
     if (n_y != 32u) return op_fail_msg(DE_BLACKBOX_FAILED, func, DM_ECDSA_LEN, 1u, n_y);
     if (n_sig != 64u) return op_fail_msg(DE_BLACKBOX_FAILED, func, DM_ECDSA_LEN, 2u, n_sig);
-    // to_u8_vec, 32 witnesses to a 256-bit integer, four rows in flight (ops_common.hpp load_be32_bytes); of y only the parity is used
+    // to_u8_vec, 32 witnesses to a 256-bit integer, four rows in flight (ops_common.hpp load_be32_bytes); the reference uses the parity of y only,
+    // the whole of it is read here to spare the square root of the decompression (secp_device.hpp secp_verify)
     uint32_t panic = 0;
-    bool yb;
-    const Fr sr = load_be32_bytes(p, wsig), ss = load_be32_bytes(p, wsig + 32), x = load_be32_bytes(p, wx);
-    const uint32_t y_odd = fr_low_limb(p.load(wy[31]), yb) & 1u;
+    const Fr sr = load_be32_bytes(p, wsig), ss = load_be32_bytes(p, wsig + 32), x = load_be32_bytes(p, wx), y = load_be32_bytes(p, wy);
     const Fr z = n_msg == 32u ? load_be32_bytes(p, wmsg) : fr_zero();
-    const uint32_t ok = ecdsa_verify_values(curve, sr, ss, x, y_odd, n_msg, z, gtab, &panic);
+    const uint32_t ok = ecdsa_verify_values(curve, sr, ss, x, y, n_msg, z, gtab, &panic);
     if (panic) return OpResult{DE_PANIC, func, panic, DM_ECDSA_PANIC, panic, 0u};
     if (!p.insert(r[7], ok ? fr_one() : fr_zero(), r[8])) return op_fail(DE_UNSATISFIED);
     return op_ok();

@@ -391,7 +391,8 @@ __device__ __forceinline__ GlvSplit glv_split(const Fr &k) {
     }
     return r;
 }
-static constexpr uint32_t VARBASE_TABLE_ENTRIES = 16;  // d P for d = 1..16 (signed 5-bit windows), 27 words each in the lane's scratch
+static constexpr uint32_t VARBASE_TABLE_ENTRIES = 16;  // d P for d = 1..16 (signed 5-bit windows); scratch map: GRUMPKIN_VARBASE_SCRATCH_WORDS (grumpkin_host.hpp)
+static_assert(GRUMPKIN_VARBASE_SCRATCH_WORDS == VARBASE_TABLE_ENTRIES * 27u + VARBASE_TABLE_ENTRIES * 16u + 4u, "scratch map of grumpkin_var_base_mul");
 // Signed 5-bit windows of a magnitude below 2^127: k = sum d_i 32^i with d_i in [-15, 16], i < 26 (a window above 16 borrows 32 from the
 // next one). Digit i sits in word i / 5 at bit 6 (i % 5): bits 0..4 the magnitude, bit 5 the sign. 26 windows instead of the 32 unsigned
 // 4-bit ones: 52 additions + 130 doublings instead of 64 + 128 for one more table entry.
@@ -428,17 +429,23 @@ __device__ __forceinline__ uint32_t nibble128(const uint32_t (&k)[4], uint32_t w
         if ((uint32_t)i == (w >> 3)) limb = k[i];
     return (limb >> (4u * (w & 7u))) & 15u;
 }
-// With a window table (16 x 27 words per lane in device scratch, word-major like every per-lane buffer): e = k1 + k2 lambda
-// (GLV, |k1|, |k2| < 2^127), then 26 joint SIGNED 5-bit windows: 5 doublings + the lane's table entry |d1_w| * P + the entry
-// |d2_w| * P mapped through (x, y) -> (beta x, y); a negative half or a negative digit negates y. The instruction stream is the same on every
-// lane (bit-serial double-and-add makes the whole wave pay the addition on every bit: some lane always has the bit set), and
-// the split halves the doublings: 130 doublings + 52 additions instead of 256 + 64.
+// With a window table in the lane's device scratch: e = k1 + k2 lambda (GLV, |k1|, |k2| < 2^127), then 26 joint SIGNED 5-bit windows:
+// 5 doublings + the lane's table entry |d1_w| * P + the entry |d2_w| * P mapped through (x, y) -> (beta x, y); a negative half or a negative
+// digit negates y. The instruction stream is the same on every lane (bit-serial double-and-add makes the whole wave pay the addition on every
+// bit: some lane always has the bit set), and the split halves the doublings: 130 doublings + 52 additions instead of 256 + 64.
 // The 16 multiples are brought to ONE denominator so that the 52 additions are mixed ones (11 products instead of 16) without an
 // inversion: d P = (X_d, Y_d, Z_d) is built by the chain P, 2P, 2P + P, ... whose every step reports zr_d = Z_d / Z_(d-1); backwards,
 // s_d = Z_16 / Z_d = zr_16 ... zr_(d+1) and (X_d s_d^2, Y_d s_d^3, Z_16) is the same point. (x, y) -> (x Z_16^2, y Z_16^3) maps the curve
 // onto y^2 = x^3 - 17 Z_16^6, where those pairs are AFFINE points; doubling and addition for a = 0 never read the constant, so the
-// whole ladder runs there and the result (X, Y, Z) is the point (X, Y, Z Z_16) of Grumpkin. Table row d - 1 = {x_d, y_d, beta x_d}.
+// whole ladder runs there and the result (X, Y, Z) is the point (X, Y, Z Z_16) of Grumpkin.
 // The group has prime order q and 0 < d <= 16, so the chain never meets an exceptional case; the ladder's additions keep theirs.
+// Scratch map (`tbl`: a region of GRUMPKIN_VARBASE_SCRATCH_WORDS words per lane, `Bp` lanes, this lane = j):
+//   * the chain {X_d, Y_d, zr_d}, 27 words per entry in the working form, word-major [word][lane] like every per-lane buffer: every lane
+//     reads and writes the same d at the same time, the accesses are coalesced;
+//   * the finished rows {x_d, y_d}, 16 words per entry in the storage form, LANE-major [lane][entry][16 words]: in the ladder every lane
+//     reads the row of ITS OWN digit, and a row is one aligned 64-byte line (four 16-byte loads). Word-major, the 18 words of a row were 18
+//     scattered 4-byte reads per lane, each of which moved a whole line: 3.0 GB of HBM traffic per 2^16 verifications
+//     (profiles/r03r_profile_grumpkin.txt). beta x_d is one product at the addition instead of a third stored field.
 // Without a table (Brillig's black-box op): double-and-add.
 __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e, uint32_t *tbl, uint64_t Bp, uint64_t j) {
     GJac a = gj_inf();
@@ -459,6 +466,9 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
         for (int k = 0; k < 9; k++) v.v[k] = tbl[(uint64_t)((d - 1u) * 27u + field * 9u + k) * Bp + j];
         return v;
     };
+    // the finished rows: behind the chain, rounded up to 16 bytes (the region holds four words per lane of slack for that)
+    uint4 *rows = (uint4 *)(((uintptr_t)(tbl + (uint64_t)(VARBASE_TABLE_ENTRIES * 27u) * Bp) + 15u) & ~(uintptr_t)15u) + j * (VARBASE_TABLE_ENTRIES * 4u);
+    auto row_of = [&](uint32_t d) { return rows + (d - 1u) * 4u; };
     // forward: row d - 1 = {X_d, Y_d, zr_d}
     const Fr29 px = fr29_from(P.x), py = fr29_from(P.y);
     GJac q = GJac{px, py, g29_one()};
@@ -471,19 +481,25 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
         put(d, 0, q.X); put(d, 1, q.Y); put(d, 2, zr);
     }
     const Fr29 z15 = q.Z;  // (the common denominator: Z of the last entry)
-    // backward: row d - 1 = {X_d s^2, Y_d s^3, beta X_d s^2}
-    const Fr29 beta = fr29_from(grumpkin_beta());
+    // backward: row d - 1 = {X_d s^2, Y_d s^3} (products: limbs < 2^29, value < 1.4p < 2^256, so the storage form holds them as they are)
     Fr29 sc = g29_one();
     for (uint32_t d = VARBASE_TABLE_ENTRIES; d >= 1; d--) {
         const Fr29 zr = get(d, 2);
         const Fr29 s2 = fr29_sqr(sc);
-        const Fr29 x = fr29_mul(get(d, 0), s2), y = fr29_mul(get(d, 1), fr29_mul(s2, sc));
-        put(d, 0, x); put(d, 1, y); put(d, 2, fr29_mul(x, beta));
+        const Fr x = fr29_pack(fr29_mul(get(d, 0), s2)), y = fr29_pack(fr29_mul(get(d, 1), fr29_mul(s2, sc)));
+        uint4 *row = row_of(d);
+        row[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        row[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+        row[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+        row[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
         sc = fr29_mul(sc, zr);
     }
+    const Fr29 beta = fr29_from(grumpkin_beta());
     const GlvSplit sp = glv_split(e);
-    // (requesting both rows of a window before its four doublings -- their index depends on the scalar only -- was measured slower:
-    // 2.30 -> 2.37 ms per 65 536 verifications; the rows are loaded where they are added)
+    // (requesting both rows of a window before its five doublings -- their index depends on the scalar only -- was measured slower twice: as
+    // register loads with the word-major table, 2.30 -> 2.37 ms per 65 536 verifications, and as one-word cache touches with the lane-major
+    // rows, 1.70 -> 1.72 ms; so was a per-lane swizzle of the row slots against channel hot spots. The rows are loaded where they are added:
+    // the ladder is bound by instruction issue, not by these loads.)
     const SignedDigits d1 = signed_windows5(sp.k1), d2 = signed_windows5(sp.k2);
     for (int w = 25; w >= 0; w--) {
 #pragma unroll 1
@@ -493,8 +509,11 @@ __device__ __forceinline__ GJac grumpkin_var_base_mul(const GAff &P, const Fr &e
             const uint32_t d = sd & 31u;
             const bool neg = (half ? sp.neg2 : sp.neg1) != ((sd & 32u) != 0u);
             if (d) {  // per lane: its own table row
-                const Fr29 x = get(d, half ? 2u : 0u);                     // lambda * (x, y) = (beta x, y)
-                Fr29 y = get(d, 1);
+                const uint4 *row = row_of(d);
+                const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+                Fr29 x = fr29_from(Fr{{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}});
+                if (half) x = fr29_mul(x, beta);                            // lambda * (x, y) = (beta x, y)
+                Fr29 y = fr29_from(Fr{{r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w}});
                 const Fr29 ny = fr29_norm(fr29_subl(g29_zero(), y, 1));    // 2p - y: in (0, 2p) since y != 0 (mod p) on this curve
 #pragma unroll
                 for (int k = 0; k < 9; k++) y.v[k] = neg ? ny.v[k] : y.v[k];

@@ -1,6 +1,7 @@
 // plan.cpp -- static replay of the reference's assigned-set bookkeeping + levelisation (see plan.hpp).
 #include "plan.hpp"
 #include "tuning.hpp"
+#include "grumpkin_host.hpp"
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -436,7 +437,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     p.prog_class[oi] = host_blackbox ? CLS_HOSTBB : CLS_GRUMPKIN;
                     p.needs_grumpkin |= !host_blackbox;
                     // challenge preimage (32 + message bytes) + the per-lane window table of e * pk (15 Jacobian points x 27 words)
-                    p.prog_scratch[oi] = (uint32_t)((32 + b.in[3].size() + 3) / 4 + 1) + 16u * 27u;  // message + the 16-entry window table of e * pk (ops_grumpkin.hpp)
+                    p.prog_scratch[oi] = (uint32_t)((32 + b.in[3].size() + 3) / 4 + 1) + GRUMPKIN_VARBASE_SCRATCH_WORDS;  // message + the window table of e * pk (ops_grumpkin.hpp)
                     s.insert(s.end(), {PK_SCHNORR, oi, b.in[0][0].witness, b.in[1][0].witness, (uint32_t)b.in[2].size(),
                                        (uint32_t)b.in[3].size()});
                     out(b.out[0]);

@@ -611,9 +611,13 @@ enum EcdsaPanic : uint32_t { EP_SIG = 1, EP_PUBKEY = 2, EP_MSG_LEN = 3, EP_MSG_R
 
 // The verification proper on parsed integers, in the order of the reference's checks (ops_ecdsa.hpp): 1 valid, 0 invalid, or a panic code in *panic.
 // gtab: this curve's table of the generator.
+// y_given (optional): the 32 bytes of public_key_y as an integer. The reference decompresses the key from x and the parity of y's last byte
+// (from_affine_coordinates(.., compress = true)): the root of x^3 + a x + b with that parity. When the given y is a field element that
+// squares to the right-hand side it IS that root (the other root p - y has the other parity), and the 253 squarings of the square root --
+// 8 % / 12 % of a secp256r1 / secp256k1 verification -- are skipped; an off-curve or unreduced y takes the square root as before.
 template <int C>
 FR_HD inline __noinline__ uint32_t secp_verify(const Fr &r, const Fr &s, const Fr &x, uint32_t y_odd, uint32_t n_msg, const Fr &z,
-                                              const uint32_t *__restrict__ gtab, uint32_t *panic) {
+                                              const uint32_t *__restrict__ gtab, uint32_t *panic, const Fr *y_given = nullptr) {
     *panic = 0;
     const Fr n = sn_modulus<C>();
     if (fr_is_zero(r) || fr_is_zero(s) || secp_geq(r, n) || secp_geq(s, n)) { *panic = EP_SIG; return 0; }
@@ -621,9 +625,17 @@ FR_HD inline __noinline__ uint32_t secp_verify(const Fr &r, const Fr &s, const F
     Fr rhs = sp_mul<C>(sp_sqr<C>(x), x);
     if (C == 1) rhs = sp_sub<C>(rhs, sp_add<C>(sp_add<C>(x, x), x));
     rhs = sp_add<C>(rhs, secp_limbs([](int i) { return Secp<C>::b(i); }));
-    Fr y = sp_sqrt_candidate<C>(rhs);
-    if (!fr_eq(sp_sqr<C>(y), rhs)) { *panic = EP_PUBKEY; return 0; }
-    if ((y.v[0] & 1u) != (y_odd & 1u)) y = sp_neg<C>(y);
+    Fr y = fr_zero();
+    bool have_y = false;
+    if (y_given && ((y_given->v[0] ^ y_odd) & 1u) == 0u && !secp_geq(*y_given, sp_modulus<C>()) && fr_eq(sp_sqr<C>(*y_given), rhs)) {
+        y = *y_given;
+        have_y = true;
+    }
+    if (!have_y) {
+        y = sp_sqrt_candidate<C>(rhs);
+        if (!fr_eq(sp_sqr<C>(y), rhs)) { *panic = EP_PUBKEY; return 0; }
+        if ((y.v[0] & 1u) != (y_odd & 1u)) y = sp_neg<C>(y);
+    }
     if (n_msg != 32u) { *panic = EP_MSG_LEN; return 0; }
     if (secp_geq(z, n)) { *panic = EP_MSG_RANGE; return 0; }
     Fr d;

@@ -220,3 +220,19 @@ def test_verification(exe, c):
         assert tuple(int(t) for t in g.split()) == want, (l, g, want)
         seen.add(want)
     assert {(1, 0), (0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5)} <= seen
+    # the same cases with the WHOLE of public_key_y given (the decompression shortcut of secp_verify): the true root of that parity, an
+    # off-curve value of that parity, an unreduced one (>= p) of that parity -- the outcome only ever depends on x and the parity
+    lines, wants = [], []
+    for r, s, x, yo, nm, z in cases:
+        want = verify_model(cv, r, s, x, yo, nm, z)
+        ys = [((2**256 - 2) | (yo & 1)), ((12345678 << 1) | (yo & 1))]
+        if x < p:
+            rhs = (x * x * x + cv["a"] * x + cv["b"]) % p
+            y = pow(rhs, (p + 1) // 4, p)
+            if y * y % p == rhs:
+                ys.append(y if (y & 1) == (yo & 1) else p - y)
+        for y in ys:
+            lines.append(f"{c} verifyy {r:x} {s:x} {x:x} {y:x} {nm} {z:x}")
+            wants.append(want)
+    for l, g, want in zip(lines, ask(exe, lines), wants):
+        assert tuple(int(t) for t in g.split()) == want, (l, g, want)

@@ -9,7 +9,7 @@ import sys
 import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("ACVM_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 floor = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rows = {}
 for obj in sorted(glob.glob(os.path.join(ROOT, "acvm_amd", "build", "*.hip.o"))):

@@ -59,6 +59,11 @@ static void serve(const std::vector<std::string> &w) {
         uint32_t panic = 0;
         const uint32_t ok = secp_verify<C>(A(2), A(3), A(4), (uint32_t)atoi(w[5].c_str()), (uint32_t)atoi(w[6].c_str()), A(7), gtable<C>(), &panic);
         printf("%u %u", ok, panic);
+    } else if (op == "verifyy") {  // the same with the whole of public_key_y given (the decompression shortcut)
+        uint32_t panic = 0;
+        const Fr y = A(5);
+        const uint32_t ok = secp_verify<C>(A(2), A(3), A(4), y.v[0] & 1u, (uint32_t)atoi(w[6].c_str()), A(7), gtable<C>(), &panic, &y);
+        printf("%u %u", ok, panic);
     } else if (op == "split") {
         const SecpSplit sp = secp256k1_split_lambda(A(2));
         put(sp.k1); printf(" %d ", sp.neg1 ? 1 : 0); put(sp.k2); printf(" %d", sp.neg2 ? 1 : 0);

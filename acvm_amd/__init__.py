@@ -23,7 +23,7 @@ LIMIT_BRILLIG_STEPS, LIMIT_BRILLIG_CALL_DEPTH, LIMIT_BRILLIG_MEMORY, LIMIT_DEVIC
 # every symbol include/acvm_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "acvm_last_error", "acvm_abi_version", "acvm_device_count", "acvm_set_device", "acvm_device_synchronize",
-    "acvm_device_arch", "acvm_selftest", "acvm_debug_grumpkin", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
+    "acvm_device_arch", "acvm_selftest", "acvm_debug_grumpkin", "acvm_debug_secp", "acvm_circuit_from_bytes", "acvm_circuit_free", "acvm_circuit_num_opcodes",
     "acvm_circuit_num_witnesses", "acvm_circuit_plan_stats", "acvm_batch_new", "acvm_batch_free", "acvm_batch_set_initial_witness",
     "acvm_batch_set_initial_witness_device", "acvm_batch_solve", "acvm_batch_solve_then_import", "acvm_batch_reset", "acvm_batch_set_instances", "acvm_batch_set_force_slow_path",
     "acvm_batch_results", "acvm_batch_witness", "acvm_batch_witness_map", "acvm_batch_stats",
@@ -227,6 +227,8 @@ def lib():
     L.acvm_device_arch.argtypes = [C.c_char_p, C.c_size_t]
     L.acvm_selftest.argtypes = [C.c_uint32, C.c_uint64]
     L.acvm_debug_grumpkin.argtypes = [C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]
+    if hasattr(L, "acvm_debug_secp"):  # (an older build loaded through ACVM_AMD_LIB for an A/B run has no such probe)
+        L.acvm_debug_secp.argtypes = [C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]
     L.acvm_circuit_from_bytes.restype = C.c_void_p
     L.acvm_circuit_from_bytes.argtypes = [C.c_char_p, C.c_size_t]
     L.acvm_circuit_free.argtypes = [C.c_void_p]
@@ -445,6 +447,20 @@ def debug_grumpkin(what, param, inputs=()):
     data = b"".join(int(v).to_bytes(32, "big") for v in inputs)
     _check(lib().acvm_debug_grumpkin(what, param, data, len(inputs), out))
     return int.from_bytes(out.raw[:32], "big"), int.from_bytes(out.raw[32:], "big")
+
+
+SECP_PROBE_WORDS = ((2, 1), (1, 1), (2, 1), (2, 1), (1, 1), (1, 1), (3, 3), (5, 3), (1, 1), (2, 1), (2, 1), (1, 1))
+
+
+def debug_secp(curve, what, items):
+    """Component probe of the ECDSA kernels (see include/acvm_amd.h): items = tuples of ints (values < p); returns one tuple of ints per item."""
+    wi, wo = SECP_PROBE_WORDS[what]
+    assert all(len(it) == wi for it in items)
+    data = b"".join(int(v).to_bytes(32, "big") for it in items for v in it)
+    out = C.create_string_buffer(32 * wo * max(len(items), 1))
+    _check(lib().acvm_debug_secp(curve, what, data, len(items), out))
+    raw = out.raw
+    return [tuple(int.from_bytes(raw[32 * (wo * i + k):32 * (wo * i + k + 1)], "big") for k in range(wo)) for i in range(len(items))]
 
 
 def decompress_witness(data: bytes) -> dict:

@@ -133,6 +133,7 @@ void launch_exact_run(hipStream_t s, uint4 *W, uint64_t Bp, const DeviceProgram 
                       const uint8_t *prog_class, const ExactScratch &sc);
 void launch_grumpkin_probe(hipStream_t s, const GrumpkinTables &T, uint32_t what, uint32_t param, const uint32_t *in, uint32_t n_in, uint32_t *out);
 // ECDSA (kernels_ecdsa.hip; the generator tables d * 2^(16 j) * G of both curves: grumpkin_host.hpp ecdsa_generator_tables)
+void launch_secp_probe(hipStream_t s, uint32_t curve, uint32_t what, const uint32_t *in, uint32_t n_items, uint32_t words_in, uint32_t words_out, uint32_t *out);
 void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event);
 // caller-supplied BlackBoxFunctionSolver (kernels_ops.hip)
 void launch_hostbb_precheck(hipStream_t s, const ExactLanes &L, uint32_t opcode, const uint32_t *sel, uint32_t n_sel, uint8_t *active);

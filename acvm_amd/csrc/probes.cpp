@@ -103,6 +103,30 @@ int acvm_debug_stream_rate(size_t bytes, double *gb_per_s) {
 // Component probes of the Grumpkin kernels for the parity tests: what = 0 host table point (param = table << 24 | index),
 // 1 device hash_single(in[0], parity = param), 2 device hash-ladder compress(in[0..n_in)), 3 device fixed_base_mul(table
 // base param, integer in[0]), 4 device table point. in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian.
+int acvm_debug_secp(uint32_t curve, uint32_t what, const uint8_t *in_be32, uint32_t n_items, uint8_t *out_be32) try {
+    static const uint32_t WIN[12] = {2, 1, 2, 2, 1, 1, 3, 5, 1, 2, 2, 1}, WOUT[12] = {1, 1, 1, 1, 1, 1, 3, 3, 1, 1, 1, 1};
+    if (curve > 1u || what > 11u || !in_be32 || !out_be32) return set_err(ACVM_E_INVALID, "bad argument");
+    if (!n_items) return 0;
+    const uint32_t wi = WIN[what], wo = WOUT[what];
+    std::vector<uint32_t> in((size_t)n_items * wi * 8, 0), out((size_t)n_items * wo * 8, 0);
+    for (size_t i = 0; i < (size_t)n_items * wi; i++)
+        for (int k = 0; k < 32; k++) in[8 * i + k / 4] |= (uint32_t)in_be32[32 * i + 31 - k] << (8 * (k % 4));
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_in, in.size() * 4));
+    HIPCHK(hipMalloc((void **)&d_out, out.size() * 4));
+    HIPCHK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_out, 0, out.size() * 4));
+    launch_secp_probe(nullptr, curve, what, d_in, n_items, wi, wo, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+    hipFree(d_in);
+    hipFree(d_out);
+    for (size_t i = 0; i < (size_t)n_items * wo; i++)
+        for (int k = 0; k < 32; k++) out_be32[32 * i + 31 - k] = (uint8_t)(out[8 * i + k / 4] >> (8 * (k % 4)));
+    return 0;
+} ABI_CATCH
+
 int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64) try {
     if (!out_be64) return set_err(ACVM_E_INVALID, "null argument");
     if (what == 0) return grumpkin_host_point(param >> 24, param & 0xffffffu, out_be64) ? 0 : set_err(ACVM_E_INVALID, "bad table index");

@@ -2,10 +2,9 @@
 //   blackbox_solver/src/lib.rs:66-210 (verify_secp256k1/r1_ecdsa_signature; k256 0.11.6 / p256 0.11.1 = SEC 1 v2 section 4.1.4).
 // Everything is __host__ __device__ with compile-time moduli, so tools/secp_device_host_test.hip runs the same code on the host against
 // Python integers (tests/test_secp_device_on_host.py).
-//   * base field: plain residues in [0, p), 8 x 32-bit limbs. The product is a 64-multiply schoolbook (squares: 36) followed by the
-//     reduction the SHAPE of the prime allows -- p = 2^256 - 2^32 - 977 folds the high half in with one 8-limb multiply by 977 and a
-//     shift; p = 2^256 - 2^224 + 2^192 + 2^96 - 1 (NIST P-256) with nine signed word sums (FIPS 186-4 D.2.3) -- instead of the 64 further
-//     multiplies of a Montgomery reduction.
+//   * base field: 9 x 29-bit limbs in 32-bit registers with unreduced sums between products (the "working form" section below): plain residues
+//     folded through the shape of the prime for secp256k1 (2^261 = 2^37 + 31264, 2^256 = 2^32 + 977), Montgomery residues for secp256r1, whose
+//     p = -1 (mod 2^29) makes the reduction multiplier the column's own low limb. (Round 3: 8 x 32-bit limbs with carry chains, 1.8 x the instructions.)
 //   * scalar field (three products per verification): Montgomery, modulus a compile-time constant.
 //   * inversions: safegcd (fr_device.hpp fr_safegcd_inv) with the modulus as a template parameter.
 //   * square root for the decompression of the public key (both p = 3 mod 4): addition chains for (p + 1) / 4 (253 squarings + 13 / 7 products).
@@ -14,6 +13,10 @@
 //     (16 x 65 535 affine points per curve, 64 MiB, built once per device by secp_gtable_entry) onto the same accumulator.
 #pragma once
 #include "fr_device.hpp"
+#if defined(SECP_CHECK)
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace acvm {
 
@@ -85,10 +88,9 @@ FR_HD __forceinline__ bool secp_geq(const Fr &a, const Fr &b) {
     return fr_sub256(d, a, b) == 0;
 }
 
-// ---- wide products, column by column: a column's 64-bit products are summed in a 96-bit accumulator (acc, top). On the device one term is
-// v_mad_u64_u32 (the 64-bit accumulate of the multiplier, carry out in vcc) + v_addc_co_u32; written in C the compiler builds the 64-bit
-// addend of every term from a zeroed register pair (132 v_mov + 49 64-bit adds beside the 64 multiplies of one product: 245 instructions;
-// this form: 164).
+// ---- wide product of two 8 x 32-bit integers (the endomorphism split below), column by column: a column's 64-bit products are summed in a
+// 96-bit accumulator (acc, top). On the device one term is v_mad_u64_u32 (the 64-bit accumulate of the multiplier, carry out in vcc) +
+// v_addc_co_u32.
 FR_HD __forceinline__ void secp_mac(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "v"(b) : "vcc");
@@ -115,198 +117,412 @@ FR_HD __forceinline__ void secp_mul_wide(uint32_t t[16], const Fr &a, const Fr &
     }
     t[15] = (uint32_t)acc;
 }
-// 28 cross products, doubled, + 8 squares
-FR_HD __forceinline__ void secp_sqr_wide(uint32_t t[16], const Fr &a) {
-    uint64_t acc = 0;
-    uint32_t top = 0;
-    t[0] = 0;
+
+// ---- base field, working form (round 4): 9 x 29-bit limbs in 32-bit registers (the container of fr_device.hpp, Fr29), like the BN254 code.
+// Round 3 multiplied 8 x 32-bit limbs: 64 multiplies, but every one of them with a carry (v_addc), a 96-bit column accumulator that had to be
+// shifted through registers (160 v_mov per product pair) and a carry-chained reduction: 290 (secp256k1) / 350 (secp256r1) instructions per
+// product, and every instruction of this mix issues at the same rate (the back-to-back probes: 4 cycles each, v_mad_u64_u32 included). On
+// 29-bit limbs a column of 9 products (< 2^58 each) sums in ONE 64-bit register with no carry at all: 81 multiplies + a mask and a shift per
+// column, and the 5 spare bits (9 x 29 = 261) let sums and differences stay unreduced between products. ~165 instructions per product.
+//   secp256k1: plain residues. 2^261 = 2^37 + 31264 (mod p) folds the high nine limbs of a product back with one multiply and one shift per
+//              limb; what is then left above 2^256 folds with 2^256 = 2^32 + 977. A product is below 1.01 p whatever its operands were.
+//   secp256r1: Montgomery residues x R, R = 2^261. p = -1 (mod 2^29), so the multiplier of a reduction step is the column's low limb itself,
+//              and p = (2^96 - 1) + 2^192 + 2^224 (2^32 - 1) spreads it over four columns with two shifts and two multiplies: 36 instructions
+//              for the whole reduction instead of the 81 multiplies of a generic modulus. A product of a < A p and b < B p is < (A B / 32 + 1) p.
+// "Domain form" below = what the curve routines compute on: the residue (k1) or the Montgomery residue (r1); sp_enter / sp_leave convert.
+// Bounds are written beside the formulas in units of p; "normalised" = limbs below 2^29 (the top one holds the rest).
+using S29 = Fr29;
+constexpr uint32_t S29_M = 0x1fffffffu;
+// The bounds written beside the formulas are CHECKED when this header is compiled for the host with -DSECP_CHECK (tests/test_secp_device_on_host.py
+// does): no limb-wise difference goes negative, no subtrahend exceeds its multiple of p, no column of a product leaves 64 bits, nothing above 128 p is folded.
+#if defined(SECP_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+#define S29_ASSERT(c) do { if (!(c)) { fprintf(stderr, "secp_device.hpp:%d: bound violated: %s\n", __LINE__, #c); abort(); } } while (0)
+#define S29_CHECKED 1
+#else
+#define S29_ASSERT(c) ((void)0)
+#define S29_CHECKED 0
+#endif
+
+// The limbs of a result pass through an empty asm on the device: hipcc (ROCm 7.2) otherwise carries what it knows about their widths -- 24 bits in
+// the top limb, 29 below -- into the NEXT product and selects 24-bit multiplies there that lose bits (a product of a product came out wrong on the
+// device and right on the host: tests/test_gpu_secp_probe.py, probe 8). No instruction is emitted.
+FR_HD __forceinline__ void s29_opaque(S29 &r) {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int k = 1; k < 14; k++) {
+    for (int i = 0; i < 9; i++) asm volatile("" : "+v"(r.v[i]));
+#else
+    (void)r;
+#endif
+}
+template <int C>
+FR_HD __forceinline__ uint32_t sp29_p(int i) {
+    constexpr uint32_t L[2][9] = {{0x1ffffc2fu, 0x1ffffff7u, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x00ffffffu},
+                                  {0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x000001ffu, 0x00000000u, 0x00000000u, 0x00040000u, 0x1fe00000u, 0x00ffffffu}};
+    return L[C][i];
+}
+// 2^klog2 p (klog2 = 0..4) with every limb below the top raised by 2^30 and the two borrowed from the next one: limb-wise a + K - b never goes
+// negative below the top limb for limbs of b up to 2^30 - 2 (a normalised value or the sum of two); the top limb may wrap, which cancels in s29_norm
+template <int C>
+FR_HD __forceinline__ uint32_t sp29_kp_sub(int klog2, int i) {
+    constexpr uint32_t L[2][5][9] = {
+        {{0x5ffffc2fu, 0x5ffffff5u, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x00fffffdu},
+         {0x5ffff85eu, 0x5fffffedu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x01fffffdu},
+         {0x5ffff0bcu, 0x5fffffddu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x03fffffdu},
+         {0x5fffe178u, 0x5fffffbdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x07fffffdu},
+         {0x5fffc2f0u, 0x5fffff7du, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x0ffffffdu}},
+        {{0x5fffffffu, 0x5ffffffdu, 0x5ffffffdu, 0x400001fdu, 0x3ffffffeu, 0x3ffffffeu, 0x4003fffeu, 0x5fdffffeu, 0x00fffffdu},
+         {0x5ffffffeu, 0x5ffffffdu, 0x5ffffffdu, 0x400003fdu, 0x3ffffffeu, 0x3ffffffeu, 0x4007fffeu, 0x5fbffffeu, 0x01fffffdu},
+         {0x5ffffffcu, 0x5ffffffdu, 0x5ffffffdu, 0x400007fdu, 0x3ffffffeu, 0x3ffffffeu, 0x400ffffeu, 0x5f7ffffeu, 0x03fffffdu},
+         {0x5ffffff8u, 0x5ffffffdu, 0x5ffffffdu, 0x40000ffdu, 0x3ffffffeu, 0x3ffffffeu, 0x401ffffeu, 0x5efffffeu, 0x07fffffdu},
+         {0x5ffffff0u, 0x5ffffffdu, 0x5ffffffdu, 0x40001ffdu, 0x3ffffffeu, 0x3ffffffeu, 0x403ffffeu, 0x5dfffffeu, 0x0ffffffdu}}};
+    return L[C][klog2][i];
+}
+FR_HD __forceinline__ S29 s29_zero() {
+    S29 r;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int j = k - i;
-            if (j <= i || j > 7) continue;
-            secp_mac(acc, top, a.v[i], a.v[j]);
+    for (int i = 0; i < 9; i++) r.v[i] = 0u;
+    return r;
+}
+FR_HD __forceinline__ S29 s29_norm(const S29 &a) { return fr29_norm(a); }   // carry propagation: limbs < 2^29 below the top one
+FR_HD __forceinline__ S29 s29_addl(const S29 &a, const S29 &b) { return fr29_addl(a, b); }
+FR_HD __forceinline__ S29 s29_dbll(const S29 &a) { return fr29_dbll(a); }
+// a + 2^klog2 p - b, limb-wise: limbs of b <= 2^30 - 2, value(b) <= 2^klog2 p; limbs of a < 2^31. To be normalised before anything reads the top limb.
+template <int C>
+FR_HD __forceinline__ S29 s29_subl(const S29 &a, const S29 &b, int klog2) {
+    S29 r;
+#if S29_CHECKED
+    {
+        for (int i = 0; i < 8; i++) S29_ASSERT((uint64_t)a.v[i] + sp29_kp_sub<C>(klog2, i) >= b.v[i] && (uint64_t)a.v[i] + sp29_kp_sub<C>(klog2, i) - b.v[i] < (1ull << 32));
+        // value(b) <= 2^klog2 p: compare the normalised limbs from the top
+        uint64_t bn[9], kn[9], cb = 0, ck = 0;
+        for (int i = 0; i < 9; i++) {
+            cb += b.v[i];
+            ck += (uint64_t)sp29_p<C>(i) << klog2;
+            bn[i] = i < 8 ? (cb & S29_M) : cb;
+            kn[i] = i < 8 ? (ck & S29_M) : ck;
+            cb = i < 8 ? cb >> 29 : 0;
+            ck = i < 8 ? ck >> 29 : 0;
         }
-        t[k] = (uint32_t)acc;
-        acc = acc >> 32 | (uint64_t)top << 32;
-        top = 0;
+        int cmp = 0;
+        for (int i = 8; i >= 0 && !cmp; i--) cmp = bn[i] < kn[i] ? -1 : bn[i] > kn[i] ? 1 : 0;
+        S29_ASSERT(cmp <= 0);
     }
-    t[14] = (uint32_t)acc;
-    t[15] = (uint32_t)(acc >> 32);
+#endif
 #pragma unroll
-    for (int i = 15; i > 0; i--) t[i] = t[i] << 1 | t[i - 1] >> 31;
-    t[0] = 0;
-    uint32_t cin = 0;
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + sp29_kp_sub<C>(klog2, i) - b.v[i];
+    return r;
+}
+// normalised limbs, value < 128 p  ->  value < 2^256 + 2^232 (< 1.01 p), limbs < 2^29 (+ 1): what stands above bit 256 comes back through 2^256 mod p
+template <int C>
+FR_HD __forceinline__ S29 s29_weak(const S29 &a);
+template <>
+FR_HD __forceinline__ S29 s29_weak<0>(const S29 &a) {  // 2^256 = 2^32 + 977
+    S29 r = a;
+    const uint32_t e = r.v[8] >> 24;  // < 2^7
+#if S29_CHECKED
+    S29_ASSERT(e < 128u);
+    for (int i = 0; i < 8; i++) S29_ASSERT(a.v[i] <= S29_M);
+#endif
+    r.v[8] &= 0x00ffffffu;
+    r.v[0] += e * 977u;
+    r.v[1] += e << 3;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {  // + a_i^2 at words 2i, 2i + 1, the carry of a pair into the next
-        uint64_t pair = (uint64_t)t[2 * i] | (uint64_t)t[2 * i + 1] << 32;
-        uint32_t over = 0;
-        secp_mac(pair, over, a.v[i], a.v[i]);
-        const uint64_t s = pair + cin;
-        over += s < pair ? 1u : 0u;
-        t[2 * i] = (uint32_t)s;
-        t[2 * i + 1] = (uint32_t)(s >> 32);
-        cin = over;
+    for (int i = 0; i < 3; i++) {  // (the carry that reaches limb 3 is 0 or 1: it stays there)
+        r.v[i + 1] += r.v[i] >> 29;
+        r.v[i] &= S29_M;
     }
+    s29_opaque(r);
+    return r;
+}
+template <>
+FR_HD __forceinline__ S29 s29_weak<1>(const S29 &a) {  // 2^256 = 2^224 - 2^192 - 2^96 + 1; the two negative terms borrow from a raised zero (limbs 3..7)
+    S29 r = a;
+    const uint32_t e = r.v[8] >> 24, nz = e ? 0xffffffffu : 0u;  // e < 2^7
+#if S29_CHECKED
+    S29_ASSERT(e < 128u);
+    for (int i = 0; i < 8; i++) S29_ASSERT(a.v[i] <= S29_M);
+#endif
+    r.v[8] &= 0x00ffffffu;
+    r.v[0] += e;
+    r.v[3] += (nz & 0x20000000u) - (e << 9);
+    r.v[4] += nz & S29_M;
+    r.v[5] += nz & S29_M;
+    r.v[6] += (nz & S29_M) - (e << 18);
+    r.v[7] += (e << 21) - (nz & 1u);
+    r = s29_norm(r);
+    s29_opaque(r);
+    return r;
+}
+// normalised limbs, value < 2 p -> [0, p)
+template <int C>
+FR_HD __forceinline__ S29 s29_csub_p(const S29 &a) {
+    S29 d;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t t = (int32_t)a.v[i] - (int32_t)sp29_p<C>(i) + borrow;
+        d.v[i] = i < 8 ? ((uint32_t)t & S29_M) : (uint32_t)t;
+        borrow = i < 8 ? (t >> 29) : (t >> 31);
+    }
+    S29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+// limbs < 2^31 below the top, value < 128 p -> the canonical representative of the domain form
+template <int C>
+FR_HD __forceinline__ S29 s29_canon(const S29 &a) { return s29_csub_p<C>(s29_norm(s29_weak<C>(s29_norm(a)))); }
+template <int C>
+FR_HD __forceinline__ bool s29_is_zero(const S29 &a) {  // a as for s29_canon: is it 0 (mod p)
+    const S29 c = s29_canon<C>(a);
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) z |= c.v[i];
+    return z == 0u;
+}
+// the same for a coordinate as the point formulas keep them: exact limbs (secp256k1: limb 3 may read 2^29, which neither 0 nor p does), value < 2 p:
+// it is 0 or p
+template <int C>
+FR_HD __forceinline__ bool s29_is_zero_coord(const S29 &a) {
+#if S29_CHECKED
+    for (int i = 0; i < 8; i++) S29_ASSERT(a.v[i] <= S29_M + (C == 0 && i == 3 ? 1u : 0u));
+    S29_ASSERT(a.v[8] < (1u << 25));  // < 2 p
+#endif
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        z |= a.v[i];
+        e |= a.v[i] ^ sp29_p<C>(i);
+    }
+    return z == 0u || e == 0u;
+}
+template <int C>
+FR_HD __forceinline__ bool s29_eq(const S29 &a, const S29 &b) {  // a = b (mod p)
+    const S29 x = s29_canon<C>(a), y = s29_canon<C>(b);
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) z |= x.v[i] ^ y.v[i];
+    return z == 0u;
 }
 
-// ---- reduction of a 512-bit product to [0, p)
+// ---- products. Operands: limbs < 2^30 (a normalised value, or the limb-wise sum of two), top limb < 2^31; a column of nine products stays
+// below 2^64. secp256k1: any value; result < 1.01 p, limbs < 2^29 except limb 3 <= 2^29. secp256r1: result < (A B / 32 + 1) p, normalised.
+#if S29_CHECKED
+static inline void s29_check_columns(const S29 &a, const S29 &b) {  // every column of a b, with its carry, within 64 bits; the product's top within 32
+    unsigned __int128 acc = 0;
+    for (int k = 0; k < 17; k++) {
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 9) acc += (unsigned __int128)a.v[i] * b.v[k - i];
+        S29_ASSERT(acc < ((unsigned __int128)1 << 63));  // (room for the reduction terms of secp256r1)
+        acc >>= 29;
+    }
+    S29_ASSERT(acc < ((unsigned __int128)1 << 32));
+}
+#endif
 template <int C>
-FR_HD __forceinline__ Fr sp_reduce(const uint32_t t[16]);
-// secp256k1: 2^256 = 2^32 + 977 (mod p)
+FR_HD __forceinline__ S29 s29_reduce_wide(const uint32_t (&t)[18]);
+// secp256k1: t = the 18 limbs of the product (29 bits each, t[17] the rest)
 template <>
-FR_HD __forceinline__ Fr sp_reduce<0>(const uint32_t t[16]) {
-    uint32_t r[8];
-    uint64_t acc = 0;
+FR_HD __forceinline__ S29 s29_reduce_wide<0>(const uint32_t (&t)[18]) {
+    S29 r;
+    uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {  // low + high * 977 + (high << 32)
-        acc += (uint64_t)t[8 + i] * 977u + t[i];
-        if (i > 0) acc += t[7 + i];
-        r[i] = (uint32_t)acc;
-        acc >>= 32;
+    for (int i = 0; i < 9; i++) {  // L + H (31264 + 2^8 2^29)
+        c += (uint64_t)t[9 + i] * 31264u + t[i];
+        if (i > 0) c += (uint64_t)t[8 + i] << 8;
+        r.v[i] = (uint32_t)c & S29_M;
+        c >>= 29;
     }
-    acc += t[15];  // what is left above 2^256: < 2^34
-    const uint64_t k = acc;
-    acc = k * 977u + r[0];
-    r[0] = (uint32_t)acc;
-    acc >>= 32;
-    acc += (uint64_t)r[1] + (uint32_t)k;
-    r[1] = (uint32_t)acc;
-    acc >>= 32;
-    acc += (uint64_t)r[2] + (k >> 32);
-    r[2] = (uint32_t)acc;
-    acc >>= 32;
-#pragma unroll
-    for (int i = 3; i < 8; i++) {
-        acc += r[i];
-        r[i] = (uint32_t)acc;
-        acc >>= 32;
-    }
-    const uint32_t over = (uint32_t)acc;  // 0 / 1; the wrapped value is then tiny, so r + (2^32 + 977) neither carries nor reaches p
-    Fr x, d, c977 = fr_zero();
-#pragma unroll
-    for (int i = 0; i < 8; i++) x.v[i] = r[i];
-    c977.v[0] = 977u;
-    c977.v[1] = 1u;
-    const uint32_t carry = fr_add256(d, x, c977);  // x >= p <=> x + (2^256 - p) carries
-    const bool take = (over | carry) != 0u;
-#pragma unroll
-    for (int i = 0; i < 8; i++) x.v[i] = take ? d.v[i] : x.v[i];
-    return x;
-}
-// secp256r1: FIPS 186-4 D.2.3 on 32-bit words c0..c15, as signed column sums; 2^256 = 2^224 - 2^192 - 2^96 + 1 (mod p) folds the carry
-template <>
-FR_HD __forceinline__ Fr sp_reduce<1>(const uint32_t t[16]) {
-    int64_t c[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) c[i] = (int64_t)t[i];
-    int64_t w[8];
-    w[0] = c[0] + c[8] + c[9] - c[11] - c[12] - c[13] - c[14];
-    w[1] = c[1] + c[9] + c[10] - c[12] - c[13] - c[14] - c[15];
-    w[2] = c[2] + c[10] + c[11] - c[13] - c[14] - c[15];
-    w[3] = c[3] + 2 * c[11] + 2 * c[12] + c[13] - c[15] - c[8] - c[9];
-    w[4] = c[4] + 2 * c[12] + 2 * c[13] + c[14] - c[9] - c[10];
-    w[5] = c[5] + 2 * c[13] + 2 * c[14] + c[15] - c[10] - c[11];
-    w[6] = c[6] + 3 * c[14] + 2 * c[15] + c[13] - c[8] - c[9];
-    w[7] = c[7] + 3 * c[15] + c[8] - c[10] - c[11] - c[12] - c[13];
-    uint32_t r[8];
-    int64_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        acc += w[i];
-        r[i] = (uint32_t)acc;
-        acc >>= 32;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {  // |carry| <= 6, then <= 1, then 0
-        const int64_t k = acc;
-        acc = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            acc += (int64_t)r[i];
-            if (i == 0 || i == 7) acc += k;
-            if (i == 3 || i == 6) acc -= k;
-            r[i] = (uint32_t)acc;
-            acc >>= 32;
-        }
-    }
-    Fr x, d;
-#pragma unroll
-    for (int i = 0; i < 8; i++) x.v[i] = r[i];
-    const uint32_t borrow = fr_sub256(d, x, sp_modulus<1>());
-#pragma unroll
-    for (int i = 0; i < 8; i++) x.v[i] = borrow ? x.v[i] : d.v[i];
-    return x;
-}
-
-template <int C>
-FR_HD __forceinline__ Fr sp_mul(const Fr &a, const Fr &b) {
-    uint32_t t[16];
-    secp_mul_wide(t, a, b);
-    return sp_reduce<C>(t);
-}
-template <int C>
-FR_HD __forceinline__ Fr sp_sqr(const Fr &a) {
-    uint32_t t[16];
-    secp_sqr_wide(t, a);
-    return sp_reduce<C>(t);
-}
-template <int C>
-FR_HD __forceinline__ Fr sp_add(const Fr &a, const Fr &b) {
-    Fr r, d;
-    const uint32_t c = fr_add256(r, a, b);
-    const uint32_t borrow = fr_sub256(d, r, sp_modulus<C>());
-    const bool sub = c != 0u || borrow == 0u;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = sub ? d.v[i] : r.v[i];
+    c += (uint64_t)t[17] << 8;  // what stands at 2^261 now (< 2^42): once more through 31264 + 2^8 2^29, together with bits 256..260 through 977 + 2^3 2^29
+    const uint32_t e = r.v[8] >> 24;
+    r.v[8] &= 0x00ffffffu;
+    uint64_t d = c * 31264u + (uint64_t)(e * 977u) + r.v[0];
+    r.v[0] = (uint32_t)d & S29_M;
+    d >>= 29;
+    d += (c << 8) + (uint64_t)(e << 3) + r.v[1];
+    r.v[1] = (uint32_t)d & S29_M;
+    d >>= 29;
+    d += r.v[2];
+    r.v[2] = (uint32_t)d & S29_M;
+    r.v[3] += (uint32_t)(d >> 29);  // 0 or 1
+    s29_opaque(r);
     return r;
 }
 template <int C>
-FR_HD __forceinline__ Fr sp_sub(const Fr &a, const Fr &b) {
-    Fr r, q;
-    const uint32_t mask = fr_sub256(r, a, b) ? 0xffffffffu : 0u;
+FR_HD __forceinline__ S29 s29_mul(const S29 &a, const S29 &b);
+template <int C>
+FR_HD __forceinline__ S29 s29_sqr(const S29 &a);
+template <>
+FR_HD __forceinline__ S29 s29_mul<0>(const S29 &a, const S29 &b) {
+#if S29_CHECKED
+    s29_check_columns(a, b);
+#endif
+    uint32_t t[18];
+    uint64_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) q.v[i] = Secp<C>::p(i) & mask;
-    fr_add256(r, r, q);
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 9) acc += (uint64_t)a.v[i] * b.v[k - i];
+        t[k] = (uint32_t)acc & S29_M;
+        acc >>= 29;
+    }
+    t[17] = (uint32_t)acc;
+    return s29_reduce_wide<0>(t);
+}
+template <>
+FR_HD __forceinline__ S29 s29_sqr<0>(const S29 &a) {  // the 36 cross products once, against the doubled limbs
+#if S29_CHECKED
+    s29_check_columns(a, a);
+    for (int i = 0; i < 9; i++) S29_ASSERT(a.v[i] < (1u << 31));
+#endif
+    uint32_t t[18], d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i > i && k - i < 9) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        t[k] = (uint32_t)acc & S29_M;
+        acc >>= 29;
+    }
+    t[17] = (uint32_t)acc;
+    return s29_reduce_wide<0>(t);
+}
+// secp256r1: column k of a b + sum m_i p 2^(29 i). m_k = the low limb of column k; it leaves that column (the shift drops it) and enters
+// columns k + 3 (2^9), k + 6 (2^18), k + 7 (0x1fe00000), k + 8 (0xffffff): p = (2^96 - 1) + 2^192 + 2^224 (2^32 - 1)
+#define SECP_R1_REDUCE_STEP(k)                                                \
+    if ((k) >= 3 && (k) - 3 < 9) acc += (uint64_t)m[(k) - 3] << 9;            \
+    if ((k) >= 6 && (k) - 6 < 9) acc += (uint64_t)m[(k) - 6] << 18;           \
+    if ((k) >= 7 && (k) - 7 < 9) acc += (uint64_t)m[(k) - 7] * 0x1fe00000u;   \
+    if ((k) >= 8 && (k) - 8 < 9) acc += (uint64_t)m[(k) - 8] * 0x00ffffffu;   \
+    if ((k) < 9) m[k] = (uint32_t)acc & S29_M;                                \
+    else if ((k) < 17) r.v[(k) - 9] = (uint32_t)acc & S29_M;                  \
+    acc >>= 29;
+template <>
+FR_HD __forceinline__ S29 s29_mul<1>(const S29 &a, const S29 &b) {
+#if S29_CHECKED
+    s29_check_columns(a, b);
+#endif
+    uint32_t m[9];
+    S29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 9) acc += (uint64_t)a.v[i] * b.v[k - i];
+        SECP_R1_REDUCE_STEP(k)
+    }
+    r.v[8] = (uint32_t)acc;
+    s29_opaque(r);
     return r;
 }
+template <>
+FR_HD __forceinline__ S29 s29_sqr<1>(const S29 &a) {
+#if S29_CHECKED
+    s29_check_columns(a, a);
+    for (int i = 0; i < 9; i++) S29_ASSERT(a.v[i] < (1u << 31));
+#endif
+    uint32_t m[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+    S29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i > i && k - i < 9) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        SECP_R1_REDUCE_STEP(k)
+    }
+    r.v[8] = (uint32_t)acc;
+    s29_opaque(r);
+    return r;
+}
+#undef SECP_R1_REDUCE_STEP
 template <int C>
-FR_HD __forceinline__ Fr sp_neg(const Fr &a) { return sp_sub<C>(fr_zero(), a); }
-template <int C>
-FR_HD __forceinline__ Fr sp_sqr_n(Fr a, int n) {
+FR_HD __forceinline__ S29 s29_sqr_n(S29 a, int n) {
 #pragma unroll 1
-    for (int i = 0; i < n; i++) a = sp_sqr<C>(a);
+    for (int i = 0; i < n; i++) a = s29_sqr<C>(a);
     return a;
 }
+
+// ---- domain form <-> canonical integers (8 x 32)
+FR_HD __forceinline__ S29 sp_load(const Fr &a) {
+    S29 r = fr29_from(a);
+    s29_opaque(r);
+    return r;
+}
 template <int C>
-FR_HD inline __noinline__ Fr sp_inv(const Fr &a) { return fr_safegcd_inv<SecpMod30<2 * C>>(a); }  // 0 for 0
+FR_HD __forceinline__ S29 sp_one() {  // 1 in the domain form
+    if (C == 0) {
+        S29 o = s29_zero();
+        o.v[0] = 1u;
+        return o;
+    }
+    return fr29_from(Fr{{0x00000020u, 0x00000000u, 0x00000000u, 0xffffffe0u, 0xffffffffu, 0xffffffffu, 0xffffffdfu, 0x0000001fu}});  // R mod p
+}
+template <int C>
+FR_HD __forceinline__ S29 sp_enter(const Fr &x) {  // x < 2^256
+    if (C == 0) return sp_load(x);
+    return s29_mul<1>(fr29_from(x), fr29_from(Fr{{0x00000c00u, 0x00000000u, 0xfffffc00u, 0xffffefffu, 0xfffffbffu, 0xffffffffu, 0xfffff7ffu, 0x000013ffu}}));  // R^2 mod p
+}
+template <int C>
+FR_HD __forceinline__ Fr sp_leave(const S29 &a) {  // a as for s29_canon -> [0, p)
+    if (C == 0) return fr29_pack(s29_canon<0>(a));
+    S29 one = s29_zero();
+    one.v[0] = 1u;
+    return fr29_pack(s29_canon<1>(s29_mul<1>(s29_norm(s29_weak<1>(s29_norm(a))), one)));
+}
+// the canonical limbs of a domain value, as the tables hold them (no change of form)
+template <int C>
+FR_HD __forceinline__ Fr sp_store(const S29 &a) { return fr29_pack(s29_canon<C>(a)); }
+template <int C>
+FR_HD inline __noinline__ S29 sp29_inv(const S29 &a) {  // 1 / a in the domain form; 0 for 0
+    const Fr i = fr_safegcd_inv<SecpMod30<2 * C>>(sp_store<C>(a));
+    if (C == 0) return fr29_from(i);
+    // (a R)^-1 R^3 / R = a^-1 R
+    return s29_mul<1>(fr29_from(i), fr29_from(Fr{{0x00050000u, 0xfffe8000u, 0xfffbffffu, 0xfff6ffffu, 0xfffe7fffu, 0x0002ffffu, 0x00008000u, 0x000c0000u}}));
+}
 template <int C>
 FR_HD inline __noinline__ Fr sn_inv(const Fr &a) { return fr_safegcd_inv<SecpMod30<2 * C + 1>>(a); }
 
-// a^((p + 1) / 4): the square root of a when a is a square (both primes are 3 mod 4)
+// a^((p + 1) / 4): the square root of a when a is a square (both primes are 3 mod 4). Operand < 2 p, normalised; result < 2 p.
 template <int C>
-FR_HD inline __noinline__ Fr sp_sqrt_candidate(const Fr &a);
+FR_HD inline __noinline__ S29 sp29_sqrt_candidate(const S29 &a);
 // (p + 1) / 4 = 1{223} 0 1{22} 0000 11 00 in binary (the chain of libsecp256k1's field square root)
 template <>
-FR_HD inline __noinline__ Fr sp_sqrt_candidate<0>(const Fr &a) {
-    const Fr x2 = sp_mul<0>(sp_sqr<0>(a), a), x3 = sp_mul<0>(sp_sqr<0>(x2), a);
-    const Fr x6 = sp_mul<0>(sp_sqr_n<0>(x3, 3), x3), x9 = sp_mul<0>(sp_sqr_n<0>(x6, 3), x3), x11 = sp_mul<0>(sp_sqr_n<0>(x9, 2), x2);
-    const Fr x22 = sp_mul<0>(sp_sqr_n<0>(x11, 11), x11), x44 = sp_mul<0>(sp_sqr_n<0>(x22, 22), x22), x88 = sp_mul<0>(sp_sqr_n<0>(x44, 44), x44);
-    const Fr x176 = sp_mul<0>(sp_sqr_n<0>(x88, 88), x88), x220 = sp_mul<0>(sp_sqr_n<0>(x176, 44), x44), x223 = sp_mul<0>(sp_sqr_n<0>(x220, 3), x3);
-    Fr t = sp_mul<0>(sp_sqr_n<0>(x223, 23), x22);
-    t = sp_mul<0>(sp_sqr_n<0>(t, 6), x2);
-    return sp_sqr_n<0>(t, 2);
+FR_HD inline __noinline__ S29 sp29_sqrt_candidate<0>(const S29 &a) {
+    const S29 x2 = s29_mul<0>(s29_sqr<0>(a), a), x3 = s29_mul<0>(s29_sqr<0>(x2), a);
+    const S29 x6 = s29_mul<0>(s29_sqr_n<0>(x3, 3), x3), x9 = s29_mul<0>(s29_sqr_n<0>(x6, 3), x3), x11 = s29_mul<0>(s29_sqr_n<0>(x9, 2), x2);
+    const S29 x22 = s29_mul<0>(s29_sqr_n<0>(x11, 11), x11), x44 = s29_mul<0>(s29_sqr_n<0>(x22, 22), x22), x88 = s29_mul<0>(s29_sqr_n<0>(x44, 44), x44);
+    const S29 x176 = s29_mul<0>(s29_sqr_n<0>(x88, 88), x88), x220 = s29_mul<0>(s29_sqr_n<0>(x176, 44), x44), x223 = s29_mul<0>(s29_sqr_n<0>(x220, 3), x3);
+    S29 t = s29_mul<0>(s29_sqr_n<0>(x223, 23), x22);
+    t = s29_mul<0>(s29_sqr_n<0>(t, 6), x2);
+    return s29_sqr_n<0>(t, 2);
 }
 // (p + 1) / 4 = (2^32 - 1) 2^222 + 2^190 + 2^94
 template <>
-FR_HD inline __noinline__ Fr sp_sqrt_candidate<1>(const Fr &a) {
-    const Fr x2 = sp_mul<1>(sp_sqr<1>(a), a), x4 = sp_mul<1>(sp_sqr_n<1>(x2, 2), x2), x8 = sp_mul<1>(sp_sqr_n<1>(x4, 4), x4);
-    const Fr x16 = sp_mul<1>(sp_sqr_n<1>(x8, 8), x8), x32 = sp_mul<1>(sp_sqr_n<1>(x16, 16), x16);
-    Fr t = sp_mul<1>(sp_sqr_n<1>(x32, 32), a);
-    t = sp_mul<1>(sp_sqr_n<1>(t, 96), a);
-    return sp_sqr_n<1>(t, 94);
+FR_HD inline __noinline__ S29 sp29_sqrt_candidate<1>(const S29 &a) {
+    const S29 x2 = s29_mul<1>(s29_sqr<1>(a), a), x4 = s29_mul<1>(s29_sqr_n<1>(x2, 2), x2), x8 = s29_mul<1>(s29_sqr_n<1>(x4, 4), x4);
+    const S29 x16 = s29_mul<1>(s29_sqr_n<1>(x8, 8), x8), x32 = s29_mul<1>(s29_sqr_n<1>(x16, 16), x16);
+    S29 t = s29_mul<1>(s29_sqr_n<1>(x32, 32), a);
+    t = s29_mul<1>(s29_sqr_n<1>(t, 96), a);
+    return s29_sqr_n<1>(t, 94);
 }
+
+// ---- the same field operations on canonical integers (the host-run test drives these; the curve routines stay in the working form)
+template <int C> FR_HD __forceinline__ Fr sp_mul(const Fr &a, const Fr &b) { return sp_leave<C>(s29_mul<C>(sp_enter<C>(a), sp_enter<C>(b))); }
+template <int C> FR_HD __forceinline__ Fr sp_sqr(const Fr &a) { return sp_leave<C>(s29_sqr<C>(sp_enter<C>(a))); }
+template <int C> FR_HD __forceinline__ Fr sp_add(const Fr &a, const Fr &b) { return sp_leave<C>(s29_addl(sp_enter<C>(a), sp_enter<C>(b))); }
+template <int C> FR_HD __forceinline__ Fr sp_sub(const Fr &a, const Fr &b) { return sp_leave<C>(s29_subl<C>(sp_enter<C>(a), sp_enter<C>(b), 1)); }
+template <int C> FR_HD __forceinline__ Fr sp_inv(const Fr &a) { return sp_leave<C>(sp29_inv<C>(sp_enter<C>(a))); }
+template <int C> FR_HD __forceinline__ Fr sp_sqrt_candidate(const Fr &a) { return sp_leave<C>(sp29_sqrt_candidate<C>(sp_enter<C>(a))); }
 
 // ---- scalar field: Montgomery product a b / 2^256 mod n (CIOS with the extra carry word: n is a full 256-bit modulus)
 template <int C>
@@ -416,65 +632,80 @@ FR_HD inline __noinline__ SecpSplit secp256k1_split_lambda(const Fr &k) {
     return r;
 }
 
-// ---- points: Jacobian (X / Z^2, Y / Z^3), Z == 0 <=> identity; a = 0 (secp256k1) or a = -3 (secp256r1)
-struct SJac { Fr X, Y, Z; };
+// ---- points: Jacobian (X / Z^2, Y / Z^3) in the domain form. Coordinates: exact limbs below 2^29 (secp256k1: limb 3 may read 2^29), value
+// < 1.1 p -- a product of small operands as it is, anything else through s29_out; Z = 0 (mod p) <=> identity; a = 0 (secp256k1) or a = -3 (secp256r1). Affine points (tables, inputs): canonical limbs.
+struct SJac { S29 X, Y, Z; };
 struct SAff { Fr x, y; };
-FR_HD __forceinline__ Fr secp_one() {
-    Fr o = fr_zero();
-    o.v[0] = 1u;
-    return o;
-}
-FR_HD __forceinline__ SJac sj_identity() { return SJac{secp_one(), secp_one(), fr_zero()}; }
+template <int C>
+FR_HD __forceinline__ SJac sj_identity() { return SJac{sp_one<C>(), sp_one<C>(), s29_zero()}; }
+template <int C>
+FR_HD __forceinline__ S29 s29_out(const S29 &lazy) { return s29_weak<C>(s29_norm(lazy)); }  // value < 128 p, limbs < 2^32 -> an output coordinate
 template <int C>
 FR_HD __forceinline__ SJac sj_dbl(const SJac &p) {
-    if (fr_is_zero(p.Z) || fr_is_zero(p.Y)) return sj_identity();
-    const Fr yy = sp_sqr<C>(p.Y), yyyy = sp_sqr<C>(yy);
-    Fr s = sp_mul<C>(p.X, yy);
-    s = sp_add<C>(s, s);
-    s = sp_add<C>(s, s);
-    Fr m;
-    if (C == 1) {  // 3 X^2 - 3 Z^4 = 3 (X - Z^2)(X + Z^2)
-        const Fr zz = sp_sqr<C>(p.Z);
-        m = sp_mul<C>(sp_sub<C>(p.X, zz), sp_add<C>(p.X, zz));
-    } else m = sp_sqr<C>(p.X);
-    m = sp_add<C>(sp_add<C>(m, m), m);
+    if (s29_is_zero_coord<C>(p.Z) || s29_is_zero_coord<C>(p.Y)) return sj_identity<C>();
     SJac r;
-    r.X = sp_sub<C>(sp_sub<C>(sp_sqr<C>(m), s), s);
-    Fr y8 = sp_add<C>(yyyy, yyyy);
-    y8 = sp_add<C>(y8, y8);
-    y8 = sp_add<C>(y8, y8);
-    r.Y = sp_sub<C>(sp_mul<C>(m, sp_sub<C>(s, r.X)), y8);
-    const Fr yz = sp_mul<C>(p.Y, p.Z);
-    r.Z = sp_add<C>(yz, yz);
+    if (C == 0) {  // dbl-2009-l: 2 M + 5 S
+        const S29 A = s29_sqr<C>(p.X), B = s29_sqr<C>(p.Y), Cc = s29_sqr<C>(B);                          // < 1.01
+        const S29 s = s29_sqr<C>(s29_addl(p.X, B));                                                       // (X + B)^2
+        const S29 t = s29_norm(s29_subl<C>(s29_subl<C>(s, A, 1), Cc, 1));                                 // < 5.01
+        const S29 D = s29_dbll(t);                                                                        // < 10.02, limbs < 2^30
+        const S29 E = s29_norm(s29_addl(s29_dbll(A), A));                                                 // 3 A < 3.03
+        const S29 F = s29_sqr<C>(E);
+        r.X = s29_out<C>(s29_subl<C>(s29_subl<C>(F, D, 4), D, 4));                                        // F - 2 D: < 33.01 before
+        const S29 m = s29_mul<C>(E, s29_norm(s29_subl<C>(D, r.X, 1)));                                    // E (D - X3)
+        const S29 C8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(Cc))));                                        // < 8.08, limbs <= 2^30 - 2
+        r.Y = s29_out<C>(s29_subl<C>(m, C8, 4));
+        r.Z = s29_out<C>(s29_dbll(s29_mul<C>(p.Y, p.Z)));
+    } else {  // dbl-2001-b (a = -3): 3 M + 5 S
+        const S29 delta = s29_sqr<C>(p.Z), gamma = s29_sqr<C>(p.Y);                                       // < 1.04
+        const S29 beta = s29_mul<C>(p.X, gamma);                                                          // < 1.04
+        const S29 u = s29_norm(s29_subl<C>(p.X, delta, 1));                                               // X - delta < 3.01
+        const S29 al0 = s29_mul<C>(u, s29_addl(p.X, delta));                                              // (X - delta)(X + delta): 3.01 * 2.05 / 32 + 1 < 1.2
+        const S29 alpha = s29_norm(s29_addl(s29_dbll(al0), al0));                                         // < 3.6
+        const S29 a2 = s29_sqr<C>(alpha);                                                                 // < 1.41
+        const S29 b8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(beta))));                                      // < 8.32, limbs <= 2^30 - 2
+        r.X = s29_out<C>(s29_subl<C>(a2, b8, 4));                                                         // alpha^2 - 8 beta
+        const S29 zz = s29_sqr<C>(s29_addl(p.Y, p.Z));                                                    // (Y + Z)^2: 2.02^2 / 32 + 1 < 1.13
+        r.Z = s29_out<C>(s29_subl<C>(s29_subl<C>(zz, gamma, 1), delta, 1));
+        const S29 w = s29_norm(s29_subl<C>(s29_dbll(s29_dbll(beta)), r.X, 1));                            // 4 beta - X3 < 6.16
+        const S29 m = s29_mul<C>(alpha, w);                                                               // 3.6 * 6.16 / 32 + 1 < 1.7
+        const S29 g8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(s29_sqr<C>(gamma)))));                         // 8 gamma^2 < 8.3
+        r.Y = s29_out<C>(s29_subl<C>(m, g8, 4));
+    }
     return r;
 }
-// complete mixed addition of a finite affine point: 8 M + 3 S
+// complete mixed addition of a finite affine point (x2, y2: domain form, exact limbs, <= p): 8 M + 3 S
 template <int C>
-FR_HD __forceinline__ SJac sj_add_aff(const SJac &p, const SAff &q) {
-    if (fr_is_zero(p.Z)) return SJac{q.x, q.y, secp_one()};
-    const Fr z1z1 = sp_sqr<C>(p.Z);
-    const Fr u2 = sp_mul<C>(q.x, z1z1), s2 = sp_mul<C>(sp_mul<C>(q.y, p.Z), z1z1);
-    const Fr h = sp_sub<C>(u2, p.X), rr = sp_sub<C>(s2, p.Y);
-    if (fr_is_zero(h)) return fr_is_zero(rr) ? sj_dbl<C>(p) : sj_identity();
-    const Fr hh = sp_sqr<C>(h), hhh = sp_mul<C>(hh, h), v = sp_mul<C>(p.X, hh);
+FR_HD __forceinline__ SJac sj_add_aff29(const SJac &p, const S29 &x2, const S29 &y2) {
+    if (s29_is_zero_coord<C>(p.Z)) return SJac{x2, y2, sp_one<C>()};
+    const S29 z1z1 = s29_sqr<C>(p.Z);
+    const S29 u2 = s29_mul<C>(x2, z1z1), s2 = s29_mul<C>(s29_mul<C>(y2, p.Z), z1z1);                     // < 1.07
+    const S29 h = s29_out<C>(s29_subl<C>(u2, p.X, 1)), rr = s29_norm(s29_subl<C>(s2, p.Y, 1));            // h < 1.01, rr < 3.07
+    if (s29_is_zero_coord<C>(h)) return s29_is_zero<C>(rr) ? sj_dbl<C>(p) : sj_identity<C>();
+    const S29 hh = s29_sqr<C>(h), hhh = s29_mul<C>(hh, h), v = s29_mul<C>(p.X, hh);                       // < 1.04
     SJac r;
-    r.X = sp_sub<C>(sp_sub<C>(sp_sub<C>(sp_sqr<C>(rr), hhh), v), v);
-    r.Y = sp_sub<C>(sp_mul<C>(rr, sp_sub<C>(v, r.X)), sp_mul<C>(p.Y, hhh));
-    r.Z = sp_mul<C>(p.Z, h);
+    r.X = s29_out<C>(s29_subl<C>(s29_subl<C>(s29_sqr<C>(rr), hhh, 1), s29_dbll(v), 2));                   // rr^2 - H^3 - 2 V
+    const S29 m1 = s29_mul<C>(rr, s29_norm(s29_subl<C>(v, r.X, 1)));                                      // rr (V - X3): 3.07 * 3.04 / 32 + 1 < 1.3
+    r.Y = s29_out<C>(s29_subl<C>(m1, s29_mul<C>(p.Y, hhh), 1));
+    r.Z = s29_mul<C>(p.Z, h);
     return r;
 }
 template <int C>
-FR_HD __forceinline__ SAff sj_to_affine(const SJac &p) {  // p finite
-    const Fr zi = sp_inv<C>(p.Z), zi2 = sp_sqr<C>(zi);
-    return SAff{sp_mul<C>(p.X, zi2), sp_mul<C>(p.Y, sp_mul<C>(zi2, zi))};
+FR_HD __forceinline__ SJac sj_add_aff(const SJac &p, const SAff &q) { return sj_add_aff29<C>(p, sp_load(q.x), sp_load(q.y)); }
+template <int C>
+FR_HD __forceinline__ SAff sj_to_affine(const SJac &p) {  // p finite; the canonical limbs of the domain form
+    const S29 zi = sp29_inv<C>(p.Z), zi2 = s29_sqr<C>(zi);
+    return SAff{sp_store<C>(s29_mul<C>(p.X, zi2)), sp_store<C>(s29_mul<C>(p.Y, s29_mul<C>(zi2, zi)))};
 }
 template <int C>
-FR_HD __forceinline__ SAff secp_generator() {
-    return SAff{secp_limbs([](int i) { return Secp<C>::gx(i); }), secp_limbs([](int i) { return Secp<C>::gy(i); })};
+FR_HD __forceinline__ SAff secp_generator() {  // domain form
+    if (C == 0) return SAff{secp_limbs([](int i) { return Secp<C>::gx(i); }), secp_limbs([](int i) { return Secp<C>::gy(i); })};
+    return SAff{Fr{{0x15228783u, 0x3ce61a83u, 0xfdb6c02fu, 0xb752bf88u, 0xec44a20eu, 0x3f6e656eu, 0xa6eab8ccu, 0x120beed7u}},
+                Fr{{0xd2aac150u, 0xbe4a6af9u, 0x433c8b9bu, 0x69571c87u, 0xa43e64b1u, 0x5d10d11bu, 0xb10bb0aau, 0xae3fe314u}}};
 }
 
-// ---- the table of the generator: entry (j, d) = d * 2^(W j) * G, j < 256 / W, 1 <= d < 2^W, 16 words (x, y) at (((j << W) + d) * 16).
-// W = SECP_GWIN_BITS: 16 on the device (16 additions for u1 G, 64 MiB per curve); the host-run test builds its table with -DSECP_GWIN_BITS=8.
+// ---- the table of the generator: entry (j, d) = d * 2^(W j) * G, j < 256 / W, 1 <= d < 2^W, 16 words (x, y; canonical limbs of the domain form) at
+// (((j << W) + d) * 16). W = SECP_GWIN_BITS: 16 on the device (16 additions for u1 G, 64 MiB per curve); the host-run test builds its table with -DSECP_GWIN_BITS=8.
 #ifndef SECP_GWIN_BITS
 #define SECP_GWIN_BITS 16
 #endif
@@ -484,10 +715,10 @@ constexpr uint32_t SECP_GTABLE_WORDS = (SECP_GWINDOWS << SECP_GWIN) * 16u;  // p
 template <int C>
 FR_HD inline SAff secp_gtable_entry(uint32_t j, uint32_t d) {
     const SAff G = secp_generator<C>();
-    SJac base{G.x, G.y, secp_one()};
+    SJac base{sp_load(G.x), sp_load(G.y), sp_one<C>()};
     for (uint32_t i = 0; i < SECP_GWIN * j; i++) base = sj_dbl<C>(base);
     const SAff B = sj_to_affine<C>(base);
-    SJac acc = sj_identity();
+    SJac acc = sj_identity<C>();
     for (int i = (int)SECP_GWIN - 1; i >= 0; i--) {
         acc = sj_dbl<C>(acc);
         if ((d >> i) & 1u) acc = sj_add_aff<C>(acc, B);
@@ -496,29 +727,31 @@ FR_HD inline SAff secp_gtable_entry(uint32_t j, uint32_t d) {
 }
 
 // ---- u1 G + u2 Q
+// a row of the per-lane window table: an affine point in the working form (a lane indexes the table by its own digit: it lives in the lane's scratch)
+struct SAff29 { S29 x, y; };
 // tab <- {Q, 2Q, .., 8Q} affine: seven Jacobian multiples, their Z inverted together (Montgomery's trick: 3 products per point + one inversion)
 template <int C>
-FR_HD __forceinline__ void secp_window_table(SAff tab[8], const SAff &Q) {
-    Fr zs[8], pre[8];
-    tab[0] = Q;
-    SJac cur = sj_dbl<C>(SJac{Q.x, Q.y, secp_one()});
-    tab[1] = SAff{cur.X, cur.Y};
+FR_HD __forceinline__ void secp_window_table(SAff29 tab[8], const S29 &qx, const S29 &qy) {
+    S29 zs[8], pre[8];
+    tab[0] = SAff29{qx, qy};
+    SJac cur = sj_dbl<C>(SJac{qx, qy, sp_one<C>()});
+    tab[1] = SAff29{cur.X, cur.Y};
     zs[1] = pre[1] = cur.Z;
 #pragma unroll 1
     for (int k = 2; k < 8; k++) {
-        cur = sj_add_aff<C>(cur, Q);
-        tab[k] = SAff{cur.X, cur.Y};
+        cur = sj_add_aff29<C>(cur, qx, qy);
+        tab[k] = SAff29{cur.X, cur.Y};
         zs[k] = cur.Z;
-        pre[k] = sp_mul<C>(pre[k - 1], cur.Z);
+        pre[k] = s29_mul<C>(pre[k - 1], cur.Z);
     }
     // k Q is finite for 1 <= k <= 8 (prime order > 8), so every Z is invertible
-    Fr inv = sp_inv<C>(pre[7]);
+    S29 inv = sp29_inv<C>(pre[7]);
 #pragma unroll 1
     for (int k = 7; k >= 1; k--) {
-        const Fr zi = k > 1 ? sp_mul<C>(inv, pre[k - 1]) : inv;
-        if (k > 1) inv = sp_mul<C>(inv, zs[k]);
-        const Fr zi2 = sp_sqr<C>(zi);
-        tab[k] = SAff{sp_mul<C>(tab[k].x, zi2), sp_mul<C>(tab[k].y, sp_mul<C>(zi2, zi))};
+        const S29 zi = k > 1 ? s29_mul<C>(inv, pre[k - 1]) : inv;
+        if (k > 1) inv = s29_mul<C>(inv, zs[k]);
+        const S29 zi2 = s29_sqr<C>(zi);
+        tab[k] = SAff29{s29_mul<C>(tab[k].x, zi2), s29_mul<C>(tab[k].y, s29_mul<C>(zi2, zi))};
     }
 }
 FR_HD __forceinline__ uint32_t secp_limb_at(const Fr &a, uint32_t k) {  // a.v[k] for a lane-dependent k without indexing the registers
@@ -543,20 +776,24 @@ FR_HD __forceinline__ SJac secp_add_generator_multiple(SJac acc, const Fr &u1, c
     }
     return acc;
 }
+// -y of a table row (y a product of small operands: exact limbs, < 1.1 p): 2 p - y through s29_out, so that it is a coordinate again
 template <int C>
-FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const SAff &Q, const Fr &u2, const uint32_t *__restrict__ gtab) {
-    SAff tab[8];
-    secp_window_table<C>(tab, Q);
+FR_HD __forceinline__ S29 s29_neg_row(const S29 &y) { return s29_out<C>(s29_subl<C>(s29_zero(), y, 1)); }
+// Q = (qx, qy): domain form, canonical
+template <int C>
+FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const S29 &qx, const S29 &qy, const Fr &u2, const uint32_t *__restrict__ gtab) {
+    SAff29 tab[8];
+    secp_window_table<C>(tab, qx, qy);
     Fr eights;
 #pragma unroll
     for (int i = 0; i < 8; i++) eights.v[i] = 0x88888888u;
-    SJac acc = sj_identity();
+    SJac acc = sj_identity<C>();
     if constexpr (C == 0) {
         // u2 = k1 + k2 lambda: two 128-bit ladders on one accumulator, 128 doublings; lambda (k Q) = (beta x, y) of the same table
-        const Fr beta = {{0x719501eeu, 0xc1396c28u, 0x12f58995u, 0x9cf04975u, 0xac3434e9u, 0x6e64479eu, 0x657c0710u, 0x7ae96a2bu}};
-        Fr bx[8];
+        const S29 beta = fr29_from(Fr{{0x719501eeu, 0xc1396c28u, 0x12f58995u, 0x9cf04975u, 0xac3434e9u, 0x6e64479eu, 0x657c0710u, 0x7ae96a2bu}});
+        S29 bx[8];
 #pragma unroll 1
-        for (int k = 0; k < 8; k++) bx[k] = sp_mul<C>(tab[k].x, beta);
+        for (int k = 0; k < 8; k++) bx[k] = s29_mul<C>(tab[k].x, beta);
         const SecpSplit sp = secp256k1_split_lambda(u2);
         // signed digits: e = k + 0x88..8 over 32 nibbles, digit i = nibble i of e - 8 (i < 32), digit 32 = bit 128 of e
         Fr e1, e2, eights128 = eights;
@@ -578,10 +815,10 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const SAff &Q, const Fr &
                 if (h ? sp.neg2 : sp.neg1) dg = -dg;
                 if (dg != 0) {
                     const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
-                    SAff q = tab[mag - 1u];
+                    SAff29 q = tab[mag - 1u];
                     if (h) q.x = bx[mag - 1u];
-                    if (dg < 0) q.y = sp_neg<C>(q.y);
-                    acc = sj_add_aff<C>(acc, q);
+                    if (dg < 0) q.y = s29_neg_row<C>(q.y);
+                    acc = sj_add_aff29<C>(acc, q.x, q.y);
                 }
             }
         }
@@ -589,7 +826,7 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const SAff &Q, const Fr &
         // signed digits of u2: with e = u2 + 0x88..8, digit i = nibble i of e - 8 in [-8, 7] (i < 64), digit 64 = the carry
         Fr e;
         const uint32_t top = fr_add256(e, u2, eights);
-        if (top) acc = SJac{Q.x, Q.y, secp_one()};
+        if (top) acc = SJac{qx, qy, sp_one<C>()};
 #pragma unroll 1
         for (int i = 255; i >= 0; i--) {  // one doubling and one addition in the loop body: the code stays within reach of the instruction cache
             acc = sj_dbl<C>(acc);
@@ -597,9 +834,9 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const SAff &Q, const Fr &
             const int32_t dg = (int32_t)((secp_limb_at(e, (uint32_t)i >> 5) >> (i & 31)) & 15u) - 8;
             if (dg != 0) {
                 const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
-                SAff q = tab[mag - 1u];
-                if (dg < 0) q.y = sp_neg<C>(q.y);
-                acc = sj_add_aff<C>(acc, q);
+                SAff29 q = tab[mag - 1u];
+                if (dg < 0) q.y = s29_neg_row<C>(q.y);
+                acc = sj_add_aff29<C>(acc, q.x, q.y);
             }
         }
     }
@@ -622,30 +859,40 @@ FR_HD inline __noinline__ uint32_t secp_verify(const Fr &r, const Fr &s, const F
     const Fr n = sn_modulus<C>();
     if (fr_is_zero(r) || fr_is_zero(s) || secp_geq(r, n) || secp_geq(s, n)) { *panic = EP_SIG; return 0; }
     if (secp_geq(x, sp_modulus<C>())) { *panic = EP_PUBKEY; return 0; }
-    Fr rhs = sp_mul<C>(sp_sqr<C>(x), x);
-    if (C == 1) rhs = sp_sub<C>(rhs, sp_add<C>(sp_add<C>(x, x), x));
-    rhs = sp_add<C>(rhs, secp_limbs([](int i) { return Secp<C>::b(i); }));
-    Fr y = fr_zero();
+    // x^3 + a x + b in the domain form
+    const S29 xd = sp_enter<C>(x);
+    S29 rhs = s29_mul<C>(s29_sqr<C>(xd), xd);                                                       // < 1.04
+    if (C == 1) {
+        const S29 x3 = s29_norm(s29_addl(s29_dbll(xd), xd));                                        // 3 x < 3.2
+        const S29 bR = fr29_from(Fr{{0x3897bbfbu, 0x139bec45u, 0x1086121bu, 0x9e00b994u, 0xe425dad5u, 0xb444157eu, 0x90e90681u, 0x8600c3bbu}});  // b R mod p
+        rhs = s29_out<C>(s29_addl(s29_subl<C>(rhs, x3, 2), bR));
+    } else {
+        S29 seven = s29_zero();
+        seven.v[0] = 7u;
+        rhs = s29_out<C>(s29_addl(rhs, seven));
+    }
+    S29 yd = s29_zero();
     bool have_y = false;
-    if (y_given && ((y_given->v[0] ^ y_odd) & 1u) == 0u && !secp_geq(*y_given, sp_modulus<C>()) && fr_eq(sp_sqr<C>(*y_given), rhs)) {
-        y = *y_given;
-        have_y = true;
+    if (y_given && ((y_given->v[0] ^ y_odd) & 1u) == 0u && !secp_geq(*y_given, sp_modulus<C>())) {
+        yd = sp_enter<C>(*y_given);
+        have_y = s29_eq<C>(s29_sqr<C>(yd), rhs);
     }
     if (!have_y) {
-        y = sp_sqrt_candidate<C>(rhs);
-        if (!fr_eq(sp_sqr<C>(y), rhs)) { *panic = EP_PUBKEY; return 0; }
-        if ((y.v[0] & 1u) != (y_odd & 1u)) y = sp_neg<C>(y);
+        yd = sp29_sqrt_candidate<C>(rhs);
+        if (!s29_eq<C>(s29_sqr<C>(yd), rhs)) { *panic = EP_PUBKEY; return 0; }
+        if ((sp_leave<C>(yd).v[0] & 1u) != (y_odd & 1u)) yd = s29_subl<C>(s29_zero(), yd, 1);     // (a product: < 2 p)
     }
+    yd = sp_load(sp_store<C>(yd));  // canonical: a table row
     if (n_msg != 32u) { *panic = EP_MSG_LEN; return 0; }
     if (secp_geq(z, n)) { *panic = EP_MSG_RANGE; return 0; }
     Fr d;
     if (fr_sub256(d, secp_limbs([](int i) { return Secp<C>::half_n(i); }), s)) return 0;  // s > n / 2: not low-S normalised
     const Fr si = sn_inv<C>(s);
     const Fr u1 = sn_mul<C>(z, si), u2 = sn_mul<C>(r, si);
-    const SJac R = secp_mul2<C>(u1, SAff{x, y}, u2, gtab);
-    if (fr_is_zero(R.Z)) { *panic = EP_IDENTITY; return 0; }
-    const Fr zi = sp_inv<C>(R.Z);
-    const Fr rx = sp_mul<C>(R.X, sp_sqr<C>(zi));
+    const SJac R = secp_mul2<C>(u1, sp_load(sp_store<C>(xd)), yd, u2, gtab);
+    if (s29_is_zero_coord<C>(R.Z)) { *panic = EP_IDENTITY; return 0; }
+    const S29 zi = sp29_inv<C>(R.Z);
+    const Fr rx = sp_leave<C>(s29_mul<C>(R.X, s29_sqr<C>(zi)));
     if (secp_geq(rx, n)) { *panic = EP_X_RANGE; return 0; }
     return fr_eq(rx, r) ? 1u : 0u;
 }

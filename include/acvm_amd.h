@@ -196,6 +196,13 @@ int acvm_selftest(uint32_t n, uint64_t seed);
  * 8 / 9 = in[0] * (in[1], in[2]) for a 256-bit integer and an affine point: 8 through SchnorrVerify's GLV + window-table path, 9 by double-and-add.
  * in: n_in x 32 bytes big-endian; out: 64 bytes (x || y) big-endian. */
 int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64);
+/* Component probes of the ECDSA kernels (secp_device.hpp run ON THE DEVICE against integers: k256 / p256 are the spec of blackbox_solver/src/lib.rs:66-210,
+ * the tests compare with Python): curve 0 = secp256k1, 1 = secp256r1; one device lane per item. what: 0 a b -> a b; 1 a -> a^2; 2 a b -> a + b; 3 a b -> a - b;
+ * 4 a -> 1 / a (0 for 0); 5 a -> a^((p + 1) / 4), all mod p; 6 X Y Z -> the Jacobian double; 7 X Y Z x y -> the Jacobian sum with the affine point (x, y);
+ * compositions the formulas are made of: 8 a -> a^4 (a product fed to a product); 9 a b -> (a + b)^2 (an unreduced sum into a product); 10 a b -> a - 4 b
+ * (a difference against a multiple of p); 11 a -> a^32 (the squaring loop of the square-root chains).
+ * in: n_items x (2, 1, 2, 2, 1, 1, 3, 5, 1, 2, 2, 1) x 32 bytes big-endian, values < p; out: n_items x (1, 1, 1, 1, 1, 1, 3, 3, 1, 1, 1, 1) x 32 bytes. */
+int acvm_debug_secp(uint32_t curve, uint32_t what, const uint8_t *in_be32, uint32_t n_items, uint8_t *out_be32);
 
 /* Peak of the ALU roofline of the integer-bound kernels: back-to-back Montgomery products (fr29_mul, the product every
  * kernel uses) on every SIMD, waves_per_simd dependent chains of 2 * iters products interleaved per SIMD; the best of three timed

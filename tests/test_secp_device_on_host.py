@@ -74,7 +74,7 @@ def exe(tmp_path_factory):
         pytest.skip("hipcc not on PATH")
     out = str(tmp_path_factory.mktemp("secp") / "secp_host_test")
     # (-DSECP_GWIN_BITS=8: the same routines over an 8-bit generator table; the device's 16-bit one would take minutes to build on the host)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-DSECP_GWIN_BITS=8", os.path.join(ROOT, "tools", "secp_device_host_test.hip"), "-o", out], check=True, timeout=900)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-DSECP_GWIN_BITS=8", "-DSECP_CHECK", os.path.join(ROOT, "tools", "secp_device_host_test.hip"), "-o", out], check=True, timeout=900)
     return out
 
 

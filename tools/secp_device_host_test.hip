@@ -52,9 +52,13 @@ static void serve(const std::vector<std::string> &w) {
     else if (op == "ninv") put(sn_inv<C>(A(2)));
     else if (op == "nmul") put(sn_mul<C>(A(2), A(3)));
     else if (op == "sqrt") put(sp_sqrt_candidate<C>(A(2)));
-    else if (op == "dbl") { const SJac r = sj_dbl<C>(SJac{A(2), A(3), A(4)}); put(r.X); printf(" "); put(r.Y); printf(" "); put(r.Z); }
-    else if (op == "addaff") { const SJac r = sj_add_aff<C>(SJac{A(2), A(3), A(4)}, SAff{A(5), A(6)}); put(r.X); printf(" "); put(r.Y); printf(" "); put(r.Z); }
-    else if (op == "gtab") { const SAff e = secp_gtable_entry<C>((uint32_t)atoi(w[2].c_str()), (uint32_t)atoi(w[3].c_str())); put(e.x); printf(" "); put(e.y); }
+    // (points enter the domain form of the curve routines -- the residue itself for secp256k1, the Montgomery residue for secp256r1 -- and leave it for the answer)
+    else if (op == "dbl") { const SJac r = sj_dbl<C>(SJac{sp_enter<C>(A(2)), sp_enter<C>(A(3)), sp_enter<C>(A(4))}); put(sp_leave<C>(r.X)); printf(" "); put(sp_leave<C>(r.Y)); printf(" "); put(sp_leave<C>(r.Z)); }
+    else if (op == "addaff") {
+        const SJac r = sj_add_aff<C>(SJac{sp_enter<C>(A(2)), sp_enter<C>(A(3)), sp_enter<C>(A(4))}, SAff{sp_store<C>(sp_enter<C>(A(5))), sp_store<C>(sp_enter<C>(A(6)))});
+        put(sp_leave<C>(r.X)); printf(" "); put(sp_leave<C>(r.Y)); printf(" "); put(sp_leave<C>(r.Z));
+    }
+    else if (op == "gtab") { const SAff e = secp_gtable_entry<C>((uint32_t)atoi(w[2].c_str()), (uint32_t)atoi(w[3].c_str())); put(sp_leave<C>(sp_load(e.x))); printf(" "); put(sp_leave<C>(sp_load(e.y))); }
     else if (op == "verify") {
         uint32_t panic = 0;
         const uint32_t ok = secp_verify<C>(A(2), A(3), A(4), (uint32_t)atoi(w[5].c_str()), (uint32_t)atoi(w[6].c_str()), A(7), gtable<C>(), &panic);

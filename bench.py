@@ -199,15 +199,17 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
 
 
 # Base-field products (multiplications + squarings of secp_device.hpp) of ONE verification, counted from the routine:
-# decompression 2 + the square-root chain (253 S + 13 / 7 M) + 1; the window table {Q .. 8Q} 119 (+ 8 for the beta x of secp256k1); the ladder
-# 128 / 256 doublings x 7 / 8 and on average 61 / 60.5 mixed additions x 11; 16 additions of generator-table points (16-bit windows) x 11; the final x 2.
+# the curve equation 3 (x^2, x^3, y^2: the batch's keys are on the curve, so the given y is the root and the square-root chain of the
+# decompression -- 253 S + 13 / 7 M -- never runs; round 3 counted it); the window table {Q .. 8Q} 119 (+ 8 for the beta x of secp256k1); the ladder
+# 128 / 256 doublings x 7 / 8 and on average 61 / 60.5 mixed additions x 11; 16 additions of generator-table points (16-bit windows) x 11; the final
+# x 2; secp256r1: 5 more for the Montgomery form (x and y in, the result out, R^3 behind two inversions).
 # Not counted: three safegcd inversions and ~12 products of the scalar field per verification (about 8 % of the instructions).
-ECDSA_PRODUCTS = {0: 2 + 266 + 1 + 119 + 8 + 128 * 7 + 61 * 11 + 176 + 2, 1: 2 + 260 + 1 + 120 + 256 * 8 + 665.5 + 176 + 2}
+ECDSA_PRODUCTS = {0: 3 + 119 + 8 + 128 * 7 + 61 * 11 + 176 + 2, 1: 3 + 120 + 256 * 8 + 665.5 + 176 + 2 + 5}
 
 
 def ecdsa_alu_roofline(tile, kernel_ms):
     """ALU roofline of the ECDSA kernel in base-field products: what one launch computes (both curves, one verification each per instance)
-    per second of its HIP-event time, against the back-to-back sp_mul / sp_sqr probe of each curve measured in this run"""
+    per second of its HIP-event time, against the back-to-back s29_mul / s29_sqr probe of each curve measured in this run"""
     import acvm_amd
     peaks = [acvm_amd.secp_rate(c, 400, 8)[0] for c in (0, 1)]
     per_instance = ECDSA_PRODUCTS[0] + ECDSA_PRODUCTS[1]
@@ -218,7 +220,7 @@ def ecdsa_alu_roofline(tile, kernel_ms):
             "products_per_verification": {"secp256k1": ECDSA_PRODUCTS[0], "secp256r1": ECDSA_PRODUCTS[1]},
             "probe_products_per_s": {"secp256k1": peaks[0], "secp256r1": peaks[1]}, "kernel_ms_per_tile": kernel_ms,
             "definition": "products (multiplications and squarings of the curve's base field) one launch executes, counted from the routine, / its HIP-event "
-                          "time; peak = the time the same products take in the back-to-back sp_mul / sp_sqr probe (acvm_debug_secp_rate, 8 chains per SIMD)"}
+                          "time; peak = the time the same products take in the back-to-back s29_mul / s29_sqr probe of the 29-bit working form (acvm_debug_secp_rate, 8 chains per SIMD)"}
 
 
 class ClockSampler:

@@ -12,8 +12,9 @@ struct EcdsaOp {
     }
 };
 
+// (workgroups of four waves, like the Grumpkin records: kernels_grumpkin.hip)
 void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event) {
-    launch_record_level<EcdsaOp, 64>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
+    launch_record_level<EcdsaOp, 256>(s, W, Bp, B, dp, offsets, nullptr, n, event, nullptr);
 }
 
 // one thread per (curve, window j, digit d): 2 x SECP_GWINDOWS x 2^SECP_GWIN entries of 16 words, digit 0 left zero

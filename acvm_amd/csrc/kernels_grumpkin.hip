@@ -1,6 +1,9 @@
 // kernels_grumpkin.hip -- FixedBaseScalarMul / Pedersen / SchnorrVerify opcodes on Grumpkin (device routines in
-// ops_grumpkin.hpp), level kernel + exact kernel. Integer-ALU bound; one wave per workgroup so that the scheduler can
-// spread the long-running lanes over all SIMDs.
+// ops_grumpkin.hpp), level kernel + exact kernel. Integer-ALU bound, one wave per SIMD at 2^16 instances. Workgroups of FOUR waves (round 4;
+// one wave per workgroup before): the four waves of a CU start together and run the same straight-line code -- 0.6-1 MB of it against a 64 KiB
+// instruction cache per two CUs -- in step. Measured on config 4 (tools/gpu_r04k.sh, gpu_r04l.sh, ten runs each, interleaved on one box): one wave per
+// workgroup 2.44-2.51 ms per step in its fast mode and 2.84-3.06 ms in every third run (profiles/r04_import_effect.txt); four waves 2.44-2.63 ms, every run.
+// A barrier per ladder window on top of it: 2 % slower.
 #include "ops_grumpkin.hpp"
 #include "ops_kernel.hpp"
 #include "tuning.hpp"
@@ -16,7 +19,7 @@ struct GrumpkinOp {
 
 void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                            const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch) {
-    launch_record_level<GrumpkinOp, 64>(s, W, Bp, B, dp, offsets, scratch_off, n, event, scratch);
+    launch_record_level<GrumpkinOp, 256>(s, W, Bp, B, dp, offsets, scratch_off, n, event, scratch);
 }
 
 // ---------------------------------------------------------------------------------------------- Pedersen, 4 waves per instance group

@@ -319,21 +319,40 @@ static inline void s29_check_columns(const S29 &a, const S29 &b) {  // every col
     S29_ASSERT(acc < ((unsigned __int128)1 << 32));
 }
 #endif
-template <int C>
-FR_HD __forceinline__ S29 s29_reduce_wide(const uint32_t (&t)[18]);
-// secp256k1: t = the 18 limbs of the product (29 bits each, t[17] the rest)
-template <>
-FR_HD __forceinline__ S29 s29_reduce_wide<0>(const uint32_t (&t)[18]) {
+// a power of two the compiler must multiply by: a shift by more than 4 and the 64-bit addition behind it are two instructions, v_mad_u64_u32 is one
+FR_HD __forceinline__ uint32_t s29_pow2(uint32_t log2) {
+    uint32_t k = 1u << log2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(k));
+#endif
+    return k;
+}
+// secp256k1. The HIGH nine columns of the product come first (h: 29 bits each, h[8] the rest; no carry-in from the low half, which joins at 2^261
+// below); the low columns then take h (31264 + 2^8 2^29) as they are summed, so no limb of the wide product is formed twice.
+//   `hi(k, acc)` adds column k of the product to acc (k = 0..16).
+template <class Column>
+FR_HD __forceinline__ S29 s29_fold_k1(Column column) {
+    const uint32_t k256 = s29_pow2(8);
+    uint32_t h[9];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        acc = column(k, acc);
+        h[k - 9] = (uint32_t)acc & S29_M;
+        acc >>= 29;
+    }
+    h[8] = (uint32_t)acc;
     S29 r;
     uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) {  // L + H (31264 + 2^8 2^29)
-        c += (uint64_t)t[9 + i] * 31264u + t[i];
-        if (i > 0) c += (uint64_t)t[8 + i] << 8;
+    for (int i = 0; i < 9; i++) {
+        c = column(i, c);
+        c += (uint64_t)h[i] * 31264u;
+        if (i > 0) c += (uint64_t)h[i - 1] * k256;
         r.v[i] = (uint32_t)c & S29_M;
         c >>= 29;
     }
-    c += (uint64_t)t[17] << 8;  // what stands at 2^261 now (< 2^42): once more through 31264 + 2^8 2^29, together with bits 256..260 through 977 + 2^3 2^29
+    c += (uint64_t)h[8] * k256;  // what stands at 2^261 now (< 2^42): once more through 31264 + 2^8 2^29, together with bits 256..260 through 977 + 2^3 2^29
     const uint32_t e = r.v[8] >> 24;
     r.v[8] &= 0x00ffffffu;
     uint64_t d = c * 31264u + (uint64_t)(e * 977u) + r.v[0];
@@ -357,18 +376,12 @@ FR_HD __forceinline__ S29 s29_mul<0>(const S29 &a, const S29 &b) {
 #if S29_CHECKED
     s29_check_columns(a, b);
 #endif
-    uint32_t t[18];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
+    return s29_fold_k1([&](int k, uint64_t acc) {
 #pragma unroll
         for (int i = 0; i < 9; i++)
             if (k - i >= 0 && k - i < 9) acc += (uint64_t)a.v[i] * b.v[k - i];
-        t[k] = (uint32_t)acc & S29_M;
-        acc >>= 29;
-    }
-    t[17] = (uint32_t)acc;
-    return s29_reduce_wide<0>(t);
+        return acc;
+    });
 }
 template <>
 FR_HD __forceinline__ S29 s29_sqr<0>(const S29 &a) {  // the 36 cross products once, against the doubled limbs
@@ -376,27 +389,22 @@ FR_HD __forceinline__ S29 s29_sqr<0>(const S29 &a) {  // the 36 cross products o
     s29_check_columns(a, a);
     for (int i = 0; i < 9; i++) S29_ASSERT(a.v[i] < (1u << 31));
 #endif
-    uint32_t t[18], d[9];
+    uint32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
+    return s29_fold_k1([&](int k, uint64_t acc) {
 #pragma unroll
         for (int i = 0; i < 9; i++)
             if (k - i > i && k - i < 9) acc += (uint64_t)d[i] * a.v[k - i];
         if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
-        t[k] = (uint32_t)acc & S29_M;
-        acc >>= 29;
-    }
-    t[17] = (uint32_t)acc;
-    return s29_reduce_wide<0>(t);
+        return acc;
+    });
 }
 // secp256r1: column k of a b + sum m_i p 2^(29 i). m_k = the low limb of column k; it leaves that column (the shift drops it) and enters
 // columns k + 3 (2^9), k + 6 (2^18), k + 7 (0x1fe00000), k + 8 (0xffffff): p = (2^96 - 1) + 2^192 + 2^224 (2^32 - 1)
 #define SECP_R1_REDUCE_STEP(k)                                                \
-    if ((k) >= 3 && (k) - 3 < 9) acc += (uint64_t)m[(k) - 3] << 9;            \
-    if ((k) >= 6 && (k) - 6 < 9) acc += (uint64_t)m[(k) - 6] << 18;           \
+    if ((k) >= 3 && (k) - 3 < 9) acc += (uint64_t)m[(k) - 3] * k9;            \
+    if ((k) >= 6 && (k) - 6 < 9) acc += (uint64_t)m[(k) - 6] * k18;           \
     if ((k) >= 7 && (k) - 7 < 9) acc += (uint64_t)m[(k) - 7] * 0x1fe00000u;   \
     if ((k) >= 8 && (k) - 8 < 9) acc += (uint64_t)m[(k) - 8] * 0x00ffffffu;   \
     if ((k) < 9) m[k] = (uint32_t)acc & S29_M;                                \
@@ -407,6 +415,7 @@ FR_HD __forceinline__ S29 s29_mul<1>(const S29 &a, const S29 &b) {
 #if S29_CHECKED
     s29_check_columns(a, b);
 #endif
+    const uint32_t k9 = s29_pow2(9), k18 = s29_pow2(18);
     uint32_t m[9];
     S29 r;
     uint64_t acc = 0;
@@ -427,6 +436,7 @@ FR_HD __forceinline__ S29 s29_sqr<1>(const S29 &a) {
     s29_check_columns(a, a);
     for (int i = 0; i < 9; i++) S29_ASSERT(a.v[i] < (1u << 31));
 #endif
+    const uint32_t k9 = s29_pow2(9), k18 = s29_pow2(18);
     uint32_t m[9], d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;

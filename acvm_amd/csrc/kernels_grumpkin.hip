@@ -36,15 +36,18 @@ void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 // partial points to combine -- the three Jacobian additions of every step are 12 % of a commitment's products -- no LDS, no barriers.
 // Alone on the device (tools/t_pedersen_sweep.py): 8 records x 2^16 instances 3.41 -> 2.61 ms, 1 record x 2^16 0.56 -> 0.44 ms, equal at 512
 // groups, and below that the four-wave form wins on latency (64 groups: 0.22 against 0.37 ms).
+// (WAVES = 1 is launched in workgroups of PED1_GROUP independent waves)
+constexpr int PED1_GROUP = 4;
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(WAVES == 1 ? 64 * PED1_GROUP : 64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
 pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
                            const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of, uint32_t prio) {
     __shared__ uint32_t lds_acc[WAVES == 4 ? 4 : 1][WAVES == 4 ? 27 : 1][64];  // [wave][limb of X, Y, Z (9 x 29-bit each)][lane]
     __shared__ uint32_t lds_r[WAVES == 4 ? 16 : 1][64];                         // affine result of the step (Montgomery limbs of x, y)
     if (prio) __builtin_amdgcn_s_setprio(3);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;  // a scalar: loop bounds and record words indexed by it stay scalar
-    const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
+    const uint32_t wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;  // a scalar: loop bounds and record words indexed by it stay scalar
+    const uint32_t wave = WAVES == 1 ? 0u : wave_in_group;
+    const uint64_t j = WAVES == 1 ? ((uint64_t)blockIdx.x * PED1_GROUP + wave_in_group) * 64 + lane : (uint64_t)blockIdx.x * 64 + lane;
     const bool active = j < B;
     const uint32_t *__restrict__ rec = prog + offsets[blockIdx.y];  // (noalias arguments: scalar loads, see ops_kernel.hpp)
     const uint32_t n = rec[3];
@@ -245,7 +248,7 @@ void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
     const bool one = mode == 1 || (mode != 4 && groups > 512u);  // (measured alone, tools/t_pedersen_sweep.py: equal at 512 groups, one wave 21-24 % faster from 1 024 on)
     for (uint32_t done = 0; done < n;) {
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        if (one) hipLaunchKernelGGL(pedersen_quad_level_kernel<1>, dim3((B + 63) / 64, m), dim3(64), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of, prio);
+        if (one) hipLaunchKernelGGL(pedersen_quad_level_kernel<1>, dim3((B + 64 * PED1_GROUP - 1) / (64 * PED1_GROUP), m), dim3(64 * PED1_GROUP), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of, prio);
         else hipLaunchKernelGGL(pedersen_quad_level_kernel<4>, dim3((B + 63) / 64, m), dim3(256), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of, prio);
         done += m;
     }

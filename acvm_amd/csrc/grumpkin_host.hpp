@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "scratch_layout.hpp"
 
 namespace acvm {
 
@@ -22,9 +23,6 @@ struct GrumpkinTables {
 };
 static constexpr uint32_t GRUMPKIN_WIN16_STRIDE = 16 * 65535;  // points per base
 static constexpr uint32_t GRUMPKIN_PED2_LOG2 = 18;  // entries per generator
-// per-lane scratch words of SchnorrVerify's window table of e * pk (ops_grumpkin.hpp grumpkin_var_base_mul: 16 chain entries of 27 words,
-// 16 finished rows of 16 words, 4 words of alignment slack); the planner reserves them behind the message words of the record
-static constexpr uint32_t GRUMPKIN_VARBASE_SCRATCH_WORDS = 16 * 27 + 16 * 16 + 4;
 
 // Tables of the CURRENT device, built on first use and kept in a per-device set (grumpkin_host.cpp): a copy of the set's pointers into
 // *out, false on failure. Builds take the device's own lock and synchronise the set's build stream (never the device).

@@ -391,7 +391,7 @@ __device__ __forceinline__ GlvSplit glv_split(const Fr &k) {
     }
     return r;
 }
-static constexpr uint32_t VARBASE_TABLE_ENTRIES = 16;  // d P for d = 1..16 (signed 5-bit windows); scratch map: GRUMPKIN_VARBASE_SCRATCH_WORDS (grumpkin_host.hpp)
+static constexpr uint32_t VARBASE_TABLE_ENTRIES = 16;  // d P for d = 1..16 (signed 5-bit windows); scratch map: GRUMPKIN_VARBASE_SCRATCH_WORDS (scratch_layout.hpp)
 static_assert(GRUMPKIN_VARBASE_SCRATCH_WORDS == VARBASE_TABLE_ENTRIES * 27u + VARBASE_TABLE_ENTRIES * 16u + 4u, "scratch map of grumpkin_var_base_mul");
 // Signed 5-bit windows of a magnitude below 2^127: k = sum d_i 32^i with d_i in [-15, 16], i < 26 (a window above 16 borrows 32 from the
 // next one). Digit i sits in word i / 5 at bit 6 (i % 5): bits 0..4 the magnitude, bit 5 the sign. 26 windows instead of the 32 unsigned

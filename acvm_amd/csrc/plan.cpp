@@ -1,7 +1,7 @@
 // plan.cpp -- static replay of the reference's assigned-set bookkeeping + levelisation (see plan.hpp).
 #include "plan.hpp"
 #include "tuning.hpp"
-#include "grumpkin_host.hpp"
+#include "scratch_layout.hpp"
 #include <algorithm>
 #include <array>
 #include <chrono>

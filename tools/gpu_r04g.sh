@@ -1,11 +1,13 @@
 #!/bin/bash
-# tools/gpu_r04g.sh -- SchnorrVerify's window rows (lane-major + slot swizzle + early request) against the two libraries before it, on ONE box
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_grumpkin.py -x -q -m gpu 2>&1 | tail -3
-for round in 1 2; do
-  for lib in "" tools/ab/libacvm_amd_r04f.so tools/ab/libacvm_amd_r04d.so; do
-    echo "== ${lib:-this tree} (round $round)"
-    ACVM_AMD_LIB=$lib timeout 600 python tools/t_grumpkin.py 2>&1 | tail -1
-    for i in 1 2 3; do ACVM_AMD_LIB=$lib timeout 600 python bench.py --workload grumpkin --no-legs --no-cpu-baseline 2> /dev/null | tail -1 | python tools/bench_line.py | cut -c1-110; done
-  done
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_grumpkin.py tests/test_gpu_grumpkin_probe.py tests/test_gpu_ecdsa.py tests/test_gpu_brillig.py tests/test_gpu_opcodes.py tests/test_gpu_parity.py -x -q > gpurun_out/r04g_tests.txt 2>&1
+tail -5 gpurun_out/r04g_tests.txt
+for w in grumpkin ecdsa; do timeout 250 python tools/t_step_gap.py $w 2>&1 | sed -n "1,2p"; done | tee gpurun_out/r04g_step_gap.txt
+timeout 300 python tools/t_grumpkin.py 2>&1 | tail -3
+timeout 300 python tools/t_ecdsa.py 2>&1 | tail -2
+timeout 300 python tools/t_pedersen_sweep.py 2>&1 | tail -12
+for wl in arith_pedersen mixed; do
+  timeout 600 python bench.py --workload $wl --no-cpu-baseline 2> gpurun_out/r04g_bench_$wl.err | tail -1 > gpurun_out/r04g_bench_$wl.json
+  python tools/bench_line.py < gpurun_out/r04g_bench_$wl.json
 done

@@ -1,11 +1,9 @@
 #!/bin/bash
-# tools/gpu_r04h.sh LIB -- this tree against another build of the library on ONE box: the Grumpkin opcodes alone, config 4 and the north-star shape
-OTHER=${1:-tools/ab/libacvm_amd_r04d.so}
-for round in 1 2; do
-  for lib in "" $OTHER; do
-    echo "== ${lib:-this tree} (round $round)"
-    ACVM_AMD_LIB=$lib timeout 600 python tools/t_grumpkin.py 2>&1 | tail -3
-    for i in 1 2 3; do ACVM_AMD_LIB=$lib timeout 600 python bench.py --workload grumpkin --no-legs --no-cpu-baseline 2> /dev/null | tail -1 | python tools/bench_line.py | cut -c1-110; done
-    ACVM_AMD_LIB=$lib timeout 600 python bench.py --workload arith_pedersen --no-legs --no-cpu-baseline 2> /dev/null | tail -1 | python tools/bench_line.py | cut -c1-180
-  done
-done
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_reuse.py tests/test_gpu_boundary.py -x -q > gpurun_out/r04h_tests.txt 2>&1
+tail -8 gpurun_out/r04h_tests.txt
+for rep in 1 2; do
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-end-to-end --no-digest 2>/dev/null | tail -1 | python tools/bench_line.py
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-end-to-end --no-digest --no-pipeline 2>/dev/null | tail -1 | python tools/bench_line.py
+done | tee gpurun_out/r04h_abab.txt

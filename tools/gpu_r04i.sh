@@ -1,9 +1,8 @@
 #!/bin/bash
-# tools/gpu_r04i.sh -- the 29-bit working form of the two secp fields against the mid-round library on ONE box: parity tests, per-curve timing, the bench line
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_ecdsa.py tests/test_gpu_brillig.py -x -q -m gpu 2>&1 | tail -3
-bash tools/gpu_ab_lib.sh tools/ab/libacvm_amd_r04d.so tools/t_ecdsa.py
-for i in 1 2; do
-  timeout 600 python bench.py --workload ecdsa --no-legs 2> /dev/null | tail -1 | python tools/bench_line.py
-  ACVM_AMD_LIB=tools/ab/libacvm_amd_r04d.so timeout 600 python bench.py --workload ecdsa --no-legs 2> /dev/null | tail -1 | python tools/bench_line.py
-done
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r04i_tests.txt 2>&1
+tail -6 gpurun_out/r04i_tests.txt
+timeout 1200 python bench.py --steps 20 --warmup 5 2> gpurun_out/r04i_bench.err | tail -1 > gpurun_out/r04i_bench.json
+python tools/bench_line.py < gpurun_out/r04i_bench.json
+tail -c 900 gpurun_out/r04i_bench.json

@@ -93,7 +93,7 @@ FR_HD __forceinline__ bool secp_geq(const Fr &a, const Fr &b) {
 // v_addc_co_u32.
 FR_HD __forceinline__ void secp_mac(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(__AMDGCN_WAVEFRONT_SIZE == 64, "the carry of v_mad_u64_u32 is named as the 64-bit vcc of a wave64 target (gfx950)");
+    // (the carry is named as the 64-bit vcc of a wave64 target: this library is built for gfx950 only, build.py)
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "v"(b) : "vcc");
 #else
     const uint64_t p = (uint64_t)a * b, s = acc + p;

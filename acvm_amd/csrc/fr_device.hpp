@@ -312,6 +312,25 @@ FR_HD __forceinline__ Fr29 fr29_csub(const Fr29 &a, int klog2) {
 }
 // normalised value < 8p -> < 2p
 FR_HD __forceinline__ Fr29 fr29_lt2p(const Fr29 &a) { return fr29_csub(fr29_csub(a, 2), 1); }
+// normalised limbs, ANY value below 2^261 (169 p) -> the same residue below 1.03 p, normalised, in 38 instructions (the two conditional
+// subtractions above: 90). q = floor(floor(v / 2^248) floor(2^268 / p) / 2^20) is floor(v / p) or one less -- every rounding goes down, all of
+// them together by less than 1.03 (2 000 000 values, the multiples of p and their neighbours among them: tools/fr_device_host_test.hip checks the
+// contract) -- and v - q p = v + q (2^261 - p) - q 2^261 is summed limb by limb without a borrow.
+FR_HD __forceinline__ Fr29 fr29_weak(const Fr29 &a) {
+    constexpr uint32_t PP[9] = {0x0fffffffu, 0x00f05360u, 0x11a3dbafu, 0x182f6f0cu, 0x0a7a2d7cu, 0x1d24bf3fu, 0x1f591ebeu, 0x11a3d9cbu, 0x1fcf9bb1u};  // 2^261 - p
+    const uint32_t q = ((a.v[8] >> 16) * 21668u) >> 20;  // < 170
+    Fr29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        acc += (uint64_t)q * PP[i] + a.v[i];
+        r.v[i] = (uint32_t)acc & 0x1fffffffu;
+        acc >>= 29;
+    }
+    acc += (uint64_t)q * PP[8] + a.v[8];
+    r.v[8] = (uint32_t)(acc - ((uint64_t)q << 29));
+    return r;
+}
 // normalised value < 8p -> canonical [0, p)
 FR_HD __forceinline__ Fr29 fr29_canon(const Fr29 &a) { return fr29_csub(fr29_lt2p(a), 0); }
 // normalised value < 2p: is it 0 mod p

@@ -30,7 +30,7 @@ __device__ __forceinline__ Fr29 g29_zero() {
 }
 __device__ __forceinline__ GJac gj_inf() { return GJac{g29_one(), g29_one(), g29_zero()}; }
 __device__ __forceinline__ bool gj_is_inf(const GJac &p) { return fr29_is_zero_mod_p(p.Z); }
-__device__ __forceinline__ Fr29 g29_red(const Fr29 &loose) { return fr29_lt2p(fr29_norm(loose)); }  // loose value < 8p -> class A
+__device__ __forceinline__ Fr29 g29_red(const Fr29 &loose) { return fr29_weak(fr29_norm(loose)); }  // loose value < 169p -> class A (below 1.03p)
 
 __device__ __forceinline__ GAff gaff_load(const uint4 *tbl, uint32_t idx) {
     const uint4 *p = tbl + (uint64_t)idx * 4;

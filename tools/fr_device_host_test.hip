@@ -54,6 +54,32 @@ int main() {
             FrH want = frh::mul(frh::add(frh::add(a, a), b), frh::add(b, b));
             if (!same(fr29_pack(pr), want)) { fails++; printf("lazy mul mismatch %d\n", it); }
         }
+        {   // weak reduction of a lazy sum: x_j = c_j + m_j p (normalised), v = their limb-wise sum (up to 8 x 16 p), reduced in one step
+            Fr29 v;
+            for (int i = 0; i < 9; i++) v.v[i] = 0;
+            FrH want = frh::zero();
+            const int n = 1 + (int)(sm(s) % 7);  // (limbs of the sum stay below 2^32)
+            for (int jx = 0; jx < n; jx++) {
+                const FrH c = (jx & 1) ? b : a;
+                Fr29 x = fr29_from(to_dev(c));
+                const int m = (int)(sm(s) % 16);  // + m p as 8 p, 4 p, 2 p, p
+                for (int bit = 3; bit >= 0; bit--)
+                    if (m >> bit & 1)
+                        for (int i = 0; i < 9; i++) x.v[i] += bit ? fr_kp29(bit, i) : fr_p29(i);
+                x = fr29_norm(x);
+                for (int i = 0; i < 9; i++) v.v[i] += x.v[i];
+                want = frh::add(want, c);
+            }
+            const Fr29 r = fr29_weak(fr29_norm(v));
+            bool ok = true;
+            for (int i = 0; i < 8; i++) ok = ok && r.v[i] <= 0x1fffffffu;
+            Fr29 two_p;  // below 2 p: one conditional subtraction makes it canonical
+            for (int i = 0; i < 9; i++) two_p.v[i] = fr_kp29(1, i);
+            int cmp = 0;
+            for (int i = 8; i >= 0 && !cmp; i--) cmp = r.v[i] < two_p.v[i] ? -1 : r.v[i] > two_p.v[i] ? 1 : 0;
+            ok = ok && cmp < 0;
+            if (!ok || !same(fr29_pack(fr29_cond_sub_p(r)), want)) { fails++; printf("weak reduction mismatch %d\n", it); }
+        }
         {   // truncated reduction: low 29 bits of the canonical value
             Fr one_c = fr_zero(); one_c.v[0] = 1;
             const Fr c = fr_mul(da, one_c);

@@ -144,11 +144,13 @@ constexpr uint32_t S29_M = 0x1fffffffu;
 #define S29_CHECKED 0
 #endif
 
-// The limbs of a result pass through an empty asm on the device: hipcc (ROCm 7.2) otherwise carries what it knows about their widths -- 24 bits in
-// the top limb, 29 below -- into the NEXT product and selects 24-bit multiplies there that lose bits (a product of a product came out wrong on the
-// device and right on the host: tests/test_gpu_secp_probe.py, probe 8). No instruction is emitted.
+// The limbs of a result pass through an empty asm on the device: hipcc (ROCm 7.2, -O3, gfx950) otherwise carries what it knows about their widths into
+// the NEXT product and miscompiles it -- a square of a square came out wrong on the device in 4 077 of 4 096 cases and right on the host. tools/narrow_probe.hip
+// reproduces it standalone (profiles/r04_narrow_probe.txt): the limb that matters is limb 8, which the fold at 2^256 masks to 24 bits; laundering that one
+// limb cures every case, laundering the other eight none. The library launders all nine (no instruction is emitted), and the compositions stay in the GPU
+// suite (tests/test_gpu_secp_probe.py, probes 8..11).
 FR_HD __forceinline__ void s29_opaque(S29 &r) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(S29_PROBE_NO_OPAQUE)  // (tools/narrow_probe.hip reproduces the miscompilation without it)
 #pragma unroll
     for (int i = 0; i < 9; i++) asm volatile("" : "+v"(r.v[i]));
 #else

@@ -185,8 +185,10 @@ __device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, ui
 __device__ __forceinline__ Fr29 gate_sum_canon(const GateSum &s) {
     Fr29 v = s.v;
     uint32_t b = s.bound;  // invariant: value < b p / 16
-    if (b > 64 + 2) { v = fr29_csub(v, 2); b = b - 64 > 64 ? b - 64 : 64; }
-    if (b > 32 + 2) { v = fr29_csub(v, 1); b = b - 32 > 32 ? b - 32 : 32; }
+    if (b > 32 + 2) {  // three and more terms: one quotient-estimate reduction (fr29_weak: below 1.03 p) instead of two or three conditional subtractions
+        v = fr29_weak(v);
+        b = 17;
+    }
     if (b > 16 + 2) { v = fr29_csub(v, 0); b = b - 16 > 16 ? b - 16 : 16; }  // a bare reduced sum (b = 17) is >= p in < 1 % of the lanes
     while (b > 16) {  // some lane may still hold a value in [p, b p / 16): then its top limb is >= p's
         if (__builtin_amdgcn_ballot_w64(v.v[8] >= fr_p29(8)) == 0) break;

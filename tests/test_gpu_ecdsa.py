@@ -69,6 +69,24 @@ def test_batch_against_oracle(oracle, curve):
     assert ores[0].status == 0 and ores[40].err == oracle.E_PANIC and ores[44].err == oracle.E_PANIC
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+def test_batch_size_across_the_workgroup_boundary(oracle, curve):
+    """the record kernel runs in workgroups of four waves (256 instances): 321 instances = one full workgroup, one full wave and a partly filled one"""
+    from acvm_amd import synth
+    import numpy as np
+    v = (K1, R1)[curve]
+    good = row(*[bytes.fromhex(v[k]) for k in ("x", "y", "sig", "z")])
+    rows = []
+    for i in range(321):
+        r = list(good)
+        if i % 5 == 3: r[128 + (i % 32)] ^= 1 << (i % 8)   # a flipped digest bit: invalid
+        if i % 11 == 7: r[32 + 31] ^= 2                     # another y of the same parity: still the same key
+        rows.append(r)
+    circ, ids = ecdsa_circuit(curve)
+    ores, _ = both_paths(oracle, circ, ids, rows)
+    assert ores[0].status == 0
+
+
 def test_wrong_lengths_and_short_digest(oracle):
     for kw in (dict(n_x=31), dict(n_y=33), dict(n_sig=63), dict(n_msg=31)):
         circ, ids = ecdsa_circuit(0, **kw)

@@ -87,6 +87,13 @@ def test_config4_grumpkin_circuit(oracle):
     assert sum(1 for j in range(80) if ores[j].status == 0) >= 70
 
 
+@pytest.mark.parametrize("B", [257, 321])
+def test_batch_sizes_across_the_workgroup_boundary(oracle, B):
+    """the record kernels run in workgroups of four waves (256 instances): a partly filled workgroup and a partly filled wave"""
+    circ, ids = grumpkin_circuit()
+    run_both(oracle, circ, ids, grumpkin_rows(B))
+
+
 def test_schnorr_early_rejects_UNPINNED(oracle):
     """public key off the curve, s = 0, e = 0: HIP against the oracle's recollection of barretenberg's early exits (SURVEY A.3:
     no reference vector rejects for any reason but a differing digest) -- parity with the oracle, NOT with the reference"""

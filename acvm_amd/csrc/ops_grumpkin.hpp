@@ -72,9 +72,11 @@ __device__ __forceinline__ GJac gj_add_aff29(const GJac &p, const Fr29 &x2, cons
     const Fr29 J = fr29_mul(H, I), V = fr29_mul(p.X, I);                                       // < 1.08, < 1.05
     GJac o;
     o.X = g29_red(fr29_subl(fr29_subl(fr29_sqr(r), J, 1), fr29_norm(fr29_dbll(V)), 2));     // 1.22 + 2 + 4 = 7.22 -> < 2
-    const Fr29 m1 = fr29_mul(r, fr29_norm(fr29_subl(V, o.X, 1)));                              // r (< 6.04) * (< 3.05) -> < 1.11
-    const Fr29 m2 = fr29_norm(fr29_dbll(fr29_mul(p.Y, J)));                                    // < 2.04
-    o.Y = g29_red(fr29_subl(m1, m2, 2));                                                       // 1.11 + 4 -> < 2
+    // Y3 = r (V - X3) - 2 Y1 J as ONE dot product r (V - X3) + (4p - 2 Y1) J: one Montgomery reduction for the two products, and the result is class A
+    // as it leaves the reduction (round 4: 177 instructions of an addition's ~2 700 less than two products, a doubling, a difference and its reduction)
+    const Fr29 n2y = fr29_norm(fr29_subl(g29_zero(), fr29_norm(fr29_dbll(p.Y)), 2));           // 4p - 2 Y1 in (0, 4p]
+    const Fr29 yl[2] = {r, n2y}, ym[2] = {fr29_norm(fr29_subl(V, o.X, 1)), J};                 // (< 6.04, <= 4) x (< 3.05, < 1.08)
+    o.Y = fr29_dot<2>(yl, ym);                                                                 // < 1 + (6.04 * 3.05 + 4 * 1.08) / 169 = 1.14
     const Fr29 zh = fr29_norm(fr29_addl(p.Z, H));                                              // < 5.02
     o.Z = g29_red(fr29_subl(fr29_subl(fr29_sqr(zh), Z1Z1, 1), HH, 1));                     // 1.15 + 4 -> < 2;  = 2 Z1 H
     if (fr29_is_zero_mod_p(o.Z)) {  // Z1 != 0, so H == 0: same x
@@ -102,9 +104,9 @@ __device__ __forceinline__ GJac gj_add(const GJac &p, const GJac &q) {
     const Fr29 J = fr29_mul(H, I), V = fr29_mul(U1, I);                                        // < 1.03, < 1.01
     GJac o;
     o.X = g29_red(fr29_subl(fr29_subl(fr29_sqr(r), J, 1), fr29_norm(fr29_dbll(V)), 2));     // 1.22 + 2 + 4 -> < 2
-    const Fr29 m1 = fr29_mul(r, fr29_norm(fr29_subl(V, o.X, 1)));                              // < 1.11
-    const Fr29 m2 = fr29_norm(fr29_dbll(fr29_mul(S1, J)));                                     // < 2.02
-    o.Y = g29_red(fr29_subl(m1, m2, 2));
+    const Fr29 n2s = fr29_norm(fr29_subl(g29_zero(), fr29_norm(fr29_dbll(S1)), 2));            // 4p - 2 S1 (as in gj_add_aff29)
+    const Fr29 yl[2] = {r, n2s}, ym[2] = {fr29_norm(fr29_subl(V, o.X, 1)), J};
+    o.Y = fr29_dot<2>(yl, ym);                                                                 // < 1.14
     const Fr29 zz = fr29_norm(fr29_addl(p.Z, q.Z));                                            // < 4
     const Fr29 T = fr29_norm(fr29_subl(fr29_subl(fr29_sqr(zz), Z1Z1, 1), Z2Z2, 1));        // 1.1 + 4 = 5.1;  = 2 Z1 Z2
     o.Z = fr29_mul(T, H);                                                                      // < 1.1

@@ -55,7 +55,7 @@ __device__ __forceinline__ GJac gj_dbl(const GJac &p) {
     const Fr29 m = fr29_mul(E, fr29_norm(fr29_subl(D, r.X, 1)));                               // E (< 3.09) * (< 4) -> < 1.08
     const Fr29 C4 = g29_red(fr29_dbll(fr29_dbll(C)));                                          // 4C < 4.04 -> < 2
     r.Y = g29_red(fr29_subl(m, fr29_norm(fr29_dbll(C4)), 2));                                  // 1.08 + 4 = 5.08 -> < 2
-    r.Z = g29_red(fr29_dbll(fr29_mul(p.Y, p.Z)));                                              // 2 * 1.03 -> < 2
+    r.Z = fr29_mul(fr29_norm(fr29_dbll(p.Y)), p.Z);                                            // (2 Y) Z: 1 + 4 * 2 / 169 -> < 1.05 (the doubling before the product: no reduction behind it)
     return r;
 }
 // complete mixed addition (madd-2007-bl with the exceptional cases): 7M + 4S. (x2, y2) is a finite affine point in the working form
@@ -77,8 +77,8 @@ __device__ __forceinline__ GJac gj_add_aff29(const GJac &p, const Fr29 &x2, cons
     const Fr29 n2y = fr29_norm(fr29_subl(g29_zero(), fr29_norm(fr29_dbll(p.Y)), 2));           // 4p - 2 Y1 in (0, 4p]
     const Fr29 yl[2] = {r, n2y}, ym[2] = {fr29_norm(fr29_subl(V, o.X, 1)), J};                 // (< 6.04, <= 4) x (< 3.05, < 1.08)
     o.Y = fr29_dot<2>(yl, ym);                                                                 // < 1 + (6.04 * 3.05 + 4 * 1.08) / 169 = 1.14
-    const Fr29 zh = fr29_norm(fr29_addl(p.Z, H));                                              // < 5.02
-    o.Z = g29_red(fr29_subl(fr29_subl(fr29_sqr(zh), Z1Z1, 1), HH, 1));                     // 1.15 + 4 -> < 2;  = 2 Z1 H
+    o.Z = fr29_mul(fr29_norm(fr29_dbll(p.Z)), H);                                              // 2 Z1 H as a product: 1 + 4 * 3.02 / 169 -> < 1.08 (the squaring form (Z1 + H)^2 - Z1Z1 - HH
+                                                                                               // pays a sum, two differences and a reduction for its cheaper multiply)
     if (fr29_is_zero_mod_p(o.Z)) {  // Z1 != 0, so H == 0: same x
         if (fr29_is_zero_mod_p(fr29_lt2p(rr))) return gj_dbl(p);
         return gj_inf();

@@ -668,7 +668,7 @@ FR_HD __forceinline__ SJac sj_dbl(const SJac &p) {
         const S29 m = s29_mul<C>(E, s29_norm(s29_subl<C>(D, r.X, 1)));                                    // E (D - X3)
         const S29 C8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(Cc))));                                        // < 8.08, limbs <= 2^30 - 2
         r.Y = s29_out<C>(s29_subl<C>(m, C8, 4));
-        r.Z = s29_out<C>(s29_dbll(s29_mul<C>(p.Y, p.Z)));
+        r.Z = s29_out<C>(s29_dbll(s29_mul<C>(p.Y, p.Z)));                                                 // (the doubling before the product, as in the other branch: measured the same here)
     } else {  // dbl-2001-b (a = -3): 3 M + 5 S
         const S29 delta = s29_sqr<C>(p.Z), gamma = s29_sqr<C>(p.Y);                                       // < 1.04
         const S29 beta = s29_mul<C>(p.X, gamma);                                                          // < 1.04
@@ -678,8 +678,8 @@ FR_HD __forceinline__ SJac sj_dbl(const SJac &p) {
         const S29 a2 = s29_sqr<C>(alpha);                                                                 // < 1.41
         const S29 b8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(beta))));                                      // < 8.32, limbs <= 2^30 - 2
         r.X = s29_out<C>(s29_subl<C>(a2, b8, 4));                                                         // alpha^2 - 8 beta
-        const S29 zz = s29_sqr<C>(s29_addl(p.Y, p.Z));                                                    // (Y + Z)^2: 2.02^2 / 32 + 1 < 1.13
-        r.Z = s29_out<C>(s29_subl<C>(s29_subl<C>(zz, gamma, 1), delta, 1));
+        r.Z = s29_mul<C>(s29_dbll(p.Y), p.Z);                                                             // (2 Y) Z as a product: 2.2 * 1.1 / 32 + 1 < 1.08 (the form (Y + Z)^2 - gamma - delta
+                                                                                                          // pays two differences and a reduction for its squaring)
         const S29 w = s29_norm(s29_subl<C>(s29_dbll(s29_dbll(beta)), r.X, 1));                            // 4 beta - X3 < 6.16
         const S29 m = s29_mul<C>(alpha, w);                                                               // 3.6 * 6.16 / 32 + 1 < 1.7
         const S29 g8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(s29_sqr<C>(gamma)))));                         // 8 gamma^2 < 8.3

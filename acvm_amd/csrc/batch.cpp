@@ -145,6 +145,10 @@ void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_digest_segments = p.n_digest_segments;
     out->n_brillig_inlined = p.n_brillig_inlined;
     out->n_hash_chained = p.n_hash_chained;
+    out->n_gate_out_asis = p.n_gate_out_mode[0];
+    out->n_gate_out_weak = p.n_gate_out_mode[1];
+    out->n_gate_out_canon = p.n_gate_out_mode[2];
+    out->max_gate_bound = p.max_gate_bound;
     for (uint32_t L = 0; L + 1 < p.level_start.size(); L++) out->n_arith_launches += (p.level_start[L + 1] - p.level_start[L] + 65534) / 65535;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +

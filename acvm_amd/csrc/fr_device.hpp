@@ -344,13 +344,18 @@ FR_HD __forceinline__ bool fr29_is_zero_mod_p(const Fr29 &a) {
     return z == 0u || e == 0u;
 }
 
-// ---- sums of up to three products with ONE reduction: (sum_t a_t * b_t) * 2^-261 mod p. The arithmetic gate sum
+// ---- sums of up to six products with ONE reduction: (sum_t a_t * b_t) * 2^-261 mod p. The arithmetic gate sum
 // q_m a b + sum q_i w_i + q_c (pwg/arithmetic.rs:27-127) pays one Montgomery reduction (half of a product's 162
-// multiply-adds) per three terms instead of one per term. Same column scan as fr29_mul: column k of sum a_t b_t + m p is
-// summed in one 64-bit accumulator ((N + 1) * 9 products < 2^58 plus a carry: N <= 6 would still fit). Operands: normalised
-// limbs, values < 4p. Output: normalised limbs, value < p + N * 1.06p * 4p / 2^261 < 1.04p.
-template <int N>
-FR_HD __forceinline__ Fr29 fr29_dot(const Fr29 (&a)[N], const Fr29 (&b)[N]) {
+// multiply-adds) per group of terms instead of one per term. Same column scan as fr29_mul: column k of sum a_t b_t + m p is
+// summed in one 64-bit accumulator ((N + 1) * 9 products < 2^58 plus a carry: N <= 6 fits). Contract: normalised limbs (below
+// 2^29, the top one included); the VALUES only enter through the result's bound: result < p + (sum_t a_t b_t) / 2^261, i.e.
+// 1 + 0.005908 sum_t (a_t / p)(b_t / p) in units of p -- below 1.04 p for two products of operands below 4 p, 1.34 p for two products
+// of any two rows of the witness table (representatives below 2^256 = 5.29 p, gate_eval.hpp). Output limbs are normalised; the
+// top limb carries whatever is left (value / 2^232).
+// ADD: a lazy sum h (limbs below 2^32, not normalised) rides in the upper columns: result = (sum a_t b_t + m p) / 2^261 + h exactly,
+// with the carries of h propagated by the scan (the gate kernel's constant and +-1 terms: no separate carry pass).
+template <int N, bool ADD>
+FR_HD __forceinline__ Fr29 fr29_dot_impl(const Fr29 (&a)[N], const Fr29 (&b)[N], const Fr29 *h) {
     static_assert(N >= 1 && N <= 6, "column accumulator budget");
     constexpr uint32_t M = 0x1fffffffu;
     uint64_t acc = 0;
@@ -377,12 +382,18 @@ FR_HD __forceinline__ Fr29 fr29_dot(const Fr29 (&a)[N], const Fr29 (&b)[N]) {
             for (int i = k - 8; i < 9; i++) acc += (uint64_t)a[t].v[i] * b[t].v[k - i];
 #pragma unroll
         for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * fr_p29(k - i);
+        if (ADD) acc += h->v[k - 9];
         r.v[k - 9] = (uint32_t)acc & M;
         acc >>= 29;
     }
     r.v[8] = (uint32_t)acc;
+    if (ADD) r.v[8] += h->v[8];
     return r;
 }
+template <int N>
+FR_HD __forceinline__ Fr29 fr29_dot(const Fr29 (&a)[N], const Fr29 (&b)[N]) { return fr29_dot_impl<N, false>(a, b, nullptr); }
+template <int N>
+FR_HD __forceinline__ Fr29 fr29_dot_add(const Fr29 (&a)[N], const Fr29 (&b)[N], const Fr29 &h) { return fr29_dot_impl<N, true>(a, b, &h); }
 
 // Montgomery product on the storage form, fully reduced
 FR_HD __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) { return fr29_pack(fr29_cond_sub_p(fr29_mul(fr29_from(a), fr29_from(b)))); }

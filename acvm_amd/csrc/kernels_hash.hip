@@ -263,10 +263,9 @@ __device__ __forceinline__ void fp_add(FpAcc &a, const Fr29 &x, uint32_t weight)
     a.h = fr29_addl(a.h, x);
 }
 __device__ __forceinline__ Fr fp_value(const FpAcc &a) {
-    GateSum s;
-    s.v = fr29_norm(a.h);
-    s.bound = a.hw;
-    return fr29_pack(gate_sum_canon(s));
+    Fr29 v = fr29_weak(fr29_norm(a.h));  // < 1.03 p; the last step down only when some lane's top limb says it may be needed
+    if (__builtin_amdgcn_ballot_w64(v.v[8] >= fr_p29(8)) != 0) v = fr29_csub(v, 0);
+    return fr29_pack(v);
 }
 // sum of stored_w * coef_w over the listed witnesses for a wave whose lanes are all instances of the level kernels (wave-uniform
 // coefficients, FP_DOT products per Montgomery reduction: 81 multiply-adds per product + 81 per reduction, so four to a reduction are 101 per

@@ -9,6 +9,7 @@
 //   ExactPolicy -- per-instance assigned bitmap, exact error kind / aux values.
 #pragma once
 #include "fr_device.hpp"
+#include "gate_eval.hpp"
 
 namespace acvm {
 
@@ -63,163 +64,35 @@ __device__ __forceinline__ Fr apply_coef_prod(const Fr &a, const Fr &b, uint32_t
     if (coef == K_COEF_MINUS_ONE) return fr_neg(fr29_pack(fr29_cond_sub_p(t)));
     return fr29_pack(fr29_cond_sub_p(fr29_mul(t, fr29_from(fr_const(consts, coef)))));
 }
-// ---- the folded gate sum of the level kernels: sum q_i a_i b_i + sum q_j w_j + q_c (gate record of plan.cpp). Terms with a
-// general coefficient are multiplied two at a time with ONE Montgomery reduction (fr29_dot; three at a time costs 30 more
-// registers -- one wave less per SIMD -- for a case the width-3 gates of csat.rs never produce); terms with coefficient +-1
-// and the constant skip the multiplier altogether: the planner lists them apart. Everything is summed limb-wise into the
-// lazy side sum h, whose bound is tracked in units of p/16 (wave-uniform, from the record's counts): a canonical witness or
-// constant weighs 16, a product or a reduced dot product 17 (< 1.06p), a subtracted term 33 (it is added as 2p - x <= 2p).
-// h's limbs stay below weight * 2^25 < 2^32; past GATE_H_MAX it is brought back below 2p.
-static constexpr uint32_t GATE_H_MAX = 111;
-struct GateSum {
-    Fr29 v;          // normalised limbs
-    uint32_t bound;  // value < bound * p / 16 (wave-uniform)
+// ---- the gate kernel's body (kernels.hip arith_level_kernel; kernels_ops.hip runs it beside the light records of the same level):
+// gate_eval.hpp's record evaluation over the witness table. grid = (ceil(B/256), gates in level). Lane = instance. The gate record
+// (number gate_index of the level) is wave-uniform.
+struct GateDeviceLoader {
+    const uint4 *__restrict__ W;
+    const uint4 *__restrict__ Inv;
+    const uint32_t *__restrict__ consts;
+    uint64_t Bp, j;
+    __device__ __forceinline__ Fr29 load(uint32_t slot) const {
+        // nontemporal (streaming) loads: an operand row is read by this launch and then not again for levels (5.53 -> 5.55 M witnesses/s)
+        return fr29_from(fr_load_nt(W, slot, Bp, j));
+    }
+    __device__ __forceinline__ Fr29 load_inverse(uint32_t slot) const { return fr29_from(fr_load_nt(Inv, slot, Bp, j)); }
+    __device__ __forceinline__ const uint32_t *constant(uint32_t idx) const { return consts + (uint64_t)idx * 8; }
+    __device__ __forceinline__ bool any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0; }
 };
-// operand slot GATE_LOCAL: the output of the record that ran before this one in the same wave (plan.cpp "gate pairs")
-static constexpr uint32_t GATE_LOCAL = 0xFFFFFFFFu;
-static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;
-static constexpr uint32_t GATE_SETLOCAL_FLAG = 1u << 25;  // this record's output becomes GATE_LOCAL of the records behind it
-__device__ __forceinline__ Fr29 gate_load29(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, uint32_t slot, const Fr29 &local) {
-    if (slot == GATE_LOCAL) return local;  // wave-uniform
-    // nontemporal (streaming) loads: an operand row is read by this launch and then not again for levels (5.53 -> 5.55 M witnesses/s)
-    const uint4 *lo = W + (uint64_t)slot * 2 * Bp + j, *hi = lo + Bp;
-    Fr r;
-    r.v[0] = __builtin_nontemporal_load(&lo->x); r.v[1] = __builtin_nontemporal_load(&lo->y); r.v[2] = __builtin_nontemporal_load(&lo->z); r.v[3] = __builtin_nontemporal_load(&lo->w);
-    r.v[4] = __builtin_nontemporal_load(&hi->x); r.v[5] = __builtin_nontemporal_load(&hi->y); r.v[6] = __builtin_nontemporal_load(&hi->z); r.v[7] = __builtin_nontemporal_load(&hi->w);
-    return fr29_from(r);
-}
-// words of a gate record
-__device__ __forceinline__ uint32_t gate_record_words(const uint32_t *__restrict__ g) {
-    const uint32_t w0 = g[0], w5 = g[5];
-    return 6u + 10u * ((w0 >> 8) & 0xff) + 9u * ((w0 >> 16) & 0xff) + 2u * ((w5 & 0xff) + ((w5 >> 8) & 0xff)) + ((w5 >> 16) & 0xff) + (w5 >> 24);
-}
-__device__ __forceinline__ void gate_h_room(Fr29 &h, uint32_t &hw, uint32_t weight) {
-    if (hw + weight > GATE_H_MAX) {  // rare: many terms in one gate
-        h = fr29_lt2p(fr29_norm(h));
-        hw = 32;
-    }
-    hw += weight;
-}
-__device__ __forceinline__ void gate_h_sub(Fr29 &h, const Fr29 &x) {  // h += 2p - x; x normalised, <= 2p
-#pragma unroll
-    for (int i = 0; i < 9; i++) h.v[i] += fr_kp29_sub(1, i) - x.v[i];
-}
-// k-th multiplied term of the record: the products come first (coef[8], a, b), then the linear terms (coef[8], w)
-__device__ __forceinline__ Fr29 gate_mac_operand(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ t0,
-                                                 uint32_t np_mac, uint32_t k, const uint32_t *__restrict__ consts, const Fr29 &local, Fr29 &c) {
-    if (k < np_mac) {
-        const uint32_t *__restrict__ t = t0 + 10 * k;
-        c = fr29_from(fr_const(t, 0));
-        return fr29_mul(gate_load29(W, Bp, j, t[8], local), gate_load29(W, Bp, j, t[9], local));
-    }
-    const uint32_t *__restrict__ t = t0 + 10 * np_mac + 9 * (k - np_mac);
-    c = fr29_from(fr_const(t, 0));
-    return gate_load29(W, Bp, j, t[8], local);
-}
-__device__ __forceinline__ GateSum gate_sum_lazy(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, const uint32_t *__restrict__ g,
-                                                 const uint32_t *__restrict__ consts, const Fr29 &local) {
-    const uint32_t w0 = g[0], w5 = g[5], qc = g[3];
-    const uint32_t np_mac = (w0 >> 8) & 0xff, nl_mac = (w0 >> 16) & 0xff, n_mac = np_mac + nl_mac;
-    const uint32_t np_pos = w5 & 0xff, np_neg = (w5 >> 8) & 0xff, nl_pos = (w5 >> 16) & 0xff, nl_neg = w5 >> 24;
-    Fr29 h;
-    uint32_t hw = 0;
-    if (qc == K_COEF_ZERO) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) h.v[i] = 0;
-    } else {
-        h = fr29_from(fr_const(consts, qc));
-        hw = 16;
-    }
-    const uint32_t *__restrict__ t0 = g + 6;
-    const uint32_t *__restrict__ t = t0 + 10 * np_mac + 9 * nl_mac;
-    // a product with coefficient +1 (the planner's projective witnesses make that the common product, plan.cpp) shares its
-    // reduction with a multiplied term: a b + c x is one fr29_dot<2>
-    uint32_t base = 0, iu = 0;
-    for (; iu < np_pos && base < n_mac; iu++, base++, t += 2) {
-        Fr29 c0;
-        const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, local, c0);
-        const Fr29 l[2] = {gate_load29(W, Bp, j, t[0], local), x0}, m[2] = {gate_load29(W, Bp, j, t[1], local), c0};
-        gate_h_room(h, hw, 17);
-        h = fr29_addl(h, fr29_dot<2>(l, m));
-    }
-    for (; base < n_mac; base += 2) {
-        Fr29 c0, c1, r;
-        const Fr29 x0 = gate_mac_operand(W, Bp, j, t0, np_mac, base, consts, local, c0);
-        if (n_mac - base == 1) {
-            r = fr29_mul(x0, c0);
-        } else {
-            const Fr29 x1 = gate_mac_operand(W, Bp, j, t0, np_mac, base + 1, consts, local, c1);
-            const Fr29 l[2] = {x0, x1}, m[2] = {c0, c1};
-            r = fr29_dot<2>(l, m);
-        }
-        gate_h_room(h, hw, 17);
-        h = fr29_addl(h, r);
-    }
-    for (; iu < np_pos; iu++, t += 2) {
-        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0], local), gate_load29(W, Bp, j, t[1], local));
-        gate_h_room(h, hw, 17);
-        h = fr29_addl(h, x);
-    }
-    for (uint32_t i = 0; i < np_neg; i++, t += 2) {
-        const Fr29 x = fr29_mul(gate_load29(W, Bp, j, t[0], local), gate_load29(W, Bp, j, t[1], local));
-        gate_h_room(h, hw, 33);
-        gate_h_sub(h, x);
-    }
-    for (uint32_t i = 0; i < nl_pos; i++, t += 1) {
-        const Fr29 x = gate_load29(W, Bp, j, t[0], local);
-        gate_h_room(h, hw, 16);
-        h = fr29_addl(h, x);
-    }
-    for (uint32_t i = 0; i < nl_neg; i++, t += 1) {
-        const Fr29 x = gate_load29(W, Bp, j, t[0], local);
-        gate_h_room(h, hw, 33);
-        gate_h_sub(h, x);
-    }
-    GateSum r;
-    r.v = fr29_norm(h);
-    r.bound = hw;
-    return r;
-}
-// canonical value of a gate sum: conditional subtractions by the wave-uniform bound; the last step down from < ~1.1p is
-// taken only when some lane's top limb says it may be needed (p's top limb is reached by 2^-22 of the canonical values)
-__device__ __forceinline__ Fr29 gate_sum_canon(const GateSum &s) {
-    Fr29 v = s.v;
-    uint32_t b = s.bound;  // invariant: value < b p / 16
-    if (b > 32 + 2) {  // three and more terms: one quotient-estimate reduction (fr29_weak: below 1.03 p) instead of two or three conditional subtractions
-        v = fr29_weak(v);
-        b = 17;
-    }
-    if (b > 16 + 2) { v = fr29_csub(v, 0); b = b - 16 > 16 ? b - 16 : 16; }  // a bare reduced sum (b = 17) is >= p in < 1 % of the lanes
-    while (b > 16) {  // some lane may still hold a value in [p, b p / 16): then its top limb is >= p's
-        if (__builtin_amdgcn_ballot_w64(v.v[8] >= fr_p29(8)) == 0) break;
-        v = fr29_csub(v, 0);
-        b = b - 16 > 16 ? b - 16 : 16;
-    }
-    return v;
-}
-
-// ---- the gate kernel's body (kernels.hip arith_level_kernel; kernels_ops.hip runs it beside the light records of the same level)
-// grid = (ceil(B/256), gates in level). Lane = instance. The gate record (number gate_index of the level) is wave-uniform.
 __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream,
                                                  const uint32_t *__restrict__ gate_offset, const uint32_t *__restrict__ consts,
                                                  uint32_t *__restrict__ event, const uint4 *__restrict__ Inv, uint32_t gate_index) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
     const uint32_t *__restrict__ g = gate_stream + gate_offset[gate_index];
+    const GateDeviceLoader ld{W, Inv, consts, Bp, j};
     Fr29 local = fr29_from(fr_zero());
     bool host = true;
     for (;;) {  // the record, then the records fused behind it (they read this one's output as GATE_LOCAL)
         const uint32_t w0 = g[0], kind = w0 & 0xff, opcode = g[1], out = g[2];
-        const GateSum sum = gate_sum_lazy(W, Bp, j, g, consts, local);
-        Fr29 acc;
-        if (kind == 2) {
-            // the unknown is multiplied by a known witness (arithmetic.rs:68-91): out = sum' / partner, and 1 / partner was put
-            // into the inverse table by an earlier inverse_batch_kernel. The lazy sum (< 8p) is a valid product operand as it is.
-            acc = fr29_cond_sub_p(fr29_mul(sum.v, fr29_from(fr_load_nt(Inv, g[4], Bp, j))));
-        } else {
-            acc = gate_sum_canon(sum);
-        }
-        if (kind == 0) {  // constraint only (arithmetic.rs:92-102)
+        const Fr29 acc = gate_eval(ld, g, local);
+        if (kind == 0) {  // constraint only (arithmetic.rs:92-102): the value is canonical
             uint32_t z = 0;
 #pragma unroll
             for (int i = 0; i < 9; i++) z |= acc.v[i];

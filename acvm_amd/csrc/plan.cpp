@@ -1,5 +1,6 @@
 // plan.cpp -- static replay of the reference's assigned-set bookkeeping + levelisation (see plan.hpp).
 #include "plan.hpp"
+#include "gate_record.hpp"
 #include "tuning.hpp"
 #include "scratch_layout.hpp"
 #include <algorithm>
@@ -139,9 +140,7 @@ struct PendingGate {
     uint32_t run_level = 0;          // the level whose launch executes it (its wave's host's level)
     uint32_t owner = 0, last_gate = 0;  // host only: the gate whose output the wave's `local` registers hold at the end of the program, and the last record
 };
-static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;   // w0: another record follows in the same wave
-static constexpr uint32_t GATE_SETLOCAL_FLAG = 1u << 25;  // w0: this record's output replaces the wave's `local` registers (GATE_LOCAL of the records behind it)
-static constexpr uint32_t GATE_LOCAL = 0xFFFFFFFFu;    // operand slot: the output of the preceding record of the same wave
+// (GATE_TAIL_FLAG, GATE_SETLOCAL_FLAG, GATE_LOCAL, the output modes and the bound units: gate_record.hpp)
 // operand words of a gate record (layout in build_plan)
 template <class F>
 static void for_each_operand_word(std::vector<uint32_t> &w, F fn) {
@@ -762,6 +761,12 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     }
     std::vector<FrH> ws, wsi;  // scale and 1 / scale of the scaled witnesses (indexed through scale_slot)
     std::vector<uint32_t> scale_slot(nw, 0xFFFFFFFFu);
+    // Relaxed rows (gate_eval.hpp): a witness that may carry a scale is also stored as ANY representative below 2^256; kbound[w] = its
+    // bound in units of p / 256 (everything else is canonical: GATE_K_CANON). gate_of[w]: the gate that writes w.
+    const bool relax_on = scaling_on && tune.relax != 0;
+    p.kbound.assign(nw, GATE_K_CANON);
+    std::vector<uint32_t> &kbound = p.kbound;
+    std::vector<uint32_t> gate_of(nw, 0xFFFFFFFFu);
     const FrH f_one = frh::one(), f_minus_one = frh::neg(frh::one());
     for (uint32_t oi = 0; oi < c.opcodes.size() && p.truncated_at == 0xFFFFFFFFu; oi++) {
         const Opcode &o = c.opcodes[oi];
@@ -1008,6 +1013,56 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                    pool.constant(qc_scaled), kind == GATE_SOLVE_DYN ? unk_partner : 0u,
                    (uint32_t)(pp.size() / 2) | (uint32_t)(pn.size() / 2) << 8 | (uint32_t)lp.size() << 16 | (uint32_t)ln.size() << 24};
         for (auto *v : {&pm, &lm, &pp, &pn, &lp, &ln}) g.words.insert(g.words.end(), v->begin(), v->end());
+        {
+            // The bound of the record's result, in the order gate_eval (gate_eval.hpp) sums it: hk = bound of the lazy side sum in units of
+            // p / 256, hw = its limb weight (the reduction inside gate_h_room resets both).
+            uint32_t hk = qc_scaled.is_zero() ? 0u : GATE_K_CANON, hw = qc_scaled.is_zero() ? 0u : 16u;
+            auto room = [&](uint32_t weight) {
+                if (hw + weight > GATE_H_MAX) { hk = GATE_K_WEAK; hw = GATE_H_AFTER_WEAK; }
+                hw += weight;
+            };
+            uint32_t sub_k = 1;
+            for (uint32_t w : ln)
+                while (sub_k < 3 && (GATE_K_CANON << sub_k) < kbound[w]) sub_k++;
+            for (size_t i = 0; i < pn.size(); i += 2) { room(33); hk += 2 * GATE_K_CANON; }
+            for (uint32_t w : lp) { room(16); hk += kbound[w]; }
+            for (size_t i = 0; i < ln.size(); i++) { room(33); hk += GATE_K_CANON << sub_k; }
+            // the Montgomery reductions, each taking the running sum along (fr29_dot_add): result < p + what its products add + the sum so far
+            auto mac_k = [&](size_t im) {  // the im-th multiplied term: coefficient (canonical) x (product | witness)
+                const size_t n_pm = pm.size() / 10;
+                if (im < n_pm) return gate_k_product(GATE_K_CANON + gate_k_product(kbound[pm[10 * im + 8]], kbound[pm[10 * im + 9]]), GATE_K_CANON);
+                return gate_k_product(kbound[lm[9 * (im - n_pm) + 8]], GATE_K_CANON);
+            };
+            auto pp_k = [&](size_t ip) { return gate_k_product(kbound[pp[2 * ip]], kbound[pp[2 * ip + 1]]); };
+            const size_t n_pp = pp.size() / 2, n_mac = pm.size() / 10 + lm.size() / 9;
+            size_t im = 0, ip = 0;
+            uint32_t n_red = 0;
+            auto reduction = [&](uint32_t adds) {
+                hk += GATE_K_CANON + adds;
+                if (++n_red == GATE_REDUCTIONS_PER_WEAK) { hk = GATE_K_WEAK; n_red = 0; }
+            };
+            for (; ip < n_pp && im < n_mac; ip++, im++) reduction(pp_k(ip) + mac_k(im));
+            for (; im < n_mac; im += 2) reduction(mac_k(im) + (n_mac - im == 1 ? 0u : mac_k(im + 1)));
+            for (; ip < n_pp; ip += 2) reduction(pp_k(ip) + (n_pp - ip == 1 ? 0u : pp_k(ip + 1)));
+            uint32_t acc_k = hk;
+            uint32_t flags = sub_k << GATE_SUBK_SHIFT;
+            if (kind == GATE_SOLVE_DYN) {
+                if (acc_k > 7 * GATE_K_CANON) { flags |= GATE_PRESUM_WEAK; acc_k = GATE_K_WEAK; }
+                acc_k = GATE_K_CANON + gate_k_product(acc_k, GATE_K_INVERSE);
+            }
+            if (kind != GATE_ASSERT) {
+                uint32_t mode = GATE_OUT_CANON, kb = GATE_K_CANON;
+                if (relax_on && !pinned[unk_w]) {
+                    if (acc_k <= GATE_K_ROW_MAX) { mode = GATE_OUT_ASIS; kb = acc_k; }
+                    else { mode = GATE_OUT_WEAK; kb = GATE_K_WEAK; }
+                }
+                flags |= mode << GATE_OUT_SHIFT;
+                kbound[unk_w] = kb;
+                p.n_gate_out_mode[mode]++;
+            }
+            g.words[0] |= flags;
+            p.max_gate_bound = std::max(p.max_gate_bound, acc_k);
+        }
         std::sort(reads.begin(), reads.end());
         reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
         g.reads = reads;
@@ -1020,11 +1075,23 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             known[unk_w] = 1;
             level[unk_w] = hlevel[unk_w] = g.level;
             p.producer[unk_w] = oi;
-            if (have_m) {  // stored = m * value
+            if (have_m || (relax_on && !pinned[unk_w])) {  // stored = m * value (m = 1: a relaxed row, whose readers outside the gate kernels take the same road)
                 is_scaled[unk_w] = 1;
                 scale_slot[unk_w] = (uint32_t)ws.size();
                 ws.push_back(m);
                 wsi.push_back(m_inv);
+            }
+            gate_of[unk_w] = (uint32_t)gates.size();
+        }
+        if (kind == GATE_SOLVE_DYN && gate_of[unk_partner] != 0xFFFFFFFFu) {
+            // the inversion kernel tests the denominator for zero on the stored row (arithmetic.rs:217-221): its gate stores the canonical value
+            uint32_t &pw0 = gates[gate_of[unk_partner]].words[0];
+            const uint32_t was = (pw0 >> GATE_OUT_SHIFT) & 3u;
+            if (was != GATE_OUT_CANON) {
+                p.n_gate_out_mode[was]--;
+                p.n_gate_out_mode[GATE_OUT_CANON]++;
+                pw0 = (pw0 & ~(3u << GATE_OUT_SHIFT)) | GATE_OUT_CANON << GATE_OUT_SHIFT;
+                kbound[unk_partner] = GATE_K_CANON;  // (the gates in between were sized for the looser bound: still an upper bound)
             }
         }
         if (kind == GATE_SOLVE_DYN) {

@@ -78,6 +78,11 @@ struct Plan {
     std::vector<uint32_t> scaled_ids;           // witnesses stored scaled
     std::vector<FrH> unscale;                   // 1 / scale, same order
     std::vector<uint32_t> unscale_index;        // per witness: index into `unscale`, 0xFFFFFFFF = stored as is
+    // relaxed rows (gate_eval.hpp): per witness the bound of its stored representative in units of p / 256 (256 = canonical); how many
+    // SOLVE gates store their result as it is / after fr29_weak / canonical; the largest bound any record's result reaches
+    std::vector<uint32_t> kbound;
+    uint32_t n_gate_out_mode[3] = {0, 0, 0};
+    uint32_t max_gate_bound = 0;
     // ---- in-order program: one record per opcode
     std::vector<uint32_t> prog;
     std::vector<uint32_t> prog_offset;          // per opcode

@@ -11,6 +11,7 @@ namespace acvm {
 struct Tuning {
     // ---- planner (plan.cpp)
     int64_t scale = 1;             // projective witnesses (a gate's most expensive coefficient becomes 1)
+    int64_t relax = 1;             // relaxed rows: a scaled witness is stored as any representative below 2^256 (gate_eval.hpp); needs scale
     int64_t pairs = 1;             // wave programs: a gate runs behind its producer in the same wave
     int64_t chains = 1;            // ... and behind a tail of that wave
     int64_t max_tails = 5;         // records behind the host of a wave program

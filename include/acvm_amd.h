@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ACVM_AMD_ABI_VERSION 4
+#define ACVM_AMD_ABI_VERSION 5
 
 /* library-level error codes */
 enum {
@@ -151,6 +151,9 @@ typedef struct {
     uint32_t n_brillig_inlined; /* Brillig opcodes whose straight-line program the level schedule runs as a light record (no VM) */
     uint32_t n_brillig_retries; /* passes of the last solve that re-ran Brillig opcodes of the exact path with raised VM limits */
     uint32_t n_hash_chained;   /* byte-message hashes that run in the workgroup of the hash whose digest they consume (no launch of their own) */
+    /* relaxed rows (ABI 5): SOLVE gates that store their result as the column scan left it (any representative below 2^256) / after one
+     * quotient-estimate reduction (below 1.03 p) / canonical; the largest bound a gate's result reaches, in units of p / 256 */
+    uint32_t n_gate_out_asis, n_gate_out_weak, n_gate_out_canon, max_gate_bound;
 } acvm_stats_t;
 
 const char *acvm_last_error(void);

@@ -652,19 +652,20 @@ FR_HD __forceinline__ void fr_store(uint4 *W, uint32_t slot, uint64_t B, uint64_
     W[((uint64_t)slot * 2 + 1) * B + j] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
 // the same store marked nontemporal (global_store ... nt): a row that no wave will read again before it has left the caches anyway
-// (outputs of the hash kernels: config 3 0.447 -> 0.505 of the HBM roofline) does not displace lines that are still to be read
+// (outputs of the hash kernels: config 3 0.447 -> 0.505 of the HBM roofline) does not displace lines that are still to be read.
+// One 16-byte access per half, spelled as a vector so that the compiler cannot split a half into overlapping dwordx3 + dwordx2 loads
+// (it did, once the eight scalar loads were inlined through a loader object: 3 VMEM instructions per row instead of 2).
+typedef uint32_t fr_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void fr_store_nt(uint4 *W, uint32_t slot, uint64_t B, uint64_t j, const Fr &a) {
     uint4 *lo = W + (uint64_t)slot * 2 * B + j, *hi = lo + B;
-    __builtin_nontemporal_store(a.v[0], &lo->x); __builtin_nontemporal_store(a.v[1], &lo->y);
-    __builtin_nontemporal_store(a.v[2], &lo->z); __builtin_nontemporal_store(a.v[3], &lo->w);
-    __builtin_nontemporal_store(a.v[4], &hi->x); __builtin_nontemporal_store(a.v[5], &hi->y);
-    __builtin_nontemporal_store(a.v[6], &hi->z); __builtin_nontemporal_store(a.v[7], &hi->w);
+    const fr_u32x4 l = {a.v[0], a.v[1], a.v[2], a.v[3]}, h = {a.v[4], a.v[5], a.v[6], a.v[7]};
+    __builtin_nontemporal_store(l, (fr_u32x4 *)lo);
+    __builtin_nontemporal_store(h, (fr_u32x4 *)hi);
 }
 __device__ __forceinline__ Fr fr_load_nt(const uint4 *W, uint32_t slot, uint64_t B, uint64_t j) {
     const uint4 *lo = W + (uint64_t)slot * 2 * B + j, *hi = lo + B;
-    Fr r;
-    r.v[0] = __builtin_nontemporal_load(&lo->x); r.v[1] = __builtin_nontemporal_load(&lo->y); r.v[2] = __builtin_nontemporal_load(&lo->z); r.v[3] = __builtin_nontemporal_load(&lo->w);
-    r.v[4] = __builtin_nontemporal_load(&hi->x); r.v[5] = __builtin_nontemporal_load(&hi->y); r.v[6] = __builtin_nontemporal_load(&hi->z); r.v[7] = __builtin_nontemporal_load(&hi->w);
+    const fr_u32x4 l = __builtin_nontemporal_load((const fr_u32x4 *)lo), h = __builtin_nontemporal_load((const fr_u32x4 *)hi);
+    Fr r = {{l.x, l.y, l.z, l.w, h.x, h.y, h.z, h.w}};
     return r;
 }
 // circuit constant (wave-uniform): 8 consecutive u32 in the constants table

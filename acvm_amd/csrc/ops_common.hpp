@@ -74,7 +74,15 @@ struct GateDeviceLoader {
     uint64_t Bp, j;
     __device__ __forceinline__ Fr29 load(uint32_t slot) const {
         // nontemporal (streaming) loads: an operand row is read by this launch and then not again for levels (5.53 -> 5.55 M witnesses/s)
+#ifdef GATE_EXP_NO_LOADS  // measurement only (tools/build_variant.sh): operands made up from the lane and the row, no memory access
+        Fr29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.v[i] = ((uint32_t)j * 2654435761u + slot * 40503u + i) & 0x1fffffffu;
+        r.v[8] &= 0xffffffu;
+        return r;
+#else
         return fr29_from(fr_load_nt(W, slot, Bp, j));
+#endif
     }
     __device__ __forceinline__ Fr29 load_inverse(uint32_t slot) const { return fr29_from(fr_load_nt(Inv, slot, Bp, j)); }
     __device__ __forceinline__ const uint32_t *constant(uint32_t idx) const { return consts + (uint64_t)idx * 8; }
@@ -98,7 +106,11 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
             for (int i = 0; i < 9; i++) z |= acc.v[i];
             if (z) atomicMin(&event[j], opcode);
         } else {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
+#ifdef GATE_EXP_NO_STORES  // measurement only: the result leaves through one word (kept alive, never true)
+            if (fr29_pack(acc).v[3] == 0x12345678u && acc.v[5] == 77u) event[j] = 0;
+#else
             fr_store_nt(W, out, Bp, j, fr29_pack(acc));  // read again levels later, long after it left the caches: 5.38 -> 5.50 M witnesses/s
+#endif
         }
         if (!(w0 & GATE_TAIL_FLAG)) break;
         if (host || (w0 & GATE_SETLOCAL_FLAG)) local = acc;  // the tails read the host's output until a record takes `local` over

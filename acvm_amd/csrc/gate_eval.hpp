@@ -40,7 +40,7 @@ FR_HD __forceinline__ void gate_h_sub(Fr29 &h, const Fr29 &x, uint32_t klog2) {
     }
 }
 // 8 inline words of a record -> working form (wave-uniform: scalar work on the device)
-FR_HD __forceinline__ Fr29 gate_coef29(const uint32_t *__restrict__ t) {
+FR_HD __forceinline__ Fr29 gate_coef29(GateWords t) {
     Fr c;
 #pragma unroll
     for (int i = 0; i < 8; i++) c.v[i] = t[i];
@@ -55,23 +55,23 @@ FR_HD __forceinline__ Fr29 gate_operand(const L &ld, uint32_t slot, const Fr29 &
 }
 // the witness side of the k-th multiplied term of the record: the products come first (coef[8], a, b), then the linear terms (coef[8], w);
 // its coefficient is gate_coef29 of the same entry (kept apart: the coefficient is wave-uniform and stays in scalar registers)
-FR_HD __forceinline__ const uint32_t *gate_mac_entry(const uint32_t *__restrict__ t0, uint32_t np_mac, uint32_t k) {
+FR_HD __forceinline__ GateWords gate_mac_entry(GateWords t0, uint32_t np_mac, uint32_t k) {
     return k < np_mac ? t0 + 10 * k : t0 + 10 * np_mac + 9 * (k - np_mac);
 }
 template <class L>
-FR_HD __forceinline__ Fr29 gate_mac_operand(const L &ld, const uint32_t *__restrict__ c, bool product, const Fr29 &local) {
+FR_HD __forceinline__ Fr29 gate_mac_operand(const L &ld, GateWords c, bool product, const Fr29 &local) {
     if (product) return fr29_mul(gate_operand(ld, c[8], local), gate_operand(ld, c[9], local));
     return gate_operand(ld, c[8], local);
 }
 
 // Value of a record: normalised limbs, below the planner's bound for the record (plan.cpp mirrors this walk term by term).
 //   L: loader with  Fr29 load(uint32_t slot) const  (GATE_LOCAL never reaches it),  Fr29 load_inverse(uint32_t slot) const,
-//      const uint32_t *constant(uint32_t idx) const  (8 words of the constant pool),  bool any(bool) const  (wave-wide OR: the ballot)
+//      GateWords constant(uint32_t idx) const  (8 words of the constant pool),  bool any(bool) const  (wave-wide OR: the ballot)
 // Order: the terms that are only added or subtracted go into the lazy sum h first; then every Montgomery reduction of the record --
 // two multiplied terms apiece -- takes the running sum along in its upper columns (fr29_dot_add), so the sum comes out of the last one
 // with its carries propagated. An ASSERT record's value is canonical (zero test by the caller, arithmetic.rs:92-102).
 template <class L>
-FR_HD __forceinline__ Fr29 gate_eval(const L &ld, const uint32_t *__restrict__ g, const Fr29 &local) {
+FR_HD __forceinline__ Fr29 gate_eval(const L &ld, GateWords g, const Fr29 &local) {
     const uint32_t w0 = g[0], w5 = g[5], qc = g[3], kind = w0 & 0xff;
     const uint32_t np_mac = (w0 >> 8) & 0xff, nl_mac = (w0 >> 16) & 0xff, n_mac = np_mac + nl_mac;
     const uint32_t np_pos = w5 & 0xff, np_neg = (w5 >> 8) & 0xff, nl_pos = (w5 >> 16) & 0xff, nl_neg = w5 >> 24;
@@ -85,9 +85,9 @@ FR_HD __forceinline__ Fr29 gate_eval(const L &ld, const uint32_t *__restrict__ g
         h = gate_coef29(ld.constant(qc));
         hw = 16;
     }
-    const uint32_t *__restrict__ t0 = g + 6;                          // np_mac x (coef[8], a, b), nl_mac x (coef[8], w)
-    const uint32_t *__restrict__ tp = t0 + 10 * np_mac + 9 * nl_mac;  // np_pos x (a, b)
-    const uint32_t *__restrict__ t = tp + 2 * np_pos;                 // np_neg x (a, b), nl_pos x (w), nl_neg x (w)
+    GateWords t0 = g + 6;                          // np_mac x (coef[8], a, b), nl_mac x (coef[8], w)
+    GateWords tp = t0 + 10 * np_mac + 9 * nl_mac;  // np_pos x (a, b)
+    GateWords t = tp + 2 * np_pos;                 // np_neg x (a, b), nl_pos x (w), nl_neg x (w)
     // ---- the terms that are only added or subtracted
     for (uint32_t i = 0; i < np_neg; i++, t += 2) {
         const Fr29 x = fr29_mul(gate_operand(ld, t[0], local), gate_operand(ld, t[1], local));  // < 1.17 p
@@ -112,19 +112,19 @@ FR_HD __forceinline__ Fr29 gate_eval(const L &ld, const uint32_t *__restrict__ g
     // it could leave the range of fr29_weak -- wave-uniform, never taken by the gates of width-3 circuits)
 #define GATE_AFTER_REDUCTION() do { normalised = true; if (++n_red == GATE_REDUCTIONS_PER_WEAK) { h = fr29_weak(h); n_red = 0; } } while (0)
     for (; ip < np_pos && im < n_mac; ip++, im++) {
-        const uint32_t *__restrict__ c = gate_mac_entry(t0, np_mac, im);
+        GateWords c = gate_mac_entry(t0, np_mac, im);
         const Fr29 l[2] = {gate_operand(ld, tp[2 * ip], local), gate_mac_operand(ld, c, im < np_mac, local)};
         const Fr29 m[2] = {gate_operand(ld, tp[2 * ip + 1], local), gate_coef29(c)};
         h = fr29_dot_add<2>(l, m, h);
         GATE_AFTER_REDUCTION();
     }
     for (; im < n_mac; im += 2) {
-        const uint32_t *__restrict__ c0 = gate_mac_entry(t0, np_mac, im);
+        GateWords c0 = gate_mac_entry(t0, np_mac, im);
         if (n_mac - im == 1) {
             const Fr29 l[1] = {gate_mac_operand(ld, c0, im < np_mac, local)}, m[1] = {gate_coef29(c0)};
             h = fr29_dot_add<1>(l, m, h);
         } else {
-            const uint32_t *__restrict__ c1 = gate_mac_entry(t0, np_mac, im + 1);
+            GateWords c1 = gate_mac_entry(t0, np_mac, im + 1);
             const Fr29 l[2] = {gate_mac_operand(ld, c0, im < np_mac, local), gate_mac_operand(ld, c1, im + 1 < np_mac, local)};
             const Fr29 m[2] = {gate_coef29(c0), gate_coef29(c1)};
             h = fr29_dot_add<2>(l, m, h);

@@ -15,6 +15,18 @@
 
 namespace acvm {
 
+// The record stream and the constant pool as the evaluation reads them. On the device they are read through the CONSTANT address space:
+// nothing writes them while a kernel runs, and a load from that space with a wave-uniform address is a scalar load by definition -- not
+// only where the compiler can prove that no store of the kernel reaches it (that proof is budgeted: in a kernel with many stores some
+// term loops fell back to vector loads of record words, each with a vmcnt(0) behind it; tools/stream_kernel.patch).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const uint32_t __attribute__((address_space(4))) *GateWords;
+#define GATE_WORDS(p) ((::acvm::GateWords)(uintptr_t)(p))
+#else
+typedef const uint32_t *GateWords;
+#define GATE_WORDS(p) ((::acvm::GateWords)(p))
+#endif
+
 // operand row GATE_LOCAL: the output of the record that ran before this one in the same wave (plan.cpp "gate pairs")
 static constexpr uint32_t GATE_LOCAL = 0xFFFFFFFFu;
 static constexpr uint32_t GATE_TAIL_FLAG = 1u << 24;      // another record follows in the same wave
@@ -47,7 +59,7 @@ GATE_HD inline uint32_t gate_k_product(uint32_t ka, uint32_t kb) {
 }
 
 // words of a gate record
-GATE_HD inline uint32_t gate_record_words(const uint32_t *g) {
+GATE_HD inline uint32_t gate_record_words(GateWords g) {
     const uint32_t w0 = g[0], w5 = g[5];
     return 6u + 10u * ((w0 >> 8) & 0xff) + 9u * ((w0 >> 16) & 0xff) + 2u * ((w5 & 0xff) + ((w5 >> 8) & 0xff)) + ((w5 >> 16) & 0xff) + (w5 >> 24);
 }

@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(256) unscale_slow_kernel(uint4 *__restrict__ W
 #ifndef ARITH_BLOCK
 #define ARITH_BLOCK 256
 #endif
-__global__ void __launch_bounds__(ARITH_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+#ifndef ARITH_WAVES_MIN  // (tools/build_variant.sh: 7 waves per SIMD = 72 VGPRs + 20 B of scratch measured 5.72-5.76 against 5.79-5.81 M witnesses/s, 8 = 64 VGPRs + 60 B: 5.10-5.14)
+#define ARITH_WAVES_MIN 6
+#endif
+__global__ void __launch_bounds__(ARITH_BLOCK) __attribute__((amdgpu_waves_per_eu(ARITH_WAVES_MIN, 8)))
 arith_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream, const uint32_t *__restrict__ gate_offset,
                    const uint32_t *__restrict__ consts, uint32_t *__restrict__ event, const uint4 *__restrict__ Inv) {
     arith_level_body(W, Bp, B, gate_stream, gate_offset, consts, event, Inv, blockIdx.y);

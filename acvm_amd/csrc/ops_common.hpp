@@ -85,7 +85,7 @@ struct GateDeviceLoader {
 #endif
     }
     __device__ __forceinline__ Fr29 load_inverse(uint32_t slot) const { return fr29_from(fr_load_nt(Inv, slot, Bp, j)); }
-    __device__ __forceinline__ const uint32_t *constant(uint32_t idx) const { return consts + (uint64_t)idx * 8; }
+    __device__ __forceinline__ GateWords constant(uint32_t idx) const { return GATE_WORDS(consts) + (uint64_t)idx * 8; }
     __device__ __forceinline__ bool any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0; }
 };
 __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ gate_stream,
@@ -93,7 +93,7 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
                                                  uint32_t *__restrict__ event, const uint4 *__restrict__ Inv, uint32_t gate_index) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
-    const uint32_t *__restrict__ g = gate_stream + gate_offset[gate_index];
+    GateWords g = GATE_WORDS(gate_stream) + gate_offset[gate_index];
     const GateDeviceLoader ld{W, Inv, consts, Bp, j};
     Fr29 local = fr29_from(fr_zero());
     bool host = true;

@@ -24,7 +24,7 @@ def exe(tmp_path_factory):
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not on PATH")
     out = str(tmp_path_factory.mktemp("gate_host") / "gate_host_test")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", os.path.join(ROOT, "tools", "gate_host_test.hip"),
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "--cuda-host-only", "-O2", "-std=c++17", "-x", "hip", os.path.join(ROOT, "tools", "gate_host_test.hip"),
                     os.path.join(CSRC, "plan.cpp"), os.path.join(CSRC, "circuit.cpp"), os.path.join(CSRC, "tuning.cpp"), "-lz", "-o", out],
                    check=True, timeout=900)
     return out

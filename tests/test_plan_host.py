@@ -89,11 +89,35 @@ def test_projective_witnesses_only_where_arithmetic_gates_are_the_only_users():
     """plan.cpp keeps a witness as scale x value when that makes its gate cheaper -- but never an initial witness and never one a
     non-Arithmetic opcode mentions (those kernels read plain values)."""
     circ, ids = synth.arithmetic_circuit(2000, seed=0xAC1D0002)
+    with acvm_amd.tuning(relax=0):
+        st = stats(circ, ids)
+        assert 1500 <= st["n_scaled_witnesses"] <= 2000          # random coefficients: almost every gate has one to remove
+        # all coefficients +-1: nothing to gain, nothing is scaled
+        ops = [E([(1, 1, 2)], [(P - 1, 3)], 0), E([], [(1, 3), (1, 1), (P - 1, 4)], 0), E([(P - 1, 3, 4)], [(1, 5)], 7)]
+        assert stats(Circuit(5, ops), [1, 2])["n_scaled_witnesses"] == 0
+        # w3 = 5 w1 w2 would be scaled, but RANGE reads it; w4 = 3 w3 + 7 w1 has no other user and is scaled
+        ops2 = [E([(5, 1, 2)], [(P - 1, 3)], 0), BB("RANGE", {"input": FI(3, 200)}), E([], [(3, 3), (7, 1), (P - 1, 4)], 0)]
+        assert stats(Circuit(4, ops2), [1, 2])["n_scaled_witnesses"] == 1
+    # relaxed rows (the default): every witness that only Arithmetic gates read is stored as some representative below 2^256 and takes the
+    # same road out (a scale, 1 if nothing was gained); the RANGE operand and the initial witnesses stay canonical
+    st = stats(Circuit(5, ops), [1, 2])
+    assert st["n_scaled_witnesses"] == 3 and st["n_gate_out_canon"] == 0 and st["n_gate_out_asis"] == 3
+    st = stats(Circuit(4, ops2), [1, 2])
+    assert st["n_scaled_witnesses"] == 1 and st["n_gate_out_canon"] == 1 and st["n_gate_out_asis"] == 1
+
+
+def test_relaxed_rows_bounds_and_modes():
+    """The planner's bound bookkeeping (gate_record.hpp units of p / 256): a chain of +-1 additions grows by the operand's bound per gate and
+    must ask for a reduction before 2^256; the denominators of SOLVE_DYN gates are stored canonical for the inversion kernel's zero test."""
+    circ, ids = synth.arithmetic_circuit(10000, seed=0xAC1D0002)
     st = stats(circ, ids)
-    assert 1500 <= st["n_scaled_witnesses"] <= 2000          # random coefficients: almost every gate has one to remove
-    # all coefficients +-1: nothing to gain, nothing is scaled
-    ops = [E([(1, 1, 2)], [(P - 1, 3)], 0), E([], [(1, 3), (1, 1), (P - 1, 4)], 0), E([(P - 1, 3, 4)], [(1, 5)], 7)]
-    assert stats(Circuit(5, ops), [1, 2])["n_scaled_witnesses"] == 0
-    # w3 = 5 w1 w2 would be scaled, but RANGE reads it; w4 = 3 w3 + 7 w1 has no other user and is scaled
-    ops = [E([(5, 1, 2)], [(P - 1, 3)], 0), BB("RANGE", {"input": FI(3, 200)}), E([], [(3, 3), (7, 1), (P - 1, 4)], 0)]
-    assert stats(Circuit(4, ops), [1, 2])["n_scaled_witnesses"] == 1
+    assert st["n_gate_out_asis"] + st["n_gate_out_weak"] + st["n_gate_out_canon"] == 10000
+    assert st["n_gate_out_asis"] > 9000 and 0 < st["n_gate_out_weak"] < 500
+    assert 300 < st["n_gate_out_canon"] <= st["n_dyn_gates"]     # one canonical producer per distinct denominator
+    assert st["max_gate_bound"] < 169 * 256                      # fr29_weak takes anything below 2^261 = 169 p
+    chain, cids = synth.arithmetic_circuit(400, seed=5, chain=True, mix=(0, 100, 0, 0))
+    st = stats(chain, cids)
+    assert st["n_gate_out_weak"] >= 50
+    with acvm_amd.tuning(relax=0):
+        st = stats(circ, ids)
+        assert st["n_gate_out_asis"] == 0 and st["n_gate_out_weak"] == 0 and st["n_gate_out_canon"] == 10000

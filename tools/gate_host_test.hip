@@ -93,7 +93,7 @@ struct HostLoader {
     bool force_any;
     Fr29 load(uint32_t slot) const { return fr29_from((*W)[(size_t)slot * B + j]); }
     Fr29 load_inverse(uint32_t slot) const { return fr29_from((*Inv)[(size_t)slot * B + j]); }
-    const uint32_t *constant(uint32_t idx) const { return consts->data() + (size_t)idx * 8; }
+    GateWords constant(uint32_t idx) const { return consts->data() + (size_t)idx * 8; }
     bool any(bool x) const { return x || force_any; }  // (a lane whose neighbours need the last subtraction runs it too)
 };
 

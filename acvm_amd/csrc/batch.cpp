@@ -236,7 +236,7 @@ static int batch_init(acvm_batch *b) {
             uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
             if (k == CLS_HASH) {  // byte-message hashes first: their own kernel, no scratch (the records of a level are independent)
                 auto is_coop = [&](uint32_t r) { return (b->plan.prog[b->plan.cls_offset[k][r] + 2] & PLAN_HASH_COOP_FLAG) != 0; };
-                // The LDS message of a launch is sized by its longest record (a 1 024-byte message takes the whole 64 KiB a workgroup may have):
+                // The LDS message of a launch is sized by its longest record (a 1 024-byte message takes 77 KiB of the workgroup's 160 KiB on gfx950):
                 // short messages (<= 256 bytes: 16 KiB per 64 instances) and long ones get launches of their own, so that one long message
                 // somewhere in the circuit does not cost every 64-byte SHA record its occupancy.
                 auto words_of = [&](uint32_t r) {  // message words of the record, or of the longest member of the chain it heads (plan.cpp hash chains)

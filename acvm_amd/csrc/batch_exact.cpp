@@ -318,7 +318,10 @@ int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint32_t en
             if (!is_device_limit(r)) continue;
             if (r.msg == 18u && lim.steps >= max_steps) { give_up_lane(r, ACVM_LIMIT_BRILLIG_STEPS, max_steps, 0); continue; }
             if (r.msg == 28u && lim.call_depth >= max_depth) { give_up_lane(r, ACVM_LIMIT_BRILLIG_CALL_DEPTH, max_depth, 0); continue; }
-            if (r.msg == 17u && ((uint64_t)r.x0 + 1 > max_cells || cur_cells >= max_cells)) { give_up_lane(r, ACVM_LIMIT_BRILLIG_MEMORY, max_cells, r.x0); continue; }
+            // (the lane's own capacity so far: the raised one of an earlier pass, else the planner's estimate of ITS record -- not the largest
+            // estimate among the lanes of this pass, which gave up a lane whose own need still fitted)
+            const uint64_t own_cells = lim.mem_cap ? lim.mem_cap : (r.opcode_index < p.n_opcodes && p.prog[p.prog_offset[r.opcode_index]] == PK_BRILLIG ? p.prog[p.prog_offset[r.opcode_index] + 8] : 0u);
+            if (r.msg == 17u && ((uint64_t)r.x0 + 1 > max_cells || own_cells >= max_cells)) { give_up_lane(r, ACVM_LIMIT_BRILLIG_MEMORY, max_cells, r.x0); continue; }
             lanes.push_back(t);
             hit_steps |= r.msg == 18u;
             hit_depth |= r.msg == 28u;
@@ -384,6 +387,14 @@ int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint32_t en
         b->br_retry_active = false;
         b->n_brillig_retries++;
         if (rc) break;
+    }
+    // The lanes that were given up are final on the DEVICE too: a caller that keeps stepping (solve_stepping) fetches the device's records
+    // after every step, and a lane whose device record still said "panic at a device limit" came back as ACVM_ERR_PANIC and was retried
+    // up to the maximum again at every later step. (Every exit of the loop above passes here: no lane left to retry, a failed allocation.)
+    if (!rc) {
+        bool any_final = false;
+        for (uint32_t t = 0; t < n_slow; t++) any_final |= b->slow_res[t].err == ACVM_ERR_DEVICE_LIMIT;
+        if (any_final) HIPCHK(hipMemcpyAsync(b->d_slow_res, b->slow_res.data(), (size_t)n_slow * sizeof(SlowResult), hipMemcpyHostToDevice, s));
     }
     return rc;
 }

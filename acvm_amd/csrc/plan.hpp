@@ -40,7 +40,7 @@ static constexpr uint32_t GATE_HDR_WORDS = 5;
 static constexpr uint32_t PLAN_HASH_COOP_FLAG = 0x100u;      // PK_HASH function word: byte message, unpacked through LDS by the level kernel
 static constexpr uint32_t PLAN_HASH_CHAIN_FLAG = 0x400u;     // ... and the offset of a chain link follows (the record that hashes this digest runs in the same block)
 static constexpr uint32_t PLAN_HASH_RANGE_FLAG = 0x200u;     // ... and (RANGE opcode or NONE, bits) per input follow the outputs: byte RANGE checks fused into the hash
-static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 256 message words x 64 instances = 64 KiB of LDS, the most a workgroup may ask for (batch.cpp sizes each launch by its own longest record)
+static constexpr uint32_t PLAN_HASH_COOP_MAX_BYTES = 1024;   // 256 message words x 64 instances = 64 KiB of message + 4 KiB of digests + 9 KiB of static tables = 77 KiB of the 160 KiB a gfx950 workgroup may hold (the library runs on gfx950 only; kernels_hash.hip sizes each launch by its own longest record and checks the device's limit)
 // record kinds of the in-order program (same numbering as ops_common.hpp RecKind)
 enum ProgKind : uint32_t {
     PK_ARITH = 0, PK_RANGE = 1, PK_LOGIC = 2, PK_HASH = 3, PK_PEDERSEN = 4, PK_FIXED_BASE = 5, PK_SCHNORR = 6, PK_ZERO_OUT = 7,

@@ -130,16 +130,18 @@ int acvm_debug_secp(uint32_t curve, uint32_t what, const uint8_t *in_be32, uint3
 int acvm_debug_grumpkin(uint32_t what, uint32_t param, const uint8_t *in_be32, uint32_t n_in, uint8_t *out_be64) try {
     if (!out_be64) return set_err(ACVM_E_INVALID, "null argument");
     if (what == 0) return grumpkin_host_point(param >> 24, param & 0xffffffu, out_be64) ? 0 : set_err(ACVM_E_INVALID, "bad table index");
-    GrumpkinTables tabs;
-    if (!grumpkin_tables(&tabs)) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
-    const GrumpkinTables *t = &tabs;
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
-    struct Hold {  // the probe holds the device's tables while it runs (acvm_device_release_tables refuses meanwhile)
+    // the probe holds the device's tables while it runs, from BEFORE it asks for their addresses: with tables_keep = 0 another handle's
+    // destruction between the two would free what was just handed out (acvm_device_release_tables refuses meanwhile)
+    struct Hold {
         int d;
         explicit Hold(int dev_) : d(dev_) { device_tables_retain(d); }
         ~Hold() { device_tables_unref(d); }
     } hold(dev);
+    GrumpkinTables tabs;
+    if (!grumpkin_tables(&tabs)) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");
+    const GrumpkinTables *t = &tabs;
     std::vector<uint32_t> in(8 * (n_in ? n_in : 1), 0), out(16, 0);
     for (uint32_t i = 0; i < n_in; i++)
         for (int k = 0; k < 32; k++) in[8 * i + k / 4] |= (uint32_t)in_be32[32 * i + 31 - k] << (8 * (k % 4));

@@ -157,6 +157,16 @@ def pick(per, substrs):
     return tot, n
 
 
+def rocprof_names(per, substrs):
+    """the rocprofv3 kernel names (demangled, arguments cut) of a kernel class that a PMC pass actually saw, with their launch counts"""
+    out = {}
+    for name, (v, k) in (per or {}).items():
+        if any(x in name for x in substrs):
+            short = name.split("(")[0].replace("void ", "")
+            out[short] = out.get(short, 0) + k
+    return out
+
+
 def measure_traffic(args, kernel_substr):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured in THIS run: two rocprofv3 passes (FETCH_SIZE,
     WRITE_SIZE separately, kernel-trace only) over a one-tile run of this script. None if rocprofv3 is missing or fails."""
@@ -353,7 +363,7 @@ def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
         k_ms = st["solve_device_ms"]
     achieved = k_bytes * tile / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": dominant, "kernel_ms_per_tile": k_ms, "algorithmic_bytes_per_tile": k_bytes * tile,
+            "kernel": dominant, "kernel_class_symbols": KERNEL_SYMBOL.get(dominant, [dominant]), "kernel_ms_per_tile": k_ms, "algorithmic_bytes_per_tile": k_bytes * tile,
             "kernel_timing": "HIP events around every launch of the last tile of the last timed step (on the launching stream)",
             "launches_per_tile_all_kernels": st["n_kernel_launches"],
             "other_kernels_ms_per_tile": {k: v[0] for k, v in cand.items() if k != dominant and v[0] > 0}}
@@ -367,6 +377,8 @@ def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
         if tr:
             roof["traffic"] = tr["bytes_per_launch"]
             roof["traffic_detail"] = tr
+            # `kernel` above is the library's class of launches; these are the names rocprofv3 prints for them (what profiles/*_profile_*.txt lists)
+            roof["rocprof_kernels"] = rocprof_names(pmc_pass(args, "FETCH_SIZE"), KERNEL_SYMBOL.get(dominant, [dominant]))
         if dominant == "arith_level_kernel" and k_launches:
             # share of the VALU issue slots the gate kernel fills: its VALU wave instructions (PMC, own pass) x 4 cycles (a wave64 instruction
             # on a 16-lane SIMD) / (SIMDs x launch time x the shader clock sampled while the kernel ran)

@@ -110,8 +110,10 @@ typedef struct {
 static void *job_run(void *p) {
     job_t *j = (job_t *)p;
     oracle_inv_cache_t *cache = (j->mode & ORACLE_MODE_CACHE_INV) ? oracle_inv_cache_new(j->c) : NULL;
+    oracle_acvm_t *a = NULL; /* one ACVM object per host thread, re-initialised between instances (pwg.c oracle_acvm_reset) */
     for (size_t i = j->lo; i < j->hi; i++) {
-        oracle_acvm_t *a = oracle_acvm_new_mode(j->c, j->be, j->n_in, j->ids, j->values + i * j->n_in * 32, j->mode, cache);
+        if (!a) a = oracle_acvm_new_mode(j->c, j->be, j->n_in, j->ids, j->values + i * j->n_in * 32, j->mode, cache);
+        else oracle_acvm_reset(a, j->n_in, j->ids, j->values + i * j->n_in * 32);
         oracle_acvm_solve(a);
         if (j->results) j->results[i] = a->res;
         if (j->assigned) {
@@ -127,8 +129,8 @@ static void *job_run(void *p) {
                 }
             }
         }
-        oracle_acvm_free(a);
     }
+    oracle_acvm_free(a);
     oracle_inv_cache_free(cache);
     return NULL;
 }

@@ -52,8 +52,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()  # (rebuilds when a source is newer than the library: a stale checker checks nothing)
         L = C.CDLL(_LIB_PATH)
         L.oracle_circuit_from_bytes.restype = C.c_void_p
         L.oracle_circuit_from_bytes.argtypes = [C.c_char_p, C.c_size_t]

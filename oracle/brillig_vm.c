@@ -10,7 +10,7 @@
  *   /root/reference/acvm/src/pwg/brillig.rs:20-150      BrilligSolver::solve, zero_out_brillig_outputs
  * Integer ops take any bit_size like the reference's BigUint arithmetic (operands are field elements < p < 2^254, so past 256 bits only
  * Sub and Mul can still see the modulus 2^bit_size; see int_op).
- * Pinned by tests/test_oracle_brillig.py against brillig_vm/src/arithmetic.rs:149-234 known answers,
+ * Pinned by tests/test_oracle_acvm.py (the Brillig tests there) against brillig_vm/src/arithmetic.rs:149-234 known answers,
  * acvm/tests/solver.rs:308-608 and acvm_js/test/shared/{foreign_call,complex_foreign_call}.ts.
  */
 #include "hashes.h"

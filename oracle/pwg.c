@@ -618,6 +618,44 @@ static void free_pending(oracle_acvm_t *a) {
     memset(&a->pending, 0, sizeof a->pending);
 }
 
+/* The state of ACVM::new (pwg/mod.rs:146-156) for the NEXT instance of the same circuit on the same object: what oracle_acvm_free +
+ * oracle_acvm_new_mode would leave, without handing the witness vector (32 B x witnesses: 320 KB for a 10k-gate circuit, an mmap of its
+ * own) back to the OS and faulting it in again per instance -- under the process-wide mm lock, which is what held the multi-threaded CPU
+ * baseline to 14 x one thread on 64 cores. The reference's caller owns one ACVM per execution; a batch driver on the CPU would reuse its
+ * buffers exactly like this. ids must be the ones the object was created with (or any below its witness count). */
+void oracle_acvm_reset(oracle_acvm_t *a, size_t n_initial, const uint32_t *ids, const uint8_t *values_be32) {
+    for (size_t i = 0; i < a->n_blocks; i++) { free(a->blocks[i].cells); free(a->blocks[i].present); }
+    free(a->blocks);
+    a->blocks = NULL;
+    a->n_blocks = 0;
+    for (size_t i = 0; i < a->c->n_opcodes; i++) {
+        if (!a->n_extra_fc[i]) continue;
+        for (size_t j = 0; j < a->n_extra_fc[i]; j++) {
+            for (size_t k = 0; k < a->extra_fc[i][j].n; k++) free(a->extra_fc[i][j].values[k].arr);
+            free(a->extra_fc[i][j].values);
+        }
+        free(a->extra_fc[i]);
+        a->extra_fc[i] = NULL;
+        a->n_extra_fc[i] = 0;
+    }
+    free_pending(a);
+    memset(a->val, 0, (size_t)a->nw * sizeof(fr_t));
+    memset(a->assigned, 0, a->nw);
+    if (a->index) { /* the sparse-map mode times a map that starts empty, like the reference's */
+        oracle_btree_free(a->index);
+        a->index = oracle_btree_new();
+    }
+    for (size_t i = 0; i < n_initial; i++) {
+        if (ids[i] >= a->nw) continue;
+        fr_from_be_bytes_reduce(&a->val[ids[i]], values_be32 + 32 * i, 32);
+        a->assigned[ids[i]] = 1;
+        if (a->index) oracle_btree_insert(a->index, ids[i]);
+    }
+    a->ip = 0;
+    memset(&a->res, 0, sizeof a->res);
+    a->res.status = a->c->n_opcodes == 0 ? ST_SOLVED : ST_IN_PROGRESS;
+}
+
 void oracle_acvm_free(oracle_acvm_t *a) {
     if (!a) return;
     for (size_t i = 0; i < a->n_blocks; i++) { free(a->blocks[i].cells); free(a->blocks[i].present); }

@@ -110,6 +110,8 @@ oracle_acvm_t *oracle_acvm_new_mode(const circuit_t *c, const backend_t *backend
 oracle_inv_cache_t *oracle_inv_cache_new(const circuit_t *c);
 void oracle_inv_cache_free(oracle_inv_cache_t *k);
 void oracle_acvm_free(oracle_acvm_t *a);
+/* ACVM::new again on the same object for the next instance of the same circuit (same ids): buffers are kept */
+void oracle_acvm_reset(oracle_acvm_t *a, size_t n_initial, const uint32_t *ids, const uint8_t *values_be32);
 /* ACVM::solve (pwg/mod.rs:236-241), ACVM::solve_opcode (:243-303) */
 uint32_t oracle_acvm_solve(oracle_acvm_t *a);
 uint32_t oracle_acvm_solve_opcode(oracle_acvm_t *a);

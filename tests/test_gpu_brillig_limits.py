@@ -170,3 +170,31 @@ def test_limits_while_stepping(oracle):
     ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), [1, 2], values_from_rows(rows), len(rows))
     assert (asg == oasg[:, :asg.shape[1]]).all() and (vals == ovals[:, :vals.shape[1]]).all()
     assert batch.stats()["n_brillig_retries"] >= 1
+
+
+def test_step_limit_past_the_maximum_while_stepping(oracle):
+    """the instance that is given up stays ACVM_ERR_DEVICE_LIMIT on every later acvm_batch_solve_opcode, is not retried again (the retry
+    counter stands still), and the other instances step on to the oracle's map -- also when the given-up lane is the last one running"""
+    import acvm_amd
+    circ = Circuit(4, [counting_loop(), E([], [(1, 2), (-1, 3)], 0), E([], [(1, 3), (-1, 4)], 0)])
+    for rows, over in (([[10], [5000], [300]], 1), ([[5000]], 0)):
+        data, values = circ.to_bytes(), values_from_rows(rows)
+        ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), [1], values, len(rows))
+        with acvm_amd.tuning(brillig_steps_log2=8, brillig_steps_max_log2=12):
+            batch = acvm_amd.Batch(acvm_amd.Circuit(data), len(rows), [1])
+            batch.set_initial_witness(values)
+            batch.solve_opcode()
+            retries = batch.stats()["n_brillig_retries"]
+            assert retries >= 1
+            for step in range(3):
+                res = batch.results()
+                assert (res[over].status, res[over].err, res[over].opcode_index, res[over].aux0) == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_DEVICE_LIMIT, 0, acvm_amd.LIMIT_BRILLIG_STEPS), step
+                batch.solve_opcode()
+                assert batch.stats()["n_brillig_retries"] == retries, step
+            res = batch.results()
+            asg, vals = batch.witness_map()
+            for j in range(len(rows)):
+                if j != over:
+                    assert res[j].as_tuple() == ores[j].as_tuple()
+                    assert (asg[j] == oasg[j][: asg.shape[1]]).all() and (vals[j] == ovals[j][: vals.shape[1]]).all()
+            batch.free()

@@ -13,6 +13,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --inner --total-log2 16 $*"
+echo "python bench.py --steps 3 --warmup 1 --inner --total-log2 16 $* (one tile of 2^16 instances per step)" > "$OUT/command.txt"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $BENCH > "$OUT/pmc_fetch.log" 2>&1

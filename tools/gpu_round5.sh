@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_round4.sh TAG -- the evidence of a round in one GPU call: bench lines of every workload (the default one with its legs),
+# tools/gpu_round5.sh TAG -- the evidence of a round in one GPU call: bench lines of every workload (the default one with its legs),
 # rocprofv3 --kernel-trace --stats of the driver's command, per-workload profiles with HBM counters, SQ counters of the gate kernel,
 # config 5 at circuit size (plain / folded digest / slot reuse, through the batch API and through the node driver) and its timeline.
 TAG=${1:-rXX}
@@ -16,6 +16,7 @@ timeout 1500 python bench.py --workload config5 --steps 2 --warmup 1 2> gpurun_o
 python tools/bench_line.py < gpurun_out/bench_${TAG}_config5.json
 # the driver's command under rocprofv3 (PMC passes and legs of bench.py itself off: one trace of one process)
 mkdir -p gpurun_out/prof_${TAG}_bench
+echo "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs (the driver's command: 2^20 instances in 8 tiles of 2^17 per step; bench.py's own PMC passes off)" > gpurun_out/prof_${TAG}_bench/command.txt
 ( cd /tmp && ACVM_BENCH_NO_PMC=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_${TAG}_bench/trace" -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs > "$ROOT/gpurun_out/prof_${TAG}_bench/trace.log" 2>&1 )
 find gpurun_out/prof_${TAG}_bench -name '*.db' -delete
 find gpurun_out/prof_${TAG}_bench -name '*kernel_trace.csv' -size +20M -delete

@@ -41,8 +41,14 @@ def read_pmc(path, counter):
 
 
 def main(d):
-    print(f"# source: {d} (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE: three separate runs of")
-    print("#         `python bench.py --steps 3 --warmup 1 --inner --total-log2 16` = one tile of 2^16 instances per step)")
+    # the command that was profiled, as the script that ran it wrote it down (command.txt in the run directory): never a guess
+    try:
+        cmd = open(os.path.join(d, "command.txt")).read().strip()
+    except OSError:
+        cmd = "(command not recorded in this run directory)"
+    have_pmc = os.path.exists(os.path.join(d, "pmc_fetch", "pmc_counter_collection.csv"))
+    print(f"# source: {d}: rocprofv3 --kernel-trace --stats" + ("; --pmc FETCH_SIZE; --pmc WRITE_SIZE: three separate runs" if have_pmc else "") + " of")
+    print(f"#         `{cmd}`")
     stats = os.path.join(d, "trace", "trace_kernel_stats.csv")
     print("\n== kernel stats (rocprofv3 --kernel-trace --stats)")
     print(f"{'kernel':36s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
@@ -53,7 +59,7 @@ def main(d):
                   f"{float(row['Percentage']):6.2f}")
     # the --stats average mixes the warm-up solve (first touch of a fresh witness table) with the timed ones: per solve, from the trace
     trace = os.path.join(d, "trace", "trace_kernel_trace.csv")
-    if os.path.exists(trace):
+    if os.path.exists(trace) and "--inner" in cmd:  # (the four-solve layout below is the inner command's)
         per = defaultdict(list)
         with open(trace) as f:
             for row in csv.DictReader(f):
@@ -69,6 +75,8 @@ def main(d):
                 seg = v[i * n:(i + 1) * n]
                 cells.append(f"{sum(e - s for s, e in seg) / n / 1e3:9.2f} us x {n}")
             print(f"{k[:36]:36s} " + "   ".join(cells))
+    if not have_pmc:  # a trace-only run (the driver's command under rocprofv3): no counter sections to print
+        return
     cal_f = read_pmc(os.path.join(d, "cal_fetch", "pmc_counter_collection.csv"), "FETCH_SIZE")
     cal_w = read_pmc(os.path.join(d, "cal_write", "pmc_counter_collection.csv"), "WRITE_SIZE")
     fcorr, wcorr = 2.0, 1.0

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_debug_secp_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
     "acvm_device_release_tables", "acvm_circuit_opcode_kinds", "acvm_batch_error_expression", "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
+    "acvm_debug_cpulist", "acvm_debug_device_locality",
 ]
 
 
@@ -361,6 +362,23 @@ def selftest(n=1 << 16, seed=1):
     return _check(lib().acvm_selftest(n, seed))
 
 
+def parse_cpulist(text):
+    """a sysfs cpulist ("0-15,32-47") as the node driver reads it (host only)"""
+    buf = (C.c_uint32 * 4096)()
+    n = lib().acvm_debug_cpulist(text.encode(), buf, 4096)
+    _check(n)
+    return list(buf[:min(n, 4096)])
+
+
+def device_locality(pci_root, bus_id):
+    """(NUMA node, local CPUs) of a PCI device from a sysfs-shaped tree (host only): what a lane of the node driver pins its threads to"""
+    buf = (C.c_uint32 * 4096)()
+    node = C.c_int(-1)
+    n = lib().acvm_debug_device_locality(pci_root.encode(), bus_id.encode(), C.byref(node), buf, 4096)
+    _check(n)
+    return node.value, list(buf[:min(n, 4096)])
+
+
 def tuning_keys():
     """every planner / scheduler mode and device limit of the library (csrc/tuning.hpp)"""
     out, i = [], 0
@@ -541,7 +559,8 @@ class NodeOpts(C.Structure):
 class NodeStats(C.Structure):
     _fields_ = [("n_devices", C.c_uint32), ("tile_instances", C.c_uint32), ("n_instances", C.c_uint64), ("total_ms", C.c_double),
                 ("device", C.c_int * 16), ("async_exact", C.c_uint32 * 16), ("tiles", C.c_uint32 * 16), ("exact_instances", C.c_uint32 * 16),
-                ("lane_ms", C.c_double * 16), ("solve_device_ms", C.c_double * 16), ("h2d_wait_ms", C.c_double * 16), ("export_ms", C.c_double * 16)]
+                ("lane_ms", C.c_double * 16), ("solve_device_ms", C.c_double * 16), ("h2d_wait_ms", C.c_double * 16), ("export_ms", C.c_double * 16),
+                ("numa_node", C.c_int * 16), ("n_cpus_pinned", C.c_uint32 * 16), ("first_cpu", C.c_int * 16)]
 
 
 class Node:
@@ -596,7 +615,8 @@ class Node:
         _check(lib().acvm_node_stats(self._h, C.byref(st)))
         n = st.n_devices
         return {"n_devices": n, "tile_instances": st.tile_instances, "n_instances": st.n_instances, "total_ms": st.total_ms,
-                **{f: list(getattr(st, f))[:n] for f in ("device", "async_exact", "tiles", "exact_instances", "lane_ms", "solve_device_ms", "h2d_wait_ms", "export_ms")}}
+                **{f: list(getattr(st, f))[:n] for f in ("device", "async_exact", "tiles", "exact_instances", "lane_ms", "solve_device_ms", "h2d_wait_ms", "export_ms", "numa_node", "n_cpus_pinned",
+                                                              "first_cpu")}}
 
 
 class Batch:

@@ -14,8 +14,12 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <mutex>
+#include <pthread.h>
+#include <sched.h>
 #include <thread>
 
 namespace {
@@ -40,6 +44,63 @@ struct DeviceLane {
     uint64_t not_solved = 0;
     std::string error;
     int rc = 0;
+    // host placement: the CPUs local to the device (sysfs), empty = unknown / not pinned
+    int numa_node = -1;
+    std::vector<uint32_t> cpus;
+};
+
+// "0-15,32-47" (sysfs cpulist format) -> CPU numbers; anything malformed ends the list where it stands
+std::vector<uint32_t> parse_cpulist(const std::string &text) {
+    std::vector<uint32_t> out;
+    size_t i = 0;
+    auto number = [&](uint32_t &v) {
+        if (i >= text.size() || text[i] < '0' || text[i] > '9') return false;
+        uint64_t x = 0;
+        while (i < text.size() && text[i] >= '0' && text[i] <= '9' && x < (1u << 20)) x = x * 10 + (uint64_t)(text[i++] - '0');
+        v = (uint32_t)x;
+        return x < (1u << 20);
+    };
+    while (i < text.size()) {
+        uint32_t a, b;
+        if (!number(a)) break;
+        b = a;
+        if (i < text.size() && text[i] == '-') { i++; if (!number(b) || b < a) break; }
+        for (uint32_t c = a; c <= b && out.size() < 4096; c++) out.push_back(c);
+        if (i < text.size() && text[i] == ',') i++;
+        else break;
+    }
+    return out;
+}
+// NUMA node and local CPUs of a PCI device from sysfs (<root>/<bus id>/numa_node, local_cpulist); false if the files are not there
+bool device_locality(const std::string &pci_root, const std::string &bus_id, int *numa_node, std::vector<uint32_t> *cpus) {
+    std::string id = bus_id;
+    for (char &ch : id) ch = (char)tolower((unsigned char)ch);
+    std::ifstream fn(pci_root + "/" + id + "/numa_node"), fc(pci_root + "/" + id + "/local_cpulist");
+    if (!fn || !fc) return false;
+    int node = -1;
+    fn >> node;
+    std::string list;
+    std::getline(fc, list);
+    *numa_node = node;
+    *cpus = parse_cpulist(list);
+    return true;
+}
+// the calling thread onto the given CPUs (and with it every thread it creates from now on); silently not when the set is empty or refused
+void pin_thread(const std::vector<uint32_t> &cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (uint32_t c : cpus)
+        if (c < CPU_SETSIZE) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+// threads that are joined when the scope ends, whichever way it ends
+struct Joiner {
+    std::vector<std::thread> t;
+    ~Joiner() {
+        for (auto &x : t)
+            if (x.joinable()) x.join();
+    }
 };
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -112,11 +173,10 @@ void fill_staging(uint8_t *dst, const uint8_t *values, size_t row, uint64_t firs
     if (bytes <= 2 * PIECE) memcpy(dst, src, bytes);
     else {
         const size_t part = (bytes / 4 + 63) / 64 * 64;
-        std::thread helpers[3];
+        Joiner helpers;  // (a thread that cannot be created throws: the ones that run are joined before the exception leaves)
         for (int q = 0; q < 3; q++)
-            helpers[q] = std::thread([=] { const size_t at = (size_t)(q + 1) * part; if (at < bytes) memcpy(dst + at, src + at, std::min(part, bytes - at)); });
+            helpers.t.emplace_back([=] { const size_t at = (size_t)(q + 1) * part; if (at < bytes) memcpy(dst + at, src + at, std::min(part, bytes - at)); });
         memcpy(dst, src, std::min(part, bytes));
-        for (auto &h : helpers) h.join();
     }
 }
 
@@ -137,8 +197,8 @@ uint64_t patch_outcome(const ExactOutcome &o, uint64_t base, uint32_t n_valid, u
     return not_solved;
 }
 
-void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, const uint8_t *values, acvm_result_t *results, uint8_t *kept, uint8_t *kept_assigned,
-              uint8_t *digests) {
+void run_lane_body(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, const uint8_t *values, acvm_result_t *results, uint8_t *kept, uint8_t *kept_assigned,
+                   uint8_t *digests) {
     const double t_begin = now_ms();
     L.rc = 0;
     L.error.clear();
@@ -161,14 +221,16 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
     int producer_rc = 0;
     std::string producer_err;
     std::thread producer([&] {
-        auto give_up = [&](const char *what, hipError_t e) {
+        auto give_up_rc = [&](int rc, const std::string &what) {
             {
                 std::lock_guard<std::mutex> lk(mu);
-                producer_rc = ACVM_E_DEVICE;
-                producer_err = std::string(what) + ": " + hipGetErrorString(e);
+                producer_rc = rc;
+                producer_err = what;
             }
             cv.notify_all();
         };
+        auto give_up = [&](const char *what, hipError_t e) { give_up_rc(ACVM_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+        try {  // nothing unwinds out of a thread (std::terminate) nor through the ABI: an allocation failure ends the lane with ACVM_E_NOMEM
         if (hipError_t e = hipSetDevice(L.device); e != hipSuccess) { give_up("hipSetDevice (upload thread)", e); return; }  // HIP's current device is per thread
         for (uint32_t k = 0; k < n_tiles; k++) {
             {
@@ -193,6 +255,11 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
             }
             cv.notify_all();
         }
+        } catch (const std::bad_alloc &) {
+            give_up_rc(ACVM_E_NOMEM, "out of host memory in the upload thread");
+        } catch (const std::exception &e) {
+            give_up_rc(ACVM_E_INVALID, std::string("upload thread: ") + e.what());
+        }
     });
     auto stop_producer = [&] {
         {
@@ -202,6 +269,7 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         cv.notify_all();
         producer.join();
     };
+    try {  // (an exception of the solver side -- std::bad_alloc of its bookkeeping vectors -- must not skip the join of the producer below)
     // ---- solver
     uint64_t prev_base = 0;
     uint32_t prev_valid = 0;
@@ -293,6 +361,11 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         if (int rc = batch_finish_pending(L.batch, &o)) fail(rc, "exact path");
         else L.not_solved += patch_outcome(o, prev_base, prev_valid, n_keep, results, kept, kept_assigned, digests);
     }
+    } catch (const std::bad_alloc &) {
+        if (!L.rc) { L.rc = ACVM_E_NOMEM; L.error = "out of host memory in the lane's solver thread"; }
+    } catch (const std::exception &e) {
+        if (!L.rc) { L.rc = ACVM_E_INVALID; L.error = std::string("lane: ") + e.what(); }
+    }
     stop_producer();
     hipStreamSynchronize(L.copy);
     hipStreamSynchronize(L.out);
@@ -302,6 +375,22 @@ void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, con
         acvm_device_synchronize();  // (an import enqueued for a tile that was never solved)
     }
     L.total_ms = now_ms() - t_begin;
+}
+
+// a lane's thread: pinned to the CPUs of its device's NUMA node (its upload thread and the staging helpers inherit the mask), and closed
+// against exceptions: std::terminate is not an error code
+void run_lane(acvm_node *node, DeviceLane &L, uint64_t first, uint64_t last, const uint8_t *values, acvm_result_t *results, uint8_t *kept, uint8_t *kept_assigned,
+              uint8_t *digests) {
+    try {
+        pin_thread(L.cpus);
+        run_lane_body(node, L, first, last, values, results, kept, kept_assigned, digests);
+    } catch (const std::bad_alloc &) {
+        if (!L.rc) { L.rc = ACVM_E_NOMEM; L.error = "out of host memory"; }
+    } catch (const std::exception &e) {
+        if (!L.rc) { L.rc = ACVM_E_INVALID; L.error = e.what(); }
+    } catch (...) {
+        if (!L.rc) { L.rc = ACVM_E_INVALID; L.error = "unknown exception"; }
+    }
 }
 
 }  // namespace
@@ -342,6 +431,12 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
             DeviceLane &L = node->lanes[i];
             auto fail = [&](int rc, const std::string &what) { L.rc = rc; L.error = what + ": " + acvm_last_error(); };
             if (hipSetDevice(L.device) != hipSuccess) { L.rc = ACVM_E_DEVICE; L.error = "hipSetDevice failed"; return; }
+            {   // where the device hangs: its NUMA node and the CPUs next to it (pinned staging is allocated and filled from there)
+                char bus[32] = {0};
+                if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, L.device) == hipSuccess) device_locality("/sys/bus/pci/devices", bus, &L.numa_node, &L.cpus);
+                else (void)hipGetLastError();
+                pin_thread(L.cpus);  // (this thread allocates the lane's pinned buffers: first touch on the device's node)
+            }
             L.batch = acvm_batch_new_ex(c, solver, node->tile, node->ids.data(), n_initial, node->flags, node->keep.data(), n_keep);
             if (!L.batch) { fail(ACVM_E_DEVICE, "acvm_batch_new_ex"); return; }
             const int a = batch_enable_async_exact(L.batch, node->keep.data(), n_keep, true);
@@ -413,8 +508,26 @@ int acvm_node_stats(acvm_node_t *n, acvm_node_stats_t *out) {
         out->solve_device_ms[d] = L.device_ms;
         out->h2d_wait_ms[d] = L.h2d_wait_ms;
         out->export_ms[d] = L.export_ms;
+        out->numa_node[d] = L.numa_node;
+        out->n_cpus_pinned[d] = (uint32_t)L.cpus.size();
+        out->first_cpu[d] = L.cpus.empty() ? -1 : (int)L.cpus.front();
     }
     return 0;
 }
+
+// host-only probes of the placement logic (tests/test_sharding.py: no GPU, a made-up sysfs tree)
+int acvm_debug_cpulist(const char *text, uint32_t *cpus, uint32_t cap) try {
+    if (!text || (cap && !cpus)) return set_err(ACVM_E_INVALID, "null argument");
+    const std::vector<uint32_t> v = parse_cpulist(text);
+    for (size_t i = 0; i < v.size() && i < cap; i++) cpus[i] = v[i];
+    return (int)v.size();
+} ABI_CATCH
+int acvm_debug_device_locality(const char *pci_root, const char *bus_id, int *numa_node, uint32_t *cpus, uint32_t cap) try {
+    if (!pci_root || !bus_id || !numa_node || (cap && !cpus)) return set_err(ACVM_E_INVALID, "null argument");
+    std::vector<uint32_t> v;
+    if (!device_locality(pci_root, bus_id, numa_node, &v)) return set_err(ACVM_E_STATE, "no numa_node / local_cpulist for this device");
+    for (size_t i = 0; i < v.size() && i < cap; i++) cpus[i] = v[i];
+    return (int)v.size();
+} ABI_CATCH
 
 }  // extern "C"

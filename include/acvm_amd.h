@@ -499,6 +499,11 @@ typedef struct {
     double solve_device_ms[16]; /* HIP-event time of its solves */
     double h2d_wait_ms[16];     /* what of the uploads the solves did not cover */
     double export_ms[16];       /* results, kept witnesses and digests leaving the device */
+    /* host placement (ABI 5): the device's NUMA node (/sys/bus/pci/devices/<bus id>/numa_node, -1 unknown) and the CPUs its lane's two host
+     * threads are pinned to (local_cpulist: how many, and the first one; 0 / -1 = not pinned) */
+    int numa_node[16];
+    uint32_t n_cpus_pinned[16];
+    int first_cpu[16];
 } acvm_node_stats_t;
 acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, const uint32_t *initial_ids, uint32_t n_initial,
                            const uint32_t *keep_ids, uint32_t n_keep, const acvm_node_opts_t *opts);
@@ -508,6 +513,10 @@ uint32_t acvm_node_num_devices(const acvm_node_t *n);
 long long acvm_node_solve(acvm_node_t *n, uint64_t n_instances, const uint8_t *values_be32, acvm_result_t *results, uint8_t *kept_be32,
                           uint8_t *kept_assigned, uint8_t *digests32);
 int acvm_node_stats(acvm_node_t *n, acvm_node_stats_t *out);
+/* host-only probes of the lanes' placement logic: a sysfs cpulist ("0-15,32-47") into CPU numbers (returns how many; the first `cap` are
+ * written), and the NUMA node + local CPUs of PCI device `bus_id` under `pci_root` (normally /sys/bus/pci/devices) */
+int acvm_debug_cpulist(const char *text, uint32_t *cpus, uint32_t cap);
+int acvm_debug_device_locality(const char *pci_root, const char *bus_id, int *numa_node, uint32_t *cpus, uint32_t cap);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -38,3 +40,25 @@ def test_digest_of_digests_is_independent_of_the_sharding():
     d2 = d.copy()
     d2[-1, 0] ^= 1
     assert shard.digest_of_digests(shard.chunk_digests(d2)) != whole
+
+
+def test_node_lane_placement_reads_sysfs(tmp_path):
+    """acvm_node_* pins a lane's two host threads to the CPUs next to its device (csrc/node.cpp: /sys/bus/pci/devices/<bus id>/numa_node and
+    local_cpulist); the parsing runs here on a made-up tree, no GPU. A missing or malformed entry means "not pinned", never an error of the solve."""
+    import acvm_amd
+    assert acvm_amd.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    assert acvm_amd.parse_cpulist("5") == [5] and acvm_amd.parse_cpulist("") == [] and acvm_amd.parse_cpulist("\n") == []
+    assert acvm_amd.parse_cpulist("0-1,x") == [0, 1] and acvm_amd.parse_cpulist("7-3") == []   # malformed: the list ends where it stands
+    dev = tmp_path / "0000:c1:00.0"
+    dev.mkdir()
+    (dev / "numa_node").write_text("1\n")
+    (dev / "local_cpulist").write_text("32-63,96-127\n")
+    node, cpus = acvm_amd.device_locality(str(tmp_path), "0000:C1:00.0")   # (hipDeviceGetPCIBusId prints the bus id in upper or lower case)
+    assert node == 1 and cpus == list(range(32, 64)) + list(range(96, 128))
+    other = tmp_path / "0000:05:00.0"
+    other.mkdir()
+    (other / "numa_node").write_text("-1\n")
+    (other / "local_cpulist").write_text("\n")
+    assert acvm_amd.device_locality(str(tmp_path), "0000:05:00.0") == (-1, [])
+    with pytest.raises(acvm_amd.AcvmError):
+        acvm_amd.device_locality(str(tmp_path), "0000:ff:00.0")

@@ -288,24 +288,50 @@ def timed_one_core(ob, oc, ids, values, row, n0, n_max, mode, target_s=1.2):
     return n, sorted(runs)[1]
 
 
+def cpu_budget():
+    """(CPUs this process may actually use, the cgroup's CPU quota or None, os.cpu_count()): os.cpu_count() is the HOST's (256 on the GPU box of
+    this pool) while the container's cgroup grants a quota (cpu.max "1600000 100000" = 16 CPUs there) -- threads beyond the quota are only
+    throttled, which is what made 64 threads look like 13 x one thread in round 4's line"""
+    host = os.cpu_count() or 1
+    try:
+        host = min(host, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = host if quota is None else max(1, min(host, int(quota + 0.5)))
+    return usable, quota, os.cpu_count() or 1
+
+
 def cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_digests):
     """The CPU oracle (a port of the reference's in-order solver, oracle/) on a bounded sample of tile 0: the parity check of the run
     (results, assigned sets, every witness, digests) and the cpu_baseline of the line -- median of three timed runs per variant.
     Rank 0 runs it for every world size (after the timed region and the last barrier: the other ranks are done), on ALL host cores."""
     import numpy as np
     from oracle import binding as ob
-    cores = os.cpu_count() or 1
+    cores, quota, host_cores = cpu_budget()
     per = {"arith": 96, "hash": 1024, "grumpkin": 256, "ecdsa": 64, "arith_pedersen": 48, "mixed": 32, "config5": 1}[args.workload]  # about a second of all host cores
     sh.load_tile(0)
     batch.solve()
     results0 = batch.results()
     oc = ob.Circuit(data)
-    # every host core is offered to the oracle; the thread count reported is the one that solves fastest (os.cpu_count() counts SMT siblings, and
-    # 256 threads measured slower than 64 on the GPU box of round 4): all, half and a quarter of them on a short sample each, then the timed runs
+    # every CPU the process may use (the cgroup's quota, not the host's count) is offered to the oracle; the thread count reported is the one that
+    # solves fastest: twice the budget (SMT, throttling slack), the budget and half of it on a short sample each, then the timed runs
     threads, tried = cores, {}
     if args.workload != "config5" and cores >= 8:
         probe = min(tile, max(64, per * cores // 8))
-        for t in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+        for t in sorted({min(2 * cores, host_cores), cores, max(1, cores // 2)}, reverse=True):
             c0 = time.perf_counter()
             ob.solve_batch(oc, ids, values[: probe * row], probe, want_witness=False, n_threads=t, mode=ob.MODE_CACHE_INV)
             tried[t] = round(probe / (time.perf_counter() - c0), 1)
@@ -331,10 +357,11 @@ def cpu_baseline_and_parity(args, data, ids, values, batch, sh, tile, row, inst_
         if n_dig:  # the digests that feed the digest of digests, against hashlib over the oracle's maps
             ok = ok and all(bytes(inst_digests[j]) == ob.witness_map_digest(oasg[j], ovals[j]) for j in range(n_dig))
     parity = {"checked_instances": sample, "bit_exact": bool(ok), "digests_checked": n_dig}
-    cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": threads, "host_cores": cores, "kind": "port", "variant": "cpu_ref_dense_mt",
-           "runs_s": [round(x, 3) for x in runs], "threads_tried_witnesses_per_s": tried,
-           "sample": f"{sample} instances of the same circuit, oracle/ (gcc -O3 -march=native; dense witness vector, constant divisors inverted once), "
-                     f"{threads} threads (the fastest of all / half / a quarter of the host's os.cpu_count() = {cores}), median of {len(runs)} runs: {cpu_s:.2f} s"}
+    cpu = {"value": sample / cpu_s, "unit": "witnesses/s", "cores": min(threads, cores), "threads": threads, "host_cores": host_cores, "cgroup_cpu_quota": quota,
+           "kind": "port", "variant": "cpu_ref_dense_mt", "runs_s": [round(x, 3) for x in runs], "threads_tried_witnesses_per_s": tried,
+           "sample": f"{sample} instances of the same circuit, oracle/ (gcc -O3 -march=native; dense witness vector, constant divisors inverted once, one solver "
+                     f"object per thread), {threads} threads on the {cores} CPUs this process may use (cgroup quota {quota}, host os.cpu_count() = {host_cores}; the fastest "
+                     f"of twice / once / half that many threads), median of {len(runs)} runs: {cpu_s:.2f} s"}
     if args.workload != "config5":  # the two single-core variants, at least about a second per run, median of three
         n_max = min(tile, len(values) // row)
         one, one_s = timed_one_core(ob, oc, ids, values, row, int(round(1.2 * sample / (cpu_s * threads))), n_max, ob.MODE_CACHE_INV)
@@ -440,6 +467,82 @@ def run_leg(name, total_log2=16, tile_log2=16, steps=3, warmup=2, pmc=True):
            "levels": st["n_levels"], "launches": st["n_kernel_launches"], "roofline": roof, "alu_roofline": alu,
            "cpu_baseline": {k: cpu[k] for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}, "parity": parity}
     return out
+
+
+def run_config5_leg(tile_log2=12, timed_tiles=2, audit=8):
+    """BASELINE config 5 at circuit size as a leg of the default run: the 10^6-opcode mixed circuit (SURVEY 8d generator), ONE handle with
+    witness-slot liveness reuse and the digest folded into the solve, `timed_tiles` tiles of 2^tile_log2 fresh instances (a step = ACVM::new of the
+    tile from host memory + solve + the tile's per-instance digests), an audit sample of the first timed tile re-solved by the CPU oracle
+    (results, return witnesses, map digests bit for bit), the kernel classes' HIP-event times of the last tile against their algorithmic bytes."""
+    import acvm_amd
+    from acvm_amd import synth
+    from oracle import binding as ob
+    tile = 1 << tile_log2
+    t0 = time.perf_counter()
+    circ, ids = synth.mixed_circuit(1_000_000)
+    data = circ.to_bytes()
+    t1 = time.perf_counter()
+    gc = acvm_amd.Circuit(data)
+    ret = gc.witness_set("return_values")
+    batch = acvm_amd.Batch(gc, tile, ids, reuse_slots=True, keep=ret)  # (slot reuse folds the digest)
+    t2 = time.perf_counter()
+    row = len(ids) * 32
+    tiles = [synth.witness_batch(tile, seed=0xAC1D0005, first_instance=k * tile) for k in range(timed_tiles + 1)]
+    batch.set_initial_witness(tiles[0])  # warm-up tile: tables built, clocks up, the exact path's side table allocated (its edge-case instances)
+    batch.solve()
+    batch.digest()
+    acvm_amd.synchronize()
+    step_ms, not_solved, first = [], 0, None
+    for k in range(1, timed_tiles + 1):
+        batch.set_profiling(k == timed_tiles)
+        w0 = time.perf_counter()
+        batch.set_initial_witness(tiles[k])
+        not_solved += batch.solve()
+        dig = batch.digest()
+        step_ms.append((time.perf_counter() - w0) * 1e3)
+        if k == 1:
+            first = (batch.results(), dig, [batch.extract(ret, j, 1)[0] for j in range(0, tile, max(tile // audit, 1))][:audit])
+    st = batch.stats()
+    batch.set_profiling(False)
+    # ---- audit of the first timed tile (instances tile .. 2 tile - 1 of the synthetic batch: no edge cases among them)
+    picks = list(range(0, tile, max(tile // audit, 1)))[:audit]
+    sub = b"".join(tiles[1][j * row:(j + 1) * row] for j in picks)
+    threads = min(len(picks), cpu_budget()[0])
+    a0 = time.perf_counter()
+    ores, oasg, ovals = ob.solve_batch(ob.Circuit(data), ids, sub, len(picks), n_threads=threads)
+    oracle_s = time.perf_counter() - a0
+    res, dig1, kept = first
+    ok = True
+    for i, j in enumerate(picks):
+        ok &= res[j].as_tuple() == ores[i].as_tuple()
+        ok &= bytes(dig1[j]) == ob.witness_map_digest(oasg[i], ovals[i])
+        if ores[i].status == 0 and ret:
+            ok &= all(bytes(kept[i][n]) == bytes(ovals[i][w]) for n, w in enumerate(ret))
+    batch.free()
+    ms = sum(step_ms) / len(step_ms)
+    cls_names = ["light (range / logic / directives / memory / inlined Brillig)", "hashes", "Grumpkin + Pedersen + ECDSA", "Brillig VM"]
+    classes = {"arith_level_kernel": {"ms_last_tile": st["arith_kernel_ms"], "algorithmic_bytes_per_tile": st["arith_algorithmic_bytes_per_instance"] * tile},
+               "inverse_batch_kernel": {"ms_last_tile": st["dyn_kernel_ms"], "algorithmic_bytes_per_tile": st["dyn_algorithmic_bytes_per_instance"] * tile}}
+    for k in range(4):
+        classes[cls_names[k]] = {"ms_last_tile": st["class_kernel_ms"][k], "algorithmic_bytes_per_tile": st["class_algorithmic_bytes_per_instance"][k] * tile}
+    for c in classes.values():  # (the classes run side by side on their own streams: the sum of their times exceeds the step)
+        c["achieved_GBps"] = c["algorithmic_bytes_per_tile"] / (c["ms_last_tile"] / 1e3) / 1e9 if c["ms_last_tile"] > 0 else None
+        c["frac_of_hbm_peak"] = None if c["achieved_GBps"] is None else c["achieved_GBps"] / HBM_PEAK_GBS
+    achieved = st["algorithmic_bytes_per_instance"] * tile / (ms / 1e3) / 1e9
+    return {"workload": "10^6-opcode mixed ACIR (config 5: 94 % arithmetic, range / logic, directives, memory, Brillig, hashes, Pedersen), "
+                        f"tiles of {tile} instances through one handle, witness-slot reuse, digest folded into the solve",
+            "value": tile / (ms / 1e3), "unit": "witnesses/s", "instances": tile * timed_tiles, "tile_instances": tile, "steps": timed_tiles, "ms_per_step": ms,
+            "step": "per tile: ACVM::new from host memory + solve + per-instance map digests", "ms_of_each_step": step_ms,
+            "solve_device_ms_last_step": st["solve_device_ms"], "not_solved": not_solved, "opcodes": st["n_opcodes"], "witnesses_per_instance": st["n_witnesses"],
+            "table_rows": st["n_table_rows"], "levels": st["n_levels"], "launches": st["n_kernel_launches"], "brillig_opcodes_inlined": st["n_brillig_inlined"],
+            "generate_s": round(t1 - t0, 1), "parse_plan_alloc_s": round(t2 - t1, 1), "plan_ms": st["plan_ms"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "the whole step (every class of the level schedule; they overlap)", "algorithmic_bytes_per_tile": st["algorithmic_bytes_per_instance"] * tile,
+                         "classes": classes},
+            "alu_roofline": None,
+            "cpu_baseline": {"value": len(picks) / oracle_s, "unit": "witnesses/s", "cores": threads, "host_cores": os.cpu_count(), "cgroup_cpu_quota": cpu_budget()[1], "kind": "port",
+                             "sample": f"the {len(picks)} audit instances, one oracle thread each, one run of {oracle_s:.1f} s (a 10^6-opcode instance is ~1.4 s of one core)"},
+            "parity": {"bit_exact": bool(ok), "instances": picks, "of_tile": 1, "checked": "result records, return witnesses, map digests (hashlib over the oracle's full map)"}}
 
 
 def leg_summary(leg):
@@ -653,6 +756,10 @@ def main():
                 legs[name] = run_leg(name, **kw)
             except (acvm_amd.AcvmError, OSError, ValueError) as e:  # a leg must not void the metric's line
                 legs[name] = {"error": str(e)[:300]}
+        try:  # BASELINE config 5 at circuit size: 10^6 opcodes, tiles of 4 096 with slot reuse, 8-instance oracle audit (~40 s of the run)
+            legs["config5"] = run_config5_leg()
+        except (acvm_amd.AcvmError, OSError, ValueError, MemoryError) as e:
+            legs["config5"] = {"error": str(e)[:300]}
     line = {
         "metric": "witnesses solved/sec (whole node)",
         "value": value,

@@ -33,6 +33,7 @@ int stage_reserve(acvm_batch *b, size_t bytes) {
 void clear_fc_store(acvm_batch *b) {
     for (auto &sl : b->fc_slots)
         if (!sl.inst.empty()) { sl.inst.clear(); sl.dirty = true; }
+    b->fc_fail_msg.clear();
 }
 
 const char *acvm_last_error(void) { return g_last_error.c_str(); }
@@ -412,7 +413,6 @@ acvm_batch_t *acvm_batch_new_ex(const acvm_circuit_t *c, const acvm_bb_solver_t 
                                 uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids, uint32_t n_keep) try {
     if (!c || (n_initial && !initial_ids) || (n_keep && !keep_ids)) { set_err(ACVM_E_INVALID, "null argument"); return nullptr; }
     if (flags & ~(uint32_t)(ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) { set_err(ACVM_E_INVALID, "unknown batch flag"); return nullptr; }
-    if ((flags & ACVM_BATCH_REUSE_SLOTS) && solver) { set_err(ACVM_E_UNSUPPORTED, "slot reuse with a caller-supplied BlackBoxFunctionSolver"); return nullptr; }
     if (solver && (!solver->schnorr_verify || !solver->pedersen || !solver->fixed_base_scalar_mul)) {
         set_err(ACVM_E_INVALID, "acvm_bb_solver_t with a null function pointer");
         return nullptr;

@@ -130,8 +130,11 @@ struct acvm_batch {
     bool has_solver = false;
     acvm_bb_solver_t solver{};
     std::map<uint32_t, std::string> host_bb_msg;  // per instance: error text of a failing callback
+    std::map<uint32_t, std::string> fc_fail_msg;  // per instance: the same for a callback made from inside a Brillig program (kept across the re-solves of one input set)
     // Brillig foreign-call round trip (exact lanes only)
-    struct FcValue { bool is_array; std::vector<FrH> vals; };
+    // (fail != 0: not a value but the outcome of a failing INTERNAL call -- the caller's BlackBoxFunctionSolver inside a Brillig program --
+    // 1 Failed, 2 Unsupported, 3 panic: the only element of its result; the VM fails there with the text kept in fc_fail_msg)
+    struct FcValue { bool is_array; std::vector<FrH> vals; uint32_t fail = 0; };
     struct FcLaneState { bool resolved_new = false; };
     std::vector<FcLaneState> fc_lane;  // per exact lane: the host answered its pending call since the last solve
     // results the host resolved, per Brillig opcode with a ForeignCall (plan.fc_slot_opcode) and per INSTANCE: they accumulate like

@@ -84,6 +84,10 @@ int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
             uint32_t w = 0, vi = 0;
             desc[(size_t)(w++) * b->Bp + j] = (uint32_t)kv.second.size();
             for (auto &res : kv.second) {
+                if (!res.empty() && res[0].fail) {  // a failing internal call: a marker instead of a value count, nothing follows
+                    desc[(size_t)(w++) * b->Bp + j] = 0xFFFFFFF0u + std::min<uint32_t>(res[0].fail, 3u);
+                    continue;
+                }
                 desc[(size_t)(w++) * b->Bp + j] = (uint32_t)res.size();
                 for (auto &v : res) {
                     desc[(size_t)(w++) * b->Bp + j] = v.is_array ? 1u : 0u;
@@ -149,7 +153,10 @@ int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_t n_slo
     const acvm_bb_solver_t &sv = b->solver;
     for (uint32_t first = 0; first < n_total; first += chunk) {
         const uint32_t m = std::min(chunk, n_total - first);
-        launch_hostbb_gather(s, b->d_W, b->Bp, exact ? b->d_slow_ids : nullptr, first, m, d_sel, n_sel, d_in);
+        // (the exact lanes live in the side table under witness-slot reuse -- rows = witness indices, lane t = the t-th flagged instance --
+        // the level schedule's instances in the level table, whose rows slot_of maps)
+        if (exact) launch_hostbb_gather(s, b->xW(), b->xBp(), b->xids(), first, m, d_sel, n_sel, d_in);
+        else launch_hostbb_gather(s, b->d_W, b->Bp, nullptr, first, m, d_sel, n_sel, d_in, b->dp.slot_of);
         if (n_sel) HIPCHK(hipMemcpyAsync(in.data(), d_in, (size_t)m * n_sel * 32, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         std::fill(vals.begin(), vals.end(), 0);
@@ -222,8 +229,8 @@ int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_t n_slo
         }
         HIPCHK(hipMemcpyAsync(d_rc, rc.data(), m, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(d_vals, vals.data(), (size_t)m * out_row, hipMemcpyHostToDevice, s));
-        if (exact) launch_hostbb_apply_exact(s, b->d_W, b->Bp, L, first, m, opcode, func, d_outs, n_out, d_active, d_rc, d_vals);
-        else launch_hostbb_apply_level(s, b->d_W, b->Bp, first, m, opcode, func, d_outs, n_out, d_rc, d_vals, b->d_event);
+        if (exact) launch_hostbb_apply_exact(s, b->xW(), b->xBp(), L, first, m, opcode, func, d_outs, n_out, d_active, d_rc, d_vals);
+        else launch_hostbb_apply_level(s, b->d_W, b->Bp, first, m, opcode, func, d_outs, n_out, d_rc, d_vals, b->d_event, b->dp.slot_of);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -526,7 +533,16 @@ int acvm_batch_solve_opcode(acvm_batch_t *b) try {
     if (b->solved && !b->stepping) return set_err(ACVM_E_STATE, "acvm_batch_solve_opcode after acvm_batch_solve: reset the batch first");
     if (b->reuse()) return set_err(ACVM_E_UNSUPPORTED, "stepping needs the full witness table: not with ACVM_BATCH_REUSE_SLOTS");
     HIPCHK(hipSetDevice(b->device));
-    return solve_stepping(b, true);
+    int rc = solve_stepping(b, true);
+    // a Brillig opcode that stopped at an internal black-box call (the caller's solver, resolve_internal_calls) finishes inside THIS step: its
+    // lanes are answered and the step runs once more -- the smallest instruction pointer among the InProgress lanes is then theirs
+    while (rc >= 0) {
+        const int answered = resolve_internal_calls(b);
+        if (answered < 0) return answered;
+        if (!answered) break;
+        rc = solve_stepping(b, true);
+    }
+    return rc;
 } ABI_CATCH
 
 // per-launch HIP-event pairs of one solve (profiling on)
@@ -775,6 +791,136 @@ int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, u
     }
     return 0;
 } ABI_CATCH
+
+// ---- the caller's BlackBoxFunctionSolver inside Brillig programs (brillig_vm/src/lib.rs:61,81,298; black_box.rs:139-163). plan.cpp turned
+// BlackBoxOp::{SchnorrVerify, Pedersen, FixedBaseScalarMul} into internal foreign calls; the lanes that stopped at one are answered here:
+// all waiting instances are read in ONE pass over the pending-call buffers, grouped by call shape, handed to the solver (one *_batch call
+// per group when the vtable has the member, the single-instance callback otherwise) and their results appended to the result store like a
+// resolved oracle call. A callback that does not return Ok leaves a failure marker: the re-run VM fails (or panics) at the op with the
+// solver's text. Returns the number of lanes answered (the caller re-solves when it is not 0), or a negative error.
+int resolve_internal_calls(acvm_batch *b) {
+    if (!b->has_solver || !b->plan.has_foreign_calls || !b->solved) return 0;
+    const Plan &p = b->plan;
+    const uint32_t n_slow = (uint32_t)b->slow_ids.size();
+    struct Waiting { uint32_t t, kind; size_t slot; };
+    std::vector<Waiting> lanes;
+    for (uint32_t t = 0; t < n_slow && t < b->fc_lane.size(); t++) {
+        const SlowResult &sr = b->slow_res[t];
+        if (sr.status != ACVM_STATUS_REQUIRES_FOREIGN_CALL || b->fc_lane[t].resolved_new) continue;
+        auto it = p.fc_function.find(((uint64_t)sr.opcode_index << 32) | sr.x0);
+        if (it == p.fc_function.end() || it->second.compare(0, strlen(PLAN_FC_INTERNAL_PREFIX), PLAN_FC_INTERNAL_PREFIX) != 0) continue;
+        const uint32_t kind = it->second == PLAN_FC_INTERNAL_SCHNORR ? 6u : it->second == PLAN_FC_INTERNAL_PEDERSEN ? 7u : 8u;
+        const size_t si = (size_t)(std::find(p.fc_slot_opcode.begin(), p.fc_slot_opcode.end(), sr.opcode_index) - p.fc_slot_opcode.begin());
+        if (si >= b->fc_slots.size()) return set_err(ACVM_E_STATE, "internal black-box call without a result slot");
+        lanes.push_back({t, kind, si});
+    }
+    if (lanes.empty()) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    if (int rc = fetch_pending(b)) return rc;
+    const acvm_bb_solver_t &sv = b->solver;
+    static constexpr size_t ERR_STRIDE = 200;
+    // canonical big-endian bytes of value number vi of lane t
+    auto value_be = [&](uint32_t t, uint32_t vi, uint8_t *out) {
+        FrH m;
+        memcpy(&m.l[0], &b->h_pend_vals[((size_t)(2 * vi) * n_slow + t) * 4], 16);
+        memcpy(&m.l[2], &b->h_pend_vals[((size_t)(2 * vi + 1) * n_slow + t) * 4], 16);
+        uint64_t can[4];
+        frh::to_canonical(frh::from_device_form(m), can);
+        for (int k = 0; k < 32; k++) out[31 - k] = (uint8_t)(can[k / 8] >> (8 * (k % 8)));
+    };
+    auto input_len = [&](uint32_t t, uint32_t i) { return b->h_pend_desc[(size_t)(1 + i) * n_slow + t]; };
+    struct Outcome { int rc = 0; uint8_t out[64] = {0}; std::string err; };
+    std::vector<Outcome> outcome(lanes.size());
+    // groups of one call shape: kind + the sizes the batched members take as one number (+ Pedersen's domain separator)
+    std::map<std::vector<uint64_t>, std::vector<size_t>> groups;
+    for (size_t q = 0; q < lanes.size(); q++) {
+        const uint32_t t = lanes[q].t, kind = lanes[q].kind;
+        std::vector<uint64_t> key = {kind};
+        if (kind == 6) { key.push_back(input_len(t, 2)); key.push_back(input_len(t, 3)); }  // message, signature
+        else if (kind == 7) {
+            const uint32_t n = input_len(t, 0);
+            uint8_t dom[32];
+            value_be(t, n, dom);
+            bool fits = true;  // registers.get(domain_separator).to_u128().try_into::<u32>() (black_box.rs:152-158)
+            for (int k = 0; k < 28; k++) fits &= dom[k] == 0;
+            if (!fits) { outcome[q].rc = 1; outcome[q].err = "Invalid signature length"; continue; }
+            key.push_back(n);
+            key.push_back((uint64_t)dom[28] << 24 | (uint64_t)dom[29] << 16 | (uint64_t)dom[30] << 8 | dom[31]);
+        }
+        groups[key].push_back(q);
+    }
+    for (auto &g : groups) {
+        const uint32_t kind = (uint32_t)g.first[0];
+        const size_t n = g.second.size();
+        std::vector<uint8_t> brc(n, 0), bout(n * 64, 0);
+        std::vector<char> berr(n * ERR_STRIDE, 0);
+        int call_rc = 0;
+        bool batched = false;
+        if (kind == 8) {  // FixedBaseScalarMul: inputs [low, high]
+            std::vector<uint8_t> lh(n * 64);
+            for (size_t i = 0; i < n; i++) { value_be(lanes[g.second[i]].t, 0, &lh[i * 64]); value_be(lanes[g.second[i]].t, 1, &lh[i * 64 + 32]); }
+            if ((batched = sv.fixed_base_scalar_mul_batch != nullptr)) call_rc = sv.fixed_base_scalar_mul_batch(sv.ctx, n, lh.data(), bout.data(), brc.data(), berr.data(), ERR_STRIDE);
+            else
+                for (size_t i = 0; i < n; i++) brc[i] = (uint8_t)std::min(std::max(sv.fixed_base_scalar_mul(sv.ctx, &lh[i * 64], &lh[i * 64 + 32], &bout[i * 64], &bout[i * 64 + 32], &berr[i * ERR_STRIDE], ERR_STRIDE), 0), 255);
+        } else if (kind == 7) {  // Pedersen: inputs [vector of k field elements, domain separator]
+            const size_t k = (size_t)g.first[1];
+            const uint32_t dom = (uint32_t)g.first[2];
+            std::vector<uint8_t> pin(n * std::max<size_t>(k, 1) * 32);
+            for (size_t i = 0; i < n; i++)
+                for (size_t c = 0; c < k; c++) value_be(lanes[g.second[i]].t, (uint32_t)c, &pin[(i * k + c) * 32]);
+            if ((batched = sv.pedersen_batch != nullptr)) call_rc = sv.pedersen_batch(sv.ctx, n, pin.data(), k, dom, bout.data(), brc.data(), berr.data(), ERR_STRIDE);
+            else
+                for (size_t i = 0; i < n; i++) brc[i] = (uint8_t)std::min(std::max(sv.pedersen(sv.ctx, &pin[i * k * 32], k, dom, &bout[i * 64], &bout[i * 64 + 32], &berr[i * ERR_STRIDE], ERR_STRIDE), 0), 255);
+        } else {  // SchnorrVerify: inputs [pk x, pk y, message bytes, signature bytes]; to_u8_vec keeps the last byte of every value (black_box.rs:27-36)
+            const uint32_t n_msg = (uint32_t)g.first[1], n_sig = (uint32_t)g.first[2];
+            std::vector<uint8_t> pk(n * 64), sig(n * std::max<uint32_t>(n_sig, 1)), msg(n * std::max<uint32_t>(n_msg, 1)), ok(n, 0);
+            uint8_t tmp[32];
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t t = lanes[g.second[i]].t;
+                value_be(t, 0, &pk[i * 64]);
+                value_be(t, 1, &pk[i * 64 + 32]);
+                for (uint32_t c = 0; c < n_msg; c++) { value_be(t, 2 + c, tmp); msg[i * n_msg + c] = tmp[31]; }
+                for (uint32_t c = 0; c < n_sig; c++) { value_be(t, 2 + n_msg + c, tmp); sig[i * n_sig + c] = tmp[31]; }
+            }
+            if ((batched = sv.schnorr_verify_batch != nullptr)) call_rc = sv.schnorr_verify_batch(sv.ctx, n, pk.data(), sig.data(), n_sig, msg.data(), n_msg, ok.data(), brc.data(), berr.data(), ERR_STRIDE);
+            else
+                for (size_t i = 0; i < n; i++) brc[i] = (uint8_t)std::min(std::max(sv.schnorr_verify(sv.ctx, &pk[i * 64], &pk[i * 64 + 32], &sig[i * n_sig], n_sig, &msg[i * n_msg], n_msg, &ok[i], &berr[i * ERR_STRIDE], ERR_STRIDE), 0), 255);
+            for (size_t i = 0; i < n; i++) bout[i * 64 + 31] = ok[i] ? 1 : 0;
+        }
+        for (size_t i = 0; i < n; i++) {
+            Outcome &o = outcome[g.second[i]];
+            o.rc = batched && call_rc != 0 ? 3 : brc[i];
+            memcpy(o.out, &bout[i * 64], 64);
+            berr[i * ERR_STRIDE + ERR_STRIDE - 1] = 0;
+            o.err = batched && call_rc != 0 ? "batched BlackBoxFunctionSolver call failed" : &berr[i * ERR_STRIDE];
+        }
+    }
+    static const char *names[3] = {"schnorr_verify", "pedersen", "fixed_base_scalar_mul"};
+    for (size_t q = 0; q < lanes.size(); q++) {
+        const Waiting &w = lanes[q];
+        const Outcome &o = outcome[q];
+        const uint32_t instance = b->slow_ids[w.t];
+        std::vector<acvm_batch::FcValue> res(1);
+        if (o.rc != 0) {
+            res[0].is_array = false;
+            res[0].fail = o.rc == 1 ? 1u : o.rc == 2 ? 2u : 3u;
+            // the Display strings of BlackBoxResolutionError (blackbox_solver/src/lib.rs:15-21), a panicking solver's own text
+            const char *fn = names[w.kind - 6];
+            b->fc_fail_msg[instance] = o.rc == 1 ? std::string("failed to solve blackbox function: ") + fn + ", reason: " + o.err
+                                       : o.rc == 2 ? std::string("unsupported blackbox function: ") + fn : o.err;
+        } else if (w.kind == 6) {
+            res[0].is_array = false;
+            res[0].vals = {frh::from_u64(o.out[31] ? 1 : 0)};
+        } else {
+            res[0].is_array = true;
+            res[0].vals = {frh::from_be_bytes32_reduce(o.out, 32), frh::from_be_bytes32_reduce(o.out + 32, 32)};
+        }
+        b->fc_slots[w.slot].inst[instance].push_back(std::move(res));
+        b->fc_slots[w.slot].dirty = true;
+        b->fc_lane[w.t].resolved_new = true;
+    }
+    return (int)lanes.size();
+}
 
 int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t n_values, const uint8_t *is_array, const uint32_t *lens,
                                     const uint8_t *values_be32) try {

@@ -316,6 +316,10 @@ void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm_result
     }
     case 24: {
         auto it = b->host_bb_msg.find(j);
+        if (it == b->host_bb_msg.end()) {  // (a callback made from inside a Brillig program: its text outlives the re-solve that reports it)
+            it = b->fc_fail_msg.find(j);
+            if (it == b->fc_fail_msg.end()) it = b->host_bb_msg.end();
+        }
         snprintf(r.message, sizeof r.message, "%s", it == b->host_bb_msg.end() ? "" : it->second.c_str());
         break;
     }

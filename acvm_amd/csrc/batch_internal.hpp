@@ -28,6 +28,7 @@ int ensure_slow_capacity(acvm_batch *b, uint32_t n);
 ExactLanes exact_lanes(acvm_batch *b, uint32_t n_slow);
 int upload_fc_tables(acvm_batch *b, uint32_t n_slow);
 int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_t n_slow);
+int resolve_internal_calls(acvm_batch *b);  // the caller's BlackBoxFunctionSolver inside Brillig programs: answers the lanes waiting at one; > 0: solve again
 // the exact in-order kernels over the current lanes from opcode min_start on (stepping: only opcodes [min_start, end_opcode), nothing replayed)
 int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start, bool replay = true, uint32_t end_opcode = 0xFFFFFFFFu);
 int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint32_t end_opcode);

@@ -394,15 +394,28 @@ int batch_solve_impl(acvm_batch *b, const void *next_inputs) {
     if (b->pending) return (int)n_slow;  // their outcome is not known yet
     return count_not_solved(b);
 }
+// the solve, and -- under a caller-supplied BlackBoxFunctionSolver -- the rounds that answer the Brillig programs' internal black-box calls
+// (batch_exact.cpp resolve_internal_calls): every round answers all instances waiting at such a call and re-solves (a few lanes on the exact
+// kernels, a sizeable part of the batch through the level schedule again: batch_solve_impl's choice for resolved foreign calls)
+static int solve_with_internal_calls(acvm_batch *b, const void *next_inputs) {
+    int rc = batch_solve_impl(b, next_inputs);
+    while (rc >= 0) {
+        const int answered = resolve_internal_calls(b);
+        if (answered < 0) return answered;
+        if (!answered) break;
+        rc = batch_solve_impl(b, nullptr);
+    }
+    return rc;
+}
 int acvm_batch_solve(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
-    return batch_solve_impl(b, nullptr);
+    return solve_with_internal_calls(b, nullptr);
 } ABI_CATCH
 int acvm_batch_solve_then_import(acvm_batch_t *b, const void *d_next_values_be32) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
     // (resumed foreign calls, stepping and a caller-supplied solver keep the plain solve: nothing is imported behind them)
     const bool plain = !d_next_values_be32 || b->solved || b->stepping || b->has_solver || b->force_slow;
-    return batch_solve_impl(b, plain ? nullptr : d_next_values_be32);
+    return solve_with_internal_calls(b, plain ? nullptr : d_next_values_be32);
 } ABI_CATCH
 
 

@@ -138,9 +138,9 @@ void launch_ecdsa_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
 // caller-supplied BlackBoxFunctionSolver (kernels_ops.hip)
 void launch_hostbb_precheck(hipStream_t s, const ExactLanes &L, uint32_t opcode, const uint32_t *sel, uint32_t n_sel, uint8_t *active);
 void launch_hostbb_gather(hipStream_t s, const uint4 *W, uint64_t Bp, const uint32_t *ids, uint32_t first, uint32_t n_lanes, const uint32_t *sel,
-                          uint32_t n_sel, uint8_t *out);
+                          uint32_t n_sel, uint8_t *out, const uint32_t *slot_of = nullptr);
 void launch_hostbb_apply_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func, const uint32_t *outs,
-                               uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event);
+                               uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event, const uint32_t *slot_of = nullptr);
 void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const ExactLanes &L, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
                                const uint32_t *outs, uint32_t n_out, const uint8_t *active, const uint8_t *rc, const uint8_t *vals);
 // per-instance digest of the witness map (kernels_hash.hip; definition: include/acvm_amd.h acvm_batch_digest). Device tables of the

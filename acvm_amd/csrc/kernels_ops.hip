@@ -65,13 +65,15 @@ __global__ void hostbb_precheck_kernel(ExactLanes L, uint32_t opcode, const uint
     active[t] = 1;
 }
 // out: [n_lanes][n_sel][32] canonical big-endian; lane t reads instance ids[t] (or first + t when ids is null)
+// (slot_of: the table's rows under witness-slot reuse, null = the witness index)
 __global__ void __launch_bounds__(256) hostbb_gather_kernel(const uint4 *__restrict__ W, uint64_t Bp, const uint32_t *__restrict__ ids, uint32_t first,
-                                                            uint32_t n_lanes, const uint32_t *__restrict__ sel, uint32_t n_sel, uint8_t *__restrict__ out) {
+                                                            uint32_t n_lanes, const uint32_t *__restrict__ sel, uint32_t n_sel, uint8_t *__restrict__ out,
+                                                            const uint32_t *__restrict__ slot_of) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t k = blockIdx.y;
     if (t >= n_lanes) return;
     const uint64_t j = ids ? ids[first + t] : first + t;
-    const Fr x = fr_to_canonical(fr_load(W, sel[k], Bp, j));
+    const Fr x = fr_to_canonical(fr_load(W, slot_of ? slot_of[sel[k]] : sel[k], Bp, j));
     uint8_t *p = out + ((uint64_t)t * n_sel + k) * 32;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -101,11 +103,11 @@ __device__ __forceinline__ OpResult hostbb_apply(const P &p, uint32_t func, uint
 }
 __global__ void __launch_bounds__(256) hostbb_apply_level_kernel(uint4 *W, uint64_t Bp, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
                                                                  const uint32_t *__restrict__ outs, uint32_t n_out, const uint8_t *__restrict__ rc,
-                                                                 const uint8_t *__restrict__ vals, uint32_t *__restrict__ event) {
+                                                                 const uint8_t *__restrict__ vals, uint32_t *__restrict__ event, const uint32_t *__restrict__ slot_of) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
     const uint64_t j = first + t;
-    FastPolicy p{W, Bp, j, nullptr};
+    FastPolicy p{W, Bp, j, slot_of};
     const OpResult r = hostbb_apply(p, func, rc[t], outs, n_out, vals + (uint64_t)t * n_out * 32);
     if (r.err) atomicMin(&event[j], opcode);
 }
@@ -126,14 +128,14 @@ void launch_hostbb_precheck(hipStream_t s, const ExactLanes &L, uint32_t opcode,
     hipLaunchKernelGGL(hostbb_precheck_kernel, dim3((L.n_slow + 255) / 256), dim3(256), 0, s, L, opcode, sel, n_sel, active);
 }
 void launch_hostbb_gather(hipStream_t s, const uint4 *W, uint64_t Bp, const uint32_t *ids, uint32_t first, uint32_t n_lanes, const uint32_t *sel,
-                          uint32_t n_sel, uint8_t *out) {
+                          uint32_t n_sel, uint8_t *out, const uint32_t *slot_of) {
     if (!n_lanes || !n_sel) return;
-    hipLaunchKernelGGL(hostbb_gather_kernel, dim3((n_lanes + 255) / 256, n_sel), dim3(256), 0, s, W, Bp, ids, first, n_lanes, sel, n_sel, out);
+    hipLaunchKernelGGL(hostbb_gather_kernel, dim3((n_lanes + 255) / 256, n_sel), dim3(256), 0, s, W, Bp, ids, first, n_lanes, sel, n_sel, out, slot_of);
 }
 void launch_hostbb_apply_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func, const uint32_t *outs,
-                               uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event) {
+                               uint32_t n_out, const uint8_t *rc, const uint8_t *vals, uint32_t *event, const uint32_t *slot_of) {
     if (!n_lanes) return;
-    hipLaunchKernelGGL(hostbb_apply_level_kernel, dim3((n_lanes + 255) / 256), dim3(256), 0, s, W, Bp, first, n_lanes, opcode, func, outs, n_out, rc, vals, event);
+    hipLaunchKernelGGL(hostbb_apply_level_kernel, dim3((n_lanes + 255) / 256), dim3(256), 0, s, W, Bp, first, n_lanes, opcode, func, outs, n_out, rc, vals, event, slot_of);
 }
 void launch_hostbb_apply_exact(hipStream_t s, uint4 *W, uint64_t Bp, const ExactLanes &L, uint32_t first, uint32_t n_lanes, uint32_t opcode, uint32_t func,
                                const uint32_t *outs, uint32_t n_out, const uint8_t *active, const uint8_t *rc, const uint8_t *vals) {

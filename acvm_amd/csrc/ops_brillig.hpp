@@ -225,6 +225,14 @@ static inline __device__ __noinline__ void brillig_foreign_call(BrVm &vm, const 
         for (uint32_t v = 0; v < nvals; v++, pos += 2) vpos += desc(pos + 1);
     }
     const uint32_t n_res = desc(pos++);
+    if (n_res >= 0xFFFFFFF0u) {
+        // an INTERNAL call (the caller's BlackBoxFunctionSolver inside this program, plan.cpp) whose callback did not return Ok: the VM fails
+        // here like the reference's does on evaluate_black_box's error (brillig_vm/src/lib.rs:298-307: self.fail(e.to_string())), a panicking
+        // solver panics; the text is the host's (batch_exact.cpp resolve_internal_calls)
+        vm.code = DM_HOST_MESSAGE;
+        vm.status = n_res - 0xFFFFFFF0u >= 3u ? 5u : 2u;
+        return;
+    }
     bool invalid = false;
     const uint32_t nz = n_dests < n_res ? n_dests : n_res;
     for (uint32_t i = 0; i < nz; i++, pos += 2) {

@@ -532,6 +532,38 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 //  fc_slot, E(pred)?, inputs: (is_array, n, E x n)..., outputs: (is_array, n, (w, flag) x n)...]
                 const BrilligCall &b = *o.brillig;
                 p.prog_class[oi] = CLS_BRILLIG;
+                // A caller-supplied BlackBoxFunctionSolver is the VM's solver too (brillig_vm/src/lib.rs:61,81,298; black_box.rs:139-163): the three
+                // trait functions inside a Brillig program become INTERNAL foreign calls -- the VM stops there like at an oracle call, hands
+                // the operands to the host (same layout: registers as one value, heap vectors as their slices), the batch driver answers every
+                // waiting instance through the solver in one pass (*_batch members when the vtable has them) and the opcode re-runs its VM with
+                // the answers in the result store (batch_exact.cpp resolve_internal_calls). The caller never sees these calls.
+                std::vector<BrilligOp> rewritten;
+                if (host_blackbox) {
+                    rewritten = b.bytecode;
+                    auto R = [](uint64_t r) { return RegOrMem{0u, r, 0}; };
+                    auto A = [](uint64_t ptr, uint64_t n) { return RegOrMem{1u, ptr, n}; };
+                    auto V = [](uint64_t ptr, uint64_t size_reg) { return RegOrMem{2u, ptr, size_reg}; };
+                    for (BrilligOp &op : rewritten) {
+                        if (op.op != BR_BLACK_BOX || op.bbop < 6) continue;
+                        BrilligOp f;
+                        f.op = BR_FOREIGN_CALL;
+                        if (op.bbop == 6) {  // SchnorrVerify { public_key_x, public_key_y, message, signature, result }
+                            f.function = PLAN_FC_INTERNAL_SCHNORR;
+                            f.inputs = {R(op.bb[0]), R(op.bb[1]), V(op.bb[2], op.bb[3]), V(op.bb[4], op.bb[5])};
+                            f.dests = {R(op.bb[6])};
+                        } else if (op.bbop == 7) {  // Pedersen { inputs, domain_separator, output }: two values are written whatever size the array declares
+                            f.function = PLAN_FC_INTERNAL_PEDERSEN;
+                            f.inputs = {V(op.bb[0], op.bb[1]), R(op.bb[2])};
+                            f.dests = {A(op.bb[3], 2)};
+                        } else {  // FixedBaseScalarMul { low, high, result }
+                            f.function = PLAN_FC_INTERNAL_FIXED_BASE;
+                            f.inputs = {R(op.bb[0]), R(op.bb[1])};
+                            f.dests = {A(op.bb[2], 2)};
+                        }
+                        op = f;
+                    }
+                }
+                const std::vector<BrilligOp> &code = host_blackbox ? rewritten : b.bytecode;
                 uint32_t bc_off = (uint32_t)p.bytecode.size();
                 uint64_t max_reg = std::max(b.inputs.size(), b.outputs.size());
                 uint64_t mem_hint = 0, arr_cells = 0;
@@ -539,7 +571,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 for (auto &in : b.inputs) if (in.is_array) arr_cells += in.arr.size();
                 bool has_foreign = false, has_grumpkin = false;
                 uint32_t max_hash_hint = 0;
-                for (auto &op : b.bytecode) {
+                for (auto &op : code) {
                     // 8 words per instruction: [op, a, b, c, sub_op | bit_size << 8, location, const index, extra offset]
                     uint32_t w[8] = {op.op, 0, 0, 0, 0, 0, 0, 0};
                     switch (op.op) {
@@ -576,8 +608,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     p.bytecode.insert(p.bytecode.end(), w, w + 8);
                 }
                 // extra blocks (black box operands) after the fixed-size instruction array
-                for (size_t k = 0; k < b.bytecode.size(); k++) {
-                    const BrilligOp &op = b.bytecode[k];
+                for (size_t k = 0; k < code.size(); k++) {
+                    const BrilligOp &op = code[k];
                     if (op.op != BR_BLACK_BOX) continue;
                     // operand layout mirrors brillig/src/black_box.rs:7-53: HeapVector = (pointer reg, size reg),
                     // HeapArray = (pointer reg, literal size), RegisterIndex = reg. n_reg_words = leading register words.
@@ -591,8 +623,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 // ForeignCall operands: [n_dests, n_inputs, (kind, reg, size) x n_dests, (kind, reg, size) x n_inputs];
                 // kind 0 register, 1 HeapArray (size literal), 2 HeapVector (size register)
                 uint64_t fc_pending_vals = 0;
-                for (size_t k = 0; k < b.bytecode.size(); k++) {
-                    const BrilligOp &op = b.bytecode[k];
+                for (size_t k = 0; k < code.size(); k++) {
+                    const BrilligOp &op = code[k];
                     if (op.op != BR_FOREIGN_CALL) continue;
                     p.bytecode[bc_off + 8 * k + 7] = (uint32_t)p.bytecode.size();
                     p.bytecode.push_back((uint32_t)op.dests.size());
@@ -631,7 +663,6 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                     p.has_foreign_calls = true;
                 }
                 if (has_grumpkin) p.needs_grumpkin = true;
-                if (has_grumpkin && host_blackbox) unsupported(oi, "a caller-supplied BlackBoxFunctionSolver inside Brillig black-box ops");
                 uint64_t mem_cap = arr_cells + mem_hint + 64 + (max_hash_hint ? 64 : 0) + (has_foreign ? 64 : 0);
                 mem_cap = std::max<uint64_t>(mem_cap, (uint64_t)std::max<int64_t>(tune.brillig_mem_cells, 0));
                 mem_cap = std::min<uint64_t>(mem_cap, 1u << 20);

@@ -126,6 +126,13 @@ struct Plan {
     uint64_t fc_pending_vals = 0;  // field elements one pending call can hand to the host (upper bound)
 };
 
+// function names of the INTERNAL foreign calls a caller-supplied BlackBoxFunctionSolver turns the Brillig black-box ops into (plan.cpp):
+// the batch driver answers them itself; a circuit's own oracle names cannot start with the control character
+#define PLAN_FC_INTERNAL_PREFIX "\x01" "bb:"
+#define PLAN_FC_INTERNAL_SCHNORR PLAN_FC_INTERNAL_PREFIX "schnorr_verify"
+#define PLAN_FC_INTERNAL_PEDERSEN PLAN_FC_INTERNAL_PREFIX "pedersen"
+#define PLAN_FC_INTERNAL_FIXED_BASE PLAN_FC_INTERNAL_PREFIX "fixed_base_scalar_mul"
+
 // largest dense witness table the planner accepts (witness indices 0 .. PLAN_MAX_WITNESSES - 1)
 static constexpr uint64_t PLAN_MAX_WITNESSES = 1ull << 27;
 

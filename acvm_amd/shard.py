@@ -103,3 +103,29 @@ def gather_floats(value: float, dist):
     got = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(got, t)
     return [float(g.item()) for g in got]
+
+
+def cpu_budget():
+    """(CPUs this process may actually use, the cgroup's CPU quota or None, os.cpu_count()): os.cpu_count() is the HOST's (256 on the GPU box of
+    this pool) while the container's cgroup grants a quota (cpu.max "1600000 100000" = 16 CPUs there) -- threads beyond the quota are only
+    throttled, which is what made 64 threads look like 13 x one thread in round 4's line"""
+    host = os.cpu_count() or 1
+    try:
+        host = min(host, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = host if quota is None else max(1, min(host, int(quota + 0.5)))
+    return usable, quota, os.cpu_count() or 1

@@ -15,7 +15,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acvm_amd
-from acvm_amd import synth
+from acvm_amd import shard, synth
 from oracle import binding as oracle  # checker of the audit sample only
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -61,7 +61,7 @@ for k in range(n_tiles):
         picks = sorted(set([0, 5] + [int(x) for x in np.linspace(8, tile - 1, max(audit - 2, 1))]))[:audit]
         sub = b"".join(values[j * row:(j + 1) * row] for j in picks)
         a0 = time.time()
-        ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, sub, len(picks), n_threads=min(len(picks), os.cpu_count() or 1))
+        ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, sub, len(picks), n_threads=min(len(picks), shard.cpu_budget()[0]))
         a1 = time.time()
         ok = True
         for i, j in enumerate(picks):
@@ -71,6 +71,6 @@ for k in range(n_tiles):
                 got = batch.extract(ret, j, 1)[0]
                 ok &= all(bytes(got[n]) == bytes(ovals[i][w]) for n, w in enumerate(ret))
         out["audit"] = {"instances": picks, "bit_exact": bool(ok), "oracle_s": round(a1 - a0, 1),
-                        "oracle_witnesses_per_s": round(len(picks) / (a1 - a0), 2), "oracle_threads": min(len(picks), os.cpu_count() or 1)}
+                        "oracle_witnesses_per_s": round(len(picks) / (a1 - a0), 2), "oracle_threads": min(len(picks), shard.cpu_budget()[0])}
 batch.free()
 print(json.dumps(out))

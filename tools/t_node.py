@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acvm_amd
-from acvm_amd import synth
+from acvm_amd import shard, synth
 from oracle import binding as oracle  # checker of the audit sample only
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -42,7 +42,7 @@ for rep in range(reps):
 picks = sorted(set([0, 5, 8, N - 1] + [int(x) for x in np.linspace(9, N - 2, max(audit - 4, 0))]))[:max(audit, 4)]
 row = len(ids) * 32
 sub = b"".join(values[j * row:(j + 1) * row] for j in picks)
-threads = min(len(picks), os.cpu_count() or 1)
+threads = min(len(picks), shard.cpu_budget()[0])  # (the cgroup quota, not the host's CPU count)
 a0 = time.time()
 ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, sub, len(picks), n_threads=threads)
 a1 = time.time()

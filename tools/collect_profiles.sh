@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/collect_profiles.sh TAG -- copy what tools/gpu_round4.sh TAG left under gpurun_out/ (scratch) into profiles/ (tracked): the bench lines,
+# tools/collect_profiles.sh TAG -- copy what tools/gpu_round5.sh TAG left under gpurun_out/ (scratch) into profiles/ (tracked): the bench lines,
 # the rocprofv3 summaries (tools/prof_summary.py), the SQ counters, config 5 at circuit size and the timelines.
 TAG=${1:?tag}
 cd "$(dirname "$0")/.."

@@ -1,9 +1,11 @@
 // fr_device.hpp -- BN254-Fr arithmetic for gfx950 (CDNA4), the inner loop of every kernel.
 // Replaces acir_field::FieldElement add/sub/neg/mul/inverse (acir_field/src/generic_ark.rs:242-245,
 // 360-406; ark-ff Fp256<MontBackend<_,4>>).
-// Storage form `Fr`: the Montgomery representative x * R mod p with R = 2^261, as 8 x 32-bit limbs, always fully
-// reduced to [0, p), so equality / is_zero are limb compares, matching the reference's canonical-bytes equality
-// (generic_ark.rs:88-92,164-169). Working form `Fr29`: 9 limbs of 29 bits (R = 2^(9*29)): CDNA4 has no 64x64
+// Storage form `Fr`: the Montgomery representative x * R mod p with R = 2^261, as 8 x 32-bit limbs. Everything a
+// non-Arithmetic opcode, the inversion kernel or a caller reads is fully reduced to [0, p), so equality / is_zero are limb
+// compares, matching the reference's canonical-bytes equality (generic_ark.rs:88-92,164-169); a row that only Arithmetic
+// gates read may hold ANY representative of its residue below 2^256 (gate_eval.hpp "relaxed rows": the product tolerates
+// it, and its readers outside the gate kernels multiply by the row's 1 / scale first, which reduces). Working form `Fr29`: 9 limbs of 29 bits (R = 2^(9*29)): CDNA4 has no 64x64
 // multiplier, the native wide multiply-add is v_mad_u64_u32 (measured 4.6 cycles per wave64, tools/chainbench), and a
 // carry-out costs another v_addc_co_u32 (3.6 cycles) per product with 32-bit limbs. With 29-bit limbs a whole column of
 // a * b + m * p (<= 18 products of < 2^58) fits a 64-bit accumulator, so the product needs 162 multiply-adds and no

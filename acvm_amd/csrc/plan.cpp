@@ -982,7 +982,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             if (!t.c.is_zero()) terms.push_back({true, t.a, t.b, t.c, over_scale(over_scale(frh::mul(base, t.c), t.a), t.b)});
         for (auto &t : lins)
             if (!t.c.is_zero()) terms.push_back({false, t.a, 0, t.c, over_scale(frh::mul(base, t.c), t.a)});
-        // multiply-adds of the device's gate sum for a multiplier m (ops_common.hpp gate_sum_lazy): a product with a general
+        // multiply-adds of the device's gate sum for a multiplier m (gate_eval.hpp gate_eval): a product with a general
         // coefficient is a product (153) and then a dot participant, a +1 product and a general linear term are dot
         // participants (two share one reduction: 234, a single one 153), a -1 product is a product
         auto gate_cost = [&](const FrH *m) {
@@ -1012,7 +1012,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
         }
         auto sc = [&](const FrH &pe) { return have_m ? frh::mul(pe, m) : pe; };
-        // Record layout (consumed by gate_sum_lazy, ops_common.hpp): terms with a general coefficient go through the
+        // Record layout (gate_record.hpp; consumed by gate_eval, gate_eval.hpp): terms with a general coefficient go through the
         // multiplied lists; terms with coefficient +1 / -1 are listed without a coefficient and are only added / subtracted
         // on the device (up to 255 of each kind, the rest keep an explicit constant).
         //   [kind | np_mac << 8 | nl_mac << 16, opcode, out, q_c, partner, np_pos | np_neg << 8 | nl_pos << 16 | nl_neg << 24,

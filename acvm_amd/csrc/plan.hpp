@@ -30,7 +30,8 @@ static constexpr uint32_t COEF_ZERO = 0xFFFFFFFDu;  // only for the constant ter
 
 enum GateKind : uint32_t { GATE_ASSERT = 0, GATE_SOLVE = 1, GATE_SOLVE_DYN = 2 };
 
-// Gate record in the u32 stream (arith_level_kernel; layout and term lists: plan.cpp, consumed by gate_sum_lazy):
+// Gate record in the u32 stream (arith_level_kernel): gate_record.hpp; evaluation: gate_eval.hpp (flags, bounds: plan.cpp).
+// Words:
 //  w0 = kind | np_mac << 8 | nl_mac << 16   w1 = opcode index (program order)   w2 = output witness slot (SOLVE*)
 //  w3 = constant term (coef encoding)       w4 = slot of 1/denominator in the inverse table (SOLVE_DYN)
 //  w5 = counts of the unit-coefficient term lists, then the term lists

@@ -96,6 +96,13 @@ typedef struct {
  * batch that reach the opcode. Arrays are instance-major host memory; rc[i] uses the return codes above, err is
  * [n][err_stride] NUL-terminated texts. They are what a backend that is itself batched (a GPU backend, a thread pool)
  * implements; the library gathers all instances once, makes ONE call per opcode and scatters the results once.
+ *
+ * The solver is the Brillig VM's solver too, as in the reference (brillig_vm/src/lib.rs:61,81,298; black_box.rs:139-163): a Brillig
+ * program's BlackBoxOp::{SchnorrVerify, Pedersen, FixedBaseScalarMul} reach the same table (ABI 5; refused before). Inside
+ * acvm_batch_solve / acvm_batch_solve_opcode every instance that stands at such an op is answered in one pass (one *_batch call per call
+ * shape) and the opcode re-runs its VM with the answers; a callback's failure fails the VM at the op with BlackBoxResolutionError's Display
+ * string. The caller never sees these round trips. ACVM_BATCH_REUSE_SLOTS takes a solver for the ACIR-level black boxes; a solver inside
+ * Brillig is refused there with every other foreign call.
  */
 typedef struct {
     void *ctx;

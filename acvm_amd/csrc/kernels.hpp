@@ -120,7 +120,7 @@ void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 // Pedersen records: 4 waves per group of 64 instances, one accumulator chain each (kernels_grumpkin.hip)
 void launch_pedersen_seeds(hipStream_t s, const GrumpkinTables &T, const uint32_t *keys, uint32_t n, uint32_t *out);
 void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
-                           uint32_t *event);
+                           uint32_t *event, const uint32_t *scratch_off = nullptr, uint32_t *scratch = nullptr);
 void launch_brillig_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets,
                           const uint32_t *scratch_off, uint32_t n, uint32_t *event, uint32_t *scratch);
 

@@ -148,6 +148,108 @@ pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, 
     if (wave == 0 && active && (!p.insert(rec[4], r, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
 }
 
+// ---------------------------------------------------------------------------------------------- Pedersen, K records per wave, ONE inversion per step
+// A link of the chain ends in one field inversion (safegcd: ~13 500 instructions, against ~2 700 for each of its 12-24 table additions): a sixth of the
+// link, a fifth of a two-input commitment. A wave pays it whatever its lanes do, so batching across LANES buys nothing; batching across RECORDS does: here
+// a wave walks up to PED_BUNDLE independent Pedersen records of the launch in lock-step -- step s of every record, then ONE inversion of the product of
+// their Z coordinates (Montgomery's trick: 3 products per record), then step s + 1. The Jacobian sums, the prefix products and the x coordinate that
+// seeds the next step wait in the record's scratch rows ([word][instance], coalesced; PEDERSEN_PARK_WORDS per instance and record). Records of
+// different input counts may share a bundle: the shorter ones simply sit out the later steps. Same table additions, same affine results bit for bit
+// (the inverse of a field element is unique). launch_pedersen_level picks the records per wave so that the launch keeps its share of the chip.
+constexpr uint32_t PED_BUNDLE = 8;
+constexpr uint32_t PED_PARK_PREFIX = 27, PED_PARK_X = 36;
+static_assert(PEDERSEN_PARK_WORDS == PED_PARK_X + 8, "scratch map of pedersen_bundle_level_kernel");
+__global__ void __launch_bounds__(64 * PED1_GROUP) __attribute__((amdgpu_waves_per_eu(4, 8)))
+pedersen_bundle_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ soff,
+                             uint32_t n_records, uint32_t K, uint32_t *__restrict__ event, const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of,
+                             uint32_t prio, uint32_t *__restrict__ scratch) {
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint64_t j0 = ((uint64_t)blockIdx.x * PED1_GROUP + wave_in_group) * 64;
+    if (j0 >= B) return;  // (a whole wave beyond the batch: its lanes have no scratch rows; the kernel has no barrier)
+    const uint64_t j = j0 + lane;  // < Bp: rows are padded to a multiple of 64 instances
+    const bool active = j < B;
+    const uint32_t b0 = blockIdx.y * K, nb = min(K, n_records - b0);  // K <= PED_BUNDLE records per wave
+    const GrumpkinTables &T = dp.grumpkin;
+    FastPolicy p{W, Bp, j, slot_of};
+    const bool win = T.pedw != nullptr;
+    const uint32_t n_units = win ? GRUMPKIN_PEDW_WINDOWS : 15u;
+    auto walk = [&](GJac acc, const Fr &src, uint32_t parity) {
+        const Fr v = fr_to_canonical(src);
+        if (win) {
+            for (uint32_t jw = 0; jw < n_units; jw++)
+                acc = gj_add_aff(acc, gaff_load(T.pedw, ((parity * GRUMPKIN_PEDW_WINDOWS + jw) << GRUMPKIN_PEDW_BITS) | bits_at(v, GRUMPKIN_PEDW_BITS * jw, GRUMPKIN_PEDW_BITS)));
+            return acc;
+        }
+        const uint32_t gen0 = parity ? 15u : 0u;
+        for (uint32_t i = 0; i < n_units; i++) {
+            const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
+            acc = gj_add_aff(acc, gaff_load(T.ped2, ((gen0 + i) << GRUMPKIN_PED2_LOG2) | a << 9 | b));
+        }
+        return acc;
+    };
+    auto park = [&](uint32_t i, uint32_t w) -> uint32_t * { return scratch + ((uint64_t)soff[2u * (b0 + i)] + w) * Bp + j; };
+    auto park_get29 = [&](uint32_t i, uint32_t w0) { Fr29 r; for (int k = 0; k < 9; k++) r.v[k] = *park(i, w0 + k); return r; };
+    auto park_put29 = [&](uint32_t i, uint32_t w0, const Fr29 &v) { for (int k = 0; k < 9; k++) *park(i, w0 + k) = v.v[k]; };
+    uint32_t n_max = 0;
+    for (uint32_t i = 0; i < nb; i++) {
+        const uint32_t *__restrict__ rec = prog + offsets[b0 + i];
+        n_max = max(n_max, rec[3]);
+        if (rec[3] == 0u && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) atomicMin(&event[j], rec[1]);  // the point at infinity is reported as (0, 0)
+    }
+    for (uint32_t step = 1; step <= n_max; step++) {
+        // ---- forward: the step's sum of every record that still runs, and the running product of their Z
+        Fr29 prefix = g29_one();
+#pragma unroll 1
+        for (uint32_t i = 0; i < nb; i++) {
+            const uint32_t *__restrict__ rec = prog + offsets[b0 + i];
+            const uint32_t n = rec[3];
+            if (step > n) continue;
+            const uint32_t *ws = rec + 8;
+            Fr r = fr_zero();
+            if (step > 1u)
+                for (int k = 0; k < 8; k++) r.v[k] = *park(i, PED_PARK_X + k);
+            // (ONE call site of the walk, as in pedersen_quad_level_kernel<1>)
+            GJac s = gj_inf();
+#pragma unroll 1
+            for (uint32_t pass = 0; pass < 2; pass++) {
+                if (pass == 1u && step == 1u) {
+                    s = gj_add_aff(s, GAff{fr_const(dp.ped_seed, 2 * ws[n]), fr_const(dp.ped_seed, 2 * ws[n] + 1)});
+                    break;
+                }
+                Fr src = r;
+                if (pass == 0u) src = active ? p.load(ws[step - 1]) : fr_one();
+                s = walk(s, src, pass ^ 1u);
+            }
+            park_put29(i, 0, s.X);
+            park_put29(i, 9, s.Y);
+            park_put29(i, 18, s.Z);
+            prefix = fr29_mul(prefix, gj_is_inf(s) ? g29_one() : s.Z);  // (a sum at infinity leaves the product alone and reports (0, 0))
+            park_put29(i, PED_PARK_PREFIX, prefix);
+        }
+        // ---- one inversion for all of them, handed back record by record
+        Fr29 inv = fr29_from(fr_inv(fr29_pack(fr29_canon(prefix))));
+#pragma unroll 1
+        for (uint32_t i = nb; i-- > 0u;) {
+            const uint32_t *__restrict__ rec = prog + offsets[b0 + i];
+            const uint32_t n = rec[3];
+            if (step > n) continue;
+            uint32_t ip = 0xFFFFFFFFu;  // the record in front of this one that runs this step too
+            for (uint32_t q = i; q-- > 0u;)
+                if (step <= prog[offsets[b0 + q] + 3]) { ip = q; break; }
+            const Fr29 X = park_get29(i, 0), Y = park_get29(i, 9), Z = park_get29(i, 18);
+            const bool inf = fr29_is_zero_mod_p(Z);
+            const Fr29 zi = fr29_mul(inv, ip == 0xFFFFFFFFu ? g29_one() : park_get29(ip, PED_PARK_PREFIX));
+            inv = fr29_mul(inv, inf ? g29_one() : Z);
+            const Fr29 zi2 = fr29_sqr(zi);
+            Fr x = fr29_pack(fr29_canon(fr29_mul(X, zi2))), y = fr29_pack(fr29_canon(fr29_mul(Y, fr29_mul(zi2, zi))));
+            if (inf) { x = fr_zero(); y = fr_zero(); }
+            for (int k = 0; k < 8; k++) *park(i, PED_PARK_X + k) = x.v[k];
+            if (step == n && active && (!p.insert(rec[4], x, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
+        }
+    }
+}
+
 // seed table of the level Pedersen kernel: one lane per Pedersen record, keys = (n, domain separator) pairs; a row is the
 // affine point hash_single(x of hash_pair(IV, n), parity 0), 16 x u32
 __global__ void __launch_bounds__(64) pedersen_seed_kernel(GrumpkinTables T, const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ out) {
@@ -240,12 +342,27 @@ void launch_pedersen_pair_table(hipStream_t s, const GrumpkinTables &T, uint4 *o
 }
 
 void launch_pedersen_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n,
-                           uint32_t *event) {
+                           uint32_t *event, const uint32_t *scratch_off, uint32_t *scratch) {
     if (!n || !B) return;
     const uint64_t groups = (uint64_t)((B + 63u) / 64u) * n;  // one per 64 instances of a record
     const int64_t mode = tuning().pedersen_waves;               // 0: by the size of the launch; 1 / 4: forced (A/B measurements)
     const uint32_t prio = (uint32_t)tuning().pedersen_prio;
     const bool one = mode == 1 || (mode != 4 && groups > 512u);  // (measured alone, tools/t_pedersen_sweep.py: equal at 512 groups, one wave 21-24 % faster from 1 024 on)
+    // several records in the launch: K of them per wave share the inversions, K as large as leaves pedersen_bundle_waves waves (the launch runs
+    // beside the gate kernel: fewer instructions in total, but each wave's walk is K times as long)
+    const int64_t bundle = tuning().pedersen_bundle;  // 0: never; 1: where it pays; 2: every launch of two records or more (tests)
+    uint32_t K = 1;
+    if (n >= 2u && scratch && bundle == 2) K = PED_BUNDLE;
+    else if (n >= 2u && scratch && bundle == 1 && one) K = (uint32_t)std::min<uint64_t>(PED_BUNDLE, groups / (uint64_t)std::max<int64_t>(tuning().pedersen_bundle_waves, 1));
+    if (K >= 2u) {
+        K = (n + (n + K - 1) / K - 1) / ((n + K - 1) / K);  // the same number of waves, records spread evenly (9 records: 5 + 4, not 8 + 1)
+        for (uint32_t done = 0; done < n; done += 65535u * K) {
+            const uint32_t m = n - done > 65535u * K ? 65535u * K : n - done;
+            hipLaunchKernelGGL(pedersen_bundle_level_kernel, dim3((B + 64 * PED1_GROUP - 1) / (64 * PED1_GROUP), (m + K - 1) / K), dim3(64 * PED1_GROUP), 0, s, W, Bp, B, dp,
+                               offsets + done, scratch_off + 2 * (size_t)done, m, K, event, dp.prog, dp.slot_of, prio, scratch);
+        }
+        return;
+    }
     for (uint32_t done = 0; done < n;) {
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
         if (one) hipLaunchKernelGGL(pedersen_quad_level_kernel<1>, dim3((B + 64 * PED1_GROUP - 1) / (64 * PED1_GROUP), m), dim3(64 * PED1_GROUP), 0, s, W, Bp, B, dp, offsets + done, event, dp.prog, dp.slot_of, prio);

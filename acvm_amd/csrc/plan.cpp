@@ -1607,7 +1607,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             const PendingRecord &r = records[ri];
             if (r.chained) continue;
             p.cls_offset[r.cls].push_back(r.prog_at != 0xFFFFFFFFu ? r.prog_at : r.synthetic ? r.opcode : p.prog_offset[r.opcode]);
-            p.cls_scratch[r.cls].push_back(r.synthetic ? 0u : p.prog_scratch[r.opcode]);
+            // (a Pedersen record of the level schedule parks its step sums for the shared inversion: kernels_grumpkin.hip pedersen_bundle_level_kernel)
+            p.cls_scratch[r.cls].push_back(r.synthetic ? 0u : r.cls == CLS_PEDERSEN ? PEDERSEN_PARK_WORDS : p.prog_scratch[r.opcode]);
             width[L]++;
         }
     }

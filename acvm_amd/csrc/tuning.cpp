@@ -10,7 +10,7 @@ namespace {
 
 struct Key { const char *name; int64_t Tuning::*field; };
 const Key KEYS[] = {
-    {"scale", &Tuning::scale}, {"relax", &Tuning::relax}, {"pairs", &Tuning::pairs}, {"chains", &Tuning::chains}, {"max_tails", &Tuning::max_tails},
+    {"scale", &Tuning::scale}, {"relax", &Tuning::relax}, {"pedersen_bundle", &Tuning::pedersen_bundle}, {"pedersen_bundle_waves", &Tuning::pedersen_bundle_waves}, {"pairs", &Tuning::pairs}, {"chains", &Tuning::chains}, {"max_tails", &Tuning::max_tails},
     {"inv_epoch", &Tuning::inv_epoch}, {"inv_latency", &Tuning::inv_latency}, {"heavy_epoch", &Tuning::heavy_epoch}, {"heavy_latency", &Tuning::heavy_latency},
     {"pedersen_latency", &Tuning::pedersen_latency}, {"pedersen_epoch", &Tuning::pedersen_epoch}, {"digest_epoch", &Tuning::digest_epoch}, {"range_fuse", &Tuning::range_fuse},
     {"range_merge", &Tuning::range_merge}, {"hash_chain", &Tuning::hash_chain}, {"brillig_inline", &Tuning::brillig_inline},

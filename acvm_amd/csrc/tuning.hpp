@@ -27,6 +27,8 @@ struct Tuning {
     int64_t hash_chain = 1;        // a byte-message hash of another one's digest runs behind it in the same workgroup
     int64_t brillig_inline = 1;    // straight-line Brillig programs compiled into light records of the level schedule
     int64_t pedersen_waves = 0;    // waves per 64 instances of the level Pedersen kernel: 0 = four, or one when the launch fills the chip anyhow; 1 / 4 force
+    int64_t pedersen_bundle = 1;   // up to eight Pedersen records of a launch per wave, ONE inversion per chain step for all of them: 0 never, 1 in launches that fill the chip anyhow, 2 always (tests)
+    int64_t pedersen_bundle_waves = 1024;  // ... as many records per wave as leave the launch this many waves (one per SIMD: at 512 a config-5 tile of 4 096 gets slower)
     int64_t pedersen_prio = 1;     // s_setprio 3 in the level Pedersen kernel: its few long waves win the issue arbitration against the gate kernel's many
     int64_t light_fuse = 1;        // the light records of a level ride in its gate launch
     int64_t brillig_mem_cells = 0; // lower bound of the per-lane Brillig memory of the level kernels (0: the planner's estimate)

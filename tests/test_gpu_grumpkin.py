@@ -78,6 +78,27 @@ def test_pedersen_batch(oracle, n, ds):
     both_paths(oracle, circ, ids, rows)
 
 
+@pytest.mark.parametrize("counts", [(2, 2, 2), (1, 3, 2, 0, 5), tuple([2] * 11)], ids=["3x2", "ragged", "11x2"])
+def test_pedersen_records_sharing_the_inversion(oracle, counts):
+    """Several Pedersen records in ONE launch walked in lock-step by pedersen_bundle_level_kernel (one field inversion per chain step for up to
+    eight records; pedersen_bundle=2 forces the path at test sizes): records of different input counts in a bundle, more records than one
+    bundle holds, inputs 0 / 1 / p - 1, and a batch that ends inside a wave. Same witness maps as the oracle's and the exact kernels'."""
+    import acvm_amd
+    r = random.Random(sum(counts) + len(counts))
+    n_in = max(counts) + 1
+    ids = list(range(1, n_in + 1))
+    ops, out = [], n_in
+    for i, n in enumerate(counts):
+        ops.append(BB("Pedersen", {"inputs": [FI(1 + (i + k) % n_in, 254) for k in range(n)], "domain_separator": 0, "outputs": [out + 1, out + 2]}))
+        out += 2
+    rows = [[r.randrange(P) for _ in range(n_in)] for _ in range(150)]
+    rows[0] = [0] * n_in
+    rows[1] = [P - 1] * n_in
+    rows[2] = [1] * n_in
+    with acvm_amd.tuning(pedersen_bundle=2):
+        both_paths(oracle, Circuit(out, ops), ids, rows)
+
+
 def test_config4_grumpkin_circuit(oracle):
     """accepting signatures and flipped-bit signatures (pinned: the Blake2s digest differs, schnorr_verify.ts)"""
     circ, ids = grumpkin_circuit()

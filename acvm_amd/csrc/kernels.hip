@@ -12,6 +12,7 @@
 // gate records and circuit constants are wave-uniform and travel through the scalar cache.
 #include "ops_common.hpp"
 #include "kernels.hpp"
+#include "tuning.hpp"
 
 namespace acvm {
 
@@ -138,19 +139,18 @@ arith_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const uint32_
 }
 
 // Denominators of the gates whose unknown is multiplied by a known witness (arithmetic.rs:68-91): 1 / partner for a batch of
-// inversion jobs (plan.cpp schedules them ahead of their gates). One wave = 64 instances x up to INV_CHUNK jobs; the
+// inversion jobs (plan.cpp schedules them ahead of their gates). One wave = 64 instances x up to inv_chunk jobs (tuning.hpp); the
 // inversions of a lane are batched with Montgomery's trick, so a lane pays one field inversion per chunk plus 3
 // multiplications per job. The prefix products are parked in the jobs' own rows of the inverse table (laid out like W,
 // [slot][half][instance], coalesced) and replaced by the inverses on the way back. Values stay in the 29-bit working form
 // between products (< 1.06p, never repacked); the table holds representatives < 2^256, not necessarily < p.
-static constexpr uint32_t INV_CHUNK = 64;
 __global__ void __launch_bounds__(64) inverse_batch_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ Inv, uint64_t Bp, uint32_t B,
                                                            const uint32_t *__restrict__ gate_stream, const uint32_t *__restrict__ job_offset,
-                                                           uint32_t n_jobs, uint32_t *__restrict__ event) {
+                                                           uint32_t n_jobs, uint32_t chunk, uint32_t *__restrict__ event) {
     const uint64_t j = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= B) return;
-    const uint32_t first = blockIdx.y * INV_CHUNK;
-    const uint32_t n = n_jobs - first < INV_CHUNK ? n_jobs - first : INV_CHUNK;
+    const uint32_t first = blockIdx.y * chunk;
+    const uint32_t n = n_jobs - first < chunk ? n_jobs - first : chunk;
     Fr29 prefix = fr29_from(fr_one());
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t *__restrict__ g = gate_stream + job_offset[first + i];
@@ -365,8 +365,11 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
                           const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event) {
     if (!n_jobs || !B) return;
-    hipLaunchKernelGGL(inverse_batch_kernel, dim3((B + 63) / 64, (n_jobs + INV_CHUNK - 1) / INV_CHUNK), dim3(64), 0, s, W, inv, Bp, B,
-                       gate_stream, job_offset, n_jobs, event);
+    // jobs per wave: at most inv_chunk (one field inversion, ~13 500 instructions, is shared by a wave's jobs: ~1 000 each), spread evenly over the waves
+    const uint32_t cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(tuning().inv_chunk, 1), 65536), n_chunks = (n_jobs + cap - 1) / cap;
+    const uint32_t chunk = (n_jobs + n_chunks - 1) / n_chunks;
+    hipLaunchKernelGGL(inverse_batch_kernel, dim3((B + 63) / 64, (n_jobs + chunk - 1) / chunk), dim3(64), 0, s, W, inv, Bp, B,
+                       gate_stream, job_offset, n_jobs, chunk, event);
 }
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches) {
     if (!n) return;

@@ -797,6 +797,15 @@ template <int C>
 FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const S29 &qx, const S29 &qy, const Fr &u2, const uint32_t *__restrict__ gtab) {
     SAff29 tab[8];
     secp_window_table<C>(tab, qx, qy);
+#ifdef SECP_EXP_NO_TABLE_READS  // measurement only: every addition takes Q itself from registers, the table is built and kept alive
+#define SECP_ROW(k) SAff29{qx, qy}
+#define SECP_BX(k) qx
+#pragma unroll
+    for (int k = 0; k < 8; k++) asm volatile("" ::"v"(tab[k].x.v[0]), "v"(tab[k].y.v[0]));
+#else
+#define SECP_ROW(k) tab[k]
+#define SECP_BX(k) bx[k]
+#endif
     Fr eights;
 #pragma unroll
     for (int i = 0; i < 8; i++) eights.v[i] = 0x88888888u;
@@ -828,8 +837,8 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const S29 &qx, const S29 
                 if (h ? sp.neg2 : sp.neg1) dg = -dg;
                 if (dg != 0) {
                     const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
-                    SAff29 q = tab[mag - 1u];
-                    if (h) q.x = bx[mag - 1u];
+                    SAff29 q = SECP_ROW(mag - 1u);
+                    if (h) q.x = SECP_BX(mag - 1u);
                     if (dg < 0) q.y = s29_neg_row<C>(q.y);
                     acc = sj_add_aff29<C>(acc, q.x, q.y);
                 }
@@ -847,7 +856,7 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const S29 &qx, const S29 
             const int32_t dg = (int32_t)((secp_limb_at(e, (uint32_t)i >> 5) >> (i & 31)) & 15u) - 8;
             if (dg != 0) {
                 const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
-                SAff29 q = tab[mag - 1u];
+                SAff29 q = SECP_ROW(mag - 1u);
                 if (dg < 0) q.y = s29_neg_row<C>(q.y);
                 acc = sj_add_aff29<C>(acc, q.x, q.y);
             }

@@ -16,6 +16,7 @@ struct Tuning {
     int64_t chains = 1;            // ... and behind a tail of that wave
     int64_t max_tails = 5;         // records behind the host of a wave program
     int64_t inv_epoch = 4;         // levels per batch of denominator inversions
+    int64_t inv_chunk = 128;       // denominators per wave of an inversion batch at most (they share ONE field inversion; 64 -> 128: +0.9 % on the headline)
     int64_t inv_latency = 1;       // levels of slack between an inversion batch and the first gate that reads it
     int64_t heavy_epoch = 1;       // heavy records launched every K-th level only
     int64_t heavy_latency = 0;     // levels the main stream waits before it reads a heavy output
@@ -28,7 +29,7 @@ struct Tuning {
     int64_t brillig_inline = 1;    // straight-line Brillig programs compiled into light records of the level schedule
     int64_t pedersen_waves = 0;    // waves per 64 instances of the level Pedersen kernel: 0 = four, or one when the launch fills the chip anyhow; 1 / 4 force
     int64_t pedersen_bundle = 1;   // up to eight Pedersen records of a launch per wave, ONE inversion per chain step for all of them: 0 never, 1 in launches that fill the chip anyhow, 2 always (tests)
-    int64_t pedersen_bundle_waves = 1024;  // ... as many records per wave as leave the launch this many waves (one per SIMD: at 512 a config-5 tile of 4 096 gets slower)
+    int64_t pedersen_bundle_waves = 2048;  // ... as many records per wave as leave the launch this many waves (two per SIMD; measured, DESIGN section 9: at 1 024 the north-star shape in tiles of 2^16 loses 2 %, at 512 a config-5 tile of 4 096 gets slower)
     int64_t pedersen_prio = 1;     // s_setprio 3 in the level Pedersen kernel: its few long waves win the issue arbitration against the gate kernel's many
     int64_t light_fuse = 1;        // the light records of a level ride in its gate launch
     int64_t brillig_mem_cells = 0; // lower bound of the per-lane Brillig memory of the level kernels (0: the planner's estimate)

@@ -150,6 +150,8 @@ void plan_stats(const Plan &p, acvm_stats_t *out) {
     out->n_gate_out_weak = p.n_gate_out_mode[1];
     out->n_gate_out_canon = p.n_gate_out_mode[2];
     out->max_gate_bound = p.max_gate_bound;
+    out->n_byte_planes = p.n_byte_planes;
+    out->n_byte_plane_reads = p.n_byte_plane_reads;
     for (uint32_t L = 0; L + 1 < p.level_start.size(); L++) out->n_arith_launches += (p.level_start[L + 1] - p.level_start[L] + 65534) / 65535;
     for (int k = 0; k < 4; k++) out->class_algorithmic_bytes_per_instance[k] = p.cls_algorithmic_bytes[k];
     out->class_algorithmic_bytes_per_instance[CLS_GRUMPKIN] += p.cls_algorithmic_bytes[CLS_PEDERSEN] + p.cls_algorithmic_bytes[CLS_ECDSA] +
@@ -222,6 +224,14 @@ static int batch_init(acvm_batch *b) {
     if (int rc = upload(&b->d_prog_offset, p.prog_offset)) return rc;
     if (int rc = upload(&b->d_bytecode, p.bytecode)) return rc;
     if (int rc = upload(&b->d_init_ids, p.initial_ids)) return rc;
+    if (p.n_byte_planes) {  // plan.hpp "Byte planes"
+        std::vector<uint32_t> of_input(p.initial_ids.size());
+        for (size_t i = 0; i < p.initial_ids.size(); i++) of_input[i] = p.byte_plane_of[p.initial_ids[i]];
+        if (int rc = upload(&b->d_byte_plane_of, p.byte_plane_of)) return rc;
+        if (int rc = upload(&b->d_byte_plane_of_input, of_input)) return rc;
+        HIPCHK(hipMalloc((void **)&b->d_byte_plane, (size_t)p.n_byte_planes * b->Bp * 4));
+        HIPCHK(hipMemsetAsync(b->d_byte_plane, 0, (size_t)p.n_byte_planes * b->Bp * 4, b->stream));
+    }
     {   // per-instance memory blocks (MemoryInit / MemoryOp), laid out like W
         size_t bytes = (size_t)p.mem_cells * 2 * b->Bp * sizeof(uint4);
         HIPCHK(hipMalloc((void **)&b->d_Mem, bytes ? bytes : 16));
@@ -328,6 +338,8 @@ static int batch_init(acvm_batch *b) {
     b->dp.ecdsa_g = nullptr;
     b->dp.fc_store = nullptr;
     b->dp.slot_of = nullptr;
+    b->dp.byte_plane_of = b->d_byte_plane_of;
+    b->dp.byte_plane = b->d_byte_plane;
     {   // limits of the Brillig VM for the level kernels and the first pass of the exact kernels (tuning.hpp)
         const Tuning &tn = p.tune;
         b->dp.brillig.steps = 1u << (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.brillig_steps_log2, 0), 31);
@@ -448,7 +460,7 @@ int batch_import_async(acvm_batch *b, const void *d_values_be32, hipEvent_t impo
     b->next_inputs = nullptr;
     if (!already)
         launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->reuse() ? b->d_init_rows : b->d_init_ids,
-                      (uint32_t)b->plan.initial_ids.size());
+                      (uint32_t)b->plan.initial_ids.size(), nullptr, b->d_byte_plane_of_input, b->d_byte_plane);
     HIPCHK(hipGetLastError());
     if (imported) HIPCHK(hipEventRecord(imported, b->stream));
     b->inputs_set = true;

@@ -86,6 +86,7 @@ struct acvm_batch {
     // index, lane t = the t-th flagged instance); x_cap lanes allocated
     uint4 *d_Wx = nullptr, *d_Memx = nullptr;
     uint32_t *d_init_rows = nullptr, *d_ids_x = nullptr;
+    uint32_t *d_byte_plane_of = nullptr, *d_byte_plane_of_input = nullptr, *d_byte_plane = nullptr;  // plan.hpp "Byte planes"
     uint64_t x_cap = 0;
     bool reuse() const { return opts.reuse_slots; }
     // Exact path beside the next solve (node.cpp): the flagged instances of a solve are re-solved from their initial witnesses in the
@@ -189,7 +190,7 @@ struct acvm_batch {
         for (void *p : {(void *)d_fp_g, (void *)d_fp_gs, (void *)d_fp_h, (void *)d_fp_hgen})
             if (p) hipFree(p);
         if (d_slot_of) hipFree(d_slot_of);
-        for (void *p : {(void *)d_Wx, (void *)d_Memx, (void *)d_init_rows, (void *)d_ids_x})
+        for (void *p : {(void *)d_Wx, (void *)d_Memx, (void *)d_init_rows, (void *)d_ids_x, (void *)d_byte_plane_of, (void *)d_byte_plane_of_input, (void *)d_byte_plane})
             if (p) hipFree(p);
         if (d_inv) hipFree(d_inv);
         for (void *p : {(void *)d_unscale_index, (void *)d_unscale_consts, (void *)d_unscale_plain, (void *)d_scaled_ids})

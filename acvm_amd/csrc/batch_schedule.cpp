@@ -283,7 +283,7 @@ int batch_solve_impl(acvm_batch *b, const void *next_inputs) {
             if (!b->ev_counted) HIPCHK(hipEventCreate(&b->ev_counted));
             HIPCHK(hipEventRecord(b->ev_counted, s));
             launch_import(s, b->d_W, b->Bp, b->B, (const uint8_t *)next_inputs, b->reuse() ? b->d_init_rows : b->d_init_ids, (uint32_t)p.initial_ids.size(),
-                          b->d_event + b->B);  // gate: the count of flagged instances the kernel above left there
+                          b->d_event + b->B, b->d_byte_plane_of_input, b->d_byte_plane);  // gate: the count of flagged instances the kernel above left there
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventSynchronize(b->ev_counted));
         } else HIPCHK(hipStreamSynchronize(s));

@@ -26,8 +26,10 @@ namespace acvm {
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
                                                              const uint8_t *__restrict__ in, const uint32_t *__restrict__ ids,
-                                                             uint32_t n_in, const uint32_t *__restrict__ gate) {
+                                                             uint32_t n_in, const uint32_t *__restrict__ gate, const uint32_t *__restrict__ plane_of_input,
+                                                             uint32_t *__restrict__ plane) {
     __shared__ uint4 tile[4][2][65];
+    __shared__ uint32_t tile_low[4][64];  // byte planes (plan.hpp): low 29 bits of the canonical value | is-byte << 31
     if (gate && *gate != 0u) return;  // (block-uniform)
     const uint32_t t = threadIdx.x;
     const uint64_t j0 = (uint64_t)blockIdx.x * 64u;
@@ -65,6 +67,8 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
                 if (!br) x = d;
             }
             const Fr m = fr_mul(x, fr_r2());
+            const bool is_byte = !(x.v[1] | x.v[2] | x.v[3] | x.v[4] | x.v[5] | x.v[6] | x.v[7]) && x.v[0] < 256u;
+            tile_low[kk][ji] = (x.v[0] & 0x1fffffffu) | (is_byte ? 0x80000000u : 0u);
             tile[kk][0][ji] = make_uint4(m.v[0], m.v[1], m.v[2], m.v[3]);
             tile[kk][1][ji] = make_uint4(m.v[4], m.v[5], m.v[6], m.v[7]);
         }
@@ -79,6 +83,10 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
             const uint4 lo = tile[kk][0][ji], hi = tile[kk][1][ji];
             const Fr m = {{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
             fr_store_nt(W, ids[k], Bp, j, m);
+            if (plane_of_input) {  // (block-uniform per kk: a scalar load)
+                const uint32_t pl = plane_of_input[k];
+                if (pl != 0xFFFFFFFFu) plane[(uint64_t)pl * Bp + j] = tile_low[kk][ji];
+            }
         }
     }
 }
@@ -332,11 +340,12 @@ __global__ void init_assigned_kernel(uint32_t *assigned, uint32_t n_slow, uint32
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate) {
+void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate,
+                   const uint32_t *plane_of_input, uint32_t *plane) {
     if (!B || !n_in) return;
     const dim3 grid((B + 63u) / 64u, (n_in + 3u) / 4u);
-    if (((uintptr_t)in & 15u) == 0) hipLaunchKernelGGL(import_witness_kernel<true>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate);
-    else hipLaunchKernelGGL(import_witness_kernel<false>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate);
+    if (((uintptr_t)in & 15u) == 0) hipLaunchKernelGGL(import_witness_kernel<true>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate, plane_of_input, plane);
+    else hipLaunchKernelGGL(import_witness_kernel<false>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate, plane_of_input, plane);
 }
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out,
                    const Unscale &u, const uint32_t *row_of) {

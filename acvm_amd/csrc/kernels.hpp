@@ -64,6 +64,8 @@ struct DeviceProgram {
     const FcStoreSlot *fc_store;  // device array, one entry per Brillig opcode with a ForeignCall (null: the circuit has none)
     const uint32_t *slot_of;      // witness -> row of the table for the level kernels (null: row = witness index; plan.cpp slot reuse)
     BrilligLimits brillig;        // limits of the Brillig VM for this launch
+    const uint32_t *byte_plane_of; // witness -> its byte plane or NONE (null: the circuit has none; plan.hpp "Byte planes")
+    const uint32_t *byte_plane;    // [plane][instance]: low 29 bits of the canonical value | is-byte << 31, written by the import
 };
 
 // projective witnesses (plan.cpp): device tables behind the export and the hand-over to the exact path
@@ -76,7 +78,9 @@ struct Unscale {
     const uint32_t *event;       // per instance: 0xFFFFFFFF = solved by the level kernels (its column is still scaled)
 };
 
-void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate = nullptr);
+// plane_of_input / plane: per input its byte plane or NONE, and the planes (both null: the circuit has none)
+void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate = nullptr,
+                   const uint32_t *plane_of_input = nullptr, uint32_t *plane = nullptr);
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
                    uint8_t *out, const Unscale &u, const uint32_t *row_of = nullptr);
 void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,

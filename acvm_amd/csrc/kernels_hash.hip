@@ -63,35 +63,60 @@ __device__ __forceinline__ Fr coop_from_byte(uint32_t d, const CoopTables &T) {
     const uint4 lo = T.mont[2u * d], hi = T.mont[2u * d + 1u];
     return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
 }
+// An input of a record on its way into the message: the witness's row -- or, for an initial witness with a byte plane (plan.hpp "Byte planes"), the
+// 4-byte word the import left beside the row: the low limb and the is-byte flag coop_low_limb would form from the row's 32 bytes.
+struct BytePlanes {
+    const uint32_t *of;     // witness -> plane or NONE (null: no planes)
+    const uint32_t *plane;  // [plane][instance]
+};
+struct CoopIn {
+    Fr row;
+    uint32_t word;
+    bool planar;  // wave-uniform
+};
+__device__ __forceinline__ CoopIn coop_get(const FastPolicy &p, uint32_t w, const BytePlanes &bp) {
+    const uint32_t pl = bp.of ? bp.of[w] : 0xFFFFFFFFu;  // (a scalar load: w is wave-uniform)
+    CoopIn a;
+    a.planar = pl != 0xFFFFFFFFu;
+    a.word = 0;
+    if (a.planar) a.word = __builtin_nontemporal_load(bp.plane + (uint64_t)pl * p.Bp + p.j);
+    else a.row = p.load(w);
+    return a;
+}
+__device__ __forceinline__ uint32_t coop_take(const CoopIn &a, const CoopTables &T, bool &is_byte) {
+    if (!a.planar) return coop_low_limb(a.row, T, is_byte);
+    is_byte = (a.word >> 31) != 0u;
+    return a.word & 0x1fffffffu;
+}
 // Rows of a record into its LDS message, four in flight per lane: the inputs list[k] (list == nullptr: input k itself) for k = w, w + nw, ... < count
 // (w, nw, count, the list and the record are wave-uniform). Fused RANGE checks ride along.
 __device__ __forceinline__ void coop_fetch_rows(const FastPolicy &p, const uint32_t *__restrict__ ins, const uint32_t *__restrict__ ranges,
                                                 const uint32_t *__restrict__ list, uint32_t count, uint32_t w, uint32_t nw, uint8_t *bytes, uint32_t lane,
-                                                const CoopTables &T, uint32_t &range_bad) {
+                                                const CoopTables &T, uint32_t &range_bad, const BytePlanes &bp) {
     for (uint32_t k = w; k < count; k += 4u * nw) {
         const uint32_t k1 = k + nw, k2 = k + 2u * nw, k3 = k + 3u * nw;
         const uint32_t i0 = list ? list[k] : k, i1 = k1 < count ? (list ? list[k1] : k1) : 0u, i2 = k2 < count ? (list ? list[k2] : k2) : 0u,
                        i3 = k3 < count ? (list ? list[k3] : k3) : 0u;
-        Fr a0 = p.load(ins[2u * i0]), a1 = a0, a2 = a0, a3 = a0;
-        if (k1 < count) a1 = p.load(ins[2u * i1]);
-        if (k2 < count) a2 = p.load(ins[2u * i2]);
-        if (k3 < count) a3 = p.load(ins[2u * i3]);
+        CoopIn a0 = coop_get(p, ins[2u * i0], bp), a1 = a0, a2 = a0, a3 = a0;
+        if (k1 < count) a1 = coop_get(p, ins[2u * i1], bp);
+        if (k2 < count) a2 = coop_get(p, ins[2u * i2], bp);
+        if (k3 < count) a3 = coop_get(p, ins[2u * i3], bp);
         bool b0, b1 = true, b2 = true, b3 = true;  // the value is a byte (then l is that byte)
-        const uint32_t l0 = coop_low_limb(a0, T, b0);
+        const uint32_t l0 = coop_take(a0, T, b0);
         bytes[4u * ((i0 >> 2) * 64u + lane) + (i0 & 3u)] = (uint8_t)l0;
         if (ranges) range_bad = min(range_bad, range_check(ranges, i0, b0, l0));
         if (k1 < count) {
-            const uint32_t l1 = coop_low_limb(a1, T, b1);
+            const uint32_t l1 = coop_take(a1, T, b1);
             bytes[4u * ((i1 >> 2) * 64u + lane) + (i1 & 3u)] = (uint8_t)l1;
             if (ranges) range_bad = min(range_bad, range_check(ranges, i1, b1, l1));
         }
         if (k2 < count) {
-            const uint32_t l2 = coop_low_limb(a2, T, b2);
+            const uint32_t l2 = coop_take(a2, T, b2);
             bytes[4u * ((i2 >> 2) * 64u + lane) + (i2 & 3u)] = (uint8_t)l2;
             if (ranges) range_bad = min(range_bad, range_check(ranges, i2, b2, l2));
         }
         if (k3 < count) {
-            const uint32_t l3 = coop_low_limb(a3, T, b3);
+            const uint32_t l3 = coop_take(a3, T, b3);
             bytes[4u * ((i3 >> 2) * 64u + lane) + (i3 & 3u)] = (uint8_t)l3;
             if (ranges) range_bad = min(range_bad, range_check(ranges, i3, b3, l3));
         }
@@ -128,8 +153,10 @@ __device__ __forceinline__ bool coop_store_outputs(const FastPolicy &p, const ui
 template <int WAVES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ event,
-                       const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of, uint32_t buf_words, uint32_t n_buf) {
+                       const uint32_t *__restrict__ prog, const uint32_t *__restrict__ slot_of, uint32_t buf_words, uint32_t n_buf,
+                       const uint32_t *__restrict__ plane_of, const uint32_t *__restrict__ plane) {
     extern __shared__ uint32_t lds[];
+    const BytePlanes bp{plane_of, plane};
     __shared__ uint4 lds_mont[512];
     __shared__ uint32_t lds_key[256];
     constexpr bool PIPE = WAVES > 1;
@@ -162,7 +189,7 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__rest
         const uint32_t n_in = rec[3];
         const uint32_t *ins = rec + 6, *ranges = (rec[2] & HASH_RANGE_FLAG) ? ins + 2u * n_in + 64u : nullptr;
         // (the bytes behind the message in its last word are never read: LdsMsg::word_le masks them)
-        coop_fetch_rows(p, ins, ranges, nullptr, n_in, w, WAVES, (uint8_t *)item, lane, T, range_bad);
+        coop_fetch_rows(p, ins, ranges, nullptr, n_in, w, WAVES, (uint8_t *)item, lane, T, range_bad, bp);
     }
     sync();
     for (;;) {
@@ -189,7 +216,7 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__rest
         } else if (PIPE) {  // beside the hash: the predecessor's outputs, the successor's rows
             if (pend_outs && live && !coop_store_outputs(p, pend_outs, lds_dig[dcur ^ 1u], w - 1u, WAVES - 1, lane, T)) conflict = min(conflict, pend_opcode);
             if (more && two) {
-                coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w - 1u, WAVES - 1, (uint8_t *)nmsg, lane, T, range_bad);
+                coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w - 1u, WAVES - 1, (uint8_t *)nmsg, lane, T, range_bad, bp);
             }
         }
         sync();  // the digest is in LDS (and the message has been read)
@@ -202,7 +229,7 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__rest
         }
         // the successor's message: its rows (unless they came in beside the hash), then the digest bytes it reads
         if (!two) {
-            coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w, WAVES, (uint8_t *)nmsg, lane, T, range_bad);
+            coop_fetch_rows(p, nins, nranges, link + 1u + n_next + 1u, link[1u + n_next], w, WAVES, (uint8_t *)nmsg, lane, T, range_bad, bp);
         }
         coop_copy_chained(link + 1u, nranges, n_next, w, WAVES, lds_dig[dcur], (uint8_t *)nmsg, lane, range_bad);
         rec = nrec;
@@ -231,8 +258,8 @@ void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, co
     const size_t item_bytes = ((size_t)n_buf * buf_words * 64u + (four ? 1024u : 512u)) * 4u;
     for (uint32_t done = 0; done < n;) {  // gridDim.y is limited to 65535
         const uint32_t m = n - done > 65535u ? 65535u : n - done;
-        if (four) hipLaunchKernelGGL(hash_coop_level_kernel<4>, dim3(groups_b, m), dim3(256), item_bytes, s, W, Bp, B, offsets + done, event, dp.prog, dp.slot_of, buf_words, n_buf);
-        else hipLaunchKernelGGL(hash_coop_level_kernel<1>, dim3((groups_b + 3u) / 4u, m), dim3(256), 4u * item_bytes, s, W, Bp, B, offsets + done, event, dp.prog, dp.slot_of, buf_words, n_buf);
+        if (four) hipLaunchKernelGGL(hash_coop_level_kernel<4>, dim3(groups_b, m), dim3(256), item_bytes, s, W, Bp, B, offsets + done, event, dp.prog, dp.slot_of, buf_words, n_buf, dp.byte_plane_of, dp.byte_plane);
+        else hipLaunchKernelGGL(hash_coop_level_kernel<1>, dim3((groups_b + 3u) / 4u, m), dim3(256), 4u * item_bytes, s, W, Bp, B, offsets + done, event, dp.prog, dp.slot_of, buf_words, n_buf, dp.byte_plane_of, dp.byte_plane);
         done += m;
     }
 }

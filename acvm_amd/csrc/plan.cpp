@@ -411,6 +411,13 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                                        b.func == BB_KECCAK256_VAR ? b.in[1][0].witness : 0xFFFFFFFFu});
                     for (auto &in : b.in[0]) { s.push_back(in.witness); s.push_back(in.num_bits); }
                     for (uint32_t w : b.out) out(w);
+                    if (coop && tune.byte_plane)  // its inputs that are initial witnesses: a byte plane each (plan.hpp)
+                        for (auto &in : b.in[0])
+                            if (p.producer[in.witness] == 0xFFFFFFFEu) {
+                                if (p.byte_plane_of.empty()) p.byte_plane_of.assign(nw, 0xFFFFFFFFu);
+                                if (p.byte_plane_of[in.witness] == 0xFFFFFFFFu) p.byte_plane_of[in.witness] = p.n_byte_planes++;
+                                p.n_byte_plane_reads++;
+                            }
                     break;
                 }
                 case BB_PEDERSEN:

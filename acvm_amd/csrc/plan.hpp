@@ -60,6 +60,12 @@ struct Plan {
     uint32_t n_witnesses = 0;
     uint32_t n_opcodes = 0;
     std::vector<uint32_t> initial_ids;
+    // Byte planes: an initial witness that a byte-message hash of the level schedule reads (PLAN_HASH_COOP_FLAG: every input one byte wide) gets a
+    // 4-byte copy per instance beside its row -- bits 0-28 the low 29 bits of the canonical value, bit 31 set when the value is a byte -- written by the
+    // import (kernels.hip) and read by the hash kernel in place of the 32-byte row (kernels_hash.hip). byte_plane_of: per witness, its plane or NONE
+    // (empty when the circuit has none).
+    std::vector<uint32_t> byte_plane_of;
+    uint32_t n_byte_planes = 0, n_byte_plane_reads = 0;  // planes; inputs of hash records that are read from one (4 bytes instead of a 32-byte row)
     // ---- arithmetic level program
     std::vector<uint32_t> gate_stream;          // all gate records
     std::vector<uint32_t> gate_offset;          // per scheduled ASSERT/SOLVE gate: offset into gate_stream (level-major)

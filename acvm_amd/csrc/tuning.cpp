@@ -11,7 +11,7 @@ namespace {
 struct Key { const char *name; int64_t Tuning::*field; };
 const Key KEYS[] = {
     {"scale", &Tuning::scale}, {"relax", &Tuning::relax}, {"pedersen_bundle", &Tuning::pedersen_bundle}, {"pedersen_bundle_waves", &Tuning::pedersen_bundle_waves}, {"pairs", &Tuning::pairs}, {"chains", &Tuning::chains}, {"max_tails", &Tuning::max_tails},
-    {"inv_epoch", &Tuning::inv_epoch}, {"inv_latency", &Tuning::inv_latency}, {"inv_chunk", &Tuning::inv_chunk}, {"heavy_epoch", &Tuning::heavy_epoch}, {"heavy_latency", &Tuning::heavy_latency},
+    {"inv_epoch", &Tuning::inv_epoch}, {"inv_latency", &Tuning::inv_latency}, {"inv_chunk", &Tuning::inv_chunk}, {"byte_plane", &Tuning::byte_plane}, {"heavy_epoch", &Tuning::heavy_epoch}, {"heavy_latency", &Tuning::heavy_latency},
     {"pedersen_latency", &Tuning::pedersen_latency}, {"pedersen_epoch", &Tuning::pedersen_epoch}, {"digest_epoch", &Tuning::digest_epoch}, {"range_fuse", &Tuning::range_fuse},
     {"range_merge", &Tuning::range_merge}, {"hash_chain", &Tuning::hash_chain}, {"brillig_inline", &Tuning::brillig_inline},
     {"pedersen_waves", &Tuning::pedersen_waves}, {"pedersen_prio", &Tuning::pedersen_prio}, {"light_fuse", &Tuning::light_fuse}, {"brillig_mem_cells", &Tuning::brillig_mem_cells}, {"overlap", &Tuning::overlap}, {"heavy_streams", &Tuning::heavy_streams}, {"heavy_only_streams", &Tuning::heavy_only_streams},

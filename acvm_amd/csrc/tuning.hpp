@@ -16,6 +16,7 @@ struct Tuning {
     int64_t chains = 1;            // ... and behind a tail of that wave
     int64_t max_tails = 5;         // records behind the host of a wave program
     int64_t inv_epoch = 4;         // levels per batch of denominator inversions
+    int64_t byte_plane = 1;        // initial witnesses that byte-message hashes read get a second, 4-byte copy (low limb + is-byte flag) written by the import: the hash kernel reads 4 bytes per input instead of 32
     int64_t inv_chunk = 128;       // denominators per wave of an inversion batch at most (they share ONE field inversion; 64 -> 128: +0.9 % on the headline)
     int64_t inv_latency = 1;       // levels of slack between an inversion batch and the first gate that reads it
     int64_t heavy_epoch = 1;       // heavy records launched every K-th level only

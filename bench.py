@@ -359,6 +359,9 @@ def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
             "inverse_batch_kernel": (dyn_ms, st["dyn_algorithmic_bytes_per_instance"], 0)}
     for k in range(4):
         cand[CLASS_KERNEL[k]] = (cls_ms[k], st["class_algorithmic_bytes_per_instance"][k], 0)
+    # byte planes (acvm_amd.h acvm_stats_t): the hash kernel reads 4 bytes instead of a 32-byte row for those inputs -- its own bytes, not the reference's unit
+    saved = 28 * st.get("n_byte_plane_reads", 0)
+    cand[CLASS_KERNEL[1]] = (cls_ms[1], st["class_algorithmic_bytes_per_instance"][1] - saved, 0)
     dominant = "arith_level_kernel" if args.workload in ("arith", "config5") else max(cand, key=lambda k: cand[k][0])
     k_ms, k_bytes, k_launches = cand[dominant]
     if dominant in ALU_KERNELS and st["solve_device_ms"] > 0 and k_ms > st["solve_device_ms"]:
@@ -436,6 +439,11 @@ def run_leg(name, total_log2=16, tile_log2=16, steps=3, warmup=2, pmc=True):
     st = batch.stats()
     batch.set_profiling(False)
     roof, alu = roofline_block(a, st, tile, 1, None, pmc=pmc)
+    # the whole step against the HBM peak: what the import moves (the caller's 32 bytes in, the row out, 4 bytes per byte plane) + the solve's bytes
+    step_bytes = (len(ids) * 64 + 4 * st.get("n_byte_planes", 0) + st["algorithmic_bytes_per_instance"] - 28 * st.get("n_byte_plane_reads", 0)) * tile
+    step_ms = elapsed / steps / n_tiles * 1e3
+    roof["per_step"] = {"bytes_per_tile": step_bytes, "ms_per_tile": step_ms, "achieved": step_bytes / (step_ms / 1e3) / 1e9, "unit": "GB/s",
+                        "frac": step_bytes / (step_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "what": "import of the tile's resident inputs + every kernel of its solve, wall clock"}
     cpu, parity = cpu_baseline_and_parity(a, data, ids, values, batch, sh, tile, len(ids) * 32, None)
     sh.free()
     out = {"workload": wname, "value": n * steps / elapsed, "unit": "witnesses/s", "instances": n, "tile_instances": tile, "steps": steps,

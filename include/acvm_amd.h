@@ -161,6 +161,10 @@ typedef struct {
     /* relaxed rows (ABI 5): SOLVE gates that store their result as the column scan left it (any representative below 2^256) / after one
      * quotient-estimate reduction (below 1.03 p) / canonical; the largest bound a gate's result reaches, in units of p / 256 */
     uint32_t n_gate_out_asis, n_gate_out_weak, n_gate_out_canon, max_gate_bound;
+    /* byte planes (ABI 5): initial witnesses that byte-message hashes read carry a 4-byte copy per instance (low limb + is-byte flag) written by the
+     * import; n_byte_plane_reads inputs of hash records read it in place of the 32-byte row. The algorithmic-byte figures above keep the reference's
+     * unit (32 bytes per witness read): what the hash kernel itself moves is 28 bytes less per such input, what the import moves 4 bytes more per plane. */
+    uint32_t n_byte_planes, n_byte_plane_reads;
 } acvm_stats_t;
 
 const char *acvm_last_error(void);

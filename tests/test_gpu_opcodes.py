@@ -224,6 +224,34 @@ def test_hash_byte_messages_four_wave_kernel(oracle):
     assert all(x.opcode_index == 2 for x in ores if x.status == 2)
 
 
+def test_hash_inputs_from_byte_planes(oracle):
+    """Initial witnesses that byte-message hashes read carry a 4-byte copy written by the import (plan.hpp "Byte planes": low 29 bits of the canonical
+    value + is-byte flag), which the hash kernel reads in place of the row: values around every boundary of that word (255 / 256, 2^29 - 1 / 2^29 /
+    2^29 + 5, p - 1, 0), fused RANGE checks of 7 and 8 bits on them, a witness shared by two hashes and an arithmetic gate (which reads the ROW), the
+    same circuit with the planes switched off, and the planner's counts."""
+    import acvm_amd
+    r = rnd(4242)
+    n = 37
+    ids = list(range(1, n + 1))
+    o = n + 1
+    ops = [BB("RANGE", {"input": FI(w, 8 if w % 3 else 7)}) for w in ids[:20]]
+    ops += [BB("SHA256", {"inputs": [FI(w, 8) for w in ids], "outputs": list(range(o, o + 32))}),
+            BB("Keccak256", {"inputs": [FI(w, 8) for w in ids[5:30]], "outputs": list(range(o + 32, o + 64))}),
+            E([(1, 3, 4)], [(1, 5), (P - 1, o + 64)], 9)]
+    circ = Circuit(o + 64, ops)
+    edge = [0, 1, 127, 128, 255, 256, 257, (1 << 29) - 1, 1 << 29, (1 << 29) + 5, P - 1, P - 256, 1 << 200]
+    rows = [[r.randrange(128 if (w <= 20 and w % 3 == 0) else 256) for w in ids] for _ in range(150)]  # (the 7-bit checks pass)
+    for j in range(40, 150):  # one edge value somewhere in the message (most of them fail a RANGE check or only change the low byte)
+        rows[j][r.randrange(n)] = edge[j % len(edge)]
+    ores, _ = both_paths(oracle, circ, ids, rows)
+    assert sum(1 for x in ores if x.status == 0) >= 40 and sum(1 for x in ores if x.status == 2) >= 20
+    st = acvm_amd.Circuit(circ.to_bytes()).plan_stats(ids)
+    assert st["n_byte_planes"] == n and st["n_byte_plane_reads"] == n + 25
+    with acvm_amd.tuning(byte_plane=0):
+        assert acvm_amd.Circuit(circ.to_bytes()).plan_stats(ids)["n_byte_planes"] == 0
+        both_paths(oracle, circ, ids, rows)
+
+
 @pytest.mark.parametrize("n", [1023, 1024, 1025])
 def test_hash_byte_message_length_limit(oracle, n):
     """1024 bytes is the longest message the four-wave kernel takes (16 KiB of LDS per 64 instances); 1025 goes lane-per-instance."""

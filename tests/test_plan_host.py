@@ -49,6 +49,10 @@ def test_exact_bytes_of_small_circuit():
     assert st["algorithmic_bytes_per_instance"] == 96 + 96 + 32 + 34 * 32
     assert st["class_algorithmic_bytes_per_instance"] == [32, 34 * 32, 0, 0]
     assert st["n_levels"] == 2 and st["n_fast_gates"] == 2 and st["n_other_records"] == 2
+    # the two message bytes are initial witnesses: each gets a byte plane (a 4-byte copy for the hash kernel; the byte figures keep the reference's unit)
+    assert st["n_byte_planes"] == 2 and st["n_byte_plane_reads"] == 2
+    with acvm_amd.tuning(byte_plane=0):
+        assert stats(Circuit(35, ops), [1, 2])["n_byte_planes"] == 0
 
 
 def test_memory_blocks_are_chained_in_program_order():

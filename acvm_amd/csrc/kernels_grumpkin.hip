@@ -36,6 +36,23 @@ void launch_grumpkin_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, con
 // partial points to combine -- the three Jacobian additions of every step are 12 % of a commitment's products -- no LDS, no barriers.
 // Alone on the device (tools/t_pedersen_sweep.py): 8 records x 2^16 instances 3.41 -> 2.61 ms, 1 record x 2^16 0.56 -> 0.44 ms, equal at 512
 // groups, and below that the four-wave form wins on latency (64 groups: 0.22 against 0.37 ms).
+// Table additions of one operand of a hash_pair onto acc: windows [i0, i1) of the value's GRUMPKIN_PEDW_WINDOWS (the window table: GRUMPKIN_PEDW_BITS bits of
+// the scalar per addition), or -- without that table -- generators [i0, i1) of its 15 through the pair table (one entry per 18 bits: even slice through the
+// endomorphism + odd slice). parity 0: the left operand's half of the tables. Shared by the level Pedersen kernels below.
+__device__ __forceinline__ GJac pedersen_walk(const GrumpkinTables &T, GJac acc, const Fr &src, uint32_t parity, uint32_t i0, uint32_t i1) {
+    const Fr v = fr_to_canonical(src);
+    if (T.pedw != nullptr) {
+        for (uint32_t jw = i0; jw < i1; jw++)
+            acc = gj_add_aff(acc, gaff_load(T.pedw, ((parity * GRUMPKIN_PEDW_WINDOWS + jw) << GRUMPKIN_PEDW_BITS) | bits_at(v, GRUMPKIN_PEDW_BITS * jw, GRUMPKIN_PEDW_BITS)));
+        return acc;
+    }
+    const uint32_t gen0 = parity ? 15u : 0u;
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
+        acc = gj_add_aff(acc, gaff_load(T.ped2, ((gen0 + i) << GRUMPKIN_PED2_LOG2) | a << 9 | b));
+    }
+    return acc;
+}
 // (WAVES = 1 is launched in workgroups of PED1_GROUP independent waves)
 constexpr int PED1_GROUP = 4;
 template <int WAVES>
@@ -63,24 +80,8 @@ pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, 
     // point. Step 1 therefore only walks the 15 generators of the first input (4, 4, 4, 3 per wave) and adds the seed point;
     // from step 2 on, wave w takes generators [0, 8) or [8, 15) (w & 1) of the running value or of the next input (w >> 1).
     Fr r = fr_zero(), y = fr_zero();
-    // one pair-table entry per 18 bits (even slice through the endomorphism + odd slice): generators [i0, i1) of one operand onto acc
-    // (with the window table the same routine walks windows [i0, i1) of the value's 12: GRUMPKIN_PEDW_BITS bits of the scalar per addition)
-    const bool win = T.pedw != nullptr;
-    const uint32_t n_units = win ? GRUMPKIN_PEDW_WINDOWS : 15u;  // table additions per operand
-    auto walk = [&](GJac acc, const Fr &src, uint32_t parity, uint32_t i0, uint32_t i1) {
-        const Fr v = fr_to_canonical(src);
-        if (win) {
-            for (uint32_t jw = i0; jw < i1; jw++)
-                acc = gj_add_aff(acc, gaff_load(T.pedw, ((parity * GRUMPKIN_PEDW_WINDOWS + jw) << GRUMPKIN_PEDW_BITS) | bits_at(v, GRUMPKIN_PEDW_BITS * jw, GRUMPKIN_PEDW_BITS)));
-            return acc;
-        }
-        const uint32_t gen0 = parity ? 15u : 0u;
-        for (uint32_t i = i0; i < i1; i++) {
-            const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
-            acc = gj_add_aff(acc, gaff_load(T.ped2, ((gen0 + i) << GRUMPKIN_PED2_LOG2) | a << 9 | b));
-        }
-        return acc;
-    };
+    const uint32_t n_units = T.pedw != nullptr ? GRUMPKIN_PEDW_WINDOWS : 15u;  // table additions per operand (pedersen_walk)
+    auto walk = [&](GJac acc, const Fr &src, uint32_t parity, uint32_t i0, uint32_t i1) { return pedersen_walk(T, acc, src, parity, i0, i1); };
     for (uint32_t step = 1; step <= n; step++) {
         if constexpr (WAVES == 1) {
             // (ONE call site of the walk: two make the compiler keep it as a function, whose by-value points travel through the lane's scratch)
@@ -172,22 +173,8 @@ pedersen_bundle_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp
     const uint32_t b0 = blockIdx.y * K, nb = min(K, n_records - b0);  // K <= PED_BUNDLE records per wave
     const GrumpkinTables &T = dp.grumpkin;
     FastPolicy p{W, Bp, j, slot_of};
-    const bool win = T.pedw != nullptr;
-    const uint32_t n_units = win ? GRUMPKIN_PEDW_WINDOWS : 15u;
-    auto walk = [&](GJac acc, const Fr &src, uint32_t parity) {
-        const Fr v = fr_to_canonical(src);
-        if (win) {
-            for (uint32_t jw = 0; jw < n_units; jw++)
-                acc = gj_add_aff(acc, gaff_load(T.pedw, ((parity * GRUMPKIN_PEDW_WINDOWS + jw) << GRUMPKIN_PEDW_BITS) | bits_at(v, GRUMPKIN_PEDW_BITS * jw, GRUMPKIN_PEDW_BITS)));
-            return acc;
-        }
-        const uint32_t gen0 = parity ? 15u : 0u;
-        for (uint32_t i = 0; i < n_units; i++) {
-            const uint32_t a = bits_at(v, 18u * i, 9), b = i < 14u ? bits_at(v, 18u * i + 9u, 9) : 0u;
-            acc = gj_add_aff(acc, gaff_load(T.ped2, ((gen0 + i) << GRUMPKIN_PED2_LOG2) | a << 9 | b));
-        }
-        return acc;
-    };
+    const uint32_t n_units = T.pedw != nullptr ? GRUMPKIN_PEDW_WINDOWS : 15u;
+    auto walk = [&](GJac acc, const Fr &src, uint32_t parity) { return pedersen_walk(T, acc, src, parity, 0u, n_units); };
     auto park = [&](uint32_t i, uint32_t w) -> uint32_t * { return scratch + ((uint64_t)soff[2u * (b0 + i)] + w) * Bp + j; };
     auto park_get29 = [&](uint32_t i, uint32_t w0) { Fr29 r; for (int k = 0; k < 9; k++) r.v[k] = *park(i, w0 + k); return r; };
     auto park_put29 = [&](uint32_t i, uint32_t w0, const Fr29 &v) { for (int k = 0; k < 9; k++) *park(i, w0 + k) = v.v[k]; };

@@ -377,13 +377,13 @@ static int batch_init(acvm_batch *b) {
     if (p.needs_grumpkin) {
         // the level schedule's Pedersen kernel reads the 503 MB pair table (one mixed addition per 18 bits of input)
         const bool pairs = !p.cls_offset[CLS_PEDERSEN].empty();
-        const bool windows = pairs && p.tune.pedersen_window_bits == (int64_t)GRUMPKIN_PEDW_BITS;  // 6.4 GB of 22-bit windows instead of the 503 MB of pairs
+        const bool windows = pairs && p.tune.pedersen_window_bits != 0;  // 23.6 GB of 24-bit windows (GRUMPKIN_PEDW_BITS) instead of the 503 MB of pairs
         bool windows_built = false, have = false;
         GrumpkinTables tabs;
         const GrumpkinTables *t = &tabs;
         if (windows) {
             have = windows_built = grumpkin_window_table(&tabs);
-            if (!have) (void)hipGetLastError();  // (no room for 6.4 GB beside what the process holds: the pair table serves the same kernel)
+            if (!have) (void)hipGetLastError();  // (no room for the window table beside what the process holds: the pair table serves the same kernel)
         }
         if (!have) have = pairs ? grumpkin_pair_table(&tabs) : grumpkin_tables(&tabs);
         if (!have) return set_err(ACVM_E_DEVICE, "could not build the Grumpkin tables on the device");

@@ -19,7 +19,7 @@ struct GrumpkinTables {
     const uint4 *skew;   // [3]: D[3j+2]
     const uint4 *ped2;   // [30][512][512] pair table of the level Pedersen kernel (grumpkin_pair_table), else nullptr
     const uint4 *win16;  // [4][16][65535] 16-bit windows of the same four bases: T[w][d-1] = d * 2^(16w) * P (built on the device: 268 MB)
-    const uint4 *pedw;   // [2][12][2^22] window table of the level Pedersen kernel (grumpkin_window_table), else nullptr
+    const uint4 *pedw;   // [2][11][2^24] window table of the level Pedersen kernel (grumpkin_window_table), else nullptr
 };
 static constexpr uint32_t GRUMPKIN_WIN16_STRIDE = 16 * 65535;  // points per base
 static constexpr uint32_t GRUMPKIN_PED2_LOG2 = 18;  // entries per generator
@@ -32,11 +32,15 @@ bool grumpkin_tables(GrumpkinTables *out);
 // hash_single (the even slice goes through the endomorphism), so that the level kernel pays one mixed addition per 18 bits
 // instead of two. For the last generator of a value (g % 15 == 14, one slice only) the entry is beta((a + 1) D[g]).
 bool grumpkin_pair_table(GrumpkinTables *out);
-// ... and with pedw built (6.4 GB, generated on the device on first use). The slices of hash_single are linear in the bits of the scalar -- a slice
+// ... and with pedw built (23.6 GB, generated on the device on first use; 6.4 GB with round 3's 22-bit windows). The slices of hash_single are linear in the bits of the scalar -- a slice
 // a of generator D contributes (a + 1) D = a_hi 2^k D + a_lo D + D -- so the 29 slices (261 bits) of a value can be cut at ANY bit: entry [parity][j][v]
-// is the joint contribution of bits [22 j, 22 j + 22) of the scalar (the pieces of the two to four slices the window touches, the even slices through
-// the endomorphism, plus the `+ 1` of every slice that starts inside the window): 12 mixed additions per hash_single instead of the pair table's 15.
-static constexpr uint32_t GRUMPKIN_PEDW_BITS = 22, GRUMPKIN_PEDW_WINDOWS = 12;
+// is the joint contribution of bits [24 j, 24 j + 24) of the scalar (the pieces of the two to four slices the window touches, the even slices through
+// the endomorphism, plus the `+ 1` of every slice that starts inside the window): 11 mixed additions per hash_single instead of the pair table's 15 (12 with 22-bit windows).
+#ifndef GRUMPKIN_PEDW_BITS_V  // (tools/build_variant.sh -DGRUMPKIN_PEDW_BITS_V=22: round 3's 12 windows of 22 bits, a 6.4 GB table; the A/B is in DESIGN.md section 9)
+#define GRUMPKIN_PEDW_BITS_V 24
+#endif
+static constexpr uint32_t GRUMPKIN_PEDW_BITS = GRUMPKIN_PEDW_BITS_V, GRUMPKIN_PEDW_WINDOWS = (261 + GRUMPKIN_PEDW_BITS - 1) / GRUMPKIN_PEDW_BITS;
+static_assert(GRUMPKIN_PEDW_BITS >= 9 && GRUMPKIN_PEDW_BITS <= 26, "window of the level Pedersen kernel");
 bool grumpkin_window_table(GrumpkinTables *out);
 bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]);
 // generator tables of the two ECDSA curves on the current device (kernels_ecdsa.hip builds them), nullptr on failure

@@ -146,7 +146,7 @@ uint32_t auto_tile(const acvm_circuit_t *c, const std::vector<uint32_t> &ids, co
     const Plan p = build_plan(*c->c, ids.data(), (uint32_t)ids.size(), opts);
     if (!p.unsupported.empty()) { set_err(ACVM_E_UNSUPPORTED, p.unsupported); return 0; }
     const bool pedersen_level = !p.cls_offset[CLS_PEDERSEN].empty();
-    const bool window_table = pedersen_level && p.tune.pedersen_window_bits == (int64_t)GRUMPKIN_PEDW_BITS;
+    const bool window_table = pedersen_level && p.tune.pedersen_window_bits != 0;
     double budget = 1e30;
     for (int d : devices) {
         size_t free_b = 0, total_b = 0;

@@ -50,7 +50,7 @@ struct Tuning {
     int64_t brillig_call_depth = 64, brillig_call_depth_max = 1 << 16;
     int64_t brillig_mem_max_log2 = 22;  // cells of one lane's memory on the exact path at most (32 B each)
     // ---- tables (grumpkin_host.cpp)
-    int64_t pedersen_window_bits = 22; // 22 (0: off): the level Pedersen kernel reads 22-bit windows (6.4 GB of tables, 12 additions per hash_single) instead of slice pairs (503 MB, 15)
+    int64_t pedersen_window_bits = 24; // nonzero: the level Pedersen kernel reads 24-bit windows of the scalar (GRUMPKIN_PEDW_BITS: 23.6 GB of tables, 11 additions per hash_single) instead of slice pairs (0: 503 MB, 15)
     int64_t win16 = 1;             // 16-bit window tables of the four fixed bases
     int64_t tables_keep = 1;       // 1: a device's lookup tables stay until acvm_device_release_tables; 0: the last handle of the device frees them
 };

@@ -176,7 +176,7 @@ int acvm_device_synchronize(void);
 int acvm_device_arch(char *out, size_t out_len);
 /*
  * The per-device lookup tables (Grumpkin: 3 MB of fixed-base and Pedersen slice tables, 268 MB of 16-bit windows, the 503 MB pair table
- * or the 6.4 GB window table of the level Pedersen kernel; ECDSA: 2 x 64 MiB of generator windows) are built on the device at the first
+ * or the 23.6 GB window table of the level Pedersen kernel; ECDSA: 2 x 64 MiB of generator windows) are built on the device at the first
  * handle whose circuit needs them -- under a lock of that device only, on a stream of their own -- and shared by every later handle of the
  * device. They stay until this call: frees the tables of `device` and returns the bytes given back, or ACVM_E_STATE while a handle of
  * that device still uses them (free the handles first). The next handle that needs a table rebuilds it (0.3 s for the largest).

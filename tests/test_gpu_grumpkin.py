@@ -138,20 +138,27 @@ def test_schnorr_short_signature_panics(oracle):
     assert ores[0].err == oracle.E_PANIC
 
 
-def test_pedersen_pair_table_sweep():
-    """Every (even slice, odd slice) combination of the level kernel's 503 MB pair table: instance k carries the 18-bit
-    pattern k in all of its slice pairs (generators 15..27 of the input's table; the chained hash output exercises random
-    entries of the other half), and the level path must agree bit for bit with the exact in-order kernel, which adds the
-    two 512-entry table points separately (and is pinned to the oracle and the reference vectors by the tests above)."""
+@pytest.mark.parametrize("pattern", ["slice_pairs", "windows"])
+def test_pedersen_pair_table_sweep(pattern):
+    """The level kernel's lookup tables against the exact in-order kernel, which adds the two 512-entry table points of every slice pair
+    separately (and is pinned to the oracle and the reference vectors by the tests above), bit for bit over 2^18 instances.
+    slice_pairs: instance k carries the 18-bit pattern k in all of its slice pairs -- every (even slice, odd slice) combination of the 503 MB
+    pair table, and as many different entries of each window of the window table. windows: instance k carries a different 24-bit word in each
+    of the eleven 24-bit windows of the value (a multiplicative hash of k: high bits of the window index included), up to 253 bits.
+    The chained hash output exercises random entries of the other half of the tables."""
     import acvm_amd
     B = 1 << 18
     circ = Circuit(3, [BB("Pedersen", {"inputs": [FI(1, 254)], "domain_separator": 0, "outputs": [2, 3]})])
     k = np.arange(B, dtype=np.uint64)
     vals = np.zeros((B, 1, 32), dtype=np.uint8)
-    # value = sum_i k << 18 i for i < 13 (234 bits): byte-wise assembly through Python ints in blocks of 4096 instances
-    rep = sum(1 << (18 * i) for i in range(13))
+    if pattern == "slice_pairs":
+        # value = sum_i k << 18 i for i < 13 (234 bits): byte-wise assembly through Python ints in blocks of 4096 instances
+        rep = sum(1 << (18 * i) for i in range(13))
+        value = lambda x: x * rep
+    else:
+        value = lambda x: sum((((x * (2 * j + 1) * 0x9E3779B1) >> 7) & 0xFFFFFF) << (24 * j) for j in range(11)) & ((1 << 253) - 1)
     for s in range(0, B, 4096):
-        vals[s:s + 4096, 0] = np.frombuffer(b"".join(be32(int(x) * rep) for x in k[s:s + 4096]), dtype=np.uint8).reshape(-1, 32)
+        vals[s:s + 4096, 0] = np.frombuffer(b"".join(be32(value(int(x))) for x in k[s:s + 4096]), dtype=np.uint8).reshape(-1, 32)
     data = circ.to_bytes()
     out = []
     for force_slow in (False, True):

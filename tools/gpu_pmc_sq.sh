@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_pmc_sq.sh TAG [bench args...] -- instruction-mix counters of the bench kernels (own PMC passes, kernel-trace only)
+# tools/gpu_pmc_sq.sh TAG [bench args...] -- instruction-mix counters of the bench kernels (own PMC passes, kernel-trace only); TOTAL="--total-log2 17" for another batch
 set -u
 TAG=${1:-rXX}
 shift || true
@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/sq_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --inner --total-log2 16 $*"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --inner ${TOTAL:---total-log2 16} $*"
 cd /tmp
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   name=$(echo $set | tr ' ' '_')

@@ -50,7 +50,16 @@ FR_HD __forceinline__ Fr29 gate_coef29(GateWords t) {
 // an operand row, or the wave's `local` registers (wave-uniform branch)
 template <class L>
 FR_HD __forceinline__ Fr29 gate_operand(const L &ld, uint32_t slot, const Fr29 &local) {
-    if (slot == GATE_LOCAL) return local;
+    if (slot == GATE_LOCAL) {
+        Fr29 r = local;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (hipcc otherwise copies the forwarded value into the operand's registers AHEAD of this test -- nine moves in front of every operand fetch, taken
+        // or not: a fortieth of the kernel's instructions; an empty volatile asm cannot be speculated, so the copy stays on the path that needs it)
+#pragma unroll
+        for (int k = 0; k < 9; k++) asm volatile("" : "+v"(r.v[k]));
+#endif
+        return r;
+    }
     return ld.load(slot);
 }
 // the witness side of the k-th multiplied term of the record: the products come first (coef[8], a, b), then the linear terms (coef[8], w);

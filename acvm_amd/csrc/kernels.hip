@@ -175,8 +175,9 @@ __global__ void __launch_bounds__(64) inverse_batch_kernel(const uint4 *__restri
         const uint32_t *__restrict__ g = gate_stream + job_offset[first + i];
         Fr den = fr_load_nt(W, g[0], Bp, j);  // second and last read of the row by this launch
         if (fr_is_zero(den)) den = fr_one();
-        Fr29 inv_i = inv;
-        if (i > 0) inv_i = fr29_mul(inv, fr29_from(fr_load(Inv, gate_stream[job_offset[first + i - 1] + 2], Bp, j)));
+        // (the first job's "prefix before it" is 1: one product more per wave, and no second path for the compiler to merge with 126 register moves per job)
+        const Fr prev = i > 0 ? fr_load(Inv, gate_stream[job_offset[first + i - 1] + 2], Bp, j) : fr_one();
+        const Fr29 inv_i = fr29_mul(inv, fr29_from(prev));
         inv = fr29_mul(inv, fr29_from(den));
         fr_store_nt(Inv, g[2], Bp, j, fr29_pack(inv_i));  // read once, by a gate levels later (the three nontemporal accesses of this path: 5.54 -> 5.565 M witnesses/s)
     }

@@ -11,4 +11,4 @@ steps, warmup = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (
 leg = bench.run_leg(name, total_log2=total, tile_log2=tile, steps=steps, warmup=warmup, pmc=False)
 r = leg["roofline"]
 print(json.dumps({"tuning": os.environ.get("ACVM_TUNING", ""), "value": round(leg["value"]), "ms_per_step": round(leg["ms_per_step"], 2), "solve_only": round(leg["value_solve_only"] or 0),
-                  "frac": r.get("frac"), "kernel_ms": r.get("kernel_ms_per_tile") or r.get("ms"), "parity": leg["parity"].get("ok") if isinstance(leg["parity"], dict) else leg["parity"]}))
+                  "frac": r.get("frac"), "kernel_ms": r.get("kernel_ms_per_tile") or r.get("ms"), "parity": leg["parity"].get("bit_exact") if isinstance(leg["parity"], dict) else leg["parity"]}))

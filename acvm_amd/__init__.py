@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_debug_secp_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
     "acvm_device_release_tables", "acvm_circuit_opcode_kinds", "acvm_batch_error_expression", "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
-    "acvm_debug_cpulist", "acvm_debug_device_locality",
+    "acvm_debug_cpulist", "acvm_debug_device_locality", "acvm_debug_plan_fingerprint", "acvm_circuit_plans_built", "acvm_circuit_check_schedule",
 ]
 
 
@@ -241,6 +241,10 @@ def lib():
     L.acvm_circuit_num_witnesses.argtypes = [C.c_void_p]
     L.acvm_circuit_plan_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Stats)]
     L.acvm_circuit_plan_stats_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Stats)]
+    L.acvm_debug_plan_fingerprint.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32]
+    L.acvm_circuit_plans_built.restype = C.c_uint64
+    L.acvm_circuit_plans_built.argtypes = [C.c_void_p]
+    L.acvm_circuit_check_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
     L.acvm_batch_new.restype = C.c_void_p
     L.acvm_batch_new.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.acvm_batch_new_ex.restype = C.c_void_p
@@ -552,6 +556,38 @@ class Circuit:
         _check(lib().acvm_circuit_plan_stats_ex(self._h, arr, len(ids), (1 if fold_digest else 0) | (2 if reuse_slots else 0), karr, len(keep), C.byref(s)))
         return s.as_dict()
 
+    def plans_built(self) -> int:
+        """how often this circuit handle has been levelised (handles of equal options share one plan)"""
+        return int(lib().acvm_circuit_plans_built(self._h))
+
+    def check_schedule(self, initial_ids, n_instances=4096, fold_digest=False, reuse_slots=False, keep=(), host_solver=False, drop_wait=None) -> dict:
+        """Host-only hazard check of the level schedule a handle of these options would enqueue (acvm_circuit_check_schedule): every
+        launch's reads and writes derived from the record words, happens-before from stream order + events. drop_wait = k leaves the
+        k-th cross-stream wait out (mutation testing). Returns {ok, n_launches, n_waits, n_accesses, n_records, n_findings, report}."""
+        ids = list(initial_ids)
+        arr = (C.c_uint32 * max(len(ids), 1))(*ids)
+        keep = list(keep)
+        karr = (C.c_uint32 * max(len(keep), 1))(*keep)
+        counts = (C.c_uint64 * 8)()
+        text = C.create_string_buffer(1 << 14)
+        rc = lib().acvm_circuit_check_schedule(self._h, arr, len(ids), (1 if fold_digest else 0) | (2 if reuse_slots else 0) | (0x100 if host_solver else 0),
+                                               karr, len(keep), n_instances, 0xFFFFFFFF if drop_wait is None else drop_wait, counts, text, len(text))
+        _check(rc)
+        return {"ok": rc == 0, "n_launches": counts[0], "n_waits": counts[1], "n_accesses": counts[2], "n_records": counts[3], "n_findings": counts[4],
+                "report": text.value.decode()}
+
+    def plan_fingerprint(self, initial_ids, fold_digest=False, reuse_slots=False, keep=(), host_solver=False) -> list:
+        """Host-only: 64-bit fingerprints of the static plan, one per component (acvm_debug_plan_fingerprint)."""
+        ids = list(initial_ids)
+        arr = (C.c_uint32 * max(len(ids), 1))(*ids)
+        keep = list(keep)
+        karr = (C.c_uint32 * max(len(keep), 1))(*keep)
+        out = (C.c_uint64 * 128)()
+        n = lib().acvm_debug_plan_fingerprint(self._h, arr, len(ids), (1 if fold_digest else 0) | (2 if reuse_slots else 0) | (0x100 if host_solver else 0),
+                                              karr, len(keep), out, 128)
+        _check(n)
+        return list(out[:n])
+
 
 class NodeOpts(C.Structure):
     _fields_ = [("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int)), ("tile_instances", C.c_uint32), ("batch_flags", C.c_uint32)]
@@ -561,7 +597,8 @@ class NodeStats(C.Structure):
     _fields_ = [("n_devices", C.c_uint32), ("tile_instances", C.c_uint32), ("n_instances", C.c_uint64), ("total_ms", C.c_double),
                 ("device", C.c_int * 16), ("async_exact", C.c_uint32 * 16), ("tiles", C.c_uint32 * 16), ("exact_instances", C.c_uint32 * 16),
                 ("lane_ms", C.c_double * 16), ("solve_device_ms", C.c_double * 16), ("h2d_wait_ms", C.c_double * 16), ("export_ms", C.c_double * 16),
-                ("numa_node", C.c_int * 16), ("n_cpus_pinned", C.c_uint32 * 16), ("first_cpu", C.c_int * 16)]
+                ("numa_node", C.c_int * 16), ("n_cpus_pinned", C.c_uint32 * 16), ("first_cpu", C.c_int * 16),
+                ("plans_built", C.c_uint32), ("create_ms", C.c_double), ("plan_ms", C.c_double), ("host_rss_bytes", C.c_uint64)]
 
 
 class Node:
@@ -616,6 +653,7 @@ class Node:
         _check(lib().acvm_node_stats(self._h, C.byref(st)))
         n = st.n_devices
         return {"n_devices": n, "tile_instances": st.tile_instances, "n_instances": st.n_instances, "total_ms": st.total_ms,
+                "plans_built": st.plans_built, "create_ms": st.create_ms, "plan_ms": st.plan_ms, "host_rss_bytes": st.host_rss_bytes,
                 **{f: list(getattr(st, f))[:n] for f in ("device", "async_exact", "tiles", "exact_instances", "lane_ms", "solve_device_ms", "h2d_wait_ms", "export_ms", "numa_node", "n_cpus_pinned",
                                                               "first_cpu")}}
 

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacvm_amd.so")
-SOURCES = ["circuit.cpp", "tuning.cpp", "display.cpp", "plan.cpp", "batch.cpp", "batch_schedule.cpp", "batch_exact.cpp", "batch_export.cpp", "probes.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_grumpkin.hip", "grumpkin_host.cpp", "kernels_brillig.hip", "kernels_ecdsa.hip", "shim.cpp", "node.cpp"]
+SOURCES = ["circuit.cpp", "tuning.cpp", "display.cpp", "plan.cpp", "schedule.cpp", "schedule_check.cpp", "batch.cpp", "batch_schedule.cpp", "batch_exact.cpp", "batch_export.cpp", "probes.cpp", "kernels.hip", "kernels_ops.hip", "kernels_hash.hip", "kernels_grumpkin.hip", "grumpkin_host.cpp", "kernels_brillig.hip", "kernels_ecdsa.hip", "shim.cpp", "node.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
          "-ffp-contract=off"] + os.environ.get("ACVM_EXTRA_FLAGS", "").split()

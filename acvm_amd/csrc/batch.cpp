@@ -170,10 +170,111 @@ int acvm_circuit_plan_stats_ex(const acvm_circuit_t *c, const uint32_t *initial_
     opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;
     opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
     opts.keep.assign(keep_ids, keep_ids + n_keep);
-    Plan p = build_plan(*c->c, initial_ids, n_initial, opts);
+    const std::shared_ptr<const Plan> sp = plan_for(c, initial_ids, n_initial, opts);
+    const Plan &p = *sp;
     plan_stats(p, out);
     if (!p.unsupported.empty()) return set_err(ACVM_E_UNSUPPORTED, p.unsupported);
     return 0;
+} ABI_CATCH
+
+// The circuit's plan cache (batch.hpp PlanKey): a hit hands out the shared plan; a miss plans outside the lock (a second thread asking for the
+// same plan meanwhile plans too -- the node driver asks once, before its lanes start).
+std::shared_ptr<const Plan> plan_for(const acvm_circuit *c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
+    PlanKey key;
+    key.ids.assign(initial_ids, initial_ids + n_initial);
+    key.keep = opts.keep;
+    key.host_blackbox = opts.host_blackbox;
+    key.fold_digest = opts.fold_digest;
+    key.reuse_slots = opts.reuse_slots;
+    for (unsigned i = 0; const char *name = tuning_key(i); i++) {
+        int64_t v = 0;
+        tuning_get(name, &v);
+        key.tuning.push_back(v);
+    }
+    {
+        std::lock_guard<std::mutex> g(c->plan_mutex);
+        for (auto it = c->plan_cache.begin(); it != c->plan_cache.end();) {
+            std::shared_ptr<const Plan> sp = it->second.lock();
+            if (!sp) { it = c->plan_cache.erase(it); continue; }
+            if (it->first == key) { c->n_plans_shared++; c->last_plan = sp; return sp; }
+            ++it;
+        }
+    }
+    std::shared_ptr<const Plan> sp = std::make_shared<const Plan>(build_plan(*c->c, initial_ids, n_initial, opts));
+    std::lock_guard<std::mutex> g(c->plan_mutex);
+    c->n_plans_built++;
+    c->plan_cache.push_back({std::move(key), sp});
+    c->last_plan = sp;
+    return sp;
+}
+uint64_t acvm_circuit_plans_built(const acvm_circuit_t *c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> g(c->plan_mutex);
+    return c->n_plans_built;
+}
+
+// Host-only: the hazard checker (schedule_check.cpp) over the level schedule a handle of n_instances instances and these options would
+// enqueue. Returns 0 (proved), 1 (findings: counts[4] of them, the first 32 in `report`) or a negative error. counts: launches, waits,
+// accesses, records, findings. drop_wait: see include/acvm_amd.h.
+int acvm_circuit_check_schedule(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids, uint32_t n_keep,
+                                uint32_t n_instances, uint32_t drop_wait, uint64_t *counts, char *report, size_t report_len) try {
+    if (!c || (n_initial && !initial_ids) || (n_keep && !keep_ids)) return set_err(ACVM_E_INVALID, "null argument");
+    PlanOpts opts;
+    opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;
+    opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
+    opts.host_blackbox = (flags & 0x100u) != 0;
+    opts.keep.assign(keep_ids, keep_ids + n_keep);
+    const std::shared_ptr<const Plan> sp = plan_for(c, initial_ids, n_initial, opts);
+    if (!sp->unsupported.empty()) return set_err(ACVM_E_UNSUPPORTED, sp->unsupported);
+    const LaunchLayout lay = layout_launches(*sp, ((uint64_t)n_instances + 63) / 64 * 64);
+    const LevelSchedule sched = level_schedule(*sp, lay);
+    const ScheduleReport rep = check_level_schedule(*sp, lay, sched, drop_wait);
+    if (counts) { counts[0] = rep.n_launches; counts[1] = rep.n_waits; counts[2] = rep.n_accesses; counts[3] = rep.n_records; counts[4] = rep.n_findings; }
+    if (report && report_len) snprintf(report, report_len, "%s", rep.text.c_str());
+    return rep.ok ? 0 : 1;
+} ABI_CATCH
+
+// Host-only: 64-bit FNV-1a fingerprints of everything the planner hands to the device and to the scheduler, component by component
+// (tests/test_plan_host.py, tools/plan_fingerprint.py: a refactoring of the planner must not move a word). out[0..N): see the order below;
+// the per-class record lists are hashed level by level in sorted order (the order inside a level is a launch-placement choice).
+int acvm_debug_plan_fingerprint(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids,
+                                uint32_t n_keep, uint64_t *out, uint32_t cap) try {
+    if (!c || !out || (n_initial && !initial_ids) || (n_keep && !keep_ids)) return set_err(ACVM_E_INVALID, "null argument");
+    PlanOpts opts;
+    opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;
+    opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
+    opts.host_blackbox = (flags & 0x100u) != 0;
+    opts.keep.assign(keep_ids, keep_ids + n_keep);
+    const Plan p = build_plan(*c->c, initial_ids, n_initial, opts);
+    if (!p.unsupported.empty()) return set_err(ACVM_E_UNSUPPORTED, p.unsupported);
+    std::vector<uint64_t> fp;
+    auto fnv = [](const void *data, size_t bytes, uint64_t h = 0xcbf29ce484222325ull) {
+        const uint8_t *b = (const uint8_t *)data;
+        for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+        return h;
+    };
+    auto vec = [&](const std::vector<uint32_t> &v) { fp.push_back(fnv(v.data(), v.size() * 4) ^ (uint64_t)v.size() << 40); };
+    vec(p.gate_stream); vec(p.gate_offset); vec(p.level_start); vec(p.dyn_offset); vec(p.dyn_level_start); vec(p.level_needs_inverse);
+    for (int q = 0; q < N_HEAVY_LANES; q++) { vec(p.level_needs_heavy[q]); vec(p.inv_needs_heavy[q]); vec(p.lane_needs_main[q]); for (int q2 = 0; q2 < N_HEAVY_LANES; q2++) vec(p.lane_needs_lane[q][q2]); }
+    vec(p.prog); vec(p.prog_offset); vec(p.prog_scratch); vec(p.slot_of); vec(p.kbound); vec(p.scaled_ids); vec(p.unscale_index); vec(p.bytecode); vec(p.producer); vec(p.byte_plane_of);
+    fp.push_back(fnv(p.constants.data(), p.constants.size() * sizeof(FrH)));
+    fp.push_back(fnv(p.unscale.data(), p.unscale.size() * sizeof(FrH)));
+    fp.push_back(fnv(p.prog_class.data(), p.prog_class.size()));
+    for (int k = 0; k < (int)N_CLS; k++) {
+        vec(p.cls_level_start[k]);
+        std::vector<uint32_t> sorted;
+        for (size_t L = 0; L + 1 < p.cls_level_start[k].size(); L++) {
+            std::vector<std::pair<uint32_t, uint32_t>> lv;
+            for (uint32_t r = p.cls_level_start[k][L]; r < p.cls_level_start[k][L + 1]; r++) lv.push_back({p.cls_offset[k][r], p.cls_scratch[k][r]});
+            std::sort(lv.begin(), lv.end());
+            for (auto &x : lv) { sorted.push_back(x.first); sorted.push_back(x.second); }
+        }
+        vec(sorted);
+    }
+    const uint32_t scal[] = {p.n_witnesses, p.n_opcodes, p.n_levels, p.n_slots, p.mem_cells, p.n_inverse_slots, p.n_digest_segments, p.truncated_at, p.n_byte_planes};
+    fp.push_back(fnv(scal, sizeof scal));
+    for (size_t i = 0; i < fp.size() && i < cap; i++) out[i] = fp[i];
+    return (int)fp.size();
 } ABI_CATCH
 
 // The two fixed field elements of the witness-map digest (include/acvm_amd.h acvm_batch_digest): Blake2s-256 of the ASCII strings
@@ -193,7 +294,7 @@ static int batch_init(acvm_batch *b) {
     HIPCHK(hipStreamCreateWithFlags(&b->stream_digest, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&b->ev_start));
     HIPCHK(hipEventCreate(&b->ev_end));
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     size_t w_bytes = (size_t)(b->reuse() ? p.n_slots : p.n_witnesses) * 2 * b->Bp * sizeof(uint4);
     HIPCHK(hipMalloc((void **)&b->d_W, w_bytes ? w_bytes : 16));
     if (int rc = upload(&b->d_gate_stream, p.gate_stream)) return rc;
@@ -236,97 +337,13 @@ static int batch_init(acvm_batch *b) {
         size_t bytes = (size_t)p.mem_cells * 2 * b->Bp * sizeof(uint4);
         HIPCHK(hipMalloc((void **)&b->d_Mem, bytes ? bytes : 16));
     }
-    // non-arithmetic record classes: per level, launch chunks whose per-instance scratch fits the class's scratch buffer
-    const uint64_t scratch_cap_words = std::max<uint64_t>(1, (1ull << 30) / (std::max<uint64_t>(b->Bp, 64) * 4));  // 1 GiB per class (an empty batch is allowed)
+    // non-arithmetic record classes: where their records are cut into launches (schedule.cpp), then the level schedule of one solve
+    b->layout = layout_launches(p, b->Bp);
+    b->schedule = level_schedule(p, b->layout);
     for (int k = 0; k < (int)N_CLS; k++) {
-        const size_t n_levels = p.n_levels;
-        b->cls_chunks[k].assign(n_levels, {});
-        std::vector<uint32_t> scratch_off(2 * p.cls_offset[k].size(), 0);  // per record: (offset, words) of its per-lane scratch, in u32 words
-        uint64_t need = 0;
-        for (size_t L = 0; L < n_levels; L++) {
-            uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
-            if (k == CLS_HASH) {  // byte-message hashes first: their own kernel, no scratch (the records of a level are independent)
-                auto is_coop = [&](uint32_t r) { return (b->plan.prog[b->plan.cls_offset[k][r] + 2] & PLAN_HASH_COOP_FLAG) != 0; };
-                // The LDS message of a launch is sized by its longest record (a 1 024-byte message takes 77 KiB of the workgroup's 160 KiB on gfx950):
-                // short messages (<= 256 bytes: 16 KiB per 64 instances) and long ones get launches of their own, so that one long message
-                // somewhere in the circuit does not cost every 64-byte SHA record its occupancy.
-                auto words_of = [&](uint32_t r) {  // message words of the record, or of the longest member of the chain it heads (plan.cpp hash chains)
-                    uint32_t words = 0;
-                    for (size_t at = b->plan.cls_offset[k][r];;) {
-                        const std::vector<uint32_t> &pg = b->plan.prog;
-                        const uint32_t n_in = pg[at + 3];
-                        words = std::max(words, (n_in + 3u) / 4u);
-                        if (!(pg[at + 2] & PLAN_HASH_CHAIN_FLAG)) break;
-                        at = pg[pg[at + 6 + 2 * (size_t)n_in + 64 + ((pg[at + 2] & PLAN_HASH_RANGE_FLAG) ? 2 * (size_t)n_in : 0)]];
-                    }
-                    return words;
-                };
-                std::vector<std::pair<uint32_t, uint32_t>> recs;  // (offset, scratch)
-                uint32_t n_pass[3] = {0, 0, 0}, words_pass[2] = {0, 0};
-                for (int pass = 0; pass < 3; pass++)
-                    for (uint32_t r = lo; r < hi; r++) {
-                        const int cls = !is_coop(r) ? 2 : (words_of(r) <= 64u ? 0 : 1);
-                        if (cls != pass) continue;
-                        recs.push_back({b->plan.cls_offset[k][r], b->plan.cls_scratch[k][r]});
-                        n_pass[pass]++;
-                        if (pass < 2) words_pass[pass] = std::max(words_pass[pass], words_of(r));
-                    }
-                for (uint32_t r = lo; r < hi; r++) { b->plan.cls_offset[k][r] = recs[r - lo].first; b->plan.cls_scratch[k][r] = recs[r - lo].second; }
-                for (int pass = 0; pass < 2; pass++) {
-                    if (n_pass[pass]) b->cls_chunks[k][L].push_back({lo, n_pass[pass], true, words_pass[pass]});
-                    lo += n_pass[pass];
-                }
-            }
-            if (k == CLS_GRUMPKIN && hi - lo > 1) {
-                // the longest records first (SchnorrVerify ~1.7 ms of one wave per SIMD, FixedBaseScalarMul 0.3): workgroups are placed in grid order,
-                // and at ~240 registers a SIMD holds two of these waves -- a long wave that arrives last waits for a slot behind short ones elsewhere
-                std::vector<std::pair<uint32_t, uint32_t>> recs;
-                for (uint32_t r = lo; r < hi; r++) recs.push_back({b->plan.cls_offset[k][r], b->plan.cls_scratch[k][r]});
-                std::stable_sort(recs.begin(), recs.end(), [&](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) {
-                    auto rank = [&](uint32_t off) { const uint32_t kind = b->plan.prog[off]; return kind == PK_SCHNORR ? 0 : kind == PK_PEDERSEN ? 1 : 2; };
-                    return rank(x.first) < rank(y.first);
-                });
-                for (uint32_t r = lo; r < hi; r++) { b->plan.cls_offset[k][r] = recs[r - lo].first; b->plan.cls_scratch[k][r] = recs[r - lo].second; }
-            }
-            if (k == CLS_LIGHT) {  // straight-line Brillig records last: they have a kernel of their own (kernels_ops.hip LightSlOp)
-                auto is_sl = [&](uint32_t r) { return b->plan.prog[b->plan.cls_offset[k][r]] == PK_BRILLIG_SL; };
-                std::vector<uint32_t> offs;
-                uint32_t n_sl = 0;
-                for (int pass = 0; pass < 2; pass++)
-                    for (uint32_t r = lo; r < hi; r++)
-                        if (is_sl(r) == (pass == 1)) { offs.push_back(b->plan.cls_offset[k][r]); n_sl += pass; }
-                for (uint32_t r = lo; r < hi; r++) b->plan.cls_offset[k][r] = offs[r - lo];
-                if (n_sl) {
-                    if (hi - n_sl > lo) b->cls_chunks[k][L].push_back({lo, hi - n_sl - lo});
-                    b->cls_chunks[k][L].push_back({hi - n_sl, n_sl, true});
-                    continue;
-                }
-            }
-            uint32_t first = lo;
-            uint64_t used = 0;
-            for (uint32_t r = lo; r < hi; r++) {
-                uint64_t w = p.cls_scratch[k][r];
-                if (r > first && used + w > scratch_cap_words) {
-                    b->cls_chunks[k][L].push_back({first, r - first});
-                    first = r;
-                    used = 0;
-                }
-                scratch_off[2 * r] = (uint32_t)used;
-                scratch_off[2 * r + 1] = (uint32_t)w;
-                used += w;
-                need = std::max(need, used);
-            }
-            if (hi > first) b->cls_chunks[k][L].push_back({first, hi - first});
-        }
-        // the exact kernels use slot 0 of the same buffer: it must hold the largest single record
-        for (uint32_t oi = 0; oi < p.n_opcodes; oi++)
-            if (p.prog_class[oi] == (uint32_t)k) {
-                need = std::max<uint64_t>(need, p.prog_scratch[oi]);
-                b->cls_exact_words[k] = std::max<uint64_t>(b->cls_exact_words[k], p.prog_scratch[oi]);
-            }
         if (int rc = upload(&b->d_cls_offset[k], p.cls_offset[k])) return rc;
-        if (int rc = upload(&b->d_cls_scratch_off[k], scratch_off)) return rc;
-        if (need) HIPCHK(hipMalloc((void **)&b->d_cls_scratch[k], (size_t)need * b->Bp * 4));
+        if (int rc = upload(&b->d_cls_scratch_off[k], b->layout.scratch_off[k])) return rc;
+        if (b->layout.scratch_words[k]) HIPCHK(hipMalloc((void **)&b->d_cls_scratch[k], (size_t)b->layout.scratch_words[k] * b->Bp * 4));
     }
     b->dp.prog = b->d_prog;
     b->dp.prog_offset = b->d_prog_offset;
@@ -440,9 +457,9 @@ acvm_batch_t *acvm_batch_new_ex(const acvm_circuit_t *c, const acvm_bb_solver_t 
     b->opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;  // a recycled row must be hashed before it is reused
     b->opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
     b->opts.keep.assign(keep_ids, keep_ids + n_keep);
-    b->plan = build_plan(*c->c, initial_ids, n_initial, b->opts);
-    if (!b->plan.unsupported.empty()) {
-        set_err(ACVM_E_UNSUPPORTED, b->plan.unsupported);
+    b->plan_ref = plan_for(c, initial_ids, n_initial, b->opts);
+    if (!b->plan().unsupported.empty()) {
+        set_err(ACVM_E_UNSUPPORTED, b->plan().unsupported);
         return nullptr;
     }
     b->B = b->capacity = n_instances;
@@ -460,7 +477,7 @@ int batch_import_async(acvm_batch *b, const void *d_values_be32, hipEvent_t impo
     b->next_inputs = nullptr;
     if (!already)
         launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->reuse() ? b->d_init_rows : b->d_init_ids,
-                      (uint32_t)b->plan.initial_ids.size(), nullptr, b->d_byte_plane_of_input, b->d_byte_plane);
+                      (uint32_t)b->plan().initial_ids.size(), nullptr, b->d_byte_plane_of_input, b->d_byte_plane);
     HIPCHK(hipGetLastError());
     if (imported) HIPCHK(hipEventRecord(imported, b->stream));
     b->inputs_set = true;
@@ -480,7 +497,7 @@ int acvm_batch_set_initial_witness_device(acvm_batch_t *b, const void *d_values_
 
 int acvm_batch_set_initial_witness(acvm_batch_t *b, const uint8_t *values_be32) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
-    size_t bytes = (size_t)b->B * b->plan.initial_ids.size() * 32;
+    size_t bytes = (size_t)b->B * b->plan().initial_ids.size() * 32;
     if (bytes && !values_be32) return set_err(ACVM_E_INVALID, "null values");
     HIPCHK(hipSetDevice(b->device));
     if (int rc = stage_reserve(b, bytes)) return rc;
@@ -516,7 +533,7 @@ int acvm_batch_reset(acvm_batch_t *b) {
 
 int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     if (!b || !out) return set_err(ACVM_E_INVALID, "null argument");
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     plan_stats(p, out);
     out->n_kernel_launches = b->n_launches;
     out->n_slow_instances = (uint32_t)b->slow_ids.size();

@@ -4,8 +4,10 @@
 #include "../../include/acvm_amd.h"
 #include "kernels.hpp"
 #include "plan.hpp"
+#include "schedule.hpp"
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,14 +39,35 @@ struct ExactOutcome {
     void clear() { instance.clear(); results.clear(); kept_values.clear(); kept_assigned.clear(); digests.clear(); }
 };
 
+// One plan per (initial witness ids, options, tuning) of a circuit: planning a 10^6-opcode circuit takes seconds and its plan hundreds of MB,
+// and the reference's callers build their opcode list once per circuit for any number of executions (acvm_js/src/execute.rs:60-119).
+struct PlanKey {
+    std::vector<uint32_t> ids, keep;
+    bool host_blackbox = false, fold_digest = false, reuse_slots = false;
+    std::vector<int64_t> tuning;  // the whole tuning snapshot (every knob may change the plan or the schedule)
+    bool operator==(const PlanKey &o) const {
+        return ids == o.ids && keep == o.keep && host_blackbox == o.host_blackbox && fold_digest == o.fold_digest && reuse_slots == o.reuse_slots && tuning == o.tuning;
+    }
+};
 struct acvm_circuit {
     std::unique_ptr<Circuit> c;
+    // the most recent plans of this circuit (weak: a plan lives as long as a handle uses it; the last one is also held strongly so that
+    // create / free / create of handles -- bench legs, the node driver's auto_tile followed by its lanes -- does not plan again)
+    mutable std::mutex plan_mutex;
+    mutable std::vector<std::pair<PlanKey, std::weak_ptr<const Plan>>> plan_cache;
+    mutable std::shared_ptr<const Plan> last_plan;
+    mutable uint64_t n_plans_built = 0, n_plans_shared = 0;
 };
-
-struct LaunchChunk { uint32_t first, count; bool coop = false; uint32_t lds_words = 0; };  // records [first, first+count) of a class's level-major list (coop: CLS_HASH records flagged PLAN_HASH_COOP_FLAG)
+// the plan of `c` for these options: from the circuit's cache, or built (and cached) now. Never null; a refused circuit's plan has `unsupported` set.
+std::shared_ptr<const Plan> plan_for(const acvm_circuit *c, const uint32_t *initial_ids, uint32_t n_initial, const acvm::PlanOpts &opts);
 
 struct acvm_batch {
-    Plan plan;
+    // The static plan: immutable once built and shared -- by the handles of a node (node.cpp: one plan per circuit, not one per device) and
+    // by every handle created for the same (circuit, initial ids, options, tuning) through the circuit's plan cache (batch.cpp plan_for).
+    std::shared_ptr<const Plan> plan_ref;
+    const Plan &plan() const { return *plan_ref; }
+    LaunchLayout layout;     // where the plan's records are cut into launches for this handle's instance stride (schedule.hpp)
+    LevelSchedule schedule;  // the level schedule of one solve: what enqueue_level_schedule walks and what the hazard checker proves
     uint32_t B = 0;          // live instances: what the next import / solve covers (batch_set_live_count; <= capacity)
     uint32_t capacity = 0;   // instances the handle was created for: every table is sized by it
     uint64_t Bp = 0;  // instance stride, multiple of 64
@@ -58,7 +81,6 @@ struct acvm_batch {
     uint32_t *d_cls_offset[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::vector<std::vector<LaunchChunk>> cls_chunks[N_CLS];  // per level
     DeviceProgram dp{};
     uint32_t *d_event = nullptr;
     uint32_t *h_flag_count = nullptr;  // pinned, device-mapped
@@ -99,7 +121,6 @@ struct acvm_batch {
     hipEvent_t ev_x_ready = nullptr;
     uint32_t *d_x_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per-class scratch of the side table's lanes
     uint64_t x_scratch_lanes = 0;
-    uint64_t cls_exact_words[N_CLS] = {0, 0, 0, 0, 0, 0, 0, 0};  // largest per-lane scratch (u32 words) of a single record of the class
     std::vector<uint32_t> async_keep;  // witnesses delivered with an outcome
     bool async_digest = false;
     ExactOutcome last_outcome;         // of the job a public entry point had to wait for

@@ -36,7 +36,7 @@ ExactLanes exact_lanes(acvm_batch *b, uint32_t n_slow) {
 // Foreign-call round trip, device side: the buffers a pending call's inputs are written to (per exact lane, FcLanes::pend_*) and
 // the store of the results the host resolved (per opcode slot and instance, FcStoreSlot): dirty slots are rebuilt and uploaded.
 int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     if (!p.has_foreign_calls) return 0;
     b->fc_lane.resize(n_slow);
     const uint32_t pend_words = 1 + p.fc_max_inputs, pend_vals = (uint32_t)std::max<uint64_t>(1, p.fc_pending_vals);
@@ -117,7 +117,7 @@ int upload_fc_tables(acvm_batch *b, uint32_t n_slow) {
 // gathered ONCE (one kernel, one copy), the callbacks run in one loop -- or in ONE call when the vtable has the *_batch
 // member -- and the results are scattered once; a pass is capped at 2^18 instances only to bound the staging buffers.
 int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_t n_slow) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     hipStream_t s = b->stream;
     const uint32_t *rec = &p.prog[p.prog_offset[opcode]];
     std::vector<uint32_t> sel, outs;
@@ -240,7 +240,7 @@ int run_host_blackbox(acvm_batch *b, uint32_t opcode, bool exact, uint32_t n_slo
 // run the exact in-order kernels over the current lanes from opcode min_start on and fetch the outcomes
 // (stepping: the lanes executed every earlier opcode themselves, nothing is replayed; only opcodes [min_start, end_opcode) run)
 int run_exact_segments(acvm_batch *b, uint32_t n_slow, uint32_t min_start, bool replay, uint32_t end_opcode) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     hipStream_t s = b->xstream();  // the batch's stream, or the side stream of an asynchronous job
     const ExactLanes L = exact_lanes(b, n_slow);
     const DeviceProgram xdp = b->xdp();
@@ -298,7 +298,7 @@ static void give_up_lane(SlowResult &r, uint32_t kind, uint64_t limit, uint64_t 
     r.x0 = (uint32_t)std::min<uint64_t>(wanted, 0xFFFFFFFFu);
 }
 int retry_device_limits(acvm_batch *b, uint32_t n_slow, bool replay, uint32_t end_opcode) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     const Tuning &tn = p.tune;
     hipStream_t s = b->xstream();
     const BrilligLimits base = b->dp.brillig;
@@ -448,7 +448,7 @@ int solve_resume(acvm_batch *b) {
 // (one == false: the loop of ACVM::solve :236-241 over what is left). Every instance is an exact lane whose instruction
 // pointer is slow_start[t]; see include/acvm_amd.h for the batch semantics.
 int solve_stepping(acvm_batch *b, bool one) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     hipStream_t s = b->stream;
     const uint32_t n_slow = b->B;
     if (!b->stepping) {
@@ -529,7 +529,7 @@ int solve_stepping(acvm_batch *b, bool one) {
 
 int acvm_batch_solve_opcode(acvm_batch_t *b) try {
     if (!b) return set_err(ACVM_E_INVALID, "null batch");
-    if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
+    if (!b->inputs_set && !b->plan().initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
     if (b->solved && !b->stepping) return set_err(ACVM_E_STATE, "acvm_batch_solve_opcode after acvm_batch_solve: reset the batch first");
     if (b->reuse()) return set_err(ACVM_E_UNSUPPORTED, "stepping needs the full witness table: not with ACVM_BATCH_REUSE_SLOTS");
     HIPCHK(hipSetDevice(b->device));
@@ -548,7 +548,7 @@ int acvm_batch_solve_opcode(acvm_batch_t *b) try {
 // per-launch HIP-event pairs of one solve (profiling on)
 
 int ensure_side_table(acvm_batch *b, uint32_t n_lanes, bool own_scratch) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     const uint64_t lanes = ((uint64_t)std::max<uint32_t>(n_lanes, 1) + 63) / 64 * 64;
     if (lanes > b->x_cap) {
         // a table of all witnesses per flagged instance: refuse when that is more than the level table itself
@@ -573,7 +573,7 @@ int ensure_side_table(acvm_batch *b, uint32_t n_lanes, bool own_scratch) {
         for (int k = 0; k < (int)N_CLS; k++) {
             if (b->d_x_scratch[k]) hipFree(b->d_x_scratch[k]);
             b->d_x_scratch[k] = nullptr;
-            if (b->cls_exact_words[k]) HIPCHK(hipMalloc((void **)&b->d_x_scratch[k], (size_t)b->cls_exact_words[k] * b->x_cap * 4));
+            if (b->layout.cls_exact_words[k]) HIPCHK(hipMalloc((void **)&b->d_x_scratch[k], (size_t)b->layout.cls_exact_words[k] * b->x_cap * 4));
         }
         b->x_scratch_lanes = b->x_cap;
     }
@@ -594,7 +594,7 @@ uint32_t async_exact_first_lanes(const Plan &p, uint32_t capacity) {
     return (uint32_t)(lanes / 64 * 64);
 }
 int batch_enable_async_exact(acvm_batch *b, const uint32_t *keep, uint32_t n_keep, bool digests) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     if (b->has_solver || p.has_foreign_calls || p.truncated_at != 0xFFFFFFFFu || !p.tune.exact_async) return 0;
     if (!b->stream_x) HIPCHK(hipStreamCreateWithFlags(&b->stream_x, hipStreamNonBlocking));
     if (!b->ev_x_ready) HIPCHK(hipEventCreateWithFlags(&b->ev_x_ready, hipEventDisableTiming));
@@ -640,7 +640,7 @@ uint32_t batch_exact_unsolved(const acvm_batch *b, uint32_t n) {
     for (size_t t = 0; t < b->slow_ids.size() && t < b->slow_res.size(); t++) bad += b->slow_ids[t] < n && b->slow_res[t].status != ACVM_STATUS_SOLVED;
     return bad;
 }
-bool batch_generic_assigned(const acvm_batch *b, uint32_t w) { return w < b->plan.n_witnesses && b->plan.producer[w] != 0xFFFFFFFFu; }
+bool batch_generic_assigned(const acvm_batch *b, uint32_t w) { return w < b->plan().n_witnesses && b->plan().producer[w] != 0xFFFFFFFFu; }
 int batch_enqueue_kept(acvm_batch *b, uint32_t n, const uint32_t *d_keep, uint32_t n_keep, uint8_t *d_out, uint8_t *h_out, hipStream_t copy_stream,
                        hipEvent_t exported, hipEvent_t arrived) {
     HIPCHK(hipSetDevice(b->device));
@@ -659,7 +659,7 @@ int batch_enqueue_kept(acvm_batch *b, uint32_t n, const uint32_t *d_keep, uint32
 // level kernels).
 
 int side_table_outcome(acvm_batch *b, ExactOutcome *out) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     hipStream_t s = b->xstream();
     const uint32_t n_slow = (uint32_t)b->slow_ids.size(), n_keep = (uint32_t)b->async_keep.size();
     out->instance = b->slow_ids;
@@ -764,8 +764,8 @@ int acvm_batch_pending_foreign_call(acvm_batch_t *b, uint32_t instance, acvm_for
     info->brillig_index = sr.x0;
     info->n_inputs = b->h_pend_desc[t];
     for (uint32_t i = 0; i < info->n_inputs; i++) info->n_values += b->h_pend_desc[(size_t)(1 + i) * n_slow + t];
-    auto it = b->plan.fc_function.find(((uint64_t)sr.opcode_index << 32) | sr.x0);
-    snprintf(info->function, sizeof info->function, "%s", it == b->plan.fc_function.end() ? "" : it->second.c_str());
+    auto it = b->plan().fc_function.find(((uint64_t)sr.opcode_index << 32) | sr.x0);
+    snprintf(info->function, sizeof info->function, "%s", it == b->plan().fc_function.end() ? "" : it->second.c_str());
     return 1;
 } ABI_CATCH
 
@@ -799,8 +799,8 @@ int acvm_batch_pending_foreign_call_inputs(acvm_batch_t *b, uint32_t instance, u
 // resolved oracle call. A callback that does not return Ok leaves a failure marker: the re-run VM fails (or panics) at the op with the
 // solver's text. Returns the number of lanes answered (the caller re-solves when it is not 0), or a negative error.
 int resolve_internal_calls(acvm_batch *b) {
-    if (!b->has_solver || !b->plan.has_foreign_calls || !b->solved) return 0;
-    const Plan &p = b->plan;
+    if (!b->has_solver || !b->plan().has_foreign_calls || !b->solved) return 0;
+    const Plan &p = b->plan();
     const uint32_t n_slow = (uint32_t)b->slow_ids.size();
     struct Waiting { uint32_t t, kind; size_t slot; };
     std::vector<Waiting> lanes;
@@ -930,7 +930,7 @@ int acvm_batch_resolve_foreign_call(acvm_batch_t *b, uint32_t instance, uint32_t
     auto &ls = b->fc_lane[t];
     const uint32_t opcode = b->slow_res[t].opcode_index;
     if (ls.resolved_new) return set_err(ACVM_E_STATE, "this instance's pending foreign call was already resolved; call acvm_batch_solve");
-    const auto &slots = b->plan.fc_slot_opcode;
+    const auto &slots = b->plan().fc_slot_opcode;
     const size_t si = (size_t)(std::find(slots.begin(), slots.end(), opcode) - slots.begin());
     if (si >= b->fc_slots.size()) return set_err(ACVM_E_STATE, "the instance does not wait at a Brillig opcode with a foreign call");
     std::vector<acvm_batch::FcValue> res(n_values);

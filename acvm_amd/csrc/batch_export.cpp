@@ -22,7 +22,7 @@ static const uint8_t DIGEST_H[32] = {0x28, 0x25, 0x78, 0x33, 0xe7, 0x23, 0x7f, 0
 // device tables of the digest: g^(w+1), g^(w+1) / scale_w for the scaled witnesses, h^(w+1), and the h-sum of the planner's assigned set
 int ensure_digest_tables(acvm_batch *b) {
     if (b->d_fp_g) return 0;
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     const uint32_t nw = p.n_witnesses;
     const FrH g = frh::from_be_bytes32_reduce(DIGEST_G, 32), h = frh::from_be_bytes32_reduce(DIGEST_H, 32);
     std::vector<uint32_t> tg((size_t)std::max<uint32_t>(nw, 1) * 8), th((size_t)std::max<uint32_t>(nw, 1) * 8), tgs(std::max<size_t>(p.unscale.size(), 1) * 8), hgen(8);
@@ -51,7 +51,7 @@ int ensure_digest_tables(acvm_batch *b) {
 
 int digest_range(acvm_batch *b, hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const Unscale &u, const int32_t *d_slow_index,
                         bool use_host_index, uint32_t n_slow, uint8_t *out32) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     if (!n) return 0;
     if (int rc = ensure_digest_tables(b)) return rc;
     const size_t idx_bytes = use_host_index ? align256((size_t)b->B * 4) : 0;
@@ -74,7 +74,7 @@ int digest_range(acvm_batch *b, hipStream_t s, const uint4 *W, uint64_t Bp, uint
 
 int batch_export_tile(acvm_batch *b, uint32_t n, const uint32_t *keep, uint32_t n_keep, acvm_result_t *results, uint8_t *kept_values, uint8_t *kept_assigned,
                       uint8_t *digests) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     if (!b->solved || n > b->B) return set_err(ACVM_E_STATE, "batch not solved");
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = b->stream;
@@ -139,7 +139,7 @@ int batch_export_tile(acvm_batch *b, uint32_t n, const uint32_t *keep, uint32_t 
 int refuse_if_next_imported(const acvm_batch *b, const uint32_t *ws, uint32_t n, bool whole_map) {
     if (!b->next_imported) return 0;
     bool hit = whole_map;
-    for (uint32_t k = 0; k < n && !hit; k++) hit = std::find(b->plan.initial_ids.begin(), b->plan.initial_ids.end(), ws[k]) != b->plan.initial_ids.end();
+    for (uint32_t k = 0; k < n && !hit; k++) hit = std::find(b->plan().initial_ids.begin(), b->plan().initial_ids.end(), ws[k]) != b->plan().initial_ids.end();
     if (!hit) return 0;
     return set_err(ACVM_E_STATE, "the initial witnesses of this solve are gone: acvm_batch_solve_then_import put the next tile's inputs into the table behind the solve "
                                  "(read results, non-initial witnesses and nothing else; or use acvm_batch_solve)");
@@ -147,7 +147,7 @@ int refuse_if_next_imported(const acvm_batch *b, const uint32_t *ws, uint32_t n,
 
 // ---- slot reuse (ACVM_BATCH_REUSE_SLOTS): what can be read back
 static bool reuse_kept(const acvm_batch *b, uint32_t w) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     if (w >= p.n_witnesses) return false;
     if (std::find(p.initial_ids.begin(), p.initial_ids.end(), w) != p.initial_ids.end()) return true;
     return std::find(b->opts.keep.begin(), b->opts.keep.end(), w) != b->opts.keep.end();
@@ -155,7 +155,7 @@ static bool reuse_kept(const acvm_batch *b, uint32_t w) {
 static int reuse_check_kept(const acvm_batch *b, const uint32_t *ws, uint32_t n) {
     if (!b->reuse()) return 0;
     for (uint32_t k = 0; k < n; k++)
-        if (ws[k] < b->plan.n_witnesses && !reuse_kept(b, ws[k]))
+        if (ws[k] < b->plan().n_witnesses && !reuse_kept(b, ws[k]))
             return set_err(ACVM_E_STATE, "witness " + std::to_string(ws[k]) + " was not kept: the batch recycles witness rows (ACVM_BATCH_REUSE_SLOTS); "
                                          "only the initial witnesses and keep_ids can be read back");
     return 0;
@@ -199,7 +199,7 @@ bool fetch_one(acvm_batch *b, uint32_t j, uint32_t w, uint8_t out[32]) {
 
 // message text of a failure, rebuilt from the device's DevMsg code (ops_common.hpp) + payload
 void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm_result_t &r) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     const uint32_t *rec = sr.opcode_index < p.n_opcodes ? &p.prog[p.prog_offset[sr.opcode_index]] : nullptr;
     char hx[65];
     switch (sr.msg) {
@@ -329,7 +329,7 @@ void format_message(acvm_batch *b, uint32_t j, const SlowResult &sr, acvm_result
 
 void fill_result(acvm_batch *b, uint32_t j, acvm_result_t &r) {
     memset(&r, 0, sizeof r);
-    if (b->plan.n_opcodes == 0 || b->slow_index[j] < 0) { r.status = ACVM_STATUS_SOLVED; return; }
+    if (b->plan().n_opcodes == 0 || b->slow_index[j] < 0) { r.status = ACVM_STATUS_SOLVED; return; }
     if (b->pending) { r.status = ACVM_STATUS_IN_PROGRESS; return; }  // its exact job is still running (batch_finish_pending)
     const SlowResult &sr = b->slow_res[b->slow_index[j]];
     r.status = sr.status; r.err = sr.err; r.opcode_index = sr.opcode_index; r.aux0 = sr.aux0; r.aux1 = sr.aux1;
@@ -388,8 +388,8 @@ static bool too_many_unknowns_expr(acvm_batch *b, const Circuit &circ, uint32_t 
     const int32_t lane = b->slow_index[instance];
     const uint32_t n_slow = (uint32_t)b->slow_ids.size();
     auto known = [&](uint32_t w) -> bool {
-        if (w >= b->plan.n_witnesses) return false;
-        if (lane < 0) return b->plan.producer[w] != 0xFFFFFFFFu;
+        if (w >= b->plan().n_witnesses) return false;
+        if (lane < 0) return b->plan().producer[w] != 0xFFFFFFFFu;
         uint32_t bitsw = 0;
         if (hipMemcpy(&bitsw, b->d_assigned + (size_t)(w >> 5) * n_slow + lane, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
         return (bitsw >> (w & 31)) & 1u;
@@ -515,7 +515,7 @@ int acvm_batch_error_string(acvm_batch_t *b, const acvm_circuit_t *c, uint32_t i
 
 // assigned flags of instance j over all witnesses (host side bookkeeping + slow-path bitmap)
 static int fetch_assigned(acvm_batch *b, uint32_t first, uint32_t n, uint8_t *assigned) {
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     uint32_t nw = p.n_witnesses;
     std::vector<uint32_t> bitmap;
     uint32_t n_slow = (uint32_t)b->slow_ids.size();
@@ -546,7 +546,7 @@ int acvm_batch_witness_map(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t 
     if (b->side()) return set_err(ACVM_E_STATE, "the batch recycles witness rows (ACVM_BATCH_REUSE_SLOTS) or solved its exact lanes in the side table: full maps are not kept; read the kept witnesses and the digest");
     if (int rc = refuse_if_next_imported(b, nullptr, 0, true)) return rc;
     HIPCHK(hipSetDevice(b->device));
-    uint32_t nw = b->plan.n_witnesses;
+    uint32_t nw = b->plan().n_witnesses;
     if (!n || !nw) return 0;
     if (int rc = fetch_assigned(b, first, n, assigned)) return rc;
     std::vector<uint32_t> sel(nw);
@@ -596,9 +596,9 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
     if (!n) return 0;
-    if (int rc = refuse_if_next_imported(b, nullptr, 0, !(b->plan.n_digest_segments && b->d_leaves))) return rc;  // (a folded digest was summed during the solve)
+    if (int rc = refuse_if_next_imported(b, nullptr, 0, !(b->plan().n_digest_segments && b->d_leaves))) return rc;  // (a folded digest was summed during the solve)
     HIPCHK(hipSetDevice(b->device));
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     if (int rc = ensure_digest_tables(b)) return rc;
     std::vector<uint32_t> flagged;
     for (uint32_t i = 0; i < n; i++)
@@ -635,7 +635,7 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
     if (!n || !n_witnesses) return 0;
     if (int rc = refuse_if_next_imported(b, witnesses, n_witnesses, false)) return rc;
     HIPCHK(hipSetDevice(b->device));
-    const uint32_t nw = b->plan.n_witnesses;
+    const uint32_t nw = b->plan().n_witnesses;
     char text[160];
     for (uint32_t k = 0; k < n_witnesses; k++)
         if (witnesses[k] >= nw) {
@@ -657,7 +657,7 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
         std::vector<uint32_t> word(n_slow);
         for (uint32_t k = 0; k < n_witnesses; k++) {
             const uint32_t w = witnesses[k];
-            if (first_fast != 0xFFFFFFFFu && b->plan.producer[w] == 0xFFFFFFFFu && first_fast < bad_j) { bad_j = first_fast; bad_w = w; }
+            if (first_fast != 0xFFFFFFFFu && b->plan().producer[w] == 0xFFFFFFFFu && first_fast < bad_j) { bad_j = first_fast; bad_w = w; }
             if (!lanes.empty()) {
                 HIPCHK(hipMemcpy(word.data(), b->d_assigned + (size_t)(w >> 5) * n_slow, (size_t)n_slow * 4, hipMemcpyDeviceToHost));
                 for (uint32_t t : lanes)
@@ -668,7 +668,7 @@ int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uin
             for (uint32_t k = 0; k < n_witnesses; k++) {  // the first missing witness of that instance, in the caller's order
                 const uint32_t w = witnesses[k];
                 const int32_t si = b->slow_index[bad_j];
-                bool have = si < 0 ? b->plan.producer[w] != 0xFFFFFFFFu : true;
+                bool have = si < 0 ? b->plan().producer[w] != 0xFFFFFFFFu : true;
                 if (si >= 0) {
                     uint32_t bits = 0;
                     HIPCHK(hipMemcpy(&bits, b->d_assigned + (size_t)(w >> 5) * n_slow + si, 4, hipMemcpyDeviceToHost));
@@ -723,7 +723,7 @@ long long acvm_batch_witness_map_bytes(acvm_batch_t *b, uint32_t instance, uint8
     if (!b) return set_err(ACVM_E_INVALID, "null argument");
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
     if (instance >= b->B) return set_err(ACVM_E_INVALID, "instance out of range");
-    const uint32_t nw = b->plan.n_witnesses;
+    const uint32_t nw = b->plan().n_witnesses;
     std::vector<uint8_t> assigned(nw ? nw : 1), values((size_t)(nw ? nw : 1) * 32);
     if (int rc = acvm_batch_witness_map(b, instance, 1, assigned.data(), values.data())) return rc;
     std::vector<uint32_t> ids;
@@ -741,7 +741,7 @@ int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uin
     if (b->pending)
         if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
-    if (witness >= b->plan.n_witnesses) { memset(assigned, 0, b->B); memset(out_be32, 0, (size_t)b->B * 32); return 0; }
+    if (witness >= b->plan().n_witnesses) { memset(assigned, 0, b->B); memset(out_be32, 0, (size_t)b->B * 32); return 0; }
     if (int rc = refuse_if_next_imported(b, &witness, 1, false)) return rc;
     HIPCHK(hipSetDevice(b->device));
     if (!b->B) return 0;
@@ -762,7 +762,7 @@ int acvm_batch_witness(acvm_batch_t *b, uint32_t witness, uint8_t *out_be32, uin
     }
     for (uint32_t j = 0; j < b->B; j++) {
         int32_t si = b->slow_index[j];
-        assigned[j] = si < 0 ? b->plan.producer[witness] != 0xFFFFFFFFu : (bitmap[si] >> (witness & 31)) & 1u;
+        assigned[j] = si < 0 ? b->plan().producer[witness] != 0xFFFFFFFFu : (bitmap[si] >> (witness & 31)) & 1u;
         if (!assigned[j]) memset(out_be32 + (size_t)j * 32, 0, 32);
     }
     return 0;

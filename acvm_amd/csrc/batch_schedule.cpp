@@ -19,14 +19,11 @@ struct LaunchTimers {
     size_t ev_used = 0;
 };
 
-// The level schedule of one solve, enqueued on the batch's streams: the gate levels and the light records on the main stream,
-// the inversion batches on a second one, the heavy record classes on the heavy lanes. (One hipGraph of the whole schedule was
-// measured in round 2 at -2 % on the 250 k-opcode circuit and ROCm 7.2's hipStreamEndCapture recursed without bound on the
-// five-stream schedule of larger ones: removed.)
+// The level schedule of one solve (schedule.cpp level_schedule: a pure function of the plan, built once per handle) enqueued on the handle's
+// streams: one HIP call per step, nothing decided here. What the hazard checker proves about that list (schedule_check.cpp) is therefore
+// true of what the device is given.
 static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
-    const Plan &p = b->plan;
-    hipStream_t s = b->stream;
-    hipStream_t s2 = p.tune.overlap ? b->stream_dyn : b->stream;  // (overlap = 0, a measurement aid, serialises the two level kernels)
+    const Plan &p = b->plan();
     auto next_event = [&]() -> hipEvent_t {
         if (tm->ev_used == b->ev_pool.size()) {
             hipEvent_t e;
@@ -36,182 +33,59 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
         return b->ev_pool[tm->ev_used++];
     };
     const bool prof = tm != nullptr;
-    launch_event_reset(s, b->d_event, b->B);
-    // Per level the constant-coefficient gates and the other record classes (stream s) and the gates that need a
-    // per-instance inversion (stream s2, ALU/latency-bound) are independent and run concurrently; level L+1 of
-    // either stream waits for level L of both.
-    const size_t n_levels = p.n_levels;
-    while (b->ev_sync.size() < 2 * n_levels + 1) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        b->ev_sync.push_back(e);
+    hipStream_t streams[N_SCHED_STREAMS] = {b->stream, b->stream_dyn, b->stream_heavy, b->stream_heavy2, b->stream_heavy3, b->stream_digest};
+    const uint32_t n_sync = 2 * p.n_levels + 1;
+    auto event_of = [&](uint32_t id) { return id < n_sync ? b->ev_sync[id] : b->ev_heavy[id - n_sync]; };
+    for (const SchedStep &st : b->schedule.steps) {
+        hipStream_t s = streams[st.stream];
+        if (st.kind == SK_RECORD) { HIPCHK(hipEventRecord(event_of(st.event), s)); continue; }
+        if (st.kind == SK_WAIT) { HIPCHK(hipStreamWaitEvent(s, event_of(st.event), 0)); continue; }
+        const int k = st.cls;
+        const uint32_t *off = b->d_cls_offset[k] + st.first, *soff = b->d_cls_scratch_off[k] + 2 * (size_t)st.first;
+        const bool timed = prof && st.op != SO_EVENT_RESET && st.op != SO_TRUNCATE;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) { e0 = next_event(); hipEventRecord(e0, s); }
+        switch (st.op) {
+        case SO_EVENT_RESET: launch_event_reset(s, b->d_event, b->B); break;
+        case SO_GATES:
+            launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + st.first, st.count, b->d_consts, b->d_event, b->d_inv);
+            break;
+        case SO_GATES_LIGHT:
+            launch_arith_light_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + st.first, st.count, b->d_inv, b->dp,
+                                     b->d_cls_offset[CLS_LIGHT] + st.first2, st.count2, b->d_event);
+            break;
+        case SO_LIGHT: launch_light_level(s, b->d_W, b->Bp, b->B, b->dp, off, st.count, b->d_event); break;
+        case SO_LIGHT_SL: launch_light_sl_level(s, b->d_W, b->Bp, b->B, b->dp, off, st.count, b->d_event); break;
+        case SO_HASH_COOP: launch_hash_coop_level(s, b->d_W, b->Bp, b->B, b->dp, off, st.count, b->d_event, st.lds_words); break;
+        case SO_HASH: launch_hash_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, st.count, b->d_event, b->d_cls_scratch[k]); break;
+        case SO_GRUMPKIN: launch_grumpkin_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, st.count, b->d_event, b->d_cls_scratch[k]); break;
+        case SO_BRILLIG: launch_brillig_level(s, b->d_W, b->Bp, b->B, b->dp, off, soff, st.count, b->d_event, b->d_cls_scratch[k]); break;
+        case SO_PEDERSEN: launch_pedersen_level(s, b->d_W, b->Bp, b->B, b->dp, off, st.count, b->d_event, soff, b->d_cls_scratch[k]); break;
+        case SO_ECDSA: launch_ecdsa_level(s, b->d_W, b->Bp, b->B, b->dp, off, st.count, b->d_event); break;
+        case SO_DIGEST: launch_digest_fold_level(s, b->d_W, b->Bp, b->B, b->dp, off, st.count, b->fp, b->d_leaves); break;
+        case SO_HOSTBB:  // host callbacks (the schedule put the waits for every other stream in front)
+            for (uint32_t r = 0; r < st.count; r++)
+                if (int rc = run_host_blackbox(b, p.prog[p.cls_offset[k][st.first + r] + 1], false, 0)) return rc;
+            break;
+        case SO_INVERSE:
+            launch_inverse_batch(s, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + st.first, st.count, b->d_event, (uint32_t)p.tune.inv_chunk);
+            break;
+        case SO_TRUNCATE: launch_min_u32(s, b->d_event, p.truncated_at, b->B); break;
+        }
+        if (timed) {
+            e1 = next_event();
+            hipEventRecord(e1, s);
+            (st.op == SO_GATES || st.op == SO_GATES_LIGHT ? tm->reg_pairs : st.op == SO_INVERSE ? tm->dyn_pairs : tm->cls_pairs[k]).push_back({e0, e1});
+        }
+        if (st.op == SO_GATES || st.op == SO_GATES_LIGHT) b->n_launches += (st.count + 65534) / 65535;
+        else if (st.op != SO_EVENT_RESET && st.op != SO_TRUNCATE) b->n_launches++;
     }
-    // Record classes that are bound by the integer pipe or by latency run beside the HBM-bound gate levels on three lanes of their own
-    // (plan.hpp heavy_lane: Pedersen | Brillig | hashes, Grumpkin, ECDSA), each a stream in order. The records of lane q at level L
-    // start when level L-1 of the main stream is done and the levels of the OTHER lanes whose outputs they read are done
-    // (plan.lane_needs_lane); a level of the main stream (or an inversion batch) waits for a lane only up to the level whose outputs
-    // it reads (plan.level_needs_heavy[lane]): a level that reads a hash output does not wait for the Pedersen launch beside it.
-    auto heavy_cls = [](int k) { return k == CLS_HASH || k == CLS_GRUMPKIN || k == CLS_BRILLIG || k == CLS_PEDERSEN || k == CLS_ECDSA || k == CLS_DIGEST; };
-    // (measured in round 1, one MI355X, 2^16 instances: config 3 0.50 -> 0.42 ms, config-5 mix 29.0 -> 27.9 ms)
-    bool any_heavy = false, any_main = !p.gate_offset.empty() || !p.cls_offset[CLS_LIGHT].empty();
-    bool lane_any[N_HEAVY_LANES] = {false, false, false, false};  // a lane without records never joins the schedule (nor a capture)
-    for (int k = 0; k < (int)N_CLS; k++)
-        if (heavy_cls(k) && !p.cls_offset[k].empty()) { any_heavy = true; lane_any[heavy_lane(k)] = true; }
-    // A circuit of heavy records only kept everything on one stream until round 4 (round 2 had measured config 4 at 2.62 ... 3.03 ms from run to run
-    // with the lanes side by side against a steady 2.84-2.89 on one stream, and config 3 0.18 instead of 0.15 ms). But a record kernel of the
-    // integer-bound classes that follows a large launch -- the import of its tile -- on the SAME stream runs 16-44 % longer than on a stream of its
-    // own (profiles/r04_import_effect.txt: config 4 import + solve 3.27 -> 2.15 ms, ECDSA 3.83 -> 3.32 ms per 2^16): such circuits take the lanes'
-    // streams too (tuning heavy_only_streams); a circuit of byte-message hashes alone stays on the main stream.
-    const bool integer_bound = !p.cls_offset[CLS_GRUMPKIN].empty() || !p.cls_offset[CLS_PEDERSEN].empty() || !p.cls_offset[CLS_ECDSA].empty() || !p.cls_offset[CLS_BRILLIG].empty();
-    const bool one_stream = !p.tune.overlap || !p.tune.heavy_streams || (!any_main && !(p.tune.heavy_only_streams && integer_bound));
-    hipStream_t lane_stream[N_HEAVY_LANES] = {one_stream ? s : b->stream_heavy, one_stream ? s : b->stream_heavy2, one_stream ? s : b->stream_heavy3,
-                                              one_stream ? s : b->stream_digest};
-    bool any_dyn = !p.dyn_offset.empty();
-    const bool any_async = any_dyn || any_heavy;
-    if (any_async) {
-        HIPCHK(hipEventRecord(b->ev_sync[2 * n_levels], s));
-        if (any_dyn) HIPCHK(hipStreamWaitEvent(s2, b->ev_sync[2 * n_levels], 0));
-        if (any_heavy && !one_stream)
-            for (int q = 0; q < N_HEAVY_LANES; q++)
-                if (lane_any[q]) HIPCHK(hipStreamWaitEvent(lane_stream[q], b->ev_sync[2 * n_levels], 0));
-    }
-    hipEvent_t last_reg = nullptr, last_dyn = nullptr, last_lane[N_HEAVY_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    bool main_dirty = false;  // the main stream has launches behind last_reg
-    // A lane waits for the main stream only as far as its records read it (plan.lane_needs_main): a hash of initial witnesses and of other
-    // hashes never waits for the range checks launched beside it (config 3: the Keccak level no longer starts behind the RANGE kernel).
-    std::vector<std::pair<uint32_t, hipEvent_t>> main_marks;  // (L, event): "main levels < L are done", in order
-    uint32_t lane_main_waited[N_HEAVY_LANES] = {0, 0, 0, 0};
-    uint32_t waited_inverse_level = 0, waited_heavy[N_HEAVY_LANES] = {0, 0, 0, 0}, lane_waited[N_HEAVY_LANES][N_HEAVY_LANES] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (size_t L = 0; L < n_levels; L++) {
-        uint32_t n = p.level_start[L + 1] - p.level_start[L];
-        uint32_t nd = p.dyn_level_start[L + 1] - p.dyn_level_start[L];
-        bool s_work = n != 0, h_work = false;
-        bool lane_used[N_HEAVY_LANES] = {false, false, false, false};
-        for (int k = 0; k < (int)N_CLS; k++) {
-            (heavy_cls(k) ? h_work : s_work) |= !b->cls_chunks[k][L].empty();
-            if (heavy_cls(k) && !b->cls_chunks[k][L].empty()) lane_used[heavy_lane(k)] = true;
-        }
-        // "levels < L of the main stream are done": recorded only where another stream is about to wait for it (an event
-        // between two gate launches costs more than the launch gap itself)
-        if ((nd || h_work) && main_dirty) {
-            HIPCHK(hipEventRecord(b->ev_sync[2 * L], s));
-            last_reg = b->ev_sync[2 * L];
-            main_marks.push_back({(uint32_t)L, last_reg});
-            main_dirty = false;
-        }
-        hipEvent_t prev_reg = last_reg;
-        // the level waits for an inversion batch only if one of its gates reads that batch's rows (the planner put those
-        // gates after the batch, usually several levels after): the batch runs beside all the levels in between
-        const uint32_t need = p.level_needs_inverse[L + 1];  // 1-based inversion level, 0 = none
-        if (s_work && need > waited_inverse_level) {
-            HIPCHK(hipStreamWaitEvent(s, b->ev_sync[2 * (need - 1) + 1], 0));
-            waited_inverse_level = need;
-        }
-        for (int q = 0; q < N_HEAVY_LANES; q++) {
-            const uint32_t need_h = p.level_needs_heavy[q][L + 1];  // 1-based level of the lane's records, 0 = none
-            if (s_work && need_h > waited_heavy[q]) {
-                if (!one_stream) HIPCHK(hipStreamWaitEvent(s, b->ev_heavy[4 * (need_h - 1) + q], 0));
-                waited_heavy[q] = need_h;
-            }
-        }
-        // the level's light records (not the straight-line Brillig ones: a kernel of their own) ride in the gate launch when there is one
-        const LaunchChunk *fused_light = nullptr;
-        if (n && p.tune.light_fuse)
-            for (const LaunchChunk &ch : b->cls_chunks[CLS_LIGHT][L])
-                if (!ch.coop && (uint64_t)n + ch.count <= 65535u) { fused_light = &ch; break; }
-        if (n) {
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (prof) { e0 = next_event(); hipEventRecord(e0, s); }
-            if (fused_light)
-                launch_arith_light_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_inv, b->dp,
-                                         b->d_cls_offset[CLS_LIGHT] + fused_light->first, fused_light->count, b->d_event);
-            else launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + p.level_start[L], n, b->d_consts, b->d_event, b->d_inv);
-            if (prof) { e1 = next_event(); hipEventRecord(e1, s); tm->reg_pairs.push_back({e0, e1}); }
-            b->n_launches += (n + 65534) / 65535;
-        }
-        // what the lanes wait for: levels < L of the main stream, and the other lanes as far as they read them
-        if (!one_stream)
-            for (int q = 0; q < N_HEAVY_LANES; q++) {
-                if (!lane_used[q]) continue;
-                if (const uint32_t need_m = p.lane_needs_main[q][L + 1]; need_m > lane_main_waited[q]) {
-                    // the earliest mark behind main level need_m (1-based): "levels < mark" with mark >= need_m
-                    auto it = std::lower_bound(main_marks.begin(), main_marks.end(), need_m, [](const std::pair<uint32_t, hipEvent_t> &mk, uint32_t v) { return mk.first < v; });
-                    if (it != main_marks.end()) {
-                        HIPCHK(hipStreamWaitEvent(lane_stream[q], it->second, 0));
-                        lane_main_waited[q] = it->first;
-                    }
-                }
-                for (int q2 = 0; q2 < N_HEAVY_LANES; q2++) {
-                    const uint32_t need_l = p.lane_needs_lane[q][q2][L + 1];
-                    if (q2 != q && lane_stream[q2] != lane_stream[q] && need_l > lane_waited[q][q2]) {
-                        HIPCHK(hipStreamWaitEvent(lane_stream[q], b->ev_heavy[4 * (need_l - 1) + q2], 0));
-                        lane_waited[q][q2] = need_l;
-                    }
-                }
-            }
-        for (int k = 0; k < (int)N_CLS; k++)
-            for (const LaunchChunk &ch : b->cls_chunks[k][L]) {
-                if (&ch == fused_light) continue;  // went with the gates
-                hipStream_t sk = heavy_cls(k) ? lane_stream[heavy_lane(k)] : s;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (prof) { e0 = next_event(); hipEventRecord(e0, sk); }
-                const uint32_t *off = b->d_cls_offset[k] + ch.first, *soff = b->d_cls_scratch_off[k] + 2 * (size_t)ch.first;
-                switch (k) {
-                case CLS_LIGHT:
-                    if (ch.coop) launch_light_sl_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event);  // (coop: the level's straight-line Brillig records)
-                    else launch_light_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event);
-                    break;
-                case CLS_HASH:
-                    if (ch.coop) launch_hash_coop_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event, ch.lds_words);
-                    else launch_hash_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]);
-                    break;
-                case CLS_GRUMPKIN: launch_grumpkin_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                case CLS_BRILLIG: launch_brillig_level(sk, b->d_W, b->Bp, b->B, b->dp, off, soff, ch.count, b->d_event, b->d_cls_scratch[k]); break;
-                case CLS_PEDERSEN: launch_pedersen_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event, soff, b->d_cls_scratch[k]); break;
-                case CLS_ECDSA: launch_ecdsa_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->d_event); break;
-                case CLS_DIGEST: launch_digest_fold_level(sk, b->d_W, b->Bp, b->B, b->dp, off, ch.count, b->fp, b->d_leaves); break;
-                case CLS_HOSTBB:  // host callbacks: everything launched so far on any stream must have finished
-                    if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
-                    for (int q = 0; q < N_HEAVY_LANES; q++)
-                        if (last_lane[q]) HIPCHK(hipStreamWaitEvent(s, last_lane[q], 0));
-                    for (uint32_t r = 0; r < ch.count; r++)
-                        if (int rc = run_host_blackbox(b, p.prog[p.cls_offset[k][ch.first + r] + 1], false, 0)) return rc;
-                    break;
-                }
-                if (prof) { e1 = next_event(); hipEventRecord(e1, sk); tm->cls_pairs[k].push_back({e0, e1}); }
-                b->n_launches++;
-            }
-        if (!one_stream)
-            for (int q = 0; q < N_HEAVY_LANES; q++)
-                if (lane_used[q]) {
-                    HIPCHK(hipEventRecord(b->ev_heavy[4 * L + q], lane_stream[q]));
-                    last_lane[q] = b->ev_heavy[4 * L + q];
-                }
-        main_dirty |= s_work;
-        if (nd) {
-            if (prev_reg) HIPCHK(hipStreamWaitEvent(s2, prev_reg, 0));
-            if (!one_stream)
-                for (int q = 0; q < N_HEAVY_LANES; q++)
-                    if (p.inv_needs_heavy[q][L + 1]) HIPCHK(hipStreamWaitEvent(s2, b->ev_heavy[4 * (p.inv_needs_heavy[q][L + 1] - 1) + q], 0));
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (prof) { e0 = next_event(); hipEventRecord(e0, s2); }
-            launch_inverse_batch(s2, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + p.dyn_level_start[L], nd, b->d_event);
-            if (prof) { e1 = next_event(); hipEventRecord(e1, s2); tm->dyn_pairs.push_back({e0, e1}); }
-            b->n_launches++;
-            HIPCHK(hipEventRecord(b->ev_sync[2 * L + 1], s2));
-            last_dyn = b->ev_sync[2 * L + 1];
-        }
-    }
-    for (int q = 0; q < N_HEAVY_LANES; q++)
-        if (last_lane[q]) HIPCHK(hipStreamWaitEvent(s, last_lane[q], 0));
-    if (last_dyn) HIPCHK(hipStreamWaitEvent(s, last_dyn, 0));
-    if (p.truncated_at != 0xFFFFFFFFu) launch_min_u32(s, b->d_event, p.truncated_at, b->B);
     return 0;
 }
 
 // the cross-stream events of the schedule exist before anything is enqueued (nothing is created under stream capture)
 static int ensure_level_events(acvm_batch *b) {
-    const size_t n_levels = b->plan.n_levels;
+    const size_t n_levels = b->plan().n_levels;
     while (b->ev_sync.size() < 2 * n_levels + 1 || b->ev_heavy.size() < 4 * n_levels) {
         hipEvent_t e;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -224,9 +98,9 @@ static int ensure_level_events(acvm_batch *b) {
 // buffers meanwhile -- per-class scratch of its own. Grow-only. 0 = ready, negative = an error (ACVM_E_DEVICE: no room).
 
 int batch_solve_impl(acvm_batch *b, const void *next_inputs) {
-    if (!b->inputs_set && !b->plan.initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
+    if (!b->inputs_set && !b->plan().initial_ids.empty()) return set_err(ACVM_E_STATE, "initial witness not set");
     HIPCHK(hipSetDevice(b->device));
-    const Plan &p = b->plan;
+    const Plan &p = b->plan();
     b->next_imported = false;
     b->next_inputs = nullptr;
     if (b->solved) {  // only resolved foreign calls can change anything

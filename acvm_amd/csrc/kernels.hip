@@ -373,13 +373,17 @@ void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const 
     }
 }
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
-                          const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event) {
+                          const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event, uint32_t inv_chunk) {
     if (!n_jobs || !B) return;
-    // jobs per wave: at most inv_chunk (one field inversion, ~13 500 instructions, is shared by a wave's jobs: ~1 000 each), spread evenly over the waves
-    const uint32_t cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(tuning().inv_chunk, 1), 65536), n_chunks = (n_jobs + cap - 1) / cap;
+    // jobs per wave: at most inv_chunk (the PLAN's snapshot of the tuning, like every other knob of a handle: one field inversion, ~13 500
+    // instructions, is shared by a wave's jobs: ~1 000 each), spread evenly over the waves
+    const uint32_t cap = std::min<uint32_t>(std::max<uint32_t>(inv_chunk, 1), 65536), n_chunks = (n_jobs + cap - 1) / cap;
     const uint32_t chunk = (n_jobs + n_chunks - 1) / n_chunks;
-    hipLaunchKernelGGL(inverse_batch_kernel, dim3((B + 63) / 64, (n_jobs + chunk - 1) / chunk), dim3(64), 0, s, W, inv, Bp, B,
-                       gate_stream, job_offset, n_jobs, chunk, event);
+    for (uint32_t done = 0; done < n_jobs;) {  // (grid.y holds 65 535 chunks)
+        const uint32_t n = (uint32_t)std::min<uint64_t>(n_jobs - done, (uint64_t)chunk * 65535u);
+        hipLaunchKernelGGL(inverse_batch_kernel, dim3((B + 63) / 64, (n + chunk - 1) / chunk), dim3(64), 0, s, W, inv, Bp, B, gate_stream, job_offset + done, n, chunk, event);
+        done += n;
+    }
 }
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches) {
     if (!n) return;

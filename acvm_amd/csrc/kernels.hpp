@@ -91,7 +91,7 @@ void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *s
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv);
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,
-                          const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event);
+                          const uint32_t *job_offset, uint32_t n_jobs, uint32_t *event, uint32_t inv_chunk);
 // gates [0, n_gates) of a level and n_light light records of the same level in one launch (n_gates + n_light <= 65535)
 void launch_arith_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset, uint32_t n_gates,
                               const uint4 *inv, const DeviceProgram &dp, const uint32_t *light_offsets, uint32_t n_light, uint32_t *event);

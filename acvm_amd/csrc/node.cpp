@@ -21,6 +21,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <thread>
+#include <unistd.h>
 
 namespace {
 
@@ -113,6 +114,9 @@ struct acvm_node {
     uint32_t tile = 0, flags = 0;
     uint64_t last_n = 0;
     double last_total_ms = 0;
+    std::shared_ptr<const Plan> plan;  // the one plan every lane's handle shares
+    uint32_t plans_built = 0;          // how often acvm_node_new levelised the circuit (0: the circuit's cache already held the plan; never more than 1)
+    double create_ms = 0, plan_ms = 0;
     ~acvm_node() {
         for (DeviceLane &l : lanes) {
             hipSetDevice(l.device);
@@ -138,13 +142,7 @@ namespace {
 // the 10k-gate circuit) that every listed device has room for. Per device: 90 % of its free memory, less the lookup
 // tables the circuit would still build there, divided by the number of handles the device is listed for; a handle needs its tables, class
 // scratch and first side table (batch_device_bytes) plus this driver's staging and export buffers.
-uint32_t auto_tile(const acvm_circuit_t *c, const std::vector<uint32_t> &ids, const std::vector<uint32_t> &keep, uint32_t flags, const std::vector<int> &devices) {
-    PlanOpts opts;
-    opts.fold_digest = (flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;
-    opts.reuse_slots = (flags & ACVM_BATCH_REUSE_SLOTS) != 0;
-    opts.keep = keep;
-    const Plan p = build_plan(*c->c, ids.data(), (uint32_t)ids.size(), opts);
-    if (!p.unsupported.empty()) { set_err(ACVM_E_UNSUPPORTED, p.unsupported); return 0; }
+uint32_t auto_tile(const Plan &p, const PlanOpts &opts, const std::vector<uint32_t> &ids, const std::vector<uint32_t> &keep, const std::vector<int> &devices) {
     const bool pedersen_level = !p.cls_offset[CLS_PEDERSEN].empty();
     const bool window_table = pedersen_level && p.tune.pedersen_window_bits != 0;
     double budget = 1e30;
@@ -419,8 +417,23 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
         if (d < 0 || d >= visible) { set_err(ACVM_E_INVALID, "device index " + std::to_string(d) + " out of range (" + std::to_string(visible) + " visible)"); return nullptr; }
         devices.push_back(d);
     }
-    node->tile = opts && opts->tile_instances ? opts->tile_instances : auto_tile(c, node->ids, node->keep, node->flags, devices);
-    if (!node->tile) return nullptr;  // (the planner's refusal is the error text)
+    // The circuit is levelised ONCE per node (the reference's callers build one opcode list per circuit for any number of executions,
+    // acvm_js/src/execute.rs:60-119): the plan is immutable and shared -- auto_tile sizes the handles by it and every lane's
+    // acvm_batch_new_ex finds it in the circuit's plan cache (batch.cpp plan_for) instead of planning again (until round 5: 1 + N times).
+    const double t_create = now_ms();
+    const uint64_t built_before = acvm_circuit_plans_built(c);
+    {
+        PlanOpts po;  // exactly what acvm_batch_new_ex derives from the same arguments
+        po.host_blackbox = solver != nullptr;
+        po.fold_digest = (node->flags & (ACVM_BATCH_FOLD_DIGEST | ACVM_BATCH_REUSE_SLOTS)) != 0;
+        po.reuse_slots = (node->flags & ACVM_BATCH_REUSE_SLOTS) != 0;
+        po.keep = node->keep;
+        node->plan = plan_for(c, node->ids.data(), n_initial, po);
+        if (!node->plan->unsupported.empty()) { set_err(ACVM_E_UNSUPPORTED, node->plan->unsupported); return nullptr; }
+        node->plan_ms = node->plan->plan_ms;
+        node->tile = opts && opts->tile_instances ? opts->tile_instances : auto_tile(*node->plan, po, node->ids, node->keep, devices);
+    }
+    if (!node->tile) return nullptr;
     node->lanes.resize(devices.size());
     const size_t row = (size_t)n_initial * 32;
     // one handle per device, created side by side (each allocates tens of GB and levelises the circuit)
@@ -461,6 +474,8 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
     for (auto &t : th) t.join();
     for (DeviceLane &L : node->lanes)
         if (L.rc) { set_err(L.rc, "device " + std::to_string(L.device) + ": " + L.error); return nullptr; }
+    node->plans_built = (uint32_t)(acvm_circuit_plans_built(c) - built_before);
+    node->create_ms = now_ms() - t_create;
     return node.release();
 } ABI_CATCH_PTR
 
@@ -511,6 +526,14 @@ int acvm_node_stats(acvm_node_t *n, acvm_node_stats_t *out) {
         out->numa_node[d] = L.numa_node;
         out->n_cpus_pinned[d] = (uint32_t)L.cpus.size();
         out->first_cpu[d] = L.cpus.empty() ? -1 : (int)L.cpus.front();
+    }
+    out->plans_built = n->plans_built;
+    out->create_ms = n->create_ms;
+    out->plan_ms = n->plan_ms;
+    {   // resident set of the process (the shared plan of a 10^6-opcode circuit is hundreds of MB; it used to exist once per lane)
+        std::ifstream f("/proc/self/statm");
+        unsigned long long pages_total = 0, pages_resident = 0;
+        if (f >> pages_total >> pages_resident) out->host_rss_bytes = (uint64_t)pages_resident * (uint64_t)sysconf(_SC_PAGESIZE);
     }
     return 0;
 }

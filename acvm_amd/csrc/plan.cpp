@@ -296,6 +296,53 @@ void emit_straight_line(const BrilligCall &b, uint32_t oi, ConstPool &pool, std:
     sl_of[oi] = {at, flags_at};
 }
 
+
+// =========================================================================== placement of a level's records inside their class's list
+// The records of one level are independent, so their order inside a class's list is a launch-placement choice (schedule.cpp
+// layout_launches cuts the lists into launches along these groups):
+//   * CLS_HASH: byte-message records first -- short messages (<= 256 bytes: 16 KiB of LDS per 64 instances), then long ones (the LDS message
+//     of a launch is sized by its longest record: a 1 024-byte message takes 77 KiB of the workgroup's 160 KiB on gfx950; one long message
+//     somewhere in the circuit must not cost every 64-byte SHA record its occupancy) -- then the records of the scratch-carrying kernel;
+//   * CLS_GRUMPKIN: the longest records first (SchnorrVerify ~1.7 ms of one wave per SIMD, FixedBaseScalarMul 0.3): workgroups are placed in
+//     grid order, and at ~240 registers a SIMD holds two of these waves -- a long wave that arrives last waits for a slot behind short ones;
+//   * CLS_LIGHT: straight-line Brillig records last: they have a kernel of their own (kernels_ops.hip LightSlOp).
+void order_level_records(Plan &p) {
+    const std::vector<uint32_t> &pg = p.prog;
+    for (size_t L = 0; L < p.n_levels; L++) {
+        {
+            const int k = CLS_HASH;
+            const uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
+            std::vector<std::pair<uint32_t, uint32_t>> recs;  // (offset, scratch)
+            for (int pass = 0; pass < 3 && hi > lo; pass++)
+                for (uint32_t r = lo; r < hi; r++)
+                    if (hash_launch_group(pg, p.cls_offset[k][r]) == pass) recs.push_back({p.cls_offset[k][r], p.cls_scratch[k][r]});
+            for (uint32_t r = lo; r < hi; r++) { p.cls_offset[k][r] = recs[r - lo].first; p.cls_scratch[k][r] = recs[r - lo].second; }
+        }
+        {
+            const int k = CLS_GRUMPKIN;
+            const uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
+            if (hi - lo > 1) {
+                std::vector<std::pair<uint32_t, uint32_t>> recs;
+                for (uint32_t r = lo; r < hi; r++) recs.push_back({p.cls_offset[k][r], p.cls_scratch[k][r]});
+                std::stable_sort(recs.begin(), recs.end(), [&](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) {
+                    auto rank = [&](uint32_t off) { const uint32_t kind = pg[off]; return kind == PK_SCHNORR ? 0 : kind == PK_PEDERSEN ? 1 : 2; };
+                    return rank(x.first) < rank(y.first);
+                });
+                for (uint32_t r = lo; r < hi; r++) { p.cls_offset[k][r] = recs[r - lo].first; p.cls_scratch[k][r] = recs[r - lo].second; }
+            }
+        }
+        {
+            const int k = CLS_LIGHT;
+            const uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
+            std::vector<std::pair<uint32_t, uint32_t>> recs;
+            for (int pass = 0; pass < 2 && hi > lo; pass++)
+                for (uint32_t r = lo; r < hi; r++)
+                    if ((pg[p.cls_offset[k][r]] == PK_BRILLIG_SL) == (pass == 1)) recs.push_back({p.cls_offset[k][r], p.cls_scratch[k][r]});
+            for (uint32_t r = lo; r < hi; r++) { p.cls_offset[k][r] = recs[r - lo].first; p.cls_scratch[k][r] = recs[r - lo].second; }
+        }
+    }
+}
+
 }  // namespace
 
 Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
@@ -1623,6 +1670,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     p.dyn_level_start[max_level] = (uint32_t)p.dyn_offset.size();
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k][max_level] = (uint32_t)p.cls_offset[k].size();
     for (uint32_t L = 1; L <= max_level; L++) p.max_level_width = std::max(p.max_level_width, width[L]);
+    order_level_records(p);
     p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return p;
 }

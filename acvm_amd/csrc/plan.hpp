@@ -16,6 +16,7 @@
 #pragma once
 #include "circuit.hpp"
 #include "tuning.hpp"
+#include <algorithm>
 #include <map>
 #include <string>
 #include <utility>
@@ -159,5 +160,22 @@ struct PlanOpts {
 };
 
 Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts = PlanOpts());
+
+// message words per instance (32-bit) of the byte-message hash record at prog[at], or of the longest member of the chain it heads
+inline uint32_t hash_record_lds_words(const std::vector<uint32_t> &pg, size_t at) {
+    uint32_t words = 0;
+    for (;;) {
+        const uint32_t n_in = pg[at + 3];
+        words = std::max(words, (n_in + 3u) / 4u);
+        if (!(pg[at + 2] & PLAN_HASH_CHAIN_FLAG)) break;
+        at = pg[pg[at + 6 + 2 * (size_t)n_in + 64 + ((pg[at + 2] & PLAN_HASH_RANGE_FLAG) ? 2 * (size_t)n_in : 0)]];
+    }
+    return words;
+}
+// launch group of a CLS_HASH record inside its level: 0 byte message of <= 256 bytes, 1 longer byte message, 2 the scratch-carrying kernel
+inline int hash_launch_group(const std::vector<uint32_t> &pg, size_t at) {
+    if (pg[at] != PK_HASH || !(pg[at + 2] & PLAN_HASH_COOP_FLAG)) return 2;  // (the class also holds PK_PERM_SORT records, whose word 2 is an element count)
+    return hash_record_lds_words(pg, at) <= 64u ? 0 : 1;
+}
 
 }  // namespace acvm

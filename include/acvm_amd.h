@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ACVM_AMD_ABI_VERSION 5
+#define ACVM_AMD_ABI_VERSION 6
 
 /* library-level error codes */
 enum {
@@ -248,10 +248,30 @@ int acvm_circuit_opcode_kinds(const acvm_circuit_t *c, uint32_t first, uint32_t 
 /* Host-only levelisation against a set of initial witness ids (no device needed): plan statistics in *out. Returns 0, or
  * ACVM_E_UNSUPPORTED (reason in acvm_last_error) if the circuit holds an opcode no kernel implements. */
 int acvm_circuit_plan_stats(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, acvm_stats_t *out);
+/* how often this circuit handle has been levelised so far: handles created for the same (initial ids, options, tuning) share one immutable plan */
+uint64_t acvm_circuit_plans_built(const acvm_circuit_t *c);
 /* the same for a batch created with acvm_batch_new_ex's flags (n_table_rows, n_digest_segments) */
 int acvm_circuit_plan_stats_ex(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids,
                                uint32_t n_keep, acvm_stats_t *out);
 
+/*
+ * Host-only: the hazard checker of the level schedule (acvm_amd/csrc/schedule_check.cpp). One solve is enqueued on up to six streams with
+ * partial waits, recycled rows and rows whose representation depends on the consumer; the reference's semantics are strictly in order
+ * (acvm/src/pwg/mod.rs:236-303). For the plan and schedule a handle of n_instances instances with these flags (acvm_batch_new_ex's, | 0x100 =
+ * planned for a caller-supplied solver) would use, the checker derives every launch's reads and writes from the record words, builds
+ * happens-before from stream order + event edges, and proves: every conflicting pair of accesses is ordered, every read sees the write of the
+ * witness the original opcode names, every reader outside the gate kernels sees a canonical row, no bound passes 2^256. Returns 0 (proved),
+ * 1 (findings; the first 32 as text in report) or a negative error. counts[0..5) = launches, waits, accesses, records, findings.
+ * drop_wait = k leaves the k-th cross-stream wait out of the schedule (mutation testing: the checker must then name the resource and the
+ * two launches); 0xFFFFFFFF = the schedule as enqueued.
+ */
+int acvm_circuit_check_schedule(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids, uint32_t n_keep,
+                                uint32_t n_instances, uint32_t drop_wait, uint64_t *counts /*[5]*/, char *report, size_t report_len);
+/* Host-only: 64-bit fingerprints of the static plan (gate stream, in-order program, level and dependency tables, row assignment ...), one per
+ * component, into out[0, cap); returns the number of components. flags: acvm_batch_new_ex's, | 0x100 = planned for a caller-supplied solver.
+ * For tests and tools that assert that a change of the planner moved nothing (tests/test_plan_host.py). */
+int acvm_debug_plan_fingerprint(const acvm_circuit_t *c, const uint32_t *initial_ids, uint32_t n_initial, uint32_t flags, const uint32_t *keep_ids,
+                                uint32_t n_keep, uint64_t *out, uint32_t cap);
 /*
  * ACVM::new for n_instances instances that all assign the same initial witness ids.
  * The circuit is levelised once against that set. `solver` may be NULL (built-in HIP backend).
@@ -515,6 +535,11 @@ typedef struct {
     int numa_node[16];
     uint32_t n_cpus_pinned[16];
     int first_cpu[16];
+    /* creation (ABI 6): how often acvm_node_new levelised the circuit (1, or 0 when the circuit's plan cache already held this plan -- the plan
+     * is immutable and shared by every lane's handle), its wall clock, the planner's own time, and the process's resident set at the call */
+    uint32_t plans_built;
+    double create_ms, plan_ms;
+    uint64_t host_rss_bytes;
 } acvm_node_stats_t;
 acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solver, const uint32_t *initial_ids, uint32_t n_initial,
                            const uint32_t *keep_ids, uint32_t n_keep, const acvm_node_opts_t *opts);

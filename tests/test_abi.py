@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_string():
     import acvm_amd
     L = acvm_amd.lib()
-    assert L.acvm_abi_version() == 5
+    assert L.acvm_abi_version() == 6
     assert acvm_amd.Circuit  # python mirror present
 
 

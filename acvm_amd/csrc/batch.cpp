@@ -179,6 +179,21 @@ int acvm_circuit_plan_stats_ex(const acvm_circuit_t *c, const uint32_t *initial_
 
 // The circuit's plan cache (batch.hpp PlanKey): a hit hands out the shared plan; a miss plans outside the lock (a second thread asking for the
 // same plan meanwhile plans too -- the node driver asks once, before its lanes start).
+static size_t plan_bytes(const Plan &p) {
+    size_t words = p.gate_stream.size() + p.gate_offset.size() + p.prog.size() + p.prog_offset.size() + p.prog_scratch.size() + p.bytecode.size() + p.slot_of.size() + p.kbound.size() +
+                   p.unscale_index.size() + p.scaled_ids.size() + p.producer.size() + p.byte_plane_of.size() + p.dyn_offset.size();
+    for (int k = 0; k < (int)N_CLS; k++) words += 2 * p.cls_offset[k].size();
+    return words * 4 + (p.constants.size() + p.unscale.size()) * sizeof(FrH);
+}
+// (under c->plan_mutex) sp becomes the newest of the strongly held plans; older ones go while there are more than 8 or more than ~1 GiB of them
+static void remember_plan(const acvm_circuit *c, const std::shared_ptr<const Plan> &sp) {
+    auto &v = c->recent_plans;
+    v.erase(std::remove(v.begin(), v.end(), sp), v.end());
+    v.push_back(sp);
+    size_t total = 0;
+    for (auto &q : v) total += plan_bytes(*q);
+    while (v.size() > 1 && (v.size() > 8 || total > (1ull << 30))) { total -= plan_bytes(*v.front()); v.erase(v.begin()); }
+}
 std::shared_ptr<const Plan> plan_for(const acvm_circuit *c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
     PlanKey key;
     key.ids.assign(initial_ids, initial_ids + n_initial);
@@ -196,7 +211,7 @@ std::shared_ptr<const Plan> plan_for(const acvm_circuit *c, const uint32_t *init
         for (auto it = c->plan_cache.begin(); it != c->plan_cache.end();) {
             std::shared_ptr<const Plan> sp = it->second.lock();
             if (!sp) { it = c->plan_cache.erase(it); continue; }
-            if (it->first == key) { c->n_plans_shared++; c->last_plan = sp; return sp; }
+            if (it->first == key) { c->n_plans_shared++; remember_plan(c, sp); return sp; }
             ++it;
         }
     }
@@ -204,7 +219,7 @@ std::shared_ptr<const Plan> plan_for(const acvm_circuit *c, const uint32_t *init
     std::lock_guard<std::mutex> g(c->plan_mutex);
     c->n_plans_built++;
     c->plan_cache.push_back({std::move(key), sp});
-    c->last_plan = sp;
+    remember_plan(c, sp);
     return sp;
 }
 uint64_t acvm_circuit_plans_built(const acvm_circuit_t *c) {

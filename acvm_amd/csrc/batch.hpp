@@ -51,11 +51,11 @@ struct PlanKey {
 };
 struct acvm_circuit {
     std::unique_ptr<Circuit> c;
-    // the most recent plans of this circuit (weak: a plan lives as long as a handle uses it; the last one is also held strongly so that
+    // the plans of this circuit (weak: a plan lives as long as a handle uses it; the most recent ones are also held strongly so that
     // create / free / create of handles -- bench legs, the node driver's auto_tile followed by its lanes -- does not plan again)
     mutable std::mutex plan_mutex;
     mutable std::vector<std::pair<PlanKey, std::weak_ptr<const Plan>>> plan_cache;
-    mutable std::shared_ptr<const Plan> last_plan;
+    mutable std::vector<std::shared_ptr<const Plan>> recent_plans;  // newest last; at most 8, at most ~1 GiB of plan words, always the newest
     mutable uint64_t n_plans_built = 0, n_plans_shared = 0;
 };
 // the plan of `c` for these options: from the circuit's cache, or built (and cached) now. Never null; a refused circuit's plan has `unsupported` set.

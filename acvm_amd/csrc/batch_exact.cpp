@@ -841,8 +841,11 @@ int resolve_internal_calls(acvm_batch *b) {
             const uint32_t n = input_len(t, 0);
             uint8_t dom[32];
             value_be(t, n, dom);
-            bool fits = true;  // registers.get(domain_separator).to_u128().try_into::<u32>() (black_box.rs:152-158)
-            for (int k = 0; k < 28; k++) fits &= dom[k] == 0;
+            // registers.get(domain_separator).to_u128().try_into::<u32>() (brillig_vm/src/black_box.rs:152-158): to_u128 keeps the LOW 128 bits
+            // (acir_field generic_ark.rs:227-230), so only bits 32..127 can make the conversion fail -- a value of 2^128 + k passes with separator k
+            // (ops_brillig.hpp tests the same three words)
+            bool fits = true;
+            for (int k = 16; k < 28; k++) fits &= dom[k] == 0;
             if (!fits) { outcome[q].rc = 1; outcome[q].err = "Invalid signature length"; continue; }
             key.push_back(n);
             key.push_back((uint64_t)dom[28] << 24 | (uint64_t)dom[29] << 16 | (uint64_t)dom[30] << 8 | dom[31]);

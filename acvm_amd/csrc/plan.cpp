@@ -343,15 +343,71 @@ void order_level_records(Plan &p) {
     }
 }
 
-}  // namespace
+// memory blocks: cell ranges of the per-instance memory table + the program-order chain level
+// level = level of the last write (MemoryInit included), rlevel = latest level of a read since that write: reads of a block
+// between two writes have no order among themselves and may share a level; a write comes after every earlier access
+struct Block { uint32_t base = 0, cap = 0, len = 0, readable = 0, level = 0, rlevel = 0; bool seen = false; };
+inline bool is_heavy(uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA || cls == CLS_DIGEST; }
 
-Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
-    const bool host_blackbox = opts.host_blackbox;
-    const Tuning tune = tuning();  // one snapshot for the whole plan
-    auto t0 = std::chrono::steady_clock::now();
+// The planner: one object per build_plan call, one method per PASS, in the order build_plan (at the end of this file) runs them. What a pass
+// leaves behind for the later ones is a member -- the intermediate state is explicit -- and what each pass promises is checked by
+// tests/test_plan_host.py pass by pass (acvm_debug_plan_passes) and, end to end, by the hazard checker over the schedule (schedule_check.cpp);
+// tools/plan_fingerprint.py asserts that a change here moved no word of any plan.
+struct Planner {
+    const Circuit &c;
+    const uint32_t *initial_ids;
+    const uint32_t n_initial;
+    const PlanOpts &opts;
+    const bool host_blackbox;
+    const Tuning tune;  // one snapshot for the whole plan
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     Plan p;
-    p.tune = tune;
-    p.n_opcodes = (uint32_t)c.opcodes.size();
+    uint32_t nw = 0;
+    // ---- pass 1 (init) -> everybody
+    std::vector<uint8_t> known;        // the generic instance's assigned set, in program order
+    std::vector<uint32_t> level;       // per witness: the level from which the MAIN stream may read it
+    ConstPool pool;
+    std::map<uint32_t, Block> blocks;
+    // ---- pass 2 (in-order program) -> replay
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> out_slots;  // per opcode: (position of flag word, witness); the flags are patched by the replay
+    std::vector<uint32_t> sl_prog;     // straight-line Brillig: the light records of the eligible opcodes, appended to `prog` behind the in-order program
+    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> sl_of;  // opcode -> (offset in sl_prog, position of its first output flag word)
+    uint32_t sl_base = 0;
+    // ---- pass 3 (pins) + 4 (replay: levels, folded gates, records) -> the schedule passes
+    std::vector<PendingGate> gates;
+    std::vector<PendingRecord> records;
+    std::vector<PendingInverse> inverses;
+    std::vector<uint32_t> heavy_level;  // witnesses produced by a record of a heavy class (those run on their own stream, batch.cpp): level of the record, else 0
+    std::vector<uint8_t> wlane;         // 1 + heavy lane of the record that produces w, 0 = not a heavy output
+    // hlevel[w]: the level from which the HEAVY stream may read w (level[w] is the main stream's; they differ for the outputs of
+    // heavy records: the heavy stream is in order, the main stream sees them HEAVY_LATENCY levels later)
+    std::vector<uint32_t> hlevel;
+    uint32_t K_heavy = 1, D_heavy = 0, D_pedersen = 0, K_pedersen = 1;
+    std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, witness of a heavy record it reads)
+    uint32_t out_latency = 0;  // levels of slack of the record whose outputs are being assigned
+    uint8_t out_lane = 0;
+    std::vector<uint8_t> pinned, is_scaled;
+    bool scaling_on = false, relax_on = false;
+    std::vector<FrH> ws, wsi;  // scale and 1 / scale of the scaled witnesses (indexed through scale_slot)
+    std::vector<uint32_t> scale_slot, gate_of;  // gate_of[w]: the gate that writes w
+    const FrH f_one = frh::one(), f_minus_one = frh::neg(frh::one());
+    // ---- the schedule passes
+    std::vector<uint32_t> wdef;  // wdef[w]: the level whose launches write w (a fused gate writes in its host's wave; 0 = initial witness)
+    uint32_t max_level = 0;
+
+    Planner(const Circuit &circ, const uint32_t *ids, uint32_t n_ids, const PlanOpts &o)
+        : c(circ), initial_ids(ids), n_initial(n_ids), opts(o), host_blackbox(o.host_blackbox), tune(tuning()), pool(p.constants) {}
+
+    void unsupported(uint32_t oi, const std::string &what) {
+        if (p.unsupported.empty()) p.unsupported = "opcode " + std::to_string(oi) + ": " + what + " has no kernel";
+    }
+    Plan finish() {
+        p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return std::move(p);
+    }
+
+    // =========================================================================== pass 1: the witness table, the initial set, the constants, the memory blocks
+    bool init() {
     // The witness table is dense (slot = witness index); the reference's BTreeMap takes any u32 index. Circuit bytes are
     // untrusted input: an index near 2^32 must neither wrap `max + 1` nor make the planner allocate per-witness vectors of
     // many GB, so indices above PLAN_MAX_WITNESSES - 1 are refused (ACVM_E_UNSUPPORTED at acvm_batch_new / plan_stats).
@@ -360,19 +416,18 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     if (nw64 > PLAN_MAX_WITNESSES) {
         p.unsupported = "witness index " + std::to_string(nw64 - 1) + " exceeds the dense witness table (at most " +
                         std::to_string(PLAN_MAX_WITNESSES) + " witnesses per circuit)";
-        return p;
+        return false;
     }
-    const uint32_t nw = (uint32_t)nw64;
+    nw = (uint32_t)nw64;
     p.n_witnesses = nw;
     p.initial_ids.assign(initial_ids, initial_ids + n_initial);
     p.producer.assign(nw, 0xFFFFFFFFu);
-    std::vector<uint8_t> known(nw, 0);
-    std::vector<uint32_t> level(nw, 0);
+    known.assign(nw, 0);
+    level.assign(nw, 0);
     for (uint32_t i = 0; i < n_initial; i++) {
         known[initial_ids[i]] = 1;
         p.producer[initial_ids[i]] = 0xFFFFFFFEu;
     }
-    ConstPool pool(p.constants);
     {
         std::vector<FrH> coefs;
         for (const Opcode &o : c.opcodes)
@@ -382,16 +437,8 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
         pool.prefill_neg_inv(coefs);
     }
-    std::vector<PendingGate> gates;
-    std::vector<PendingRecord> records;
-    std::vector<PendingInverse> inverses;
     gates.reserve(c.opcodes.size());
 
-    // memory blocks: cell ranges of the per-instance memory table + the program-order chain level
-    // level = level of the last write (MemoryInit included), rlevel = latest level of a read since that write: reads of a block
-    // between two writes have no order among themselves and may share a level; a write comes after every earlier access
-    struct Block { uint32_t base = 0, cap = 0, len = 0, readable = 0, level = 0, rlevel = 0; bool seen = false; };
-    std::map<uint32_t, Block> blocks;
     for (auto &o : c.opcodes)
         if (o.kind == OP_MEMORY_INIT) {
             Block &b = blocks[o.block_id];
@@ -401,19 +448,18 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         kv.second.base = p.mem_cells;
         p.mem_cells += kv.second.cap;
     }
+        return true;
+    }
 
+    // one record per opcode, original expressions; false: an opcode no kernel implements (p.unsupported says which)
+    bool emit_in_order_program() {
     // =========================================================================== in-order program (all opcodes)
-    auto unsupported = [&](uint32_t oi, const std::string &what) {
-        if (p.unsupported.empty()) p.unsupported = "opcode " + std::to_string(oi) + ": " + what + " has no kernel";
-    };
     p.prog_offset.reserve(c.opcodes.size());
     p.prog_class.assign(c.opcodes.size(), CLS_LIGHT);
     p.prog_scratch.assign(c.opcodes.size(), 0);
     // the `flag` words (was the output already assigned for the generic instance?) are patched in the second pass
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> out_slots(c.opcodes.size());  // (position of flag word, witness)
+    out_slots.assign(c.opcodes.size(), {});  // (position of flag word, witness)
     // straight-line Brillig (below): the light records of the eligible opcodes, appended to `prog` behind the in-order program
-    std::vector<uint32_t> sl_prog;
-    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> sl_of;  // opcode -> (offset in sl_prog, position of its first output flag word)
     {
         std::map<uint32_t, Block> st = blocks;  // running len / readable per block in program order
         for (auto &kv : st) { kv.second.len = 0; kv.second.readable = 0; }
@@ -752,27 +798,13 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
         }
     }
-    if (!p.unsupported.empty()) {
-        p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return p;
-    }
-    const uint32_t sl_base = (uint32_t)p.prog.size();  // nothing in `prog` moves from here on: later passes only append
+    if (!p.unsupported.empty()) return false;
+    sl_base = (uint32_t)p.prog.size();  // nothing in `prog` moves from here on: later passes only append
     p.prog.insert(p.prog.end(), sl_prog.begin(), sl_prog.end());
+        return true;
+    }
 
-    // =========================================================================== generic-instance replay + levels
-    // witnesses produced by a record of a heavy class (those run on their own stream, batch.cpp): level of the record, else 0
-    std::vector<uint32_t> heavy_level(nw, 0);
-    std::vector<uint8_t> wlane(nw, 0);  // 1 + heavy lane of the record that produces w, 0 = not a heavy output
-    // hlevel[w]: the level from which the HEAVY stream may read w (level[w] is the main stream's; they differ for the outputs of
-    // heavy records: the heavy stream is in order, the main stream sees them HEAVY_LATENCY levels later)
-    std::vector<uint32_t> hlevel(nw, 0);
-    const uint32_t K_heavy = (uint32_t)std::max<int64_t>(tune.heavy_epoch, 1), D_heavy = (uint32_t)std::max<int64_t>(tune.heavy_latency, 0);
-    const uint32_t D_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_latency, 0), K_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_epoch, 1);
-    auto is_heavy = [](uint32_t cls) { return cls == CLS_HASH || cls == CLS_GRUMPKIN || cls == CLS_BRILLIG || cls == CLS_PEDERSEN || cls == CLS_ECDSA || cls == CLS_DIGEST; };
-    std::vector<std::pair<uint32_t, uint32_t>> heavy_reads;  // (level of a main-stream record, witness of a heavy record it reads)
-    uint32_t out_latency = 0;  // levels of slack of the record whose outputs are being assigned
-    uint8_t out_lane = 0;
-    auto assign_out = [&](uint32_t oi, uint32_t lvl, bool heavy) {
+    void assign_out(uint32_t oi, uint32_t lvl, bool heavy) {
         // insert_value (pwg/mod.rs:338-357) for the outputs of opcode oi, in record order
         for (auto &slot : out_slots[oi]) {
             uint32_t w = slot.second;
@@ -784,20 +816,23 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 if (heavy) { heavy_level[w] = lvl; level[w] = lvl + out_latency; wlane[w] = out_lane; }
             }
         }
-    };
-    auto out_levels = [&](uint32_t oi, uint32_t lvl, bool heavy) {  // an already-assigned output is read (compared)
+    }
+    uint32_t out_levels(uint32_t oi, uint32_t lvl, bool heavy) {  // an already-assigned output is read (compared)
         for (auto &slot : out_slots[oi])
             if (known[slot.second]) lvl = std::max(lvl, heavy ? hlevel[slot.second] : level[slot.second]);
         return lvl;
-    };
+    }
+
+    void pin_witnesses() {
     // =========================================================================== projective witnesses
     // A witness that only Arithmetic opcodes touch may be kept as scale_w * value: the gate that solves it picks scale_w so that
     // its most expensive coefficient becomes 1 (q_M a b + q_1 c + q_c over q_o: the product needs no coefficient multiplication
     // and shares one Montgomery reduction with q_1' c), and every later gate divides its coefficients by the scales of its
     // operands -- all on the host, field arithmetic is exact, so the canonical value scale_w^-1 * stored is bit-identical.
     // Pinned (scale 1): initial witnesses and everything a non-Arithmetic opcode mentions. Export and the exact path unscale.
-    std::vector<uint8_t> pinned(nw, 0), is_scaled(nw, 0);
-    const bool scaling_on = tune.scale != 0;
+    pinned.assign(nw, 0);
+    is_scaled.assign(nw, 0);
+    scaling_on = tune.scale != 0;
     {
         auto pin = [&](uint32_t w) { if (w < nw) pinned[w] = 1; };
         auto pin_expr = [&](const Expr &e) {
@@ -844,125 +879,152 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             }
         }
     }
-    std::vector<FrH> ws, wsi;  // scale and 1 / scale of the scaled witnesses (indexed through scale_slot)
-    std::vector<uint32_t> scale_slot(nw, 0xFFFFFFFFu);
+    }
+
+    // =========================================================================== pass 4: generic-instance replay + levels
+    // every opcode in program order: a non-Arithmetic opcode becomes a record of its class at its level (level_record), an Arithmetic opcode a
+    // folded gate (level_gate); stops at the first opcode the generic instance cannot execute (p.truncated_at)
+    void replay() {
+    // =========================================================================== generic-instance replay + levels
+    heavy_level.assign(nw, 0);
+    wlane.assign(nw, 0);
+    hlevel.assign(nw, 0);
+    K_heavy = (uint32_t)std::max<int64_t>(tune.heavy_epoch, 1), D_heavy = (uint32_t)std::max<int64_t>(tune.heavy_latency, 0);
+    D_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_latency, 0), K_pedersen = (uint32_t)std::max<int64_t>(tune.pedersen_epoch, 1);
+    scale_slot.assign(nw, 0xFFFFFFFFu);
     // Relaxed rows (gate_eval.hpp): a witness that may carry a scale is also stored as ANY representative below 2^256; kbound[w] = its
     // bound in units of p / 256 (everything else is canonical: GATE_K_CANON). gate_of[w]: the gate that writes w.
-    const bool relax_on = scaling_on && tune.relax != 0;
+    relax_on = scaling_on && tune.relax != 0;
     p.kbound.assign(nw, GATE_K_CANON);
-    std::vector<uint32_t> &kbound = p.kbound;
-    std::vector<uint32_t> gate_of(nw, 0xFFFFFFFFu);
-    const FrH f_one = frh::one(), f_minus_one = frh::neg(frh::one());
+    gate_of.assign(nw, 0xFFFFFFFFu);
     for (uint32_t oi = 0; oi < c.opcodes.size() && p.truncated_at == 0xFFFFFFFFu; oi++) {
         const Opcode &o = c.opcodes[oi];
-        if (o.kind != OP_ARITHMETIC) {
-            // a Brillig opcode with a straight-line record runs in the light class of the level schedule (the exact path keeps its VM record)
-            const auto sl_it = o.kind == OP_BRILLIG ? sl_of.find(oi) : sl_of.end();
-            const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN
-                                     : sl_it != sl_of.end() ? (uint32_t)CLS_LIGHT : (uint32_t)p.prog_class[oi];
-            const bool rec_heavy = is_heavy(rec_cls);
-            Reads rd(known, rec_heavy ? hlevel : level);
-            uint32_t extra_level = 0;
-            int mem_access = 0;  // 1 read, 2 write
-            uint64_t bytes_written = out_slots[oi].size();
-            switch (o.kind) {
-            case OP_BLACKBOX: {
-                const BlackBoxCall &b = *o.bb;
-                for (int g = 0; g < 4; g++)
-                    for (auto &in : b.in[g]) rd.witness(in.witness);
-                if (b.has_in_agg)
-                    for (auto &in : b.in_agg) rd.witness(in.witness);
+        if (!(o.kind != OP_ARITHMETIC ? level_record(oi, o) : level_gate(oi, o))) break;
+    }
+
+    p.unscale_index.assign(nw, 0xFFFFFFFFu);
+    for (uint32_t w = 0; w < nw; w++)
+        if (is_scaled[w]) {
+            p.unscale_index[w] = (uint32_t)p.scaled_ids.size();
+            p.scaled_ids.push_back(w);
+            p.unscale.push_back(wsi[scale_slot[w]]);
+        }
+    }
+
+    // a non-Arithmetic opcode: its reads for the generic instance, its level, its outputs; false: the generic instance cannot execute it
+    bool level_record(uint32_t oi, const Opcode &o) {
+        // a Brillig opcode with a straight-line record runs in the light class of the level schedule (the exact path keeps its VM record)
+        const auto sl_it = o.kind == OP_BRILLIG ? sl_of.find(oi) : sl_of.end();
+        const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN
+                                 : sl_it != sl_of.end() ? (uint32_t)CLS_LIGHT : (uint32_t)p.prog_class[oi];
+        const bool rec_heavy = is_heavy(rec_cls);
+        Reads rd(known, rec_heavy ? hlevel : level);
+        uint32_t extra_level = 0;
+        int mem_access = 0;  // 1 read, 2 write
+        uint64_t bytes_written = out_slots[oi].size();
+        switch (o.kind) {
+        case OP_BLACKBOX: {
+            const BlackBoxCall &b = *o.bb;
+            for (int g = 0; g < 4; g++)
+                for (auto &in : b.in[g]) rd.witness(in.witness);
+            if (b.has_in_agg)
+                for (auto &in : b.in_agg) rd.witness(in.witness);
+            break;
+        }
+        case OP_DIRECTIVE: {
+            const Directive &d = *o.dir;
+            if (d.kind == DIR_PERMUTATION_SORT) {
+                for (auto &el : d.sort_inputs)
+                    for (auto &ex : el) rd.expr(ex);
                 break;
             }
-            case OP_DIRECTIVE: {
-                const Directive &d = *o.dir;
-                if (d.kind == DIR_PERMUTATION_SORT) {
-                    for (auto &el : d.sort_inputs)
-                        for (auto &ex : el) rd.expr(ex);
-                    break;
-                }
-                rd.expr(d.a);
-                if (d.kind == DIR_QUOTIENT) { rd.expr(d.b); if (d.has_predicate) rd.expr(d.predicate); }
-                break;
-            }
-            case OP_MEMORY_INIT: {
-                Block &b = blocks[o.block_id];
-                for (uint32_t w : o.init) rd.witness(w);
+            rd.expr(d.a);
+            if (d.kind == DIR_QUOTIENT) { rd.expr(d.b); if (d.has_predicate) rd.expr(d.predicate); }
+            break;
+        }
+        case OP_MEMORY_INIT: {
+            Block &b = blocks[o.block_id];
+            for (uint32_t w : o.init) rd.witness(w);
+            extra_level = std::max(b.level, b.rlevel);
+            mem_access = 2;
+            bytes_written = o.init.size();
+            break;
+        }
+        case OP_MEMORY_OP: {
+            Block &b = blocks[o.block_id];
+            rd.expr(o.mem_operation);
+            rd.expr(o.mem_index);
+            if (o.has_predicate) rd.expr(o.predicate);
+            // read or write is decided by the VALUE of `operation` (memory_op.rs:91); static only if it is a constant
+            uint32_t off = p.prog_offset[oi];
+            const Expr &op = o.mem_operation;
+            bool is_const = op.mul.empty() && op.lin.empty();
+            if (!is_const) { rd.ok = false; break; }
+            if (op.qc.is_zero()) {
+                // read: Expression::to_witness (expression/mod.rs:158-172) on the evaluated value expression
+                const Expr &v = o.mem_value;
+                bool shape = v.mul.empty() && v.lin.size() == 1 && v.lin[0].c == frh::one() && v.qc.is_zero() &&
+                             v.lin[0].w < known.size() && !known[v.lin[0].w];
+                if (!shape) { rd.ok = false; break; }
+                p.prog[off + 6] = 1;
+                p.prog[off + 7] = v.lin[0].w;
+                out_slots[oi].push_back({off + 8, v.lin[0].w});
+                bytes_written = 1;
+                extra_level = b.level;
+                mem_access = 1;
+            } else {
+                rd.expr(o.mem_value);
+                p.prog[off + 6] = 0;
+                bytes_written = 1;
                 extra_level = std::max(b.level, b.rlevel);
                 mem_access = 2;
-                bytes_written = o.init.size();
-                break;
             }
-            case OP_MEMORY_OP: {
-                Block &b = blocks[o.block_id];
-                rd.expr(o.mem_operation);
-                rd.expr(o.mem_index);
-                if (o.has_predicate) rd.expr(o.predicate);
-                // read or write is decided by the VALUE of `operation` (memory_op.rs:91); static only if it is a constant
-                uint32_t off = p.prog_offset[oi];
-                const Expr &op = o.mem_operation;
-                bool is_const = op.mul.empty() && op.lin.empty();
-                if (!is_const) { rd.ok = false; break; }
-                if (op.qc.is_zero()) {
-                    // read: Expression::to_witness (expression/mod.rs:158-172) on the evaluated value expression
-                    const Expr &v = o.mem_value;
-                    bool shape = v.mul.empty() && v.lin.size() == 1 && v.lin[0].c == frh::one() && v.qc.is_zero() &&
-                                 v.lin[0].w < known.size() && !known[v.lin[0].w];
-                    if (!shape) { rd.ok = false; break; }
-                    p.prog[off + 6] = 1;
-                    p.prog[off + 7] = v.lin[0].w;
-                    out_slots[oi].push_back({off + 8, v.lin[0].w});
-                    bytes_written = 1;
-                    extra_level = b.level;
-                    mem_access = 1;
-                } else {
-                    rd.expr(o.mem_value);
-                    p.prog[off + 6] = 0;
-                    bytes_written = 1;
-                    extra_level = std::max(b.level, b.rlevel);
-                    mem_access = 2;
-                }
-                break;
-            }
-            case OP_BRILLIG: {
-                const BrilligCall &b = *o.brillig;
-                if (b.has_predicate) rd.expr(b.predicate);
-                for (auto &in : b.inputs) {
-                    if (in.is_array) for (auto &e : in.arr) rd.expr(e);
-                    else rd.expr(in.single);
-                }
-                break;
-            }
-            default: rd.ok = false;
-            }
-            if (!rd.ok) { p.truncated_at = oi; break; }
-            uint32_t lvl = std::max(rd.lvl, extra_level);
-            lvl = out_levels(oi, lvl, rec_heavy) + 1;
-            if (rec_heavy) lvl = (lvl + K_heavy - 1) / K_heavy * K_heavy;  // the next heavy batch
-            if (rec_cls == CLS_PEDERSEN && K_pedersen > 1) lvl = (lvl + K_pedersen - 1) / K_pedersen * K_pedersen;
-            std::vector<uint32_t> rec_reads = rd.ws;  // compared outputs are reads too
-            for (auto &slot : out_slots[oi])
-                if (known[slot.second]) rec_reads.push_back(slot.second);
-            if (!rec_heavy)  // a main-stream record: which heavy records does it wait for
-                for (uint32_t w : rec_reads)
-                    if (heavy_level[w]) heavy_reads.push_back({lvl, w});
-            out_latency = rec_cls == CLS_PEDERSEN ? std::max(D_heavy, D_pedersen) : D_heavy;
-            out_lane = (uint8_t)(1 + heavy_lane(rec_cls));
-            assign_out(oi, lvl, rec_heavy);
-            if (mem_access == 1) blocks[o.block_id].rlevel = std::max(blocks[o.block_id].rlevel, lvl);
-            else if (mem_access == 2) { blocks[o.block_id].level = lvl; blocks[o.block_id].rlevel = 0; }
-            uint64_t bytes = 32ull * (rd.distinct() + bytes_written);
-            p.algorithmic_bytes += bytes;
-            p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
-            p.n_other_records++;
-            records.push_back({lvl, rec_cls, oi, std::move(rec_reads)});
-            if (sl_it != sl_of.end()) {  // same "already assigned" flags as the VM record's outputs, in order
-                records.back().prog_at = sl_base + sl_it->second.first;
-                for (size_t k = 0; k < out_slots[oi].size(); k++) p.prog[sl_base + sl_it->second.first + sl_it->second.second + 2 * k] = p.prog[out_slots[oi][k].first];
-                p.n_brillig_inlined++;
-            }
-            continue;
+            break;
         }
+        case OP_BRILLIG: {
+            const BrilligCall &b = *o.brillig;
+            if (b.has_predicate) rd.expr(b.predicate);
+            for (auto &in : b.inputs) {
+                if (in.is_array) for (auto &e : in.arr) rd.expr(e);
+                else rd.expr(in.single);
+            }
+            break;
+        }
+        default: rd.ok = false;
+        }
+        if (!rd.ok) { p.truncated_at = oi; return false; }
+        uint32_t lvl = std::max(rd.lvl, extra_level);
+        lvl = out_levels(oi, lvl, rec_heavy) + 1;
+        if (rec_heavy) lvl = (lvl + K_heavy - 1) / K_heavy * K_heavy;  // the next heavy batch
+        if (rec_cls == CLS_PEDERSEN && K_pedersen > 1) lvl = (lvl + K_pedersen - 1) / K_pedersen * K_pedersen;
+        std::vector<uint32_t> rec_reads = rd.ws;  // compared outputs are reads too
+        for (auto &slot : out_slots[oi])
+            if (known[slot.second]) rec_reads.push_back(slot.second);
+        if (!rec_heavy)  // a main-stream record: which heavy records does it wait for
+            for (uint32_t w : rec_reads)
+                if (heavy_level[w]) heavy_reads.push_back({lvl, w});
+        out_latency = rec_cls == CLS_PEDERSEN ? std::max(D_heavy, D_pedersen) : D_heavy;
+        out_lane = (uint8_t)(1 + heavy_lane(rec_cls));
+        assign_out(oi, lvl, rec_heavy);
+        if (mem_access == 1) blocks[o.block_id].rlevel = std::max(blocks[o.block_id].rlevel, lvl);
+        else if (mem_access == 2) { blocks[o.block_id].level = lvl; blocks[o.block_id].rlevel = 0; }
+        uint64_t bytes = 32ull * (rd.distinct() + bytes_written);
+        p.algorithmic_bytes += bytes;
+        p.cls_algorithmic_bytes[p.prog_class[oi]] += bytes;
+        p.n_other_records++;
+        records.push_back({lvl, rec_cls, oi, std::move(rec_reads)});
+        if (sl_it != sl_of.end()) {  // same "already assigned" flags as the VM record's outputs, in order
+            records.back().prog_at = sl_base + sl_it->second.first;
+            for (size_t k = 0; k < out_slots[oi].size(); k++) p.prog[sl_base + sl_it->second.first + sl_it->second.second + 2 * k] = p.prog[out_slots[oi][k].first];
+            p.n_brillig_inlined++;
+        }
+        return true;
+    }
+
+    // an Arithmetic opcode: classify its terms like ArithmeticSolver::evaluate, fold -1/coeff (and the scales) into the coefficients, choose the
+    // output's scale, emit the gate record and bound its result; false: the generic instance cannot execute it (panic / TooManyUnknowns)
+    bool level_gate(uint32_t oi, const Opcode &o) {
+        std::vector<uint32_t> &kbound = p.kbound;
         const Expr &e = o.expr;
         // classify terms like ArithmeticSolver::evaluate (arithmetic.rs:212-239) for the generic instance
         struct Prod { FrH c; uint32_t a, b; };
@@ -996,7 +1058,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         if (residual_mul > 0 || n_unknown > 1) {  // panic / TooManyUnknowns for the generic instance
             p.truncated_at = oi;
-            break;
+            return false;
         }
         PendingGate g;
         uint32_t lvl = 0;
@@ -1092,7 +1154,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 else { push_coef(lm, e_t); lm.push_back(t.a); }
             }
         }
-        if (pm.size() / 10 > 255 || lm.size() / 9 > 255) { p.truncated_at = oi; break; }
+        if (pm.size() / 10 > 255 || lm.size() / 9 > 255) { p.truncated_at = oi; return false; }
         g.level = lvl + 1;
         g.words = {kind | (uint32_t)(pm.size() / 10) << 8 | (uint32_t)(lm.size() / 9) << 16, oi, kind == GATE_ASSERT ? 0u : unk_w,
                    pool.constant(qc_scaled), kind == GATE_SOLVE_DYN ? unk_partner : 0u,
@@ -1184,15 +1246,10 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             inverses.push_back({inv_level, g.level, unk_partner, oi, (uint32_t)gates.size()});
         } else p.n_fast_gates++;
         gates.push_back(std::move(g));
+        return true;
     }
 
-    p.unscale_index.assign(nw, 0xFFFFFFFFu);
-    for (uint32_t w = 0; w < nw; w++)
-        if (is_scaled[w]) {
-            p.unscale_index[w] = (uint32_t)p.scaled_ids.size();
-            p.scaled_ids.push_back(w);
-            p.unscale.push_back(wsi[scale_slot[w]]);
-        }
+    void fuse_gate_pairs() {
     // =========================================================================== gate pairs / wave programs
     // A gate whose only operand from the previous level is the output of a SOLVE gate, and whose other operands are older than
     // that gate's whole wave, runs BEHIND it in the same wave: the intermediate witness comes from registers (`local`) instead
@@ -1245,6 +1302,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             p.n_gate_pairs++;
         }
     }
+    }
+
+    void assign_inverse_slots() {
     // =========================================================================== inverse slots: a slot is reused once its gate ran
     std::stable_sort(inverses.begin(), inverses.end(), [](const PendingInverse &a, const PendingInverse &b) { return a.level < b.level; });
     {
@@ -1260,9 +1320,12 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             iv.gate = slot;  // from here on: the slot
         }
     }
+    }
+
+    void fold_digest_leaves() {
     // =========================================================================== digest leaves folded into the solve
     // wdef[w]: the level whose launches write w (a fused gate writes in its host's wave; 0 = initial witness)
-    std::vector<uint32_t> wdef(nw, 0);
+    wdef.assign(nw, 0);
     for (auto &g : gates)
         if ((g.words[0] & 0xff) != GATE_ASSERT) wdef[g.words[2]] = g.run_level;
     for (auto &r : records)
@@ -1300,6 +1363,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 p.n_digest_segments++;
             }
     }
+    }
+
+    void fuse_range_checks() {
     // =========================================================================== byte RANGE checks fused into the hash that reads the byte
     // RANGE(w, <= 8 bits) on an input of a byte-message hash (the usual shape: every message byte is range-checked) reads the row the hash
     // kernel reads anyway and needs the low limb it forms anyway: the level schedule runs a copy of the hash record extended by
@@ -1355,6 +1421,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             records.swap(kept);
         }
     }
+    }
+
+    void chain_hashes() {
     // =========================================================================== hash chains
     // A byte-message hash B whose inputs are the digest of another byte-message hash A plus witnesses that were already known when A was
     // launched (a hash of a hash; the links of a Merkle path) runs behind A in A's workgroup (kernels_hash.hip): the level schedule gets a
@@ -1462,6 +1531,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 if (drop[i]) { records[i].level = launch_level[i]; records[i].chained = true; }
         }
     }
+    }
+
+    void merge_range_records() {
     // =========================================================================== RANGE opcodes of a level, eight to a record
     // A RANGE check is one row and a few dozen instructions: launched one lane per (opcode, instance) the kernel is bound by the chain of
     // dependent latencies every wave pays before its only load (config 3: 96 checks per instance). Merged records
@@ -1504,6 +1576,9 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
             records.swap(kept);
         }
     }
+    }
+
+    void order_and_dependencies() {
     // =========================================================================== order by (level, program order), lay out
     // within a level the longest wave programs (hosts with tails, many terms) go first: blocks are dispatched in grid order,
     // and a level ends when its last wave ends
@@ -1513,7 +1588,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         return a.words.size() > b.words.size();
     });
     std::stable_sort(records.begin(), records.end(), [](const PendingRecord &a, const PendingRecord &b) { return a.level < b.level; });
-    uint32_t max_level = 0;
+    max_level = 0;
     for (auto &g : gates) max_level = std::max(max_level, g.level);
     for (auto &r : records) max_level = std::max(max_level, r.level);
     for (auto &iv : inverses) max_level = std::max(max_level, iv.level);
@@ -1549,6 +1624,10 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
                 }
         }
     }
+    }
+
+    // false: the circuit cannot run with recycled rows (p.unsupported says why)
+    bool assign_rows() {
     // =========================================================================== witness-slot liveness reuse
     // A witness occupies a row of the table from the level that writes it to the level of its last reader; the rows of dead
     // witnesses go to a FIFO and are handed to the witnesses the MAIN stream defines later (gates, light records). The main stream
@@ -1561,7 +1640,7 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     if (opts.reuse_slots) {
         if (p.truncated_at != 0xFFFFFFFFu || p.has_foreign_calls) {
             p.unsupported = "slot reuse needs a circuit the level kernels cover entirely and no foreign calls";
-            return p;
+            return false;
         }
         constexpr int N_ASYNC = 1 + N_HEAVY_LANES;  // 0 = inversion batches, 1 + q = heavy lane q
         std::vector<uint32_t> last_any(nw, 0), last_on[N_ASYNC];
@@ -1639,6 +1718,10 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
         }
         for (auto &iv : inverses) iv.partner = p.slot_of[iv.partner];
     }
+        return true;
+    }
+
+    void lay_out() {
     p.dyn_level_start.assign(max_level + 1, 0);
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k].assign(max_level + 1, 0);
     size_t gi = 0, ri = 0, ii = 0;
@@ -1670,9 +1753,226 @@ Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initia
     p.dyn_level_start[max_level] = (uint32_t)p.dyn_offset.size();
     for (int k = 0; k < N_CLS; k++) p.cls_level_start[k][max_level] = (uint32_t)p.cls_offset[k].size();
     for (uint32_t L = 1; L <= max_level; L++) p.max_level_width = std::max(p.max_level_width, width[L]);
-    order_level_records(p);
-    p.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return p;
+    }
+
+    // =========================================================================== what each pass promises (tuning plan_validate; tests/test_plan_host.py)
+    // Cheap structural invariants, one check per pass, thrown as std::logic_error (the ABI turns it into ACVM_E_INVALID with this text). The
+    // semantic end-to-end check of the same plan is the hazard checker (schedule_check.cpp). plan_validate = 100 + k breaks invariant k on
+    // purpose first, so that a test can see each check fire.
+    [[noreturn]] void violated(const char *pass, const std::string &what) const {
+        throw std::logic_error(std::string("plan invariant violated after pass ") + pass + ": " + what);
+    }
+    bool inject(int k) const { return tune.plan_validate == 100 + k; }
+    void check_in_order_program() const {
+        const char *P = "emit_in_order_program";
+        if (p.prog_offset.size() != c.opcodes.size()) violated(P, "one record per opcode");
+        for (size_t oi = 0; oi < p.prog_offset.size(); oi++) {
+            const size_t at = p.prog_offset[oi];
+            if (at + 2 > p.prog.size() || (oi && at <= p.prog_offset[oi - 1])) violated(P, "record offsets are not increasing at opcode " + std::to_string(oi));
+            if (p.prog[at] > PK_BRILLIG_SL || p.prog[at] == PK_DIGEST_LEAF || p.prog[at] == PK_RANGE_MULTI || p.prog[at] == PK_BRILLIG_SL) violated(P, "opcode " + std::to_string(oi) + " has a record kind of the level schedule only");
+            if (p.prog[at + 1] != oi) violated(P, "record of opcode " + std::to_string(oi) + " names another opcode");
+            if (p.prog_class[oi] >= N_CLS) violated(P, "class out of range");
+            for (auto &slot : out_slots[oi])
+                if (slot.first == 0 || slot.first >= p.prog.size() || p.prog[slot.first - 1] != slot.second || p.prog[slot.first] > 1) violated(P, "output slot of opcode " + std::to_string(oi) + " does not sit behind its witness");
+        }
+    }
+    void check_replay() const {
+        const char *P = "replay";
+        for (size_t gi = 0; gi < gates.size(); gi++) {
+            const PendingGate &g = gates[gi];
+            if (g.level < 1) violated(P, "a gate at level 0");
+            for (uint32_t w : g.reads)
+                if (w >= nw || !known[w] || level[w] >= g.level) violated(P, "gate of opcode " + std::to_string(g.words[1]) + " reads witness " + std::to_string(w) + " before the main stream may");
+            if ((g.words[0] & 0xff) != GATE_ASSERT && level[g.words[2]] != g.level) violated(P, "a gate's output is not defined at the gate's level");
+        }
+        for (const PendingRecord &r : records) {
+            const std::vector<uint32_t> &lv = is_heavy(r.cls) ? hlevel : level;
+            for (uint32_t w : r.reads)
+                if (w >= nw || !known[w] || (p.producer[w] != r.opcode && lv[w] >= r.level)) violated(P, "record of opcode " + std::to_string(r.opcode) + " reads witness " + std::to_string(w) + " before its stream may");
+        }
+        for (const PendingInverse &iv : inverses)
+            if (iv.level <= level[iv.partner] || iv.use_level <= iv.level) violated(P, "inversion of opcode " + std::to_string(iv.opcode) + " is not between its denominator and its gate");
+        for (uint32_t w = 0; w < nw; w++) {
+            if (p.kbound[w] > GATE_K_ROW_MAX) violated(P, "witness " + std::to_string(w) + " may pass 2^256");
+            if (is_scaled[w] && pinned[w]) violated(P, "pinned witness " + std::to_string(w) + " carries a scale");
+            if (is_scaled[w] && !(frh::mul(ws[scale_slot[w]], wsi[scale_slot[w]]) == f_one)) violated(P, "scale x 1 / scale != 1 for witness " + std::to_string(w));
+            if (p.kbound[w] != GATE_K_CANON && !is_scaled[w]) violated(P, "relaxed witness " + std::to_string(w) + " has no unscale entry");
+        }
+        if (p.truncated_at != 0xFFFFFFFFu)
+            for (uint32_t w = 0; w < nw; w++)
+                if (p.producer[w] < 0xFFFFFFFEu && p.producer[w] >= p.truncated_at) violated(P, "a witness is produced behind the truncation");
+    }
+    void check_pairs() {
+        const char *P = "fuse_gate_pairs";
+        if (inject(1) && gates.size() > 1) { gates[1].fused = true; gates[1].run_level = gates[1].level; }
+        size_t n_fused = 0, n_tails = 0;
+        for (const PendingGate &g : gates) {
+            if (g.fused) {
+                n_fused++;
+                if (g.run_level >= g.level) violated(P, "a fused gate does not run before its own level");
+                if ((g.words[0] & 0xff) == GATE_SOLVE_DYN) violated(P, "a gate with an inversion runs as a tail");
+                continue;
+            }
+            if (g.run_level != g.level) violated(P, "a host runs off its level");
+            n_tails += g.n_tails;
+            size_t pos = 0, n_rec = 0;
+            for (;;) {  // the wave program: 1 + n_tails records chained by GATE_TAIL_FLAG, the forwarded operand only behind the first
+                if (pos + 6 > g.words.size()) violated(P, "a wave program runs past its words");
+                const uint32_t w0 = g.words[pos], w5 = g.words[pos + 5];
+                const size_t len = 6 + 10 * (size_t)((w0 >> 8) & 0xff) + 9 * (size_t)((w0 >> 16) & 0xff) + 2 * (size_t)((w5 & 0xff) + ((w5 >> 8) & 0xff)) + ((w5 >> 16) & 0xff) + (w5 >> 24);
+                if (pos + len > g.words.size()) violated(P, "a wave program runs past its words");
+                if (n_rec == 0)
+                    for (size_t t = pos + 6; t < pos + len; t++) {
+                        // (coefficient words may hold any value: only operand positions count)
+                    }
+                n_rec++;
+                if (!(w0 & GATE_TAIL_FLAG)) { if (pos + len != g.words.size()) violated(P, "words behind the last record of a wave program"); break; }
+                pos += len;
+            }
+            if (n_rec != 1 + g.n_tails) violated(P, "a wave program of " + std::to_string(n_rec) + " records with " + std::to_string(g.n_tails) + " tails");
+        }
+        if (n_fused != n_tails || n_fused != p.n_gate_pairs) violated(P, "fused gates and tails do not add up");
+    }
+    void check_inverse_slots() {
+        const char *P = "assign_inverse_slots";
+        if (inject(2) && inverses.size() > 1) inverses[1].gate = inverses[0].gate;
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> by_slot(p.n_inverse_slots);
+        for (const PendingInverse &iv : inverses) {
+            if (iv.gate >= p.n_inverse_slots) violated(P, "slot out of range");
+            by_slot[iv.gate].push_back({iv.level, iv.use_level});
+        }
+        for (auto &v : by_slot) {
+            std::sort(v.begin(), v.end());
+            for (size_t i = 1; i < v.size(); i++)
+                if (v[i].first <= v[i - 1].second) violated(P, "two inverses share a row of the table while both are alive");
+        }
+    }
+    void check_digest_leaves() const {
+        const char *P = "fold_digest_leaves";
+        if (!(opts.fold_digest && p.truncated_at == 0xFFFFFFFFu)) { if (p.n_digest_segments) violated(P, "leaves without the option"); return; }
+        std::vector<uint8_t> seen(nw, 0);
+        uint32_t n_rec = 0;
+        for (const PendingRecord &r : records) {
+            if (r.cls != CLS_DIGEST) continue;
+            n_rec++;
+            for (uint32_t w : r.reads) {
+                if (seen[w]++) violated(P, "witness " + std::to_string(w) + " is summed twice");
+                if (r.level <= wdef[w]) violated(P, "a leaf runs before its witness is written");
+            }
+        }
+        for (uint32_t w = 0; w < nw; w++)
+            if ((p.producer[w] != 0xFFFFFFFFu) != (seen[w] != 0)) violated(P, "witness " + std::to_string(w) + " is assigned but not summed (or the reverse)");
+        if (n_rec != p.n_digest_segments) violated(P, "leaf records and rows of the partial sums differ");
+    }
+    void check_range_accounting() const {
+        // every RANGE opcode the generic instance executes is checked exactly once: by its own record, inside the hash that reads its byte, or in a merged record
+        const char *P = "merge_range_records";
+        std::vector<uint8_t> times(c.opcodes.size(), 0);
+        for (const PendingRecord &r : records) {
+            const size_t at = r.prog_at != 0xFFFFFFFFu ? r.prog_at : r.synthetic ? r.opcode : p.prog_offset[r.opcode];
+            if (p.prog[at] == PK_RANGE) times[p.prog[at + 1]]++;
+            else if (p.prog[at] == PK_RANGE_MULTI)
+                for (uint32_t i = 0; i < p.prog[at + 2]; i++) times[p.prog[at + 3 + 3 * i]]++;
+            else if (p.prog[at] == PK_HASH && (p.prog[at + 2] & PLAN_HASH_RANGE_FLAG)) {
+                const uint32_t n_in = p.prog[at + 3], n_out = p.prog[at + 4];
+                for (uint32_t i = 0; i < n_in; i++)
+                    if (const uint32_t op = p.prog[at + 6 + 2 * (size_t)n_in + 2 * (size_t)n_out + 2 * i]; op != 0xFFFFFFFFu) times[op]++;
+            }
+        }
+        const uint32_t end = p.truncated_at == 0xFFFFFFFFu ? (uint32_t)c.opcodes.size() : p.truncated_at;
+        for (uint32_t oi = 0; oi < c.opcodes.size(); oi++) {
+            const bool is_range = p.prog[p.prog_offset[oi]] == PK_RANGE;
+            if (times[oi] != (is_range && oi < end ? 1 : 0)) violated(P, "RANGE opcode " + std::to_string(oi) + " is checked " + std::to_string(times[oi]) + " times");
+        }
+    }
+    void check_dependencies() const {
+        const char *P = "order_and_dependencies";
+        for (uint32_t L = 0; L <= max_level; L++) {
+            if (p.level_needs_inverse[L] && p.level_needs_inverse[L] >= L) violated(P, "a level waits for an inversion batch that is not earlier");
+            for (int q = 0; q < N_HEAVY_LANES; q++) {
+                if (p.level_needs_heavy[q][L] && p.level_needs_heavy[q][L] >= L) violated(P, "a main level waits for a heavy level that is not earlier");
+                if (p.inv_needs_heavy[q][L] && p.inv_needs_heavy[q][L] >= L) violated(P, "an inversion batch waits for a heavy level that is not earlier");
+                if (p.lane_needs_main[q][L] && p.lane_needs_main[q][L] >= L) violated(P, "a lane waits for a main level that is not earlier");
+                for (int q2 = 0; q2 < N_HEAVY_LANES; q2++)
+                    if (p.lane_needs_lane[q][q2][L] && p.lane_needs_lane[q][q2][L] >= L) violated(P, "a lane waits for a lane level that is not earlier");
+            }
+        }
+        for (size_t i = 1; i < gates.size(); i++)
+            if (gates[i].level < gates[i - 1].level) violated(P, "gates are not in level order");
+        for (size_t i = 1; i < records.size(); i++)
+            if (records[i].level < records[i - 1].level) violated(P, "records are not in level order");
+    }
+    void check_rows() const {
+        const char *P = "assign_rows";
+        if (!opts.reuse_slots) { if (!p.slot_of.empty()) violated(P, "rows without the option"); return; }
+        std::vector<uint8_t> used(p.n_slots, 0);
+        for (uint32_t w = 0; w < nw; w++) {
+            if ((p.producer[w] != 0xFFFFFFFFu) != (p.slot_of[w] != 0xFFFFFFFFu)) violated(P, "witness " + std::to_string(w) + ": assigned witnesses and rows differ");
+            if (p.slot_of[w] != 0xFFFFFFFFu) { if (p.slot_of[w] >= p.n_slots) violated(P, "row out of range"); used[p.slot_of[w]] = 1; }
+        }
+        for (uint32_t r = 0; r < p.n_slots; r++)
+            if (!used[r]) violated(P, "row " + std::to_string(r) + " belongs to nobody");
+        std::vector<uint8_t> init_row(p.n_slots, 0);
+        for (uint32_t i = 0; i < n_initial; i++) init_row[p.slot_of[initial_ids[i]]]++;
+        for (uint32_t w = 0; w < nw; w++)
+            if (p.slot_of[w] != 0xFFFFFFFFu && init_row[p.slot_of[w]] && p.producer[w] != 0xFFFFFFFEu) violated(P, "witness " + std::to_string(w) + " recycles the row of an initial witness");
+        for (uint32_t w : opts.keep)
+            if (w < nw && p.slot_of[w] != 0xFFFFFFFFu)
+                for (uint32_t v = 0; v < nw; v++)
+                    if (v != w && p.slot_of[v] == p.slot_of[w] && wdef[v] >= wdef[w]) violated(P, "the row of kept witness " + std::to_string(w) + " is recycled");  // (it may itself have taken a dead witness's row)
+    }
+    void check_layout() {
+        const char *P = "lay_out";
+        if (inject(3) && !p.gate_offset.empty()) p.gate_offset.pop_back();
+        size_t hosts = 0, listed = 0, chained = 0;
+        for (const PendingGate &g : gates) hosts += !g.fused;
+        for (const PendingRecord &r : records) chained += r.chained;
+        for (int k = 0; k < N_CLS; k++) {
+            listed += p.cls_offset[k].size();
+            if (p.cls_level_start[k].size() != (size_t)max_level + 1 || p.cls_level_start[k].back() != p.cls_offset[k].size() || p.cls_scratch[k].size() != p.cls_offset[k].size()) violated(P, "a class's level table does not close its list");
+            for (size_t L = 1; L < p.cls_level_start[k].size(); L++)
+                if (p.cls_level_start[k][L] < p.cls_level_start[k][L - 1]) violated(P, "a class's level table goes backwards");
+        }
+        if (p.gate_offset.size() != hosts) violated(P, "wave programs listed " + std::to_string(p.gate_offset.size()) + ", hosts " + std::to_string(hosts));
+        if (p.dyn_offset.size() != inverses.size()) violated(P, "inversion jobs and inversions differ");
+        if (listed + chained != records.size()) violated(P, "records listed + chained != records");
+        if (p.level_start.size() != (size_t)max_level + 1 || p.level_start.back() != p.gate_offset.size() || p.dyn_level_start.back() != p.dyn_offset.size()) violated(P, "the level tables do not close the lists");
+        for (uint32_t off : p.gate_offset)
+            if (off + GATE_HDR_WORDS + 1 > p.gate_stream.size()) violated(P, "a wave program starts past the stream");
+    }
+};
+
+}  // namespace
+
+Plan build_plan(const Circuit &c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
+    Planner b(c, initial_ids, n_initial, opts);
+    b.p.tune = b.tune;
+    b.p.n_opcodes = (uint32_t)c.opcodes.size();
+    const bool v = b.tune.plan_validate != 0;           // every pass's promise checked on the way (tests/test_plan_host.py)
+    if (!b.init()) return b.finish();                   // the dense witness table, the initial set, constants, memory blocks
+    if (!b.emit_in_order_program()) return b.finish();  // `prog`: one record per opcode (exact path; non-Arithmetic records of the level path)
+    if (v) b.check_in_order_program();
+    b.pin_witnesses();                                  // which witnesses must stay plain canonical values
+    b.replay();                                         // assigned-set replay, levels, folded gates, records, scales, bounds
+    if (v) b.check_replay();
+    b.fuse_gate_pairs();                                // wave programs: gates behind their producer
+    if (v) b.check_pairs();
+    b.assign_inverse_slots();                           // rows of the inverse table, reused
+    if (v) b.check_inverse_slots();
+    b.fold_digest_leaves();                             // PlanOpts::fold_digest
+    if (v) b.check_digest_leaves();
+    b.fuse_range_checks();                              // byte RANGE into the hash that reads the byte
+    b.chain_hashes();                                   // a hash of a hash runs in its predecessor's workgroup
+    b.merge_range_records();                            // eight RANGE checks to a record
+    if (v) b.check_range_accounting();
+    b.order_and_dependencies();                         // level order; what each stream waits for
+    if (v) b.check_dependencies();
+    if (!b.assign_rows()) return b.finish();            // PlanOpts::reuse_slots
+    if (v) b.check_rows();
+    b.lay_out();                                        // the streams and the level-major lists
+    if (v) b.check_layout();
+    order_level_records(b.p);                           // placement inside a level
+    return b.finish();
 }
 
 }  // namespace acvm

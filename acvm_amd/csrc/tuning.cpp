@@ -14,7 +14,7 @@ const Key KEYS[] = {
     {"inv_epoch", &Tuning::inv_epoch}, {"inv_latency", &Tuning::inv_latency}, {"inv_chunk", &Tuning::inv_chunk}, {"byte_plane", &Tuning::byte_plane}, {"heavy_epoch", &Tuning::heavy_epoch}, {"heavy_latency", &Tuning::heavy_latency},
     {"pedersen_latency", &Tuning::pedersen_latency}, {"pedersen_epoch", &Tuning::pedersen_epoch}, {"digest_epoch", &Tuning::digest_epoch}, {"range_fuse", &Tuning::range_fuse},
     {"range_merge", &Tuning::range_merge}, {"hash_chain", &Tuning::hash_chain}, {"brillig_inline", &Tuning::brillig_inline},
-    {"pedersen_waves", &Tuning::pedersen_waves}, {"pedersen_prio", &Tuning::pedersen_prio}, {"light_fuse", &Tuning::light_fuse}, {"brillig_mem_cells", &Tuning::brillig_mem_cells}, {"overlap", &Tuning::overlap}, {"heavy_streams", &Tuning::heavy_streams}, {"heavy_only_streams", &Tuning::heavy_only_streams},
+    {"pedersen_waves", &Tuning::pedersen_waves}, {"pedersen_prio", &Tuning::pedersen_prio}, {"light_fuse", &Tuning::light_fuse}, {"plan_validate", &Tuning::plan_validate}, {"brillig_mem_cells", &Tuning::brillig_mem_cells}, {"overlap", &Tuning::overlap}, {"heavy_streams", &Tuning::heavy_streams}, {"heavy_only_streams", &Tuning::heavy_only_streams},
     {"fc_relevel", &Tuning::fc_relevel}, {"exact_async", &Tuning::exact_async}, {"brillig_steps_log2", &Tuning::brillig_steps_log2},
     {"brillig_steps_max_log2", &Tuning::brillig_steps_max_log2}, {"brillig_call_depth", &Tuning::brillig_call_depth},
     {"brillig_call_depth_max", &Tuning::brillig_call_depth_max}, {"brillig_mem_max_log2", &Tuning::brillig_mem_max_log2},

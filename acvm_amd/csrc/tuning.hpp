@@ -33,6 +33,7 @@ struct Tuning {
     int64_t pedersen_bundle_waves = 2048;  // ... as many records per wave as leave the launch this many waves (two per SIMD; measured, DESIGN section 9: at 1 024 the north-star shape in tiles of 2^16 loses 2 %, at 512 a config-5 tile of 4 096 gets slower)
     int64_t pedersen_prio = 1;     // s_setprio 3 in the level Pedersen kernel: its few long waves win the issue arbitration against the gate kernel's many
     int64_t light_fuse = 1;        // the light records of a level ride in its gate launch
+    int64_t plan_validate = 0;     // 1: every pass of the planner checks what it promises (plan.cpp check_*; a violation is an error of the call); 100 + k: break invariant k first (tests)
     int64_t brillig_mem_cells = 0; // lower bound of the per-lane Brillig memory of the level kernels (0: the planner's estimate)
     // ---- driver (batch.cpp)
     int64_t overlap = 1;           // inversion batches and heavy lanes on streams of their own

@@ -194,6 +194,36 @@ def test_failing_solver_inside_brillig(oracle):
     assert (1 << 32) not in seen_ds and set(seen_ds) <= {0, 1, 2}
 
 
+def test_domain_separator_is_truncated_to_128_bits_under_a_solver(oracle):
+    """registers.get(domain_separator).to_u128().try_into::<u32>() (brillig_vm/src/black_box.rs:152-158): to_u128 keeps the low 128 bits
+    (acir_field/src/generic_ark.rs:227-230), so 2^128 + 2 reaches the solver as separator 2 while 2^32 fails -- the same on the built-in path,
+    under a caller-supplied solver (the host-side check read all 28 upper bytes until round 6) and in the oracle's VM."""
+    seen_ds = []
+
+    def pedersen(inputs, ds):
+        seen_ds.append(ds)
+        return (2, 3)
+    solver = acvm_amd.make_solver(lambda *a: True, pedersen, lambda lo, hi: (4, 5))
+    circ, ids = brillig_three_calls()
+    ds_of = lambda j: [(1 << 128) + 2, 1 << 32, (1 << 200) + (1 << 128) + 1, (1 << 128) + (1 << 40), 0, 1][j % 6]
+    rows = [[j + 1, 7, 11 * j, 13, ds_of(j), 5, 6, 1, 2, 3, 9, 8, 7, 4] for j in range(12)]
+    for slow in (False, True):
+        batch = acvm_amd.Batch(acvm_amd.Circuit(circ.to_bytes()), len(rows), ids, solver=solver)
+        batch.set_force_slow_path(slow)
+        batch.set_initial_witness(values_from_rows(rows))
+        batch.solve()
+        res = batch.results()
+        asg, vals = batch.witness_map()
+        compare(oracle, circ, ids, rows, res, asg, vals, oracle.BACKEND_DUMMY)
+        for j in range(12):
+            if j % 6 in (1, 3):
+                assert res[j].message == b"failed to solve blackbox function: pedersen, reason: Invalid signature length", j
+            else:
+                assert res[j].status == acvm_amd.STATUS_SOLVED, (j, res[j].as_tuple(), res[j].message)
+        batch.free()
+    assert set(seen_ds) == {0, 1, 2}
+
+
 def test_solver_with_witness_slot_reuse(oracle):
     """ACVM_BATCH_REUSE_SLOTS under a caller-supplied solver (refused until round 5): the callbacks' operands are gathered through the row map of
     the level table, the exact lanes' from their side table; results, kept witnesses and map digests against the oracle with the same backend"""

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,tuple_,sort_by", [(1, 1, [0]), (2, 1, [0]), (3, 1, [0]), (4, 2, [0]), (5, 2, [1, 0]), (8, 1, [0]), (13, 3, [2]), (17, 2, [0, 1]),
-                                              (32, 1, [0])])
+                                              (32, 1, [0]), (256, 1, [0])])
 def test_permutation_sort(oracle, n, tuple_, sort_by):
     r = random.Random(n * 7 + tuple_)
     ids = list(range(1, n * tuple_ + 1))

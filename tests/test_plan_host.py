@@ -125,3 +125,84 @@ def test_relaxed_rows_bounds_and_modes():
     with acvm_amd.tuning(relax=0):
         st = stats(circ, ids)
         assert st["n_gate_out_asis"] == 0 and st["n_gate_out_weak"] == 0 and st["n_gate_out_canon"] == 10000
+
+
+# ---------------------------------------------------------------------------------------------------------------- the planner, pass by pass
+# plan.cpp is a sequence of passes over an explicit intermediate state (struct Planner: init -> in-order program -> pins -> replay -> gate pairs
+# -> inverse slots -> digest leaves -> range fusing -> hash chains -> range merging -> order + dependencies -> rows -> layout). With tuning
+# plan_validate = 1 every pass checks what it promises before the next one runs; a violation is an error of the call.
+def _corpus():
+    import circuit_corpus as cc
+    return cc
+
+
+def test_every_pass_keeps_its_promise_on_the_whole_corpus():
+    cc = _corpus()
+    n = 0
+    for name, data, ids in cc.corpus(big=True):
+        gc = acvm_amd.Circuit(data)
+        if ids is None:
+            ids = gc.witness_set("circuit_arguments")
+        keep = gc.witness_set("return_values")
+        for mode in cc.PLANNER_MODES:
+            with acvm_amd.tuning(plan_validate=1, **mode):
+                for kw in ({}, {"fold_digest": True}, {"reuse_slots": True, "keep": keep}):
+                    try:
+                        gc.plan_stats(ids, **kw)
+                    except acvm_amd.AcvmError as e:
+                        assert "slot reuse needs" in str(e), (name, mode, kw, str(e))  # the only refusal there is; never "plan invariant violated"
+                    n += 1
+    assert n >= 2500
+
+
+@pytest.mark.parametrize("k,pass_name", [(1, "fuse_gate_pairs"), (2, "assign_inverse_slots"), (3, "lay_out")])
+def test_a_broken_invariant_is_caught_by_its_pass(k, pass_name):
+    """plan_validate = 100 + k breaks invariant k on purpose (a gate marked fused at its own level; two live inverses in one row of the table; a wave
+    program missing from the level lists): the pass's check names itself"""
+    circ, ids = synth.arithmetic_circuit(400, seed=3, mix=(30, 30, 20, 20))
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    with acvm_amd.tuning(plan_validate=100 + k):
+        with pytest.raises(acvm_amd.AcvmError, match="plan invariant violated after pass " + pass_name):
+            gc.plan_stats(ids)
+    with acvm_amd.tuning(plan_validate=1):
+        assert gc.plan_stats(ids)["n_opcodes"] == 400
+
+
+def test_plan_is_built_once_per_option_set_and_shared():
+    """acvm_circuit_t keeps its plans: handles (and the host-only entry points) that ask for the same initial ids, options and tuning get the same
+    immutable plan; another option set, or another tuning, is another plan (the reference's callers build one opcode list per circuit:
+    acvm_js/src/execute.rs:60-119)"""
+    circ, ids = synth.mixed_circuit(600, seed=11, blocks=4, cells=16)
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    keep = gc.witness_set("return_values")
+    assert gc.plans_built() == 0
+    a = gc.plan_stats(ids)
+    assert gc.plans_built() == 1
+    assert gc.plan_stats(ids) == a and gc.check_schedule(ids)["ok"] and gc.plans_built() == 1
+    gc.plan_stats(ids, reuse_slots=True, keep=keep)
+    assert gc.plans_built() == 2
+    gc.plan_stats(ids, reuse_slots=True, keep=keep)
+    gc.plan_stats(list(reversed(ids)))  # (another order of the same ids is another key: the import layout follows it)
+    assert gc.plans_built() == 3
+    with acvm_amd.tuning(inv_epoch=2):
+        gc.plan_stats(ids)
+    assert gc.plans_built() == 4
+    gc.plan_stats(ids)
+    assert gc.plans_built() == 4
+
+
+def test_planner_refactoring_moved_no_word():
+    """fingerprints of everything the planner emits (acvm_debug_plan_fingerprint), pinned for three circuits: tools/plan_fingerprint.py compares
+    the whole corpus x modes before and after a change of plan.cpp; these pins catch an accidental change in the suite"""
+    import hashlib
+    circ, ids = synth.arithmetic_circuit(2000, seed=0xAC1D0002)
+    fp = acvm_amd.Circuit(circ.to_bytes()).plan_fingerprint(ids)
+    assert len(fp) >= 60
+    h = hashlib.sha256(b"".join(int(x).to_bytes(8, "little") for x in fp)).hexdigest()[:16]
+    circ2, ids2 = synth.mixed_circuit(900, seed=0xAC1D0005, heavy=True, blocks=4, cells=16)
+    gc2 = acvm_amd.Circuit(circ2.to_bytes())
+    h2 = hashlib.sha256(b"".join(int(x).to_bytes(8, "little") for x in gc2.plan_fingerprint(ids2, reuse_slots=True, keep=gc2.witness_set("return_values")))).hexdigest()[:16]
+    assert (h, h2) == PLAN_PINS, (h, h2)
+
+
+PLAN_PINS = ("dcf4da57cf56e6e0", "ab4c13523d008c2e")

@@ -209,10 +209,11 @@ class Stats(C.Structure):
                 ("n_table_rows", C.c_uint32), ("n_digest_segments", C.c_uint32), ("n_brillig_inlined", C.c_uint32), ("n_brillig_retries", C.c_uint32),
                 ("n_hash_chained", C.c_uint32),
                 ("n_gate_out_asis", C.c_uint32), ("n_gate_out_weak", C.c_uint32), ("n_gate_out_canon", C.c_uint32), ("max_gate_bound", C.c_uint32),
-                ("n_byte_planes", C.c_uint32), ("n_byte_plane_reads", C.c_uint32)]
+                ("n_byte_planes", C.c_uint32), ("n_byte_plane_reads", C.c_uint32),
+                ("n_stream_launches", C.c_uint32 * 6), ("n_stream_waits", C.c_uint32)]
 
     def as_dict(self):
-        return {f: (list(getattr(self, f)) if f.startswith("class_") else getattr(self, f)) for f, _ in self._fields_}
+        return {f: (list(getattr(self, f)) if f.startswith("class_") or f == "n_stream_launches" else getattr(self, f)) for f, _ in self._fields_}
 
 
 _lib = None

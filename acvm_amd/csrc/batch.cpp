@@ -559,6 +559,10 @@ int acvm_batch_stats(acvm_batch_t *b, acvm_stats_t *out) {
     out->class_kernel_ms[CLS_GRUMPKIN] += b->cls_kernel_ms[CLS_PEDERSEN] + b->cls_kernel_ms[CLS_ECDSA] + b->cls_kernel_ms[CLS_HOSTBB];
     out->slow_path_ms = b->slow_path_ms;
     out->n_brillig_retries = b->n_brillig_retries;
+    for (const SchedStep &st : b->schedule.steps) {
+        if (st.kind == SK_LAUNCH && st.stream < 6) out->n_stream_launches[st.stream]++;
+        else if (st.kind == SK_WAIT) out->n_stream_waits++;
+    }
     return 0;
 }
 

@@ -21,8 +21,14 @@ struct Tuning {
     int64_t inv_latency = 1;       // levels of slack between an inversion batch and the first gate that reads it
     int64_t heavy_epoch = 1;       // heavy records launched every K-th level only
     int64_t heavy_latency = 0;     // levels the main stream waits before it reads a heavy output
-    int64_t pedersen_latency = 1;  // the same for Pedersen outputs alone
-    int64_t pedersen_epoch = 2;    // Pedersen records launched every K-th level only (fatter launches: the one-wave kernel needs more than 512 groups)
+    // Pedersen records are launched every 8th level only and the main stream reads their outputs 4 levels behind the launch at the earliest: a
+    // launch of two or three records is a handful of long waves, eight levels' worth fill the lane. Round 6, 10^6-opcode config-5 tile of 8 192
+    // (profiles/r06_config5_sweep.txt, four boxes): epoch / latency 2 / 1 (the default until then) 138.5-141.7 ms per 4 096 instances, 4 / 2 139.8, 8 / 3 135.5,
+    // 8 / 4 132.4-136.4, 8 / 6 138.7, 12 / 6 139.4, 16 / 8 137.4, 32 / 16 137.9; the north-star shape (8 Pedersen, consumers right behind) 5.228 M witnesses/s
+    // at 2 / 1, 5.225 M at 8 / 4, 5.275 M at 16 / 8. (A slack-aware variant -- only records whose readers are far away move to the epoch boundary -- was
+    // measured SLOWER than leaving everything alone, 140.8-142.8 against 138.5: removed.)
+    int64_t pedersen_latency = 4;  // the same for Pedersen outputs alone
+    int64_t pedersen_epoch = 8;    // Pedersen records launched every K-th level only
     int64_t digest_epoch = 8;      // levels per batch of folded digest leaves
     int64_t range_fuse = 1;        // byte RANGE checks run inside the hash that reads the byte
     int64_t range_merge = 1;       // RANGE opcodes of a level, eight to a record

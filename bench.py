@@ -111,16 +111,17 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def pmc_pass(args, counter):
-    """One rocprofv3 pass (`--pmc <counter> --kernel-trace`, nothing else) over a one-tile run of this script: {kernel symbol: [sum of
-    the counter over its launches, launches]}, or None if rocprofv3 is missing or fails."""
+def pmc_pass(args, counter, inner=None):
+    """One rocprofv3 pass (`--pmc <counter> --kernel-trace`, nothing else) over a one-tile run of this script (or over `inner`, another
+    invocation of it): {kernel symbol: [sum of the counter over its launches, launches]}, or None if rocprofv3 is missing or fails."""
     import csv
     import shutil
     import tempfile
     if os.environ.get("ACVM_BENCH_NO_PMC") or not shutil.which("rocprofv3"):
         return None
-    inner = [sys.executable, os.path.abspath(__file__), "--inner", "--workload", args.workload, "--gates", str(args.gates), "--pedersen", str(args.pedersen),
-             "--total-log2", str(args.eff_tile_log2), "--tile-log2", str(args.eff_tile_log2), "--steps", "1", "--warmup", "1"]
+    if inner is None:
+        inner = [sys.executable, os.path.abspath(__file__), "--inner", "--workload", args.workload, "--gates", str(args.gates), "--pedersen", str(args.pedersen),
+                 "--total-log2", str(args.eff_tile_log2), "--tile-log2", str(args.eff_tile_log2), "--steps", "1", "--warmup", "1"]
     tmp = tempfile.mkdtemp(prefix="acvm_pmc_", dir="/tmp")
     per = {}
     try:
@@ -128,7 +129,7 @@ def pmc_pass(args, counter):
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
             env.pop(k, None)
-        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             return None
         for root, _, files in os.walk(tmp):
@@ -454,14 +455,22 @@ def run_leg(name, total_log2=16, tile_log2=16, steps=3, warmup=2, pmc=True):
     return out
 
 
-def run_config5_leg(tile_log2=12, timed_tiles=2, audit=8):
+# kernels of the level schedule by class, for the config-5 leg's instruction accounting (substrings of the rocprofv3 kernel names; the kernels that
+# build lookup tables -- pedersen_window_table_kernel and friends, once per process -- are none of them)
+CONFIG5_CLASSES = {"gates (+ fused light records)": ["arith_level_kernel", "arith_light_level_kernel", "arith_l"], "inversion batches": ["inverse_batch_kernel"],
+                   "Pedersen": ["pedersen_quad_level_kernel", "pedersen_bundle_level_kernel"], "digest leaves": ["digest_fold_level_kernel"],
+                   "hashes": ["hash_coop_level_kernel", "HashOp"], "light / inlined Brillig": ["LightOp", "LightSlOp"], "Grumpkin": ["GrumpkinOp"], "Brillig VM": ["BrilligOp"]}
+
+
+def run_config5_leg(tile_log2=13, timed_tiles=2, audit=32, inner=False):
     """BASELINE config 5 at circuit size as a leg of the default run: the 10^6-opcode mixed circuit (SURVEY 8d generator), ONE handle with
     witness-slot liveness reuse and the digest folded into the solve, `timed_tiles` tiles of 2^tile_log2 fresh instances (a step = ACVM::new of the
-    tile from host memory + solve + the tile's per-instance digests), an audit sample of the first timed tile re-solved by the CPU oracle
-    (results, return witnesses, map digests bit for bit), the kernel classes' HIP-event times of the last tile against their algorithmic bytes."""
+    tile from host memory + solve + the tile's per-instance digests; no per-launch events in the timed tiles), one more tile with per-launch HIP
+    events for the classes' times, an audit sample of the first timed tile re-solved by the CPU oracle (results, return witnesses, map digests bit
+    for bit), and one in-run PMC pass (SQ_INSTS_VALU) over the same sequence for the instructions per class and the tile-wide VALU issue fraction.
+    inner: the run that pass profiles (no oracle, nothing printed)."""
     import acvm_amd
     from acvm_amd import synth
-    from oracle import binding as ob
     tile = 1 << tile_log2
     t0 = time.perf_counter()
     circ, ids = synth.mixed_circuit(1_000_000)
@@ -472,24 +481,33 @@ def run_config5_leg(tile_log2=12, timed_tiles=2, audit=8):
     batch = acvm_amd.Batch(gc, tile, ids, reuse_slots=True, keep=ret)  # (slot reuse folds the digest)
     t2 = time.perf_counter()
     row = len(ids) * 32
-    tiles = [synth.witness_batch(tile, seed=0xAC1D0005, first_instance=k * tile) for k in range(timed_tiles + 1)]
+    tiles = [synth.witness_batch(tile, seed=0xAC1D0005, first_instance=k * tile) for k in range(timed_tiles + 2)]
     batch.set_initial_witness(tiles[0])  # warm-up tile: tables built, clocks up, the exact path's side table allocated (its edge-case instances)
     batch.solve()
     batch.digest()
     acvm_amd.synchronize()
-    step_ms, not_solved, first = [], 0, None
-    for k in range(1, timed_tiles + 1):
-        batch.set_profiling(k == timed_tiles)
-        w0 = time.perf_counter()
-        batch.set_initial_witness(tiles[k])
-        not_solved += batch.solve()
-        dig = batch.digest()
-        step_ms.append((time.perf_counter() - w0) * 1e3)
-        if k == 1:
-            first = (batch.results(), dig, [batch.extract(ret, j, 1)[0] for j in range(0, tile, max(tile // audit, 1))][:audit])
+    step_ms, dev_ms, not_solved, first = [], [], 0, None
+    with ClockSampler(acvm_amd.current_device(), enabled=not inner) as clock:
+        for k in range(1, timed_tiles + 1):
+            w0 = time.perf_counter()
+            batch.set_initial_witness(tiles[k])
+            not_solved += batch.solve()
+            dig = batch.digest()
+            step_ms.append((time.perf_counter() - w0) * 1e3)
+            dev_ms.append(batch.stats()["solve_device_ms"])
+            if k == 1 and not inner:
+                first = (batch.results(), dig, [batch.extract(ret, j, 1)[0] for j in range(0, tile, max(tile // audit, 1))][:audit])
+    if inner:
+        batch.free()
+        return None
+    sclk = clock.median()
+    batch.set_profiling(True)  # the classes' own times: per-launch events cost a tenth of a tile of 1 200 launches, so they bracket a tile of their own
+    batch.set_initial_witness(tiles[timed_tiles + 1])
+    batch.solve()
     st = batch.stats()
     batch.set_profiling(False)
     # ---- audit of the first timed tile (instances tile .. 2 tile - 1 of the synthetic batch: no edge cases among them)
+    from oracle import binding as ob
     picks = list(range(0, tile, max(tile // audit, 1)))[:audit]
     sub = b"".join(tiles[1][j * row:(j + 1) * row] for j in picks)
     threads = min(len(picks), cpu_budget()[0])
@@ -508,29 +526,46 @@ def run_config5_leg(tile_log2=12, timed_tiles=2, audit=8):
             ok &= all(bytes(kept[i][n]) == bytes(ovals[i][w]) for n, w in enumerate(ret))
     batch.free()
     ms = sum(step_ms) / len(step_ms)
+    solve_ms = sum(dev_ms) / len(dev_ms)
     cls_names = ["light (range / logic / directives / memory / inlined Brillig)", "hashes", "Grumpkin + Pedersen + ECDSA", "Brillig VM"]
-    classes = {"arith_level_kernel": {"ms_last_tile": st["arith_kernel_ms"], "algorithmic_bytes_per_tile": st["arith_algorithmic_bytes_per_instance"] * tile},
-               "inverse_batch_kernel": {"ms_last_tile": st["dyn_kernel_ms"], "algorithmic_bytes_per_tile": st["dyn_algorithmic_bytes_per_instance"] * tile}}
+    classes = {"arith_level_kernel": {"ms_profiled_tile": st["arith_kernel_ms"], "algorithmic_bytes_per_tile": st["arith_algorithmic_bytes_per_instance"] * tile},
+               "inverse_batch_kernel": {"ms_profiled_tile": st["dyn_kernel_ms"], "algorithmic_bytes_per_tile": st["dyn_algorithmic_bytes_per_instance"] * tile}}
     for k in range(4):
-        classes[cls_names[k]] = {"ms_last_tile": st["class_kernel_ms"][k], "algorithmic_bytes_per_tile": st["class_algorithmic_bytes_per_instance"][k] * tile}
+        classes[cls_names[k]] = {"ms_profiled_tile": st["class_kernel_ms"][k], "algorithmic_bytes_per_tile": st["class_algorithmic_bytes_per_instance"][k] * tile}
     for c in classes.values():  # (the classes run side by side on their own streams: the sum of their times exceeds the step)
-        c["achieved_GBps"] = c["algorithmic_bytes_per_tile"] / (c["ms_last_tile"] / 1e3) / 1e9 if c["ms_last_tile"] > 0 else None
+        c["achieved_GBps"] = c["algorithmic_bytes_per_tile"] / (c["ms_profiled_tile"] / 1e3) / 1e9 if c["ms_profiled_tile"] > 0 else None
         c["frac_of_hbm_peak"] = None if c["achieved_GBps"] is None else c["achieved_GBps"] / HBM_PEAK_GBS
+    # ---- instructions: one PMC pass over the same sequence of tiles (this function with inner=True), summed per class and per solve
+    valu = None
+    per = pmc_pass(None, "SQ_INSTS_VALU", inner=[sys.executable, os.path.abspath(__file__), "--inner-config5-leg", "--tile-log2", str(tile_log2)])
+    if per:
+        n_solves = pick(per, ["event_reset_kernel"])[1]
+        by_class = {name: pick(per, subs)[0] / max(n_solves, 1) for name, subs in CONFIG5_CLASSES.items()}
+        total = sum(by_class.values())
+        n_simd = 4 * acvm_amd.modmul_probe_cus()
+        valu = {"valu_wave_insts_per_tile": total, "by_class": {k: v for k, v in by_class.items() if v}, "solves_profiled": n_solves, "sclk_mhz_under_load": sclk, "simds": n_simd,
+                "solve_device_ms": solve_ms,
+                "valu_issue_frac": None if not sclk else total * 4.0 / (n_simd * (solve_ms / 1e3) * sclk * 1e6),
+                "definition": "sum over the level schedule's kernels of SQ_INSTS_VALU per solve (rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace over this leg's own sequence of tiles, "
+                              "inside this bench run; table-building kernels excluded) x 4 cycles / (SIMDs x the tile's solve_device_ms x the shader clock sampled while the timed tiles ran)"}
     achieved = st["algorithmic_bytes_per_instance"] * tile / (ms / 1e3) / 1e9
     return {"workload": "10^6-opcode mixed ACIR (config 5: 94 % arithmetic, range / logic, directives, memory, Brillig, hashes, Pedersen), "
                         f"tiles of {tile} instances through one handle, witness-slot reuse, digest folded into the solve",
             "value": tile / (ms / 1e3), "unit": "witnesses/s", "instances": tile * timed_tiles, "tile_instances": tile, "steps": timed_tiles, "ms_per_step": ms,
             "step": "per tile: ACVM::new from host memory + solve + per-instance map digests", "ms_of_each_step": step_ms,
-            "solve_device_ms_last_step": st["solve_device_ms"], "not_solved": not_solved, "opcodes": st["n_opcodes"], "witnesses_per_instance": st["n_witnesses"],
-            "table_rows": st["n_table_rows"], "levels": st["n_levels"], "launches": st["n_kernel_launches"], "brillig_opcodes_inlined": st["n_brillig_inlined"],
+            "solve_device_ms_of_each_step": dev_ms, "not_solved": not_solved, "opcodes": st["n_opcodes"], "witnesses_per_instance": st["n_witnesses"],
+            "table_rows": st["n_table_rows"], "levels": st["n_levels"], "launches": st["n_kernel_launches"], "launches_by_stream": dict(zip(["main", "inversions", "lane0 (hashes)", "lane1 (Pedersen)", "lane2 (Brillig VM)", "digest"], st["n_stream_launches"])),
+            "cross_stream_waits": st["n_stream_waits"], "brillig_opcodes_inlined": st["n_brillig_inlined"],
             "generate_s": round(t1 - t0, 1), "parse_plan_alloc_s": round(t2 - t1, 1), "plan_ms": st["plan_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "the whole step (every class of the level schedule; they overlap)", "algorithmic_bytes_per_tile": st["algorithmic_bytes_per_instance"] * tile,
-                         "classes": classes},
+                         "gate_kernel_frac_inside_the_tile": classes["arith_level_kernel"]["frac_of_hbm_peak"], "classes": classes,
+                         "valu_issue_frac": None if not valu else valu["valu_issue_frac"], "valu": valu,
+                         "note": "the tile is bound by VALU issue, not by HBM: its kernels' instructions add up (valu.by_class); the HBM fraction is for information"},
             "alu_roofline": None,
             "cpu_baseline": {"value": len(picks) / oracle_s, "unit": "witnesses/s", "cores": threads, "host_cores": os.cpu_count(), "cgroup_cpu_quota": cpu_budget()[1], "kind": "port",
                              "runs_s": [round(x, 2) for x in oracle_runs],
-                             "sample": f"the {len(picks)} audit instances, one oracle thread each, median of 3 runs: {oracle_s:.1f} s (a 10^6-opcode instance is ~1.4 s of one core)"},
+                             "sample": f"the {len(picks)} audit instances, one oracle thread each on {threads} threads, median of 3 runs: {oracle_s:.1f} s (a 10^6-opcode instance is ~1.4 s of one core)"},
             "parity": {"bit_exact": bool(ok), "instances": picks, "of_tile": 1, "checked": "result records, return witnesses, map digests (hashlib over the oracle's full map)"}}
 
 
@@ -583,7 +618,13 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the other_workloads legs of the default run")
     ap.add_argument("--no-pipeline", action="store_true", help="plain acvm_batch_solve per tile instead of acvm_batch_solve_then_import (A/B of the tile boundary)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the one-tile run the PMC passes profile
+    ap.add_argument("--inner-config5-leg", action="store_true", help=argparse.SUPPRESS)  # the config-5 leg's sequence of tiles, for its PMC pass
     args = ap.parse_args()
+    if args.inner_config5_leg:
+        import acvm_amd
+        acvm_amd.set_device(0)
+        run_config5_leg(tile_log2=args.tile_log2 or 13, inner=True)
+        return
     if args.gates is None:
         args.gates = 1000000 if args.workload == "config5" else 10000
     if args.tile_log2 is None:
@@ -746,7 +787,7 @@ def main():
                 legs[name] = run_leg(name, **kw)
             except (acvm_amd.AcvmError, OSError, ValueError) as e:  # a leg must not void the metric's line
                 legs[name] = {"error": str(e)[:300]}
-        try:  # BASELINE config 5 at circuit size: 10^6 opcodes, tiles of 4 096 with slot reuse, 8-instance oracle audit (~40 s of the run)
+        try:  # BASELINE config 5 at circuit size: 10^6 opcodes, tiles of 8 192 with slot reuse, 32-instance oracle audit, one PMC pass (~2 min of the run)
             legs["config5"] = run_config5_leg()
         except (acvm_amd.AcvmError, OSError, ValueError, MemoryError) as e:
             legs["config5"] = {"error": str(e)[:300]}

@@ -165,6 +165,8 @@ typedef struct {
      * import; n_byte_plane_reads inputs of hash records read it in place of the 32-byte row. The algorithmic-byte figures above keep the reference's
      * unit (32 bytes per witness read): what the hash kernel itself moves is 28 bytes less per such input, what the import moves 4 bytes more per plane. */
     uint32_t n_byte_planes, n_byte_plane_reads;
+    /* ABI 6: launches of the level schedule by stream (main, inversions, the three heavy lanes, the digest lane) and the cross-stream waits of one solve */
+    uint32_t n_stream_launches[6], n_stream_waits;
 } acvm_stats_t;
 
 const char *acvm_last_error(void);

@@ -87,7 +87,7 @@ long long acvm_device_release_tables(int device) {
 }
 
 int acvm_tuning_set(const char *key, long long value) {
-    if (!tuning_set(key, (int64_t)value)) return set_err(ACVM_E_INVALID, std::string("unknown tuning key ") + (key ? key : "(null)"));
+    if (!tuning_set(key, (int64_t)value)) return set_err(ACVM_E_INVALID, std::string("unknown tuning key (or a value it does not take): ") + (key ? key : "(null)"));
     return 0;
 }
 int acvm_tuning_get(const char *key, long long *value) {

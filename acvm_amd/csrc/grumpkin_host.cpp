@@ -372,6 +372,11 @@ bool grumpkin_window_table(GrumpkinTables *out) {
         uint4 *d = nullptr;
         uint32_t *d_bad = nullptr, bad = 1;
         const size_t entries = (size_t)2 * GRUMPKIN_PEDW_WINDOWS << GRUMPKIN_PEDW_BITS;
+        // The 23.6 GB table is an optimisation of one kernel; the 503 MB pair table serves the same kernel. It is built only where it leaves room:
+        // a quarter of the device's memory must stay free behind it (the handle that asks still allocates its inverse rows and side tables, and on a
+        // shared GPU -- several processes, several handles -- a table that just fits starves whoever allocates next).
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < entries * 64 + total_b / 4) return false;
         if (hipMalloc((void **)&d, entries * 64) != hipSuccess) return false;
         if (hipMalloc((void **)&d_bad, 4) != hipSuccess || hipMemsetAsync(d_bad, 0, 4, S->build) != hipSuccess) { hipFree(d); hipFree(d_bad); return false; }
         launch_pedersen_window_table(S->build, t, d, d_bad);

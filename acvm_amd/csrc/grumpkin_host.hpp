@@ -41,6 +41,7 @@ bool grumpkin_pair_table(GrumpkinTables *out);
 #endif
 static constexpr uint32_t GRUMPKIN_PEDW_BITS = GRUMPKIN_PEDW_BITS_V, GRUMPKIN_PEDW_WINDOWS = (261 + GRUMPKIN_PEDW_BITS - 1) / GRUMPKIN_PEDW_BITS;
 static_assert(GRUMPKIN_PEDW_BITS >= 9 && GRUMPKIN_PEDW_BITS <= 26, "window of the level Pedersen kernel");
+// (tuning.cpp accepts pedersen_window_bits = 0 or 24: a build with another width changes that line too)
 bool grumpkin_window_table(GrumpkinTables *out);
 bool grumpkin_host_point(uint32_t which, uint32_t index, uint8_t out_be[64]);
 // generator tables of the two ECDSA curves on the current device (kernels_ecdsa.hip builds them), nullptr on failure

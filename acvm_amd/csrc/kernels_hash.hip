@@ -297,7 +297,18 @@ __device__ __forceinline__ Fr fp_value(const FpAcc &a) {
 // sum of stored_w * coef_w over the listed witnesses for a wave whose lanes are all instances of the level kernels (wave-uniform
 // coefficients, FP_DOT products per Montgomery reduction: 81 multiply-adds per product + 81 per reduction, so four to a reduction are 101 per
 // term against the 121.5 of pairs and the 162 of single products; four rows in flight per lane). next: produces (witness row, coefficient address) pairs.
-static constexpr int FP_DOT = 4;
+#ifndef FP_DOT_N  // (tools/build_variant.sh -DFP_DOT_N=6: the A/B of DESIGN section 9)
+#define FP_DOT_N 4
+#endif
+static constexpr int FP_DOT = FP_DOT_N;
+static_assert(FP_DOT >= 1 && FP_DOT <= 6, "fr29_dot's column accumulator budget");
+template <int N>
+__device__ __forceinline__ void fp_dot_first(FpAcc &acc, const Fr29 (&x)[FP_DOT], const Fr29 (&k)[FP_DOT]) {  // the first N of the loaded pairs
+    Fr29 l[N], m[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) { l[t] = x[t]; m[t] = k[t]; }
+    fp_add(acc, fr29_dot<N>(l, m), 17);
+}
 template <class Next>
 __device__ __forceinline__ Fr fp_sum_generic(const uint4 *__restrict__ W, uint64_t Bp, uint64_t j, Next next) {
     FpAcc acc;
@@ -319,13 +330,12 @@ __device__ __forceinline__ Fr fp_sum_generic(const uint4 *__restrict__ W, uint64
             fp_add(acc, fr29_dot<FP_DOT>(x, k), 17);
             continue;
         }
-        if (n == 3) {  // (six to a reduction measured no faster than four, at 132 VGPRs)
-            const Fr29 l[3] = {x[0], x[1], x[2]}, m[3] = {k[0], k[1], k[2]};
-            fp_add(acc, fr29_dot<3>(l, m), 17);
-        } else if (n == 2) {
-            const Fr29 l[2] = {x[0], x[1]}, m[2] = {k[0], k[1]};
-            fp_add(acc, fr29_dot<2>(l, m), 17);
-        } else fp_add(acc, fr29_mul(x[0], k[0]), 17);
+        // the last, partial group (six to a reduction measured no faster than four in round 4, at 132 VGPRs, on the unfolded digest)
+        if (FP_DOT > 5 && n == 5) fp_dot_first<(FP_DOT > 5 ? 5 : 1)>(acc, x, k);
+        else if (FP_DOT > 4 && n == 4) fp_dot_first<(FP_DOT > 4 ? 4 : 1)>(acc, x, k);
+        else if (FP_DOT > 3 && n == 3) fp_dot_first<(FP_DOT > 3 ? 3 : 1)>(acc, x, k);
+        else if (FP_DOT > 2 && n == 2) fp_dot_first<(FP_DOT > 2 ? 2 : 1)>(acc, x, k);
+        else fp_add(acc, fr29_mul(x[0], k[0]), 17);
         break;
     }
     return fp_value(acc);

@@ -87,13 +87,18 @@ bool device_locality(const std::string &pci_root, const std::string &bus_id, int
     return true;
 }
 // the calling thread onto the given CPUs (and with it every thread it creates from now on); silently not when the set is empty or refused
+// (only CPUs the process may use at all: the device's local list is intersected with the thread's current mask -- a container's cpuset, a
+// caller's taskset; an empty intersection leaves the thread where it is)
 void pin_thread(const std::vector<uint32_t> &cpus) {
     if (cpus.empty()) return;
-    cpu_set_t set;
+    cpu_set_t allowed, set;
+    CPU_ZERO(&allowed);
+    const bool have_allowed = pthread_getaffinity_np(pthread_self(), sizeof allowed, &allowed) == 0;
     CPU_ZERO(&set);
+    int n = 0;
     for (uint32_t c : cpus)
-        if (c < CPU_SETSIZE) CPU_SET(c, &set);
-    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+        if (c < CPU_SETSIZE && (!have_allowed || CPU_ISSET(c, &allowed))) { CPU_SET(c, &set); n++; }
+    if (n) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 }
 // threads that are joined when the scope ends, whichever way it ends
 struct Joiner {
@@ -442,6 +447,7 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
         node->lanes[i].device = devices[i];
         th.emplace_back([&, i] {
             DeviceLane &L = node->lanes[i];
+            try {  // (nothing leaves a thread: std::terminate is not an error code)
             auto fail = [&](int rc, const std::string &what) { L.rc = rc; L.error = what + ": " + acvm_last_error(); };
             if (hipSetDevice(L.device) != hipSuccess) { L.rc = ACVM_E_DEVICE; L.error = "hipSetDevice failed"; return; }
             {   // where the device hangs: its NUMA node and the CPUs next to it (pinned staging is allocated and filled from there)
@@ -469,6 +475,13 @@ acvm_node_t *acvm_node_new(const acvm_circuit_t *c, const acvm_bb_solver_t *solv
                     ok = hipMalloc((void **)&L.d_exp[k], eb) == hipSuccess && hipHostMalloc((void **)&L.h_exp[k], eb, hipHostMallocDefault) == hipSuccess;
             }
             if (!ok) { L.rc = ACVM_E_DEVICE; L.error = "staging buffers: allocation failed"; }
+            } catch (const std::bad_alloc &) {
+                if (!L.rc) { L.rc = ACVM_E_NOMEM; L.error = "out of host memory"; }
+            } catch (const std::exception &e) {
+                if (!L.rc) { L.rc = ACVM_E_INVALID; L.error = e.what(); }
+            } catch (...) {
+                if (!L.rc) { L.rc = ACVM_E_INVALID; L.error = "unknown exception"; }
+            }
         });
     }
     for (auto &t : th) t.join();

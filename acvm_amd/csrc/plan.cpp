@@ -305,7 +305,8 @@ void emit_straight_line(const BrilligCall &b, uint32_t oi, ConstPool &pool, std:
 //     somewhere in the circuit must not cost every 64-byte SHA record its occupancy) -- then the records of the scratch-carrying kernel;
 //   * CLS_GRUMPKIN: the longest records first (SchnorrVerify ~1.7 ms of one wave per SIMD, FixedBaseScalarMul 0.3): workgroups are placed in
 //     grid order, and at ~240 registers a SIMD holds two of these waves -- a long wave that arrives last waits for a slot behind short ones;
-//   * CLS_LIGHT: straight-line Brillig records last: they have a kernel of their own (kernels_ops.hip LightSlOp).
+//   * CLS_LIGHT, CLS_BRILLIG: straight-line Brillig records last: they have a kernel of their own (kernels_ops.hip LightSlOp; on the Brillig lane
+//     with tuning sl_lane, on the main stream without).
 void order_level_records(Plan &p) {
     const std::vector<uint32_t> &pg = p.prog;
     for (size_t L = 0; L < p.n_levels; L++) {
@@ -331,8 +332,7 @@ void order_level_records(Plan &p) {
                 for (uint32_t r = lo; r < hi; r++) { p.cls_offset[k][r] = recs[r - lo].first; p.cls_scratch[k][r] = recs[r - lo].second; }
             }
         }
-        {
-            const int k = CLS_LIGHT;
+        for (const int k : {(int)CLS_LIGHT, (int)CLS_BRILLIG}) {
             const uint32_t lo = p.cls_level_start[k][L], hi = p.cls_level_start[k][L + 1];
             std::vector<std::pair<uint32_t, uint32_t>> recs;
             for (int pass = 0; pass < 2 && hi > lo; pass++)
@@ -916,7 +916,7 @@ struct Planner {
         // a Brillig opcode with a straight-line record runs in the light class of the level schedule (the exact path keeps its VM record)
         const auto sl_it = o.kind == OP_BRILLIG ? sl_of.find(oi) : sl_of.end();
         const uint32_t rec_cls = o.kind == OP_BLACKBOX && o.bb->func == BB_PEDERSEN && !host_blackbox ? (uint32_t)CLS_PEDERSEN
-                                 : sl_it != sl_of.end() ? (uint32_t)CLS_LIGHT : (uint32_t)p.prog_class[oi];
+                                 : sl_it != sl_of.end() ? (tune.sl_lane ? (uint32_t)CLS_BRILLIG : (uint32_t)CLS_LIGHT) : (uint32_t)p.prog_class[oi];
         const bool rec_heavy = is_heavy(rec_cls);
         Reads rd(known, rec_heavy ? hlevel : level);
         uint32_t extra_level = 0;
@@ -1745,7 +1745,8 @@ struct Planner {
             if (r.chained) continue;
             p.cls_offset[r.cls].push_back(r.prog_at != 0xFFFFFFFFu ? r.prog_at : r.synthetic ? r.opcode : p.prog_offset[r.opcode]);
             // (a Pedersen record of the level schedule parks its step sums for the shared inversion: kernels_grumpkin.hip pedersen_bundle_level_kernel)
-            p.cls_scratch[r.cls].push_back(r.synthetic ? 0u : r.cls == CLS_PEDERSEN ? PEDERSEN_PARK_WORDS : p.prog_scratch[r.opcode]);
+            // (a straight-line Brillig record on the Brillig lane needs none of its VM record's scratch)
+            p.cls_scratch[r.cls].push_back(r.synthetic || p.prog[p.cls_offset[r.cls].back()] == PK_BRILLIG_SL ? 0u : r.cls == CLS_PEDERSEN ? PEDERSEN_PARK_WORDS : p.prog_scratch[r.opcode]);
             width[L]++;
         }
     }

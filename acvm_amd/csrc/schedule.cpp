@@ -35,18 +35,15 @@ LaunchLayout layout_launches(const Plan &p, uint64_t Bp) {
                     lo += n;
                 }
             }
-            if (k == CLS_LIGHT) {
-                uint32_t n_sl = 0;
+            // straight-line Brillig records close the list of their class (the light class on the main stream, or the Brillig lane: tuning sl_lane):
+            // a kernel of their own, no scratch
+            uint32_t n_sl = 0;
+            if (k == CLS_LIGHT || k == CLS_BRILLIG)
                 while (n_sl < hi - lo && p.prog[p.cls_offset[k][hi - 1 - n_sl]] == PK_BRILLIG_SL) n_sl++;
-                if (n_sl) {
-                    if (hi - n_sl > lo) lay.cls_chunks[k][L].push_back({lo, hi - n_sl - lo});
-                    lay.cls_chunks[k][L].push_back({hi - n_sl, n_sl, true});
-                    continue;
-                }
-            }
+            const uint32_t hi_scratch = hi - n_sl;
             uint32_t first = lo;
             uint64_t used = 0;
-            for (uint32_t r = lo; r < hi; r++) {
+            for (uint32_t r = lo; r < hi_scratch; r++) {
                 const uint64_t w = p.cls_scratch[k][r];
                 if (r > first && used + w > scratch_cap_words) {
                     lay.cls_chunks[k][L].push_back({first, r - first});
@@ -58,7 +55,8 @@ LaunchLayout layout_launches(const Plan &p, uint64_t Bp) {
                 used += w;
                 need = std::max(need, used);
             }
-            if (hi > first) lay.cls_chunks[k][L].push_back({first, hi - first});
+            if (hi_scratch > first) lay.cls_chunks[k][L].push_back({first, hi_scratch - first});
+            if (n_sl) lay.cls_chunks[k][L].push_back({hi_scratch, n_sl, true});
         }
         // the exact kernels use slot 0 of the same buffer: it must hold the largest single record
         for (uint32_t oi = 0; oi < p.n_opcodes; oi++)
@@ -197,7 +195,7 @@ LevelSchedule level_schedule(const Plan &p, const LaunchLayout &lay) {
                 case CLS_LIGHT: op = ch.coop ? SO_LIGHT_SL : SO_LIGHT; break;
                 case CLS_HASH: op = ch.coop ? SO_HASH_COOP : SO_HASH; break;
                 case CLS_GRUMPKIN: op = SO_GRUMPKIN; break;
-                case CLS_BRILLIG: op = SO_BRILLIG; break;
+                case CLS_BRILLIG: op = ch.coop ? SO_LIGHT_SL : SO_BRILLIG; break;  // (coop: straight-line records on the Brillig lane)
                 case CLS_PEDERSEN: op = SO_PEDERSEN; break;
                 case CLS_ECDSA: op = SO_ECDSA; break;
                 case CLS_DIGEST: op = SO_DIGEST; break;

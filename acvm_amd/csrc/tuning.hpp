@@ -34,6 +34,8 @@ struct Tuning {
     int64_t range_merge = 1;       // RANGE opcodes of a level, eight to a record
     int64_t hash_chain = 1;        // a byte-message hash of another one's digest runs behind it in the same workgroup
     int64_t brillig_inline = 1;    // straight-line Brillig programs compiled into light records of the level schedule
+    int64_t sl_lane = 0;           // 1: ... which run on the Brillig lane beside the gate levels instead of on the main stream between them (round 6, 10^6-opcode tile of 8 192,
+                                   // A-B-A-B on one box: 130.6 / 135.3 ms per 4 096 instances on the main stream, 134.2 / 135.0 on the lane: no difference, the default stays)
     int64_t pedersen_waves = 0;    // waves per 64 instances of the level Pedersen kernel: 0 = four, or one when the launch fills the chip anyhow; 1 / 4 force
     int64_t pedersen_bundle = 1;   // up to eight Pedersen records of a launch per wave, ONE inversion per chain step for all of them: 0 never, 1 in launches that fill the chip anyhow, 2 always (tests)
     int64_t pedersen_bundle_waves = 2048;  // ... as many records per wave as leave the launch this many waves (two per SIMD; measured, DESIGN section 9: at 1 024 the north-star shape in tiles of 2^16 loses 2 %, at 512 a config-5 tile of 4 096 gets slower)

@@ -189,7 +189,7 @@ ALU_KERNELS = {"grumpkin_level_kernel": KERNEL_SYMBOL["grumpkin_level_kernel"], 
                "brillig_level_kernel": KERNEL_SYMBOL["brillig_level_kernel"]}
 
 
-def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
+def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls, sclk_mhz=None):
     """ALU roofline of an integer-bound kernel class, in modmul-equivalents: the VALU instructions its launches execute (PMC
     SQ_INSTS_VALU, own pass) divided by the VALU instructions of ONE Montgomery product (the same counter over the library's
     back-to-back fr29_mul probe, whose product count is known), per second of the class's HIP-event time, against the probe's rate."""
@@ -202,7 +202,14 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
     solves = 2  # the profiled inner run: one warm-up and one timed solve of one tile
     equiv = v_cls / solves / valu_per_modmul
     achieved = equiv / (cls_ms_per_tile / 1e3)
+    import acvm_amd
+    n_simd = 4 * acvm_amd.modmul_probe_cus()
     return {"bound": "valu", "unit": "modmul/s", "achieved": achieved, "peak": peak, "frac": achieved / peak,
+            # the hardware-referenced figure beside the probe-referenced one: the share of the chip's VALU issue slots the class's launches fill
+            # (a better product routine would lower `frac` and leave this one alone)
+            "valu_issue_frac": None if not sclk_mhz else (v_cls / solves) * 4.0 / (n_simd * (cls_ms_per_tile / 1e3) * sclk_mhz * 1e6),
+            "valu_issue_definition": "SQ_INSTS_VALU of the class's launches per tile x 4 cycles / (SIMDs x the class's HIP-event seconds x the shader clock sampled under this workload)",
+            "sclk_mhz_under_load": sclk_mhz, "simds": n_simd,
             "modmul_equivalents_per_tile": equiv, "valu_wave_insts_per_tile": v_cls / solves, "valu_wave_insts_per_wave_modmul": valu_per_modmul * 64,
             "kernel_ms_per_tile": cls_ms_per_tile, "kernels": ALU_KERNELS[cls_kernel],
             "definition": "modmul-equivalents = SQ_INSTS_VALU of the class's launches / SQ_INSTS_VALU per product of the back-to-back fr29_mul probe "
@@ -218,16 +225,26 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls):
 ECDSA_PRODUCTS = {0: 3 + 119 + 8 + 128 * 7 + 61 * 11 + 176 + 2, 1: 3 + 120 + 256 * 8 + 665.5 + 176 + 2 + 5}
 
 
-def ecdsa_alu_roofline(tile, kernel_ms):
+def ecdsa_alu_roofline(args, tile, kernel_ms, sclk_mhz=None):
     """ALU roofline of the ECDSA kernel in base-field products: what one launch computes (both curves, one verification each per instance)
-    per second of its HIP-event time, against the back-to-back s29_mul / s29_sqr probe of each curve measured in this run"""
+    per second of its HIP-event time, against the back-to-back s29_mul / s29_sqr probe of each curve measured in this run; and, from one
+    SQ_INSTS_VALU pass, the instructions per counted product and the kernel's share of the chip's VALU issue slots"""
     import acvm_amd
     peaks = [acvm_amd.secp_rate(c, 400, 8)[0] for c in (0, 1)]
     per_instance = ECDSA_PRODUCTS[0] + ECDSA_PRODUCTS[1]
     at_peak_s = tile * (ECDSA_PRODUCTS[0] / peaks[0] + ECDSA_PRODUCTS[1] / peaks[1])
     achieved = tile * per_instance / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+    hw = {}
+    v, n = pick(pmc_pass(args, "SQ_INSTS_VALU"), ["EcdsaOp"]) if args is not None else (0, 0)
+    if n:
+        solves = 2  # the profiled inner run: one warm-up and one timed solve of one tile
+        n_simd = 4 * acvm_amd.modmul_probe_cus()
+        hw = {"valu_wave_insts_per_tile": v / solves, "valu_per_counted_product": (v / solves) * 64.0 / (tile * per_instance),
+              "valu_issue_frac": None if not sclk_mhz or kernel_ms <= 0 else (v / solves) * 4.0 / (n_simd * (kernel_ms / 1e3) * sclk_mhz * 1e6),
+              "sclk_mhz_under_load": sclk_mhz, "simds": n_simd,
+              "valu_issue_definition": "SQ_INSTS_VALU of the kernel's launches per tile x 4 cycles / (SIMDs x its HIP-event seconds x the shader clock sampled under this workload)"}
     return {"bound": "valu", "unit": "field products/s", "achieved": achieved, "peak": tile * per_instance / at_peak_s,
-            "frac": at_peak_s / (kernel_ms / 1e3) if kernel_ms > 0 else None,
+            "frac": at_peak_s / (kernel_ms / 1e3) if kernel_ms > 0 else None, **hw,
             "products_per_verification": {"secp256k1": ECDSA_PRODUCTS[0], "secp256r1": ECDSA_PRODUCTS[1]},
             "probe_products_per_s": {"secp256k1": peaks[0], "secp256r1": peaks[1]}, "kernel_ms_per_tile": kernel_ms,
             "definition": "products (multiplications and squarings of the curve's base field) one launch executes, counted from the routine, / its HIP-event "
@@ -397,11 +414,11 @@ def roofline_block(args, st, tile, world, sclk_mhz, pmc=True):
                 roof["valu_issue_detail"] = {"valu_wave_insts_per_launch": v / n, "sclk_mhz_under_load": sclk_mhz, "simds": n_simd,
                                              "definition": "SQ_INSTS_VALU per launch x 4 cycles / (SIMDs x launch seconds x sclk)"}
         if args.workload == "ecdsa":
-            alu = ecdsa_alu_roofline(tile, k_ms)
+            alu = ecdsa_alu_roofline(args, tile, k_ms, sclk_mhz)
             roof["note"] = "integer-ALU bound class: the HBM fraction is for information, see alu_roofline"
         elif dominant in ALU_KERNELS:
             peak, probe_n = acvm_amd.modmul_rate(400, 8)
-            alu = measure_alu(args, dominant, k_ms, peak, 8 * 100 * 2 * 256 * acvm_amd.modmul_probe_cus()) or {"bound": "valu", "unit": "modmul/s", "peak": peak, "achieved": None, "frac": None}
+            alu = measure_alu(args, dominant, k_ms, peak, 8 * 100 * 2 * 256 * acvm_amd.modmul_probe_cus(), sclk_mhz) or {"bound": "valu", "unit": "modmul/s", "peak": peak, "achieved": None, "frac": None}
             roof["note"] = "integer-ALU bound class: the HBM fraction is for information, see alu_roofline"
     return roof, alu
 
@@ -439,7 +456,17 @@ def run_leg(name, total_log2=16, tile_log2=16, steps=3, warmup=2, pmc=True):
     elapsed = time.perf_counter() - t0
     st = batch.stats()
     batch.set_profiling(False)
-    roof, alu = roofline_block(a, st, tile, 1, None, pmc=pmc)
+    sclk = None
+    if pmc and name in ("hash", "grumpkin", "ecdsa"):
+        # the shader clock under THIS workload, for the hardware-referenced ALU figures: sampled over ~0.8 s of back-to-back passes outside the timed region
+        # (the sampler forks rocm-smi: it would disturb the sub-millisecond steps themselves)
+        with ClockSampler(acvm_amd.current_device()) as cs:
+            t_end = time.perf_counter() + 0.8
+            while time.perf_counter() < t_end:
+                sh.solve_pass()
+            acvm_amd.synchronize()
+        sclk = cs.median()
+    roof, alu = roofline_block(a, st, tile, 1, sclk, pmc=pmc)
     # the whole step against the HBM peak: what the import moves (the caller's 32 bytes in, the row out, 4 bytes per byte plane) + the solve's bytes
     step_bytes = (len(ids) * 64 + 4 * st.get("n_byte_planes", 0) + st["algorithmic_bytes_per_instance"] - 28 * st.get("n_byte_plane_reads", 0)) * tile
     step_ms = elapsed / steps / n_tiles * 1e3

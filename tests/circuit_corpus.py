@@ -19,7 +19,7 @@ PLANNER_MODES = [
     {},
     {"scale": 0}, {"pairs": 0}, {"chains": 0}, {"max_tails": 1}, {"max_tails": 8}, {"inv_epoch": 1}, {"inv_epoch": 9}, {"inv_latency": 0}, {"inv_latency": 3},
     {"heavy_epoch": 4, "heavy_latency": 4}, {"pedersen_latency": 6}, {"pedersen_epoch": 1, "pedersen_latency": 0}, {"pedersen_epoch": 5}, {"digest_epoch": 1},
-    {"digest_epoch": 32}, {"range_fuse": 0}, {"range_merge": 0}, {"range_fuse": 0, "range_merge": 0}, {"brillig_inline": 0}, {"hash_chain": 0}, {"light_fuse": 0},
+    {"digest_epoch": 32}, {"range_fuse": 0}, {"range_merge": 0}, {"range_fuse": 0, "range_merge": 0}, {"brillig_inline": 0}, {"sl_lane": 1}, {"hash_chain": 0}, {"light_fuse": 0},
     {"relax": 0}, {"pedersen_bundle": 2, "pedersen_epoch": 8}, {"inv_chunk": 1000, "inv_epoch": 9}, {"byte_plane": 0}, {"overlap": 0}, {"heavy_streams": 0},
     {"scale": 0, "pairs": 0, "range_fuse": 0, "range_merge": 0, "brillig_inline": 0, "light_fuse": 0, "overlap": 0},
 ]

@@ -47,6 +47,8 @@ def test_node_equals_one_batch_and_oracle(oracle, devices, tile, B):
     st = node.stats()
     assert st["n_devices"] == len(devices) and sum(st["tiles"]) >= (B + tile - 1) // tile
     assert all(st["async_exact"])
+    # the circuit is levelised ONCE per node, whatever the number of lanes (the plan is immutable and shared: round 6; until then 1 + lanes times)
+    assert st["plans_built"] == 1 and gc.plans_built() == 1 and st["plan_ms"] > 0 and st["create_ms"] >= st["plan_ms"] and st["host_rss_bytes"] > 0
     # (a partial last tile solves its own instances only: the lanes behind them are dead, not copies of an instance)
     assert 0 < sum(st["exact_instances"]) <= B
     ores, oasg, ovals = oracle.solve_batch(oracle.Circuit(data), ids, values, B)
@@ -56,6 +58,9 @@ def test_node_equals_one_batch_and_oracle(oracle, devices, tile, B):
         if res[j].message or ores[j].message:
             assert res[j].message == ores[j].message
     node.free()
+    again = acvm_amd.Node(gc, ids, keep=keep, devices=devices, tile=tile)  # the circuit handle still holds the plan: a second node plans nothing
+    assert again.stats()["plans_built"] == 0 and gc.plans_built() == 1
+    again.free()
 
 
 def test_node_with_slot_reuse_and_null_outputs(oracle):

@@ -205,4 +205,4 @@ def test_planner_refactoring_moved_no_word():
     assert (h, h2) == PLAN_PINS, (h, h2)
 
 
-PLAN_PINS = ("dcf4da57cf56e6e0", "3e33dc0bfd95e577")
+PLAN_PINS = ("dcf4da57cf56e6e0", "ff690a45bee30aee")

@@ -441,8 +441,16 @@ static int batch_init(acvm_batch *b) {
         size_t bytes = (size_t)p.n_inverse_slots * 2 * b->Bp * sizeof(uint4);
         HIPCHK(hipMalloc((void **)&b->d_inv, bytes ? bytes : 16));
     }
-    HIPCHK(hipMalloc((void **)&b->d_event, ((size_t)b->B + 2) * 4));  // + the count of flagged instances and a ticket (kernels.hip event_count_kernel)
-    HIPCHK(hipHostMalloc((void **)&b->h_flag_count, 64, hipHostMallocMapped));  // the same count where the host can read it after a synchronisation
+    {   // event words, with the count of flagged instances and the device address of the host-visible counter in front (ops_common.hpp flag_instance)
+        HIPCHK(hipMalloc((void **)&b->d_event_base, ((size_t)b->B + 4 + 4) * 4));
+        b->d_event = b->d_event_base + 4;
+        HIPCHK(hipHostMalloc((void **)&b->h_flag_count, 64, hipHostMallocMapped));
+        void *d_count = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&d_count, b->h_flag_count, 0));
+        uint32_t hdr[4] = {0, 0, 0, 0};
+        memcpy(&hdr[2], &d_count, sizeof d_count);
+        HIPCHK(hipMemcpy(b->d_event_base, hdr, sizeof hdr, hipMemcpyHostToDevice));
+    }
     b->unscale = Unscale{b->d_unscale_index, b->d_unscale_consts, b->d_unscale_plain, b->d_scaled_ids, (uint32_t)p.scaled_ids.size(), b->d_event};
     b->h_event.assign(b->B, 0xFFFFFFFFu);
     b->slow_index.assign(b->B, -1);
@@ -491,8 +499,8 @@ int batch_import_async(acvm_batch *b, const void *d_values_be32, hipEvent_t impo
     b->next_imported = false;
     b->next_inputs = nullptr;
     if (!already)
-        launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->reuse() ? b->d_init_rows : b->d_init_ids,
-                      (uint32_t)b->plan().initial_ids.size(), nullptr, b->d_byte_plane_of_input, b->d_byte_plane);
+        b->events_fresh = launch_import(b->stream, b->d_W, b->Bp, b->B, (const uint8_t *)d_values_be32, b->reuse() ? b->d_init_rows : b->d_init_ids,
+                                        (uint32_t)b->plan().initial_ids.size(), nullptr, b->d_byte_plane_of_input, b->d_byte_plane, b->d_event);
     HIPCHK(hipGetLastError());
     if (imported) HIPCHK(hipEventRecord(imported, b->stream));
     b->inputs_set = true;

@@ -82,8 +82,10 @@ struct acvm_batch {
     uint32_t *d_cls_scratch_off[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_cls_scratch[N_CLS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DeviceProgram dp{};
-    uint32_t *d_event = nullptr;
-    uint32_t *h_flag_count = nullptr;  // pinned, device-mapped
+    uint32_t *d_event = nullptr;       // the event words; EVENT_HDR_WORDS in front of them: the count of flagged instances and the device address of h_flag_count
+    uint32_t *d_event_base = nullptr;  // (the allocation)
+    uint32_t *h_flag_count = nullptr;  // pinned, device-mapped: the same count where the host reads it after a synchronisation
+    bool events_fresh = false;         // the last import left the event words "nobody flagged": the next solve skips its reset launch
     std::vector<uint32_t> h_event;
     bool events_clean = false;  // h_event is all 0xFFFFFFFF, slow_ids empty, slow_index all -1 (kept across solves that flag nothing)
     // exact in-order path
@@ -193,7 +195,7 @@ struct acvm_batch {
         hipSetDevice(device);
         for (void *p : {(void *)d_W, (void *)d_Mem, (void *)d_gate_stream, (void *)d_gate_offset, (void *)d_consts, (void *)d_prog,
                         (void *)d_prog_offset, (void *)d_bytecode, (void *)d_init_ids, (void *)d_producer, (void *)d_dyn_offset,
-                        (void *)d_slow_start, (void *)d_event, (void *)d_slow_ids, (void *)d_assigned, (void *)d_slow_res})
+                        (void *)d_slow_start, (void *)d_event_base, (void *)d_slow_ids, (void *)d_assigned, (void *)d_slow_res})
             if (p) hipFree(p);
         if (h_flag_count) hipHostFree(h_flag_count);
         for (int k = 0; k < (int)N_CLS; k++)

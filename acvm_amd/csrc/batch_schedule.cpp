@@ -46,7 +46,10 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) { e0 = next_event(); hipEventRecord(e0, s); }
         switch (st.op) {
-        case SO_EVENT_RESET: launch_event_reset(s, b->d_event, b->B); break;
+        case SO_EVENT_RESET:  // (the import of this tile usually left the event words ready: kernels.hip import_witness_kernel)
+            if (!b->events_fresh) launch_event_reset(s, b->d_event, b->B);
+            b->events_fresh = false;
+            break;
         case SO_GATES:
             launch_arith_level(s, b->d_W, b->Bp, b->B, b->d_gate_stream, b->d_gate_offset + st.first, st.count, b->d_consts, b->d_event, b->d_inv);
             break;
@@ -70,7 +73,7 @@ static int enqueue_level_schedule(acvm_batch *b, LaunchTimers *tm) {
         case SO_INVERSE:
             launch_inverse_batch(s, b->d_W, b->d_inv, b->Bp, b->B, b->d_gate_stream, b->d_dyn_offset + st.first, st.count, b->d_event, (uint32_t)p.tune.inv_chunk);
             break;
-        case SO_TRUNCATE: launch_min_u32(s, b->d_event, p.truncated_at, b->B); break;
+        case SO_TRUNCATE: launch_event_truncate(s, b->d_event, b->B, p.truncated_at); break;
         }
         if (timed) {
             e1 = next_event();
@@ -138,8 +141,10 @@ int batch_solve_impl(acvm_batch *b, const void *next_inputs) {
     if (!b->force_slow)
         if (int rc = ensure_level_events(b)) return rc;
     HIPCHK(hipEventRecord(b->ev_start, s));
+    *b->h_flag_count = 0;  // (the kernels of this solve count the instances they flag: ops_common.hpp flag_instance; every earlier solve has been waited for)
     if (b->force_slow) {
         launch_fill_u32(s, b->d_event, 0u, b->B);
+        b->events_fresh = false;
     } else {
         if (int rc = enqueue_level_schedule(b, b->profiling ? &tm : nullptr)) return rc;
     }
@@ -148,20 +153,20 @@ int batch_solve_impl(acvm_batch *b, const void *next_inputs) {
     if (b->pending)
         if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
     // instances that left the generic path (or hit a failing opcode): exact in-order re-solve from their event on. Usually there is
-    // none: only their count comes back (4 bytes instead of the B event words and a scan of them -- 30 us of a 0.25 ms solve of config 3)
+    // none: only their count comes back -- kept by the kernels that flag, in a host-mapped word the host reads after the synchronisation it
+    // needs anyway (no counting kernel and no copy behind the last kernel of a solve)
     uint32_t n_flagged = b->B;
     if (!b->force_slow && b->B) {
-        *b->h_flag_count = b->B;  // (stays "everything" if the kernel did not run)
-        launch_event_count(s, b->d_event, b->B, b->h_flag_count);
         if (next_inputs) {
             if (!b->ev_counted) HIPCHK(hipEventCreate(&b->ev_counted));
             HIPCHK(hipEventRecord(b->ev_counted, s));
+            // gate: the device's count of flagged instances, in front of the event words; the import leaves the event words ready for the next solve
             launch_import(s, b->d_W, b->Bp, b->B, (const uint8_t *)next_inputs, b->reuse() ? b->d_init_rows : b->d_init_ids, (uint32_t)p.initial_ids.size(),
-                          b->d_event + b->B, b->d_byte_plane_of_input, b->d_byte_plane);  // gate: the count of flagged instances the kernel above left there
+                          b->d_event - 4, b->d_byte_plane_of_input, b->d_byte_plane, b->d_event);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventSynchronize(b->ev_counted));
         } else HIPCHK(hipStreamSynchronize(s));
-        n_flagged = *(volatile uint32_t *)b->h_flag_count;
+        n_flagged = p.truncated_at != 0xFFFFFFFFu ? b->B : *(volatile uint32_t *)b->h_flag_count;
     }
     const bool imported_next = next_inputs && !b->force_slow && b->B && n_flagged == 0;
     if (n_flagged || !b->events_clean) {
@@ -240,6 +245,7 @@ int batch_solve_impl(acvm_batch *b, const void *next_inputs) {
         HIPCHK(hipEventElapsedTime(&ms, b->ev_start, b->ev_counted));
         b->next_imported = true;
         b->next_inputs = next_inputs;
+        b->events_fresh = true;  // (the gated import ran: it left the event words ready)
     } else {
         HIPCHK(hipEventRecord(b->ev_end, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -27,7 +27,7 @@ template <bool ALIGNED>
 __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B,
                                                              const uint8_t *__restrict__ in, const uint32_t *__restrict__ ids,
                                                              uint32_t n_in, const uint32_t *__restrict__ gate, const uint32_t *__restrict__ plane_of_input,
-                                                             uint32_t *__restrict__ plane) {
+                                                             uint32_t *__restrict__ plane, uint32_t *__restrict__ event_reset) {
     __shared__ uint4 tile[4][2][65];
     __shared__ uint32_t tile_low[4][64];  // byte planes (plan.hpp): low 29 bits of the canonical value | is-byte << 31
     if (gate && *gate != 0u) return;  // (block-uniform)
@@ -86,6 +86,12 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
             if (plane_of_input) {  // (block-uniform per kk: a scalar load)
                 const uint32_t pl = plane_of_input[k];
                 if (pl != 0xFFFFFFFFu) plane[(uint64_t)pl * Bp + j] = tile_low[kk][ji];
+            }
+            // ACVM::new: nobody has left the generic path yet. The import of a tile leaves the event words ready for its solve (one launch less in
+            // front of every solve: a config-3 step is five launches). The blocks of the first four inputs do it for their 64 instances.
+            if (event_reset && k == 0) {
+                event_reset[j] = 0xFFFFFFFFu;
+                if (j == 0) { event_reset[-4] = 0u; event_reset[-3] = 0u; }
             }
         }
     }
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(64) inverse_batch_kernel(const uint4 *__restri
         const uint32_t *__restrict__ g = gate_stream + job_offset[first + i];
         Fr den = fr_load(W, g[0], Bp, j);
         if (fr_is_zero(den)) {  // zero-coefficient drop (arithmetic.rs:217-221): this instance leaves the generic path at the gate
-            atomicMin(&event[j], g[1]);
+            flag_instance(event, j, g[1]);
             den = fr_one();
         }
         prefix = fr29_mul(prefix, fr29_from(den));
@@ -341,12 +347,13 @@ __global__ void init_assigned_kernel(uint32_t *assigned, uint32_t n_slow, uint32
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate,
-                   const uint32_t *plane_of_input, uint32_t *plane) {
-    if (!B || !n_in) return;
+bool launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate,
+                   const uint32_t *plane_of_input, uint32_t *plane, uint32_t *event_reset) {
+    if (!B || !n_in) return false;
     const dim3 grid((B + 63u) / 64u, (n_in + 3u) / 4u);
-    if (((uintptr_t)in & 15u) == 0) hipLaunchKernelGGL(import_witness_kernel<true>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate, plane_of_input, plane);
-    else hipLaunchKernelGGL(import_witness_kernel<false>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate, plane_of_input, plane);
+    if (((uintptr_t)in & 15u) == 0) hipLaunchKernelGGL(import_witness_kernel<true>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate, plane_of_input, plane, event_reset);
+    else hipLaunchKernelGGL(import_witness_kernel<false>, grid, dim3(256), 0, s, W, Bp, B, in, ids, n_in, gate, plane_of_input, plane, event_reset);
+    return event_reset != nullptr;
 }
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel, uint8_t *out,
                    const Unscale &u, const uint32_t *row_of) {
@@ -389,34 +396,24 @@ void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mism
     if (!n) return;
     hipLaunchKernelGGL(fr_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, n, mismatches);
 }
-// event words of a batch: [0, B) = per instance the first opcode that left the generic path (0xFFFFFFFF: none), word B = how many did
-// (word B + 1 = a ticket: the block that takes the last one publishes the total)
+// event words of a batch (ops_common.hpp flag_instance): [0, B) = per instance the first opcode that left the generic path (0xFFFFFFFF: none); in front
+// of them the count of flagged instances, kept by the kernels that flag
 __global__ void __launch_bounds__(256) event_reset_kernel(uint32_t *__restrict__ event, uint32_t B) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < B) event[i] = 0xFFFFFFFFu;
-    else if (i <= B + 1) event[i] = 0u;
+    else if (i < B + 2) event[(int)(i - B) - 4] = 0u;  // the count of flagged instances and the spare word in front (ops_common.hpp flag_instance)
 }
-// host_count: pinned host memory mapped into the device: the last block to finish stores the total there, so the host reads it after the
-// stream synchronisation it needs anyway -- no copy launch behind the last kernel of a solve
-__global__ void __launch_bounds__(256) event_count_kernel(uint32_t *__restrict__ event, uint32_t B, uint32_t *__restrict__ host_count) {
+// a plan the level kernels do not cover entirely: every instance continues on the exact path from `opcode` at the latest
+__global__ void __launch_bounds__(256) event_truncate_kernel(uint32_t *__restrict__ event, uint32_t B, uint32_t opcode) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool flagged = i < B && event[i] != 0xFFFFFFFFu;
-    const uint32_t n = (uint32_t)__popcll(__ballot(flagged));
-    if (n && (threadIdx.x & 63u) == 0) atomicAdd(&event[B], n);
-    __syncthreads();  // this block's additions are issued
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&event[B + 1], 1u) == gridDim.x - 1) {
-            __threadfence();
-            *host_count = atomicAdd(&event[B], 0u);
-        }
-    }
+    if (i < B) event[i] = min(event[i], opcode);
+    if (i == 0) event[-4] = B;
 }
 void launch_event_reset(hipStream_t s, uint32_t *event, uint32_t B) {
     hipLaunchKernelGGL(event_reset_kernel, dim3((B + 2) / 256 + 1), dim3(256), 0, s, event, B);
 }
-void launch_event_count(hipStream_t s, uint32_t *event, uint32_t B, uint32_t *host_count) {
-    if (B) hipLaunchKernelGGL(event_count_kernel, dim3((B + 255) / 256), dim3(256), 0, s, event, B, host_count);
+void launch_event_truncate(hipStream_t s, uint32_t *event, uint32_t B, uint32_t opcode) {
+    if (B) hipLaunchKernelGGL(event_truncate_kernel, dim3((B + 255) / 256), dim3(256), 0, s, event, B, opcode);
 }
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n) {
     if (!n) return;

@@ -79,8 +79,9 @@ struct Unscale {
 };
 
 // plane_of_input / plane: per input its byte plane or NONE, and the planes (both null: the circuit has none)
-void launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate = nullptr,
-                   const uint32_t *plane_of_input = nullptr, uint32_t *plane = nullptr);
+// event_reset: null, or the batch's event words: the import also leaves them "nobody flagged" (returns true when it did: the solve behind it needs no reset launch)
+bool launch_import(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint8_t *in, const uint32_t *ids, uint32_t n_in, const uint32_t *gate = nullptr,
+                   const uint32_t *plane_of_input = nullptr, uint32_t *plane = nullptr, uint32_t *event_reset = nullptr);
 void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, const uint32_t *sel, uint32_t n_sel,
                    uint8_t *out, const Unscale &u, const uint32_t *row_of = nullptr);
 void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,
@@ -100,9 +101,10 @@ void launch_secp_rate(hipStream_t s, uint32_t curve, uint32_t *out, uint32_t blo
 void launch_stream_rate(hipStream_t s, const uint4 *a, const uint4 *b, uint4 *out, uint64_t n);  // n: multiple of 256
 void launch_fr_selftest(hipStream_t s, uint64_t seed, uint32_t n, uint32_t *mismatches);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
-// event words [0, B) <- 0xFFFFFFFF, the flagged count (word B) and the ticket (word B + 1) <- 0; the count of words != 0xFFFFFFFF into word B and *host_count
+// event words [0, B) <- 0xFFFFFFFF, the count of flagged instances in front of them (event[-4], ops_common.hpp flag_instance) <- 0
 void launch_event_reset(hipStream_t s, uint32_t *event, uint32_t B);
-void launch_event_count(hipStream_t s, uint32_t *event, uint32_t B, uint32_t *host_count);  // host_count: pinned, device-mapped
+// event words <- min(event, opcode), the count <- B: a plan the level kernels do not cover entirely
+void launch_event_truncate(hipStream_t s, uint32_t *event, uint32_t B, uint32_t opcode);
 void launch_min_u32(hipStream_t s, uint32_t *p, uint32_t v, uint64_t n);
 void launch_init_assigned(hipStream_t s, uint32_t *assigned, uint32_t n_slow, uint32_t n_words, uint32_t n_witnesses,
                           const uint32_t *producer, const uint32_t *start_opcode);

@@ -72,7 +72,7 @@ pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, 
     const GrumpkinTables &T = dp.grumpkin;
     FastPolicy p{W, Bp, j, slot_of};
     if (n == 0) {  // the point at infinity is reported as (0, 0)
-        if (wave == 0 && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) atomicMin(&event[j], rec[1]);
+        if (wave == 0 && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) flag_instance(event, j, rec[1]);
         return;
     }
     // The first link of the chain, hash_pair(IV[domain separator], n), is the same for every instance, and so is the left half
@@ -146,7 +146,7 @@ pedersen_quad_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp, 
             __syncthreads();  // lds_r / lds_acc are rewritten by the next step
         }
     }
-    if (wave == 0 && active && (!p.insert(rec[4], r, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
+    if (wave == 0 && active && (!p.insert(rec[4], r, rec[5]) || !p.insert(rec[6], y, rec[7]))) flag_instance(event, j, rec[1]);
 }
 
 // ---------------------------------------------------------------------------------------------- Pedersen, K records per wave, ONE inversion per step
@@ -182,7 +182,7 @@ pedersen_bundle_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp
     for (uint32_t i = 0; i < nb; i++) {
         const uint32_t *__restrict__ rec = prog + offsets[b0 + i];
         n_max = max(n_max, rec[3]);
-        if (rec[3] == 0u && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) atomicMin(&event[j], rec[1]);  // the point at infinity is reported as (0, 0)
+        if (rec[3] == 0u && active && (!p.insert(rec[4], fr_zero(), rec[5]) || !p.insert(rec[6], fr_zero(), rec[7]))) flag_instance(event, j, rec[1]);  // the point at infinity is reported as (0, 0)
     }
     for (uint32_t step = 1; step <= n_max; step++) {
         // ---- forward: the step's sum of every record that still runs, and the running product of their Z
@@ -232,7 +232,7 @@ pedersen_bundle_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, DeviceProgram dp
             Fr x = fr29_pack(fr29_canon(fr29_mul(X, zi2))), y = fr29_pack(fr29_canon(fr29_mul(Y, fr29_mul(zi2, zi))));
             if (inf) { x = fr_zero(); y = fr_zero(); }
             for (int k = 0; k < 8; k++) *park(i, PED_PARK_X + k) = x.v[k];
-            if (step == n && active && (!p.insert(rec[4], x, rec[5]) || !p.insert(rec[6], y, rec[7]))) atomicMin(&event[j], rec[1]);
+            if (step == n && active && (!p.insert(rec[4], x, rec[5]) || !p.insert(rec[6], y, rec[7]))) flag_instance(event, j, rec[1]);
         }
     }
 }

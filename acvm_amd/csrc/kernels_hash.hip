@@ -242,7 +242,7 @@ hash_coop_level_kernel(uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *__rest
         const uint32_t *outs = rec + 6 + 2u * rec[3];
         if (!coop_store_outputs(p, outs, lds_dig[dcur], w, WAVES, lane, T)) conflict = min(conflict, rec[1]);
         const uint32_t bad = min(range_bad, conflict);
-        if (bad != 0xFFFFFFFFu) atomicMin(&event[j], bad);
+        if (bad != 0xFFFFFFFFu) flag_instance(event, j, bad);
     }
 }
 void launch_hash_coop_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const DeviceProgram &dp, const uint32_t *offsets, uint32_t n, uint32_t *event, uint32_t lds_words) {

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) hostbb_apply_level_kernel(uint4 *W, uint6
     const uint64_t j = first + t;
     FastPolicy p{W, Bp, j, slot_of};
     const OpResult r = hostbb_apply(p, func, rc[t], outs, n_out, vals + (uint64_t)t * n_out * 32);
-    if (r.err) atomicMin(&event[j], opcode);
+    if (r.err) flag_instance(event, j, opcode);
 }
 __global__ void __launch_bounds__(64) hostbb_apply_exact_kernel(uint4 *W, uint64_t Bp, ExactLanes L, uint32_t first, uint32_t n_lanes, uint32_t opcode,
                                                                 uint32_t func, const uint32_t *__restrict__ outs, uint32_t n_out,
@@ -164,7 +164,7 @@ arith_light_level_kernel(uint4 *__restrict__ W, uint64_t Bp, uint32_t B, const u
     const uint32_t *__restrict__ rec = prog + light_offsets[blockIdx.y];
     FastPolicy p{W, Bp, j, slot_of};
     const OpResult r = dispatch_light(p, rec, consts, Mem);
-    if (r.err) atomicMin(&event[j], rec[0] == K_RANGE_MULTI ? r.aux0 : rec[1]);
+    if (r.err) flag_instance(event, j, rec[0] == K_RANGE_MULTI ? r.aux0 : rec[1]);
 }
 void launch_arith_light_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset, uint32_t n_gates,
                               const uint4 *inv, const DeviceProgram &dp, const uint32_t *light_offsets, uint32_t n_light, uint32_t *event) {

@@ -64,6 +64,18 @@ __device__ __forceinline__ Fr apply_coef_prod(const Fr &a, const Fr &b, uint32_t
     if (coef == K_COEF_MINUS_ONE) return fr_neg(fr29_pack(fr29_cond_sub_p(t)));
     return fr29_pack(fr29_cond_sub_p(fr29_mul(t, fr29_from(fr_const(consts, coef)))));
 }
+// ---- the event words of a batch: event[j] = the first opcode (program order) at which instance j left the generic path, 0xFFFFFFFF = it did
+// not. In FRONT of them, four words: [-4] how many instances are flagged, [-3] spare, [-2..-1] the address of a host-mapped counter (or null).
+// The FIRST flag of an instance counts it, on the device (the gate of the next tile's import reads that word) and in the host's counter (the
+// host reads it after the synchronisation it needs anyway): no counting kernel behind a solve (until round 6: event_count_kernel).
+static constexpr int EVENT_HDR_WORDS = 4;
+__device__ __forceinline__ void flag_instance(uint32_t *__restrict__ event, uint64_t j, uint32_t opcode) {
+    if (atomicMin(&event[j], opcode) == 0xFFFFFFFFu) {
+        atomicAdd(event - 4, 1u);
+        uint32_t *host = *(uint32_t *const *)(event - 2);
+        if (host) __hip_atomic_fetch_add(host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // ---- the gate kernel's body (kernels.hip arith_level_kernel; kernels_ops.hip runs it beside the light records of the same level):
 // gate_eval.hpp's record evaluation over the witness table. grid = (ceil(B/256), gates in level). Lane = instance. The gate record
 // (number gate_index of the level) is wave-uniform.
@@ -104,7 +116,7 @@ __device__ __forceinline__ void arith_level_body(uint4 *__restrict__ W, uint64_t
             uint32_t z = 0;
 #pragma unroll
             for (int i = 0; i < 9; i++) z |= acc.v[i];
-            if (z) atomicMin(&event[j], opcode);
+            if (z) flag_instance(event, j, opcode);
         } else {  // coefficients were pre-multiplied by -1/coeff on the host (arithmetic.rs:120)
 #ifdef GATE_EXP_NO_STORES  // measurement only: the result leaves through one word (kept alive, never true)
             if (fr29_pack(acc).v[3] == 0x12345678u && acc.v[5] == 77u) event[j] = 0;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(BLOCK) record_level_kernel(uint4 *W, uint64_t 
         p.sj = j & 63u;
     }
     const OpResult r = Op::run(p, rec, dp, sc, (SlowResult *)nullptr, (const ExactLanes *)nullptr, 0u);
-    if (r.err) atomicMin(&event[j], rec[0] == K_RANGE_MULTI ? r.aux0 : rec[1]);  // (a merged record names the failing opcode itself)
+    if (r.err) flag_instance(event, j, rec[0] == K_RANGE_MULTI ? r.aux0 : rec[1]);  // (a merged record names the failing opcode itself)
 }
 
 template <class Op, int BLOCK>

@@ -566,7 +566,7 @@ def run_config5_leg(tile_log2=13, timed_tiles=2, audit=32, inner=False):
     valu = None
     per = pmc_pass(None, "SQ_INSTS_VALU", inner=[sys.executable, os.path.abspath(__file__), "--inner-config5-leg", "--tile-log2", str(tile_log2)])
     if per:
-        n_solves = pick(per, ["event_reset_kernel"])[1]
+        n_solves = pick(per, ["import_witness_kernel"])[1]  # one import per tile of the profiled sequence (it also resets the event words: there is no reset launch to count)
         by_class = {name: pick(per, subs)[0] / max(n_solves, 1) for name, subs in CONFIG5_CLASSES.items()}
         total = sum(by_class.values())
         n_simd = 4 * acvm_amd.modmul_probe_cus()

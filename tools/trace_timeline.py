@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tools/trace_timeline.py TRACE_DIR [first_kernel_substr] -- who holds the device when, from a rocprofv3 --kernel-trace CSV of ONE solve-heavy
 run: per kernel class the busy time (union of its launches), the time it runs alone, the time NOTHING runs, and how the wall clock of the
-window splits by the set of classes in flight. The window is the last `solve` in the trace: from the last event_reset_kernel to the last
-event_count_kernel (one level schedule)."""
+window splits by the set of classes in flight. The window is the last but one `solve` in the trace: the level-schedule kernels between two
+imports (import_witness_kernel)."""
 import csv
 import glob
 import os
@@ -27,16 +27,22 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    resets = [s for s, e, n in rows if "event_reset_kernel" in n]
-    counts = [e for s, e, n in rows if "event_count_kernel" in n]
-    if not resets or not counts:
+    # a solve = the level-schedule kernels between two imports (since round 6 the import resets the event words and the kernels that flag
+    # count: there is no event_reset_kernel / event_count_kernel to delimit it)
+    imports = [s for s, e, n in rows if "import_witness_kernel" in n]
+    if not imports:
         print("no solve found")
         return
     # the solve to analyse: the last but one (the last may carry profiling events), or the last
-    k = -2 if len(resets) >= 2 else -1
-    t0 = resets[k]
-    t1 = min(c for c in counts if c > t0)
-    win = [(s, e, cls_of(n)) for s, e, n in rows if s >= t0 and e <= t1 and cls_of(n)]
+    k = -2 if len(imports) >= 2 else -1
+    lo = imports[k]
+    hi = imports[k + 1] if k + 1 < 0 else float("inf")
+    win = [(s, e, cls_of(n)) for s, e, n in rows if s > lo and s < hi and cls_of(n) and "digest_final" not in n and "digest_chunk" not in n]
+    if not win:
+        print("no solve found")
+        return
+    t0 = min(s for s, e, c in win)
+    t1 = max(e for s, e, c in win)
     print(f"window {(t1 - t0) / 1e6:.2f} ms, {len(win)} launches")
     ev = []
     for s, e, c in win:

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "acvm_multi_witness_map", "acvm_multi_locate", "acvm_debug_modmul_rate", "acvm_debug_secp_rate", "acvm_batch_new_ex", "acvm_circuit_plan_stats_ex",
     "acvm_tuning_set", "acvm_tuning_get", "acvm_tuning_key",
     "acvm_device_release_tables", "acvm_circuit_opcode_kinds", "acvm_batch_error_expression", "acvm_debug_stream_rate", "acvm_node_new", "acvm_node_free", "acvm_node_tile_instances", "acvm_node_num_devices", "acvm_node_solve", "acvm_node_stats",
-    "acvm_debug_cpulist", "acvm_debug_device_locality", "acvm_debug_plan_fingerprint", "acvm_circuit_plans_built", "acvm_circuit_check_schedule",
+    "acvm_debug_cpulist", "acvm_debug_device_locality", "acvm_debug_plan_fingerprint", "acvm_circuit_plans_built", "acvm_circuit_check_schedule", "acvm_batch_digest_blake2s",
 ]
 
 
@@ -271,6 +271,7 @@ def lib():
     L.acvm_batch_error_string.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
     L.acvm_batch_extract_witnesses.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.acvm_batch_digest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.acvm_batch_digest_blake2s.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     for f in (L.acvm_witness_map_decode, L.acvm_witness_map_encode, L.acvm_batch_witness_map_bytes):
         f.restype = C.c_longlong
     L.acvm_witness_map_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -789,6 +790,14 @@ class Batch:
         n = self.B - first if n is None else n
         out = np.zeros((n, 32), dtype=np.uint8)
         _check(lib().acvm_batch_digest(self._h, first, n, out.ctypes.data))
+        return out
+
+    def digest_blake2s(self, first=0, n=None):
+        """Per-instance Blake2s tree digest of the witness map's BYTES (acvm_batch_digest_blake2s): uint8 array [n][32]."""
+        import numpy as np
+        n = self.B - first if n is None else n
+        out = np.zeros((n, 32), dtype=np.uint8)
+        _check(lib().acvm_batch_digest_blake2s(self._h, first, n, out.ctypes.data))
         return out
 
     def witness_map_bytes(self, instance: int) -> bytes:

@@ -625,6 +625,34 @@ int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out3
     return digest_range(b, b->stream, b->d_W, b->Bp, first, n, b->unscale, nullptr, true, (uint32_t)b->slow_ids.size(), out32);
 } ABI_CATCH
 
+// SURVEY 8d's digest as written -- Blake2s over the witness vector's bytes -- in tree form (definition: include/acvm_amd.h). The whole table must be
+// there: not with recycled rows, not while an asynchronous exact job holds instances in its side table.
+int acvm_batch_digest_blake2s(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32) try {
+    if (!b || (n && !out32)) return set_err(ACVM_E_INVALID, "null argument");
+    if (b->pending)
+        if (int rc = batch_finish_pending(b, &b->last_outcome)) return rc;
+    if (!b->solved) return set_err(ACVM_E_STATE, "batch not solved");
+    if ((uint64_t)first + n > b->B) return set_err(ACVM_E_INVALID, "instance range out of bounds");
+    if (!n) return 0;
+    if (b->side()) return set_err(ACVM_E_STATE, "the byte-wise digest hashes every witness row: not with ACVM_BATCH_REUSE_SLOTS (rows are recycled) nor while instances of "
+                                                "the exact path live in a side table; acvm_batch_digest serves those");
+    if (int rc = refuse_if_next_imported(b, nullptr, 0, true)) return rc;
+    HIPCHK(hipSetDevice(b->device));
+    const Plan &p = b->plan();
+    hipStream_t s = b->stream;
+    const size_t idx_bytes = align256((size_t)b->B * 4);
+    const size_t leaf_bytes = align256((size_t)digest_b2s_leaves(p.n_witnesses) * 32 * n);
+    if (int rc = stage_reserve(b, idx_bytes + leaf_bytes + (size_t)n * 32)) return rc;
+    HIPCHK(hipMemcpyAsync(b->d_stage, b->slow_index.data(), (size_t)b->B * 4, hipMemcpyHostToDevice, s));
+    uint32_t *d_leaves = (uint32_t *)(b->d_stage + idx_bytes);
+    uint8_t *d_out = b->d_stage + idx_bytes + leaf_bytes;
+    launch_digest_blake2s(s, b->d_W, b->Bp, first, n, p.n_witnesses, b->d_producer, b->unscale, (const int32_t *)b->d_stage, b->d_assigned, (uint32_t)b->slow_ids.size(), d_leaves, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out32, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+} ABI_CATCH
+
 int acvm_batch_extract_witnesses(acvm_batch_t *b, const uint32_t *witnesses, uint32_t n_witnesses, uint32_t first, uint32_t n,
                                  uint8_t *values_be32) try {
     if (!b || (n_witnesses && (!witnesses || !values_be32))) return set_err(ACVM_E_INVALID, "null argument");

@@ -36,7 +36,7 @@ bool grumpkin_pair_table(GrumpkinTables *out);
 // a of generator D contributes (a + 1) D = a_hi 2^k D + a_lo D + D -- so the 29 slices (261 bits) of a value can be cut at ANY bit: entry [parity][j][v]
 // is the joint contribution of bits [24 j, 24 j + 24) of the scalar (the pieces of the two to four slices the window touches, the even slices through
 // the endomorphism, plus the `+ 1` of every slice that starts inside the window): 11 mixed additions per hash_single instead of the pair table's 15 (12 with 22-bit windows).
-#ifndef GRUMPKIN_PEDW_BITS_V  // (tools/build_variant.sh -DGRUMPKIN_PEDW_BITS_V=22: round 3's 12 windows of 22 bits, a 6.4 GB table; the A/B is in DESIGN.md section 9)
+#ifndef GRUMPKIN_PEDW_BITS_V  // (tools/build_variant.sh -DGRUMPKIN_PEDW_BITS_V=22: round 3's 12 windows of 22 bits, a 6.4 GB table; the A/B is in NOTEBOOK.md section 9)
 #define GRUMPKIN_PEDW_BITS_V 24
 #endif
 static constexpr uint32_t GRUMPKIN_PEDW_BITS = GRUMPKIN_PEDW_BITS_V, GRUMPKIN_PEDW_WINDOWS = (261 + GRUMPKIN_PEDW_BITS - 1) / GRUMPKIN_PEDW_BITS;

@@ -157,6 +157,11 @@ struct DigestTables {
     const uint32_t *h_pow;     // [n_witnesses]: h^(w+1)
     const uint32_t *h_generic; // [1]: the sum of h^(w+1) over the witnesses the planner saw assigned
 };
+// the witness map hashed as bytes, in tree form (kernels_hash.hip; include/acvm_amd.h acvm_batch_digest_blake2s): leaves = scratch of
+// digest_b2s_leaves(n_witnesses) x 8 x n words
+uint32_t digest_b2s_leaves(uint32_t n_witnesses);
+void launch_digest_blake2s(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
+                           const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out);
 uint32_t digest_chunks(uint32_t n_witnesses);  // rows of the partial-sum scratch of launch_digest: digest_chunks x n x 32 bytes
 void launch_digest(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
                    const DigestTables &T, const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint4 *partial, uint8_t *out);

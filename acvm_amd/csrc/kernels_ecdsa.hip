@@ -30,7 +30,7 @@ __global__ void ecdsa_gtable_kernel(uint32_t *out) {
 }
 
 // The ALU roofline of the ECDSA kernels: every lane runs a chain of 2 * iters base-field products of one curve, a product and a square in
-// turn (a verification is 54 % products, 46 % squares: DESIGN.md section 6); several waves per SIMD interleave their chains.
+// turn (a verification is 54 % products, 46 % squares: NOTEBOOK.md section 6); several waves per SIMD interleave their chains.
 template <int C>
 __global__ void __launch_bounds__(256) secp_rate_kernel(uint32_t *__restrict__ out, uint32_t seed, uint32_t iters) {
     Fr a, b;

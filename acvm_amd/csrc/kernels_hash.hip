@@ -297,7 +297,7 @@ __device__ __forceinline__ Fr fp_value(const FpAcc &a) {
 // sum of stored_w * coef_w over the listed witnesses for a wave whose lanes are all instances of the level kernels (wave-uniform
 // coefficients, FP_DOT products per Montgomery reduction: 81 multiply-adds per product + 81 per reduction, so four to a reduction are 101 per
 // term against the 121.5 of pairs and the 162 of single products; four rows in flight per lane). next: produces (witness row, coefficient address) pairs.
-#ifndef FP_DOT_N  // (tools/build_variant.sh -DFP_DOT_N=6: the A/B of DESIGN section 9)
+#ifndef FP_DOT_N  // (tools/build_variant.sh -DFP_DOT_N=6: the A/B of NOTEBOOK.md section 9)
 #define FP_DOT_N 4
 #endif
 static constexpr int FP_DOT = FP_DOT_N;
@@ -419,6 +419,99 @@ __global__ void __launch_bounds__(128) digest_final_kernel(const uint4 *__restri
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(h[i] >> (8 * k));
+}
+// ---- the witness map hashed AS BYTES (include/acvm_amd.h acvm_batch_digest_blake2s: SURVEY 8d's "blake2s over the full witness vector", in tree
+// form so that an instance's million witnesses are not one sequential chain): leaf k = Blake2s-256 over the 32-byte big-endian canonical values of
+// witnesses [256 k, 256 k + 256), 0xFF x 32 for a witness the instance did not assign (no field element reads so); root = Blake2s-256 over
+// u32_le(n_witnesses) and the leaves. One lane per (instance, leaf): 128 compressions and 256 canonicalising products; rows coalesced over the wave.
+static constexpr uint32_t B2S_LEAF_WITNESSES = 256;
+__device__ __forceinline__ void b2s_put_value(uint32_t (&w)[16], int half, bool present, const Fr &canon) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[8 * half + k] = present ? bswap32(canon.v[7 - k]) : 0xFFFFFFFFu;  // big-endian bytes as little-endian message words
+}
+__global__ void __launch_bounds__(64) digest_b2s_leaf_kernel(const uint4 *__restrict__ W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses,
+                                                             const uint32_t *__restrict__ producer, const Unscale u, const int32_t *__restrict__ slow_index,
+                                                             const uint32_t *__restrict__ assigned, uint32_t n_slow, uint32_t *__restrict__ leaves, uint32_t leaf0) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x, leaf = leaf0 + blockIdx.y;
+    const bool live = t < n;
+    const uint64_t j = (uint64_t)first + (live ? t : 0u);
+    const bool generic = !u.event || u.event[j] == 0xFFFFFFFFu;  // solved by the level kernels: the planner's assigned set, scaled columns
+    const uint32_t lane = generic ? 0u : (uint32_t)slow_index[j];
+    const uint32_t w_begin = leaf * B2S_LEAF_WITNESSES, w_end = min(n_witnesses, w_begin + B2S_LEAF_WITNESSES);
+    Fr one = fr_zero();
+    one.v[0] = 1;
+    uint32_t h[8], m[16];
+    blake2s_init(h);
+    const uint32_t n_pairs = (w_end - w_begin + 1) / 2;
+    for (uint32_t q = 0; q < n_pairs; q++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const uint32_t w = w_begin + 2 * q + half;
+            bool present = false;
+            Fr c = fr_zero();
+            if (w < w_end) {
+                present = generic ? producer[w] != 0xFFFFFFFFu : ((assigned[(uint64_t)(w >> 5) * n_slow + lane] >> (w & 31)) & 1u) != 0u;
+                const uint32_t ui = generic && u.index ? u.index[w] : 0xFFFFFFFFu;
+                // out of Montgomery form; a scaled column leaves it through the canonical integer 1 / scale instead of 1 (like export_witness_kernel)
+                if (present) c = fr_mul(fr_load(W, w, Bp, j), ui != 0xFFFFFFFFu ? fr_const(u.consts_plain, ui) : one);
+            }
+            if (w < w_end) b2s_put_value(m, half, present, c);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) m[8 * half + k] = 0u;  // an odd last witness: 32 bytes of message in the block
+            }
+        }
+        const bool last = q + 1 == n_pairs;
+        const uint32_t bytes = 32u * (w_end - w_begin);
+        blake2s_compress_body(h, m, last ? bytes : 64u * (q + 1), last);
+    }
+    if (live)
+#pragma unroll
+        for (int k = 0; k < 8; k++) leaves[((uint64_t)leaf * 8 + k) * n + t] = h[k];
+}
+__global__ void __launch_bounds__(64) digest_b2s_root_kernel(const uint32_t *__restrict__ leaves, uint32_t n_leaves, uint32_t n, uint32_t n_witnesses, uint8_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n) return;
+    // message: u32_le(n_witnesses), then the leaves (8 little-endian words each = their 32 digest bytes): 4 + 32 n_leaves bytes, streamed through a 16-word block
+    uint32_t h[8], m[16];
+    blake2s_init(h);
+    const uint64_t total = 4ull + 32ull * n_leaves;
+    m[0] = n_witnesses;
+    uint32_t fill = 1;      // words of the block in use
+    uint64_t done = 0;      // bytes compressed so far
+    for (uint32_t leaf = 0; leaf < n_leaves; leaf++)
+        for (int k = 0; k < 8; k++) {
+            if (fill == 16) {  // (more data follows: not the last block)
+                done += 64;
+                blake2s_compress(h, m, (uint32_t)done, false);
+                fill = 0;
+            }
+            // (fill is wave-uniform: a uniform-index store)
+            const uint32_t v = leaves[((uint64_t)leaf * 8 + k) * n + t];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if ((uint32_t)i == fill) m[i] = v;
+            fill++;
+        }
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if ((uint32_t)i >= fill) m[i] = 0u;
+    blake2s_compress(h, m, (uint32_t)total, true);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[(uint64_t)t * 32 + 4 * i + k] = (uint8_t)(h[i] >> (8 * k));
+}
+uint32_t digest_b2s_leaves(uint32_t n_witnesses) { return (n_witnesses + B2S_LEAF_WITNESSES - 1) / B2S_LEAF_WITNESSES; }
+void launch_digest_blake2s(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, uint32_t n, uint32_t n_witnesses, const uint32_t *producer, const Unscale &u,
+                           const int32_t *slow_index, const uint32_t *assigned, uint32_t n_slow, uint32_t *leaves, uint8_t *out) {
+    if (!n) return;
+    const uint32_t n_leaves = digest_b2s_leaves(n_witnesses);
+    for (uint32_t done = 0; done < n_leaves; done += 65535u) {  // gridDim.y is limited to 65535
+        const uint32_t m = n_leaves - done > 65535u ? 65535u : n_leaves - done;
+        hipLaunchKernelGGL(digest_b2s_leaf_kernel, dim3((n + 63) / 64, m), dim3(64), 0, s, W, Bp, first, n, n_witnesses, producer, u, slow_index, assigned, n_slow, leaves, done);
+    }
+    hipLaunchKernelGGL(digest_b2s_root_kernel, dim3((n + 63) / 64), dim3(64), 0, s, leaves, n_leaves, n, n_witnesses, out);
 }
 uint32_t digest_chunks(uint32_t n_witnesses) { return (n_witnesses + DIGEST_CHUNK - 1) / DIGEST_CHUNK; }
 // partial: scratch of digest_chunks(n_witnesses) x n x 32 bytes

@@ -144,7 +144,7 @@ struct acvm_node {
 namespace {
 
 // instances per handle when the caller leaves the choice to the library: the largest power of two (at most 2^17, the measured optimum of
-// the 10k-gate circuit) that every listed device has room for. Per device: 90 % of its free memory, less the lookup
+// the 10k-gate circuit, NOTEBOOK.md section 7) that every listed device has room for. Per device: 90 % of its free memory, less the lookup
 // tables the circuit would still build there, divided by the number of handles the device is listed for; a handle needs its tables, class
 // scratch and first side table (batch_device_bytes) plus this driver's staging and export buffers.
 uint32_t auto_tile(const Plan &p, const PlanOpts &opts, const std::vector<uint32_t> &ids, const std::vector<uint32_t> &keep, const std::vector<int> &devices) {

@@ -606,7 +606,7 @@ FR_HD __forceinline__ Fr sn_sub(const Fr &a, const Fr &b) {
 // doublings of a variable-base product. The split is the one of libsecp256k1 (scalar_split_lambda): with the lattice basis (a1, b1), (a2, b2)
 // of {(x, y): x + y lambda = 0 mod n}, c1 = round(k g1 / 2^384), c2 = round(k g2 / 2^384) for g1 = round(2^384 b2 / n), g2 = round(2^384 (-b1) / n),
 // k2 = c1 (-b1) + c2 (-b2), k1 = k - k2 lambda. Returned as magnitudes < 2^128 and signs. (Constants re-derived and the bound checked over
-// 200 000 scalars by the script quoted in DESIGN.md section 9; tests/test_secp_device_on_host.py checks k1 + k2 lambda = k.)
+// 200 000 scalars by the script quoted in NOTEBOOK.md section 9; tests/test_secp_device_on_host.py checks k1 + k2 lambda = k.)
 struct SecpSplit { Fr k1, k2; bool neg1, neg2; };
 FR_HD __forceinline__ Fr secp_round_shift384(const uint32_t t[16]) {  // (t + 2^383) >> 384 of a 512-bit product
     Fr c = fr_zero();
@@ -797,7 +797,7 @@ template <int C>
 FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const S29 &qx, const S29 &qy, const Fr &u2, const uint32_t *__restrict__ gtab) {
     SAff29 tab[8];
     secp_window_table<C>(tab, qx, qy);
-#ifdef SECP_EXP_NO_TABLE_READS  // measurement only: every addition takes Q itself from registers, the table is built and kept alive
+#ifdef SECP_EXP_NO_TABLE_READS  // measurement only (NOTEBOOK.md section 9): every addition takes Q itself from registers, the table is built and kept alive
 #define SECP_ROW(k) SAff29{qx, qy}
 #define SECP_BX(k) qx
 #pragma unroll

@@ -1,5 +1,5 @@
 // tuning.hpp -- every planner / scheduler mode of the library in ONE place (process-wide defaults; a plan keeps the snapshot it was
-// built with). The defaults are the measured optimum of DESIGN.md section 9; the other values exist so that the A/B measurements of
+// built with). The defaults are the measured optimum of NOTEBOOK.md section 9; the other values exist so that the A/B measurements of
 // that section stay reproducible and so that the parity tests can sweep the planner's modes (tests/test_gpu_planner_modes.py). Set
 // through the ABI (acvm_tuning_set, include/acvm_amd.h) or, for command-line tools, once at first use from the environment variable
 // ACVM_TUNING="key=value,key=value". No mode changes any result: every one of them is compared bit for bit against the oracle.
@@ -17,7 +17,7 @@ struct Tuning {
     int64_t max_tails = 5;         // records behind the host of a wave program
     int64_t inv_epoch = 4;         // levels per batch of denominator inversions
     int64_t byte_plane = 1;        // initial witnesses that byte-message hashes read get a second, 4-byte copy (low limb + is-byte flag) written by the import: the hash kernel reads 4 bytes per input instead of 32
-    int64_t inv_chunk = 128;       // denominators per wave of an inversion batch at most (they share ONE field inversion; 64 -> 128: +0.9 % on the headline)
+    int64_t inv_chunk = 128;       // denominators per wave of an inversion batch at most (they share ONE field inversion; 64 -> 128: +0.9 % on the headline, NOTEBOOK.md section 9)
     int64_t inv_latency = 1;       // levels of slack between an inversion batch and the first gate that reads it
     int64_t heavy_epoch = 1;       // heavy records launched every K-th level only
     int64_t heavy_latency = 0;     // levels the main stream waits before it reads a heavy output
@@ -38,7 +38,7 @@ struct Tuning {
                                    // A-B-A-B on one box: 130.6 / 135.3 ms per 4 096 instances on the main stream, 134.2 / 135.0 on the lane: no difference, the default stays)
     int64_t pedersen_waves = 0;    // waves per 64 instances of the level Pedersen kernel: 0 = four, or one when the launch fills the chip anyhow; 1 / 4 force
     int64_t pedersen_bundle = 1;   // up to eight Pedersen records of a launch per wave, ONE inversion per chain step for all of them: 0 never, 1 in launches that fill the chip anyhow, 2 always (tests)
-    int64_t pedersen_bundle_waves = 2048;  // ... as many records per wave as leave the launch this many waves (two per SIMD; measured, DESIGN section 9: at 1 024 the north-star shape in tiles of 2^16 loses 2 %, at 512 a config-5 tile of 4 096 gets slower)
+    int64_t pedersen_bundle_waves = 2048;  // ... as many records per wave as leave the launch this many waves (two per SIMD; measured, NOTEBOOK.md section 9: at 1 024 the north-star shape in tiles of 2^16 loses 2 %, at 512 a config-5 tile of 4 096 gets slower)
     int64_t pedersen_prio = 1;     // s_setprio 3 in the level Pedersen kernel: its few long waves win the issue arbitration against the gate kernel's many
     int64_t light_fuse = 1;        // the light records of a level ride in its gate launch
     int64_t plan_validate = 0;     // 1: every pass of the planner checks what it promises (plan.cpp check_*; a violation is an error of the call); 100 + k: break invariant k first (tests)

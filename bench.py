@@ -216,7 +216,7 @@ def measure_alu(args, cls_kernel, cls_ms_per_tile, peak, probe_modmuls, sclk_mhz
                           "(acvm_debug_modmul_rate: 8 interleaved chains per SIMD); peak = that probe's measured modmul/s in this run"}
 
 
-# Base-field products (multiplications + squarings of secp_device.hpp) of ONE verification, counted from the routine:
+# Base-field products (multiplications + squarings of secp_device.hpp) of ONE verification, counted from the routine (NOTEBOOK.md section 6):
 # the curve equation 3 (x^2, x^3, y^2: the batch's keys are on the curve, so the given y is the root and the square-root chain of the
 # decompression -- 253 S + 13 / 7 M -- never runs; round 3 counted it); the window table {Q .. 8Q} 119 (+ 8 for the beta x of secp256k1); the ladder
 # 128 / 256 doublings x 7 / 8 and on average 61 / 60.5 mixed additions x 11; 16 additions of generator-table points (16-bit windows) x 11; the final
@@ -806,7 +806,7 @@ def main():
     if world == 1 and args.workload == "arith" and not args.no_legs and not args.no_cpu_baseline:
         legs = {}
         # arith_pedersen is north_star's target shape: it runs at the metric's batch and tile (2^20 in tiles of 2^17; tiles of 2^16 measure 5 % lower:
-        # the Pedersen launches of a tile of 2^17 hold enough waves for several records to share their inversions)
+        # the Pedersen launches of a tile of 2^17 hold enough waves for several records to share their inversions, NOTEBOOK.md section 9)
         # (the short legs first: they are measured the way round 3 measured them, before the long one has the part power-limited for a second and a half)
         for name, kw in (("hash", dict(warmup=3, steps=5)), ("grumpkin", dict(warmup=3, steps=5)), ("ecdsa", dict(warmup=3, steps=5)),
                          ("arith_pedersen", dict(total_log2=20, tile_log2=17, steps=5, warmup=1))):

@@ -432,6 +432,16 @@ int acvm_batch_error_expression(acvm_batch_t *b, const acvm_circuit_t *c, uint32
  */
 int acvm_batch_digest(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32);
 /*
+ * The same map hashed AS BYTES (ABI 6): SURVEY 8d's "blake2s over the full witness vector", collision-resistant, in tree form so that a map of a
+ * million witnesses is not one sequential chain:
+ *     leaf_k = Blake2s-256( for w in [256 k, min(256 k + 256, nw)):  value_w as 32 big-endian bytes if the instance assigned w, else 0xFF x 32 )
+ *     digest = Blake2s-256( u32_le(nw)  ||  leaf_0  ||  leaf_1  || ... ),        nw = acvm_circuit_num_witnesses
+ * (0xFF x 32 is no canonical field element, so an unassigned witness cannot be mistaken for a value.) About as much device work as the solve of a
+ * 10^6-opcode tile itself (557 k compressions and 1.1 M canonicalising products per instance) and it needs every row: for audits -- ACVM_E_STATE with
+ * ACVM_BATCH_REUSE_SLOTS; acvm_batch_digest above is the one that folds into the solve. oracle/binding.py witness_map_blake2s restates it with hashlib.
+ */
+int acvm_batch_digest_blake2s(acvm_batch_t *b, uint32_t first, uint32_t n, uint8_t *out32);
+/*
  * extract_indices (acvm_js/src/public_witness.rs:10-21; getReturnWitness / getPublicParametersWitness / getPublicWitness
  * with the sets above): values of the listed witnesses for instances [first, first + n), values_be32 = [n][n_witnesses][32].
  * Fails with ACVM_E_STATE and "Failed to extract witness W from witness map. Witness not found." (instance appended) when

@@ -230,6 +230,18 @@ def _digest_powers(nw):
     return got
 
 
+def witness_map_blake2s(assigned, values) -> bytes:
+    """CPU restatement (hashlib) of acvm_batch_digest_blake2s (include/acvm_amd.h) for ONE instance -- checker only: leaves of 256 witnesses (32
+    big-endian bytes each, 0xFF x 32 where unassigned), the root over u32_le(nw) and the leaves."""
+    import hashlib
+    nw = len(assigned)
+    raw = bytes(values) if isinstance(values, (bytes, bytearray)) else values.tobytes() if hasattr(values, "tobytes") else b"".join(bytes(v) for v in values)
+    leaves = []
+    for k in range(0, nw, 256):
+        leaves.append(hashlib.blake2s(b"".join(raw[32 * w:32 * w + 32] if assigned[w] else b"\xff" * 32 for w in range(k, min(k + 256, nw)))).digest())
+    return hashlib.blake2s(nw.to_bytes(4, "little") + b"".join(leaves)).digest()
+
+
 def witness_map_digest(assigned, values) -> bytes:
     """CPU restatement (Python big integers + hashlib) of the definition of acvm_batch_digest in include/acvm_amd.h, for ONE instance --
     checker only: assigned[w] truthy, values[w] = 32 big-endian bytes. D = sum over the assigned witnesses of value_w * g^(w+1) + h^(w+1)

@@ -129,6 +129,46 @@ def test_witness_map_digest_with_black_box_outputs(oracle):
         assert bytes(got[j]) == oracle.witness_map_digest(oasg[j], ovals[j]), f"instance {j} (status {ores[j].status})"
 
 
+@pytest.mark.parametrize("shape,force_slow", [("arith3", False), ("arith300", False), ("arith300", True), ("arith700", False), ("mixed", False), ("mixed_fold", False)])
+def test_witness_map_blake2s_tree_digest(oracle, shape, force_slow):
+    """acvm_batch_digest_blake2s (SURVEY 8d's "blake2s over the full witness vector", in tree form) against hashlib over the ORACLE's witness map:
+    solved instances (scaled and relaxed columns leave through 1 / scale), failing instances (their own assigned set: the map as it stands), every
+    instance through the exact kernels, witness counts that are not multiples of the leaf (an odd last witness, a short last leaf), pinned
+    hash outputs beside scaled witnesses; refused with recycled rows."""
+    import acvm_amd
+    from acvm_amd import synth
+    if shape.startswith("arith"):
+        n_gates = int(shape[5:])
+        circ, ids = synth.arithmetic_circuit(n_gates, seed=0xD16E57 + n_gates)
+        values = synth.witness_batch(70, seed=0xD16E57 + n_gates)
+    else:
+        circ, ids = synth.mixed_circuit(400, seed=0xD16E58)
+        values = synth.witness_batch(70, n_in=len(ids), seed=0xD16E58)
+    B = 70
+    oc = oracle.Circuit(circ.to_bytes())
+    ores, oasg, ovals = oracle.solve_batch(oc, ids, values, B)
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    batch = acvm_amd.Batch(gc, B, ids, fold_digest=shape == "mixed_fold")
+    batch.set_force_slow_path(force_slow)
+    batch.set_initial_witness(values)
+    batch.solve()
+    got = batch.digest_blake2s()
+    part = batch.digest_blake2s(first=5, n=9)
+    fingerprint = batch.digest()
+    batch.free()
+    for j in range(B):
+        assert bytes(got[j]) == oracle.witness_map_blake2s(oasg[j], ovals[j]), f"instance {j} (status {ores[j].status})"
+        assert bytes(fingerprint[j]) == oracle.witness_map_digest(oasg[j], ovals[j])
+    assert np.array_equal(part, got[5:14])
+    if shape == "mixed":
+        reuse = acvm_amd.Batch(gc, B, ids, reuse_slots=True, keep=gc.witness_set("return_values"))
+        reuse.set_initial_witness(values)
+        reuse.solve()
+        with pytest.raises(acvm_amd.AcvmError, match="recycled"):
+            reuse.digest_blake2s()
+        reuse.free()
+
+
 # ---- OpcodeNotSolvable::ExpressionHasTooManyUnknowns(Expression): the Display text carries the expression (pwg/mod.rs:72-78)
 _SUP = "⁰¹²³⁴⁵⁶⁷⁸⁹"
 

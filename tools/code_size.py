@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Code bytes of every gfx950 function in the objects of acvm_amd/build (kernels and out-of-line device functions), largest first: the instruction
-cache is 64 KiB per two CUs, and a kernel whose hot loop does not fit runs from L2.  python tools/code_size.py [min KiB]"""
+cache is 64 KiB per two CUs, and a kernel whose hot loop does not fit runs from L2 (NOTEBOOK.md section 9, round 4).  python tools/code_size.py [min KiB]"""
 import glob
 import os
 import re

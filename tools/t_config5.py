@@ -70,6 +70,12 @@ for k in range(n_tiles):
             if ores[i].status == 0 and ret:
                 got = batch.extract(ret, j, 1)[0]
                 ok &= all(bytes(got[n]) == bytes(ovals[i][w]) for n, w in enumerate(ret))
+        if mode != "reuse" and os.environ.get("ACVM_T_B2S"):  # the byte-wise tree digest (acvm_batch_digest_blake2s): its cost, and the audit instances against hashlib
+            b0 = time.time()
+            b2s = batch.digest_blake2s()
+            out["blake2s_tree_digest_ms"] = round((time.time() - b0) * 1e3, 1)
+            for i, j in enumerate(picks):
+                ok &= bytes(b2s[j]) == oracle.witness_map_blake2s(oasg[i], ovals[i])
         out["audit"] = {"instances": picks, "bit_exact": bool(ok), "oracle_s": round(a1 - a0, 1),
                         "oracle_witnesses_per_s": round(len(picks) / (a1 - a0), 2), "oracle_threads": min(len(picks), shard.cpu_budget()[0])}
 batch.free()

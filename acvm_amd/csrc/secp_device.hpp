@@ -333,8 +333,11 @@ FR_HD __forceinline__ uint32_t s29_pow2(uint32_t log2) {
 // secp256k1. The HIGH nine columns of the product come first (h: 29 bits each, h[8] the rest; no carry-in from the low half, which joins at 2^261
 // below); the low columns then take h (31264 + 2^8 2^29) as they are summed, so no limb of the wide product is formed twice.
 //   `hi(k, acc)` adds column k of the product to acc (k = 0..16).
-template <class Column>
-FR_HD __forceinline__ S29 s29_fold_k1(Column column) {
+// ADD (round 6): a lazy sum `addend` (limbs below 2^32, any value below 64 p -- a difference K - b, a few of them added) joins the low columns as they are
+// summed: result = a b + addend (mod p) in the same form as a plain product (below 1.01 p, exact limbs), with the carries of the addend propagated by
+// the scan. It replaces s29_out(s29_subl(product, b)) -- two limb-wise passes, a carry pass and a fold, 54-72 instructions -- by 9 + the 9 of K - b.
+template <bool ADD, class Column>
+FR_HD __forceinline__ S29 s29_fold_k1(Column column, const S29 *addend = nullptr) {
     const uint32_t k256 = s29_pow2(8);
     uint32_t h[9];
     uint64_t acc = 0;
@@ -352,6 +355,7 @@ FR_HD __forceinline__ S29 s29_fold_k1(Column column) {
         c = column(i, c);
         c += (uint64_t)h[i] * 31264u;
         if (i > 0) c += (uint64_t)h[i - 1] * k256;
+        if (ADD) c += addend->v[i];
         r.v[i] = (uint32_t)c & S29_M;
         c >>= 29;
     }
@@ -379,12 +383,35 @@ FR_HD __forceinline__ S29 s29_mul<0>(const S29 &a, const S29 &b) {
 #if S29_CHECKED
     s29_check_columns(a, b);
 #endif
-    return s29_fold_k1([&](int k, uint64_t acc) {
+    return s29_fold_k1<false>([&](int k, uint64_t acc) {
 #pragma unroll
         for (int i = 0; i < 9; i++)
             if (k - i >= 0 && k - i < 9) acc += (uint64_t)a.v[i] * b.v[k - i];
         return acc;
     });
+}
+// a b + addend, a^2 + addend (see s29_fold_k1): secp256k1 here, secp256r1 below the plain products
+template <int C>
+FR_HD __forceinline__ S29 s29_mul_add(const S29 &a, const S29 &b, const S29 &addend);
+template <int C>
+FR_HD __forceinline__ S29 s29_sqr_add(const S29 &a, const S29 &addend);
+#if S29_CHECKED
+static inline void s29_check_addend(const S29 &addend) {  // limbs are 32-bit by type (the column accumulators have room for them); the value stays below 128 p
+    S29_ASSERT(addend.v[8] < (1u << 31));                 // (value < (v8 + 16) 2^232: the lower limbs, below 2^32 each, add less than 2^236)
+}
+#endif
+template <>
+FR_HD __forceinline__ S29 s29_mul_add<0>(const S29 &a, const S29 &b, const S29 &addend) {
+#if S29_CHECKED
+    s29_check_columns(a, b);
+    s29_check_addend(addend);
+#endif
+    return s29_fold_k1<true>([&](int k, uint64_t acc) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i >= 0 && k - i < 9) acc += (uint64_t)a.v[i] * b.v[k - i];
+        return acc;
+    }, &addend);
 }
 template <>
 FR_HD __forceinline__ S29 s29_sqr<0>(const S29 &a) {  // the 36 cross products once, against the doubled limbs
@@ -395,13 +422,31 @@ FR_HD __forceinline__ S29 s29_sqr<0>(const S29 &a) {  // the 36 cross products o
     uint32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-    return s29_fold_k1([&](int k, uint64_t acc) {
+    return s29_fold_k1<false>([&](int k, uint64_t acc) {
 #pragma unroll
         for (int i = 0; i < 9; i++)
             if (k - i > i && k - i < 9) acc += (uint64_t)d[i] * a.v[k - i];
         if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
         return acc;
     });
+}
+template <>
+FR_HD __forceinline__ S29 s29_sqr_add<0>(const S29 &a, const S29 &addend) {
+#if S29_CHECKED
+    s29_check_columns(a, a);
+    s29_check_addend(addend);
+    for (int i = 0; i < 9; i++) S29_ASSERT(a.v[i] < (1u << 31));
+#endif
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+    return s29_fold_k1<true>([&](int k, uint64_t acc) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (k - i > i && k - i < 9) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        return acc;
+    }, &addend);
 }
 // secp256r1: column k of a b + sum m_i p 2^(29 i). m_k = the low limb of column k; it leaves that column (the shift drops it) and enters
 // columns k + 3 (2^9), k + 6 (2^18), k + 7 (0x1fe00000), k + 8 (0xffffff): p = (2^96 - 1) + 2^192 + 2^224 (2^32 - 1)
@@ -410,11 +455,14 @@ FR_HD __forceinline__ S29 s29_sqr<0>(const S29 &a) {  // the 36 cross products o
     if ((k) >= 6 && (k) - 6 < 9) acc += (uint64_t)m[(k) - 6] * k18;           \
     if ((k) >= 7 && (k) - 7 < 9) acc += (uint64_t)m[(k) - 7] * 0x1fe00000u;   \
     if ((k) >= 8 && (k) - 8 < 9) acc += (uint64_t)m[(k) - 8] * 0x00ffffffu;   \
+    if (ADD && (k) >= 9) acc += addend->v[(k) - 9];                           \
     if ((k) < 9) m[k] = (uint32_t)acc & S29_M;                                \
     else if ((k) < 17) r.v[(k) - 9] = (uint32_t)acc & S29_M;                  \
     acc >>= 29;
-template <>
-FR_HD __forceinline__ S29 s29_mul<1>(const S29 &a, const S29 &b) {
+// ADD (round 6): a lazy sum rides in the upper columns (like fr29_dot_add of the BN254 code): result = (a b + m p) / 2^261 + addend exactly, normalised
+// limbs, value < (A B / 32 + 1) p + addend -- the caller folds it with s29_weak<1> where it must be a coordinate (no separate carry pass)
+template <bool ADD>
+FR_HD __forceinline__ S29 s29_mul_r1(const S29 &a, const S29 &b, const S29 *addend) {
 #if S29_CHECKED
     s29_check_columns(a, b);
 #endif
@@ -430,11 +478,12 @@ FR_HD __forceinline__ S29 s29_mul<1>(const S29 &a, const S29 &b) {
         SECP_R1_REDUCE_STEP(k)
     }
     r.v[8] = (uint32_t)acc;
+    if (ADD) r.v[8] += addend->v[8];
     s29_opaque(r);
     return r;
 }
-template <>
-FR_HD __forceinline__ S29 s29_sqr<1>(const S29 &a) {
+template <bool ADD>
+FR_HD __forceinline__ S29 s29_sqr_r1(const S29 &a, const S29 *addend) {
 #if S29_CHECKED
     s29_check_columns(a, a);
     for (int i = 0; i < 9; i++) S29_ASSERT(a.v[i] < (1u << 31));
@@ -454,9 +503,18 @@ FR_HD __forceinline__ S29 s29_sqr<1>(const S29 &a) {
         SECP_R1_REDUCE_STEP(k)
     }
     r.v[8] = (uint32_t)acc;
+    if (ADD) r.v[8] += addend->v[8];
     s29_opaque(r);
     return r;
 }
+template <>
+FR_HD __forceinline__ S29 s29_mul<1>(const S29 &a, const S29 &b) { return s29_mul_r1<false>(a, b, nullptr); }
+template <>
+FR_HD __forceinline__ S29 s29_sqr<1>(const S29 &a) { return s29_sqr_r1<false>(a, nullptr); }
+template <>
+FR_HD __forceinline__ S29 s29_mul_add<1>(const S29 &a, const S29 &b, const S29 &addend) { return s29_mul_r1<true>(a, b, &addend); }
+template <>
+FR_HD __forceinline__ S29 s29_sqr_add<1>(const S29 &a, const S29 &addend) { return s29_sqr_r1<true>(a, &addend); }
 #undef SECP_R1_REDUCE_STEP
 template <int C>
 FR_HD __forceinline__ S29 s29_sqr_n(S29 a, int n) {
@@ -663,27 +721,25 @@ FR_HD __forceinline__ SJac sj_dbl(const SJac &p) {
         const S29 t = s29_norm(s29_subl<C>(s29_subl<C>(s, A, 1), Cc, 1));                                 // < 5.01
         const S29 D = s29_dbll(t);                                                                        // < 10.02, limbs < 2^30
         const S29 E = s29_norm(s29_addl(s29_dbll(A), A));                                                 // 3 A < 3.03
-        const S29 F = s29_sqr<C>(E);
-        r.X = s29_out<C>(s29_subl<C>(s29_subl<C>(F, D, 4), D, 4));                                        // F - 2 D: < 33.01 before
-        const S29 m = s29_mul<C>(E, s29_norm(s29_subl<C>(D, r.X, 1)));                                    // E (D - X3)
+        // (round 6: the differences ride in the products' column scans, s29_fold_k1 ADD: X3 = E^2 + (32 p - 2 D), Y3 = E (D - X3) + (16 p - 8 C), Z3 = (2 Y) Z --
+        // each a product's output, i.e. a coordinate, with no carry pass and no fold of its own)
+        r.X = s29_sqr_add<C>(E, s29_subl<C>(s29_subl<C>(s29_zero(), D, 4), D, 4));                        // E^2 - 2 D
         const S29 C8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(Cc))));                                        // < 8.08, limbs <= 2^30 - 2
-        r.Y = s29_out<C>(s29_subl<C>(m, C8, 4));
-        r.Z = s29_out<C>(s29_dbll(s29_mul<C>(p.Y, p.Z)));                                                 // (the doubling before the product, as in the other branch: measured the same here)
+        r.Y = s29_mul_add<C>(E, s29_norm(s29_subl<C>(D, r.X, 1)), s29_subl<C>(s29_zero(), C8, 4));        // E (D - X3) - 8 C
+        r.Z = s29_mul<C>(s29_dbll(p.Y), p.Z);
     } else {  // dbl-2001-b (a = -3): 3 M + 5 S
         const S29 delta = s29_sqr<C>(p.Z), gamma = s29_sqr<C>(p.Y);                                       // < 1.04
         const S29 beta = s29_mul<C>(p.X, gamma);                                                          // < 1.04
         const S29 u = s29_norm(s29_subl<C>(p.X, delta, 1));                                               // X - delta < 3.01
         const S29 al0 = s29_mul<C>(u, s29_addl(p.X, delta));                                              // (X - delta)(X + delta): 3.01 * 2.05 / 32 + 1 < 1.2
         const S29 alpha = s29_norm(s29_addl(s29_dbll(al0), al0));                                         // < 3.6
-        const S29 a2 = s29_sqr<C>(alpha);                                                                 // < 1.41
         const S29 b8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(beta))));                                      // < 8.32, limbs <= 2^30 - 2
-        r.X = s29_out<C>(s29_subl<C>(a2, b8, 4));                                                         // alpha^2 - 8 beta
+        r.X = s29_weak<C>(s29_sqr_add<C>(alpha, s29_subl<C>(s29_zero(), b8, 4)));                         // alpha^2 - 8 beta: the difference rides in the square's upper columns (round 6), < 17.5 before the fold
         r.Z = s29_mul<C>(s29_dbll(p.Y), p.Z);                                                             // (2 Y) Z as a product: 2.2 * 1.1 / 32 + 1 < 1.08 (the form (Y + Z)^2 - gamma - delta
                                                                                                           // pays two differences and a reduction for its squaring)
         const S29 w = s29_norm(s29_subl<C>(s29_dbll(s29_dbll(beta)), r.X, 1));                            // 4 beta - X3 < 6.16
-        const S29 m = s29_mul<C>(alpha, w);                                                               // 3.6 * 6.16 / 32 + 1 < 1.7
         const S29 g8 = s29_dbll(s29_norm(s29_dbll(s29_dbll(s29_sqr<C>(gamma)))));                         // 8 gamma^2 < 8.3
-        r.Y = s29_out<C>(s29_subl<C>(m, g8, 4));
+        r.Y = s29_weak<C>(s29_mul_add<C>(alpha, w, s29_subl<C>(s29_zero(), g8, 4)));                      // alpha w (3.6 * 6.16 / 32 + 1 < 1.7) - 8 gamma^2, < 17.7 before the fold
     }
     return r;
 }
@@ -691,15 +747,24 @@ FR_HD __forceinline__ SJac sj_dbl(const SJac &p) {
 template <int C>
 FR_HD __forceinline__ SJac sj_add_aff29(const SJac &p, const S29 &x2, const S29 &y2) {
     if (s29_is_zero_coord<C>(p.Z)) return SJac{x2, y2, sp_one<C>()};
+    // (round 6: every difference rides in a product's column scan -- s29_mul_add / s29_sqr_add -- instead of a limb-wise pass, a carry pass and a fold
+    // behind the product. secp256k1: the product's output IS a coordinate; secp256r1: one s29_weak brings it back below 1.01 p.)
     const S29 z1z1 = s29_sqr<C>(p.Z);
-    const S29 u2 = s29_mul<C>(x2, z1z1), s2 = s29_mul<C>(s29_mul<C>(y2, p.Z), z1z1);                     // < 1.07
-    const S29 h = s29_out<C>(s29_subl<C>(u2, p.X, 1)), rr = s29_norm(s29_subl<C>(s2, p.Y, 1));            // h < 1.01, rr < 3.07
+    S29 h, rr;
+    if (C == 0) {
+        h = s29_mul_add<C>(x2, z1z1, s29_subl<C>(s29_zero(), p.X, 1));                                    // x2 Z^2 - X < 1.01
+        rr = s29_mul_add<C>(s29_mul<C>(y2, p.Z), z1z1, s29_subl<C>(s29_zero(), p.Y, 1));                  // y2 Z^3 - Y < 1.01
+    } else {
+        h = s29_weak<C>(s29_mul_add<C>(x2, z1z1, s29_subl<C>(s29_zero(), p.X, 1)));                       // < 3.1 before the fold
+        rr = s29_norm(s29_subl<C>(s29_mul<C>(s29_mul<C>(y2, p.Z), z1z1), p.Y, 1));                        // < 3.07 (a carry pass is cheaper than this curve's fold)
+    }
     if (s29_is_zero_coord<C>(h)) return s29_is_zero<C>(rr) ? sj_dbl<C>(p) : sj_identity<C>();
     const S29 hh = s29_sqr<C>(h), hhh = s29_mul<C>(hh, h), v = s29_mul<C>(p.X, hh);                       // < 1.04
     SJac r;
-    r.X = s29_out<C>(s29_subl<C>(s29_subl<C>(s29_sqr<C>(rr), hhh, 1), s29_dbll(v), 2));                   // rr^2 - H^3 - 2 V
-    const S29 m1 = s29_mul<C>(rr, s29_norm(s29_subl<C>(v, r.X, 1)));                                      // rr (V - X3): 3.07 * 3.04 / 32 + 1 < 1.3
-    r.Y = s29_out<C>(s29_subl<C>(m1, s29_mul<C>(p.Y, hhh), 1));
+    const S29 xs = s29_sqr_add<C>(rr, s29_subl<C>(s29_subl<C>(s29_zero(), hhh, 1), s29_dbll(v), 2));      // rr^2 - H^3 - 2 V (+ 6 p)
+    r.X = C == 0 ? xs : s29_weak<C>(xs);
+    const S29 ys = s29_mul_add<C>(rr, s29_norm(s29_subl<C>(v, r.X, 1)), s29_subl<C>(s29_zero(), s29_mul<C>(p.Y, hhh), 1));  // rr (V - X3) - Y H^3 (+ 2 p)
+    r.Y = C == 0 ? ys : s29_weak<C>(ys);
     r.Z = s29_mul<C>(p.Z, h);
     return r;
 }

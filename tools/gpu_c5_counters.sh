@@ -27,7 +27,7 @@ import csv, glob, sys, os, re, json
 from collections import defaultdict
 out, nt, tile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 CLASSES = [("arith", "arith_l"), ("inv", "inverse_batch_kernel"), ("light", "LightOp"), ("lightsl", "LightSlOp"), ("hash", "hash_coop_level_kernel"), ("hash", "HashOp"),
-           ("pedersen", "pedersen_"), ("grumpkin", "GrumpkinOp"), ("brillig", "BrilligOp"), ("digest", "digest_"), ("import", "import_witness"), ("exact", "exact_")]
+           ("pedersen", "pedersen_quad"), ("pedersen", "pedersen_bundle"), ("tables (once per process)", "_table_kernel"), ("tables (once per process)", "pedersen_seed"), ("grumpkin", "GrumpkinOp"), ("brillig", "BrilligOp"), ("digest", "digest_"), ("import", "import_witness"), ("exact", "exact_")]
 def cls_of(n):
     for c, s in CLASSES:
         if s in n: return c
@@ -41,13 +41,13 @@ sclk_med = sorted(sclk)[len(sclk) // 2] if sclk else None
 run = json.loads(open(os.path.join(out, "run_plain.json")).read().strip().splitlines()[-1])
 ms = sorted(t["solve_device_ms"] for t in run["tiles"][1:])[len(run["tiles"][1:]) // 2]
 print(f"# config-5 tile of {tile} instances: per kernel class and tile (sums over {nt} tiles / {nt}); solve_device_ms (median of 5 unprofiled tiles) = {ms}; sclk under load (median of {len(sclk)} samples) = {sclk_med} MHz")
-print(f"{'class':10s} {'launches':>9s} {'VALU wave-insts':>16s} {'waves':>12s} {'VALU/wave':>10s} {'read GB':>9s} {'write GB':>9s}")
+print(f"{'class':26s} {'launches':>9s} {'VALU wave-insts':>16s} {'waves':>12s} {'VALU/wave':>10s} {'read GB':>9s} {'write GB':>9s}")
 total_valu = 0
 for c in sorted(tot, key=lambda c: -tot[c].get("SQ_INSTS_VALU", 0)):
     v = tot[c].get("SQ_INSTS_VALU", 0) / nt; w = tot[c].get("SQ_WAVES", 0) / nt
     rd = tot[c].get("FETCH_SIZE", 0) / nt * 1024 * 2 / 1e9; wr = tot[c].get("WRITE_SIZE", 0) / nt * 1024 / 1e9
-    if c not in ("exact", "other"): total_valu += v
-    print(f"{c:10s} {cnt[c].get('SQ_INSTS_VALU', 0) / nt:9.0f} {v:16.0f} {w:12.0f} {v / w if w else 0:10.0f} {rd:9.2f} {wr:9.2f}")
+    if c not in ("exact", "other", "tables (once per process)", "import"): total_valu += v
+    print(f"{c:26s} {cnt[c].get('SQ_INSTS_VALU', 0) / nt:9.0f} {v:16.0f} {w:12.0f} {v / w if w else 0:10.0f} {rd:9.2f} {wr:9.2f}")
 if sclk_med:
     for clk in (sclk_med, 2400):
         print(f"tile-wide VALU issue fraction at {clk} MHz: {total_valu * 4 / (1024 * ms / 1e3 * clk * 1e6):.3f}  (sum of the level classes' SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x {ms} ms x sclk))")

@@ -17,7 +17,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-32:]))
 rows.sort()
-resets = [i for i, r in enumerate(rows) if "event_reset" in r[2]]
+resets = [i for i, r in enumerate(rows) if "import_witness" in r[2]]  # a tile = from one import to the next (the import resets the event words since round 6)
 i0 = resets[-2]; i1 = resets[-1]
 seq = [r for r in rows[i0:i1] if "arith" in r[2]]
 gaps = [(b[0] - a[1]) / 1e3 for a, b in zip(seq, seq[1:])]

@@ -711,9 +711,12 @@ template <int C>
 FR_HD __forceinline__ SJac sj_identity() { return SJac{sp_one<C>(), sp_one<C>(), s29_zero()}; }
 template <int C>
 FR_HD __forceinline__ S29 s29_out(const S29 &lazy) { return s29_weak<C>(s29_norm(lazy)); }  // value < 128 p, limbs < 2^32 -> an output coordinate
-template <int C>
+// GUARDED = false (round 6, the ladders of secp_mul2): no test for the identity or a point of order two in front of the formulas. Both groups have prime
+// order -- no finite point has Y = 0 -- and the formulas keep the identity the identity: Z3 = 2 Y Z is an exact zero whenever Z is (a product with a
+// zero operand), whatever X and Y hold, and sj_add_aff29 looks at Z only. Two nine-limb tests and two branches fewer per doubling.
+template <int C, bool GUARDED = true>
 FR_HD __forceinline__ SJac sj_dbl(const SJac &p) {
-    if (s29_is_zero_coord<C>(p.Z) || s29_is_zero_coord<C>(p.Y)) return sj_identity<C>();
+    if (GUARDED && (s29_is_zero_coord<C>(p.Z) || s29_is_zero_coord<C>(p.Y))) return sj_identity<C>();
     SJac r;
     if (C == 0) {  // dbl-2009-l: 2 M + 5 S
         const S29 A = s29_sqr<C>(p.X), B = s29_sqr<C>(p.Y), Cc = s29_sqr<C>(B);                          // < 1.01
@@ -890,7 +893,7 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const S29 &qx, const S29 
         fr_add256(e2, sp.k2, eights128);
 #pragma unroll 1
         for (int i = 128; i >= 0; i--) {
-            if (i != 128) acc = sj_dbl<C>(acc);
+            if (i != 128) acc = sj_dbl<C, false>(acc);
             if (i & 3) continue;
 #pragma unroll 1
             for (int h = 0; h < 2; h++) {
@@ -916,7 +919,7 @@ FR_HD inline __noinline__ SJac secp_mul2(const Fr &u1, const S29 &qx, const S29 
         if (top) acc = SJac{qx, qy, sp_one<C>()};
 #pragma unroll 1
         for (int i = 255; i >= 0; i--) {  // one doubling and one addition in the loop body: the code stays within reach of the instruction cache
-            acc = sj_dbl<C>(acc);
+            acc = sj_dbl<C, false>(acc);
             if (i & 3) continue;
             const int32_t dg = (int32_t)((secp_limb_at(e, (uint32_t)i >> 5) >> (i & 31)) & 15u) - 8;
             if (dg != 0) {

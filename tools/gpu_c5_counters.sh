@@ -18,9 +18,7 @@ for set in "SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $set | tr ' ' '_')
   ACVM_TUNING="$TUNE" rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/$name" -o pmc -- python $ROOT/tools/t_config5.py $G $TILE $NT 2 $MODE > "$OUT/$name.log" 2>&1
 done
-( for i in $(seq 1 40); do rocm-smi --showclocks 2>/dev/null | grep -o "sclk clock level: [0-9]*: ([0-9]*Mhz)" | head -1; sleep 0.05; done > "$OUT/sclk.txt" ) &
 python $ROOT/tools/t_config5.py $G $TILE 6 0 $MODE > "$OUT/run_plain.json" 2>/dev/null
-wait
 find "$OUT" -name '*.db' -delete; find "$OUT" -name '*kernel_trace.csv' -size +30M -delete
 python - "$OUT" $NT $TILE > "$OUT/summary.txt" <<'PY'
 import csv, glob, sys, os, re, json
@@ -36,11 +34,10 @@ tot = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: default
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         c = cls_of(r["Kernel_Name"]); tot[c][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[c][r["Counter_Name"]] += 1
-sclk = [int(x) for x in re.findall(r"\((\d+)Mhz\)", open(os.path.join(out, "sclk.txt")).read())]
-sclk_med = sorted(sclk)[len(sclk) // 2] if sclk else None
+# (the shader clock under this load is sampled by bench.py's config-5 leg, 2.1-2.2 GHz on the boxes of this pool: the fraction is printed for a range)
 run = json.loads(open(os.path.join(out, "run_plain.json")).read().strip().splitlines()[-1])
 ms = sorted(t["solve_device_ms"] for t in run["tiles"][1:])[len(run["tiles"][1:]) // 2]
-print(f"# config-5 tile of {tile} instances: per kernel class and tile (sums over {nt} tiles / {nt}); solve_device_ms (median of 5 unprofiled tiles) = {ms}; sclk under load (median of {len(sclk)} samples) = {sclk_med} MHz")
+print(f"# config-5 tile of {tile} instances: per kernel class and tile (sums over {nt} tiles / {nt}); solve_device_ms (median of 5 unprofiled tiles) = {ms}")
 print(f"{'class':26s} {'launches':>9s} {'VALU wave-insts':>16s} {'waves':>12s} {'VALU/wave':>10s} {'read GB':>9s} {'write GB':>9s}")
 total_valu = 0
 for c in sorted(tot, key=lambda c: -tot[c].get("SQ_INSTS_VALU", 0)):
@@ -48,8 +45,8 @@ for c in sorted(tot, key=lambda c: -tot[c].get("SQ_INSTS_VALU", 0)):
     rd = tot[c].get("FETCH_SIZE", 0) / nt * 1024 * 2 / 1e9; wr = tot[c].get("WRITE_SIZE", 0) / nt * 1024 / 1e9
     if c not in ("exact", "other", "tables (once per process)", "import"): total_valu += v
     print(f"{c:26s} {cnt[c].get('SQ_INSTS_VALU', 0) / nt:9.0f} {v:16.0f} {w:12.0f} {v / w if w else 0:10.0f} {rd:9.2f} {wr:9.2f}")
-if sclk_med:
-    for clk in (sclk_med, 2400):
+if True:
+    for clk in (1900, 2160, 2400):
         print(f"tile-wide VALU issue fraction at {clk} MHz: {total_valu * 4 / (1024 * ms / 1e3 * clk * 1e6):.3f}  (sum of the level classes' SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x {ms} ms x sclk))")
 PY
 cat "$OUT/summary.txt"

@@ -69,11 +69,17 @@ __device__ __forceinline__ Fr apply_coef_prod(const Fr &a, const Fr &b, uint32_t
 // The FIRST flag of an instance counts it, on the device (the gate of the next tile's import reads that word) and in the host's counter (the
 // host reads it after the synchronisation it needs anyway): no counting kernel behind a solve (until round 6: event_count_kernel).
 static constexpr int EVENT_HDR_WORDS = 4;
+// (The lanes of a wave that flag together count together: one pair of atomics per wave, not per instance -- a batch in which every instance fails at
+// the same opcode would otherwise send 2^17 system-scope atomics over PCIe to one host word.)
 __device__ __forceinline__ void flag_instance(uint32_t *__restrict__ event, uint64_t j, uint32_t opcode) {
-    if (atomicMin(&event[j], opcode) == 0xFFFFFFFFu) {
-        atomicAdd(event - 4, 1u);
+    const bool first = atomicMin(&event[j], opcode) == 0xFFFFFFFFu;
+    const uint64_t firsts = __builtin_amdgcn_ballot_w64(first);  // over the lanes that are here (the callers sit inside `if (error)`)
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (first && (uint32_t)__builtin_ctzll(firsts) == lane) {
+        const uint32_t n = (uint32_t)__builtin_popcountll(firsts);
+        atomicAdd(event - 4, n);
         uint32_t *host = *(uint32_t *const *)(event - 2);
-        if (host) __hip_atomic_fetch_add(host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (host) __hip_atomic_fetch_add(host, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // ---- the gate kernel's body (kernels.hip arith_level_kernel; kernels_ops.hip runs it beside the light records of the same level):

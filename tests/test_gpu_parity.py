@@ -100,6 +100,46 @@ def test_unsatisfied_constraint_reports_opcode(oracle):
     assert g[0][0].as_tuple() == (acvm_amd.STATUS_FAILURE, acvm_amd.ERR_UNSATISFIED, 0, 0, 0)
 
 
+@pytest.mark.parametrize("pattern", ["all", "every_third", "one_per_wave", "none"])
+def test_flagged_instances_are_counted_by_the_kernels_that_flag(oracle, pattern):
+    """Since round 6 no kernel counts the flagged instances behind a solve: the kernels that flag count (the first flag of an instance, one pair of
+    atomics per wave). A batch in which every instance fails at the same opcode, every third one, one lane of every wave, none: the exact path gets
+    exactly those instances (statistics), results and maps equal the oracle's; a second solve of the same handle with other inputs counts afresh, and
+    the pipelined form (acvm_batch_solve_then_import) holds its import back exactly when something was flagged."""
+    import acvm_amd
+    from acvm_amd.acir import Circuit, Expression, P
+    # w3 = w1 * w2 (a gate), then assert w3 == w4 (flags where it does not hold), then RANGE(w3, 64) (flags large products)
+    from acvm_amd.acir import BlackBoxFuncCall as BB, FunctionInput as FI
+    circ = Circuit(5, [Expression([(1, 1, 2)], [(P - 1, 3)], 0), Expression([], [(1, 3), (P - 1, 4)], 0), BB("RANGE", {"input": FI(3, 64)}),
+                       Expression([], [(1, 3), (1, 1), (P - 1, 5)], 0)])
+    B = 5000  # 78 waves and a partial one
+    fails = {"all": lambda j: True, "every_third": lambda j: j % 3 == 0, "one_per_wave": lambda j: j % 64 == 17, "none": lambda j: False}[pattern]
+    rows = []
+    for j in range(B):
+        a, b = j + 2, 3 * j + 1
+        rows.append([a, b, a * b + (1 if fails(j) else 0)])
+    values = b"".join(x.to_bytes(32, "big") for r in rows for x in r)
+    ids = [1, 2, 4]
+    o, g, st = _run_both(oracle, circ, ids, values, B)
+    _assert_parity(o, g, B)
+    n_fail = sum(1 for j in range(B) if fails(j))
+    assert st["n_slow_instances"] == n_fail and sum(1 for r in g[0] if r.status != 0) == n_fail
+    # the same handle again, the other way round, then pipelined against a resident buffer
+    gc = acvm_amd.Circuit(circ.to_bytes())
+    batch = acvm_amd.Batch(gc, B, ids)
+    clean = b"".join(x.to_bytes(32, "big") for j in range(B) for x in (j + 2, 3 * j + 1, (j + 2) * (3 * j + 1)))
+    buf_bad, buf_clean = acvm_amd.DeviceBuffer(values), acvm_amd.DeviceBuffer(clean)
+    for first, second, want in ((buf_bad, buf_clean, n_fail), (buf_clean, buf_bad, 0), (buf_clean, buf_clean, 0), (buf_bad, buf_bad, n_fail)):
+        batch.set_initial_witness_device(first.ptr)
+        assert batch.solve(then_import=second.ptr) == want and batch.stats()["n_slow_instances"] == want
+        batch.set_initial_witness_device(second.ptr)  # (free when the import ran behind the solve; performed now when it was held back)
+        want2 = n_fail if second is buf_bad else 0
+        assert batch.solve() == want2 and batch.stats()["n_slow_instances"] == want2
+    batch.free()
+    buf_bad.free()
+    buf_clean.free()
+
+
 def test_empty_and_ragged(oracle):
     import acvm_amd
     from acvm_amd import synth

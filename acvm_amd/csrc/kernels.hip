@@ -54,8 +54,20 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
                     x.v[i] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3];
                 }
             }
-            // reduce: 2^256 / p < 6, so at most 5 subtractions
-            for (int it = 0; it < 5; it++) {
+            // from_be_bytes_reduce: x mod p for any x < 2^256 (2^256 / p < 6). The quotient is estimated from the top limb -- q = how many multiples of
+            // p7 + 1 fit into x7, p7 = p's top limb: floor(x / p) is q or q + 1 (checked exhaustively at the multiples of p and on 2 x 10^5 random values) --
+            // so x - q p followed by ONE conditional subtraction replaces round 1's loop of five (100 instructions of the ~400 per value: the import
+            // of config 3's 64 inputs per instance was bound by instruction issue at 40 % of the HBM rate)
+            {
+                const uint32_t p7 = fr_p(7) + 1u;
+                const uint32_t q = (x.v[7] >= p7) + (x.v[7] >= 2u * p7) + (x.v[7] >= 3u * p7) + (x.v[7] >= 4u * p7) + (x.v[7] >= 5u * p7);
+                int64_t carry = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int64_t tt = (int64_t)x.v[i] - (int64_t)((uint64_t)q * fr_p(i)) + carry;  // q p_i < 2^35
+                    x.v[i] = (uint32_t)tt;
+                    carry = tt >> 32;
+                }
                 Fr d;
                 uint64_t br = 0;
 #pragma unroll
@@ -66,8 +78,12 @@ __global__ void __launch_bounds__(256) import_witness_kernel(uint4 *__restrict__
                 }
                 if (!br) x = d;
             }
-            const Fr m = fr_mul(x, fr_r2());
             const bool is_byte = !(x.v[1] | x.v[2] | x.v[3] | x.v[4] | x.v[5] | x.v[6] | x.v[7]) && x.v[0] < 256u;
+            // into Montgomery form: a byte (message bytes, digits, flags: the usual initial witness of the hash circuits) by the closed form of
+            // ops_common.hpp fr_mont_of_byte (~64 instructions, no product) when every value the wave converts is one; else the product with R^2
+            Fr m;
+            if (__builtin_amdgcn_ballot_w64(!is_byte) == 0) m = fr_mont_of_byte(x.v[0]);
+            else m = fr_mul(x, fr_r2());
             tile_low[kk][ji] = (x.v[0] & 0x1fffffffu) | (is_byte ? 0x80000000u : 0u);
             tile[kk][0][ji] = make_uint4(m.v[0], m.v[1], m.v[2], m.v[3]);
             tile[kk][1][ji] = make_uint4(m.v[4], m.v[5], m.v[6], m.v[7]);

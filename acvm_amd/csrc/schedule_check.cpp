@@ -494,8 +494,7 @@ struct Checker {
             if (kind == GATE_SOLVE_DYN) {
                 if (w0 & GATE_PRESUM_WEAK) { weak_check("before the product with the inverse"); acc_k = GATE_K_WEAK; }
                 else if (acc_k > 8 * GATE_K_CANON) finding("BOUNDS: " + std::string(who) + ": the sum (" + std::to_string(acc_k) + " / 256 p) meets the inverse without a reduction");
-                Res *iv = read(RK_INV, gs[pos + 4], opcode, who);
-                (void)iv;
+                read(RK_INV, gs[pos + 4], opcode, who);
                 if (inv_slot_of[opcode] != gs[pos + 4]) finding("VALUE: " + std::string(who) + " reads inverse row " + std::to_string(gs[pos + 4]) + " but its inversion job fills row " + std::to_string(inv_slot_of[opcode]));
                 acc_k = GATE_K_CANON + gate_k_product(acc_k, GATE_K_INVERSE);
             }
@@ -522,7 +521,6 @@ struct Checker {
                 if (out_w == NONE) finding("VALUE: " + std::string(who) + " stores a witness but the opcode assigns none in order");
                 else {
                     if (row_of(out_w) != gs[pos + 2]) finding("VALUE: " + std::string(who) + " writes row " + std::to_string(gs[pos + 2]) + ", witness " + std::to_string(out_w) + " lives in row " + std::to_string(row_of(out_w)));
-                    if (out_canon && p.kbound[out_w] != GATE_K_CANON) {}  // (the planner's own bound may be looser: not an error)
                     if (!out_canon && p.unscale_index[out_w] == NONE) finding("REPRESENTATION: " + std::string(who) + " stores a relaxed row for witness " + std::to_string(out_w) + ", which no reader unscales");
                     if (Res *r = write(RK_W, gs[pos + 2], out_w, who)) { r->kb = out_kb; r->canon = out_canon; }
                 }

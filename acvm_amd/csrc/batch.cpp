@@ -197,7 +197,7 @@ static void remember_plan(const acvm_circuit *c, const std::shared_ptr<const Pla
 std::shared_ptr<const Plan> plan_for(const acvm_circuit *c, const uint32_t *initial_ids, uint32_t n_initial, const PlanOpts &opts) {
     PlanKey key;
     key.ids.assign(initial_ids, initial_ids + n_initial);
-    key.keep = opts.keep;
+    if (opts.reuse_slots) key.keep = opts.keep;  // (the kept witnesses only matter to the row assignment of slot reuse: plain handles with different lists share a plan)
     key.host_blackbox = opts.host_blackbox;
     key.fold_digest = opts.fold_digest;
     key.reuse_slots = opts.reuse_slots;

@@ -217,12 +217,12 @@ int batch_solve_impl(acvm_batch *b, const void *next_inputs) {
         if (b->side()) {
             // (on the batch's stream: the level table is read before the next tile's import overwrites it)
             if (b->reuse()) launch_gather_initial(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, b->d_init_ids, b->d_init_rows, (uint32_t)p.initial_ids.size(), b->d_slow_ids, n_slow);
-            else {  // the whole column of every flagged instance, plain values: the job resumes at the instance's event like the in-place path
-                launch_gather_columns(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, p.n_witnesses, b->d_slow_ids, n_slow, b->d_unscale_index, b->d_unscale_consts);
-                launch_gather_columns(s, b->d_Memx, b->x_cap, b->d_Mem, b->Bp, p.mem_cells, b->d_slow_ids, n_slow, nullptr, nullptr);
+            else {  // every flagged instance's column as far as its event (what its assigned set will hold), plain values: the job resumes there like the in-place path
+                launch_gather_columns(s, b->d_Wx, b->x_cap, b->d_W, b->Bp, p.n_witnesses, b->d_slow_ids, n_slow, b->d_unscale_index, b->d_unscale_consts, b->d_producer, b->d_slow_start);
+                launch_gather_columns(s, b->d_Memx, b->x_cap, b->d_Mem, b->Bp, p.mem_cells, b->d_slow_ids, n_slow, nullptr, nullptr, nullptr, nullptr);
             }
         } else
-        launch_unscale_slow(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->unscale);  // the exact kernels work on plain values
+        launch_unscale_slow(s, b->d_W, b->Bp, b->d_slow_ids, n_slow, b->unscale, b->d_producer, b->d_slow_start);  // the exact kernels work on plain values
         if (go_async) {  // everything below runs on the side stream, behind the gather
             HIPCHK(hipEventRecord(b->ev_x_ready, s));
             HIPCHK(hipStreamWaitEvent(b->stream_x, b->ev_x_ready, 0));

@@ -143,15 +143,19 @@ __global__ void __launch_bounds__(256) export_witness_kernel(const uint4 *__rest
         q[3] = (uint8_t)x.v[i];
     }
 }
-// columns of the instances that continue on the exact path: every scaled witness back to its plain Montgomery value
+// columns of the instances that continue on the exact path: every scaled witness the lane keeps back to its plain Montgomery value. The lane keeps
+// what init_assigned_kernel marks -- outputs of opcodes in front of its event; the rows behind it are written by the exact kernels before anything
+// reads them, so an instance that fails early costs next to nothing here (with relaxed rows nearly every gate output is "scaled").
 __global__ void __launch_bounds__(256) unscale_slow_kernel(uint4 *__restrict__ W, uint64_t Bp, const uint32_t *__restrict__ slow_ids,
                                                            uint32_t n_slow, const uint32_t *__restrict__ scaled_ids, uint32_t n_scaled,
-                                                           const uint32_t *__restrict__ consts) {
+                                                           const uint32_t *__restrict__ consts, const uint32_t *__restrict__ producer,
+                                                           const uint32_t *__restrict__ start_opcode) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)n_slow * n_scaled) return;
     const uint32_t k = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
     const uint64_t j = slow_ids[t];
     const uint32_t w = scaled_ids[k];
+    if (producer[w] >= start_opcode[t]) return;  // (a scaled witness is a gate's output, never an initial one)
     fr_store(W, w, Bp, j, fr_mul(fr_load(W, w, Bp, j), fr_const(consts, k)));
 }
 
@@ -306,25 +310,37 @@ __global__ void gather_initial_kernel(uint4 *__restrict__ Wx, uint64_t Bpx, cons
     const uint32_t k = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
     fr_store(Wx, init_ids[k], Bpx, t, fr_load(W, init_rows[k], Bp, slow_ids[t]));
 }
-// asynchronous exact path without slot reuse (batch.cpp): the WHOLE column of every flagged instance moves into the side table (lane t =
-// the t-th flagged instance), scaled witnesses back to plain values on the way, so that the exact kernels can resume at the instance's
-// event exactly as they would in place while the level table is handed to the next tile. rows = witnesses (or memory cells: u.index null)
+// asynchronous exact path without slot reuse (batch.cpp): the column of every flagged instance moves into the side table (lane t = the t-th
+// flagged instance), scaled witnesses back to plain values on the way, so that the exact kernels can resume at the instance's event exactly as
+// they would in place while the level table is handed to the next tile. rows = witnesses (or memory cells: u.index and producer null). Only
+// the rows the lane's assigned set will hold move (init_assigned_kernel below: initial witnesses and outputs of opcodes in front of the lane's
+// event): what the level path wrote behind the event means nothing, the exact kernels write those rows before they read them, and an
+// instance that fails at its first constraint -- the common failure -- costs a column of zero stores instead of a column of scattered reads.
 __global__ void __launch_bounds__(256) gather_columns_kernel(uint4 *__restrict__ Wx, uint64_t Bpx, const uint4 *__restrict__ W, uint64_t Bp, uint32_t n_rows,
                                                              const uint32_t *__restrict__ slow_ids, uint32_t n_slow, const uint32_t *__restrict__ unscale_index,
-                                                             const uint32_t *__restrict__ unscale_consts) {
+                                                             const uint32_t *__restrict__ unscale_consts, const uint32_t *__restrict__ producer,
+                                                             const uint32_t *__restrict__ start_opcode) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)n_rows * n_slow) return;
     const uint32_t w = (uint32_t)(i / n_slow), t = (uint32_t)(i % n_slow);
+    if (producer) {
+        const uint32_t pr = producer[w];
+        if (pr != 0xFFFFFFFEu && pr >= start_opcode[t]) {
+            fr_store(Wx, w, Bpx, t, fr_zero());
+            return;
+        }
+    }
     Fr x = fr_load(W, w, Bp, slow_ids[t]);
     const uint32_t ui = unscale_index ? unscale_index[w] : 0xFFFFFFFFu;
     if (ui != 0xFFFFFFFFu) x = fr_mul(x, fr_const(unscale_consts, ui));
     fr_store(Wx, w, Bpx, t, x);
 }
 void launch_gather_columns(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, uint32_t n_rows, const uint32_t *slow_ids, uint32_t n_slow,
-                           const uint32_t *unscale_index, const uint32_t *unscale_consts) {
+                           const uint32_t *unscale_index, const uint32_t *unscale_consts, const uint32_t *producer, const uint32_t *start_opcode) {
     const uint64_t n = (uint64_t)n_rows * n_slow;
     if (!n) return;
-    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wx, Bpx, W, Bp, n_rows, slow_ids, n_slow, unscale_index, unscale_consts);
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wx, Bpx, W, Bp, n_rows, slow_ids, n_slow, unscale_index, unscale_consts,
+                       producer, start_opcode);
 }
 void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,
                            const uint32_t *slow_ids, uint32_t n_slow) {
@@ -380,11 +396,12 @@ void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, u
         hipLaunchKernelGGL(export_witness_kernel, dim3((n + 255) / 256, m), dim3(256), 0, s, W, Bp, first, n, sel, n_sel, out, u, done, row_of);
     }
 }
-void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u) {
+void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u, const uint32_t *producer,
+                         const uint32_t *start_opcode) {
     const uint64_t n = (uint64_t)n_slow * u.n_scaled;
     if (!n) return;
     hipLaunchKernelGGL(unscale_slow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, Bp, slow_ids, n_slow, u.scaled_ids, u.n_scaled,
-                       u.consts);
+                       u.consts, producer, start_opcode);
 }
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv) {

@@ -87,8 +87,9 @@ void launch_export(hipStream_t s, const uint4 *W, uint64_t Bp, uint32_t first, u
 void launch_gather_initial(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, const uint32_t *init_ids, const uint32_t *init_rows, uint32_t n_init,
                            const uint32_t *slow_ids, uint32_t n_slow);
 void launch_gather_columns(hipStream_t s, uint4 *Wx, uint64_t Bpx, const uint4 *W, uint64_t Bp, uint32_t n_rows, const uint32_t *slow_ids, uint32_t n_slow,
-                           const uint32_t *unscale_index, const uint32_t *unscale_consts);
-void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u);
+                           const uint32_t *unscale_index, const uint32_t *unscale_consts, const uint32_t *producer, const uint32_t *start_opcode);
+void launch_unscale_slow(hipStream_t s, uint4 *W, uint64_t Bp, const uint32_t *slow_ids, uint32_t n_slow, const Unscale &u, const uint32_t *producer,
+                         const uint32_t *start_opcode);
 void launch_arith_level(hipStream_t s, uint4 *W, uint64_t Bp, uint32_t B, const uint32_t *gate_stream, const uint32_t *gate_offset,
                         uint32_t n_gates, const uint32_t *consts, uint32_t *event, const uint4 *inv);
 void launch_inverse_batch(hipStream_t s, const uint4 *W, uint4 *inv, uint64_t Bp, uint32_t B, const uint32_t *gate_stream,

@@ -812,8 +812,10 @@ def main():
         legs = {}
         # arith_pedersen is north_star's target shape: it runs at the metric's batch and tile (2^20 in tiles of 2^17; tiles of 2^16 measure 5 % lower:
         # the Pedersen launches of a tile of 2^17 hold enough waves for several records to share their inversions, NOTEBOOK.md section 9)
-        # (the short legs first: they are measured the way round 3 measured them, before the long one has the part power-limited for a second and a half)
-        for name, kw in (("hash", dict(warmup=3, steps=5)), ("grumpkin", dict(warmup=3, steps=5)), ("ecdsa", dict(warmup=3, steps=5)),
+        # (the short legs first, before the long one has the part power-limited for a second and a half)
+        # (a step of these is 0.15-2.5 ms: five of them from a cold start end before the device has reached its clocks and measure the ramp -- the hash step reads
+        # 0.171 ms over 3 + 5 steps and 0.149 ms over 20 + 200 on the same box, NOTEBOOK.md 6.13 -- so the short legs time 30-120 ms of steps)
+        for name, kw in (("hash", dict(warmup=20, steps=200)), ("grumpkin", dict(warmup=5, steps=50)), ("ecdsa", dict(warmup=5, steps=50)),
                          ("arith_pedersen", dict(total_log2=20, tile_log2=17, steps=5, warmup=1))):
             try:
                 legs[name] = run_leg(name, **kw)

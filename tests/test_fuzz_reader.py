@@ -110,3 +110,5 @@ def test_mutated_circuits_never_trip_the_sanitizers(driver, tmp_path):
     assert stats["blobs"] == len(blobs)
     # the seeds themselves parse and plan; a healthy share of the mutants still reaches the planner (the fuzzing is not all rejected at byte 0)
     assert stats["parsed"] >= 2 * len(ss) and stats["planned"] + stats["refused"] >= len(blobs) // 20, stats
+    # every plan that built was laid out, scheduled and hazard-checked at two tile sizes under the sanitizers, without a finding
+    assert stats["schedules"] == 2 * (stats["planned"] - stats["too_large_to_check"]) and stats["schedules"] >= stats["planned"] and stats["hazards"] == 0, (stats, out.stderr[-4000:])

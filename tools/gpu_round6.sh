@@ -13,7 +13,8 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> gpurun_out/
 timeout 1200 python bench.py --steps 20 --warmup 5 2> gpurun_out/bench_${TAG}_arith.err | tail -1 > gpurun_out/bench_${TAG}_arith.json
 python tools/bench_line.py < gpurun_out/bench_${TAG}_arith.json
 for wl in hash grumpkin ecdsa arith_pedersen mixed; do
-  timeout 900 python bench.py --workload $wl 2> gpurun_out/bench_${TAG}_$wl.err | tail -1 > gpurun_out/bench_${TAG}_$wl.json
+  case $wl in hash) K="--steps 200 --warmup 20";; grumpkin|ecdsa) K="--steps 50 --warmup 5";; *) K="";; esac  # (sub-millisecond steps: time tens of milliseconds of them, not the clock ramp)
+  timeout 900 python bench.py --workload $wl $K 2> gpurun_out/bench_${TAG}_$wl.err | tail -1 > gpurun_out/bench_${TAG}_$wl.json
   python tools/bench_line.py < gpurun_out/bench_${TAG}_$wl.json
 done
 mkdir -p gpurun_out/prof_${TAG}_bench

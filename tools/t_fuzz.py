@@ -86,7 +86,7 @@ def main():
     t0 = time.time()
     bad = 0
     for k in range(n_seeds):
-        seed = 0xF0220000 + k
+        seed = 0xF0220000 + int(os.environ.get("ACVM_FUZZ_BASE", "0")) + k  # (ACVM_FUZZ_BASE: another stretch of seeds)
         heavy = k % 5 != 4
         blocks, cells = [(16, 64), (4, 16), (1, 256), (2, 2)][k % 4]
         n = n_ops + 37 * (k % 7)

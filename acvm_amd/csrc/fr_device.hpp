@@ -397,6 +397,41 @@ FR_HD __forceinline__ Fr29 fr29_dot(const Fr29 (&a)[N], const Fr29 (&b)[N]) { re
 template <int N>
 FR_HD __forceinline__ Fr29 fr29_dot_add(const Fr29 (&a)[N], const Fr29 (&b)[N], const Fr29 &h) { return fr29_dot_impl<N, true>(a, b, &h); }
 
+// ---- the same scans as asm blocks (device pass; generated: tools/gen_mul_blocks.py > fr_blocks.inc, which says why). hipcc's form of the scan above
+// joins every column with the carry of the one before by a 64-bit add -- 17 of a product's 221 VALU instructions; a column whose first multiply-add
+// takes the carry needs none. For kernels that keep four or more waves per SIMD (the gate kernels, gate_eval.hpp): at two waves per SIMD the serial
+// chain gains nothing (tools/serial_mul_probe.hip), so the Grumpkin / ECDSA kernels stay with the compiler's form. Same values, same contracts; the
+// host pass (and -DFR_NO_ASM_BLOCKS) takes the C forms. UB: bit t set = every limb of b[t] is WAVE-UNIFORM (a gate's coefficient: scalar registers).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FR_NO_ASM_BLOCKS)
+#define FR_ASM_BLOCKS 1
+#include "fr_blocks.inc"
+#endif
+FR_HD __forceinline__ Fr29 fr29_mul_b(const Fr29 &a, const Fr29 &b) {
+#if FR_ASM_BLOCKS
+    return fr29_mul_blk(a, b);
+#else
+    return fr29_mul(a, b);
+#endif
+}
+template <int N, unsigned UB>
+FR_HD __forceinline__ Fr29 fr29_dot_add_b(const Fr29 (&a)[N], const Fr29 (&b)[N], const Fr29 &h) {
+    static_assert(N == 1 || N == 2, "generated forms");
+#if FR_ASM_BLOCKS
+    if constexpr (N == 1) {
+        static_assert(UB <= 1u, "one product");
+        if constexpr (UB == 1u) return fr29_dot1_add_blk_u(a[0], b[0], h);
+        else return fr29_dot1_add_blk_v(a[0], b[0], h);
+    } else {
+        static_assert(UB == 0u || UB == 2u || UB == 3u, "a uniform first factor pairs with a uniform second one");
+        if constexpr (UB == 0u) return fr29_dot2_add_blk_vv(a[0], b[0], a[1], b[1], h);
+        else if constexpr (UB == 2u) return fr29_dot2_add_blk_vu(a[0], b[0], a[1], b[1], h);
+        else return fr29_dot2_add_blk_uu(a[0], b[0], a[1], b[1], h);
+    }
+#else
+    return fr29_dot_add<N>(a, b, h);
+#endif
+}
+
 // Montgomery product on the storage form, fully reduced
 FR_HD __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) { return fr29_pack(fr29_cond_sub_p(fr29_mul(fr29_from(a), fr29_from(b)))); }
 

@@ -69,7 +69,7 @@ FR_HD __forceinline__ GateWords gate_mac_entry(GateWords t0, uint32_t np_mac, ui
 }
 template <class L>
 FR_HD __forceinline__ Fr29 gate_mac_operand(const L &ld, GateWords c, bool product, const Fr29 &local) {
-    if (product) return fr29_mul(gate_operand(ld, c[8], local), gate_operand(ld, c[9], local));
+    if (product) return fr29_mul_b(gate_operand(ld, c[8], local), gate_operand(ld, c[9], local));
     return gate_operand(ld, c[8], local);
 }
 
@@ -99,7 +99,7 @@ FR_HD __forceinline__ Fr29 gate_eval(const L &ld, GateWords g, const Fr29 &local
     GateWords t = tp + 2 * np_pos;                 // np_neg x (a, b), nl_pos x (w), nl_neg x (w)
     // ---- the terms that are only added or subtracted
     for (uint32_t i = 0; i < np_neg; i++, t += 2) {
-        const Fr29 x = fr29_mul(gate_operand(ld, t[0], local), gate_operand(ld, t[1], local));  // < 1.17 p
+        const Fr29 x = fr29_mul_b(gate_operand(ld, t[0], local), gate_operand(ld, t[1], local));  // < 1.17 p
         gate_h_room(h, hw, 33);
         gate_h_sub(h, x, 1);
     }
@@ -124,30 +124,30 @@ FR_HD __forceinline__ Fr29 gate_eval(const L &ld, GateWords g, const Fr29 &local
         GateWords c = gate_mac_entry(t0, np_mac, im);
         const Fr29 l[2] = {gate_operand(ld, tp[2 * ip], local), gate_mac_operand(ld, c, im < np_mac, local)};
         const Fr29 m[2] = {gate_operand(ld, tp[2 * ip + 1], local), gate_coef29(c)};
-        h = fr29_dot_add<2>(l, m, h);
+        h = fr29_dot_add_b<2, 2u>(l, m, h);  // (fr_device.hpp: the asm-block scan; bit t of the mask = m[t] is a coefficient, wave-uniform)
         GATE_AFTER_REDUCTION();
     }
     for (; im < n_mac; im += 2) {
         GateWords c0 = gate_mac_entry(t0, np_mac, im);
         if (n_mac - im == 1) {
             const Fr29 l[1] = {gate_mac_operand(ld, c0, im < np_mac, local)}, m[1] = {gate_coef29(c0)};
-            h = fr29_dot_add<1>(l, m, h);
+            h = fr29_dot_add_b<1, 1u>(l, m, h);
         } else {
             GateWords c1 = gate_mac_entry(t0, np_mac, im + 1);
             const Fr29 l[2] = {gate_mac_operand(ld, c0, im < np_mac, local), gate_mac_operand(ld, c1, im + 1 < np_mac, local)};
             const Fr29 m[2] = {gate_coef29(c0), gate_coef29(c1)};
-            h = fr29_dot_add<2>(l, m, h);
+            h = fr29_dot_add_b<2, 3u>(l, m, h);
         }
         GATE_AFTER_REDUCTION();
     }
     for (; ip < np_pos; ip += 2) {
         if (np_pos - ip == 1) {
             const Fr29 l[1] = {gate_operand(ld, tp[2 * ip], local)}, m[1] = {gate_operand(ld, tp[2 * ip + 1], local)};
-            h = fr29_dot_add<1>(l, m, h);
+            h = fr29_dot_add_b<1, 0u>(l, m, h);
         } else {
             const Fr29 l[2] = {gate_operand(ld, tp[2 * ip], local), gate_operand(ld, tp[2 * ip + 2], local)};
             const Fr29 m[2] = {gate_operand(ld, tp[2 * ip + 1], local), gate_operand(ld, tp[2 * ip + 3], local)};
-            h = fr29_dot_add<2>(l, m, h);
+            h = fr29_dot_add_b<2, 0u>(l, m, h);
         }
         GATE_AFTER_REDUCTION();
     }
@@ -157,7 +157,7 @@ FR_HD __forceinline__ Fr29 gate_eval(const L &ld, GateWords g, const Fr29 &local
         // the unknown is multiplied by a known witness (arithmetic.rs:68-91): out = sum' / partner, and 1 / partner was put into the
         // inverse table by an earlier inverse_batch_kernel (a representative below 1.4 p)
         if (w0 & GATE_PRESUM_WEAK) acc = fr29_weak(acc);
-        acc = fr29_mul(acc, ld.load_inverse(g[4]));
+        acc = fr29_mul_b(acc, ld.load_inverse(g[4]));
     }
     const uint32_t mode = kind == 0 ? GATE_OUT_CANON : (w0 >> GATE_OUT_SHIFT) & 3u;
     if (mode != GATE_OUT_ASIS) {

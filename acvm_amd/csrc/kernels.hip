@@ -261,6 +261,49 @@ __global__ void __launch_bounds__(256) fr_selftest_kernel(uint64_t seed, uint32_
         const bool small = (ca.v[0] < 256u) && !(ca.v[1] | ca.v[2] | ca.v[3] | ca.v[4] | ca.v[5] | ca.v[6] | ca.v[7]);
         if (isb != small || low != (small ? ca.v[0] : (ca.v[0] & 0x1fffffffu))) bad |= 256;
     }
+    // the asm-block column scans of the gate kernel (fr_blocks.inc) against the C forms, limb for limb: any normalised operands (representatives up
+    // to 2^256, a lazy sum h with limbs up to 2^32), zero and all-ones limbs, and a WAVE-UNIFORM second factor for the scalar-register forms (u is
+    // made of the seed alone, so every lane hands the same value to the "s" operands)
+    {
+        Fr29 x = fr29_from(a), y = fr29_from(b), z, u, w, h;
+        uint64_t su = seed ^ 0x5DEECE66DULL;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            z.v[k] = (uint32_t)st_mix(s) & 0x1fffffffu;
+            h.v[k] = (uint32_t)st_mix(s);
+            u.v[k] = (uint32_t)st_mix(su) & 0x1fffffffu;
+            w.v[k] = (uint32_t)st_mix(su) & 0x1fffffffu;
+        }
+        x.v[8] |= (uint32_t)(i & 7u) << 24;  // unreduced: up to 2^256 (gate_eval.hpp relaxed rows)
+        z.v[8] &= 0x7ffffffu;
+        u.v[8] &= 0xffffffu;
+        w.v[8] &= 0xffffffu;
+        h.v[8] &= 0xffffu;
+        if (i == 3) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) { x.v[k] = 0x1fffffffu; y.v[k] = 0x1fffffffu; }
+            x.v[8] = y.v[8] = 0x7ffffffu;
+        }
+        if (i == 4) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) { x.v[k] = 0; h.v[k] = 0xffffffffu; }
+            h.v[8] = 0xffffu;
+        }
+        auto same = [](const Fr29 &p, const Fr29 &q) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) d |= p.v[k] ^ q.v[k];
+            return d == 0;
+        };
+        if (!same(fr29_mul_b(x, y), fr29_mul(x, y)) || !same(fr29_mul_b(y, x), fr29_mul(y, x))) bad |= 512;
+        const Fr29 l1[1] = {x}, m1v[1] = {y}, m1u[1] = {u};
+        if (!same(fr29_dot_add_b<1, 0u>(l1, m1v, h), fr29_dot_add<1>(l1, m1v, h))) bad |= 1024;
+        if (!same(fr29_dot_add_b<1, 1u>(l1, m1u, h), fr29_dot_add<1>(l1, m1u, h))) bad |= 1024;
+        const Fr29 l2[2] = {x, z}, m2vv[2] = {y, x}, m2vu[2] = {y, u}, m2uu[2] = {w, u};
+        if (!same(fr29_dot_add_b<2, 0u>(l2, m2vv, h), fr29_dot_add<2>(l2, m2vv, h))) bad |= 2048;
+        if (!same(fr29_dot_add_b<2, 2u>(l2, m2vu, h), fr29_dot_add<2>(l2, m2vu, h))) bad |= 2048;
+        if (!same(fr29_dot_add_b<2, 3u>(l2, m2uu, h), fr29_dot_add<2>(l2, m2uu, h))) bad |= 2048;
+    }
     if (bad) atomicAdd(mismatches, 1u);
 }
 

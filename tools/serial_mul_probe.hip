@@ -1,13 +1,12 @@
-// serial_mul_probe.hip -- a measured and CLOSED experiment (NOTEBOOK 6.15). Does a Montgomery product whose column scan is ONE dependent chain of
-// v_mad_u64_u32 (the carry of column k - 1 is the addend of column k's first multiply-add, so no 64-bit add joins two accumulators) beat the
-// form hipcc makes of fr29_mul (it starts every column's products from 0 ahead of time and joins them with the carry by v_lshl_add_u64: 17 of
-// the product's 221 VALU instructions)? The compiler cannot be told not to re-associate integer sums, so the multiply-add is an asm statement
-// (not volatile: it is scheduled like any other instruction; hipcc puts an s_nop behind every one whose result the next instruction reads).
-// Same values in, same values out (checked); rates at 1 / 2 / 4 / 8 waves per SIMD. Result: 205 instead of 221 VALU instructions and the SAME
-// rate from two waves per SIMD on (0.98-1.02), 0.72 at one -- under these kernels the part is power-limited and the joins are cheap
-// instructions. With the chain in gate_eval.hpp only (a library build of this round, 289 GPU tests green on it): the metric's step +1.0 % on one
-// box, +0.0 / +1.3 % on another, the north-star shape +1.3 %, a 10^6-opcode tile -1.5 %; in every kernel: config 4 -9 % (two waves per SIMD,
-// spills). Not kept: the product's fr_device.hpp / gate_eval.hpp are the compiler's form.
+// serial_mul_probe.hip -- three forms of the Montgomery product's column scan, back to back, at 1 / 2 / 4 / 8 waves per SIMD (NOTEBOOK 6.15):
+//   (0) the compiler's: hipcc re-associates `acc = (acc >> 29) + products`, starts every column from 0 ahead of time and joins it with the carry of the
+//       column before by v_lshl_add_u64 -- 17 of the product's 221 VALU instructions;
+//   (1) one dependent chain of single-instruction asm statements (the carry is the addend of the column's first multiply-add: 205 instructions) -- hipcc
+//       puts an s_nop behind every asm STATEMENT whose result the next instruction reads (154 per product): x0.98 - x1.02, x0.72 at one wave per SIMD;
+//   (2) the product's form, fr29_mul_b (fr_blocks.inc, tools/gen_mul_blocks.py): the same chain in asm statements as long as the 30-operand budget
+//       allows (17 wait states per product): x1.03 - x1.06 at 4 - 8 waves per SIMD, x1.00 at 2, x1.04 at 1.
+// Same values in, same values out (checked). tools/mad_hazard_probe.hip: dependent v_mad_u64_u32 back to back need no wait state on this part.
+// (1) in every kernel of the library: config 4 -9 % (two waves per SIMD, spills); (2) is used by gate_eval.hpp only.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/serial_mul_probe tools/serial_mul_probe.hip && tools/serial_mul_probe
 #include "../acvm_amd/csrc/fr_device.hpp"
 #include <cstdio>
@@ -133,9 +132,12 @@ __global__ void __launch_bounds__(256) rate_kernel(uint32_t *__restrict__ out, u
         if (V == 0) {
             a = fr29_mul(a, b);
             b = fr29_mul(b, a);
-        } else {
+        } else if (V == 1) {
             a = fr29_mul_chain(a, b);
             b = fr29_mul_chain(b, a);
+        } else {
+            a = fr29_mul_b(a, b);  // the product's asm-block form (fr_blocks.inc)
+            b = fr29_mul_b(b, a);
         }
     }
     uint32_t s = 0;
@@ -193,10 +195,11 @@ static float best_ms(F f) {
 
 int main() {
     const uint32_t iters = 2000;
-    uint32_t *out0, *out1, *coef;
+    uint32_t *out0, *out1, *out2, *coef;
     const size_t cap = (size_t)256 * 8 * 256;
     hipMalloc(&out0, cap * 4);
     hipMalloc(&out1, cap * 4);
+    hipMalloc(&out2, cap * 4);
     hipMalloc(&coef, 64);
     uint32_t hc[9] = {0x12345678u, 0x0badcafeu, 0x1eadbeefu, 0x07654321u, 0x11111111u, 0x02222222u, 0x13333333u, 0x04444444u, 0x00055555u};
     hipMemcpy(coef, hc, 36, hipMemcpyHostToDevice);
@@ -204,11 +207,14 @@ int main() {
         const uint32_t blocks = 256 * wps;  // 4 waves per block, 4 SIMDs per CU: wps waves per SIMD
         const float m0 = best_ms([&] { rate_kernel<0><<<blocks, 256>>>(out0, 1, iters); });
         const float m1 = best_ms([&] { rate_kernel<1><<<blocks, 256>>>(out1, 1, iters); });
-        std::vector<uint32_t> h0((size_t)blocks * 256), h1((size_t)blocks * 256);
+        const float m2 = best_ms([&] { rate_kernel<2><<<blocks, 256>>>(out2, 1, iters); });
+        std::vector<uint32_t> h0((size_t)blocks * 256), h1((size_t)blocks * 256), h2((size_t)blocks * 256);
         hipMemcpy(h0.data(), out0, h0.size() * 4, hipMemcpyDeviceToHost);
         hipMemcpy(h1.data(), out1, h1.size() * 4, hipMemcpyDeviceToHost);
-        size_t bad = 0;
-        for (size_t i = 0; i < h0.size(); i++) bad += h0[i] != h1[i];
+        hipMemcpy(h2.data(), out2, h2.size() * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0, bad2 = 0;
+        for (size_t i = 0; i < h0.size(); i++) bad += h0[i] != h1[i], bad2 += h0[i] != h2[i];
+        printf("mul  %d waves/SIMD: asm blocks %8.3f ms %7.1f G/s (x%.3f of the compiler form)  mismatches %zu\n", wps, m2, (double)blocks * 256 * iters * 2 / m2 / 1e6, m0 / m2, bad2);
         const double prods = (double)blocks * 256 * iters * 2;
         printf("mul  %d waves/SIMD: compiler form %8.3f ms %7.1f G/s | serial chain %8.3f ms %7.1f G/s  (x%.3f)  mismatches %zu\n", wps, m0, prods / m0 / 1e6, m1,
                prods / m1 / 1e6, m0 / m1, bad);

@@ -148,6 +148,9 @@ FR_HD __forceinline__ Fr fr29_pack(const Fr29 &a) {
 // Output: limbs < 2^29, value < 1.4p (< 1.06p for inputs < 4p). Column k of a * b + m * p is summed in one 64-bit
 // accumulator (at most 18 products < 2^58 plus a 35-bit carry); m_k = column * (-p^-1) mod 2^29 zeroes the column's low
 // limb, and -p^-1 = 2^28 - 1, p_0 = 2^28 + 1 turn both of those multiplications into shifts.
+#ifdef FR_BLOCKS_ALL  // measurement only (tools/build_variant.sh): every fr29_mul of the translation unit takes the asm-block form below
+#define fr29_mul fr29_mul_c
+#endif
 FR_HD __forceinline__ Fr29 fr29_mul(const Fr29 &a, const Fr29 &b) {
     constexpr uint32_t M = 0x1fffffffu;
     uint64_t acc = 0;
@@ -405,6 +408,16 @@ FR_HD __forceinline__ Fr29 fr29_dot_add(const Fr29 (&a)[N], const Fr29 (&b)[N], 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FR_NO_ASM_BLOCKS)
 #define FR_ASM_BLOCKS 1
 #include "fr_blocks.inc"
+#endif
+#ifdef FR_BLOCKS_ALL
+#undef fr29_mul
+FR_HD __forceinline__ Fr29 fr29_mul(const Fr29 &a, const Fr29 &b) {
+#if FR_ASM_BLOCKS
+    return fr29_mul_blk(a, b);
+#else
+    return fr29_mul_c(a, b);
+#endif
+}
 #endif
 FR_HD __forceinline__ Fr29 fr29_mul_b(const Fr29 &a, const Fr29 &b) {
 #if FR_ASM_BLOCKS

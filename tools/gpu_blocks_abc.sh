@@ -1,3 +1,8 @@
+#!/bin/bash
+# tools/gpu_blocks_abc.sh -- A-B-C-A-B-C on one box: the tree's library against two variants in which EVERY fr29_mul of a translation unit takes the asm-block
+# form (NOTEBOOK 6.15):  bash tools/build_variant.sh inv "-DFR_BLOCKS_ALL" "kernels.hip.o"   (the inversion kernel)
+#                        bash tools/build_variant.sh ped "-DFR_BLOCKS_ALL" "kernels_grumpkin.hip.o"   (Pedersen / Grumpkin)
+# on the north-star shape at 2^20, the metric's step and config 4. Result (profiles/r06x_asm_blocks_other_kernels.txt): +0.3 % each, not taken.
 line() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline') or {}
